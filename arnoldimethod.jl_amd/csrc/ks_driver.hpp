@@ -1,0 +1,190 @@
+// Krylov-Schur outer loop (`_partialschur`, src/run.jl:224-392) written against an abstract
+// compute backend.  The backend owns the n-sized data (V in HBM) and implements the three verbs
+// that scale with n -- expansion, reinitialise, rotation -- the host code in this file only
+// touches H ((maxdim+1) x maxdim) and Q (maxdim x maxdim).
+#pragma once
+
+#include <chrono>
+#include <cstring>
+
+#include "ks_smalldense.hpp"
+
+namespace ks {
+
+struct ExpandStats {
+  int steps = 0, reorth = 0, breakdowns = 0;
+};
+
+// What the driver needs from whoever owns V.  Column/step numbering follows the reference with
+// 0-based columns: step j (from..to as passed to iterate_arnoldi!) builds column j from column j-1.
+template <class T> struct Backend {
+  virtual ~Backend() = default;
+  virtual int64_t n_global() const = 0;
+  // iterate_arnoldi!(A, arnoldi, from:to)  src/expansion.jl:116-133; fills H[0..j, j-1] for each step.
+  virtual void iterate_arnoldi(int from, int to, const Mat<T>& H, ExpandStats& st) = 0;
+  // reinitialize!(arnoldi, j, populate!)  src/expansion.jl:12-59.  v1 == nullptr -> rand!.
+  virtual bool reinitialize(int j, const T* v1_host) = 0;
+  // V[:, c0:c0+r) <- V[:, c0:c0+c) * Q[c0:c0+c, c0:c0+r)   (src/run.jl:363-364, :382-383); Q host.
+  virtual void rotate(int c0, int c, int r, const Mat<T>& Q) = 0;
+  // V[:, dst] <- V[:, src]   (src/run.jl:365)
+  virtual void col_copy(int dst, int src) = 0;
+};
+
+struct Params {
+  int nev, which;
+  double tol;
+  int mindim, maxdim, restarts, start_from, initialize;
+};
+
+struct History {
+  int mvproducts = 0, nconverged = 0, converged = 0, nev = 0, restarts = 0, reorth = 0, breakdowns = 0;
+  double seconds_expand = 0, seconds_host = 0, seconds_rotate = 0;
+};
+
+// include_conjugate_pair, src/run.jl:510-517 (i 0-based position in ord).
+template <class T> inline int include_conjugate_pair(const cplx* lams, const int* ord, int nord, int i) {
+  if constexpr (!is_real_v<T>) return i;
+  if (i >= nord - 1) return i;
+  const cplx l1 = lams[ord[i]], l2 = lams[ord[i + 1]];
+  return (l1.imag() != 0.0 && std::conj(l1) == l2) ? i + 1 : i;
+}
+
+// Scratch reused across restarts (src/run.jl:242-252).
+template <class T> struct RestartScratch {
+  std::vector<cplx> x, lams;
+  std::vector<double> rs;
+  std::vector<int> ord, groups;
+  Reflector<T> G;
+  explicit RestartScratch(int maxdim)
+      : x(maxdim), lams(maxdim), rs(maxdim), ord(maxdim), groups(maxdim, 0), G(maxdim) {}
+};
+
+struct RestartResult {
+  int k, nlock, purge, effective_nev;
+};
+
+// One restart's host work: src/run.jl:278-360.  `active` 0-based.  H is the full (maxdim+1) x maxdim
+// array, Q is maxdim x maxdim.
+template <class T>
+inline RestartResult restart_host_step(const Mat<T>& H, const Mat<T>& Q, int maxdim, int mindim, int nev,
+                                       const Ordering& ordering, double tol, int active, RestartScratch<T>& s) {
+  // Q <- I  (:278)
+  for (int j = 0; j < maxdim; ++j)
+    for (int i = 0; i < maxdim; ++i) Q(i, j) = (i == j) ? T(1) : T(0);
+  // Schur form of the active block of H[0:maxdim, :]  (:281)
+  local_schurfact(H.top(maxdim), active, maxdim - 1, Q);
+  for (int i = 0; i < maxdim; ++i) s.ord[i] = i;                       // :284
+  copy_eigenvalues(s.lams.data(), H, 0, maxdim - 1);                   // :285
+  copy_residuals(s.rs.data(), H, Q, H(maxdim, maxdim - 1), s.x.data(), active, maxdim - 1);  // :286
+  sort_perm(s.ord.data(), maxdim, s.lams.data(), ordering);            // :289
+  double fro = 0.0;                                                    // :292 norm(H), whole array
+  for (int j = 0; j < H.n; ++j)
+    for (int i = 0; i < H.m; ++i) fro += abs2_(H(i, j));
+  fro = std::sqrt(fro);
+  auto isconverged = [&](int i) {                                      // :206-208
+    return s.rs[i] <= std::max(kEps * fro, tol * std::abs(s.lams[i]));
+  };
+  const int* ord = s.ord.data();
+  int* groups = s.groups.data();
+  const int effective_nev = include_conjugate_pair<T>(s.lams.data(), ord, maxdim, nev - 1) + 1;  // :298
+  int nlock = 0;
+  for (int i = 0; i < effective_nev; ++i) {                            // :301-308
+    if (isconverged(ord[i])) { groups[ord[i]] = 1; ++nlock; } else groups[ord[i]] = 2;
+  }
+  const int ideal_size = std::min(nlock + mindim, (mindim + maxdim) / 2);  // :316
+  int k = effective_nev;
+  int i = effective_nev;
+  while (i < maxdim) {                                                 // :320-339
+    const bool is_pair = include_conjugate_pair<T>(s.lams.data(), ord, maxdim, i) == i + 1;
+    const int num = is_pair ? 2 : 1;
+    int group;
+    if (k < ideal_size && !isconverged(ord[i])) { group = 2; k += num; } else group = 3;
+    if (is_pair) { groups[ord[i]] = group; groups[ord[i + 1]] = group; i += 2; }
+    else { groups[ord[i]] = group; i += 1; }
+  }
+  int purge = 0;                                                       // :350-353
+  while (purge < active && groups[purge] == 1) ++purge;
+  partition_schur_three_way(H, Q, groups, maxdim);                     // :355
+  restore_arnoldi(H, nlock, k - 1, Q, s.G);                            // :360
+  return RestartResult{k, nlock, purge, effective_nev};
+}
+
+inline double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// _partialschur, src/run.jl:224-392.  H: (maxdim+1) x maxdim host, Q: maxdim x maxdim host.
+// eigenvalues: out, at least maxdim entries.  `active` 0-based (= start_from - 1).
+template <class T>
+inline History partialschur_driver(Backend<T>& be, const Mat<T>& H, const Mat<T>& Q, const Params& p, int active,
+                                   cplx* eigenvalues) {
+  const int mindim = p.mindim, maxdim = p.maxdim, nev = p.nev;
+  RestartScratch<T> scratch(maxdim);
+  const Ordering ordering{p.which};
+  History hist;
+  hist.nev = nev;
+  ExpandStats st;
+
+  int k = mindim;
+  int prods = std::max(0, mindim - active);  // length(active:mindim), :264
+  double t0 = now_s();
+  be.iterate_arnoldi(active + 1, mindim, H, st);  // :267
+  hist.seconds_expand += now_s() - t0;
+
+  for (int iter = 0; iter < p.restarts; ++iter) {
+    t0 = now_s();
+    be.iterate_arnoldi(k + 1, maxdim, H, st);  // :272
+    hist.seconds_expand += now_s() - t0;
+    prods += std::max(0, maxdim - k);          // :275
+    hist.restarts++;
+
+    t0 = now_s();
+    const RestartResult r = restart_host_step(H, Q, maxdim, mindim, nev, ordering, p.tol, active, scratch);
+    hist.seconds_host += now_s() - t0;
+    k = r.k;
+
+    // :363-365  V[:, purge:k) <- V[:, purge:maxdim) Q[purge:maxdim, purge:k);  V[:, k] <- V[:, maxdim]
+    t0 = now_s();
+    be.rotate(r.purge, maxdim - r.purge, k - r.purge, Q);
+    be.col_copy(k, maxdim);
+    hist.seconds_rotate += now_s() - t0;
+
+    active = r.nlock;              // :368  (jl: active = nlock + 1)
+    if (active + 1 > nev) break;   // :370
+  }
+
+  const int nconverged = active;   // :373
+  t0 = now_s();
+  for (int j = 0; j < maxdim; ++j)
+    for (int i = 0; i < maxdim; ++i) Q(i, j) = (i == j) ? T(1) : T(0);
+  sortschur(H, Q, nconverged, ordering);                              // :379
+  hist.seconds_host += now_s() - t0;
+  t0 = now_s();
+  if (nconverged > 0) be.rotate(0, nconverged, nconverged, Q);        // :382-383
+  hist.seconds_rotate += now_s() - t0;
+  copy_eigenvalues(eigenvalues, H, 0, nconverged - 1);                // :386
+
+  hist.mvproducts = prods;
+  hist.nconverged = nconverged;
+  hist.converged = nconverged >= nev;
+  hist.reorth = st.reorth;
+  hist.breakdowns = st.breakdowns;
+  return hist;
+}
+
+// Argument checks of partialschur / partialschur!, src/run.jl:110-116, :162-174.
+// Returns 0 (ok), 1 (ArgumentError) and fills msg.
+inline int check_params(int64_t n, int ncolsV, const Params& p, std::string& msg) {
+  if (p.nev < 1) { msg = "nev cannot be less than 1"; return 1; }
+  if (!(p.nev <= p.mindim && p.mindim <= p.maxdim && (int64_t)p.maxdim <= n)) {
+    msg = "nev ≤ mindim ≤ maxdim ≤ size(A, 1) does not hold, got " + std::to_string(p.nev) + " ≤ " +
+          std::to_string(p.mindim) + " ≤ " + std::to_string(p.maxdim) + " ≤ " + std::to_string(n);
+    return 1;
+  }
+  if (!(p.maxdim < ncolsV)) { msg = "maxdim should be strictly less than size(arnoldi.V, 2)"; return 1; }
+  if (!(1 <= p.start_from && p.start_from <= p.maxdim)) { msg = "start_from should be between 1 and maxdim"; return 1; }
+  if (p.which < 0 || p.which > 4) { msg = "Unknown target"; return 1; }
+  return 0;
+}
+
+}  // namespace ks

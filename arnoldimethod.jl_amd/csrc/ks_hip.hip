@@ -1,0 +1,1412 @@
+// libkschur_hip.so -- host side of the MI355X Krylov-Schur hot path: context / operator / workspace
+// objects, the HIP backend of the driver (async expansion, in-place MFMA rotation), RCCL plumbing and
+// the extern "C" entry points declared in include/kschur.h.
+//
+// There is NO CPU fallback in this library: without a gfx950 device every compute entry point
+// returns KS_ERR_NO_DEVICE / KS_ERR_HIP.  Only the ks_host_* small-dense exports run without a GPU.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/kschur.h"
+#include "ks_driver.hpp"
+#include "ks_kernels.hpp"
+
+using ks::cplx;
+using ksd::cd;
+using ksd::DevState;
+using ksd::kBlock;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_last_error;
+
+struct KsError {
+  int code;
+  std::string msg;
+};
+
+#define KS_HIP(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e__ = (expr);                                                                      \
+    if (e__ != hipSuccess)                                                                        \
+      throw KsError{KS_ERR_HIP, std::string(#expr) + " failed: " + hipGetErrorString(e__) + " (" + \
+                                    __FILE__ + ":" + std::to_string(__LINE__) + ")"};             \
+  } while (0)
+
+#define KS_NCCL(expr)                                                                               \
+  do {                                                                                              \
+    ncclResult_t r__ = (expr);                                                                      \
+    if (r__ != ncclSuccess)                                                                         \
+      throw KsError{KS_ERR_RCCL, std::string(#expr) + " failed: " + ncclGetErrorString(r__) + " (" + \
+                                     __FILE__ + ":" + std::to_string(__LINE__) + ")"};              \
+  } while (0)
+
+#define KS_REQUIRE(cond, code, text)           \
+  do {                                         \
+    if (!(cond)) throw KsError{(code), (text)}; \
+  } while (0)
+
+template <class F> int guarded(F&& f) {
+  try {
+    f();
+    return KS_OK;
+  } catch (const KsError& e) {
+    g_last_error = e.msg;
+    return e.code;
+  } catch (const ks::QRNotConverged& e) {
+    g_last_error = e.what();
+    return KS_ERR_QR;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return KS_ERR_INTERNAL;
+  } catch (...) {
+    g_last_error = "unknown error";
+    return KS_ERR_INTERNAL;
+  }
+}
+
+template <class T> struct DevT;
+template <> struct DevT<double> { using type = double; };
+template <> struct DevT<cplx> { using type = cd; };
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+inline int env_int(const char* name, int dflt) {
+  const char* s = std::getenv(name);
+  return s ? std::atoi(s) : dflt;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct ks_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int rank = 0, nranks = 1;
+  ncclComm_t comm = nullptr;
+  int num_cu = 256;
+  int bpc = 4;  // streaming workgroups per CU (KS_BPC)
+  int nblocks() const { return num_cu * bpc; }
+  void use() const { KS_HIP(hipSetDevice(device)); }
+  // in-place sum over ranks of `count` doubles living in device memory
+  void allreduce(double* dev, int count) {
+    if (nranks > 1) KS_NCCL(ncclAllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, comm, stream));
+  }
+};
+
+static void ctx_init_device(ks_ctx* c, int device) {
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    throw KsError{KS_ERR_NO_DEVICE, "no HIP device visible: libkschur_hip has no CPU fallback"};
+  KS_REQUIRE(device >= 0 && device < ndev, KS_ERR_ARGUMENT, "device index out of range");
+  c->device = device;
+  KS_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  KS_HIP(hipGetDeviceProperties(&prop, device));
+  c->num_cu = prop.multiProcessorCount;
+  c->bpc = env_int("KS_BPC", 4);
+  KS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+}
+
+// ------------------------------------------------------------------------------------------------
+// operators
+// ------------------------------------------------------------------------------------------------
+struct ks_operator {
+  ks_ctx* ctx = nullptr;
+  int64_t n_local = 0, nnz = 0;
+  int dtype = KS_F64;
+  bool async_capable = true;  // may be enqueued ahead without host involvement
+  virtual ~ks_operator() = default;
+  // y = A x on device pointers, enqueued on ctx->stream; `st` lets the kernels of a batch skip work
+  // after a breakdown.
+  virtual void apply(const void* x, void* y, const DevState* st) = 0;
+};
+
+namespace {
+
+template <class D> struct CsrOp : ks_operator {
+  int32_t* rowptr = nullptr;
+  int32_t* colidx = nullptr;
+  D* val = nullptr;
+  int ntiles = 0;
+  // halo plan (distributed)
+  int64_t nghost = 0;
+  D* ghost = nullptr;
+  D* sendbuf = nullptr;
+  int32_t* send_idx = nullptr;
+  std::vector<int> neigh;
+  std::vector<int64_t> send_ptr, recv_ptr;
+
+  ~CsrOp() override {
+    (void)hipFree(rowptr); (void)hipFree(colidx); (void)hipFree(val);
+    (void)hipFree(ghost); (void)hipFree(sendbuf); (void)hipFree(send_idx);
+  }
+  void apply(const void* xv, void* yv, const DevState* st) override {
+    const D* x = static_cast<const D*>(xv);
+    D* y = static_cast<D*>(yv);
+    hipStream_t s = ctx->stream;
+    if (!neigh.empty()) {
+      const int64_t nsend = send_ptr.back();
+      if (nsend > 0) {
+        const int gb = (int)std::min<int64_t>((nsend + kBlock - 1) / kBlock, 4096);
+        ksd::k_gather<D><<<gb, kBlock, 0, s>>>(x, send_idx, sendbuf, nsend, st);
+      }
+      constexpr int dpe = sizeof(D) / 8;  // doubles per element
+      KS_NCCL(ncclGroupStart());
+      for (size_t p = 0; p < neigh.size(); ++p) {
+        const int64_t sc = send_ptr[p + 1] - send_ptr[p], rc = recv_ptr[p + 1] - recv_ptr[p];
+        if (sc > 0) KS_NCCL(ncclSend(sendbuf + send_ptr[p], (size_t)sc * dpe, ncclDouble, neigh[p], ctx->comm, s));
+        if (rc > 0) KS_NCCL(ncclRecv(ghost + recv_ptr[p], (size_t)rc * dpe, ncclDouble, neigh[p], ctx->comm, s));
+      }
+      KS_NCCL(ncclGroupEnd());
+    }
+    if (ntiles > 0)
+      ksd::k_spmv_csr<D><<<ntiles, kBlock, 0, s>>>(rowptr, colidx, val, x, ghost, y, n_local, ntiles, st);
+    KS_HIP(hipGetLastError());
+  }
+};
+
+struct HostCallbackOp : ks_operator {
+  ks_host_apply_fn fn = nullptr;
+  void* user = nullptr;
+  void* xh = nullptr;
+  void* yh = nullptr;
+  ~HostCallbackOp() override { (void)hipHostFree(xh); (void)hipHostFree(yh); }
+  void apply(const void* x, void* y, const DevState*) override {
+    const size_t bytes = (size_t)n_local * (dtype == KS_F64 ? 8 : 16);
+    KS_HIP(hipMemcpyAsync(xh, x, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    KS_HIP(hipStreamSynchronize(ctx->stream));
+    const int rc = fn(user, xh, yh);
+    KS_REQUIRE(rc == 0, KS_ERR_OPERATOR, "host operator callback returned " + std::to_string(rc));
+    KS_HIP(hipMemcpyAsync(y, yh, bytes, hipMemcpyHostToDevice, ctx->stream));
+  }
+};
+
+struct DeviceCallbackOp : ks_operator {
+  ks_device_apply_fn fn = nullptr;
+  void* user = nullptr;
+  void apply(const void* x, void* y, const DevState*) override {
+    const int rc = fn(user, x, y, (void*)ctx->stream);
+    KS_REQUIRE(rc == 0, KS_ERR_OPERATOR, "device operator callback returned " + std::to_string(rc));
+  }
+};
+
+// Host conversion of whatever the caller has into int32 0-based CSR.
+template <class I> inline int64_t idx_at(const void* p, int64_t i) { return (int64_t) static_cast<const I*>(p)[i]; }
+
+template <class D>
+void build_csr_host(int64_t nrows, int64_t ncols, int64_t nnz, const void* ptr, const void* idx, const void* val,
+                    int layout, int base, int itype, std::vector<int32_t>& rp, std::vector<int32_t>& ci,
+                    std::vector<D>& vv) {
+  auto P = [&](int64_t i) { return (itype == KS_I32 ? idx_at<int32_t>(ptr, i) : idx_at<int64_t>(ptr, i)) - base; };
+  auto J = [&](int64_t i) { return (itype == KS_I32 ? idx_at<int32_t>(idx, i) : idx_at<int64_t>(idx, i)) - base; };
+  const D* v = static_cast<const D*>(val);
+  KS_REQUIRE(nnz < (int64_t)2147483647, KS_ERR_ARGUMENT, "nnz must fit int32");
+  rp.assign(nrows + 1, 0);
+  ci.resize(nnz);
+  vv.resize(nnz);
+  if (layout == KS_CSR) {
+    for (int64_t i = 0; i <= nrows; ++i) rp[i] = (int32_t)P(i);
+    KS_REQUIRE(rp[0] == 0 && rp[nrows] == nnz, KS_ERR_ARGUMENT, "row pointer does not match nnz");
+    for (int64_t p = 0; p < nnz; ++p) {
+      const int64_t c = J(p);
+      KS_REQUIRE(c >= 0 && c < ncols, KS_ERR_ARGUMENT, "column index out of range");
+      ci[p] = (int32_t)c;
+      vv[p] = v[p];
+    }
+  } else {  // CSC (Julia SparseMatrixCSC: colptr, rowval, nzval) -> CSR by counting sort
+    KS_REQUIRE(P(0) == 0 && P(ncols) == nnz, KS_ERR_ARGUMENT, "column pointer does not match nnz");
+    for (int64_t p = 0; p < nnz; ++p) {
+      const int64_t r = J(p);
+      KS_REQUIRE(r >= 0 && r < nrows, KS_ERR_ARGUMENT, "row index out of range");
+      rp[r + 1]++;
+    }
+    for (int64_t i = 0; i < nrows; ++i) rp[i + 1] += rp[i];
+    std::vector<int32_t> fill(rp.begin(), rp.end() - 1);
+    for (int64_t c = 0; c < ncols; ++c)
+      for (int64_t p = P(c); p < P(c + 1); ++p) {
+        const int64_t r = J(p);
+        const int32_t q = fill[r]++;
+        ci[q] = (int32_t)c;
+        vv[q] = v[p];
+      }
+  }
+}
+
+template <class D>
+CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<int32_t>& rp,
+                   const std::vector<int32_t>& ci, const std::vector<D>& vv) {
+  auto op = std::make_unique<CsrOp<D>>();
+  op->ctx = ctx;
+  op->n_local = nrows;
+  op->nnz = nnz;
+  op->dtype = sizeof(D) == 8 ? KS_F64 : KS_C64;
+  op->ntiles = (int)((nrows + ksd::kSpmvRows - 1) / ksd::kSpmvRows);
+  KS_HIP(hipMalloc(&op->rowptr, (size_t)(nrows + 1) * 4));
+  KS_HIP(hipMalloc(&op->colidx, std::max<size_t>((size_t)nnz * 4, 16)));
+  KS_HIP(hipMalloc(&op->val, std::max<size_t>((size_t)nnz * sizeof(D), 16)));
+  KS_HIP(hipMemcpy(op->rowptr, rp.data(), (size_t)(nrows + 1) * 4, hipMemcpyHostToDevice));
+  if (nnz) {
+    KS_HIP(hipMemcpy(op->colidx, ci.data(), (size_t)nnz * 4, hipMemcpyHostToDevice));
+    KS_HIP(hipMemcpy(op->val, vv.data(), (size_t)nnz * sizeof(D), hipMemcpyHostToDevice));
+  }
+  return op.release();
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------------
+struct ks_workspace {
+  ks_ctx* ctx = nullptr;
+  int dtype = KS_F64;
+  int64_t n = 0, n_global = 0, row_begin = 0, ld = 0;
+  int maxdim = 0;
+  size_t esz = 8;
+  void* V = nullptr;        // device, ld x (maxdim+1)
+  void* H = nullptr;        // pinned host, (maxdim+1) x maxdim
+  void* Q = nullptr;        // pinned host, maxdim x maxdim
+  void* Hd = nullptr;       // device mirror the expansion kernels write into
+  void* Hstage = nullptr;   // pinned host staging for Hd
+  void* Hscratch = nullptr; // device, maxdim+1 elements (verbs that must not touch H)
+  void* partial = nullptr;  // device, nblocks x pstride elements
+  double* partial2 = nullptr;  // device, nblocks doubles
+  void* coef = nullptr;     // device, pstride + 136 elements
+  void* red = nullptr;      // device, pstride elements (all-reduce buffer)
+  double* scal = nullptr;   // device, 8 doubles
+  double* scal_h = nullptr; // pinned host, 8 doubles
+  void* coef_h = nullptr;   // pinned host, pstride elements
+  DevState* st = nullptr;   // device
+  DevState* st_h = nullptr; // pinned host
+  void* Qd = nullptr;       // device, maxdim x maxdim
+  void* Qstage = nullptr;   // pinned host
+  void* tmp = nullptr;      // device scratch, lazily sized
+  size_t tmp_bytes = 0;
+  void* tmp2 = nullptr;
+  size_t tmp2_bytes = 0;
+  int pstride = 0;
+  int nb = 0;               // streaming workgroups
+  uint64_t seed = 20240917ull;
+  uint64_t rng_count = 0;
+
+  void* col(int j) const { return static_cast<char*>(V) + (size_t)j * ld * esz; }
+  void* ensure_tmp(size_t bytes) {
+    if (bytes > tmp_bytes) {
+      (void)hipFree(tmp);
+      tmp = nullptr;
+      KS_HIP(hipMalloc(&tmp, bytes));
+      tmp_bytes = bytes;
+    }
+    return tmp;
+  }
+  void* ensure_tmp2(size_t bytes) {
+    if (bytes > tmp2_bytes) {
+      (void)hipFree(tmp2);
+      tmp2 = nullptr;
+      KS_HIP(hipMalloc(&tmp2, bytes));
+      tmp2_bytes = bytes;
+    }
+    return tmp2;
+  }
+  ~ks_workspace() {
+    (void)hipFree(V); (void)hipHostFree(H); (void)hipHostFree(Q); (void)hipFree(Hd); (void)hipHostFree(Hstage);
+    (void)hipFree(Hscratch); (void)hipFree(partial); (void)hipFree(partial2); (void)hipFree(coef); (void)hipFree(red);
+    (void)hipFree(scal); (void)hipHostFree(scal_h); (void)hipHostFree(coef_h); (void)hipFree(st);
+    (void)hipHostFree(st_h); (void)hipFree(Qd); (void)hipHostFree(Qstage); (void)hipFree(tmp); (void)hipFree(tmp2);
+  }
+};
+
+namespace {
+
+uint64_t next_seed(ks_workspace* ws) {
+  const uint64_t s = ws->seed + ws->rng_count * 0x9E3779B97F4A7C15ull;
+  ws->rng_count++;
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel launch helpers (T = host scalar type; D = device scalar type)
+// ------------------------------------------------------------------------------------------------
+// Streaming kernels partition the rows into one contiguous range per workgroup, so every workgroup
+// must be co-resident: the grid is num_cu x min(KS_BPC, occupancy of that kernel).
+template <class K> int resident_blocks(ks_ctx* ctx, K kernel, size_t smem, int& cache) {
+  if (cache < 0) {
+    int occ = 0;
+    KS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kBlock, smem));
+    cache = std::max(1, std::min(occ, ctx->bpc));
+  }
+  return ctx->num_cu * cache;
+}
+
+template <class D, int NC4> int dots_blocks(ks_workspace* ws) {
+  static int cache = -1;
+  return resident_blocks(ws->ctx, ksd::k_dots<D, NC4>, 0, cache);
+}
+
+template <class D> int dots_blocks_for(ks_workspace* ws, int nc4) {
+  switch (nc4) {
+    case 1: return dots_blocks<D, 1>(ws);
+    case 2: return dots_blocks<D, 2>(ws);
+    case 3: return dots_blocks<D, 3>(ws);
+    case 4: return dots_blocks<D, 4>(ws);
+    case 5: return dots_blocks<D, 5>(ws);
+    case 6: return dots_blocks<D, 6>(ws);
+    case 7: return dots_blocks<D, 7>(ws);
+    case 8: return dots_blocks<D, 8>(ws);
+    case 9: return dots_blocks<D, 9>(ws);
+    default: return dots_blocks<D, 10>(ws);
+  }
+}
+
+template <class D, int NC4>
+void launch_dots_nc(ks_workspace* ws, int nb, const D* V, int jc, const D* w, D* partial, int norm_slot, int pass,
+                    const DevState* st) {
+  ksd::k_dots<D, NC4><<<nb, kBlock, 0, ws->ctx->stream>>>(V, ws->ld, jc, w, partial, ws->pstride, norm_slot, pass, st);
+}
+
+// partial[b][0..j) = V[:,0:j)^H w (block-local), partial[b][j] = |w|^2 (block-local); returns the
+// number of workgroups that wrote partials
+template <class D> int launch_dots(ks_workspace* ws, int j, const D* w, int pass, const DevState* st) {
+  const D* V = static_cast<const D*>(ws->V);
+  D* partial = static_cast<D*>(ws->partial);
+  const int nb = dots_blocks_for<D>(ws, (std::min(j, 40) + 3) / 4);  // first chunk is the widest
+  for (int c0 = 0; c0 < j; c0 += 40) {
+    const int jc = std::min(40, j - c0);
+    const int norm_slot = (c0 + 40 >= j) ? (j - c0) : -1;
+    const D* Vc = V + (size_t)c0 * ws->ld;
+    D* pc = partial + c0;
+    switch ((jc + 3) / 4) {
+      case 1: launch_dots_nc<D, 1>(ws, nb, Vc, jc, w, pc, norm_slot, pass, st); break;
+      case 2: launch_dots_nc<D, 2>(ws, nb, Vc, jc, w, pc, norm_slot, pass, st); break;
+      case 3: launch_dots_nc<D, 3>(ws, nb, Vc, jc, w, pc, norm_slot, pass, st); break;
+      case 4: launch_dots_nc<D, 4>(ws, nb, Vc, jc, w, pc, norm_slot, pass, st); break;
+      case 5: launch_dots_nc<D, 5>(ws, nb, Vc, jc, w, pc, norm_slot, pass, st); break;
+      case 6: launch_dots_nc<D, 6>(ws, nb, Vc, jc, w, pc, norm_slot, pass, st); break;
+      case 7: launch_dots_nc<D, 7>(ws, nb, Vc, jc, w, pc, norm_slot, pass, st); break;
+      case 8: launch_dots_nc<D, 8>(ws, nb, Vc, jc, w, pc, norm_slot, pass, st); break;
+      case 9: launch_dots_nc<D, 9>(ws, nb, Vc, jc, w, pc, norm_slot, pass, st); break;
+      default: launch_dots_nc<D, 10>(ws, nb, Vc, jc, w, pc, norm_slot, pass, st); break;
+    }
+  }
+  return nb;
+}
+
+// reduce the per-workgroup partials (+ all-reduce over ranks) and post-process on the device
+template <class D> void launch_fin_dots(ks_workspace* ws, int nbd, int j, D* Hcol, int pass, DevState* st) {
+  ks_ctx* c = ws->ctx;
+  D* partial = static_cast<D*>(ws->partial);
+  D* red = static_cast<D*>(ws->red);
+  D* coef = static_cast<D*>(ws->coef);
+  if (c->nranks == 1) {
+    ksd::k_fin_dots<D><<<1, kBlock, 0, c->stream>>>(partial, nbd, ws->pstride, j, red, Hcol, coef, pass, 0, st);
+  } else {
+    ksd::k_fin_dots<D><<<1, kBlock, 0, c->stream>>>(partial, nbd, ws->pstride, j, red, Hcol, coef, pass, 1, st);
+    c->allreduce(reinterpret_cast<double*>(red), (j + 1) * (int)(sizeof(D) / 8));
+    ksd::k_fin_dots<D><<<1, kBlock, 0, c->stream>>>(partial, nbd, ws->pstride, j, red, Hcol, coef, pass, 2, st);
+  }
+}
+
+template <class D> void launch_fin_norm(ks_workspace* ws, int j, D* Hsub, int pass, DevState* st) {
+  ks_ctx* c = ws->ctx;
+  double* red = reinterpret_cast<double*>(ws->red);
+  if (c->nranks == 1) {
+    ksd::k_fin_norm<D><<<1, kBlock, 0, c->stream>>>(ws->partial2, ws->nb, red, Hsub, j, pass, 0, st);
+  } else {
+    ksd::k_fin_norm<D><<<1, kBlock, 0, c->stream>>>(ws->partial2, ws->nb, red, Hsub, j, pass, 1, st);
+    c->allreduce(red, 1);
+    ksd::k_fin_norm<D><<<1, kBlock, 0, c->stream>>>(ws->partial2, ws->nb, red, Hsub, j, pass, 2, st);
+  }
+}
+
+// Enqueue orthogonalize!(arnoldi, j) (src/expansion.jl:69-109) entirely on the device: two DGKS
+// passes (the second one skips itself unless the first requested it), H column into Hd, v ./= wnorm.
+template <class D> void enqueue_orthogonalize(ks_workspace* ws, int j) {
+  hipStream_t s = ws->ctx->stream;
+  D* w = static_cast<D*>(ws->col(j));
+  D* Hd = static_cast<D*>(ws->Hd);
+  const int ldh = ws->maxdim + 1;
+  D* Hcol = Hd + (size_t)(j - 1) * ldh;
+  const D* V = static_cast<const D*>(ws->V);
+  for (int pass = 1; pass <= 2; ++pass) {
+    const int nbd = launch_dots<D>(ws, j, w, pass, ws->st);
+    launch_fin_dots<D>(ws, nbd, j, Hcol, pass, ws->st);
+    ksd::k_axpy<D><<<ws->nb, kBlock, 0, s>>>(V, ws->ld, j, w, static_cast<const D*>(ws->coef), ws->partial2, pass, ws->st);
+    launch_fin_norm<D>(ws, j, Hcol + j, pass, ws->st);
+  }
+  ksd::k_scale<D><<<ws->nb, kBlock, 0, s>>>(w, ws->ld, 0.0, ws->st);
+  KS_HIP(hipGetLastError());
+}
+
+inline void reset_state(ks_workspace* ws) {
+  std::memset(ws->st_h, 0, sizeof(DevState));
+  ws->st_h->breakdown = -1;
+  KS_HIP(hipMemcpyAsync(ws->st, ws->st_h, sizeof(DevState), hipMemcpyHostToDevice, ws->ctx->stream));
+}
+inline void fetch_state(ks_workspace* ws) {
+  KS_HIP(hipMemcpyAsync(ws->st_h, ws->st, sizeof(DevState), hipMemcpyDeviceToHost, ws->ctx->stream));
+  KS_HIP(hipStreamSynchronize(ws->ctx->stream));
+}
+
+// global 2-norm of column j (synchronous)
+template <class D> double col_norm(ks_workspace* ws, int j) {
+  ks_ctx* c = ws->ctx;
+  ksd::k_norm2<D><<<ws->nb, kBlock, 0, c->stream>>>(static_cast<const D*>(ws->col(j)), ws->ld, ws->partial2);
+  ksd::k_sum<<<1, kBlock, 0, c->stream>>>(ws->partial2, ws->nb, ws->scal);
+  c->allreduce(ws->scal, 1);
+  KS_HIP(hipMemcpyAsync(ws->scal_h, ws->scal, 8, hipMemcpyDeviceToHost, c->stream));
+  KS_HIP(hipStreamSynchronize(c->stream));
+  return std::sqrt(ws->scal_h[0]);
+}
+
+template <class D> void col_scale(ks_workspace* ws, int j, double factor) {
+  ksd::k_scale<D><<<ws->nb, kBlock, 0, ws->ctx->stream>>>(static_cast<D*>(ws->col(j)), ws->ld, factor, nullptr);
+  KS_HIP(hipGetLastError());
+}
+
+// h = V[:,0:j)^H V[:,jv]  -> coef (device) and, if h_host, the host copy (synchronous)
+template <class D> void gemv_t(ks_workspace* ws, int j, int jv, void* h_host) {
+  ks_ctx* c = ws->ctx;
+  const int nbd = launch_dots<D>(ws, j, static_cast<const D*>(ws->col(jv)), 1, nullptr);
+  // post into the scratch column so H is untouched; st must be valid for k_fin_dots -> use ws->st with
+  // breakdown cleared (verbs run outside batches)
+  launch_fin_dots<D>(ws, nbd, j, static_cast<D*>(ws->Hscratch), 1, ws->st);
+  if (h_host) {
+    KS_HIP(hipMemcpyAsync(ws->coef_h, ws->coef, (size_t)j * sizeof(D), hipMemcpyDeviceToHost, c->stream));
+    KS_HIP(hipStreamSynchronize(c->stream));
+    std::memcpy(h_host, ws->coef_h, (size_t)j * sizeof(D));
+  }
+}
+
+// V[:,jv] -= V[:,0:j) h ; returns nothing (partial2 holds block-local |v|^2)
+template <class D> void gemv_n_sub(ks_workspace* ws, int j, int jv, const void* h_host) {
+  ks_ctx* c = ws->ctx;
+  if (h_host) {
+    std::memcpy(ws->coef_h, h_host, (size_t)j * sizeof(D));
+    KS_HIP(hipMemcpyAsync(ws->coef, ws->coef_h, (size_t)j * sizeof(D), hipMemcpyHostToDevice, c->stream));
+  }
+  ksd::k_axpy<D><<<ws->nb, kBlock, 0, c->stream>>>(static_cast<const D*>(ws->V), ws->ld, j, static_cast<D*>(ws->col(jv)),
+                                                    static_cast<const D*>(ws->coef), ws->partial2, 1, nullptr);
+  KS_HIP(hipGetLastError());
+  if (h_host) KS_HIP(hipStreamSynchronize(c->stream));  // coef_h is reused by the next verb
+}
+
+template <class D> double norm_from_partial2(ks_workspace* ws) {
+  ks_ctx* c = ws->ctx;
+  ksd::k_sum<<<1, kBlock, 0, c->stream>>>(ws->partial2, ws->nb, ws->scal);
+  c->allreduce(ws->scal, 1);
+  KS_HIP(hipMemcpyAsync(ws->scal_h, ws->scal, 8, hipMemcpyDeviceToHost, c->stream));
+  KS_HIP(hipStreamSynchronize(c->stream));
+  return std::sqrt(ws->scal_h[0]);
+}
+
+// copyto!(view(V,:,j), host) incl. zeroing the pad rows
+template <class D> void col_upload(ks_workspace* ws, int j, const void* host) {
+  ks_ctx* c = ws->ctx;
+  KS_HIP(hipMemcpyAsync(ws->col(j), host, (size_t)ws->n * sizeof(D), hipMemcpyHostToDevice, c->stream));
+  if (ws->ld > ws->n)
+    KS_HIP(hipMemsetAsync(static_cast<char*>(ws->col(j)) + (size_t)ws->n * sizeof(D), 0,
+                          (size_t)(ws->ld - ws->n) * sizeof(D), c->stream));
+  KS_HIP(hipStreamSynchronize(c->stream));
+}
+
+// reinitialize!(arnoldi, j, populate!)  src/expansion.jl:12-59 (synchronous; rare)
+template <class D> bool reinit_column(ks_workspace* ws, int j, const void* v1_host) {
+  ks_ctx* c = ws->ctx;
+  D* v = static_cast<D*>(ws->col(j));
+  if (v1_host) {
+    col_upload<D>(ws, j, v1_host);
+  } else {
+    const int gb = (int)std::min<int64_t>((ws->ld + kBlock - 1) / kBlock, 8192);
+    ksd::k_fill_uniform<D><<<gb, kBlock, 0, c->stream>>>(v, ws->n, ws->ld, next_seed(ws), (uint64_t)ws->row_begin);
+  }
+  double rnorm = col_norm<D>(ws, j);                      // :24
+  if (j == 0) {                                           // :27-30
+    col_scale<D>(ws, j, 1.0 / rnorm);
+    return true;
+  }
+  // st->breakdown must read -1 for the fin kernels
+  reset_state(ws);
+  gemv_t<D>(ws, j, j, nullptr);                           // :37
+  gemv_n_sub<D>(ws, j, j, nullptr);                       // :38
+  double wnorm = norm_from_partial2<D>(ws);               // :41
+  if (wnorm < ksd::kEta * rnorm) {                        // :44
+    rnorm = wnorm;
+    gemv_t<D>(ws, j, j, nullptr);
+    gemv_n_sub<D>(ws, j, j, nullptr);
+    wnorm = norm_from_partial2<D>(ws);
+  }
+  if (wnorm <= ksd::kEta * rnorm) return false;           // :51
+  col_scale<D>(ws, j, 1.0 / wnorm);                       // :56
+  return true;
+}
+
+// copy the H columns produced on the device for steps from..to into the host H
+template <class T> void fetch_H_columns(ks_workspace* ws, int from, int to, const ks::Mat<T>& H) {
+  if (to < from) return;
+  const int ldh = ws->maxdim + 1;
+  const size_t off = (size_t)(from - 1) * ldh * sizeof(T);
+  const size_t bytes = (size_t)(to - from + 1) * ldh * sizeof(T);
+  KS_HIP(hipMemcpyAsync(static_cast<char*>(ws->Hstage) + off, static_cast<char*>(ws->Hd) + off, bytes,
+                        hipMemcpyDeviceToHost, ws->ctx->stream));
+  KS_HIP(hipStreamSynchronize(ws->ctx->stream));
+  const T* hs = static_cast<const T*>(ws->Hstage);
+  for (int j = from; j <= to; ++j)
+    for (int i = 0; i <= j; ++i) H(i, j - 1) = hs[(size_t)(j - 1) * ldh + i];
+}
+
+// V[:, c0:c0+r) <- V[:, c0:c0+c) Q  with Q already on the device (column-major, ld = c)
+template <class D> void rotate_device(ks_workspace* ws, int c0, int c, int r) {
+  ks_ctx* ctx = ws->ctx;
+  hipStream_t s = ctx->stream;
+  D* Vc = static_cast<D*>(ws->col(c0));
+  const D* Qd = static_cast<const D*>(ws->Qd);
+  const bool force_valu = env_int("KS_ROTATE_VALU", 0) != 0;
+  if constexpr (sizeof(D) == 8) {
+    if (!force_valu && c <= 64) {
+      const int ntile = (r + 15) / 16;
+      const int nb = ctx->num_cu * 4;
+      auto smem = [&](int KC) { return (size_t)ntile * 16 * (4 * KC + 1) * 8; };
+      if (c <= 24) ksd::k_rotate_mfma<6><<<nb, kBlock, smem(6), s>>>(Vc, ws->ld, c, r, Qd, c);
+      else if (c <= 40) ksd::k_rotate_mfma<10><<<nb, kBlock, smem(10), s>>>(Vc, ws->ld, c, r, Qd, c);
+      else ksd::k_rotate_mfma<16><<<nb, kBlock, smem(16), s>>>(Vc, ws->ld, c, r, Qd, c);
+      KS_HIP(hipGetLastError());
+      return;
+    }
+  }
+  const size_t smem = (size_t)c * r * sizeof(D);
+  const int nb = ctx->num_cu * 2;
+  if (c <= 8) ksd::k_rotate_valu<D, 8><<<nb, kBlock, smem, s>>>(Vc, ws->ld, c, r, Qd, c, Vc, ws->ld);
+  else if (c <= 16) ksd::k_rotate_valu<D, 16><<<nb, kBlock, smem, s>>>(Vc, ws->ld, c, r, Qd, c, Vc, ws->ld);
+  else if (c <= 24) ksd::k_rotate_valu<D, 24><<<nb, kBlock, smem, s>>>(Vc, ws->ld, c, r, Qd, c, Vc, ws->ld);
+  else if (c <= 40) ksd::k_rotate_valu<D, 40><<<nb, kBlock, smem, s>>>(Vc, ws->ld, c, r, Qd, c, Vc, ws->ld);
+  else {
+    // out of place through scratch, then copy back
+    D* tmp = static_cast<D*>(ws->ensure_tmp((size_t)ws->ld * r * sizeof(D)));
+    KS_REQUIRE(smem <= 64 * 1024, KS_ERR_ARGUMENT, "rotation shape too large for the generic kernel (c*r*elsize > 64 KiB)");
+    KS_HIP(hipMemsetAsync(tmp, 0, (size_t)ws->ld * r * sizeof(D), s));
+    ksd::k_gemm_tall<D, D><<<ctx->num_cu * 4, kBlock, smem, s>>>(Vc, ws->ld, ws->n, c, r, Qd, c, tmp, ws->ld);
+    KS_HIP(hipMemcpyAsync(Vc, tmp, (size_t)ws->ld * r * sizeof(D), hipMemcpyDeviceToDevice, s));
+  }
+  KS_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// the HIP backend of the driver
+// ------------------------------------------------------------------------------------------------
+template <class T> struct HipBackend : ks::Backend<T> {
+  using D = typename DevT<T>::type;
+  ks_operator* op;
+  ks_workspace* ws;
+  HipBackend(ks_operator* o, ks_workspace* w) : op(o), ws(w) {}
+
+  int64_t n_global() const override { return ws->n_global; }
+
+  void iterate_arnoldi(int from, int to, const ks::Mat<T>& H, ks::ExpandStats& stats) override {
+    ws->ctx->use();
+    int j0 = from;
+    while (j0 <= to) {
+      reset_state(ws);
+      int jend = to;
+      if (!op->async_capable) jend = j0;  // host operators: one step per batch
+      for (int j = j0; j <= jend; ++j) {
+        op->apply(ws->col(j - 1), ws->col(j), ws->st);
+        enqueue_orthogonalize<D>(ws, j);
+      }
+      fetch_state(ws);
+      const int bd = ws->st_h->breakdown;
+      const int last_done = bd >= 0 ? bd : jend;
+      fetch_H_columns<T>(ws, j0, last_done, H);
+      stats.steps += last_done - j0 + 1;
+      stats.reorth += ws->st_h->n_reorth;
+      if (bd >= 0) {
+        // orthogonalize! returned false at step bd: H[bd, bd-1] = 0 is already in place
+        // (src/expansion.jl:99-102); draw a fresh vector unless bd == n (src/expansion.jl:127-129)
+        if ((int64_t)bd != ws->n_global) {
+          reinit_column<D>(ws, bd, nullptr);
+          stats.breakdowns++;
+        }
+      }
+      j0 = last_done + 1;
+    }
+  }
+
+  bool reinitialize(int j, const T* v1_host) override {
+    ws->ctx->use();
+    return reinit_column<D>(ws, j, v1_host);
+  }
+
+  void rotate(int c0, int c, int r, const ks::Mat<T>& Q) override {
+    if (c <= 0 || r <= 0) return;
+    ws->ctx->use();
+    KS_HIP(hipStreamSynchronize(ws->ctx->stream));  // Qstage may still be in flight from a previous rotation
+    T* qs = static_cast<T*>(ws->Qstage);
+    for (int jj = 0; jj < r; ++jj)
+      for (int ii = 0; ii < c; ++ii) qs[ii + (size_t)jj * c] = Q(c0 + ii, c0 + jj);
+    KS_HIP(hipMemcpyAsync(ws->Qd, qs, (size_t)c * r * sizeof(T), hipMemcpyHostToDevice, ws->ctx->stream));
+    rotate_device<D>(ws, c0, c, r);
+  }
+
+  void col_copy(int dst, int src) override {
+    if (dst == src) return;
+    ksd::k_copy<D><<<ws->nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const D*>(ws->col(src)), static_cast<D*>(ws->col(dst)), ws->ld);
+    KS_HIP(hipGetLastError());
+  }
+};
+
+template <class F> void dispatch_dtype(int dtype, F&& f) {
+  if (dtype == KS_F64) f(double{});
+  else if (dtype == KS_C64) f(cplx{});
+  else throw KsError{KS_ERR_ARGUMENT, "unknown dtype"};
+}
+
+void check_col(const ks_workspace* ws, int j) {
+  KS_REQUIRE(ws != nullptr, KS_ERR_ARGUMENT, "null workspace");
+  KS_REQUIRE(j >= 0 && j <= ws->maxdim, KS_ERR_ARGUMENT, "column index out of range");
+}
+
+}  // namespace
+
+namespace {
+
+// Frobenius norm of (A X - Y C) where X = V[:, 0:nx), Y = V[:, 0:ny), C (ny x nx) host; and of (Y^H Y - I).
+template <class T>
+void relation_norms(ks_operator* A, ks_workspace* ws, int nx, int ny, const T* C, int ldc, double* resid, double* orth) {
+  using D = typename DevT<T>::type;
+  ks_ctx* c = ws->ctx;
+  hipStream_t s = c->stream;
+  D* y = static_cast<D*>(ws->ensure_tmp((size_t)ws->ld * sizeof(D)));
+  KS_HIP(hipMemsetAsync(y, 0, (size_t)ws->ld * sizeof(D), s));
+  const int nbk = c->num_cu * 4;
+  double r2 = 0.0;
+  for (int i = 0; i < nx; ++i) {
+    A->apply(ws->col(i), y, nullptr);
+    std::memcpy(ws->coef_h, C + (size_t)i * ldc, (size_t)ny * sizeof(T));
+    KS_HIP(hipMemcpyAsync(ws->coef, ws->coef_h, (size_t)ny * sizeof(T), hipMemcpyHostToDevice, s));
+    ksd::k_sub_lincomb<D><<<nbk, kBlock, 0, s>>>(y, static_cast<const D*>(ws->V), ws->ld, ny, static_cast<const D*>(ws->coef), ws->n);
+    ksd::k_norm2<D><<<ws->nb, kBlock, 0, s>>>(y, ws->ld, ws->partial2);
+    ksd::k_sum<<<1, kBlock, 0, s>>>(ws->partial2, ws->nb, ws->scal);
+    c->allreduce(ws->scal, 1);
+    KS_HIP(hipMemcpyAsync(ws->scal_h, ws->scal, 8, hipMemcpyDeviceToHost, s));
+    KS_HIP(hipStreamSynchronize(s));
+    r2 += ws->scal_h[0];
+  }
+  *resid = std::sqrt(r2);
+  // Gram matrix in 8x8 tiles
+  const int gnb = std::min(ws->nb, c->num_cu * 2);
+  D* gp = static_cast<D*>(ws->ensure_tmp2((size_t)gnb * 64 * sizeof(D) + 64 * sizeof(D)));
+  D* gout = gp + (size_t)gnb * 64;
+  std::vector<T> tile(64);
+  double o2 = 0.0;
+  for (int i0 = 0; i0 < ny; i0 += 8)
+    for (int j0 = 0; j0 < ny; j0 += 8) {
+      const int na = std::min(8, ny - i0), nbc = std::min(8, ny - j0);
+      ksd::k_gram_tile<D><<<gnb, kBlock, 0, s>>>(static_cast<const D*>(ws->col(i0)), ws->ld, na, static_cast<const D*>(ws->col(j0)),
+                                                  ws->ld, nbc, ws->n, gp);
+      ksd::k_reduce_cols<D><<<1, kBlock, 0, s>>>(gp, gnb, 64, 64, gout);
+      c->allreduce(reinterpret_cast<double*>(gout), 64 * (int)(sizeof(D) / 8));
+      KS_HIP(hipMemcpyAsync(tile.data(), gout, 64 * sizeof(D), hipMemcpyDeviceToHost, s));
+      KS_HIP(hipStreamSynchronize(s));
+      for (int jj = 0; jj < nbc; ++jj)
+        for (int ii = 0; ii < na; ++ii) {
+          T g = tile[ii + 8 * jj];
+          if (i0 + ii == j0 + jj) g -= T(1);
+          o2 += ks::abs2_(g);
+        }
+    }
+  *orth = std::sqrt(o2);
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char* ks_last_error_string(void) { return g_last_error.c_str(); }
+
+int ks_version(int* major, int* minor) {
+  if (major) *major = KS_VERSION_MAJOR;
+  if (minor) *minor = KS_VERSION_MINOR;
+  return KS_OK;
+}
+
+int ks_ctx_create(int device, ks_ctx** out) {
+  return guarded([&] {
+    KS_REQUIRE(out, KS_ERR_ARGUMENT, "null out");
+    auto c = std::make_unique<ks_ctx>();
+    ctx_init_device(c.get(), device);
+    *out = c.release();
+  });
+}
+
+int ks_comm_unique_id(void* out128) {
+  return guarded([&] {
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    KS_NCCL(ncclGetUniqueId(&id));
+    std::memcpy(out128, &id, 128);
+  });
+}
+
+int ks_ctx_create_dist(int device, int rank, int nranks, const void* unique_id128, ks_ctx** out) {
+  return guarded([&] {
+    KS_REQUIRE(out && unique_id128, KS_ERR_ARGUMENT, "null argument");
+    KS_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, KS_ERR_ARGUMENT, "bad rank/nranks");
+    auto c = std::make_unique<ks_ctx>();
+    ctx_init_device(c.get(), device);
+    c->rank = rank;
+    c->nranks = nranks;
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id128, 128);
+    KS_NCCL(ncclCommInitRank(&c->comm, nranks, id, rank));
+    *out = c.release();
+  });
+}
+
+int ks_ctx_destroy(ks_ctx* ctx) {
+  return guarded([&] {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+  });
+}
+
+int ks_ctx_synchronize(ks_ctx* ctx) {
+  return guarded([&] {
+    KS_REQUIRE(ctx, KS_ERR_ARGUMENT, "null ctx");
+    ctx->use();
+    KS_HIP(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int ks_ctx_rank(const ks_ctx* ctx, int* rank, int* nranks) {
+  return guarded([&] {
+    KS_REQUIRE(ctx, KS_ERR_ARGUMENT, "null ctx");
+    if (rank) *rank = ctx->rank;
+    if (nranks) *nranks = ctx->nranks;
+  });
+}
+
+int ks_ctx_stream(ks_ctx* ctx, void** hip_stream) {
+  return guarded([&] {
+    KS_REQUIRE(ctx && hip_stream, KS_ERR_ARGUMENT, "null argument");
+    *hip_stream = (void*)ctx->stream;
+  });
+}
+
+// ---- operators -----------------------------------------------------------------------------------
+int ks_operator_csr(ks_ctx* ctx, int64_t nrows_local, int64_t ncols, int64_t nnz, const void* ptr, const void* idx,
+                    const void* val, int layout, int index_base, int index_type, int dtype, ks_operator** out) {
+  return guarded([&] {
+    KS_REQUIRE(ctx && out, KS_ERR_ARGUMENT, "null argument");
+    KS_REQUIRE(nrows_local >= 0 && ncols >= 0 && nnz >= 0, KS_ERR_ARGUMENT, "negative size");
+    KS_REQUIRE(ctx->nranks > 1 || nrows_local == ncols, KS_ERR_DIMENSION,
+               "matrix is not square: dimensions are (" + std::to_string(nrows_local) + ", " + std::to_string(ncols) + ")");
+    KS_REQUIRE(ctx->nranks == 1, KS_ERR_ARGUMENT, "use ks_operator_csr_dist on a multi-GPU context");
+    KS_REQUIRE(layout == KS_CSR || layout == KS_CSC, KS_ERR_ARGUMENT, "bad layout");
+    KS_REQUIRE(index_type == KS_I32 || index_type == KS_I64, KS_ERR_ARGUMENT, "bad index type");
+    ctx->use();
+    std::vector<int32_t> rp, ci;
+    dispatch_dtype(dtype, [&](auto tag) {
+      using T = decltype(tag);
+      using D = typename DevT<T>::type;
+      std::vector<D> vv;
+      build_csr_host<D>(nrows_local, ncols, nnz, ptr, idx, val, layout, index_base, index_type, rp, ci, vv);
+      *out = make_csr<D>(ctx, nrows_local, nnz, rp, ci, vv);
+    });
+  });
+}
+
+int ks_operator_csr_dist(ks_ctx* ctx, int64_t nrows_local, int64_t nghost, int64_t nnz, const int64_t* rowptr,
+                         const int32_t* colidx, const void* val, int dtype, int nneigh, const int32_t* neigh,
+                         const int64_t* send_ptr, const int32_t* send_idx, const int64_t* recv_cnt, ks_operator** out) {
+  return guarded([&] {
+    KS_REQUIRE(ctx && out && rowptr, KS_ERR_ARGUMENT, "null argument");
+    KS_REQUIRE(nnz < (int64_t)2147483647, KS_ERR_ARGUMENT, "nnz must fit int32");
+    ctx->use();
+    std::vector<int32_t> rp(nrows_local + 1);
+    for (int64_t i = 0; i <= nrows_local; ++i) rp[i] = (int32_t)rowptr[i];
+    std::vector<int32_t> ci(colidx, colidx + nnz);
+    for (int64_t p = 0; p < nnz; ++p)
+      KS_REQUIRE(ci[p] >= 0 && ci[p] < nrows_local + nghost, KS_ERR_ARGUMENT, "local-extended column index out of range");
+    dispatch_dtype(dtype, [&](auto tag) {
+      using T = decltype(tag);
+      using D = typename DevT<T>::type;
+      std::vector<D> vv(static_cast<const D*>(val), static_cast<const D*>(val) + nnz);
+      CsrOp<D>* op = make_csr<D>(ctx, nrows_local, nnz, rp, ci, vv);
+      std::unique_ptr<CsrOp<D>> guard(op);
+      op->nghost = nghost;
+      KS_HIP(hipMalloc(&op->ghost, std::max<size_t>((size_t)nghost * sizeof(D), 16)));
+      KS_HIP(hipMemset(op->ghost, 0, std::max<size_t>((size_t)nghost * sizeof(D), 16)));
+      op->neigh.assign(neigh, neigh + nneigh);
+      op->send_ptr.assign(send_ptr, send_ptr + nneigh + 1);
+      op->recv_ptr.assign(nneigh + 1, 0);
+      for (int p = 0; p < nneigh; ++p) op->recv_ptr[p + 1] = op->recv_ptr[p] + recv_cnt[p];
+      KS_REQUIRE(op->recv_ptr[nneigh] == nghost, KS_ERR_ARGUMENT, "recv counts do not add up to nghost");
+      const int64_t nsend = nneigh ? op->send_ptr[nneigh] : 0;
+      KS_HIP(hipMalloc(&op->sendbuf, std::max<size_t>((size_t)nsend * sizeof(D), 16)));
+      KS_HIP(hipMalloc(&op->send_idx, std::max<size_t>((size_t)nsend * 4, 16)));
+      if (nsend) KS_HIP(hipMemcpy(op->send_idx, send_idx, (size_t)nsend * 4, hipMemcpyHostToDevice));
+      KS_REQUIRE(nneigh == 0 || ctx->comm != nullptr, KS_ERR_ARGUMENT, "halo plan needs a distributed context");
+      *out = guard.release();
+    });
+  });
+}
+
+int ks_operator_host_callback(ks_ctx* ctx, int64_t n_local, int dtype, ks_host_apply_fn apply, void* user,
+                              ks_operator** out) {
+  return guarded([&] {
+    KS_REQUIRE(ctx && out && apply, KS_ERR_ARGUMENT, "null argument");
+    KS_REQUIRE(dtype == KS_F64 || dtype == KS_C64, KS_ERR_ARGUMENT, "unknown dtype");
+    ctx->use();
+    auto op = std::make_unique<HostCallbackOp>();
+    op->ctx = ctx; op->n_local = n_local; op->dtype = dtype; op->fn = apply; op->user = user;
+    op->async_capable = false;
+    const size_t bytes = std::max<size_t>((size_t)n_local * (dtype == KS_F64 ? 8 : 16), 16);
+    KS_HIP(hipHostMalloc(&op->xh, bytes));
+    KS_HIP(hipHostMalloc(&op->yh, bytes));
+    *out = op.release();
+  });
+}
+
+int ks_operator_device_callback(ks_ctx* ctx, int64_t n_local, int dtype, ks_device_apply_fn apply, void* user,
+                                ks_operator** out) {
+  return guarded([&] {
+    KS_REQUIRE(ctx && out && apply, KS_ERR_ARGUMENT, "null argument");
+    KS_REQUIRE(dtype == KS_F64 || dtype == KS_C64, KS_ERR_ARGUMENT, "unknown dtype");
+    auto op = std::make_unique<DeviceCallbackOp>();
+    op->ctx = ctx; op->n_local = n_local; op->dtype = dtype; op->fn = apply; op->user = user;
+    *out = op.release();
+  });
+}
+
+int ks_operator_destroy(ks_operator* op) {
+  return guarded([&] {
+    if (!op) return;
+    (void)hipSetDevice(op->ctx->device);
+    (void)hipStreamSynchronize(op->ctx->stream);
+    delete op;
+  });
+}
+
+int ks_operator_size(const ks_operator* op, int64_t* n_local, int64_t* nnz, int* dtype) {
+  return guarded([&] {
+    KS_REQUIRE(op, KS_ERR_ARGUMENT, "null operator");
+    if (n_local) *n_local = op->n_local;
+    if (nnz) *nnz = op->nnz;
+    if (dtype) *dtype = op->dtype;
+  });
+}
+
+int ks_operator_apply_raw(ks_operator* op, const void* x_dev, void* y_dev) {
+  return guarded([&] {
+    KS_REQUIRE(op && x_dev && y_dev, KS_ERR_ARGUMENT, "null argument");
+    op->ctx->use();
+    op->apply(x_dev, y_dev, nullptr);
+  });
+}
+
+// ---- workspace -----------------------------------------------------------------------------------
+int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t row_begin, int maxdim, int dtype,
+                        ks_workspace** out) {
+  return guarded([&] {
+    KS_REQUIRE(ctx && out, KS_ERR_ARGUMENT, "null argument");
+    KS_REQUIRE(dtype == KS_F64 || dtype == KS_C64, KS_ERR_ARGUMENT, "unknown dtype");
+    KS_REQUIRE(maxdim >= 1, KS_ERR_ARGUMENT, "maxdim must be positive");
+    // ArnoldiWorkspace(T, n, k): "Krylov dimension should be less than matrix order." src/ArnoldiMethod.jl:62-63
+    KS_REQUIRE((int64_t)maxdim <= n_global, KS_ERR_ARGUMENT, "Krylov dimension should be less than matrix order.");
+    KS_REQUIRE(n_local >= 0 && n_local <= n_global, KS_ERR_ARGUMENT, "bad n_local");
+    ctx->use();
+    auto w = std::make_unique<ks_workspace>();
+    w->ctx = ctx;
+    w->dtype = dtype;
+    w->esz = dtype == KS_F64 ? 8 : 16;
+    w->n = n_local;
+    w->n_global = n_global;
+    w->row_begin = row_begin;
+    w->maxdim = maxdim;
+    w->ld = std::max<int64_t>(round_up(n_local, 64), 64);
+    w->pstride = (int)round_up(maxdim + 2, 8);
+    w->nb = ctx->nblocks();
+    const size_t esz = w->esz;
+    const size_t vbytes = (size_t)w->ld * (maxdim + 1) * esz;
+    KS_HIP(hipMalloc(&w->V, vbytes));
+    KS_HIP(hipMemsetAsync(w->V, 0, vbytes, ctx->stream));
+    const size_t hbytes = (size_t)(maxdim + 1) * maxdim * esz, qbytes = (size_t)maxdim * maxdim * esz;
+    KS_HIP(hipHostMalloc(&w->H, hbytes));
+    KS_HIP(hipHostMalloc(&w->Q, qbytes));
+    KS_HIP(hipHostMalloc(&w->Hstage, hbytes));
+    KS_HIP(hipHostMalloc(&w->Qstage, qbytes));
+    std::memset(w->H, 0, hbytes);   // zeros(T, k+1, k), src/ArnoldiMethod.jl:66
+    std::memset(w->Q, 0, qbytes);
+    std::memset(w->Hstage, 0, hbytes);
+    KS_HIP(hipMalloc(&w->Hd, hbytes));
+    KS_HIP(hipMemsetAsync(w->Hd, 0, hbytes, ctx->stream));
+    KS_HIP(hipMalloc(&w->Hscratch, (size_t)(maxdim + 2) * esz));
+    KS_HIP(hipMalloc(&w->partial, (size_t)w->nb * w->pstride * esz));
+    KS_HIP(hipMalloc(&w->partial2, (size_t)std::max(w->nb, ctx->num_cu * 8) * 8));
+    KS_HIP(hipMalloc(&w->coef, (size_t)(w->pstride + 136) * esz));
+    KS_HIP(hipMemsetAsync(w->coef, 0, (size_t)(w->pstride + 136) * esz, ctx->stream));
+    KS_HIP(hipMalloc(&w->red, (size_t)w->pstride * esz));
+    KS_HIP(hipMalloc(&w->scal, 64));
+    KS_HIP(hipHostMalloc(&w->scal_h, 64));
+    KS_HIP(hipHostMalloc(&w->coef_h, (size_t)w->pstride * esz));
+    KS_HIP(hipMalloc(&w->st, sizeof(DevState)));
+    KS_HIP(hipHostMalloc(&w->st_h, sizeof(DevState)));
+    KS_HIP(hipMalloc(&w->Qd, std::max<size_t>(qbytes, 16)));
+    reset_state(w.get());
+    KS_HIP(hipStreamSynchronize(ctx->stream));
+    *out = w.release();
+  });
+}
+
+int ks_workspace_destroy(ks_workspace* ws) {
+  return guarded([&] {
+    if (!ws) return;
+    (void)hipSetDevice(ws->ctx->device);
+    (void)hipStreamSynchronize(ws->ctx->stream);
+    delete ws;
+  });
+}
+
+int ks_workspace_dims(const ks_workspace* ws, int64_t* n_local, int* maxdim, int* dtype, int64_t* ldv) {
+  return guarded([&] {
+    KS_REQUIRE(ws, KS_ERR_ARGUMENT, "null workspace");
+    if (n_local) *n_local = ws->n;
+    if (maxdim) *maxdim = ws->maxdim;
+    if (dtype) *dtype = ws->dtype;
+    if (ldv) *ldv = ws->ld;
+  });
+}
+
+int ks_workspace_H(ks_workspace* ws, void** H, int* ldh) {
+  return guarded([&] {
+    KS_REQUIRE(ws && H, KS_ERR_ARGUMENT, "null argument");
+    *H = ws->H;
+    if (ldh) *ldh = ws->maxdim + 1;
+  });
+}
+
+int ks_workspace_Q(ks_workspace* ws, void** Q, int* ldq) {
+  return guarded([&] {
+    KS_REQUIRE(ws && Q, KS_ERR_ARGUMENT, "null argument");
+    *Q = ws->Q;
+    if (ldq) *ldq = ws->maxdim;
+  });
+}
+
+int ks_workspace_col_ptr(ks_workspace* ws, int j, void** dev_ptr) {
+  return guarded([&] {
+    check_col(ws, j);
+    KS_REQUIRE(dev_ptr, KS_ERR_ARGUMENT, "null argument");
+    *dev_ptr = ws->col(j);
+  });
+}
+
+int ks_workspace_set_seed(ks_workspace* ws, uint64_t seed) {
+  return guarded([&] {
+    KS_REQUIRE(ws, KS_ERR_ARGUMENT, "null workspace");
+    ws->seed = seed;
+    ws->rng_count = 0;
+  });
+}
+
+// ---- verbs ---------------------------------------------------------------------------------------
+int ks_col_upload(ks_workspace* ws, int j, const void* host) {
+  return guarded([&] {
+    check_col(ws, j);
+    KS_REQUIRE(host, KS_ERR_ARGUMENT, "null host pointer");
+    ws->ctx->use();
+    dispatch_dtype(ws->dtype, [&](auto tag) { col_upload<typename DevT<decltype(tag)>::type>(ws, j, host); });
+  });
+}
+
+int ks_col_download(ks_workspace* ws, int j, void* host) {
+  return guarded([&] {
+    check_col(ws, j);
+    KS_REQUIRE(host, KS_ERR_ARGUMENT, "null host pointer");
+    ws->ctx->use();
+    KS_HIP(hipMemcpyAsync(host, ws->col(j), (size_t)ws->n * ws->esz, hipMemcpyDeviceToHost, ws->ctx->stream));
+    KS_HIP(hipStreamSynchronize(ws->ctx->stream));
+  });
+}
+
+int ks_cols_download(ks_workspace* ws, int j0, int ncols, void* host, int64_t ldhost) {
+  return guarded([&] {
+    KS_REQUIRE(ws && host, KS_ERR_ARGUMENT, "null argument");
+    KS_REQUIRE(j0 >= 0 && ncols >= 0 && j0 + ncols <= ws->maxdim + 1, KS_ERR_ARGUMENT, "column range out of bounds");
+    KS_REQUIRE(ldhost >= ws->n, KS_ERR_ARGUMENT, "ldhost too small");
+    if (ncols == 0 || ws->n == 0) return;
+    ws->ctx->use();
+    KS_HIP(hipMemcpy2DAsync(host, (size_t)ldhost * ws->esz, ws->col(j0), (size_t)ws->ld * ws->esz,
+                            (size_t)ws->n * ws->esz, (size_t)ncols, hipMemcpyDeviceToHost, ws->ctx->stream));
+    KS_HIP(hipStreamSynchronize(ws->ctx->stream));
+  });
+}
+
+int ks_cols_upload(ks_workspace* ws, int j0, int ncols, const void* host, int64_t ldhost) {
+  return guarded([&] {
+    KS_REQUIRE(ws && host, KS_ERR_ARGUMENT, "null argument");
+    KS_REQUIRE(j0 >= 0 && ncols >= 0 && j0 + ncols <= ws->maxdim + 1, KS_ERR_ARGUMENT, "column range out of bounds");
+    KS_REQUIRE(ldhost >= ws->n, KS_ERR_ARGUMENT, "ldhost too small");
+    if (ncols == 0 || ws->n == 0) return;
+    ws->ctx->use();
+    KS_HIP(hipMemcpy2DAsync(ws->col(j0), (size_t)ws->ld * ws->esz, host, (size_t)ldhost * ws->esz,
+                            (size_t)ws->n * ws->esz, (size_t)ncols, hipMemcpyHostToDevice, ws->ctx->stream));
+    KS_HIP(hipStreamSynchronize(ws->ctx->stream));
+  });
+}
+
+int ks_col_fill_uniform(ks_workspace* ws, int j, uint64_t seed) {
+  return guarded([&] {
+    check_col(ws, j);
+    ws->ctx->use();
+    const int gb = (int)std::min<int64_t>((ws->ld + kBlock - 1) / kBlock, 8192);
+    dispatch_dtype(ws->dtype, [&](auto tag) {
+      using D = typename DevT<decltype(tag)>::type;
+      ksd::k_fill_uniform<D><<<gb, kBlock, 0, ws->ctx->stream>>>(static_cast<D*>(ws->col(j)), ws->n, ws->ld, seed,
+                                                                (uint64_t)ws->row_begin);
+    });
+    KS_HIP(hipGetLastError());
+    KS_HIP(hipStreamSynchronize(ws->ctx->stream));
+  });
+}
+
+int ks_col_norm(ks_workspace* ws, int j, double* out) {
+  return guarded([&] {
+    check_col(ws, j);
+    KS_REQUIRE(out, KS_ERR_ARGUMENT, "null out");
+    ws->ctx->use();
+    dispatch_dtype(ws->dtype, [&](auto tag) { *out = col_norm<typename DevT<decltype(tag)>::type>(ws, j); });
+  });
+}
+
+int ks_col_div(ks_workspace* ws, int j, double s) {
+  return guarded([&] {
+    check_col(ws, j);
+    ws->ctx->use();
+    dispatch_dtype(ws->dtype, [&](auto tag) { col_scale<typename DevT<decltype(tag)>::type>(ws, j, 1.0 / s); });
+    KS_HIP(hipStreamSynchronize(ws->ctx->stream));
+  });
+}
+
+int ks_col_copy(ks_workspace* ws, int dst, int src) {
+  return guarded([&] {
+    check_col(ws, dst);
+    check_col(ws, src);
+    ws->ctx->use();
+    if (dst == src) return;
+    dispatch_dtype(ws->dtype, [&](auto tag) {
+      using D = typename DevT<decltype(tag)>::type;
+      ksd::k_copy<D><<<ws->nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const D*>(ws->col(src)), static_cast<D*>(ws->col(dst)), ws->ld);
+    });
+    KS_HIP(hipGetLastError());
+    KS_HIP(hipStreamSynchronize(ws->ctx->stream));
+  });
+}
+
+int ks_apply(ks_operator* A, ks_workspace* ws, int jsrc, int jdst) {
+  return guarded([&] {
+    KS_REQUIRE(A, KS_ERR_ARGUMENT, "null operator");
+    check_col(ws, jsrc);
+    check_col(ws, jdst);
+    KS_REQUIRE(jsrc != jdst, KS_ERR_ARGUMENT, "source and destination columns must differ");
+    KS_REQUIRE(A->n_local == ws->n && A->dtype == ws->dtype, KS_ERR_DIMENSION, "operator / workspace mismatch");
+    ws->ctx->use();
+    A->apply(ws->col(jsrc), ws->col(jdst), nullptr);
+    KS_HIP(hipStreamSynchronize(ws->ctx->stream));
+  });
+}
+
+int ks_gemv_t(ks_workspace* ws, int j, int jv, void* h_host) {
+  return guarded([&] {
+    check_col(ws, jv);
+    KS_REQUIRE(j >= 1 && j <= ws->maxdim + 1 && h_host, KS_ERR_ARGUMENT, "bad arguments");
+    ws->ctx->use();
+    reset_state(ws);
+    dispatch_dtype(ws->dtype, [&](auto tag) { gemv_t<typename DevT<decltype(tag)>::type>(ws, j, jv, h_host); });
+  });
+}
+
+int ks_gemv_n_sub(ks_workspace* ws, int j, int jv, const void* h_host) {
+  return guarded([&] {
+    check_col(ws, jv);
+    KS_REQUIRE(j >= 1 && j <= ws->maxdim + 1 && h_host, KS_ERR_ARGUMENT, "bad arguments");
+    KS_REQUIRE(jv >= j, KS_ERR_ARGUMENT, "the updated column must not be one of the projected-out columns");
+    ws->ctx->use();
+    dispatch_dtype(ws->dtype, [&](auto tag) { gemv_n_sub<typename DevT<decltype(tag)>::type>(ws, j, jv, h_host); });
+  });
+}
+
+int ks_rotate(ks_workspace* ws, int c0, int c, int r, const void* Q_host, int ldq) {
+  return guarded([&] {
+    KS_REQUIRE(ws && Q_host, KS_ERR_ARGUMENT, "null argument");
+    KS_REQUIRE(c0 >= 0 && c >= 1 && r >= 1 && r <= c && c0 + c <= ws->maxdim + 1 && ldq >= c, KS_ERR_ARGUMENT,
+               "bad rotation shape");
+    KS_REQUIRE((size_t)c * r <= (size_t)ws->maxdim * ws->maxdim, KS_ERR_ARGUMENT, "rotation larger than the workspace Q");
+    ws->ctx->use();
+    KS_HIP(hipStreamSynchronize(ws->ctx->stream));
+    dispatch_dtype(ws->dtype, [&](auto tag) {
+      using T = decltype(tag);
+      using D = typename DevT<T>::type;
+      const T* Qh = static_cast<const T*>(Q_host);
+      T* qs = static_cast<T*>(ws->Qstage);
+      for (int jj = 0; jj < r; ++jj)
+        for (int ii = 0; ii < c; ++ii) qs[ii + (size_t)jj * c] = Qh[ii + (size_t)jj * ldq];
+      KS_HIP(hipMemcpyAsync(ws->Qd, qs, (size_t)c * r * sizeof(T), hipMemcpyHostToDevice, ws->ctx->stream));
+      rotate_device<D>(ws, c0, c, r);
+    });
+    KS_HIP(hipStreamSynchronize(ws->ctx->stream));
+  });
+}
+
+int ks_basis_times(ks_workspace* ws, int c, int r, const void* Y_host, int ldy, int ydtype, void* out_host,
+                   int64_t ldout) {
+  return guarded([&] {
+    KS_REQUIRE(ws && Y_host && out_host, KS_ERR_ARGUMENT, "null argument");
+    KS_REQUIRE(c >= 1 && r >= 1 && c <= ws->maxdim + 1 && ldy >= c && ldout >= ws->n, KS_ERR_ARGUMENT, "bad shape");
+    KS_REQUIRE(ydtype == KS_C64 || ydtype == ws->dtype, KS_ERR_ARGUMENT, "coefficient dtype must be complex or match the basis");
+    ws->ctx->use();
+    hipStream_t s = ws->ctx->stream;
+    const size_t yes = ydtype == KS_F64 ? 8 : 16;
+    const size_t smem = (size_t)c * r * yes;
+    KS_REQUIRE(smem <= 64 * 1024, KS_ERR_ARGUMENT, "coefficient block too large");
+    // coefficients -> device (contiguous, ld = c)
+    std::vector<char> yc(smem);
+    for (int jj = 0; jj < r; ++jj)
+      std::memcpy(yc.data() + (size_t)jj * c * yes, static_cast<const char*>(Y_host) + (size_t)jj * ldy * yes, (size_t)c * yes);
+    void* yd = ws->ensure_tmp2(smem);
+    KS_HIP(hipMemcpyAsync(yd, yc.data(), smem, hipMemcpyHostToDevice, s));
+    void* out = ws->ensure_tmp((size_t)ws->ld * r * yes);
+    const int nb = ws->ctx->num_cu * 4;
+    if (ws->dtype == KS_F64 && ydtype == KS_F64)
+      ksd::k_gemm_tall<double, double><<<nb, kBlock, smem, s>>>((const double*)ws->V, ws->ld, ws->n, c, r, (const double*)yd, c, (double*)out, ws->ld);
+    else if (ws->dtype == KS_F64)
+      ksd::k_gemm_tall<double, cd><<<nb, kBlock, smem, s>>>((const double*)ws->V, ws->ld, ws->n, c, r, (const cd*)yd, c, (cd*)out, ws->ld);
+    else
+      ksd::k_gemm_tall<cd, cd><<<nb, kBlock, smem, s>>>((const cd*)ws->V, ws->ld, ws->n, c, r, (const cd*)yd, c, (cd*)out, ws->ld);
+    KS_HIP(hipGetLastError());
+    if (ws->n > 0)
+      KS_HIP(hipMemcpy2DAsync(out_host, (size_t)ldout * yes, out, (size_t)ws->ld * yes, (size_t)ws->n * yes, (size_t)r,
+                              hipMemcpyDeviceToHost, s));
+    KS_HIP(hipStreamSynchronize(s));
+  });
+}
+
+// ---- fused hot path --------------------------------------------------------------------------------
+int ks_orthogonalize(ks_workspace* ws, int j, int* ok) {
+  return guarded([&] {
+    check_col(ws, j);
+    KS_REQUIRE(j >= 1, KS_ERR_ARGUMENT, "orthogonalize needs j >= 1");
+    ws->ctx->use();
+    reset_state(ws);
+    dispatch_dtype(ws->dtype, [&](auto tag) {
+      using T = decltype(tag);
+      using D = typename DevT<T>::type;
+      enqueue_orthogonalize<D>(ws, j);
+      fetch_state(ws);
+      ks::Mat<T> H(static_cast<T*>(ws->H), ws->maxdim + 1, ws->maxdim, ws->maxdim + 1);
+      fetch_H_columns<T>(ws, j, j, H);
+    });
+    if (ok) *ok = ws->st_h->breakdown < 0;
+  });
+}
+
+int ks_reinitialize(ks_workspace* ws, int j, const void* v1_host, int* ok) {
+  return guarded([&] {
+    check_col(ws, j);
+    ws->ctx->use();
+    bool good = true;
+    dispatch_dtype(ws->dtype, [&](auto tag) { good = reinit_column<typename DevT<decltype(tag)>::type>(ws, j, v1_host); });
+    if (ok) *ok = good ? 1 : 0;
+  });
+}
+
+int ks_iterate_arnoldi(ks_operator* A, ks_workspace* ws, int from, int to, ks_expand_stats* stats) {
+  return guarded([&] {
+    KS_REQUIRE(A && ws, KS_ERR_ARGUMENT, "null argument");
+    KS_REQUIRE(A->n_local == ws->n && A->dtype == ws->dtype, KS_ERR_DIMENSION, "operator / workspace mismatch");
+    KS_REQUIRE(from >= 1 && to <= ws->maxdim, KS_ERR_ARGUMENT, "step range out of bounds");
+    ws->ctx->use();
+    ks::ExpandStats st;
+    dispatch_dtype(ws->dtype, [&](auto tag) {
+      using T = decltype(tag);
+      HipBackend<T> be(A, ws);
+      ks::Mat<T> H(static_cast<T*>(ws->H), ws->maxdim + 1, ws->maxdim, ws->maxdim + 1);
+      be.iterate_arnoldi(from, to, H, st);
+    });
+    if (stats) {
+      stats->steps = st.steps;
+      stats->reorth = st.reorth;
+      stats->breakdowns = st.breakdowns;
+      stats->reserved = 0;
+    }
+  });
+}
+
+// ---- driver ------------------------------------------------------------------------------------------
+int ks_params_default(int64_t n, ks_params* p) {
+  return guarded([&] {
+    KS_REQUIRE(p, KS_ERR_ARGUMENT, "null params");
+    p->nev = (int32_t)std::min<int64_t>(6, n);                              // src/run.jl:103
+    p->which = KS_LM;                                                        // :104
+    p->tol = std::sqrt(ks::kEps);                                            // :105
+    p->mindim = (int32_t)std::min<int64_t>(std::max(10, p->nev), n);         // :106
+    p->maxdim = (int32_t)std::min<int64_t>(std::max(20, 2 * p->nev), n);     // :107
+    p->restarts = 200;                                                       // :108
+    p->start_from = 1;
+    p->initialize = 1;
+    p->reserved = 0;
+  });
+}
+
+int ks_partialschur(ks_operator* A, ks_workspace* ws, const ks_params* p, const void* v1_host,
+                    double* eigenvalues_c64, ks_history* history) {
+  return guarded([&] {
+    KS_REQUIRE(A && ws && p, KS_ERR_ARGUMENT, "null argument");
+    KS_REQUIRE(A->n_local == ws->n && A->dtype == ws->dtype, KS_ERR_DIMENSION, "operator / workspace mismatch");
+    ks::Params prm{p->nev, p->which, p->tol, p->mindim, p->maxdim, p->restarts, p->start_from, p->initialize};
+    std::string msg;
+    if (ks::check_params(ws->n_global, ws->maxdim + 1, prm, msg)) throw KsError{KS_ERR_ARGUMENT, msg};
+    ws->ctx->use();
+    dispatch_dtype(ws->dtype, [&](auto tag) {
+      using T = decltype(tag);
+      const int ldh = ws->maxdim + 1;
+      T* Hh = static_cast<T*>(ws->H);
+      // fill!(view(H, :, start_from:end), 0)   src/run.jl:176
+      for (int j = prm.start_from - 1; j < ws->maxdim; ++j)
+        for (int i = 0; i < ldh; ++i) Hh[i + (size_t)j * ldh] = T(0);
+      ks::Mat<T> H(Hh, prm.maxdim + 1, prm.maxdim, ldh);
+      ks::Mat<T> Q(static_cast<T*>(ws->Q), prm.maxdim, prm.maxdim, ws->maxdim);
+      HipBackend<T> be(A, ws);
+      if (prm.initialize) be.reinitialize(prm.start_from - 1, prm.start_from == 1 ? static_cast<const T*>(v1_host) : nullptr);
+      std::vector<cplx> lams(prm.maxdim);
+      ks::History h = ks::partialschur_driver<T>(be, H, Q, prm, prm.start_from - 1, lams.data());
+      KS_HIP(hipStreamSynchronize(ws->ctx->stream));
+      if (eigenvalues_c64)
+        for (int i = 0; i < h.nconverged; ++i) {
+          eigenvalues_c64[2 * i] = lams[i].real();
+          eigenvalues_c64[2 * i + 1] = lams[i].imag();
+        }
+      if (history) {
+        history->mvproducts = h.mvproducts;
+        history->nconverged = h.nconverged;
+        history->converged = h.converged;
+        history->nev = h.nev;
+        history->restarts = h.restarts;
+        history->reorth = h.reorth;
+        history->breakdowns = h.breakdowns;
+        history->reserved = 0;
+        history->seconds_expand = h.seconds_expand;
+        history->seconds_host = h.seconds_host;
+        history->seconds_rotate = h.seconds_rotate;
+      }
+    });
+  });
+}
+
+// ---- on-device residual checks -------------------------------------------------------------------------
+int ks_residual_norms(ks_operator* A, ks_workspace* ws, int ncols, double* resid, double* orth) {
+  return guarded([&] {
+    KS_REQUIRE(A && ws && resid && orth, KS_ERR_ARGUMENT, "null argument");
+    KS_REQUIRE(ncols >= 0 && ncols <= ws->maxdim, KS_ERR_ARGUMENT, "bad ncols");
+    ws->ctx->use();
+    *resid = 0.0;
+    *orth = 0.0;
+    if (ncols == 0) return;
+    dispatch_dtype(ws->dtype, [&](auto tag) {
+      using T = decltype(tag);
+      relation_norms<T>(A, ws, ncols, ncols, static_cast<const T*>(ws->H), ws->maxdim + 1, resid, orth);
+    });
+  });
+}
+
+int ks_arnoldi_relation(ks_operator* A, ks_workspace* ws, int k, double* resid, double* orth) {
+  return guarded([&] {
+    KS_REQUIRE(A && ws && resid && orth, KS_ERR_ARGUMENT, "null argument");
+    KS_REQUIRE(k >= 1 && k <= ws->maxdim, KS_ERR_ARGUMENT, "bad k");
+    ws->ctx->use();
+    dispatch_dtype(ws->dtype, [&](auto tag) {
+      using T = decltype(tag);
+      relation_norms<T>(A, ws, k, k + 1, static_cast<const T*>(ws->H), ws->maxdim + 1, resid, orth);
+    });
+  });
+}
+
+// ---- host small dense exports (no device needed) ----------------------------------------------------------
+int ks_host_schurfact(int dtype, void* H, int m, int n, int ldh, int start, int to, void* Q, int nq, int ldq) {
+  return guarded([&] {
+    KS_REQUIRE(H, KS_ERR_ARGUMENT, "null H");
+    dispatch_dtype(dtype, [&](auto tag) {
+      using T = decltype(tag);
+      ks::Mat<T> Hm(static_cast<T*>(H), m, n, ldh), Qm(static_cast<T*>(Q), nq, nq, ldq);
+      const bool ok = ks::local_schurfact(Hm, start, to, Qm);
+      if (!ok) throw KsError{KS_ERR_QR, "QR algorithm did not converge"};
+    });
+  });
+}
+
+int ks_host_restart_step(int dtype, void* H, int ldh, void* Q, int ldq, int maxdim, int mindim, int nev, int which,
+                         double tol, int active, int* k, int* nlock, int* purge, double* lams_c64, double* rs,
+                         int32_t* groups) {
+  return guarded([&] {
+    KS_REQUIRE(H && Q, KS_ERR_ARGUMENT, "null argument");
+    dispatch_dtype(dtype, [&](auto tag) {
+      using T = decltype(tag);
+      ks::Mat<T> Hm(static_cast<T*>(H), maxdim + 1, maxdim, ldh), Qm(static_cast<T*>(Q), maxdim, maxdim, ldq);
+      ks::RestartScratch<T> sc(maxdim);
+      const ks::RestartResult r = ks::restart_host_step(Hm, Qm, maxdim, mindim, nev, ks::Ordering{which}, tol, active, sc);
+      if (k) *k = r.k;
+      if (nlock) *nlock = r.nlock;
+      if (purge) *purge = r.purge;
+      for (int i = 0; i < maxdim; ++i) {
+        if (lams_c64) { lams_c64[2 * i] = sc.lams[i].real(); lams_c64[2 * i + 1] = sc.lams[i].imag(); }
+        if (rs) rs[i] = sc.rs[i];
+        if (groups) groups[i] = sc.groups[i];
+      }
+    });
+  });
+}
+
+int ks_host_sortschur(int dtype, void* H, int m, int n, int ldh, void* Q, int nq, int ldq, int nconv, int which) {
+  return guarded([&] {
+    KS_REQUIRE(H, KS_ERR_ARGUMENT, "null H");
+    dispatch_dtype(dtype, [&](auto tag) {
+      using T = decltype(tag);
+      ks::Mat<T> Hm(static_cast<T*>(H), m, n, ldh), Qm(static_cast<T*>(Q), nq, nq, ldq);
+      ks::sortschur(Hm, Qm, nconv, ks::Ordering{which});
+    });
+  });
+}
+
+int ks_host_givens(int dtype, const double* f, const double* g, double* c, double* s, double* r) {
+  return guarded([&] {
+    if (dtype == KS_F64) {
+      ks::givens(f[0], g[0], *c, s[0], r[0]);
+      s[1] = 0.0; r[1] = 0.0;
+    } else {
+      cplx sn, rr;
+      ks::givens(cplx(f[0], f[1]), cplx(g[0], g[1]), *c, sn, rr);
+      s[0] = sn.real(); s[1] = sn.imag(); r[0] = rr.real(); r[1] = rr.imag();
+    }
+  });
+}
+
+}  // extern "C"

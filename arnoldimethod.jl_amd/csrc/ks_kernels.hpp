@@ -1,0 +1,719 @@
+// gfx950 (MI355X / CDNA4) kernels of the Krylov-Schur hot path.  Written for wave64, 256 CUs in
+// 8 XCDs, HBM3E-bound streaming: 16-byte per-lane accesses, contiguous per-workgroup row ranges,
+// deterministic two-stage reductions (no float atomics), decisions of the DGKS test taken on the
+// device so a whole expansion can be enqueued without host round trips.
+//
+// Data layout in HBM
+//   V   : column-major n x (maxdim+1), leading dimension ldv (multiple of 64 elements, so every
+//         column starts 512-byte aligned); rows n..ldv-1 of every column are ZERO (kernels stream
+//         whole 16-byte packs without tail masks and the pad contributes nothing to dots/norms).
+//   CSR : rowptr int32[n+1], colidx int32[nnz], val T[nnz]  (12 B / nnz + 4 B / row).
+//
+// Element types: double (Float64) and cd (ComplexF64, interleaved).  A "pack" is 16 bytes:
+// two consecutive rows of a real column or one row of a complex column.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ksd {
+
+struct cd {
+  double x, y;
+};
+
+constexpr int kBlock = 256;           // threads per workgroup (4 waves)
+constexpr double kEta = 0.70710678118654752440;  // sqrt(2)/2, src/expansion.jl:32,74
+
+// Per-workspace device state shared by the kernels of one expansion batch.
+struct DevState {
+  double rnorm;       // norm before the (current) projection     src/expansion.jl:81,92
+  double wnorm;       // norm after the projection                src/expansion.jl:88,96
+  double inv_norm;    // 1 / wnorm of the step just finished (consumed by k_scale)
+  int32_t reorth;     // 1 while the DGKS second pass of the current step is pending
+  int32_t breakdown;  // step index j at which orthogonalize! returned false, else -1
+  int32_t n_reorth;   // number of second passes taken in this batch
+  int32_t n_steps;    // steps completed in this batch
+  int32_t pad[2];
+};
+
+// ------------------------------------------------------------------------------------------------
+// element helpers
+// ------------------------------------------------------------------------------------------------
+template <class T> struct Pack;
+template <> struct Pack<double> {
+  using type = double2;
+  static constexpr int R = 2;  // rows per 16-byte pack
+};
+template <> struct Pack<cd> {
+  using type = cd;
+  static constexpr int R = 1;
+};
+
+__device__ __forceinline__ double2 ld_pack(const double* p) { return *reinterpret_cast<const double2*>(p); }
+__device__ __forceinline__ cd ld_pack(const cd* p) {
+  const double2 t = *reinterpret_cast<const double2*>(p);
+  return cd{t.x, t.y};
+}
+__device__ __forceinline__ void st_pack(double* p, double2 v) { *reinterpret_cast<double2*>(p) = v; }
+__device__ __forceinline__ void st_pack(cd* p, cd v) { *reinterpret_cast<double2*>(p) = make_double2(v.x, v.y); }
+
+__device__ __forceinline__ double zero_of(double) { return 0.0; }
+__device__ __forceinline__ cd zero_of(cd) { return cd{0.0, 0.0}; }
+__device__ __forceinline__ double2 zero_pack(double) { return make_double2(0.0, 0.0); }
+__device__ __forceinline__ cd zero_pack(cd) { return cd{0.0, 0.0}; }
+
+// acc += sum over the pack of conj(v) * w
+__device__ __forceinline__ void dot_acc(double& acc, double2 v, double2 w) {
+  acc = fma(v.x, w.x, acc);
+  acc = fma(v.y, w.y, acc);
+}
+__device__ __forceinline__ void dot_acc(cd& acc, cd v, cd w) {
+  acc.x = fma(v.x, w.x, fma(v.y, w.y, acc.x));
+  acc.y = fma(v.x, w.y, fma(-v.y, w.x, acc.y));
+}
+// s += v * g   (g one coefficient)
+__device__ __forceinline__ void axpy_acc(double2& s, double2 v, double g) {
+  s.x = fma(v.x, g, s.x);
+  s.y = fma(v.y, g, s.y);
+}
+__device__ __forceinline__ void axpy_acc(cd& s, cd v, cd g) {
+  s.x = fma(v.x, g.x, fma(-v.y, g.y, s.x));
+  s.y = fma(v.x, g.y, fma(v.y, g.x, s.y));
+}
+__device__ __forceinline__ double2 sub_pack(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cd sub_pack(cd a, cd b) { return cd{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ double nrm2_pack(double2 a) { return fma(a.x, a.x, a.y * a.y); }
+__device__ __forceinline__ double nrm2_pack(cd a) { return fma(a.x, a.x, a.y * a.y); }
+__device__ __forceinline__ double2 scale_pack(double2 a, double s) { return make_double2(a.x * s, a.y * s); }
+__device__ __forceinline__ cd scale_pack(cd a, double s) { return cd{a.x * s, a.y * s}; }
+
+__device__ __forceinline__ double add_(double a, double b) { return a + b; }
+__device__ __forceinline__ cd add_(cd a, cd b) { return cd{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ double mul_(double a, double b) { return a * b; }
+__device__ __forceinline__ cd mul_(cd a, cd b) { return cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return fma(a, b, c); }
+__device__ __forceinline__ cd fma_(cd a, cd b, cd c) {
+  return cd{fma(a.x, b.x, fma(-a.y, b.y, c.x)), fma(a.x, b.y, fma(a.y, b.x, c.y))};
+}
+
+// wave64 sum (all lanes end up with the total)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ cd wave_sum(cd v) { return cd{wave_sum(v.x), wave_sum(v.y)}; }
+
+// Contiguous pack range of workgroup b out of nb: [begin, end)
+__device__ __forceinline__ void block_range(int64_t npacks, int b, int nb, int64_t& begin, int64_t& end) {
+  const int64_t per = (npacks + nb - 1) / nb;
+  begin = (int64_t)b * per;
+  end = begin + per;
+  if (end > npacks) end = npacks;
+  if (begin > npacks) begin = npacks;
+}
+
+// splitmix64 finaliser: the portable counter-based RNG of SURVEY.md section 8d.
+__device__ __host__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  uint64_t z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __host__ __forceinline__ double uniform_hash(uint64_t seed, uint64_t idx) {
+  return (double)(splitmix64(seed ^ idx) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rand!(v)  (src/expansion.jl:15,21) -- pure function of (seed, global row)
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_fill_uniform(T* __restrict__ v, int64_t n, int64_t ld, uint64_t seed,
+                                                         uint64_t row_begin) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ld; i += (int64_t)gridDim.x * kBlock) {
+    if constexpr (sizeof(T) == 8) {
+      v[i] = i < n ? uniform_hash(seed, row_begin + i) : 0.0;
+    } else {
+      v[i] = i < n ? cd{uniform_hash(seed, 2 * (row_begin + i)), uniform_hash(seed, 2 * (row_begin + i) + 1)}
+                   : cd{0.0, 0.0};
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CSR SpMV  y = A x   (mul!(y, A, x), src/expansion.jl:121)
+//
+// "CSR-stream": a workgroup owns 256 consecutive rows.  Phase 1 streams the tile's column indices
+// and values with fully coalesced loads (lane p reads non-zero p), gathers x and writes the products
+// to LDS; phase 2: one thread per row sums its LDS segment and writes y coalesced.  Tiles whose
+// non-zeros do not fit the LDS buffer fall back to one-wave-per-row.  Tile -> workgroup mapping is
+// XCD-aware (each XCD's private L2 sees a contiguous range of rows, so the +-plane neighbours of the
+// 3-D stencil hit in the same L2).
+//
+// Distributed mode: column indices >= n_local address the ghost buffer `xg` (filled by the halo
+// exchange) instead of the local column.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSpmvRows = 256;
+constexpr int kSpmvCap = 3072;  // products held in LDS per tile
+
+__device__ __forceinline__ int xcd_remap(int b, int nt) {
+  const int q = nt >> 3, r = nt & 7, xcd = b & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+    k_spmv_csr(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const T* __restrict__ val,
+               const T* __restrict__ x, const T* __restrict__ xg, T* __restrict__ y, int64_t n, int ntiles,
+               const DevState* __restrict__ st) {
+  if (st && st->breakdown >= 0) return;
+  __shared__ T prod[kSpmvCap];
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int64_t r0 = (int64_t)tile * kSpmvRows;
+  const int64_t r1 = (r0 + kSpmvRows < n) ? r0 + kSpmvRows : n;
+  const int tid = threadIdx.x;
+  const int32_t p0 = rowptr[r0];
+  const int32_t p1 = rowptr[r1];
+  const int32_t cnt = p1 - p0;
+  if (cnt <= kSpmvCap) {
+#pragma unroll 4
+    for (int32_t p = tid; p < cnt; p += kBlock) {
+      const int32_t c = colidx[p0 + p];
+      const T a = val[p0 + p];
+      const T xv = (c < n) ? x[c] : xg[c - n];
+      prod[p] = mul_(a, xv);
+    }
+    __syncthreads();
+    const int64_t r = r0 + tid;
+    if (r < r1) {
+      const int32_t a = rowptr[r] - p0, b = rowptr[r + 1] - p0;
+      T s = zero_of(T{});
+      for (int32_t p = a; p < b; ++p) s = add_(s, prod[p]);
+      y[r] = s;
+    }
+  } else {
+    // long-row fallback: one wave per row, lanes stride over the row's non-zeros
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int64_t r = r0 + wave; r < r1; r += kBlock / 64) {
+      const int32_t a = rowptr[r], b = rowptr[r + 1];
+      T s = zero_of(T{});
+      for (int32_t p = a + lane; p < b; p += 64) {
+        const int32_t c = colidx[p];
+        const T xv = (c < n) ? x[c] : xg[c - n];
+        s = fma_(val[p], xv, s);
+      }
+      s = wave_sum(s);
+      if (lane == 0) y[r] = s;
+    }
+  }
+}
+
+// gather x[idx[i]] into a contiguous send buffer (halo exchange pack)
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+    k_gather(const T* __restrict__ x, const int32_t* __restrict__ idx, T* __restrict__ out, int64_t cnt,
+             const DevState* __restrict__ st) {
+  if (st && st->breakdown >= 0) return;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * kBlock)
+    out[i] = x[idx[i]];
+}
+
+// ------------------------------------------------------------------------------------------------
+// DOTS:  partial[b][c] = sum_{rows of b} conj(V[r,c]) w[r]  (c < j),  partial[b][norm_slot] = sum |w[r]|^2
+// (j = columns of this launch; > 40 columns are covered by several launches on column chunks)
+// First half of  mul!(h, Vprev', v)  + norm(v)   (src/expansion.jl:81,84 / :93).
+//
+// NC4 = ceil(j/4): accumulators live in registers with static indexing; the ragged last chunk
+// re-reads column j-1 (an L1/L2 hit) instead of branching so all loads of a pack issue back to back.
+// `pass` 1: first projection; 2: DGKS correction (skipped unless st->reorth).
+// ------------------------------------------------------------------------------------------------
+template <class T, int NC4>
+__global__ void __launch_bounds__(kBlock)
+    k_dots(const T* __restrict__ V, int64_t ldv, int j, const T* __restrict__ w, T* __restrict__ partial,
+           int pstride, int norm_slot, int pass, const DevState* __restrict__ st) {
+  if (st) {
+    if (st->breakdown >= 0) return;
+    if (pass == 2 && !st->reorth) return;
+  }
+  using P = typename Pack<T>::type;
+  constexpr int R = Pack<T>::R;
+  constexpr int NC = 4 * NC4;
+  T acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = zero_of(T{});
+  double nrm = 0.0;
+
+  int64_t pb, pe;
+  block_range(ldv / R, blockIdx.x, gridDim.x, pb, pe);
+  const int jm1 = j - 1;
+  for (int64_t p = pb + threadIdx.x; p < pe; p += kBlock) {
+    const int64_t r = p * R;
+    const P wv = ld_pack(w + r);
+    nrm += nrm2_pack(wv);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int cc = c < jm1 ? c : jm1;  // clamp: ragged tail re-reads the last real column
+      const P v = ld_pack(V + (int64_t)cc * ldv + r);
+      dot_acc(acc[c], v, wv);
+    }
+  }
+
+  __shared__ T red[kBlock / 64][NC + 1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const T s = wave_sum(acc[c]);
+    if (lane == 0) red[wave][c] = s;
+  }
+  {
+    const double s = wave_sum(nrm);
+    if (lane == 0) {
+      if constexpr (sizeof(T) == 8) red[wave][NC] = s; else red[wave][NC] = cd{s, 0.0};
+    }
+  }
+  __syncthreads();
+  // thread c < j writes column c of this chunk; thread j writes |w|^2 into `norm_slot` (if any)
+  for (int c = threadIdx.x; c <= j; c += kBlock) {
+    const int src = c < j ? c : NC;
+    if (c == j && norm_slot < 0) continue;
+    T s = red[0][src];
+#pragma unroll
+    for (int wv = 1; wv < kBlock / 64; ++wv) s = add_(s, red[wv][src]);
+    partial[(int64_t)blockIdx.x * pstride + (c < j ? c : norm_slot)] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FIN_DOTS (one workgroup): h = sum_b partial[b][0..j];  mode 0: reduce + post (single GPU);
+// mode 1: reduce only -> red (then RCCL all-reduce);  mode 2: post only from red.
+// post: pass 1: H[0:j, j-1] = h, coef = h, rnorm = sqrt(h[j])     (src/expansion.jl:81,84)
+//       pass 2: H[0:j, j-1] += h, coef = h                        (src/expansion.jl:93,95)
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+    k_fin_dots(const T* __restrict__ partial, int nb, int pstride, int j, T* __restrict__ red, T* __restrict__ Hcol,
+               T* __restrict__ coef, int pass, int mode, DevState* __restrict__ st) {
+  if (st->breakdown >= 0) return;
+  if (pass == 2 && !st->reorth) return;
+  __shared__ T sm[kBlock];
+  const int tid = threadIdx.x;
+  const int cnt = j + 1;
+  for (int c0 = 0; c0 < cnt; c0 += 64) {
+    const int c = c0 + (tid & 63);
+    T s = zero_of(T{});
+    if (mode != 2) {
+      if (c < cnt)
+        for (int b = tid >> 6; b < nb; b += kBlock / 64) s = add_(s, partial[(int64_t)b * pstride + c]);
+      sm[tid] = s;
+      __syncthreads();
+      if (tid < 64) {
+        s = add_(add_(sm[tid], sm[tid + 64]), add_(sm[tid + 128], sm[tid + 192]));
+        if (c < cnt && mode == 1) red[c] = s;
+      }
+      __syncthreads();
+    } else if (tid < 64 && c < cnt) {
+      s = red[c];
+    }
+    if (mode != 1 && tid < 64 && c < cnt) {
+      if (c < j) {
+        coef[c] = s;
+        Hcol[c] = (pass == 1) ? s : add_(Hcol[c], s);
+      } else if (pass == 1) {
+        double v;
+        if constexpr (sizeof(T) == 8) v = s; else v = s.x;
+        st->rnorm = sqrt(v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// AXPY:  w -= V[:, 0:j) coef;  partial2[b] = sum |w|^2      (mul!(v, Vprev, h, -1, 1) + norm(v),
+// src/expansion.jl:85,88 / :94,96)
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+    k_axpy(const T* __restrict__ V, int64_t ldv, int j, T* __restrict__ w, const T* __restrict__ coef,
+           double* __restrict__ partial2, int pass, const DevState* __restrict__ st) {
+  if (st) {
+    if (st->breakdown >= 0) return;
+    if (pass == 2 && !st->reorth) return;
+  }
+  using P = typename Pack<T>::type;
+  constexpr int R = Pack<T>::R;
+  __shared__ T g[128];
+  __shared__ double red[kBlock / 64];
+  // coefficients padded with zeros to a multiple of 8 (ragged tail multiplies a re-read column by 0)
+  int64_t pb, pe;
+  block_range(ldv / R, blockIdx.x, gridDim.x, pb, pe);
+  double nrm = 0.0;
+  const int jm1 = j - 1;
+  for (int jb = 0; jb < j; jb += 128) {  // chunks of <= 128 columns (maxdim > 128 loops)
+    const int jc = (j - jb) < 128 ? (j - jb) : 128;
+    __syncthreads();
+    if (threadIdx.x < 128) g[threadIdx.x] = threadIdx.x < jc ? coef[jb + threadIdx.x] : zero_of(T{});
+    __syncthreads();
+    const bool last = jb + 128 >= j;
+    for (int64_t p = pb + threadIdx.x; p < pe; p += kBlock) {
+      const int64_t r = p * R;
+      P s = zero_pack(T{});
+      for (int c0 = 0; c0 < jc; c0 += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int c = c0 + u;
+          const int cc = (jb + c) < jm1 ? (jb + c) : jm1;
+          const P v = ld_pack(V + (int64_t)cc * ldv + r);
+          axpy_acc(s, v, g[c]);
+        }
+      }
+      P wv = ld_pack(w + r);
+      wv = sub_pack(wv, s);
+      st_pack(w + r, wv);
+      if (last) nrm += nrm2_pack(wv);
+    }
+  }
+  const double s = wave_sum(nrm);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial2[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ------------------------------------------------------------------------------------------------
+// FIN_NORM (one workgroup): wnorm = sqrt(sum_b partial2[b]) and the DGKS decisions
+// (src/expansion.jl:88-108).  mode as in k_fin_dots (red[0] carries the all-reduced sum).
+//   pass 1:  wnorm <  eta*rnorm -> request second pass (rnorm <- wnorm), else finalize
+//   pass 2:  (only if requested) finalize
+//   finalize: wnorm <= eta*rnorm -> H[j,j-1] = 0, breakdown = j;  else H[j,j-1] = wnorm, inv = 1/wnorm
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+    k_fin_norm(const double* __restrict__ partial2, int nb, double* __restrict__ red, T* __restrict__ Hsub, int j,
+               int pass, int mode, DevState* __restrict__ st) {
+  if (st->breakdown >= 0) return;
+  if (pass == 2 && !st->reorth) return;
+  __shared__ double sm[kBlock];
+  const int tid = threadIdx.x;
+  double s = 0.0;
+  if (mode != 2) {
+    for (int b = tid; b < nb; b += kBlock) s += partial2[b];
+    sm[tid] = s;
+    __syncthreads();
+    for (int off = kBlock / 2; off >= 1; off >>= 1) {
+      if (tid < off) sm[tid] += sm[tid + off];
+      __syncthreads();
+    }
+    s = sm[0];
+    if (mode == 1) {
+      if (tid == 0) red[0] = s;
+      return;
+    }
+  } else {
+    s = red[0];
+  }
+  if (tid != 0) return;
+  const double wnorm = sqrt(s);
+  st->wnorm = wnorm;
+  if (pass == 1) {
+    if (wnorm < kEta * st->rnorm) {  // src/expansion.jl:91
+      st->reorth = 1;
+      st->rnorm = wnorm;             // :92
+      st->n_reorth += 1;
+      return;
+    }
+    st->reorth = 0;
+  } else {
+    st->reorth = 0;
+  }
+  if (wnorm <= kEta * st->rnorm) {   // :99
+    if constexpr (sizeof(T) == 8) *Hsub = 0.0; else *Hsub = cd{0.0, 0.0};
+    st->breakdown = j;
+    st->inv_norm = 0.0;
+  } else {
+    if constexpr (sizeof(T) == 8) *Hsub = wnorm; else *Hsub = cd{wnorm, 0.0};
+    st->inv_norm = 1.0 / wnorm;      // :106  v ./= wnorm
+    st->n_steps += 1;
+  }
+}
+
+// v *= st->inv_norm  (v ./= wnorm, src/expansion.jl:106) -- or by an immediate factor when st == null
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+    k_scale(T* __restrict__ v, int64_t ld, double factor, const DevState* __restrict__ st) {
+  using P = typename Pack<T>::type;
+  constexpr int R = Pack<T>::R;
+  double f = factor;
+  if (st) {
+    if (st->breakdown >= 0) return;
+    f = st->inv_norm;
+  }
+  int64_t pb, pe;
+  block_range(ld / R, blockIdx.x, gridDim.x, pb, pe);
+  for (int64_t p = pb + threadIdx.x; p < pe; p += kBlock) {
+    const int64_t r = p * R;
+    st_pack(v + r, scale_pack(ld_pack(v + r), f));
+  }
+}
+
+// partial2[b] = sum |v|^2   (norm(v))
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_norm2(const T* __restrict__ v, int64_t ld, double* __restrict__ partial2) {
+  constexpr int R = Pack<T>::R;
+  __shared__ double red[kBlock / 64];
+  int64_t pb, pe;
+  block_range(ld / R, blockIdx.x, gridDim.x, pb, pe);
+  double nrm = 0.0;
+  for (int64_t p = pb + threadIdx.x; p < pe; p += kBlock) nrm += nrm2_pack(ld_pack(v + p * R));
+  const double s = wave_sum(nrm);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial2[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// out[0] = sum_b partial2[b]   (plain reduction used by the synchronous verbs)
+__global__ void __launch_bounds__(kBlock) k_sum(const double* __restrict__ partial2, int nb, double* __restrict__ out) {
+  __shared__ double sm[kBlock];
+  const int tid = threadIdx.x;
+  double s = 0.0;
+  for (int b = tid; b < nb; b += kBlock) s += partial2[b];
+  sm[tid] = s;
+  __syncthreads();
+  for (int off = kBlock / 2; off >= 1; off >>= 1) {
+    if (tid < off) sm[tid] += sm[tid + off];
+    __syncthreads();
+  }
+  if (tid == 0) out[0] = sm[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic tall-skinny product (fallback + checker for the MFMA kernel, and the complex path):
+//   OUT[:, 0:r) = V[:, 0:c) * Qd[0:c, 0:r)     Qd device, column-major ldq.
+// In place (OUT == V) is allowed when c <= CT: every thread first reads its whole row slice.
+// ------------------------------------------------------------------------------------------------
+template <class T, int CT>
+__global__ void __launch_bounds__(kBlock)
+    k_rotate_valu(const T* __restrict__ Vin, int64_t ldv, int c, int r, const T* __restrict__ Qd, int ldq,
+                  T* __restrict__ Vout, int64_t ldo) {
+  using P = typename Pack<T>::type;
+  constexpr int R = Pack<T>::R;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* qs = reinterpret_cast<T*>(smem_raw);  // c x r, column-major, ld = c
+  for (int i = threadIdx.x; i < c * r; i += kBlock) qs[i] = Qd[(i % c) + (int64_t)(i / c) * ldq];
+  __syncthreads();
+  int64_t pb, pe;
+  block_range(ldv / R, blockIdx.x, gridDim.x, pb, pe);
+  for (int64_t p = pb + threadIdx.x; p < pe; p += kBlock) {
+    const int64_t row = p * R;
+    P in[CT];
+#pragma unroll
+    for (int cc = 0; cc < CT; ++cc) {
+      const int c2 = cc < c ? cc : c - 1;
+      in[cc] = ld_pack(Vin + (int64_t)c2 * ldv + row);
+    }
+    for (int rr = 0; rr < r; ++rr) {
+      P s = zero_pack(T{});
+#pragma unroll
+      for (int cc = 0; cc < CT; ++cc) {
+        if (cc < c) axpy_acc(s, in[cc], qs[cc + rr * c]);
+      }
+      st_pack(Vout + (int64_t)rr * ldo + row, s);
+    }
+  }
+}
+
+// Out-of-place general product for shapes the in-place kernels do not cover (c > 64) and for
+// real-basis x complex-coefficient products (partialeigen, src/eigvals.jl:94):
+//   OUT[:, rr] = sum_cc V[:, cc] * Y[cc, rr],  TV basis type, TY coefficient/result type.
+template <class TV, class TY>
+__global__ void __launch_bounds__(kBlock)
+    k_gemm_tall(const TV* __restrict__ V, int64_t ldv, int64_t n, int c, int r, const TY* __restrict__ Y, int ldy,
+                TY* __restrict__ out, int64_t ldo) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  TY* ys = reinterpret_cast<TY*>(smem_raw);
+  for (int i = threadIdx.x; i < c * r; i += kBlock) ys[i] = Y[(i % c) + (int64_t)(i / c) * ldy];
+  __syncthreads();
+  for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < n; row += (int64_t)gridDim.x * kBlock) {
+    for (int r0 = 0; r0 < r; r0 += 8) {
+      TY acc[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] = zero_of(TY{});
+      for (int cc = 0; cc < c; ++cc) {
+        const TV v = V[(int64_t)cc * ldv + row];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (r0 + u < r) {
+            const TY y = ys[cc + (r0 + u) * c];
+            if constexpr (sizeof(TV) == 8 && sizeof(TY) == 16) {
+              acc[u].x = fma(v, y.x, acc[u].x);
+              acc[u].y = fma(v, y.y, acc[u].y);
+            } else {
+              acc[u] = fma_(v, y, acc[u]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (r0 + u < r) out[(int64_t)(r0 + u) * ldo + row] = acc[u];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA restart rotation (Float64):  V[:, 0:r) <- V[:, 0:c) * Q[0:c, 0:r)  IN PLACE.
+// (mul!(V_tmp, V, Q) + copyto!(V, V_tmp), src/run.jl:363-364, :382-383 -- the one dense contraction.)
+//
+// v_mfma_f64_16x16x4_f64 computes D(16x16) = A(16x4) B(4x16) + C.  We compute the TRANSPOSE of the
+// output tile so that both the loads of V and the stores of the result are 16-byte per lane and
+// 256-byte contiguous per 16-lane group:
+//     D^T[i][jn] = sum_k  Q[k][n0+i] * V[row0+jn][k]
+//   A operand: lane l holds Q[kb + (l>>4)][n0 + (l&15)]            (from LDS)
+//   B operand: lane l holds V[row0 + rowsel(l&15)][kb + (l>>4)]     (one double2 load = 2 row tiles)
+//   D:         lane l, reg v holds out[row0 + rowsel(l&15)][n0 + (l>>4) + 4v]
+// A wave owns 32 consecutive rows: row tile 0 = even rows, row tile 1 = odd rows, so lane l's
+// double2 at rows (2*(l&15), 2*(l&15)+1) feeds both tiles and the results pair up again into one
+// double2 store.  Every output row depends only on the same input row, and a wave reads all its
+// c <= 4*KC input columns into registers before storing anything, so the update is in place and the
+// reference's V_tmp + copy-back (2 extra passes over n x r) disappear.
+// ------------------------------------------------------------------------------------------------
+typedef double double4v __attribute__((ext_vector_type(4)));
+
+template <int KC>
+__global__ void __launch_bounds__(kBlock)
+    k_rotate_mfma(double* __restrict__ V, int64_t ldv, int c, int r, const double* __restrict__ Qd, int ldq) {
+  // Q^T tile in LDS: qs[k][n] with k < 4*KC (zero padded), n < NTmax*16 (zero padded); stride 4*KC+... keep simple
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* qs = reinterpret_cast<double*>(smem_raw);  // [ncol16][4*KC] : qs[n * KP + k]
+  constexpr int KP = 4 * KC + 1;                     // +1 pad: lanes of a 16-group read stride-KP -> conflict free
+  const int ntile = (r + 15) >> 4;
+  const int ncol = ntile * 16;
+  for (int i = threadIdx.x; i < ncol * 4 * KC; i += kBlock) {
+    const int k = i % (4 * KC), n = i / (4 * KC);
+    qs[n * KP + k] = (k < c && n < r) ? Qd[k + (int64_t)n * ldq] : 0.0;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int64_t nwt = ldv / 32;  // 32-row wave tiles (ldv is a multiple of 64)
+  for (int64_t wt = (int64_t)blockIdx.x * (kBlock / 64) + wave; wt < nwt; wt += (int64_t)gridDim.x * (kBlock / 64)) {
+    const int64_t row = wt * 32 + 2 * l15;
+    double2 b[KC];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      const int col = 4 * kc + l4;
+      const int c2 = col < c ? col : c - 1;  // padded k rows of Q are zero, value irrelevant
+      b[kc] = *reinterpret_cast<const double2*>(V + (int64_t)c2 * ldv + row);
+    }
+    for (int nt = 0; nt < ntile; ++nt) {
+      double4v acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+      const double* qrow = qs + (nt * 16 + l15) * KP + l4;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const double a = qrow[4 * kc];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[kc].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[kc].y, acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int col = nt * 16 + l4 + 4 * v;
+        if (col < r) *reinterpret_cast<double2*>(V + (int64_t)col * ldv + row) = make_double2(acc0[v], acc1[v]);
+      }
+    }
+  }
+}
+
+// Gram / cross-Gram for the on-device residual checks:
+//   partial[b][i + j*nc] = sum_rows conj(A[r,i]) * B[r,j]     (i < nc_a, j < nc_b, both <= 8 wide tiles)
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+    k_gram_tile(const T* __restrict__ A, int64_t lda, int na, const T* __restrict__ B, int64_t ldb, int nbcols,
+                int64_t n, T* __restrict__ partial) {
+  T acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = zero_of(T{});
+  for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < n; row += (int64_t)gridDim.x * kBlock) {
+    T a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = i < na ? A[(int64_t)i * lda + row] : zero_of(T{});
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = j < nbcols ? B[(int64_t)j * ldb + row] : zero_of(T{});
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if constexpr (sizeof(T) == 8) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+        else {
+          acc[i][j].x = fma(a[i].x, b[j].x, fma(a[i].y, b[j].y, acc[i][j].x));
+          acc[i][j].y = fma(a[i].x, b[j].y, fma(-a[i].y, b[j].x, acc[i][j].y));
+        }
+      }
+  }
+  __shared__ T red[kBlock / 64][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const T s = wave_sum(acc[i][j]);
+      if (lane == 0) red[wave][i + 8 * j] = s;
+    }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    T s = red[0][threadIdx.x];
+    for (int wv = 1; wv < kBlock / 64; ++wv) s = add_(s, red[wv][threadIdx.x]);
+    partial[(int64_t)blockIdx.x * 64 + threadIdx.x] = s;
+  }
+}
+
+// out[c] = sum_b partial[b*stride + c], c < cnt  (one workgroup)
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+    k_reduce_cols(const T* __restrict__ partial, int nb, int stride, int cnt, T* __restrict__ out) {
+  __shared__ T sm[kBlock];
+  const int tid = threadIdx.x;
+  for (int c0 = 0; c0 < cnt; c0 += 64) {
+    const int c = c0 + (tid & 63);
+    T s = zero_of(T{});
+    if (c < cnt)
+      for (int b = tid >> 6; b < nb; b += kBlock / 64) s = add_(s, partial[(int64_t)b * stride + c]);
+    sm[tid] = s;
+    __syncthreads();
+    if (tid < 64 && c < cnt) out[c] = add_(add_(sm[tid], sm[tid + 64]), add_(sm[tid + 128], sm[tid + 192]));
+    __syncthreads();
+  }
+}
+
+// y = x (column copy), pads included
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_copy(const T* __restrict__ x, T* __restrict__ y, int64_t ld) {
+  constexpr int R = Pack<T>::R;
+  int64_t pb, pe;
+  block_range(ld / R, blockIdx.x, gridDim.x, pb, pe);
+  for (int64_t p = pb + threadIdx.x; p < pe; p += kBlock) st_pack(y + p * R, ld_pack(x + p * R));
+}
+
+// w = A*x - (combination) helpers for the residual checks:  y -= sum_c X[:,c] * coef[c]
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+    k_sub_lincomb(T* __restrict__ y, const T* __restrict__ X, int64_t ldx, int nc, const T* __restrict__ coef,
+                  int64_t n) {
+  for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < n; row += (int64_t)gridDim.x * kBlock) {
+    T s = y[row];
+    for (int c = 0; c < nc; ++c) {
+      const T g = coef[c];
+      const T v = X[(int64_t)c * ldx + row];
+      if constexpr (sizeof(T) == 8) s = fma(-v, g, s);
+      else {
+        s.x -= v.x * g.x - v.y * g.y;
+        s.y -= v.x * g.y + v.y * g.x;
+      }
+    }
+    y[row] = s;
+  }
+}
+
+}  // namespace ksd

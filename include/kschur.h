@@ -1,0 +1,245 @@
+/*
+ * kschur.h -- C ABI of libkschur_hip.so: the MI355X (gfx950) implementation of the
+ * Krylov-Schur Arnoldi hot path of ArnoldiMethod.jl.
+ *
+ * This header is the drop-in boundary.  Every entry point names the reference
+ * interface it replaces as  <file>:<line>  relative to the reference tree
+ * (JuliaLinearAlgebra/ArnoldiMethod.jl v0.4.0).  The Julia-side binding a maintainer
+ * would add is shown in INTEGRATION.md (one `ccall` per function below).
+ *
+ * Conventions
+ *   - plain C: opaque handles, plain pointers and sizes, no C++/torch types;
+ *   - every function returns an int status (KS_OK == 0); no exceptions cross the ABI;
+ *     ks_last_error_string() describes the last failure on the calling thread;
+ *   - matrices are COLUMN-MAJOR like Julia's `Matrix`; indices in THIS header are 0-based
+ *     (column j here is column j+1 of the reference);
+ *   - dtype: KS_F64 = Float64, KS_C64 = ComplexF64 (interleaved re,im); host pointers typed
+ *     `void*` point at elements of the handle's dtype;
+ *   - host pointers are borrowed for the duration of a call only (GC.@preserve suffices);
+ *   - one host thread drives one context; calls are stream-ordered on the device and
+ *     synchronous with respect to any host value they return;
+ *   - multi-GPU: one process per GPU, rows of A and V are block-partitioned across ranks,
+ *     the global sums inside the Gram-Schmidt steps are RCCL all-reduces, H/Q stay
+ *     replicated on every host.
+ */
+#ifndef KSCHUR_H
+#define KSCHUR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KS_VERSION_MAJOR 0
+#define KS_VERSION_MINOR 1
+
+/* ---- status codes -------------------------------------------------------------------- */
+enum {
+  KS_OK = 0,
+  KS_ERR_ARGUMENT = 1,  /* Julia ArgumentError     (src/run.jl:111-116,123-124,165-174,185) */
+  KS_ERR_DIMENSION = 2, /* Julia DimensionMismatch (checksquare, src/run.jl:110)            */
+  KS_ERR_HIP = 3,       /* HIP runtime failure                                              */
+  KS_ERR_RCCL = 4,      /* RCCL failure                                                     */
+  KS_ERR_QR = 5,        /* "QR algorithm did not converge" (src/schurfact.jl:406)           */
+  KS_ERR_INTERNAL = 6,
+  KS_ERR_NO_DEVICE = 7, /* no gfx950 device visible: the product path has NO CPU fallback   */
+  KS_ERR_OPERATOR = 8   /* user operator callback reported failure                          */
+};
+
+enum { KS_F64 = 0, KS_C64 = 1 };                 /* element type of A, V, H, Q              */
+enum { KS_I32 = 0, KS_I64 = 1 };                 /* index type of an uploaded sparse matrix */
+enum { KS_CSR = 0, KS_CSC = 1 };                 /* layout of an uploaded sparse matrix     */
+/* Targets, src/targets.jl:7-32 and _symbol_to_target, src/run.jl:181-185 */
+enum { KS_LM = 0, KS_LR = 1, KS_SR = 2, KS_LI = 3, KS_SI = 4 };
+
+typedef struct ks_ctx ks_ctx;             /* device + stream (+ RCCL communicator)           */
+typedef struct ks_operator ks_operator;   /* anything with mul!(y, A, x)  (src/run.jl:21-22) */
+typedef struct ks_workspace ks_workspace; /* ArnoldiWorkspace (src/ArnoldiMethod.jl:41-93)   */
+
+const char* ks_last_error_string(void);
+int ks_version(int* major, int* minor);
+
+/* ---- context ------------------------------------------------------------------------- */
+/* Single-GPU context on HIP device `device`. */
+int ks_ctx_create(int device, ks_ctx** out);
+/* Multi-GPU context: rank `rank` of `nranks`, one process per GPU.  `unique_id` is the 128-byte
+ * RCCL id produced by ks_comm_unique_id() on rank 0 and broadcast by the host language
+ * (torch.distributed / MPI / Distributed.jl).  No reference equivalent: the reference is a
+ * single process. */
+int ks_comm_unique_id(void* out128);
+int ks_ctx_create_dist(int device, int rank, int nranks, const void* unique_id128, ks_ctx** out);
+int ks_ctx_destroy(ks_ctx* ctx);
+int ks_ctx_synchronize(ks_ctx* ctx);
+int ks_ctx_rank(const ks_ctx* ctx, int* rank, int* nranks);
+/* Raw hipStream_t of the context (so a caller can time with hipEvents on the right stream). */
+int ks_ctx_stream(ks_ctx* ctx, void** hip_stream);
+
+/* ---- operator seam:  mul!(y, A, x), eltype(A), size(A)   (src/expansion.jl:121) ------- */
+/* (i) device-resident CSR operand.  Accepts CSR or CSC (Julia's SparseMatrixCSC: colptr /
+ * rowval / nzval, 1-based Int64 -> layout=KS_CSC, index_base=1, index_type=KS_I64) and
+ * converts once to int32 0-based CSR in HBM.  `nrows_local` x `ncols` is this rank's row block
+ * (single GPU: the whole square matrix).  Replaces SparseArrays' `mul!` for
+ * `SparseMatrixCSC` (stdlib; call site src/expansion.jl:121). */
+int ks_operator_csr(ks_ctx* ctx, int64_t nrows_local, int64_t ncols, int64_t nnz,
+                    const void* ptr, const void* idx, const void* val, int layout, int index_base,
+                    int index_type, int dtype, ks_operator** out);
+/* Distributed CSR: this rank owns global rows [row_begin, row_begin+nrows_local); column indices
+ * are already LOCAL-EXTENDED: 0..nrows_local-1 address owned entries of x, nrows_local+g
+ * addresses ghost slot g.  Ghost slots are filled before every product by the halo plan:
+ * for each neighbour p: send x[send_idx[send_ptr[p] .. send_ptr[p+1])] to rank neigh[p] and
+ * receive recv_cnt[p] values into consecutive ghost slots (in neighbour order). */
+int ks_operator_csr_dist(ks_ctx* ctx, int64_t nrows_local, int64_t nghost, int64_t nnz,
+                         const int64_t* rowptr, const int32_t* colidx, const void* val, int dtype,
+                         int nneigh, const int32_t* neigh, const int64_t* send_ptr,
+                         const int32_t* send_idx, const int64_t* recv_cnt, ks_operator** out);
+/* (ii) opaque host operator (e.g. a LinearMap wrapping ldiv! with a host LU,
+ * docs/src/index.md:246-249): `apply(user, x_host, y_host)` computes y = A*x on n_local
+ * elements of `dtype`; return nonzero to signal failure.  The library stages the two columns
+ * over PCIe. */
+typedef int (*ks_host_apply_fn)(void* user, const void* x_host, void* y_host);
+int ks_operator_host_callback(ks_ctx* ctx, int64_t n_local, int dtype, ks_host_apply_fn apply,
+                              void* user, ks_operator** out);
+/* (iii) opaque device operator: `apply(user, x_dev, y_dev, hip_stream)` must enqueue y = A*x on
+ * the given stream (x_dev/y_dev are device pointers to n_local elements). */
+typedef int (*ks_device_apply_fn)(void* user, const void* x_dev, void* y_dev, void* hip_stream);
+int ks_operator_device_callback(ks_ctx* ctx, int64_t n_local, int dtype, ks_device_apply_fn apply,
+                                void* user, ks_operator** out);
+int ks_operator_destroy(ks_operator* op);
+int ks_operator_size(const ks_operator* op, int64_t* n_local, int64_t* nnz, int* dtype);
+/* y = A*x on raw device pointers (bench / tests; the solver uses ks_apply below). */
+int ks_operator_apply_raw(ks_operator* op, const void* x_dev, void* y_dev);
+
+/* ---- workspace: ArnoldiWorkspace{T}(V, H, V_tmp, Q)  (src/ArnoldiMethod.jl:41-93) ------ */
+/* V: n_local x (maxdim+1) in HBM (column-major, leading dimension padded, pad rows zero);
+ * H: (maxdim+1) x maxdim on the host, zero-initialised (src/ArnoldiMethod.jl:66,76);
+ * Q: maxdim x maxdim on the host.  V_tmp of the reference is not materialised: the restart
+ * rotation runs in place (scratch is allocated only for shapes the in-place kernel does not
+ * cover).  `n_global` is the order of A (== n_local on one GPU); `row_begin` this rank's
+ * first global row (feeds the counter-based RNG so random vectors are partition-independent). */
+int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t row_begin,
+                        int maxdim, int dtype, ks_workspace** out);
+int ks_workspace_destroy(ks_workspace* ws);
+int ks_workspace_dims(const ks_workspace* ws, int64_t* n_local, int* maxdim, int* dtype, int64_t* ldv);
+/* Host arrays (valid until the workspace is destroyed); ldh = maxdim+1, ldq = maxdim. */
+int ks_workspace_H(ks_workspace* ws, void** H, int* ldh);
+int ks_workspace_Q(ks_workspace* ws, void** Q, int* ldq);
+/* Device pointer of column j of V (for device-side consumers; PartialSchur.Q is a view of V,
+ * src/run.jl:375,389). */
+int ks_workspace_col_ptr(ks_workspace* ws, int j, void** dev_ptr);
+int ks_workspace_set_seed(ks_workspace* ws, uint64_t seed);
+
+/* ---- the verbs the reference applies to V (array-type seam) ------ */
+/* copyto!(view(V,:,j+1), v1)   src/run.jl:126   (n_local elements from host) */
+int ks_col_upload(ks_workspace* ws, int j, const void* host);
+/* Array(view(V,:,j+1))   (result views, src/run.jl:375,389; eigvals.jl:94) */
+int ks_col_download(ks_workspace* ws, int j, void* host);
+/* V[:, j0:j0+ncols) -> host matrix with leading dimension ldhost */
+int ks_cols_download(ks_workspace* ws, int j0, int ncols, void* host, int64_t ldhost);
+int ks_cols_upload(ks_workspace* ws, int j0, int ncols, const void* host, int64_t ldhost);
+/* rand!(view(V,:,j+1))   src/expansion.jl:15,21  -- counter-based uniform [0,1) */
+int ks_col_fill_uniform(ks_workspace* ws, int j, uint64_t seed);
+/* norm(view(V,:,j+1))   src/expansion.jl:24,41,48,81,88,96  (global 2-norm) */
+int ks_col_norm(ks_workspace* ws, int j, double* out);
+/* v ./= s   src/expansion.jl:28,56,106 */
+int ks_col_div(ks_workspace* ws, int j, double s);
+/* copyto!(view(V,:,dst+1), view(V,:,src+1))   src/run.jl:365 */
+int ks_col_copy(ks_workspace* ws, int dst, int src);
+/* mul!(view(V,:,jdst+1), A, view(V,:,jsrc+1))   src/expansion.jl:121 */
+int ks_apply(ks_operator* A, ks_workspace* ws, int jsrc, int jdst);
+/* mul!(h, view(V,:,1:j)', view(V,:,jv+1))   src/expansion.jl:37,46,84,93   (h: j host values) */
+int ks_gemv_t(ks_workspace* ws, int j, int jv, void* h_host);
+/* mul!(view(V,:,jv+1), view(V,:,1:j), h, -1, 1)   src/expansion.jl:38,47,85,94 */
+int ks_gemv_n_sub(ks_workspace* ws, int j, int jv, const void* h_host);
+/* V[:, c0:c0+r) <- V[:, c0:c0+c) * Q[0:c, 0:r)  with Q a HOST matrix, leading dimension ldq
+ * (mul! into V_tmp + copyto! back, src/run.jl:363-364 and :382-383, done in place). */
+int ks_rotate(ks_workspace* ws, int c0, int c, int r, const void* Q_host, int ldq);
+/* out(n_local x r, host or device scratch) = V[:, 0:c) * Y[0:c, 0:r), Y complex or real host
+ * matrix: the tall-skinny product of partialeigen (P.Q * vecs, src/eigvals.jl:94).  Output is
+ * written to host memory `out_host` with leading dimension ldout, dtype `ydtype`. */
+int ks_basis_times(ks_workspace* ws, int c, int r, const void* Y_host, int ldy, int ydtype,
+                   void* out_host, int64_t ldout);
+
+/* ---- fused hot path ---------------------------------------------------------------------- */
+/* orthogonalize!(arnoldi, j)   src/expansion.jl:69-109
+ * DGKS classical Gram-Schmidt of column j against columns 0..j-1 with all decisions taken on
+ * globally reduced norms; writes H[0:j, j-1] and H[j, j-1] into the workspace's host H.
+ * *ok = 0 on breakdown (reference returns false). */
+int ks_orthogonalize(ks_workspace* ws, int j, int* ok);
+/* reinitialize!(arnoldi, j, populate!)   src/expansion.jl:12-59
+ * v1_host == NULL -> rand!; otherwise copyto!(v, v1).  Does not touch H. */
+int ks_reinitialize(ks_workspace* ws, int j, const void* v1_host, int* ok);
+/* iterate_arnoldi!(A, arnoldi, from:to)   src/expansion.jl:116-133  (from/to as in the
+ * reference: step j builds 0-based column j from column j-1).  The whole range is enqueued
+ * asynchronously (operator apply + fused DGKS per step, decisions on-device) and the host
+ * synchronises once at the end to fetch the new columns of H. */
+typedef struct ks_expand_stats {
+  int32_t steps;       /* operator applications performed                                    */
+  int32_t reorth;      /* steps whose DGKS test requested the second pass (src/expansion.jl:91) */
+  int32_t breakdowns;  /* steps that ended in reinitialize! (src/expansion.jl:127-129)        */
+  int32_t reserved;
+} ks_expand_stats;
+int ks_iterate_arnoldi(ks_operator* A, ks_workspace* ws, int from, int to, ks_expand_stats* stats);
+
+/* ---- driver:  partialschur / partialschur!   (src/run.jl:100-179, _partialschur :224-392) - */
+typedef struct ks_params {
+  int32_t nev;        /* default min(6, n)                       src/run.jl:103 */
+  int32_t which;      /* KS_LM ...                               src/run.jl:104 */
+  double tol;         /* default sqrt(eps)                       src/run.jl:105 */
+  int32_t mindim;     /* default min(max(10, nev), n)            src/run.jl:106 */
+  int32_t maxdim;     /* default min(max(20, 2nev), n)           src/run.jl:107 */
+  int32_t restarts;   /* default 200                             src/run.jl:108 */
+  int32_t start_from; /* 1-based as in partialschur!; 1 = fresh  src/run.jl:155 */
+  int32_t initialize; /* 1: reinitialize!(arnoldi, start_from-1) src/run.jl:156,177 */
+  int32_t reserved;
+} ks_params;
+typedef struct ks_history { /* src/run.jl:217-222 (+ diagnostics) */
+  int32_t mvproducts;
+  int32_t nconverged;
+  int32_t converged;
+  int32_t nev;
+  int32_t restarts;   /* outer iterations performed */
+  int32_t reorth;     /* DGKS second passes taken   */
+  int32_t breakdowns;
+  int32_t reserved;
+  double seconds_expand; /* wall time spent waiting for the device in iterate_arnoldi  */
+  double seconds_host;   /* wall time in the host Schur / reorder / restore            */
+  double seconds_rotate; /* wall time enqueueing+waiting for rotations (mostly async)  */
+} ks_history;
+/* Fill `p` with the reference defaults for an order-n problem (src/run.jl:103-108). */
+int ks_params_default(int64_t n, ks_params* p);
+/* partialschur!(A, arnoldi; ...) on a caller-owned workspace.  `v1_host` (may be NULL) is the
+ * start vector of partialschur(A; v1) (src/run.jl:122-127), used only when initialize != 0 and
+ * start_from == 1.  On return: V[:, 0:nconverged) = Schur vectors, H[0:nconv,0:nconv) = R,
+ * eigenvalues[0:nconv) (interleaved complex doubles, src/run.jl:386-389). */
+int ks_partialschur(ks_operator* A, ks_workspace* ws, const ks_params* p, const void* v1_host,
+                    double* eigenvalues_c64, ks_history* history);
+
+/* Residual checks evaluated on the device: ||A*Q - Q*R||_F and ||Q'Q - I||_F for the first
+ * `ncols` columns with R = H[0:ncols, 0:ncols) (test/partial_schur.jl:24-25,104-105). */
+int ks_residual_norms(ks_operator* A, ks_workspace* ws, int ncols, double* resid, double* orth);
+/* Arnoldi relation check ||A V_k - V_{k+1} H_k||_F and ||V'V - I||_F (test/expansion.jl:24-31). */
+int ks_arnoldi_relation(ks_operator* A, ks_workspace* ws, int k, double* resid, double* orth);
+
+/* ---- host small dense kernels, exported for the host-logic tests (no device needed) ------ */
+/* local_schurfact!(H, start, to, Q)   src/schurfact.jl:393-538; H is m x n column-major. */
+int ks_host_schurfact(int dtype, void* H, int m, int n, int ldh, int start, int to, void* Q, int nq,
+                      int ldq);
+/* One complete restart's worth of host work on (H (maxdim+1 x maxdim), Q): Schur form of the
+ * active block, Ritz values/residuals, grouping, 3-way partition, restore_arnoldi!
+ * (src/run.jl:278-360).  In/out: active (0-based).  Out: k, nlock, purge, eigenvalues, residuals,
+ * groups. */
+int ks_host_restart_step(int dtype, void* H, int ldh, void* Q, int ldq, int maxdim, int mindim,
+                         int nev, int which, double tol, int active, int* k, int* nlock, int* purge,
+                         double* lams_c64, double* rs, int32_t* groups);
+/* sortschur!(H, Q, nconv, ordering)   src/run.jl:465-502 */
+int ks_host_sortschur(int dtype, void* H, int m, int n, int ldh, void* Q, int nq, int ldq, int nconv,
+                      int which);
+/* givensAlgorithm (Julia stdlib LinearAlgebra = LAPACK dlartg/zlartg); out: c, s(re,im), r(re,im) */
+int ks_host_givens(int dtype, const double* f, const double* g, double* c, double* s, double* r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KSCHUR_H */

@@ -289,6 +289,7 @@ def _partialschur(A, ws, mindim, maxdim, nev, tol, restarts, which, active=0, st
         prods += len(range(k + 1, maxdim + 1))  # :275
         nrestarts += 1
 
+        H_in = H.copy() if trace is not None else None
         Q[:, :] = np.eye(maxdim, dtype=dtype)  # :278
         Hm = H[:maxdim, :]
         sd.local_schurfact(Hm, active, maxdim - 1, Q)  # :281
@@ -335,6 +336,7 @@ def _partialschur(A, ws, mindim, maxdim, nev, tol, restarts, which, active=0, st
             trace.append(
                 dict(
                     iter=_it,
+                    H_in=H_in,
                     active=active,
                     k=k,
                     nlock=nlock,
