@@ -101,6 +101,10 @@ PROTOTYPES = {
     "ks_iterate_arnoldi": [vp, vp, i32, i32, P(ks_expand_stats)],
     "ks_params_default": [i64, P(ks_params)],
     "ks_partialschur": [vp, vp, P(ks_params), vp, vp, P(ks_history)],
+    "ks_restart": [vp, P(ks_params), i32, P(C.c_int), P(C.c_int), P(C.c_int), vp, vp, vp],
+    "ks_profile_enable": [vp, i32],
+    "ks_profile_reset": [vp],
+    "ks_profile_get": [vp, i32, vp, vp, vp],
     "ks_residual_norms": [vp, vp, i32, P(dbl), P(dbl)],
     "ks_arnoldi_relation": [vp, vp, i32, P(dbl), P(dbl)],
     "ks_host_schurfact": [i32, vp, i32, i32, i32, i32, i32, vp, i32, i32],

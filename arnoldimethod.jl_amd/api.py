@@ -110,6 +110,21 @@ class Context:
         check(_lib.load().ks_ctx_stream(self._h, C.byref(s)))
         return s.value or 0
 
+    # per-kernel-class HIP-event timing (bench.py)
+    PROFILE_CLASSES = ("spmv", "dots", "axpy", "scale", "rotate", "fin")
+
+    def profile_enable(self, on: bool = True):
+        check(_lib.load().ks_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        check(_lib.load().ks_profile_reset(self._h))
+
+    def profile_get(self) -> dict:
+        n = len(self.PROFILE_CLASSES)
+        ms, by, cnt = np.zeros(n), np.zeros(n), np.zeros(n, dtype=np.int64)
+        check(_lib.load().ks_profile_get(self._h, n, ms.ctypes.data, by.ctypes.data, cnt.ctypes.data))
+        return {k: dict(ms=float(ms[i]), bytes=float(by[i]), count=int(cnt[i])) for i, k in enumerate(self.PROFILE_CLASSES)}
+
     def close(self):
         if getattr(self, "_h", None):
             _lib.load().ks_ctx_destroy(self._h)
@@ -356,6 +371,20 @@ class ArnoldiWorkspace:
         st = _lib.ks_expand_stats()
         check(_lib.load().ks_iterate_arnoldi(A._h, self._h, frm, to, C.byref(st)))
         return dict(steps=st.steps, reorth=st.reorth, breakdowns=st.breakdowns)
+
+    def restart(self, active: int, nev: int, which="LM", tol=None, mindim=None, maxdim=None):
+        """One Krylov-Schur restart (src/run.jl:278-365): host Schur / grouping / restore, then the
+        basis rotation on the device.  `active` is 0-based.  Returns dict(k, nlock, purge, ...)."""
+        maxdim = self.maxdim if maxdim is None else maxdim
+        mindim = min(max(10, nev), self.n_global) if mindim is None else mindim
+        tol = math.sqrt(EPS) if tol is None else tol
+        p = _lib.ks_params(nev, _which_code(which), float(tol), mindim, maxdim, 1, 1, 0, 0)
+        k, nlock, purge = C.c_int(), C.c_int(), C.c_int()
+        lams, rs, groups = np.zeros(2 * maxdim), np.zeros(maxdim), np.zeros(maxdim, dtype=np.int32)
+        check(_lib.load().ks_restart(self._h, C.byref(p), active, C.byref(k), C.byref(nlock), C.byref(purge),
+                                     lams.ctypes.data, rs.ctypes.data, groups.ctypes.data))
+        return dict(k=k.value, nlock=nlock.value, purge=purge.value, eigenvalues=lams[0::2] + 1j * lams[1::2],
+                    residuals=rs, groups=groups)
 
     def residual_norms(self, A: Operator, ncols: int):
         r, o = C.c_double(), C.c_double()

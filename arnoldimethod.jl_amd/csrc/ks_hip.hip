@@ -90,7 +90,23 @@ inline int env_int(const char* name, int dflt) {
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
+// Optional per-kernel-class timing with HIP events recorded on the context's stream (bench.py):
+// class ids index ks_profile_* below.
+enum { KSP_SPMV = 0, KSP_DOTS = 1, KSP_AXPY = 2, KSP_SCALE = 3, KSP_ROTATE = 4, KSP_FIN = 5, KSP_NCLASS = 6 };
+
+struct ProfRecord {
+  hipEvent_t a, b;
+  int cls;
+  double bytes;
+};
+
 struct ks_ctx {
+  bool profiling = false;
+  std::vector<ProfRecord> prof_pending;
+  std::vector<hipEvent_t> prof_pool;
+  double prof_ms[KSP_NCLASS] = {0, 0, 0, 0, 0, 0};
+  double prof_bytes[KSP_NCLASS] = {0, 0, 0, 0, 0, 0};
+  int64_t prof_count[KSP_NCLASS] = {0, 0, 0, 0, 0, 0};
   int device = 0;
   hipStream_t stream = nullptr;
   int rank = 0, nranks = 1;
@@ -104,6 +120,45 @@ struct ks_ctx {
     if (nranks > 1) KS_NCCL(ncclAllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, comm, stream));
   }
 };
+
+namespace {
+// RAII scope: records an event pair around the enclosed launches when profiling is on.
+struct ProfScope {
+  ks_ctx* c;
+  ProfRecord r;
+  bool on;
+  ProfScope(ks_ctx* ctx, int cls, double bytes) : c(ctx), on(ctx->profiling) {
+    if (!on) return;
+    auto get = [&]() {
+      hipEvent_t e;
+      if (!c->prof_pool.empty()) { e = c->prof_pool.back(); c->prof_pool.pop_back(); }
+      else KS_HIP(hipEventCreate(&e));
+      return e;
+    };
+    r.a = get(); r.b = get(); r.cls = cls; r.bytes = bytes;
+    KS_HIP(hipEventRecord(r.a, c->stream));
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(r.b, c->stream);
+    c->prof_pending.push_back(r);
+  }
+};
+// fold finished event pairs into the per-class totals (call after a stream synchronize)
+void prof_collect(ks_ctx* c) {
+  for (auto& r : c->prof_pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      c->prof_ms[r.cls] += ms;
+      c->prof_bytes[r.cls] += r.bytes;
+      c->prof_count[r.cls] += 1;
+    }
+    c->prof_pool.push_back(r.a);
+    c->prof_pool.push_back(r.b);
+  }
+  c->prof_pending.clear();
+}
+}  // namespace
 
 static void ctx_init_device(ks_ctx* c, int device) {
   int ndev = 0;
@@ -172,8 +227,11 @@ template <class D> struct CsrOp : ks_operator {
       }
       KS_NCCL(ncclGroupEnd());
     }
-    if (ntiles > 0)
+    if (ntiles > 0) {
+      // algorithmic bytes: 12 nnz + 4 (n+1) + 16 n   (8 -> 16 for complex)
+      ProfScope ps(ctx, KSP_SPMV, (double)nnz * (4 + sizeof(D)) + 4.0 * (n_local + 1) + 2.0 * sizeof(D) * n_local);
       ksd::k_spmv_csr<D><<<ntiles, kBlock, 0, s>>>(rowptr, colidx, val, x, ghost, y, n_local, ntiles, st);
+    }
     KS_HIP(hipGetLastError());
   }
 };
@@ -440,13 +498,30 @@ template <class D> void enqueue_orthogonalize(ks_workspace* ws, int j) {
   const int ldh = ws->maxdim + 1;
   D* Hcol = Hd + (size_t)(j - 1) * ldh;
   const D* V = static_cast<const D*>(ws->V);
+  const double nb8 = (double)ws->n * sizeof(D);  // bytes of one column
   for (int pass = 1; pass <= 2; ++pass) {
-    const int nbd = launch_dots<D>(ws, j, w, pass, ws->st);
-    launch_fin_dots<D>(ws, nbd, j, Hcol, pass, ws->st);
-    ksd::k_axpy<D><<<ws->nb, kBlock, 0, s>>>(V, ws->ld, j, w, static_cast<const D*>(ws->coef), ws->partial2, pass, ws->st);
-    launch_fin_norm<D>(ws, j, Hcol + j, pass, ws->st);
+    int nbd;
+    {
+      ProfScope ps(ws->ctx, KSP_DOTS, nb8 * (j + 1));       // read V[:,0:j) and w
+      nbd = launch_dots<D>(ws, j, w, pass, ws->st);
+    }
+    {
+      ProfScope ps(ws->ctx, KSP_FIN, 0.0);
+      launch_fin_dots<D>(ws, nbd, j, Hcol, pass, ws->st);
+    }
+    {
+      ProfScope ps(ws->ctx, KSP_AXPY, nb8 * (j + 2));       // read V[:,0:j), read + write w
+      ksd::k_axpy<D><<<ws->nb, kBlock, 0, s>>>(V, ws->ld, j, w, static_cast<const D*>(ws->coef), ws->partial2, pass, ws->st);
+    }
+    {
+      ProfScope ps(ws->ctx, KSP_FIN, 0.0);
+      launch_fin_norm<D>(ws, j, Hcol + j, pass, ws->st);
+    }
   }
-  ksd::k_scale<D><<<ws->nb, kBlock, 0, s>>>(w, ws->ld, 0.0, ws->st);
+  {
+    ProfScope ps(ws->ctx, KSP_SCALE, nb8 * 2);
+    ksd::k_scale<D><<<ws->nb, kBlock, 0, s>>>(w, ws->ld, 0.0, ws->st);
+  }
   KS_HIP(hipGetLastError());
 }
 
@@ -458,6 +533,7 @@ inline void reset_state(ks_workspace* ws) {
 inline void fetch_state(ks_workspace* ws) {
   KS_HIP(hipMemcpyAsync(ws->st_h, ws->st, sizeof(DevState), hipMemcpyDeviceToHost, ws->ctx->stream));
   KS_HIP(hipStreamSynchronize(ws->ctx->stream));
+  if (ws->ctx->profiling) prof_collect(ws->ctx);
 }
 
 // global 2-norm of column j (synchronous)
@@ -573,6 +649,7 @@ template <class D> void rotate_device(ks_workspace* ws, int c0, int c, int r) {
   hipStream_t s = ctx->stream;
   D* Vc = static_cast<D*>(ws->col(c0));
   const D* Qd = static_cast<const D*>(ws->Qd);
+  ProfScope ps(ctx, KSP_ROTATE, (double)ws->n * sizeof(D) * (c + r));  // in place: read c, write r columns
   const bool force_valu = env_int("KS_ROTATE_VALU", 0) != 0;
   if constexpr (sizeof(D) == 8) {
     if (!force_valu && c <= 64) {
@@ -1319,6 +1396,67 @@ int ks_partialschur(ks_operator* A, ks_workspace* ws, const ks_params* p, const 
         history->seconds_rotate = h.seconds_rotate;
       }
     });
+  });
+}
+
+int ks_restart(ks_workspace* ws, const ks_params* p, int active, int* k_out, int* nlock_out, int* purge_out,
+               double* lams_c64, double* rs, int32_t* groups) {
+  return guarded([&] {
+    KS_REQUIRE(ws && p, KS_ERR_ARGUMENT, "null argument");
+    ks::Params prm{p->nev, p->which, p->tol, p->mindim, p->maxdim, p->restarts, 1, 0};
+    std::string msg;
+    if (ks::check_params(ws->n_global, ws->maxdim + 1, prm, msg)) throw KsError{KS_ERR_ARGUMENT, msg};
+    KS_REQUIRE(active >= 0 && active < prm.maxdim, KS_ERR_ARGUMENT, "active out of range");
+    ws->ctx->use();
+    dispatch_dtype(ws->dtype, [&](auto tag) {
+      using T = decltype(tag);
+      ks::Mat<T> H(static_cast<T*>(ws->H), prm.maxdim + 1, prm.maxdim, ws->maxdim + 1);
+      ks::Mat<T> Q(static_cast<T*>(ws->Q), prm.maxdim, prm.maxdim, ws->maxdim);
+      ks::RestartScratch<T> sc(prm.maxdim);
+      const ks::RestartResult r =
+          ks::restart_host_step(H, Q, prm.maxdim, prm.mindim, prm.nev, ks::Ordering{prm.which}, prm.tol, active, sc);
+      HipBackend<T> be(nullptr, ws);
+      be.rotate(r.purge, prm.maxdim - r.purge, r.k - r.purge, Q);  // src/run.jl:363-364
+      be.col_copy(r.k, prm.maxdim);                                 // src/run.jl:365
+      if (k_out) *k_out = r.k;
+      if (nlock_out) *nlock_out = r.nlock;
+      if (purge_out) *purge_out = r.purge;
+      for (int i = 0; i < prm.maxdim; ++i) {
+        if (lams_c64) { lams_c64[2 * i] = sc.lams[i].real(); lams_c64[2 * i + 1] = sc.lams[i].imag(); }
+        if (rs) rs[i] = sc.rs[i];
+        if (groups) groups[i] = sc.groups[i];
+      }
+    });
+  });
+}
+
+int ks_profile_enable(ks_ctx* ctx, int on) {
+  return guarded([&] {
+    KS_REQUIRE(ctx, KS_ERR_ARGUMENT, "null ctx");
+    ctx->use();
+    KS_HIP(hipStreamSynchronize(ctx->stream));
+    prof_collect(ctx);
+    ctx->profiling = on != 0;
+  });
+}
+
+int ks_profile_reset(ks_ctx* ctx) {
+  return guarded([&] {
+    KS_REQUIRE(ctx, KS_ERR_ARGUMENT, "null ctx");
+    ctx->use();
+    KS_HIP(hipStreamSynchronize(ctx->stream));
+    prof_collect(ctx);
+    for (int i = 0; i < KSP_NCLASS; ++i) { ctx->prof_ms[i] = 0; ctx->prof_bytes[i] = 0; ctx->prof_count[i] = 0; }
+  });
+}
+
+int ks_profile_get(ks_ctx* ctx, int nclass, double* ms, double* bytes, int64_t* counts) {
+  return guarded([&] {
+    KS_REQUIRE(ctx && ms && bytes && counts, KS_ERR_ARGUMENT, "null argument");
+    ctx->use();
+    KS_HIP(hipStreamSynchronize(ctx->stream));
+    prof_collect(ctx);
+    for (int i = 0; i < nclass && i < KSP_NCLASS; ++i) { ms[i] = ctx->prof_ms[i]; bytes[i] = ctx->prof_bytes[i]; counts[i] = ctx->prof_count[i]; }
   });
 }
 

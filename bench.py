@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's configuration.
+
+    metric   : Arnoldi iterations / second (one iteration = one operator apply + orthogonalize!,
+               src/expansion.jl:119-130), steady state over full Krylov-Schur restart cycles
+               INCLUDING the host Schur/reorder work and the restart rotation
+    workload : 3-D 7-point Laplacian, 216^3 = 10 077 696 rows (the "n = 10^7" headline case),
+               nev = 20, which = :SR, mindim = 20, maxdim = 40, Float64, explicit start vector
+    step     : one restart cycle = expand the Krylov basis from k+1 to maxdim, restart to k
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU; rows of A and V are block-partitioned
+     over the ranks -- total work fixed => "scaling": "strong", as north_star asks.)
+
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel class (algorithmic bytes per
+launch / HIP-event duration on the library's own stream) and, as `fused_step`, the north-star quantity
+(bytes of the fused SpMV + DGKS step / expansion wall time).  `cpu_baseline` times the reference's
+un-fused op sequence on the host cores (oracle/cpu_backend.cpp, kind "port") on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
+
+
+def step_bytes(n, nnz, j, reorth):
+    """Algorithmic bytes of one Arnoldi step at basis size j (SURVEY.md 8d / BASELINE.md section 4)."""
+    b = 12.0 * nnz + 4.0 * (n + 1) + 8.0 * n * (2 * j + 2)
+    if reorth:
+        b += 16.0 * j * n + 16.0 * n
+    return b
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--grid", type=int, default=216, help="grid points per dimension (216^3 ~ 1e7 rows)")
+    ap.add_argument("--nev", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    args = ap.parse_args()
+
+    import torch
+
+    from __graft_entry__ import import_package
+
+    pkg = import_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    m = args.grid
+    n = m ** 3
+    nev, mindim, maxdim = args.nev, max(10, args.nev), max(20, 2 * args.nev)
+    which = "SR"
+    tol = float(np.sqrt(np.finfo(np.float64).eps))
+
+    # ---- operand + workspace (rows block-partitioned over the ranks) ----
+    if world == 1:
+        ctx = pkg.Context(local_rank)
+        ip, ix, dv = pkg.matrices.laplace3d_csr(m, m, m)
+        nnz_global = int(ip[-1])
+        A_host = (ip, ix, dv)
+        op = pkg.csr_operator(pkg.matrices.to_scipy(ip, ix, dv, n), ctx)
+        ws = pkg.ArnoldiWorkspace(n, maxdim, np.float64, ctx=ctx)
+        v1 = pkg.matrices.start_vector(n)
+    else:
+        from arnoldimethod_jl_amd import dist as ksdist  # registered by import_package()
+
+        ctx, op, ws, v1, nnz_global = ksdist.setup_laplace3d(pkg, dist, m, maxdim, local_rank)
+        A_host = None
+    ws.reinitialize(0, v1)
+    ws.iterate_arnoldi(op, 1, mindim)  # initial expansion, src/run.jl:267 (untimed)
+
+    state = dict(k=mindim, active=0, steps=0, bytes=0.0, t_expand=0.0, t_restart=0.0, reorth=0)
+
+    def cycle(timed):
+        k = state["k"]
+        t0 = time.perf_counter()
+        st = ws.iterate_arnoldi(op, k + 1, maxdim)
+        t1 = time.perf_counter()
+        r = ws.restart(state["active"], nev, which, tol, mindim, maxdim)
+        ctx.synchronize()
+        t2 = time.perf_counter()
+        if timed:
+            nst = maxdim - k
+            state["steps"] += nst
+            state["reorth"] += st["reorth"]
+            # all steps of this workload take the DGKS second pass; attribute per step when they do
+            all_re = st["reorth"] == nst
+            for j in range(k + 1, maxdim + 1):
+                state["bytes"] += step_bytes(n, nnz_global, j, all_re)
+            if not all_re:
+                jm = (k + 1 + maxdim) / 2.0
+                state["bytes"] += st["reorth"] * (16.0 * jm * n + 16.0 * n)
+            state["t_expand"] += t1 - t0
+            state["t_restart"] += t2 - t1
+        state["k"], state["active"] = r["k"], r["nlock"]
+
+    for _ in range(args.warmup):
+        cycle(False)
+    if not args.no_profile:
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cycle(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = None
+    if not args.no_profile:
+        prof = ctx.profile_get()
+        ctx.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    iters_per_s = state["steps"] / elapsed
+    out = {
+        "metric": "arnoldi_iters_per_sec",
+        "value": iters_per_s,
+        "unit": "iters/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"laplace3d-7pt {m}^3 (n={n}, nnz={nnz_global}), nev={nev}, which=SR, mindim={mindim}, maxdim={maxdim}, "
+                        f"tol=sqrt(eps), explicit v1 (splitmix64 seed 20240917); step = one Krylov-Schur restart cycle",
+            "n": n,
+            "nnz": nnz_global,
+            "arnoldi_iterations_timed": state["steps"],
+            "dgks_second_passes": state["reorth"],
+            "parallelism": f"rows/{world}" if world > 1 else "single-gpu",
+        },
+    }
+
+    # ---- roofline ----
+    fused_gbs = state["bytes"] / max(state["t_expand"], 1e-12) / 1e9 / world  # per GPU
+    roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
+    if prof:
+        classes = {k: v for k, v in prof.items() if k != "fin" and v["count"] > 0}
+        dom = max(classes, key=lambda k: classes[k]["ms"])
+        d = classes[dom]
+        ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        roof.update({
+            "kernel": {"dots": "k_dots (h = V'w, |w|^2)", "axpy": "k_axpy (w -= V h, |w|^2)", "spmv": "k_spmv_csr",
+                       "scale": "k_scale", "rotate": "k_rotate_mfma"}[dom],
+            "achieved": ach,
+            "frac": ach / HBM_PEAK_GBS,
+            "launches": d["count"],
+            "avg_launch_ms": d["ms"] / d["count"],
+            "algorithmic_bytes_per_launch": d["bytes"] / d["count"],
+            "per_class": {k: {"ms_total": v["ms"], "launches": v["count"],
+                              "GBps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 and v["bytes"] > 0 else None}
+                          for k, v in prof.items()},
+        })
+    else:
+        roof.update({"kernel": "fused step (no per-kernel events)", "achieved": fused_gbs, "frac": fused_gbs / HBM_PEAK_GBS})
+    roof["fused_step"] = {
+        "what": "algorithmic bytes of SpMV + DGKS (both passes when taken) per Arnoldi step / expansion wall time, per GPU",
+        "achieved": fused_gbs,
+        "frac": fused_gbs / HBM_PEAK_GBS,
+        "frac_of_measured_copy_ceiling": fused_gbs / 6290.0,
+        "expand_seconds": state["t_expand"],
+        "restart_seconds": state["t_restart"],
+    }
+    out["roofline"] = roof
+
+    # ---- CPU baseline: the reference's op sequence on the host cores (rank 0, N = 1 only) ----
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        try:
+            from oracle import cpuref
+
+            A = pkg.matrices.to_scipy(*A_host, n)
+            tb = cpuref.timed_cycles_csr(A, nev=nev, which=which, mindim=mindim, maxdim=maxdim, cycles=1)
+            out["cpu_baseline"] = {
+                "value": tb["steps"] / tb["seconds"],
+                "unit": "iters/s",
+                "cores": tb["threads"],
+                "kind": "port",
+                "sample": f"same matrix and parameters; 1 restart cycle = {tb['steps']} Arnoldi iterations after the initial "
+                          f"expansion (untimed), {tb['seconds']:.1f} s; un-fused reference op sequence with OpenMP over rows "
+                          f"(spmv {tb['t_spmv']:.1f} s, orthogonalize {tb['t_orth']:.1f} s, rotation {tb['t_rot']:.1f} s)",
+            }
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"] = {"value": None, "unit": "iters/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -216,6 +216,23 @@ int ks_params_default(int64_t n, ks_params* p);
 int ks_partialschur(ks_operator* A, ks_workspace* ws, const ks_params* p, const void* v1_host,
                     double* eigenvalues_c64, ks_history* history);
 
+/* One Krylov-Schur restart on the workspace: Schur form of the active block of H, Ritz values and
+ * residual estimates, lock/retain/purge grouping, three-way partition, restore_arnoldi! (all on the
+ * host, src/run.jl:278-360), then the change of basis V[:, purge:k) <- V[:, purge:maxdim) Q[...] and
+ * V[:, k] <- V[:, maxdim] on the device (src/run.jl:363-365).  `active` is 0-based (first non-locked
+ * column).  With ks_iterate_arnoldi this lets a host language run `_partialschur`'s loop itself:
+ *     ks_iterate_arnoldi(A, ws, k+1, maxdim) ; ks_restart(ws, p, active, &k, &nlock, ...) ; active = nlock
+ * Out (optional): eigenvalues / residual estimates / groups of this restart (maxdim entries each). */
+int ks_restart(ks_workspace* ws, const ks_params* p, int active, int* k, int* nlock, int* purge,
+               double* lams_c64, double* rs, int32_t* groups);
+
+/* Per-kernel-class timing with HIP events on the context's stream (bench.py's roofline figures).
+ * Classes: 0 SpMV, 1 dots (V'w), 2 axpy (w -= Vh), 3 scale, 4 rotation, 5 reductions/decisions.
+ * `bytes` are ALGORITHMIC bytes accumulated per launch. */
+int ks_profile_enable(ks_ctx* ctx, int on);
+int ks_profile_reset(ks_ctx* ctx);
+int ks_profile_get(ks_ctx* ctx, int nclass, double* ms, double* bytes, int64_t* counts);
+
 /* Residual checks evaluated on the device: ||A*Q - Q*R||_F and ||Q'Q - I||_F for the first
  * `ncols` columns with R = H[0:ncols, 0:ncols) (test/partial_schur.jl:24-25,104-105). */
 int ks_residual_norms(ks_operator* A, ks_workspace* ws, int ncols, double* resid, double* orth);

@@ -1,0 +1,480 @@
+"""`-m gpu`: parity tests proper.  Everything goes through the C ABI of libkschur_hip.so (ctypes) and
+is compared with the oracle on the same seeded inputs.  Tolerances are stated next to each check:
+the arithmetic is Float64 / ComplexF64 and differs from the oracle only by summation order.
+
+  * verbs: rand!, norm, ./=, mul!(y,A,x), V'w, w -= Vh, rotation, copy
+  * fused path: orthogonalize!, iterate_arnoldi! incl. the breakdown / reinitialize! branch
+  * end to end: the reference's own tests (test/expansion.jl, test/partial_schur.jl,
+    test/schur_to_eigen.jl, readme example) replayed on the HIP path
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from __graft_entry__ import import_package
+from oracle import arnoldi as oa
+from oracle import smalldense as sd
+from oracle.matrices import hashed_nonsymmetric, laplace1d, laplace3d, laplace3d_eigs
+
+pytestmark = pytest.mark.gpu
+pkg = import_package()
+EPS = np.finfo(np.float64).eps
+DTYPES = [np.float64, np.complex128]
+
+
+def rnd(rng, dtype, *shape):
+    a = rng.standard_normal(shape)
+    if np.dtype(dtype).kind == "c":
+        a = a + 1j * rng.standard_normal(shape)
+    return a.astype(dtype)
+
+
+def sprand(rng, dtype, n, density):
+    M = sp.random(n, n, density=density, random_state=rng, format="csr", dtype=np.float64)
+    if np.dtype(dtype).kind == "c":
+        M = (M + 1j * sp.random(n, n, density=density, random_state=rng, format="csr", dtype=np.float64)).tocsr()
+    return M.astype(dtype)
+
+
+# ------------------------------------------------------------------ loaded native code
+def test_native_library_is_loaded():
+    import ctypes as C
+
+    L = pkg._lib.load()
+    h = C.c_void_p()
+    assert L.ks_ctx_create(0, C.byref(h)) == 0, L.ks_last_error_string()
+    assert L.ks_ctx_destroy(h) == 0
+    maps = open("/proc/self/maps").read()
+    assert "libkschur_hip.so" in maps
+
+
+# ------------------------------------------------------------------ verbs
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 4097])
+def test_column_verbs(dtype, n):
+    rng = np.random.default_rng(n)
+    m = min(6, n)
+    ws = pkg.ArnoldiWorkspace(n, m, dtype)
+    # rand!: bit-identical to the portable RNG
+    ws.fill_uniform(0, 1234)
+    ref = np.empty(n, dtype=dtype)
+    oa.rand_fill(ref, 1234)
+    assert (ws.col(0) == ref).all()
+    # upload / download round trip, norm, ./=, copy
+    v = rnd(rng, dtype, n)
+    ws.set_col(1, v)
+    assert (ws.col(1) == v).all()
+    assert ws.norm(1) == pytest.approx(np.linalg.norm(v), rel=1e-14)
+    ws.div(1, 3.0)
+    np.testing.assert_allclose(ws.col(1), v / 3.0, rtol=2 * EPS)
+    ws.copy_col(2 % (m + 1), 1)
+    assert (ws.col(2 % (m + 1)) == ws.col(1)).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,j", [(50, 1), (1000, 3), (1000, 4), (3000, 5), (3000, 17), (2049, 40), (700, 41), (520, 95)])
+def test_gemv_t_and_gemv_n(dtype, n, j):
+    """h = V[:,0:j)' w and w -= V[:,0:j) h vs numpy (rel 1e-13: different summation order)."""
+    rng = np.random.default_rng(j)
+    ws = pkg.ArnoldiWorkspace(n, j, dtype)
+    V = rnd(rng, dtype, n, j + 1)
+    ws.set_cols(0, V)
+    h = ws.gemv_t(j, j)
+    href = V[:, :j].conj().T @ V[:, j]
+    np.testing.assert_allclose(h, href, rtol=1e-13, atol=1e-13 * np.abs(href).max())
+    g = rnd(rng, dtype, j)
+    ws.gemv_n_sub(j, j, g)
+    wref = V[:, j] - V[:, :j] @ g
+    np.testing.assert_allclose(ws.col(j), wref, rtol=1e-13, atol=1e-13 * np.abs(wref).max())
+    # the other columns are untouched
+    assert (ws.cols(0, j) == V[:, :j]).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_spmv_laplace_and_irregular(dtype):
+    rng = np.random.default_rng(5)
+    mats = [laplace3d(7, 9, 11).astype(dtype), hashed_nonsymmetric(5000, seed=3).astype(dtype), laplace1d(300).astype(dtype)]
+    # rows far longer than the LDS tile (exercise the one-wave-per-row fallback) and empty rows
+    B = sp.random(600, 600, density=0.0, format="lil", dtype=np.float64)
+    B[3, :] = rng.standard_normal(600)
+    B[300:340, ::2] = rng.standard_normal((40, 300))
+    B[599, 0] = 2.0
+    mats.append(sp.csr_matrix(B).astype(dtype))
+    if np.dtype(dtype).kind == "c":
+        mats = [M + 1j * 0.5 * M for M in mats]
+    for A in mats:
+        n = A.shape[0]
+        for fmt in ("csr", "csc"):  # CSC is what Julia's SparseMatrixCSC hands over
+            op = pkg.csr_operator(A.asformat(fmt))
+            ws = pkg.ArnoldiWorkspace(n, 2, dtype)
+            x = rnd(rng, dtype, n)
+            ws.set_col(0, x)
+            ws.apply(op, 0, 1)
+            y = A @ x
+            np.testing.assert_allclose(ws.col(1), y, rtol=1e-13, atol=1e-13 * np.abs(y).max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c0,c,r", [(0, 3, 3), (2, 20, 11), (0, 24, 24), (1, 25, 17), (0, 40, 30), (5, 36, 26), (0, 41, 29), (0, 64, 33)])
+def test_rotation_in_place(dtype, c0, c, r):
+    """V[:, c0:c0+r) <- V[:, c0:c0+c) Q  (src/run.jl:363-364) -- MFMA path for Float64."""
+    rng = np.random.default_rng(c * 100 + r)
+    n = 777
+    m = c0 + c + 1
+    ws = pkg.ArnoldiWorkspace(n, m, dtype)
+    V = rnd(rng, dtype, n, m + 1)
+    # asymmetric Q (catches transposed operand / output maps)
+    Q = rnd(rng, dtype, c, r) + np.arange(c)[:, None] * 0.01 - np.arange(r)[None, :] * 0.02
+    ws.set_cols(0, V)
+    ws.rotate(c0, Q)
+    want = V.copy()
+    want[:, c0 : c0 + r] = V[:, c0 : c0 + c] @ Q
+    got = ws.cols(0, m + 1)
+    scale = np.abs(want).max()
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-13 * scale * c)
+
+
+def test_rotation_mfma_equals_valu_kernel(monkeypatch):
+    rng = np.random.default_rng(9)
+    n, c, r = 5000, 40, 30
+    V = rng.standard_normal((n, c + 1))
+    Q = rng.standard_normal((c, r))
+    outs = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("KS_ROTATE_VALU", force)
+        ws = pkg.ArnoldiWorkspace(n, c, np.float64)
+        ws.set_cols(0, V)
+        ws.rotate(0, Q)
+        outs.append(ws.cols(0, c + 1))
+    np.testing.assert_allclose(outs[0], outs[1], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(outs[0][:, :r], V[:, :c] @ Q, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_basis_times(dtype):
+    rng = np.random.default_rng(11)
+    n, c = 900, 7
+    ws = pkg.ArnoldiWorkspace(n, c, dtype)
+    V = rnd(rng, dtype, n, c + 1)
+    ws.set_cols(0, V)
+    Y = rnd(rng, np.complex128, c, 5)
+    np.testing.assert_allclose(ws.basis_times(c, Y), V[:, :c] @ Y, atol=1e-12)
+    if np.dtype(dtype).kind == "f":
+        Yr = rng.standard_normal((c, 4))
+        out = ws.basis_times(c, Yr)
+        assert out.dtype == np.float64
+        np.testing.assert_allclose(out, V[:, :c] @ Yr, atol=1e-12)
+
+
+# ------------------------------------------------------------------ fused hot path
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_orthogonalize_matches_oracle(dtype):
+    """One DGKS step vs the oracle's orthogonalize! on the same data: H column to 1e-13, new
+    basis vector to 1e-12, decisions identical."""
+    rng = np.random.default_rng(21)
+    n, j = 2000, 9
+    Vq, _ = np.linalg.qr(rnd(rng, dtype, n, j))
+    w = rnd(rng, dtype, n)
+    for wvec in (w, Vq @ rnd(rng, dtype, j) + 1e-3 * w):  # second one forces the re-orthogonalisation
+        ows = oa.ArnoldiWorkspace.from_dims(dtype, n, j + 1)
+        ows.V[:, :j] = Vq
+        ows.V[:, j] = wvec
+        st = {}
+        ok_ref = oa.orthogonalize(ows, j, st)
+        ws = pkg.ArnoldiWorkspace(n, j + 1, dtype)
+        ws.set_cols(0, np.hstack([Vq, wvec[:, None]]))
+        ok = ws.orthogonalize(j)
+        assert ok == ok_ref
+        np.testing.assert_allclose(ws.H[: j + 1, j - 1], ows.H[: j + 1, j - 1], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(ws.col(j), ows.V[:, j], atol=1e-11)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_arnoldi_factorization(dtype):  # test/expansion.jl:12-32
+    rng = np.random.default_rng(5)
+    n, mx = 10, 6
+    A = (sprand(rng, dtype, n, 0.1) + sp.identity(n)).tocsr().astype(dtype)
+    op = pkg.csr_operator(A)
+    ws = pkg.ArnoldiWorkspace(n, mx, dtype)
+    assert ws.reinitialize(0)
+    assert ws.norm(0) == pytest.approx(1.0)
+    ws.iterate_arnoldi(op, 1, 3)
+    V, H = ws.V, ws.H
+    np.testing.assert_allclose(A @ V[:, :3], V[:, :4] @ H[:4, :3], atol=1e-13)
+    assert np.linalg.norm(V[:, :4].conj().T @ V[:, :4] - np.eye(4)) < np.sqrt(EPS) / 100
+    ws.iterate_arnoldi(op, 4, mx)
+    V, H = ws.V, ws.H
+    np.testing.assert_allclose(A @ V[:, :mx], V @ H, atol=1e-13)
+    assert np.linalg.norm(V.conj().T @ V - np.eye(mx + 1)) < np.sqrt(EPS) / 100
+    res, orth = ws.arnoldi_relation(op, mx)  # the same two numbers evaluated on the device
+    assert res < 1e-13 and orth < np.sqrt(EPS) / 100
+
+
+def test_invariant_subspace_breakdown():  # test/expansion.jl:34-55 (KAT-3)
+    rng = np.random.default_rng(6)
+    A = np.zeros((8, 8))
+    A[:4, :4] = rng.random((4, 4))
+    A[4:, 4:] = rng.random((4, 4))
+    op = pkg.csr_operator(A)
+    ws = pkg.ArnoldiWorkspace(8, 5, np.float64)
+    e1 = np.zeros(8)
+    e1[0] = 1
+    ws.set_col(0, e1)
+    st = ws.iterate_arnoldi(op, 1, 5)
+    V = ws.V
+    assert np.linalg.norm(V.T @ V - np.eye(6)) < np.sqrt(EPS) / 100
+    assert ws.H[4, 3] == 0  # jl: iszero(H[5, 4])
+    assert st["breakdowns"] == 1 and st["steps"] == 5
+
+
+def test_expansion_matches_oracle_H():
+    """Same start vector, same operator: the Hessenberg matrix built on the GPU equals the oracle's
+    to 1e-11 (it is a continuous function of the data while no DGKS branch flips)."""
+    A = laplace3d(9, 10, 11)
+    n = A.shape[0]
+    v1 = oa.uniform_hash(oa.DEFAULT_SEED, np.arange(n))
+    m = 24
+    ows = oa.ArnoldiWorkspace.from_vector(v1, m)
+    oa.reinitialize(ows, 0, lambda v: v.__setitem__(slice(None), v1))
+    st = {}
+    oa.iterate_arnoldi(A, ows, 1, m, st)
+    op = pkg.csr_operator(A)
+    ws = pkg.ArnoldiWorkspace(n, m, np.float64)
+    ws.reinitialize(0, v1)
+    got = ws.iterate_arnoldi(op, 1, m)
+    assert got["reorth"] == st["reorth"] and got["steps"] == m
+    np.testing.assert_allclose(ws.H, ows.H, atol=1e-11)
+    V = ws.V
+    # signs are fixed by H[j+1,j] > 0, so the bases agree too
+    np.testing.assert_allclose(V, ows.V, atol=1e-9)
+
+
+# ------------------------------------------------------------------ end to end
+def check_schur(A, dec, tol_res, tol_orth=100 * EPS):
+    Q, R = dec.Q, np.array(dec.R)
+    k = Q.shape[1]
+    assert np.linalg.norm(Q.conj().T @ Q - np.eye(k)) < tol_orth * max(1, k)
+    assert np.linalg.norm(A @ Q - Q @ R) < tol_res
+    return Q, R
+
+
+def test_readme_example():  # KAT-1
+    A = laplace1d(100)
+    v1 = oa.uniform_hash(oa.DEFAULT_SEED, np.arange(100))
+    dec, hist = pkg.partialschur(A, v1=v1, nev=10, tol=1e-6, which="SR")
+    ref, rhist = oa.partialschur(A, v1=v1, nev=10, tol=1e-6, which="SR")
+    assert hist.converged and hist.nconverged == 10
+    assert hist.mvproducts == rhist.mvproducts  # same decisions as the oracle on identical input
+    exact = 2 - 2 * np.cos(np.arange(1, 11) * np.pi / 101)
+    np.testing.assert_allclose(dec.eigenvalues.real, exact, atol=1e-7)
+    np.testing.assert_allclose(dec.eigenvalues, ref.eigenvalues, atol=1e-10)
+    check_schur(A, dec, 1e-6)
+    vals, vecs = pkg.partialeigen(dec)
+    assert np.linalg.norm(A @ vecs - vecs * vals) < 1e-6
+    assert str(hist) == str(rhist)
+    assert "PartialSchur decomposition (Float64) of dimension 10" in repr(dec)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_low_rank(dtype):  # test/partial_schur.jl:6-27 (KAT-2: 7 products)
+    rng = np.random.default_rng(7)
+    X = rng.random((10, 3)) + (1j * rng.random((10, 3)) if np.dtype(dtype).kind == "c" else 0)
+    B = (X @ X.conj().T).astype(dtype)
+    dec, hist = pkg.partialschur(B, nev=5, mindim=5, maxdim=7, tol=EPS)
+    assert hist.converged and hist.mvproducts == 7
+    nb = max(1.0, np.linalg.norm(B))
+    Q, R = check_schur(B, dec, 1000 * EPS * nb, 1000 * EPS)
+    assert np.linalg.norm(np.diag(R)[3:5]) < 1000 * EPS * nb
+
+
+def test_right_number_type_and_small_matrix():  # test/partial_schur.jl:41-52
+    rng = np.random.default_rng(8)
+    A = (rng.random((10, 10)) < 0.5).astype(np.int64)
+    dec, hist = pkg.partialschur(A, nev=2, mindim=3, maxdim=8)
+    assert dec.Q.dtype == np.float64
+    A3 = rng.random((3, 3))
+    dec, hist = pkg.partialschur(A3)
+    assert hist.converged and hist.mvproducts == 3
+
+
+def test_incorrect_input():  # test/partial_schur.jl:54-62
+    rng = np.random.default_rng(10)
+    A = rng.random((6, 6))
+    with pytest.raises(pkg.DimensionMismatch):
+        pkg.partialschur(rng.random((4, 3)))
+    for kw in (dict(mindim=5, maxdim=3), dict(nev=5, mindim=3), dict(nev=5, maxdim=3), dict(nev=10), dict(nev=0), dict(which="XX")):
+        with pytest.raises(pkg.ArgumentError):
+            pkg.partialschur(A, **kw)
+    with pytest.raises(pkg.ArgumentError):
+        pkg.partialschur(A, v1=np.ones(5))
+    with pytest.raises(pkg.ArgumentError):
+        pkg.ArnoldiWorkspace(5, 6)
+
+
+def test_eigenvector_as_initial_vector():  # test/partial_schur.jl:65-76
+    rng = np.random.default_rng(11)
+    A = rng.random((30, 30))
+    A = A + A.T
+    lams, X = np.linalg.eigh(A)
+    x = X[:, -1].copy()
+    dec, hist = pkg.partialschur(A, v1=x, nev=2, tol=1e-8)
+    assert (x == X[:, -1]).all()
+    assert hist.converged
+    check_schur(A, dec, 1e-7)
+    assert abs(dec.eigenvalues.real.max() - lams[-1]) < 1e-7
+
+
+def test_target_non_dominant_and_repeated():  # test/partial_schur.jl:79-106 (KAT-4)
+    d = np.concatenate([np.arange(1, 10.0001, 0.1), [50, 51, 52, 53]])
+    dec, hist = pkg.partialschur(sp.diags(d).tocsr(), which="SR")
+    assert (sd.eigenvalues(np.asfortranarray(np.array(dec.R))).real <= 10).all()
+    d = np.concatenate([np.arange(1, 9.0001, 0.1), [9.97, 9.98, 9.99, 10.0, 10.0, 10.0]])
+    A = sp.diags(d).tocsr()
+    dec, hist = pkg.partialschur(A, nev=5, maxdim=20, tol=1e-12)
+    assert hist.converged
+    check_schur(A, dec, A.shape[0] * 1e-12)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_zero_matrix(dtype):  # test/partial_schur.jl:108-120 (KAT-2: 5 products, residual exactly 0)
+    A = sp.csr_matrix((5, 5), dtype=dtype)
+    dec, hist = pkg.partialschur(A)
+    assert hist.converged and hist.mvproducts == hist.nconverged == 5
+    Q, R = dec.Q, np.array(dec.R)
+    assert np.linalg.norm(Q.conj().T @ Q - np.eye(5)) < 100 * EPS
+    assert np.linalg.norm(A @ Q - Q @ R) == 0
+
+
+def test_passing_initial_schur_decomp():  # test/partial_schur.jl:122-138
+    rng = np.random.default_rng(12)
+    A = rng.random((100, 100))
+    ws = pkg.ArnoldiWorkspace(100, 20)
+    F, hist = pkg.partialschur_(A, ws, nev=3, tol=1e-12)
+    assert hist.converged and hist.nconverged in (3, 4)
+    check_schur(A, F, 1e-10)
+    F2, hist2 = pkg.partialschur_(A, ws, nev=5, start_from=hist.nconverged + 1, tol=1e-8)
+    assert hist2.converged and hist2.nconverged in (5, 6)
+    check_schur(A, F2, 1e-6)
+    assert F2.workspace is ws  # results are views of the caller's workspace (src/run.jl:149-150)
+    with pytest.raises(pkg.ArgumentError):
+        pkg.partialschur_(A, ws, maxdim=21)
+    with pytest.raises(pkg.ArgumentError):
+        pkg.partialschur_(A, ws, start_from=0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("seed", range(1, 6))
+def test_schur_to_eigen(dtype, seed):  # test/schur_to_eigen.jl
+    rng = np.random.default_rng(seed)
+    A = (sp.diags(np.arange(1, 101, dtype=float)) + sprand(rng, dtype, 100, 0.01)).tocsr().astype(dtype)
+    eps_ = np.sqrt(EPS)
+    dec, hist = pkg.partialschur(A, nev=10, tol=eps_, restarts=200, seed=seed)
+    assert hist.converged
+    vals, vecs = pkg.partialeigen(dec)
+    for i in range(10):
+        assert np.linalg.norm(A @ vecs[:, i] - vecs[:, i] * vals[i]) < eps_ * abs(vals[i])
+
+
+def test_nonsymmetric_complex_pairs_vs_oracle():
+    """config 3 flavour at parity size: real nonsymmetric, which=:LM, planted complex pairs."""
+    planted = [(5.0, 3.0), (4.0, -2.5), (-6.0, 1.0), (7.5, 0.0)]
+    A = hashed_nonsymmetric(3000, seed=7, planted=planted)
+    n = A.shape[0]
+    v1 = oa.uniform_hash(oa.DEFAULT_SEED, np.arange(n))
+    dec, hist = pkg.partialschur(A, v1=v1, nev=6, which="LM", tol=1e-10)
+    ref, rhist = oa.partialschur(A, v1=v1, nev=6, which="LM", tol=1e-10)
+    assert hist.converged and hist.nconverged == rhist.nconverged and hist.mvproducts == rhist.mvproducts
+    np.testing.assert_allclose(np.sort_complex(dec.eigenvalues), np.sort_complex(ref.eigenvalues), atol=1e-9)
+    check_schur(A, dec, 1e-10 * 10)  # ||AQ - QR|| <= 1e-10-class (north_star), sum over 7 columns
+    R = np.array(dec.R)
+    assert any(R[i + 1, i] != 0 for i in range(R.shape[0] - 1))  # a real 2x2 block survived the restarts
+
+
+def test_complex_operator_callback_shift_invert():
+    """config 4 flavour at parity size: ComplexF64 shift-and-invert through an opaque host operator
+    (LinearMap wrapping a factorisation, docs/src/index.md:246-249), interior eigenvalues, :LM."""
+    import scipy.sparse.linalg as spla
+
+    n = 400
+    rng = np.random.default_rng(3)
+    A = (laplace1d(n) + 1j * sp.diags(0.3 * rng.random(n))).tocsc().astype(np.complex128)
+    sigma = 1.7 + 0.1j
+    lu = spla.splu((A - sigma * sp.identity(n)).tocsc())
+
+    class ShiftInvert:
+        shape = (n, n)
+        dtype = np.complex128
+
+        def mul_(self, y, x):
+            y[:] = lu.solve(x)
+
+    v1 = oa.uniform_hash(1, np.arange(n)) + 1j * oa.uniform_hash(2, np.arange(n))
+    dec, hist = pkg.partialschur(ShiftInvert(), v1=v1, nev=6, which="LM", tol=1e-10)
+    ref, rhist = oa.partialschur(ShiftInvert(), v1=v1, nev=6, which="LM", tol=1e-10)
+    assert hist.converged and hist.mvproducts == rhist.mvproducts
+    lam = sigma + 1.0 / dec.eigenvalues
+    exact = np.linalg.eigvals(A.toarray())
+    want = exact[np.argsort(np.abs(exact - sigma))][:6]
+    np.testing.assert_allclose(np.sort_complex(lam), np.sort_complex(want), atol=1e-8)
+    np.testing.assert_allclose(np.sort_complex(dec.eigenvalues), np.sort_complex(ref.eigenvalues), atol=1e-8)
+
+
+@pytest.mark.parametrize("which", ["LM", "LR", "SR", "LI", "SI"])
+def test_all_targets_complex(which):
+    rng = np.random.default_rng(15)
+    n = 60
+    d = rng.standard_normal(n) * 3 + 1j * rng.standard_normal(n) * 3
+    A = (sp.diags(d) + sprand(rng, np.complex128, n, 0.02) * 0.01).tocsr()
+    dec, hist = pkg.partialschur(A, nev=4, which=getattr(pkg, which)(), tol=1e-10)
+    assert hist.converged
+    ref = np.linalg.eigvals(A.toarray())
+    key = {"LM": lambda z: -abs(z), "LR": lambda z: -z.real, "SR": lambda z: z.real, "LI": lambda z: -z.imag, "SI": lambda z: z.imag}[which]
+    np.testing.assert_allclose(sorted(dec.eigenvalues[:4], key=key), sorted(ref, key=key)[:4], atol=1e-7)
+
+
+def test_laplace3d_parity_size_1e10():
+    """north_star parity bar: ||AQ - QR|| <= 1e-10 on a converged run (anisotropic 3-D Laplacian,
+    tol = 1e-12 like test/partial_schur.jl:102), eigenvalues vs analytic, residual also evaluated
+    on the device."""
+    mx, my, mz = 30, 31, 32
+    A = laplace3d(mx, my, mz)
+    n = A.shape[0]
+    v1 = oa.uniform_hash(oa.DEFAULT_SEED, np.arange(n))
+    dec, hist = pkg.partialschur(A, v1=v1, nev=8, which="SR", tol=1e-12, mindim=20, maxdim=40, restarts=400)
+    assert hist.converged
+    Q, R = check_schur(A, dec, 1e-10)
+    np.testing.assert_allclose(np.sort(dec.eigenvalues.real)[:8], laplace3d_eigs(mx, my, mz)[:8], atol=1e-10)
+    dres, dorth = dec.workspace.residual_norms(pkg.as_operator(A), dec.nconverged)
+    assert dres <= 1e-10 and dorth < 100 * EPS * 8
+    assert dres == pytest.approx(np.linalg.norm(A @ Q - Q @ R), abs=1e-12)
+
+
+def test_full_size_properties_1e6():
+    """BASELINE config 2 (n = 100^3, nev = 20, maxdim = 40) at full size through size-independent
+    properties: the Arnoldi relation ||A V_k - V_{k+1} H_k||_F <= 1e-12 ||H||_F and
+    ||V'V - I|| <= sqrt(eps)/100 (test/expansion.jl:29-30) evaluated on the device after a full
+    expansion; restarted runs are deterministic (bit-identical H on a repeat) and any locked Ritz
+    value is an analytic eigenvalue."""
+    m = 100
+    n = m ** 3
+    ip, ix, dv = pkg.matrices.laplace3d_csr(m, m, m)
+    op = pkg.csr_operator(pkg.matrices.to_scipy(ip, ix, dv, n))
+    v1 = pkg.matrices.start_vector(n)
+    ws = pkg.ArnoldiWorkspace(n, 40)
+    ws.reinitialize(0, v1)
+    st = ws.iterate_arnoldi(op, 1, 40)
+    assert st["steps"] == 40 and st["breakdowns"] == 0
+    res, orth = ws.arnoldi_relation(op, 40)
+    assert res <= 1e-12 * np.linalg.norm(ws.H) and orth <= np.sqrt(EPS) / 100
+    Hs = []
+    for _ in range(2):
+        F, hist = pkg.partialschur_(op, pkg.ArnoldiWorkspace(v1, 40), nev=20, which="SR", tol=1e-8, restarts=5)
+        Hs.append(np.array(F.workspace.H))
+    assert (Hs[0] == Hs[1]).all()
+    assert hist.restarts == 5 and hist.mvproducts >= 20 + 5 * 10
+    ev = pkg.matrices.laplace3d_eigs(m, m, m, 40)
+    for lam in F.eigenvalues:
+        assert np.min(np.abs(ev - lam.real)) < 1e-7
+    if F.nconverged:
+        dres, dorth = F.workspace.residual_norms(op, F.nconverged)
+        assert dres < 1e-7 * F.nconverged and dorth < 1e-12
