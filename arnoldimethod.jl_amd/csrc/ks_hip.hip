@@ -112,7 +112,7 @@ struct ks_ctx {
   int rank = 0, nranks = 1;
   ncclComm_t comm = nullptr;
   int num_cu = 256;
-  int bpc = 4;  // streaming workgroups per CU (KS_BPC)
+  int bpc = 6;  // streaming workgroups per CU (KS_BPC; 6 measured best on MI355X, tools/streambench.hip)
   int nblocks() const { return num_cu * bpc; }
   void use() const { KS_HIP(hipSetDevice(device)); }
   // in-place sum over ranks of `count` doubles living in device memory
@@ -171,7 +171,7 @@ static void ctx_init_device(ks_ctx* c, int device) {
   hipDeviceProp_t prop;
   KS_HIP(hipGetDeviceProperties(&prop, device));
   c->num_cu = prop.multiProcessorCount;
-  c->bpc = env_int("KS_BPC", 4);
+  c->bpc = env_int("KS_BPC", 6);
   KS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 }
 
@@ -432,7 +432,7 @@ template <class D> int dots_blocks_for(ks_workspace* ws, int nc4) {
 template <class D, int NC4>
 void launch_dots_nc(ks_workspace* ws, int nb, const D* V, int jc, const D* w, D* partial, int norm_slot, int pass,
                     const DevState* st) {
-  ksd::k_dots<D, NC4><<<nb, kBlock, 0, ws->ctx->stream>>>(V, ws->ld, jc, w, partial, ws->pstride, norm_slot, pass, st);
+  ksd::k_dots<D, NC4><<<nb, kBlock, 0, ws->ctx->stream>>>(V, ws->ld, jc, w, partial, ws->nb, norm_slot, pass, st);
 }
 
 // partial[b][0..j) = V[:,0:j)^H w (block-local), partial[b][j] = |w|^2 (block-local); returns the
@@ -445,7 +445,7 @@ template <class D> int launch_dots(ks_workspace* ws, int j, const D* w, int pass
     const int jc = std::min(40, j - c0);
     const int norm_slot = (c0 + 40 >= j) ? (j - c0) : -1;
     const D* Vc = V + (size_t)c0 * ws->ld;
-    D* pc = partial + c0;
+    D* pc = partial + (size_t)c0 * ws->nb;  // partial is [column][workgroup], column stride ws->nb
     switch ((jc + 3) / 4) {
       case 1: launch_dots_nc<D, 1>(ws, nb, Vc, jc, w, pc, norm_slot, pass, st); break;
       case 2: launch_dots_nc<D, 2>(ws, nb, Vc, jc, w, pc, norm_slot, pass, st); break;
@@ -468,24 +468,78 @@ template <class D> void launch_fin_dots(ks_workspace* ws, int nbd, int j, D* Hco
   D* partial = static_cast<D*>(ws->partial);
   D* red = static_cast<D*>(ws->red);
   D* coef = static_cast<D*>(ws->coef);
+  // one workgroup per column (0..j-1 = inner products, j = |w|^2; pass 2 ignores column j)
+  const int ncol = pass == 1 ? j + 1 : j;
   if (c->nranks == 1) {
-    ksd::k_fin_dots<D><<<1, kBlock, 0, c->stream>>>(partial, nbd, ws->pstride, j, red, Hcol, coef, pass, 0, st);
+    ksd::k_fin_dots<D><<<ncol, kBlock, 0, c->stream>>>(partial, nbd, ws->nb, j, red, Hcol, coef, pass, 0, st);
   } else {
-    ksd::k_fin_dots<D><<<1, kBlock, 0, c->stream>>>(partial, nbd, ws->pstride, j, red, Hcol, coef, pass, 1, st);
-    c->allreduce(reinterpret_cast<double*>(red), (j + 1) * (int)(sizeof(D) / 8));
-    ksd::k_fin_dots<D><<<1, kBlock, 0, c->stream>>>(partial, nbd, ws->pstride, j, red, Hcol, coef, pass, 2, st);
+    ksd::k_fin_dots<D><<<ncol, kBlock, 0, c->stream>>>(partial, nbd, ws->nb, j, red, Hcol, coef, pass, 1, st);
+    c->allreduce(reinterpret_cast<double*>(red), ncol * (int)(sizeof(D) / 8));
+    ksd::k_fin_dots<D><<<ncol, 64, 0, c->stream>>>(partial, nbd, ws->nb, j, red, Hcol, coef, pass, 2, st);
   }
 }
 
-template <class D> void launch_fin_norm(ks_workspace* ws, int j, D* Hsub, int pass, DevState* st) {
+template <class D> void launch_fin_norm(ks_workspace* ws, int nbp, int j, D* Hsub, int pass, DevState* st) {
   ks_ctx* c = ws->ctx;
   double* red = reinterpret_cast<double*>(ws->red);
   if (c->nranks == 1) {
-    ksd::k_fin_norm<D><<<1, kBlock, 0, c->stream>>>(ws->partial2, ws->nb, red, Hsub, j, pass, 0, st);
+    ksd::k_fin_norm<D><<<1, kBlock, 0, c->stream>>>(ws->partial2, nbp, red, Hsub, j, pass, 0, st);
   } else {
-    ksd::k_fin_norm<D><<<1, kBlock, 0, c->stream>>>(ws->partial2, ws->nb, red, Hsub, j, pass, 1, st);
+    ksd::k_fin_norm<D><<<1, kBlock, 0, c->stream>>>(ws->partial2, nbp, red, Hsub, j, pass, 1, st);
     c->allreduce(red, 1);
-    ksd::k_fin_norm<D><<<1, kBlock, 0, c->stream>>>(ws->partial2, ws->nb, red, Hsub, j, pass, 2, st);
+    ksd::k_fin_norm<D><<<1, kBlock, 0, c->stream>>>(ws->partial2, nbp, red, Hsub, j, pass, 2, st);
+  }
+}
+
+// fused first projection + second-pass inner products (Float64, j <= 40); returns workgroups used
+template <int NC4, int RPL> int axpy_dots_blocks(ks_workspace* ws) {
+  static int cache = -1;
+  return resident_blocks(ws->ctx, ksd::k_axpy_dots<NC4, RPL>, 0, cache);
+}
+template <int NC4, int RPL> int launch_axpy_dots_nc(ks_workspace* ws, int j, double* w) {
+  const int nb = axpy_dots_blocks<NC4, RPL>(ws);
+  ksd::k_axpy_dots<NC4, RPL><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const double*>(ws->V), ws->ld, j, w,
+                                                              static_cast<const double*>(ws->coef),
+                                                              static_cast<double*>(ws->partial), ws->nb, ws->partial2, ws->st);
+  return nb;
+}
+template <int NCW, int U> int launch_axpy_dots_cs_nc(ks_workspace* ws, int j, double* w) {
+  static int cache = -1;
+  const int nb = resident_blocks(ws->ctx, ksd::k_axpy_dots_cs<NCW, U>, 0, cache);
+  ksd::k_axpy_dots_cs<NCW, U><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const double*>(ws->V), ws->ld, j, w,
+                                                               static_cast<const double*>(ws->coef),
+                                                               static_cast<double*>(ws->partial), ws->nb, ws->partial2, ws->st);
+  return nb;
+}
+template <int U> int launch_axpy_dots_cs(ks_workspace* ws, int j, double* w) {
+  switch ((j + 3) / 4) {
+    case 1: return launch_axpy_dots_cs_nc<1, U>(ws, j, w);
+    case 2: return launch_axpy_dots_cs_nc<2, U>(ws, j, w);
+    case 3: return launch_axpy_dots_cs_nc<3, U>(ws, j, w);
+    case 4: return launch_axpy_dots_cs_nc<4, U>(ws, j, w);
+    case 5: return launch_axpy_dots_cs_nc<5, U>(ws, j, w);
+    case 6: return launch_axpy_dots_cs_nc<6, U>(ws, j, w);
+    case 7: return launch_axpy_dots_cs_nc<7, U>(ws, j, w);
+    case 8: return launch_axpy_dots_cs_nc<8, U>(ws, j, w);
+    case 9: return launch_axpy_dots_cs_nc<9, U>(ws, j, w);
+    default: return launch_axpy_dots_cs_nc<10, U>(ws, j, w);
+  }
+}
+inline int launch_axpy_dots(ks_workspace* ws, int j, double* w) {
+  static const int variant = env_int("KS_FUSED_VARIANT", 2);  // 0: per-lane columns, 1: column split U=1, 2: U=2
+  if (variant == 1) return launch_axpy_dots_cs<1>(ws, j, w);
+  if (variant == 2) return launch_axpy_dots_cs<2>(ws, j, w);
+  switch ((j + 3) / 4) {
+    case 1: return launch_axpy_dots_nc<1, 2>(ws, j, w);
+    case 2: return launch_axpy_dots_nc<2, 2>(ws, j, w);
+    case 3: return launch_axpy_dots_nc<3, 2>(ws, j, w);
+    case 4: return launch_axpy_dots_nc<4, 2>(ws, j, w);
+    case 5: return launch_axpy_dots_nc<5, 2>(ws, j, w);
+    case 6: return launch_axpy_dots_nc<6, 1>(ws, j, w);
+    case 7: return launch_axpy_dots_nc<7, 1>(ws, j, w);
+    case 8: return launch_axpy_dots_nc<8, 1>(ws, j, w);
+    case 9: return launch_axpy_dots_nc<9, 1>(ws, j, w);
+    default: return launch_axpy_dots_nc<10, 1>(ws, j, w);
   }
 }
 
@@ -499,23 +553,60 @@ template <class D> void enqueue_orthogonalize(ks_workspace* ws, int j) {
   D* Hcol = Hd + (size_t)(j - 1) * ldh;
   const D* V = static_cast<const D*>(ws->V);
   const double nb8 = (double)ws->n * sizeof(D);  // bytes of one column
-  for (int pass = 1; pass <= 2; ++pass) {
-    int nbd;
-    {
-      ProfScope ps(ws->ctx, KSP_DOTS, nb8 * (j + 1));       // read V[:,0:j) and w
-      nbd = launch_dots<D>(ws, j, w, pass, ws->st);
+  const bool fused = sizeof(D) == 8 && j <= 40 && env_int("KS_NO_FUSE", 0) == 0;
+  if constexpr (sizeof(D) == 8) {
+    if (fused) {
+      // pass 1 inner products
+      int nbd;
+      {
+        ProfScope ps(ws->ctx, KSP_DOTS, nb8 * (j + 1));
+        nbd = launch_dots<D>(ws, j, w, 1, ws->st);
+      }
+      {
+        ProfScope ps(ws->ctx, KSP_FIN, 0.0);
+        launch_fin_dots<D>(ws, nbd, j, Hcol, 1, ws->st);
+      }
+      // pass 1 projection + (speculative) pass 2 inner products: V is read once for both.
+      // algorithmic bytes = axpy (j+2 columns) + dots (j+1 columns) of the un-fused sequence
+      int nbf;
+      {
+        ProfScope ps(ws->ctx, KSP_AXPY, nb8 * (2 * j + 3));
+        nbf = launch_axpy_dots(ws, j, w);
+      }
+      {
+        ProfScope ps(ws->ctx, KSP_FIN, 0.0);
+        launch_fin_norm<D>(ws, nbf, j, Hcol + j, 1, ws->st);   // decides whether pass 2 is taken
+        launch_fin_dots<D>(ws, nbf, j, Hcol, 2, ws->st);       // (skips itself otherwise)
+      }
+      {
+        ProfScope ps(ws->ctx, KSP_AXPY, nb8 * (j + 2));
+        ksd::k_axpy<D><<<ws->nb, kBlock, 0, s>>>(V, ws->ld, j, w, static_cast<const D*>(ws->coef), ws->partial2, 2, ws->st);
+      }
+      {
+        ProfScope ps(ws->ctx, KSP_FIN, 0.0);
+        launch_fin_norm<D>(ws, ws->nb, j, Hcol + j, 2, ws->st);
+      }
     }
-    {
-      ProfScope ps(ws->ctx, KSP_FIN, 0.0);
-      launch_fin_dots<D>(ws, nbd, j, Hcol, pass, ws->st);
-    }
-    {
-      ProfScope ps(ws->ctx, KSP_AXPY, nb8 * (j + 2));       // read V[:,0:j), read + write w
-      ksd::k_axpy<D><<<ws->nb, kBlock, 0, s>>>(V, ws->ld, j, w, static_cast<const D*>(ws->coef), ws->partial2, pass, ws->st);
-    }
-    {
-      ProfScope ps(ws->ctx, KSP_FIN, 0.0);
-      launch_fin_norm<D>(ws, j, Hcol + j, pass, ws->st);
+  }
+  if (!fused) {
+    for (int pass = 1; pass <= 2; ++pass) {
+      int nbd;
+      {
+        ProfScope ps(ws->ctx, KSP_DOTS, nb8 * (j + 1));       // read V[:,0:j) and w
+        nbd = launch_dots<D>(ws, j, w, pass, ws->st);
+      }
+      {
+        ProfScope ps(ws->ctx, KSP_FIN, 0.0);
+        launch_fin_dots<D>(ws, nbd, j, Hcol, pass, ws->st);
+      }
+      {
+        ProfScope ps(ws->ctx, KSP_AXPY, nb8 * (j + 2));       // read V[:,0:j), read + write w
+        ksd::k_axpy<D><<<ws->nb, kBlock, 0, s>>>(V, ws->ld, j, w, static_cast<const D*>(ws->coef), ws->partial2, pass, ws->st);
+      }
+      {
+        ProfScope ps(ws->ctx, KSP_FIN, 0.0);
+        launch_fin_norm<D>(ws, ws->nb, j, Hcol + j, pass, ws->st);
+      }
     }
   }
   {

@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace ksd {
 
 struct cd {
@@ -57,6 +59,29 @@ __device__ __forceinline__ cd ld_pack(const cd* p) {
 }
 __device__ __forceinline__ void st_pack(double* p, double2 v) { *reinterpret_cast<double2*>(p) = v; }
 __device__ __forceinline__ void st_pack(cd* p, cd v) { *reinterpret_cast<double2*>(p) = make_double2(v.x, v.y); }
+
+// Non-temporal (streaming) forms: V columns, matrix values/indices and the updated vector are touched
+// once per kernel; keeping them out of L2 is worth ~5 % on reads and removes most of the read/write
+// interference of the update kernels on gfx950 (tools/streambench.hip).
+__device__ __forceinline__ double2 ld_pack_nt(const double* p) {
+  double2 v;
+  v.x = __builtin_nontemporal_load(p);
+  v.y = __builtin_nontemporal_load(p + 1);
+  return v;
+}
+__device__ __forceinline__ cd ld_pack_nt(const cd* p) {
+  const double* q = reinterpret_cast<const double*>(p);
+  return cd{__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1)};
+}
+__device__ __forceinline__ void st_pack_nt(double* p, double2 v) {
+  __builtin_nontemporal_store(v.x, p);
+  __builtin_nontemporal_store(v.y, p + 1);
+}
+__device__ __forceinline__ void st_pack_nt(cd* p, cd v) {
+  double* q = reinterpret_cast<double*>(p);
+  __builtin_nontemporal_store(v.x, q);
+  __builtin_nontemporal_store(v.y, q + 1);
+}
 
 __device__ __forceinline__ double zero_of(double) { return 0.0; }
 __device__ __forceinline__ cd zero_of(cd) { return cd{0.0, 0.0}; }
@@ -232,7 +257,7 @@ __global__ void __launch_bounds__(kBlock)
 template <class T, int NC4>
 __global__ void __launch_bounds__(kBlock)
     k_dots(const T* __restrict__ V, int64_t ldv, int j, const T* __restrict__ w, T* __restrict__ partial,
-           int pstride, int norm_slot, int pass, const DevState* __restrict__ st) {
+           int pnb, int norm_slot, int pass, const DevState* __restrict__ st) {
   if (st) {
     if (st->breakdown >= 0) return;
     if (pass == 2 && !st->reorth) return;
@@ -255,7 +280,7 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int cc = c < jm1 ? c : jm1;  // clamp: ragged tail re-reads the last real column
-      const P v = ld_pack(V + (int64_t)cc * ldv + r);
+      const P v = ld_pack_nt(V + (int64_t)cc * ldv + r);
       dot_acc(acc[c], v, wv);
     }
   }
@@ -281,51 +306,53 @@ __global__ void __launch_bounds__(kBlock)
     T s = red[0][src];
 #pragma unroll
     for (int wv = 1; wv < kBlock / 64; ++wv) s = add_(s, red[wv][src]);
-    partial[(int64_t)blockIdx.x * pstride + (c < j ? c : norm_slot)] = s;
+    partial[(int64_t)(c < j ? c : norm_slot) * pnb + blockIdx.x] = s;  // [column][workgroup]
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// FIN_DOTS (one workgroup): h = sum_b partial[b][0..j];  mode 0: reduce + post (single GPU);
-// mode 1: reduce only -> red (then RCCL all-reduce);  mode 2: post only from red.
-// post: pass 1: H[0:j, j-1] = h, coef = h, rnorm = sqrt(h[j])     (src/expansion.jl:81,84)
-//       pass 2: H[0:j, j-1] += h, coef = h                        (src/expansion.jl:93,95)
+// FIN_DOTS: h[c] = sum_b partial[c][b], ONE WORKGROUP PER COLUMN c = 0..j (column j = |w|^2), every
+// thread a few independent loads + a fixed-shape LDS tree (deterministic).
+//   mode 0: reduce + post (single GPU);  mode 1: reduce only -> red[c] (then RCCL all-reduce);
+//   mode 2: post only from red (launched with one workgroup per column as well).
+// post: pass 1: H[c, j-1] = h[c], coef[c] = h[c], rnorm = sqrt(h[j])      (src/expansion.jl:81,84)
+//       pass 2: H[c, j-1] += h[c], coef[c] = h[c]                          (src/expansion.jl:93,95)
 // ------------------------------------------------------------------------------------------------
 template <class T>
 __global__ void __launch_bounds__(kBlock)
-    k_fin_dots(const T* __restrict__ partial, int nb, int pstride, int j, T* __restrict__ red, T* __restrict__ Hcol,
+    k_fin_dots(const T* __restrict__ partial, int nb, int pnb, int j, T* __restrict__ red, T* __restrict__ Hcol,
                T* __restrict__ coef, int pass, int mode, DevState* __restrict__ st) {
   if (st->breakdown >= 0) return;
   if (pass == 2 && !st->reorth) return;
   __shared__ T sm[kBlock];
   const int tid = threadIdx.x;
-  const int cnt = j + 1;
-  for (int c0 = 0; c0 < cnt; c0 += 64) {
-    const int c = c0 + (tid & 63);
-    T s = zero_of(T{});
-    if (mode != 2) {
-      if (c < cnt)
-        for (int b = tid >> 6; b < nb; b += kBlock / 64) s = add_(s, partial[(int64_t)b * pstride + c]);
-      sm[tid] = s;
+  const int c = blockIdx.x;  // 0..j
+  T s = zero_of(T{});
+  if (mode != 2) {
+    const T* pc = partial + (int64_t)c * pnb;
+    for (int b = tid; b < nb; b += kBlock) s = add_(s, pc[b]);
+    sm[tid] = s;
+    __syncthreads();
+    for (int off = kBlock / 2; off >= 1; off >>= 1) {
+      if (tid < off) sm[tid] = add_(sm[tid], sm[tid + off]);
       __syncthreads();
-      if (tid < 64) {
-        s = add_(add_(sm[tid], sm[tid + 64]), add_(sm[tid + 128], sm[tid + 192]));
-        if (c < cnt && mode == 1) red[c] = s;
-      }
-      __syncthreads();
-    } else if (tid < 64 && c < cnt) {
-      s = red[c];
     }
-    if (mode != 1 && tid < 64 && c < cnt) {
-      if (c < j) {
-        coef[c] = s;
-        Hcol[c] = (pass == 1) ? s : add_(Hcol[c], s);
-      } else if (pass == 1) {
-        double v;
-        if constexpr (sizeof(T) == 8) v = s; else v = s.x;
-        st->rnorm = sqrt(v);
-      }
+    s = sm[0];
+    if (mode == 1) {
+      if (tid == 0) red[c] = s;
+      return;
     }
+  } else {
+    s = red[c];
+  }
+  if (tid != 0) return;
+  if (c < j) {
+    coef[c] = s;
+    Hcol[c] = (pass == 1) ? s : add_(Hcol[c], s);
+  } else if (pass == 1) {
+    double v;
+    if constexpr (sizeof(T) == 8) v = s; else v = s.x;
+    st->rnorm = sqrt(v);
   }
 }
 
@@ -343,6 +370,7 @@ __global__ void __launch_bounds__(kBlock)
   }
   using P = typename Pack<T>::type;
   constexpr int R = Pack<T>::R;
+  constexpr int U = 4;  // packs per lane per iteration: 4 x 4 KiB contiguous per column and workgroup
   __shared__ T g[128];
   __shared__ double red[kBlock / 64];
   // coefficients padded with zeros to a multiple of 8 (ragged tail multiplies a re-read column by 0)
@@ -356,28 +384,210 @@ __global__ void __launch_bounds__(kBlock)
     if (threadIdx.x < 128) g[threadIdx.x] = threadIdx.x < jc ? coef[jb + threadIdx.x] : zero_of(T{});
     __syncthreads();
     const bool last = jb + 128 >= j;
-    for (int64_t p = pb + threadIdx.x; p < pe; p += kBlock) {
-      const int64_t r = p * R;
-      P s = zero_pack(T{});
-      for (int c0 = 0; c0 < jc; c0 += 8) {
+    for (int64_t p = pb + threadIdx.x; p < pe; p += kBlock * U) {
+      int64_t r[U];
+      bool ok[U];
+      P s[U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int c = c0 + u;
+      for (int u = 0; u < U; ++u) {
+        const int64_t q = p + (int64_t)u * kBlock;
+        ok[u] = q < pe;
+        r[u] = (ok[u] ? q : p) * R;  // out-of-range slots redo slot 0 (identical value, not stored)
+        s[u] = zero_pack(T{});
+      }
+      for (int c0 = 0; c0 < jc; c0 += 4) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int c = c0 + t;
           const int cc = (jb + c) < jm1 ? (jb + c) : jm1;
-          const P v = ld_pack(V + (int64_t)cc * ldv + r);
-          axpy_acc(s, v, g[c]);
+          const T gc = g[c];
+#pragma unroll
+          for (int u = 0; u < U; ++u) axpy_acc(s[u], ld_pack_nt(V + (int64_t)cc * ldv + r[u]), gc);
         }
       }
-      P wv = ld_pack(w + r);
-      wv = sub_pack(wv, s);
-      st_pack(w + r, wv);
-      if (last) nrm += nrm2_pack(wv);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        P wv = ld_pack(w + r[u]);
+        wv = sub_pack(wv, s[u]);
+        if (ok[u]) {
+          st_pack_nt(w + r[u], wv);
+          if (last) nrm += nrm2_pack(wv);
+        }
+      }
     }
   }
   const double s = wave_sum(nrm);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) partial2[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ------------------------------------------------------------------------------------------------
+// AXPY+DOTS (Float64): the first DGKS projection fused with the inner products of the second one.
+//     w' = w - V[:,0:j) h                 (mul!(v, Vprev, h, -1, 1),  src/expansion.jl:85)
+//     partial2[b]  = sum |w'|^2            (norm(v),                   src/expansion.jl:88)
+//     partial[c][b] = sum V[r,c] w'[r]     (correction = Vprev' * v,   src/expansion.jl:93)
+// The correction inner products are row-local once w' is known, so each lane keeps its slice of V in
+// registers between the two uses and V is streamed from HBM ONCE for both -- the step reads V three
+// times instead of the reference's four whenever the DGKS test asks for the second pass (it always
+// does for operators with a dominant diagonal such as the Laplacian).  The correction is speculative:
+// k_fin_norm decides afterwards whether it is used (src/expansion.jl:91).
+// RPL = rows per lane: 2 (16-byte loads) while 4*NC4 <= 20 columns, 1 above (register budget).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double ldp(const double* p, double) { return *p; }
+__device__ __forceinline__ double2 ldp(const double* p, double2) { return *reinterpret_cast<const double2*>(p); }
+__device__ __forceinline__ double ldp_nt(const double* p, double) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ double2 ldp_nt(const double* p, double2) { return ld_pack_nt(p); }
+__device__ __forceinline__ void stp_nt(double* p, double v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void stp_nt(double* p, double2 v) { st_pack_nt(p, v); }
+__device__ __forceinline__ void fma_p(double& s, double v, double g) { s = fma(v, g, s); }
+__device__ __forceinline__ void fma_p(double2& s, double2 v, double g) { s.x = fma(v.x, g, s.x); s.y = fma(v.y, g, s.y); }
+__device__ __forceinline__ double sub_p(double a, double b) { return a - b; }
+__device__ __forceinline__ double2 sub_p(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double nrm_p(double a) { return a * a; }
+__device__ __forceinline__ double nrm_p(double2 a) { return fma(a.x, a.x, a.y * a.y); }
+__device__ __forceinline__ void dot_p(double& acc, double v, double w) { acc = fma(v, w, acc); }
+__device__ __forceinline__ void dot_p(double& acc, double2 v, double2 w) { acc = fma(v.x, w.x, fma(v.y, w.y, acc)); }
+
+template <int NC4, int RPL>
+__global__ void __launch_bounds__(kBlock)
+    k_axpy_dots(const double* __restrict__ V, int64_t ldv, int j, double* __restrict__ w, const double* __restrict__ coef,
+                double* __restrict__ partial, int pnb, double* __restrict__ partial2, const DevState* __restrict__ st) {
+  if (st && st->breakdown >= 0) return;
+  using P = typename std::conditional<RPL == 2, double2, double>::type;
+  constexpr int NC = 4 * NC4;
+  __shared__ double g[NC];
+  __shared__ double red[kBlock / 64][NC + 1];
+  if (threadIdx.x < NC) g[threadIdx.x] = threadIdx.x < j ? coef[threadIdx.x] : 0.0;
+  __syncthreads();
+  double acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+  double nrm = 0.0;
+  int64_t pb, pe;
+  block_range(ldv / RPL, blockIdx.x, gridDim.x, pb, pe);
+  const int jm1 = j - 1;
+  for (int64_t p = pb + threadIdx.x; p < pe; p += kBlock) {
+    const int64_t r = p * RPL;
+    P v[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int cc = c < jm1 ? c : jm1;
+      v[c] = ldp_nt(V + (int64_t)cc * ldv + r, P{});
+    }
+    P s = ldp(w + r, P{});
+    P t = P{};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) fma_p(t, v[c], g[c]);  // padded coefficients are zero
+    s = sub_p(s, t);
+    stp_nt(w + r, s);
+    nrm += nrm_p(s);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) dot_p(acc[c], v[c], s);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const double sred = wave_sum(acc[c]);
+    if (lane == 0) red[wave][c] = sred;
+  }
+  {
+    const double sred = wave_sum(nrm);
+    if (lane == 0) red[wave][NC] = sred;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c <= j; c += kBlock) {
+    const int src = c < j ? c : NC;
+    const double sred = (red[0][src] + red[1][src]) + (red[2][src] + red[3][src]);
+    if (c < j) partial[(int64_t)c * pnb + blockIdx.x] = sred;
+    else partial2[blockIdx.x] = sred;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// AXPY+DOTS, column-split form (Float64): same contract as k_axpy_dots, but the j columns are dealt
+// round-robin to the 4 waves of the workgroup (wave q owns columns q, q+4, ...), all waves walk the SAME
+// rows.  Each lane therefore keeps only NCW = ceil(j/4) column slices (16-byte loads, 2 rows per lane)
+// instead of j, which lifts occupancy from 2 to 4-6 waves per SIMD.  The per-row partial sums of the
+// projection are exchanged through a double-buffered 8 KiB LDS array (one barrier per iteration); the
+// second-pass inner products then need no cross-wave reduction at all, because every column belongs to
+// exactly one wave.  Summation order is fixed (wave 0..3), so results are run-to-run deterministic.
+// ------------------------------------------------------------------------------------------------
+template <int NCW, int U>
+__global__ void __launch_bounds__(kBlock)
+    k_axpy_dots_cs(const double* __restrict__ V, int64_t ldv, int j, double* __restrict__ w,
+                   const double* __restrict__ coef, double* __restrict__ partial, int pnb,
+                   double* __restrict__ partial2, const DevState* __restrict__ st) {
+  if (st && st->breakdown >= 0) return;
+  __shared__ double2 tbuf[2][4][U][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const double* colp[NCW];
+  double g[NCW];
+  double acc[NCW];
+#pragma unroll
+  for (int i = 0; i < NCW; ++i) {
+    const int c = wave + 4 * i;
+    const bool valid = c < j;
+    colp[i] = V + (int64_t)(valid ? c : j - 1) * ldv;
+    g[i] = valid ? coef[c] : 0.0;
+    acc[i] = 0.0;
+  }
+  double nrm = 0.0;
+  int64_t pb, pe;
+  block_range(ldv / 2, blockIdx.x, gridDim.x, pb, pe);
+  int it = 0;
+  for (int64_t base = pb; base < pe; base += 64 * U, ++it) {
+    int64_t r[U];
+    bool ok[U];
+    double2 v[NCW][U];
+    double2 wv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t q = base + u * 64 + lane;
+      ok[u] = q < pe;
+      r[u] = (ok[u] ? q : pb) * 2;
+    }
+#pragma unroll
+    for (int i = 0; i < NCW; ++i)
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[i][u] = ld_pack_nt(colp[i] + r[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) wv[u] = ld_pack(w + r[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      double2 t = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int i = 0; i < NCW; ++i) { t.x = fma(v[i][u].x, g[i], t.x); t.y = fma(v[i][u].y, g[i], t.y); }
+      tbuf[it & 1][wave][u][lane] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double2 t0 = tbuf[it & 1][0][u][lane], t1 = tbuf[it & 1][1][u][lane];
+      const double2 t2 = tbuf[it & 1][2][u][lane], t3 = tbuf[it & 1][3][u][lane];
+      double2 wn;
+      wn.x = wv[u].x - ((t0.x + t1.x) + (t2.x + t3.x));
+      wn.y = wv[u].y - ((t0.y + t1.y) + (t2.y + t3.y));
+      if (!ok[u]) wn = make_double2(0.0, 0.0);
+      if (wave == 0 && ok[u]) {
+        st_pack_nt(w + r[u], wn);
+        nrm += fma(wn.x, wn.x, wn.y * wn.y);
+      }
+#pragma unroll
+      for (int i = 0; i < NCW; ++i) acc[i] = fma(v[i][u].x, wn.x, fma(v[i][u].y, wn.y, acc[i]));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NCW; ++i) {
+    const double sred = wave_sum(acc[i]);
+    const int c = wave + 4 * i;
+    if (lane == 0 && c < j) partial[(int64_t)c * pnb + blockIdx.x] = sred;
+  }
+  if (wave == 0) {
+    const double sred = wave_sum(nrm);
+    if (lane == 0) partial2[blockIdx.x] = sred;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--grid", type=int, default=216, help="grid points per dimension (216^3 ~ 1e7 rows)")
     ap.add_argument("--nev", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--no-profile", action="store_true", help="skip the second (HIP-event instrumented) pass")
     args = ap.parse_args()
 
     import torch
@@ -126,17 +126,22 @@ def main():
 
     for _ in range(args.warmup):
         cycle(False)
-    if not args.no_profile:
-        ctx.profile_reset()
-        ctx.profile_enable(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         cycle(True)
     barrier()
     elapsed = time.perf_counter() - t0
+    # Per-kernel HIP-event timing: the event pairs (recorded on the library's own stream around every
+    # launch) cost ~4 % of throughput on this launch-dense path, so they are NOT left on while `value`
+    # is measured; the same K cycles are repeated immediately afterwards with events on and the
+    # per-kernel figures of `roofline` come from that second pass (same workload, same state machine).
     prof = None
     if not args.no_profile:
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        for _ in range(args.steps):
+            cycle(False)
         prof = ctx.profile_get()
         ctx.profile_enable(False)
     if dist is not None:
