@@ -116,8 +116,11 @@ struct ks_ctx {
   int nblocks() const { return num_cu * bpc; }
   void use() const { KS_HIP(hipSetDevice(device)); }
   // in-place sum over ranks of `count` doubles living in device memory
+  // A context created with ks_ctx_create_dist always goes through RCCL (even with nranks == 1, which is
+  // how the collective code path is exercised on a single-GPU box).
+  bool distributed() const { return comm != nullptr; }
   void allreduce(double* dev, int count) {
-    if (nranks > 1) KS_NCCL(ncclAllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, comm, stream));
+    if (comm) KS_NCCL(ncclAllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, comm, stream));
   }
 };
 
@@ -470,7 +473,7 @@ template <class D> void launch_fin_dots(ks_workspace* ws, int nbd, int j, D* Hco
   D* coef = static_cast<D*>(ws->coef);
   // one workgroup per column (0..j-1 = inner products, j = |w|^2; pass 2 ignores column j)
   const int ncol = pass == 1 ? j + 1 : j;
-  if (c->nranks == 1) {
+  if (!c->distributed()) {
     ksd::k_fin_dots<D><<<ncol, kBlock, 0, c->stream>>>(partial, nbd, ws->nb, j, red, Hcol, coef, pass, 0, st);
   } else {
     ksd::k_fin_dots<D><<<ncol, kBlock, 0, c->stream>>>(partial, nbd, ws->nb, j, red, Hcol, coef, pass, 1, st);
@@ -482,7 +485,7 @@ template <class D> void launch_fin_dots(ks_workspace* ws, int nbd, int j, D* Hco
 template <class D> void launch_fin_norm(ks_workspace* ws, int nbp, int j, D* Hsub, int pass, DevState* st) {
   ks_ctx* c = ws->ctx;
   double* red = reinterpret_cast<double*>(ws->red);
-  if (c->nranks == 1) {
+  if (!c->distributed()) {
     ksd::k_fin_norm<D><<<1, kBlock, 0, c->stream>>>(ws->partial2, nbp, red, Hsub, j, pass, 0, st);
   } else {
     ksd::k_fin_norm<D><<<1, kBlock, 0, c->stream>>>(ws->partial2, nbp, red, Hsub, j, pass, 1, st);
@@ -987,7 +990,7 @@ int ks_operator_csr(ks_ctx* ctx, int64_t nrows_local, int64_t ncols, int64_t nnz
     KS_REQUIRE(nrows_local >= 0 && ncols >= 0 && nnz >= 0, KS_ERR_ARGUMENT, "negative size");
     KS_REQUIRE(ctx->nranks > 1 || nrows_local == ncols, KS_ERR_DIMENSION,
                "matrix is not square: dimensions are (" + std::to_string(nrows_local) + ", " + std::to_string(ncols) + ")");
-    KS_REQUIRE(ctx->nranks == 1, KS_ERR_ARGUMENT, "use ks_operator_csr_dist on a multi-GPU context");
+    KS_REQUIRE(ctx->nranks == 1, KS_ERR_ARGUMENT, "use ks_operator_csr_dist on a multi-rank context");
     KS_REQUIRE(layout == KS_CSR || layout == KS_CSC, KS_ERR_ARGUMENT, "bad layout");
     KS_REQUIRE(index_type == KS_I32 || index_type == KS_I64, KS_ERR_ARGUMENT, "bad index type");
     ctx->use();

@@ -478,3 +478,49 @@ def test_full_size_properties_1e6():
     if F.nconverged:
         dres, dorth = F.workspace.residual_norms(op, F.nconverged)
         assert dres < 1e-7 * F.nconverged and dorth < 1e-12
+
+
+# ------------------------------------------------------------------ RCCL code path on one GPU
+def test_rccl_path_single_rank_communicator():
+    """A 1-rank RCCL communicator drives the distributed code path of the library on a single GPU:
+    reduce-only / all-reduce / post kernels of the DGKS step, and the halo plan executed with
+    ncclSend/ncclRecv (here: a self exchange that copies own rows into ghost slots)."""
+    from arnoldimethod_jl_amd import api, dist as ksd
+
+    ctx = pkg.Context(0, 0, 1, pkg.Context.unique_id())
+    mx, my, mz = 6, 7, 8
+    A = laplace3d(mx, my, mz)
+    n = A.shape[0]
+    # periodic closure in z implemented through GHOSTS: row i also couples (-1) to row (i + n/2) mod n,
+    # addressed as a ghost column that the plan fills from this very rank.
+    half = n // 2
+    extra_cols = (np.arange(n) + half) % n
+    ghosts = np.unique(extra_cols)                     # all rows, each once
+    ip = np.zeros(n + 1, dtype=np.int64)
+    rows_idx, rows_val = [], []
+    Ac = A.tocsr()
+    for i in range(n):
+        c = Ac.indices[Ac.indptr[i]:Ac.indptr[i + 1]].astype(np.int64)
+        v = Ac.data[Ac.indptr[i]:Ac.indptr[i + 1]]
+        rows_idx.append(np.concatenate([c, [n + np.searchsorted(ghosts, extra_cols[i])]]))
+        rows_val.append(np.concatenate([v, [-0.5]]))
+        ip[i + 1] = ip[i] + len(c) + 1
+    plan = ksd.HaloPlan(n_local=n, nghost=len(ghosts), neigh=np.array([0], dtype=np.int32), send_ptr=np.array([0, len(ghosts)], dtype=np.int64),
+                        send_idx=ghosts.astype(np.int32), recv_cnt=np.array([len(ghosts)], dtype=np.int64), ghost_global=ghosts,
+                        colidx_local=np.concatenate(rows_idx).astype(np.int32))
+    op = ksd.dist_operator(api, ctx, ip, np.concatenate(rows_val), plan, n)
+    P = sp.csr_matrix((np.full(n, -0.5), (np.arange(n), extra_cols)), shape=(n, n))
+    B = (A + P).tocsr()
+    ws = pkg.ArnoldiWorkspace(n, 20, np.float64, ctx=ctx)
+    x = oa.uniform_hash(5, np.arange(n)) - 0.5
+    ws.set_col(0, x)
+    ws.apply(op, 0, 1)
+    np.testing.assert_allclose(ws.col(1), B @ x, rtol=1e-13, atol=1e-13)
+    # whole solver through the all-reduce variants of the reduction kernels
+    v1 = oa.uniform_hash(oa.DEFAULT_SEED, np.arange(n))
+    F, hist = pkg.partialschur_(op, pkg.ArnoldiWorkspace(v1, 20, ctx=ctx), nev=4, which="LR", tol=1e-10)
+    ref, rhist = oa.partialschur(B, v1=v1, nev=4, which="LR", tol=1e-10)
+    assert hist.converged and hist.mvproducts == rhist.mvproducts
+    np.testing.assert_allclose(np.sort_complex(F.eigenvalues), np.sort_complex(ref.eigenvalues), atol=1e-9)
+    Q, R = F.Q, np.array(F.R)
+    assert np.linalg.norm(B @ Q - Q @ R) < 1e-8
