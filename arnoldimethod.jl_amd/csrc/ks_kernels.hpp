@@ -272,16 +272,19 @@ __global__ void __launch_bounds__(kBlock)
 
   int64_t pb, pe;
   block_range(ldv / R, blockIdx.x, gridDim.x, pb, pe);
-  const int jm1 = j - 1;
   for (int64_t p = pb + threadIdx.x; p < pe; p += kBlock) {
     const int64_t r = p * R;
     const P wv = ld_pack(w + r);
     nrm += nrm2_pack(wv);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const int cc = c < jm1 ? c : jm1;  // clamp: ragged tail re-reads the last real column
-      const P v = ld_pack_nt(V + (int64_t)cc * ldv + r);
-      dot_acc(acc[c], v, wv);
+      // only the last 3 columns of the 4-wide template granule can be absent; `c < j` is wave-uniform,
+      // so the ragged tail costs a scalar branch and NO extra memory traffic (non-temporal loads of a
+      // clamped duplicate column would go back to HBM).
+      if (c < NC - 3 || c < j) {
+        const P v = ld_pack_nt(V + (int64_t)c * ldv + r);
+        dot_acc(acc[c], v, wv);
+      }
     }
   }
 
@@ -360,6 +363,22 @@ __global__ void __launch_bounds__(kBlock)
 // AXPY:  w -= V[:, 0:j) coef;  partial2[b] = sum |w|^2      (mul!(v, Vprev, h, -1, 1) + norm(v),
 // src/expansion.jl:85,88 / :94,96)
 // ------------------------------------------------------------------------------------------------
+template <class T, int U, int REM>
+__device__ __forceinline__ void axpy_tail(typename Pack<T>::type (&s)[U], const T* __restrict__ Vc, int64_t ldv,
+                                          const int64_t (&r)[U], const T* g) {
+  typename Pack<T>::type tv[REM][U];
+#pragma unroll
+  for (int t = 0; t < REM; ++t)
+#pragma unroll
+    for (int u = 0; u < U; ++u) tv[t][u] = ld_pack_nt(Vc + (int64_t)t * ldv + r[u]);
+#pragma unroll
+  for (int t = 0; t < REM; ++t) {
+    const T gc = g[t];
+#pragma unroll
+    for (int u = 0; u < U; ++u) axpy_acc(s[u], tv[t][u], gc);
+  }
+}
+
 template <class T>
 __global__ void __launch_bounds__(kBlock)
     k_axpy(const T* __restrict__ V, int64_t ldv, int j, T* __restrict__ w, const T* __restrict__ coef,
@@ -377,7 +396,6 @@ __global__ void __launch_bounds__(kBlock)
   int64_t pb, pe;
   block_range(ldv / R, blockIdx.x, gridDim.x, pb, pe);
   double nrm = 0.0;
-  const int jm1 = j - 1;
   for (int jb = 0; jb < j; jb += 128) {  // chunks of <= 128 columns (maxdim > 128 loops)
     const int jc = (j - jb) < 128 ? (j - jb) : 128;
     __syncthreads();
@@ -395,15 +413,23 @@ __global__ void __launch_bounds__(kBlock)
         r[u] = (ok[u] ? q : p) * R;  // out-of-range slots redo slot 0 (identical value, not stored)
         s[u] = zero_pack(T{});
       }
-      for (int c0 = 0; c0 < jc; c0 += 4) {
+      int c0 = 0;
+      for (; c0 + 4 <= jc; c0 += 4) {  // full groups of 4 columns: 16 independent loads in flight
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const int c = c0 + t;
-          const int cc = (jb + c) < jm1 ? (jb + c) : jm1;
-          const T gc = g[c];
+          const T gc = g[c0 + t];
+          const T* colp = V + (int64_t)(jb + c0 + t) * ldv;
 #pragma unroll
-          for (int u = 0; u < U; ++u) axpy_acc(s[u], ld_pack_nt(V + (int64_t)cc * ldv + r[u]), gc);
+          for (int u = 0; u < U; ++u) axpy_acc(s[u], ld_pack_nt(colp + r[u]), gc);
         }
+      }
+      // ragged tail: 1..3 columns, straight-line code per case so all loads issue together; no
+      // duplicate reads (non-temporal loads of a clamped column would go back to HBM).
+      switch (jc - c0) {
+        case 1: axpy_tail<T, U, 1>(s, V + (int64_t)(jb + c0) * ldv, ldv, r, g + c0); break;
+        case 2: axpy_tail<T, U, 2>(s, V + (int64_t)(jb + c0) * ldv, ldv, r, g + c0); break;
+        case 3: axpy_tail<T, U, 3>(s, V + (int64_t)(jb + c0) * ldv, ldv, r, g + c0); break;
+        default: break;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -533,6 +559,7 @@ __global__ void __launch_bounds__(kBlock)
     g[i] = valid ? coef[c] : 0.0;
     acc[i] = 0.0;
   }
+  const bool last_valid = (wave + 4 * (NCW - 1)) < j;
   double nrm = 0.0;
   int64_t pb, pe;
   block_range(ldv / 2, blockIdx.x, gridDim.x, pb, pe);
@@ -549,9 +576,15 @@ __global__ void __launch_bounds__(kBlock)
       r[u] = (ok[u] ? q : pb) * 2;
     }
 #pragma unroll
-    for (int i = 0; i < NCW; ++i)
+    for (int i = 0; i < NCW; ++i) {
+      if (i < NCW - 1 || last_valid) {  // wave-uniform: only this wave's last column can be absent
 #pragma unroll
-      for (int u = 0; u < U; ++u) v[i][u] = ld_pack_nt(colp[i] + r[u]);
+        for (int u = 0; u < U; ++u) v[i][u] = ld_pack_nt(colp[i] + r[u]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[i][u] = make_double2(0.0, 0.0);
+      }
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) wv[u] = ld_pack(w + r[u]);
 #pragma unroll

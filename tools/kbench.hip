@@ -23,7 +23,7 @@ int main(int argc, char** argv) {
   for (long off = 0; off + (long)h.size() <= ld * NC; off += h.size() * 29) CK(hipMemcpy(V + off, h.data(), h.size() * 8, hipMemcpyHostToDevice));
   const int cu = 256;
   double* w = V + ld * 40;
-  const int j = 40;
+  const int j = argc > 1 ? atoi(argv[1]) : 40;
   const double GB = (double)ld * 8 / 1e6;  // per column, in GB*1e3/ms units
   for (int bpc : {4, 6}) {
     float ms;
