@@ -32,11 +32,13 @@ struct DevState {
   double rnorm;       // norm before the (current) projection     src/expansion.jl:81,92
   double wnorm;       // norm after the projection                src/expansion.jl:88,96
   double inv_norm;    // 1 / wnorm of the step just finished (consumed by k_scale)
+  double rnorm2;      // rnorm of the second pass (= wnorm of the first, src/expansion.jl:92)
   int32_t reorth;     // 1 while the DGKS second pass of the current step is pending
   int32_t breakdown;  // step index j at which orthogonalize! returned false, else -1
   int32_t n_reorth;   // number of second passes taken in this batch
   int32_t n_steps;    // steps completed in this batch
   int32_t pad[2];
+  int32_t pad2[2];
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -624,6 +626,79 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // ------------------------------------------------------------------------------------------------
+// FIN_MID (fused path): after k_axpy_dots* both ||w'||^2 and the speculative second-pass inner
+// products c are known, so ONE reduction stage (and, multi-GPU, ONE all-reduce of j+1 doubles) serves
+// the DGKS test and the correction:   workgroup c < j reduces column c, workgroup j reduces |w'|^2.
+//   wnorm = sqrt(sum |w'|^2);   wnorm < eta * rnorm  ->  second pass: H[0:j, j-1] += c, coef = c,
+//   rnorm2 = wnorm (src/expansion.jl:91-95);  otherwise finalize like k_fin_norm (src/expansion.jl:99-108).
+// Every workgroup evaluates the (identical) test itself from read-only inputs; only workgroup j writes state.
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ T block_sum(const T* __restrict__ p, int nb, T* sm) {
+  const int tid = threadIdx.x;
+  T s = zero_of(T{});
+  for (int b = tid; b < nb; b += kBlock) s = add_(s, p[b]);
+  sm[tid] = s;
+  __syncthreads();
+  for (int off = kBlock / 2; off >= 1; off >>= 1) {
+    if (tid < off) sm[tid] = add_(sm[tid], sm[tid + off]);
+    __syncthreads();
+  }
+  const T r = sm[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_fin_mid(const double* __restrict__ partial, const double* __restrict__ partial2, int nb, int pnb, int j,
+              double* __restrict__ red, double* __restrict__ Hcol, double* __restrict__ coef, int mode,
+              DevState* __restrict__ st) {
+  if (st->breakdown >= 0) return;
+  __shared__ double sm[kBlock];
+  const int c = blockIdx.x;  // 0..j
+  double s = 0.0, nrm2 = 0.0;
+  if (mode != 2) {
+    s = block_sum(c < j ? partial + (int64_t)c * pnb : partial2, nb, sm);
+    if (mode == 1) {
+      if (threadIdx.x == 0) red[c] = s;
+      return;
+    }
+    nrm2 = (c == j) ? s : block_sum(partial2, nb, sm);
+  } else {
+    s = red[c];
+    nrm2 = red[j];
+  }
+  if (threadIdx.x != 0) return;
+  const double wnorm = sqrt(nrm2);
+  const double rnorm = st->rnorm;  // written by the previous kernel, read-only here
+  const bool reorth = wnorm < kEta * rnorm;  // src/expansion.jl:91
+  if (c < j) {
+    if (reorth) {
+      coef[c] = s;
+      Hcol[c] += s;  // h .+= correction, src/expansion.jl:95
+    }
+    return;
+  }
+  st->wnorm = wnorm;
+  if (reorth) {
+    st->reorth = 1;
+    st->rnorm2 = wnorm;  // :92
+    st->n_reorth += 1;
+    return;
+  }
+  st->reorth = 0;
+  if (wnorm <= kEta * rnorm) {  // :99
+    Hcol[j] = 0.0;
+    st->breakdown = j;
+    st->inv_norm = 0.0;
+  } else {
+    Hcol[j] = wnorm;
+    st->inv_norm = 1.0 / wnorm;
+    st->n_steps += 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // FIN_NORM (one workgroup): wnorm = sqrt(sum_b partial2[b]) and the DGKS decisions
 // (src/expansion.jl:88-108).  mode as in k_fin_dots (red[0] carries the all-reduced sum).
 //   pass 1:  wnorm <  eta*rnorm -> request second pass (rnorm <- wnorm), else finalize
@@ -661,7 +736,7 @@ __global__ void __launch_bounds__(kBlock)
   if (pass == 1) {
     if (wnorm < kEta * st->rnorm) {  // src/expansion.jl:91
       st->reorth = 1;
-      st->rnorm = wnorm;             // :92
+      st->rnorm2 = wnorm;            // :92
       st->n_reorth += 1;
       return;
     }
@@ -669,7 +744,8 @@ __global__ void __launch_bounds__(kBlock)
   } else {
     st->reorth = 0;
   }
-  if (wnorm <= kEta * st->rnorm) {   // :99
+  const double rn = (pass == 1) ? st->rnorm : st->rnorm2;
+  if (wnorm <= kEta * rn) {          // :99
     if constexpr (sizeof(T) == 8) *Hsub = 0.0; else *Hsub = cd{0.0, 0.0};
     st->breakdown = j;
     st->inv_norm = 0.0;
