@@ -360,7 +360,8 @@ struct ks_workspace {
   void* tmp2 = nullptr;
   size_t tmp2_bytes = 0;
   int pstride = 0;
-  int nb = 0;               // streaming workgroups
+  int nb = 0;               // streaming workgroups (capped for small problems)
+  int pnb = 0;              // column stride of `partial` (>= every producer's grid)
   uint64_t seed = 20240917ull;
   uint64_t rng_count = 0;
 
@@ -393,6 +394,12 @@ struct ks_workspace {
 
 namespace {
 
+inline int cap_blocks(const ks_workspace* ws, int nb, int packs_per_iter) {
+  const int64_t npacks = ws->ld * (int64_t)ws->esz / 16;
+  const int64_t want = std::max<int64_t>(1, npacks / (2 * (int64_t)packs_per_iter));
+  return (int)std::min<int64_t>(nb, want);
+}
+
 uint64_t next_seed(ks_workspace* ws) {
   const uint64_t s = ws->seed + ws->rng_count * 0x9E3779B97F4A7C15ull;
   ws->rng_count++;
@@ -412,6 +419,8 @@ template <class K> int resident_blocks(ks_ctx* ctx, K kernel, size_t smem, int& 
   }
   return ctx->num_cu * cache;
 }
+// Small problems (n = 1e6, or 1/8 of 1e7 per GPU): do not launch more workgroups than there are
+// `packs_per_iter`-sized pieces of work, two iterations each.
 
 template <class D, int NC4> int dots_blocks(ks_workspace* ws) {
   static int cache = -1;
@@ -436,7 +445,7 @@ template <class D> int dots_blocks_for(ks_workspace* ws, int nc4) {
 template <class D, int NC4>
 void launch_dots_nc(ks_workspace* ws, int nb, const D* V, int jc, const D* w, D* partial, int norm_slot, int pass,
                     const DevState* st) {
-  ksd::k_dots<D, NC4><<<nb, kBlock, 0, ws->ctx->stream>>>(V, ws->ld, jc, w, partial, ws->nb, norm_slot, pass, st);
+  ksd::k_dots<D, NC4><<<nb, kBlock, 0, ws->ctx->stream>>>(V, ws->ld, jc, w, partial, ws->pnb, norm_slot, pass, st);
 }
 
 // partial[b][0..j) = V[:,0:j)^H w (block-local), partial[b][j] = |w|^2 (block-local); returns the
@@ -444,12 +453,12 @@ void launch_dots_nc(ks_workspace* ws, int nb, const D* V, int jc, const D* w, D*
 template <class D> int launch_dots(ks_workspace* ws, int j, const D* w, int pass, const DevState* st) {
   const D* V = static_cast<const D*>(ws->V);
   D* partial = static_cast<D*>(ws->partial);
-  const int nb = dots_blocks_for<D>(ws, (std::min(j, 40) + 3) / 4);  // first chunk is the widest
+  const int nb = cap_blocks(ws, dots_blocks_for<D>(ws, (std::min(j, 40) + 3) / 4), kBlock);  // first chunk is the widest
   for (int c0 = 0; c0 < j; c0 += 40) {
     const int jc = std::min(40, j - c0);
     const int norm_slot = (c0 + 40 >= j) ? (j - c0) : -1;
     const D* Vc = V + (size_t)c0 * ws->ld;
-    D* pc = partial + (size_t)c0 * ws->nb;  // partial is [column][workgroup], column stride ws->nb
+    D* pc = partial + (size_t)c0 * ws->pnb;  // partial is [column][workgroup], column stride ws->pnb
     switch ((jc + 3) / 4) {
       case 1: launch_dots_nc<D, 1>(ws, nb, Vc, jc, w, pc, norm_slot, pass, st); break;
       case 2: launch_dots_nc<D, 2>(ws, nb, Vc, jc, w, pc, norm_slot, pass, st); break;
@@ -475,11 +484,11 @@ template <class D> void launch_fin_dots(ks_workspace* ws, int nbd, int j, D* Hco
   // one workgroup per column (0..j-1 = inner products, j = |w|^2; pass 2 ignores column j)
   const int ncol = pass == 1 ? j + 1 : j;
   if (!c->distributed()) {
-    ksd::k_fin_dots<D><<<ncol, kBlock, 0, c->stream>>>(partial, nbd, ws->nb, j, red, Hcol, coef, pass, 0, st);
+    ksd::k_fin_dots<D><<<ncol, kBlock, 0, c->stream>>>(partial, nbd, ws->pnb, j, red, Hcol, coef, pass, 0, st);
   } else {
-    ksd::k_fin_dots<D><<<ncol, kBlock, 0, c->stream>>>(partial, nbd, ws->nb, j, red, Hcol, coef, pass, 1, st);
+    ksd::k_fin_dots<D><<<ncol, kBlock, 0, c->stream>>>(partial, nbd, ws->pnb, j, red, Hcol, coef, pass, 1, st);
     c->allreduce(reinterpret_cast<double*>(red), ncol * (int)(sizeof(D) / 8));
-    ksd::k_fin_dots<D><<<ncol, 64, 0, c->stream>>>(partial, nbd, ws->nb, j, red, Hcol, coef, pass, 2, st);
+    ksd::k_fin_dots<D><<<ncol, 64, 0, c->stream>>>(partial, nbd, ws->pnb, j, red, Hcol, coef, pass, 2, st);
   }
 }
 
@@ -504,15 +513,15 @@ template <int NC4, int RPL> int launch_axpy_dots_nc(ks_workspace* ws, int j, dou
   const int nb = axpy_dots_blocks<NC4, RPL>(ws);
   ksd::k_axpy_dots<NC4, RPL><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const double*>(ws->V), ws->ld, j, w,
                                                               static_cast<const double*>(ws->coef),
-                                                              static_cast<double*>(ws->partial), ws->nb, ws->partial2, ws->st);
+                                                              static_cast<double*>(ws->partial), ws->pnb, ws->partial2, ws->st);
   return nb;
 }
 template <int NCW, int U> int launch_axpy_dots_cs_nc(ks_workspace* ws, int j, double* w) {
   static int cache = -1;
-  const int nb = resident_blocks(ws->ctx, ksd::k_axpy_dots_cs<NCW, U>, 0, cache);
+  const int nb = cap_blocks(ws, resident_blocks(ws->ctx, ksd::k_axpy_dots_cs<NCW, U>, 0, cache), 64 * U);
   ksd::k_axpy_dots_cs<NCW, U><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const double*>(ws->V), ws->ld, j, w,
                                                                static_cast<const double*>(ws->coef),
-                                                               static_cast<double*>(ws->partial), ws->nb, ws->partial2, ws->st);
+                                                               static_cast<double*>(ws->partial), ws->pnb, ws->partial2, ws->st);
   return nb;
 }
 template <int U> int launch_axpy_dots_cs(ks_workspace* ws, int j, double* w) {
@@ -586,11 +595,11 @@ template <class D> void enqueue_orthogonalize(ks_workspace* ws, int j) {
         double* Hc = reinterpret_cast<double*>(Hcol);
         double* cf = reinterpret_cast<double*>(ws->coef);
         if (!cx->distributed()) {
-          ksd::k_fin_mid<<<j + 1, kBlock, 0, s>>>(part, ws->partial2, nbf, ws->nb, j, red, Hc, cf, 0, ws->st);
+          ksd::k_fin_mid<<<j + 1, kBlock, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hc, cf, 0, ws->st);
         } else {
-          ksd::k_fin_mid<<<j + 1, kBlock, 0, s>>>(part, ws->partial2, nbf, ws->nb, j, red, Hc, cf, 1, ws->st);
+          ksd::k_fin_mid<<<j + 1, kBlock, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hc, cf, 1, ws->st);
           cx->allreduce(red, j + 1);
-          ksd::k_fin_mid<<<j + 1, 64, 0, s>>>(part, ws->partial2, nbf, ws->nb, j, red, Hc, cf, 2, ws->st);
+          ksd::k_fin_mid<<<j + 1, 64, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hc, cf, 2, ws->st);
         }
       }
       {
@@ -1127,7 +1136,9 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     w->maxdim = maxdim;
     w->ld = std::max<int64_t>(round_up(n_local, 64), 64);
     w->pstride = (int)round_up(maxdim + 2, 8);
-    w->nb = ctx->nblocks();
+    w->esz = dtype == KS_F64 ? 8 : 16;
+    w->pnb = ctx->nblocks();
+    w->nb = cap_blocks(w.get(), w->pnb, 2 * kBlock);  // generic streaming grid (axpy: 4 packs per lane)
     const size_t esz = w->esz;
     const size_t vbytes = (size_t)w->ld * (maxdim + 1) * esz;
     KS_HIP(hipMalloc(&w->V, vbytes));
@@ -1143,8 +1154,8 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     KS_HIP(hipMalloc(&w->Hd, hbytes));
     KS_HIP(hipMemsetAsync(w->Hd, 0, hbytes, ctx->stream));
     KS_HIP(hipMalloc(&w->Hscratch, (size_t)(maxdim + 2) * esz));
-    KS_HIP(hipMalloc(&w->partial, (size_t)w->nb * w->pstride * esz));
-    KS_HIP(hipMalloc(&w->partial2, (size_t)std::max(w->nb, ctx->num_cu * 8) * 8));
+    KS_HIP(hipMalloc(&w->partial, (size_t)w->pnb * w->pstride * esz));
+    KS_HIP(hipMalloc(&w->partial2, (size_t)std::max(w->pnb, ctx->num_cu * 8) * 8));
     KS_HIP(hipMalloc(&w->coef, (size_t)(w->pstride + 136) * esz));
     KS_HIP(hipMemsetAsync(w->coef, 0, (size_t)(w->pstride + 136) * esz, ctx->stream));
     KS_HIP(hipMalloc(&w->red, (size_t)w->pstride * esz));

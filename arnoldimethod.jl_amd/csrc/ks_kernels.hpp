@@ -381,6 +381,43 @@ __device__ __forceinline__ void axpy_tail(typename Pack<T>::type (&s)[U], const 
   }
 }
 
+// U packs (rows r[0..U)) of  w -= V[:, jb:jb+jc) g ; returns sum |w_new|^2 of those packs
+template <class T, int U>
+__device__ __forceinline__ double axpy_body(const T* __restrict__ V, int64_t ldv, int jb, int jc, T* __restrict__ w,
+                                            const T* g, const int64_t (&r)[U]) {
+  using P = typename Pack<T>::type;
+  P s[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) s[u] = zero_pack(T{});
+  int c0 = 0;
+  for (; c0 + 4 <= jc; c0 += 4) {  // full groups of 4 columns: 4*U independent loads in flight
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const T gc = g[c0 + t];
+      const T* colp = V + (int64_t)(jb + c0 + t) * ldv;
+#pragma unroll
+      for (int u = 0; u < U; ++u) axpy_acc(s[u], ld_pack_nt(colp + r[u]), gc);
+    }
+  }
+  // ragged tail: 1..3 columns, straight-line code per case so all loads issue together; no duplicate
+  // reads (non-temporal loads of a clamped column would go back to HBM).
+  switch (jc - c0) {
+    case 1: axpy_tail<T, U, 1>(s, V + (int64_t)(jb + c0) * ldv, ldv, r, g + c0); break;
+    case 2: axpy_tail<T, U, 2>(s, V + (int64_t)(jb + c0) * ldv, ldv, r, g + c0); break;
+    case 3: axpy_tail<T, U, 3>(s, V + (int64_t)(jb + c0) * ldv, ldv, r, g + c0); break;
+    default: break;
+  }
+  double nrm = 0.0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    P wv = ld_pack(w + r[u]);
+    wv = sub_pack(wv, s[u]);
+    st_pack_nt(w + r[u], wv);
+    nrm += nrm2_pack(wv);
+  }
+  return nrm;
+}
+
 template <class T>
 __global__ void __launch_bounds__(kBlock)
     k_axpy(const T* __restrict__ V, int64_t ldv, int j, T* __restrict__ w, const T* __restrict__ coef,
@@ -389,12 +426,10 @@ __global__ void __launch_bounds__(kBlock)
     if (st->breakdown >= 0) return;
     if (pass == 2 && !st->reorth) return;
   }
-  using P = typename Pack<T>::type;
   constexpr int R = Pack<T>::R;
   constexpr int U = 4;  // packs per lane per iteration: 4 x 4 KiB contiguous per column and workgroup
   __shared__ T g[128];
   __shared__ double red[kBlock / 64];
-  // coefficients padded with zeros to a multiple of 8 (ragged tail multiplies a re-read column by 0)
   int64_t pb, pe;
   block_range(ldv / R, blockIdx.x, gridDim.x, pb, pe);
   double nrm = 0.0;
@@ -404,44 +439,18 @@ __global__ void __launch_bounds__(kBlock)
     if (threadIdx.x < 128) g[threadIdx.x] = threadIdx.x < jc ? coef[jb + threadIdx.x] : zero_of(T{});
     __syncthreads();
     const bool last = jb + 128 >= j;
-    for (int64_t p = pb + threadIdx.x; p < pe; p += kBlock * U) {
+    int64_t p = pb + threadIdx.x;
+    for (; p + (U - 1) * kBlock < pe; p += kBlock * U) {  // all U slots of this lane are in range
       int64_t r[U];
-      bool ok[U];
-      P s[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int64_t q = p + (int64_t)u * kBlock;
-        ok[u] = q < pe;
-        r[u] = (ok[u] ? q : p) * R;  // out-of-range slots redo slot 0 (identical value, not stored)
-        s[u] = zero_pack(T{});
-      }
-      int c0 = 0;
-      for (; c0 + 4 <= jc; c0 += 4) {  // full groups of 4 columns: 16 independent loads in flight
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const T gc = g[c0 + t];
-          const T* colp = V + (int64_t)(jb + c0 + t) * ldv;
-#pragma unroll
-          for (int u = 0; u < U; ++u) axpy_acc(s[u], ld_pack_nt(colp + r[u]), gc);
-        }
-      }
-      // ragged tail: 1..3 columns, straight-line code per case so all loads issue together; no
-      // duplicate reads (non-temporal loads of a clamped column would go back to HBM).
-      switch (jc - c0) {
-        case 1: axpy_tail<T, U, 1>(s, V + (int64_t)(jb + c0) * ldv, ldv, r, g + c0); break;
-        case 2: axpy_tail<T, U, 2>(s, V + (int64_t)(jb + c0) * ldv, ldv, r, g + c0); break;
-        case 3: axpy_tail<T, U, 3>(s, V + (int64_t)(jb + c0) * ldv, ldv, r, g + c0); break;
-        default: break;
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        P wv = ld_pack(w + r[u]);
-        wv = sub_pack(wv, s[u]);
-        if (ok[u]) {
-          st_pack_nt(w + r[u], wv);
-          if (last) nrm += nrm2_pack(wv);
-        }
-      }
+      for (int u = 0; u < U; ++u) r[u] = (p + (int64_t)u * kBlock) * R;
+      const double t = axpy_body<T, U>(V, ldv, jb, jc, w, g, r);
+      if (last) nrm += t;
+    }
+    for (; p < pe; p += kBlock) {  // remainder, one pack at a time
+      const int64_t r1[1] = {p * R};
+      const double t = axpy_body<T, 1>(V, ldv, jb, jc, w, g, r1);
+      if (last) nrm += t;
     }
   }
   const double s = wave_sum(nrm);
