@@ -111,7 +111,7 @@ class Context:
         return s.value or 0
 
     # per-kernel-class HIP-event timing (bench.py)
-    PROFILE_CLASSES = ("spmv", "dots", "axpy", "scale", "rotate", "fin")
+    PROFILE_CLASSES = ("spmv", "dots", "axpy", "scale", "rotate", "fin", "fused")
 
     def profile_enable(self, on: bool = True):
         check(_lib.load().ks_profile_enable(self._h, 1 if on else 0))

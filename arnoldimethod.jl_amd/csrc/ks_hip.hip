@@ -92,7 +92,7 @@ inline int env_int(const char* name, int dflt) {
 // ------------------------------------------------------------------------------------------------
 // Optional per-kernel-class timing with HIP events recorded on the context's stream (bench.py):
 // class ids index ks_profile_* below.
-enum { KSP_SPMV = 0, KSP_DOTS = 1, KSP_AXPY = 2, KSP_SCALE = 3, KSP_ROTATE = 4, KSP_FIN = 5, KSP_NCLASS = 6 };
+enum { KSP_SPMV = 0, KSP_DOTS = 1, KSP_AXPY = 2, KSP_SCALE = 3, KSP_ROTATE = 4, KSP_FIN = 5, KSP_FUSED = 6, KSP_NCLASS = 7 };
 
 struct ProfRecord {
   hipEvent_t a, b;
@@ -104,9 +104,9 @@ struct ks_ctx {
   bool profiling = false;
   std::vector<ProfRecord> prof_pending;
   std::vector<hipEvent_t> prof_pool;
-  double prof_ms[KSP_NCLASS] = {0, 0, 0, 0, 0, 0};
-  double prof_bytes[KSP_NCLASS] = {0, 0, 0, 0, 0, 0};
-  int64_t prof_count[KSP_NCLASS] = {0, 0, 0, 0, 0, 0};
+  double prof_ms[KSP_NCLASS] = {};
+  double prof_bytes[KSP_NCLASS] = {};
+  int64_t prof_count[KSP_NCLASS] = {};
   int device = 0;
   hipStream_t stream = nullptr;
   int rank = 0, nranks = 1;
@@ -580,10 +580,12 @@ template <class D> void enqueue_orthogonalize(ks_workspace* ws, int j) {
         launch_fin_dots<D>(ws, nbd, j, Hcol, 1, ws->st);
       }
       // pass 1 projection + (speculative) pass 2 inner products: V is read once for both.
-      // algorithmic bytes = axpy (j+2 columns) + dots (j+1 columns) of the un-fused sequence
+      // per-kernel roofline bytes = what the fused op must move (read V[:,0:j) and w, write w); the
+      // un-fused pair it replaces would move (j+2) + (j+1) columns -- that gain shows up in the
+      // fused-step figure of bench.py, not here.
       int nbf;
       {
-        ProfScope ps(ws->ctx, KSP_AXPY, nb8 * (2 * j + 3));
+        ProfScope ps(ws->ctx, KSP_FUSED, nb8 * (j + 2));
         nbf = launch_axpy_dots(ws, j, w);
       }
       {

@@ -33,6 +33,30 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
 
 
+KERNEL_NAMES = {
+    "dots": "k_dots (h = V'w, |w|^2)",
+    "axpy": "k_axpy (w -= V c, |w|^2; second DGKS pass)",
+    "fused": "k_axpy_dots_cs (w -= V h, |w|^2 and c = V'w of the second DGKS pass, V read once)",
+    "spmv": "k_spmv_csr",
+    "scale": "k_scale",
+    "rotate": "k_rotate_mfma",
+}
+
+
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE collected separately, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_summary.py)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        e = d["classes"][kernel_class]
+        return {"bytes_per_launch": e["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": e["algorithmic_bytes_per_launch"],
+                "ratio": e["hbm_bytes_per_launch"] / e["algorithmic_bytes_per_launch"], "source": "profiles/pmc_traffic.json (" + d.get("source", "") + ")"}
+    except Exception:
+        return None
+
+
 def step_bytes(n, nnz, j, reorth):
     """Algorithmic bytes of one Arnoldi step at basis size j (SURVEY.md 8d / BASELINE.md section 4)."""
     b = 12.0 * nnz + 4.0 * (n + 1) + 8.0 * n * (2 * j + 2)
@@ -183,13 +207,13 @@ def main():
         d = classes[dom]
         ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
         roof.update({
-            "kernel": {"dots": "k_dots (h = V'w, |w|^2)", "axpy": "k_axpy (w -= V h, |w|^2)", "spmv": "k_spmv_csr",
-                       "scale": "k_scale", "rotate": "k_rotate_mfma"}[dom],
+            "kernel": KERNEL_NAMES[dom],
             "achieved": ach,
             "frac": ach / HBM_PEAK_GBS,
             "launches": d["count"],
             "avg_launch_ms": d["ms"] / d["count"],
             "algorithmic_bytes_per_launch": d["bytes"] / d["count"],
+            "traffic": pmc_traffic(dom) if (m == 216 and world == 1) else None,
             "per_class": {k: {"ms_total": v["ms"], "launches": v["count"],
                               "GBps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 and v["bytes"] > 0 else None}
                           for k, v in prof.items()},

@@ -227,7 +227,8 @@ int ks_restart(ks_workspace* ws, const ks_params* p, int active, int* k, int* nl
                double* lams_c64, double* rs, int32_t* groups);
 
 /* Per-kernel-class timing with HIP events on the context's stream (bench.py's roofline figures).
- * Classes: 0 SpMV, 1 dots (V'w), 2 axpy (w -= Vh), 3 scale, 4 rotation, 5 reductions/decisions.
+ * Classes: 0 SpMV, 1 dots (V'w), 2 axpy (w -= Vh), 3 scale, 4 rotation, 5 reductions/decisions,
+ * 6 fused axpy+dots (first projection + second-pass inner products).
  * `bytes` are ALGORITHMIC bytes accumulated per launch. */
 int ks_profile_enable(ks_ctx* ctx, int on);
 int ks_profile_reset(ks_ctx* ctx);

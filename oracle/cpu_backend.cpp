@@ -22,6 +22,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -48,16 +49,40 @@ template <class T> struct CpuBackend : ks::Backend<T> {
   const int32_t* rowptr;
   const int32_t* colidx;
   const T* val;
-  std::vector<T> V, Vtmp;
   uint64_t seed = 20240917ull, rng_count = 0;
   int spmv_threads = 0;  // 0 = all
   double t_spmv = 0, t_orth = 0, t_rot = 0;
 
   CpuBackend(int64_t n_, int maxdim_, const int32_t* rp, const int32_t* ci, const T* v)
-      : n(n_), maxdim(maxdim_), rowptr(rp), colidx(ci), val(v), V((size_t)n_ * (maxdim_ + 1)),
-        Vtmp((size_t)n_ * (maxdim_ + 1)) {}
+      : n(n_), maxdim(maxdim_), rowptr(rp), colidx(ci), val(v) {
+    // first-touch in parallel with the same static row partition every kernel uses, so each thread's
+    // rows live on its own NUMA node (std::vector's serial value-initialisation would put all of V on one)
+    Vbuf.reset(new T[(size_t)n * (maxdim + 1)]);
+    Tbuf.reset(new T[(size_t)n * (maxdim + 1)]);
+    V = Vbuf.get();
+    Vtmp = Tbuf.get();
+#pragma omp parallel
+    {
+      int64_t a, b;
+      my_rows(a, b);
+      for (int c = 0; c <= maxdim; ++c)
+        for (int64_t i = a; i < b; ++i) { V[(size_t)c * n + i] = T(0); Vtmp[(size_t)c * n + i] = T(0); }
+    }
+  }
 
-  T* col(int j) { return V.data() + (size_t)j * n; }
+  std::unique_ptr<T[]> Vbuf, Tbuf;
+  T* V = nullptr;
+  T* Vtmp = nullptr;
+
+  // contiguous row range of the calling thread
+  void my_rows(int64_t& a, int64_t& b) const {
+    const int nt = omp_get_num_threads(), t = omp_get_thread_num();
+    const int64_t per = (n + nt - 1) / nt;
+    a = std::min<int64_t>(n, t * per);
+    b = std::min<int64_t>(n, a + per);
+  }
+
+  T* col(int j) { return V + (size_t)j * n; }
   int64_t n_global() const override { return n; }
 
   void spmv(const T* x, T* y) {
@@ -75,30 +100,49 @@ template <class T> struct CpuBackend : ks::Backend<T> {
     for (int64_t i = 0; i < n; ++i) s += ks::abs2_(v[i]);
     return std::sqrt(s);
   }
-  void gemv_t(int j, const T* v, T* h) {  // h = V[:,0:j)^H v
-    for (int c0 = 0; c0 < j; c0 += 8) {
-      const int nc = std::min(8, j - c0);
-      double re[8] = {0}, im[8] = {0};
-#pragma omp parallel for reduction(+ : re[:8], im[:8]) schedule(static)
-      for (int64_t i = 0; i < n; ++i) {
-        const T vi = v[i];
-        for (int c = 0; c < nc; ++c) {
-          const T t = ks::conj_(V[(size_t)(c0 + c) * n + i]) * vi;
-          re[c] += ks::real_(t);
-          im[c] += ks::imag_(t);
+  // h = V[:,0:j)^H v   (gemv 'T'/'C'): every thread streams its row block column by column (its slice of v
+  // stays in cache), partial results are summed in thread order
+  void gemv_t(int j, const T* v, T* h) {
+    const int ntmax = omp_get_max_threads();
+    std::vector<T> part((size_t)ntmax * j, T(0));
+    int used = 1;
+#pragma omp parallel
+    {
+      int64_t a, b;
+      my_rows(a, b);
+      const int t = omp_get_thread_num();
+#pragma omp single
+      used = omp_get_num_threads();
+      for (int c = 0; c < j; ++c) {
+        const T* vc = V + (size_t)c * n;
+        double sr = 0.0, si = 0.0;
+#pragma omp simd reduction(+ : sr, si)
+        for (int64_t i = a; i < b; ++i) {
+          const T t2 = ks::conj_(vc[i]) * v[i];
+          sr += ks::real_(t2);
+          si += ks::imag_(t2);
         }
-      }
-      for (int c = 0; c < nc; ++c) {
-        if constexpr (ks::is_real_v<T>) h[c0 + c] = re[c]; else h[c0 + c] = cplx(re[c], im[c]);
+        if constexpr (ks::is_real_v<T>) part[(size_t)t * j + c] = sr; else part[(size_t)t * j + c] = cplx(sr, si);
       }
     }
-  }
-  void gemv_n_sub(int j, T* v, const T* h) {  // v -= V[:,0:j) h
-#pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < n; ++i) {
+    for (int c = 0; c < j; ++c) {
       T s = T(0);
-      for (int c = 0; c < j; ++c) s += V[(size_t)c * n + i] * h[c];
-      v[i] -= s;
+      for (int t = 0; t < used; ++t) s += part[(size_t)t * j + c];
+      h[c] = s;
+    }
+  }
+  // v -= V[:,0:j) h   (gemv 'N' with alpha = -1, beta = 1)
+  void gemv_n_sub(int j, T* v, const T* h) {
+#pragma omp parallel
+    {
+      int64_t a, b;
+      my_rows(a, b);
+      for (int c = 0; c < j; ++c) {
+        const T* vc = V + (size_t)c * n;
+        const T hc = h[c];
+#pragma omp simd
+        for (int64_t i = a; i < b; ++i) v[i] -= vc[i] * hc;
+      }
     }
   }
   void scal(T* v, double f) {
@@ -182,17 +226,31 @@ template <class T> struct CpuBackend : ks::Backend<T> {
   // mul!(V_tmp, V, Q) + copyto!, src/run.jl:363-364 / :382-383
   void rotate(int c0, int c, int r, const ks::Mat<T>& Q) override {
     double t0 = ks::now_s();
-#pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < n; ++i) {
-      for (int jj = 0; jj < r; ++jj) {
-        T s = T(0);
-        for (int cc = 0; cc < c; ++cc) s += V[(size_t)(c0 + cc) * n + i] * Q(c0 + cc, c0 + jj);
-        Vtmp[(size_t)(c0 + jj) * n + i] = s;
+#pragma omp parallel
+    {
+      int64_t a, b;
+      my_rows(a, b);
+      constexpr int64_t BS = 256;  // row tile kept in cache while looping over the small Q
+      for (int64_t i0 = a; i0 < b; i0 += BS) {
+        const int64_t i1 = std::min(b, i0 + BS);
+        for (int jj = 0; jj < r; ++jj) {
+          T* out = Vtmp + (size_t)(c0 + jj) * n;
+          for (int64_t i = i0; i < i1; ++i) out[i] = T(0);
+          for (int cc = 0; cc < c; ++cc) {
+            const T q = Q(c0 + cc, c0 + jj);
+            const T* vc = V + (size_t)(c0 + cc) * n;
+#pragma omp simd
+            for (int64_t i = i0; i < i1; ++i) out[i] += vc[i] * q;
+          }
+        }
+      }
+#pragma omp barrier
+      for (int jj = 0; jj < r; ++jj) {  // copyto!(V, V_tmp)
+        const T* in = Vtmp + (size_t)(c0 + jj) * n;
+        T* out = V + (size_t)(c0 + jj) * n;
+        for (int64_t i = a; i < b; ++i) out[i] = in[i];
       }
     }
-#pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < n; ++i)
-      for (int jj = 0; jj < r; ++jj) V[(size_t)(c0 + jj) * n + i] = Vtmp[(size_t)(c0 + jj) * n + i];
     t_rot += ks::now_s() - t0;
   }
   void col_copy(int dst, int src) override {
@@ -224,7 +282,7 @@ int run_partialschur(int64_t n, const int32_t* rowptr, const int32_t* colidx, co
     return 5;
   }
   if (Hout) std::memcpy(Hout, H.data(), H.size() * sizeof(T));
-  if (Vout) std::memcpy(Vout, be.V.data(), (size_t)n * (maxdim + 1) * sizeof(T));
+  if (Vout) std::memcpy(Vout, be.V, (size_t)n * (maxdim + 1) * sizeof(T));
   for (int i = 0; i < h.nconverged; ++i) { eig_c64[2 * i] = lams[i].real(); eig_c64[2 * i + 1] = lams[i].imag(); }
   hist_i[0] = h.mvproducts; hist_i[1] = h.nconverged; hist_i[2] = h.converged; hist_i[3] = h.nev;
   hist_i[4] = h.restarts; hist_i[5] = h.reorth; hist_i[6] = h.breakdowns;

@@ -1,40 +1,99 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes per kernel and compare with the algorithmic
-bytes of each launch (n, nnz, j recovered from the kernel name / launch order).
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (collected in SEPARATE runs, each with only
+--kernel-trace next to --pmc) per kernel, and write profiles/pmc_traffic.json for bench.py.
 
-usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <n> <nnz>
+usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <n> <nnz> [out.json]
 
-gfx950 corrections (MI355X_MICROARCH.md, section HBM): FETCH_SIZE is in KiB and reports exactly 1/2 of
-the bytes of a wide (16 B/lane) coalesced streaming read -> x2 for such kernels; WRITE_SIZE (KiB) is
-uncalibrated by the guide -- calibrated here on k_copy / k_scale whose written bytes are known."""
+gfx950 corrections (MI355X_MICROARCH.md, section HBM): FETCH_SIZE is in KiB and reports exactly 1/2 of the
+bytes of a wide (16 B/lane) coalesced streaming read -> x2 for the streaming kernels (k_dots, k_axpy*,
+k_scale, k_rotate, k_copy; verified here: k_scale/k_copy/k_norm2 read exactly one column = 8n bytes and
+report 4n).  The same factor is applied to k_spmv_csr, whose 4- and 8-byte loads are NOT covered by the
+guide's calibration -- its figure is flagged "uncalibrated".  WRITE_SIZE (KiB) needs no correction: k_copy,
+k_scale and the SpMV write exactly 8n bytes and report 8n.
+Algorithmic bytes per launch are recomputed from the launch order (the basis size j of each step)."""
 import csv
+import json
 import re
 import sys
 from collections import defaultdict
 
 
 def load(path):
-    per = defaultdict(list)
-    order = []
+    rows = []
     for r in csv.DictReader(open(path)):
         name = re.sub(r"void ksd::|\(.*", "", r["Kernel_Name"])
-        per[name].append(float(r["Counter_Value"]))
-        order.append((int(r["Dispatch_Id"]), name, float(r["Counter_Value"])))
-    return per, sorted(order)
+        rows.append((int(r["Dispatch_Id"]), name, float(r["Counter_Value"])))
+    rows.sort()
+    return rows
+
+
+def klass(name):
+    if name.startswith("k_dots"):
+        return "dots"
+    if name.startswith("k_axpy_dots"):
+        return "fused"
+    if name.startswith("k_axpy"):
+        return "axpy"
+    if name.startswith("k_spmv"):
+        return "spmv"
+    if name.startswith("k_scale"):
+        return "scale"
+    if name.startswith("k_rotate"):
+        return "rotate"
+    return None
 
 
 def main():
     fpath, wpath, n, nnz = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
-    F, fo = load(fpath)
-    W, wo = load(wpath)
-    # recover j per dots/axpy launch from launch order: each step = spmv, dots(j), fin, fused(j), fin, fin, axpy(j), fin, scale
-    print(f"{'kernel':30s} {'launches':>8s} {'FETCH KiB avg':>14s} {'x2 -> GB':>10s} {'WRITE KiB avg':>14s} {'GB':>8s}")
-    for name in sorted(F, key=lambda k: -sum(F[k])):
-        f = sum(F[name]) / len(F[name])
-        w = sum(W.get(name, [0])) / max(len(W.get(name, [0])), 1)
-        print(f"{name:30s} {len(F[name]):8d} {f:14.1f} {2*f*1024/1e9:10.3f} {w:14.1f} {w*1024/1e9:8.3f}")
+    out = sys.argv[5] if len(sys.argv) > 5 else None
+    F, W = load(fpath), load(wpath)
+    assert [x[1] for x in F] == [x[1] for x in W], "the two passes must replay the same launch sequence"
     col = 8.0 * n
-    print("\nreference byte counts: one column = %.4f GB; matrix stream (12 nnz + 4 (n+1)) = %.4f GB" % (col / 1e9, (12.0 * nnz + 4 * (n + 1)) / 1e9))
+    # basis size j of a step = number of k_fin_dots/k_fin_mid workgroups is not in the trace; recover it from
+    # the dots template parameter and the order inside one expansion (j increases by one per step).
+    per = defaultdict(lambda: dict(launches=0, fetch=0.0, write=0.0, alg=0.0))
+    j = None
+    last_nc4 = None
+    for (_, name, f), (_, _, w) in zip(F, W):
+        k = klass(name)
+        if k is None:
+            continue
+        if k == "spmv":
+            alg = 12.0 * nnz + 4.0 * (n + 1) + 2 * col
+        elif k == "dots":
+            nc4 = int(re.search(r"k_dots<double, (\d+)>", name).group(1))
+            # first step of an expansion: smallest j of the granule is unknown -> track by sequence
+            if j is None or nc4 < (last_nc4 or 0):
+                j = None
+            last_nc4 = nc4
+            j = (j + 1) if j is not None and (j + 1 + 3) // 4 == nc4 else (4 * (nc4 - 1) + 1 if j is None else j + 1)
+            alg = col * (j + 1)
+        elif k == "fused":
+            alg = col * (j + 2)
+        elif k == "axpy":
+            alg = col * (j + 2)
+        elif k == "scale":
+            alg = 2 * col
+        else:
+            alg = None
+        e = per[k]
+        e["launches"] += 1
+        e["fetch"] += f * 1024.0
+        e["write"] += w * 1024.0
+        if alg is not None:
+            e["alg"] += alg
+    res = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes; FETCH x2 (gfx950)", "n": n, "nnz": nnz, "classes": {}}
+    print(f"{'class':8s} {'launches':>8s} {'HBM GB/launch (2F+W)':>22s} {'algorithmic GB/launch':>22s} {'ratio':>6s}")
+    for k, e in per.items():
+        hbm = (2 * e["fetch"] + e["write"]) / e["launches"]
+        alg = e["alg"] / e["launches"] if e["alg"] else None
+        res["classes"][k] = {"launches": e["launches"], "hbm_bytes_per_launch": hbm, "fetch_bytes_raw_per_launch": e["fetch"] / e["launches"],
+                             "write_bytes_per_launch": e["write"] / e["launches"], "algorithmic_bytes_per_launch": alg,
+                             "calibrated": k != "spmv"}
+        print(f"{k:8s} {e['launches']:8d} {hbm/1e9:22.4f} {(alg or 0)/1e9:22.4f} {(hbm/alg if alg else 0):6.3f}")
+    if out:
+        json.dump(res, open(out, "w"), indent=1)
+        print("wrote", out)
 
 
 if __name__ == "__main__":
