@@ -199,6 +199,7 @@ template <class D> struct CsrOp : ks_operator {
   int32_t* colidx = nullptr;
   D* val = nullptr;
   int ntiles = 0;
+  int lds_cap = 256;  // products per tile held in LDS (largest tile of this matrix, capped)
   // halo plan (distributed)
   int64_t nghost = 0;
   D* ghost = nullptr;
@@ -234,7 +235,10 @@ template <class D> struct CsrOp : ks_operator {
       // algorithmic bytes: 12 nnz + 4 (n+1) + 16 n   (8 -> 16 for complex)
       ProfScope ps(ctx, KSP_SPMV, (double)nnz * (4 + sizeof(D)) + 4.0 * (n_local + 1) + 2.0 * sizeof(D) * n_local);
       // (a variant reading the non-zeros as aligned pairs with non-temporal loads measured 15 % slower)
-      ksd::k_spmv_csr<D><<<ntiles, kBlock, 0, s>>>(rowptr, colidx, val, x, ghost, y, n_local, ntiles, st);
+      static const int nt = env_int("KS_SPMV_NT", 0);
+      const size_t smem = (size_t)lds_cap * sizeof(D);
+      if (nt) ksd::k_spmv_csr<D, true><<<ntiles, kBlock, smem, s>>>(rowptr, colidx, val, x, ghost, y, n_local, ntiles, lds_cap, st);
+      else ksd::k_spmv_csr<D, false><<<ntiles, kBlock, smem, s>>>(rowptr, colidx, val, x, ghost, y, n_local, ntiles, lds_cap, st);
     }
     KS_HIP(hipGetLastError());
   }
@@ -316,6 +320,18 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
   op->nnz = nnz;
   op->dtype = sizeof(D) == 8 ? KS_F64 : KS_C64;
   op->ntiles = (int)((nrows + ksd::kSpmvRows - 1) / ksd::kSpmvRows);
+  {
+    // LDS buffer = the largest 256-row tile (multiple of 256 products), at most kSpmvCapMax; tiles above
+    // the cap take the wave-per-row path.  KS_SPMV_CAP overrides (experiments).
+    int64_t mx = 0;
+    for (int64_t r0 = 0; r0 < nrows; r0 += ksd::kSpmvRows) {
+      const int64_t r1 = std::min<int64_t>(nrows, r0 + ksd::kSpmvRows);
+      mx = std::max<int64_t>(mx, (int64_t)rp[r1] - rp[r0]);
+    }
+    const int capmax = ksd::kSpmvCapMax / (int)(sizeof(D) / 8);
+    int cap = (int)std::min<int64_t>(capmax, std::max<int64_t>(256, round_up(mx, 256)));
+    op->lds_cap = env_int("KS_SPMV_CAP", cap);
+  }
   KS_HIP(hipMalloc(&op->rowptr, (size_t)(nrows + 1) * 4));
   KS_HIP(hipMalloc(&op->colidx, (size_t)(nnz + 2) * 4 + 16));
   KS_HIP(hipMalloc(&op->val, (size_t)(nnz + 2) * sizeof(D) + 16));
@@ -760,6 +776,22 @@ template <class T> void fetch_H_columns(ks_workspace* ws, int from, int to, cons
     for (int i = 0; i <= j; ++i) H(i, j - 1) = hs[(size_t)(j - 1) * ldh + i];
 }
 
+// out[:, 0:r) = V[:, 0:c) * Y[0:c, 0:r)  (device Y, column-major ldy) for any c, r: the coefficient block
+// a launch keeps in LDS is limited to 48 KiB, wider products are split over output-column chunks.
+template <class TV, class TY>
+void gemm_tall_chunked(ks_workspace* ws, const TV* V, int c, int r, const TY* Yd, int ldy, TY* out, int64_t ldo) {
+  ks_ctx* ctx = ws->ctx;
+  const int rc_max = std::max<int>(1, (int)((48 * 1024) / ((size_t)c * sizeof(TY))));
+  KS_REQUIRE((size_t)c * sizeof(TY) <= 48 * 1024, KS_ERR_ARGUMENT, "too many columns for the generic tall-skinny kernel");
+  for (int r0 = 0; r0 < r; r0 += rc_max) {
+    const int rc = std::min(rc_max, r - r0);
+    const size_t smem = (size_t)c * rc * sizeof(TY);
+    ksd::k_gemm_tall<TV, TY><<<ctx->num_cu * 4, kBlock, smem, ctx->stream>>>(V, ws->ld, ws->n, c, rc, Yd + (size_t)r0 * ldy, ldy,
+                                                                          out + (size_t)r0 * ldo, ldo);
+  }
+  KS_HIP(hipGetLastError());
+}
+
 // V[:, c0:c0+r) <- V[:, c0:c0+c) Q  with Q already on the device (column-major, ld = c)
 template <class D> void rotate_device(ks_workspace* ws, int c0, int c, int r) {
   ks_ctx* ctx = ws->ctx;
@@ -789,9 +821,8 @@ template <class D> void rotate_device(ks_workspace* ws, int c0, int c, int r) {
   else {
     // out of place through scratch, then copy back
     D* tmp = static_cast<D*>(ws->ensure_tmp((size_t)ws->ld * r * sizeof(D)));
-    KS_REQUIRE(smem <= 64 * 1024, KS_ERR_ARGUMENT, "rotation shape too large for the generic kernel (c*r*elsize > 64 KiB)");
-    KS_HIP(hipMemsetAsync(tmp, 0, (size_t)ws->ld * r * sizeof(D), s));
-    ksd::k_gemm_tall<D, D><<<ctx->num_cu * 4, kBlock, smem, s>>>(Vc, ws->ld, ws->n, c, r, Qd, c, tmp, ws->ld);
+    KS_HIP(hipMemsetAsync(tmp, 0, (size_t)ws->ld * r * sizeof(D), s));  // keeps the pad rows zero
+    gemm_tall_chunked<D, D>(ws, Vc, c, r, Qd, c, tmp, ws->ld);
     KS_HIP(hipMemcpyAsync(Vc, tmp, (size_t)ws->ld * r * sizeof(D), hipMemcpyDeviceToDevice, s));
   }
   KS_HIP(hipGetLastError());
@@ -1383,7 +1414,6 @@ int ks_basis_times(ks_workspace* ws, int c, int r, const void* Y_host, int ldy, 
     hipStream_t s = ws->ctx->stream;
     const size_t yes = ydtype == KS_F64 ? 8 : 16;
     const size_t smem = (size_t)c * r * yes;
-    KS_REQUIRE(smem <= 64 * 1024, KS_ERR_ARGUMENT, "coefficient block too large");
     // coefficients -> device (contiguous, ld = c)
     std::vector<char> yc(smem);
     for (int jj = 0; jj < r; ++jj)
@@ -1391,14 +1421,12 @@ int ks_basis_times(ks_workspace* ws, int c, int r, const void* Y_host, int ldy, 
     void* yd = ws->ensure_tmp2(smem);
     KS_HIP(hipMemcpyAsync(yd, yc.data(), smem, hipMemcpyHostToDevice, s));
     void* out = ws->ensure_tmp((size_t)ws->ld * r * yes);
-    const int nb = ws->ctx->num_cu * 4;
     if (ws->dtype == KS_F64 && ydtype == KS_F64)
-      ksd::k_gemm_tall<double, double><<<nb, kBlock, smem, s>>>((const double*)ws->V, ws->ld, ws->n, c, r, (const double*)yd, c, (double*)out, ws->ld);
+      gemm_tall_chunked<double, double>(ws, (const double*)ws->V, c, r, (const double*)yd, c, (double*)out, ws->ld);
     else if (ws->dtype == KS_F64)
-      ksd::k_gemm_tall<double, cd><<<nb, kBlock, smem, s>>>((const double*)ws->V, ws->ld, ws->n, c, r, (const cd*)yd, c, (cd*)out, ws->ld);
+      gemm_tall_chunked<double, cd>(ws, (const double*)ws->V, c, r, (const cd*)yd, c, (cd*)out, ws->ld);
     else
-      ksd::k_gemm_tall<cd, cd><<<nb, kBlock, smem, s>>>((const cd*)ws->V, ws->ld, ws->n, c, r, (const cd*)yd, c, (cd*)out, ws->ld);
-    KS_HIP(hipGetLastError());
+      gemm_tall_chunked<cd, cd>(ws, (const cd*)ws->V, c, r, (const cd*)yd, c, (cd*)out, ws->ld);
     if (ws->n > 0)
       KS_HIP(hipMemcpy2DAsync(out_host, (size_t)ldout * yes, out, (size_t)ws->ld * yes, (size_t)ws->n * yes, (size_t)r,
                               hipMemcpyDeviceToHost, s));

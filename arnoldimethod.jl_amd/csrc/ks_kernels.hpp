@@ -183,20 +183,27 @@ __global__ void __launch_bounds__(kBlock) k_fill_uniform(T* __restrict__ v, int6
 // exchange) instead of the local column.
 // ------------------------------------------------------------------------------------------------
 constexpr int kSpmvRows = 256;
-constexpr int kSpmvCap = 3072;  // products held in LDS per tile
+constexpr int kSpmvCapMax = 4096;  // upper bound of products held in LDS per tile (32 KiB of f64)
 
 __device__ __forceinline__ int xcd_remap(int b, int nt) {
   const int q = nt >> 3, r = nt & 7, xcd = b & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
-template <class T>
+__device__ __forceinline__ int32_t ld_i32(const int32_t* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ double ld_val(const double* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ cd ld_val(const cd* p, bool nt) { return nt ? ld_pack_nt(p) : *p; }
+
+// `cap` = products the dynamic LDS buffer holds (chosen per matrix at upload: the largest 256-row tile,
+// so that regular matrices never take the fallback and occupancy is not wasted on unused LDS).
+template <class T, bool NT>
 __global__ void __launch_bounds__(kBlock)
     k_spmv_csr(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const T* __restrict__ val,
-               const T* __restrict__ x, const T* __restrict__ xg, T* __restrict__ y, int64_t n, int ntiles,
+               const T* __restrict__ x, const T* __restrict__ xg, T* __restrict__ y, int64_t n, int ntiles, int cap,
                const DevState* __restrict__ st) {
   if (st && st->breakdown >= 0) return;
-  __shared__ T prod[kSpmvCap];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* prod = reinterpret_cast<T*>(smem_raw);
   const int tile = xcd_remap(blockIdx.x, ntiles);
   const int64_t r0 = (int64_t)tile * kSpmvRows;
   const int64_t r1 = (r0 + kSpmvRows < n) ? r0 + kSpmvRows : n;
@@ -204,11 +211,11 @@ __global__ void __launch_bounds__(kBlock)
   const int32_t p0 = rowptr[r0];
   const int32_t p1 = rowptr[r1];
   const int32_t cnt = p1 - p0;
-  if (cnt <= kSpmvCap) {
+  if (cnt <= cap) {
 #pragma unroll 4
     for (int32_t p = tid; p < cnt; p += kBlock) {
-      const int32_t c = colidx[p0 + p];
-      const T a = val[p0 + p];
+      const int32_t c = ld_i32(colidx + p0 + p, NT);
+      const T a = ld_val(val + p0 + p, NT);
       const T xv = (c < n) ? x[c] : xg[c - n];
       prod[p] = mul_(a, xv);
     }

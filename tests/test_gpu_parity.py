@@ -524,3 +524,56 @@ def test_rccl_path_single_rank_communicator():
     np.testing.assert_allclose(np.sort_complex(F.eigenvalues), np.sort_complex(ref.eigenvalues), atol=1e-9)
     Q, R = F.Q, np.array(F.R)
     assert np.linalg.norm(B @ Q - Q @ R) < 1e-8
+
+
+# ------------------------------------------------------------------ wide Krylov spaces / shape limits
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_wide_krylov_space_end_to_end(dtype):
+    """maxdim = 90 > 40: chunked inner products (3 launches per pass), un-fused DGKS path, rotation
+    shapes c > 64 (out-of-place kernel) -- same decisions as the oracle."""
+    rng = np.random.default_rng(31)
+    n = 1500
+    d = np.linspace(1, 50, n) + (1j * rng.standard_normal(n) * 0.1 if np.dtype(dtype).kind == "c" else 0)
+    A = (sp.diags(d) + 0.01 * sprand(rng, dtype, n, 0.002)).tocsr().astype(dtype)
+    v1 = oa.uniform_hash(3, np.arange(n)).astype(dtype)
+    kw = dict(nev=30, which="LR", tol=1e-9, mindim=45, maxdim=90, restarts=100)
+    dec, hist = pkg.partialschur(A, v1=v1, **kw)
+    ref, rhist = oa.partialschur(A, v1=v1, **kw)
+    assert hist.converged and hist.mvproducts == rhist.mvproducts and hist.nconverged == rhist.nconverged
+    np.testing.assert_allclose(np.sort_complex(dec.eigenvalues), np.sort_complex(ref.eigenvalues), atol=1e-8)
+    check_schur(A, dec, 1e-7)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c,r", [(70, 41), (100, 64), (128, 3)])
+def test_rotation_wide_out_of_place(dtype, c, r):
+    rng = np.random.default_rng(c + r)
+    n = 321
+    ws = pkg.ArnoldiWorkspace(n, c, dtype)
+    V = rnd(rng, dtype, n, c + 1)
+    Q = rnd(rng, dtype, c, r)
+    ws.set_cols(0, V)
+    ws.rotate(0, Q)
+    want = V.copy()
+    want[:, :r] = V[:, :c] @ Q
+    np.testing.assert_allclose(ws.cols(0, c + 1), want, atol=1e-11 * c)
+
+
+def test_full_spectrum_nev_equals_n():
+    """nev = mindim = maxdim = n: the Krylov space is the whole space (cf. test/partial_schur.jl:47-52)."""
+    rng = np.random.default_rng(33)
+    A = rng.random((12, 12))
+    dec, hist = pkg.partialschur(A, nev=12, mindim=12, maxdim=12, tol=1e-10)
+    assert hist.converged and hist.mvproducts == 12
+    np.testing.assert_allclose(np.sort_complex(dec.eigenvalues), np.sort_complex(np.linalg.eigvals(A)), atol=1e-9)
+    check_schur(A, dec, 1e-9)
+
+
+def test_identity_and_one_by_one():
+    """Degenerate operators: the identity (immediate breakdown every step) and a 1x1 matrix."""
+    dec, hist = pkg.partialschur(sp.identity(50, format="csr") * 3.0, nev=3, tol=1e-10)
+    assert hist.converged
+    np.testing.assert_allclose(dec.eigenvalues, 3.0, atol=1e-12)
+    check_schur(sp.identity(50, format="csr") * 3.0, dec, 1e-12)
+    dec, hist = pkg.partialschur(np.array([[2.5]]), nev=1)
+    assert hist.converged and hist.mvproducts == 1 and dec.eigenvalues[0] == pytest.approx(2.5)
