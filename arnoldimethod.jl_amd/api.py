@@ -155,9 +155,10 @@ class Operator:
         self.ctx, self._h, self.shape, self.dtype, self._keep = ctx, handle, shape, np.dtype(dtype), keep
 
     def close(self):
-        if getattr(self, "_h", None):
+        # never touch a handle whose context is already gone (interpreter shutdown order is arbitrary)
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
             _lib.load().ks_operator_destroy(self._h)
-            self._h = None
+        self._h = None
 
     def __del__(self):
         try:
@@ -397,9 +398,9 @@ class ArnoldiWorkspace:
         return r.value, o.value
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
             _lib.load().ks_workspace_destroy(self._h)
-            self._h = None
+        self._h = None
 
     def __del__(self):
         try:

@@ -92,11 +92,16 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("KS_FORCE_DIST") == "1"  # run the sharded code path on a single rank (debugging)
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if world > 1:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=0, world_size=1)
 
     def barrier():
         if dist is not None:
@@ -110,7 +115,7 @@ def main():
     tol = float(np.sqrt(np.finfo(np.float64).eps))
 
     # ---- operand + workspace (rows block-partitioned over the ranks) ----
-    if world == 1:
+    if dist is None:
         ctx = pkg.Context(local_rank)
         ip, ix, dv = pkg.matrices.laplace3d_csr(m, m, m)
         nnz_global = int(ip[-1])
@@ -171,7 +176,7 @@ def main():
             cycle(False)
         prof = ctx.profile_get()
         ctx.profile_enable(False)
-    if dist is not None:
+    if dist is not None and world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -216,7 +221,7 @@ def main():
             "launches": d["count"],
             "avg_launch_ms": d["ms"] / d["count"],
             "algorithmic_bytes_per_launch": d["bytes"] / d["count"],
-            "traffic": pmc_traffic(dom) if (m == 216 and world == 1) else None,
+            "traffic": pmc_traffic(dom) if (m == 216 and world == 1 and not force_dist) else None,
             "per_class": {k: {"ms_total": v["ms"], "launches": v["count"],
                               "GBps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 and v["bytes"] > 0 else None}
                           for k, v in prof.items()},
@@ -234,7 +239,7 @@ def main():
     out["roofline"] = roof
 
     # ---- CPU baseline: the reference's op sequence on the host cores (rank 0, N = 1 only) ----
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and A_host is not None:
         try:
             from oracle import cpuref
 
