@@ -376,6 +376,13 @@ struct ks_workspace {
   void* tmp2 = nullptr;
   size_t tmp2_bytes = 0;
   int pstride = 0;
+  // lazy normalisation (fused Float64 path): columns lazy_lo..lazy_hi are stored unnormalised in HBM with
+  // factor hostscale[c] (device mirror colscale[c]); everything else has factor 1
+  double* colscale = nullptr;   // device, maxdim+2 doubles
+  std::vector<double> hostscale;
+  std::vector<double> ones;
+  int lazy_lo = 1 << 30, lazy_hi = -1;
+  bool has_lazy() const { return lazy_hi >= lazy_lo; }
   int nb = 0;               // streaming workgroups (capped for small problems)
   int pnb = 0;              // column stride of `partial` (>= every producer's grid)
   uint64_t seed = 20240917ull;
@@ -401,7 +408,7 @@ struct ks_workspace {
     return tmp2;
   }
   ~ks_workspace() {
-    (void)hipFree(V); (void)hipHostFree(H); (void)hipHostFree(Q); (void)hipFree(Hd); (void)hipHostFree(Hstage);
+    (void)hipFree(colscale); (void)hipFree(V); (void)hipHostFree(H); (void)hipHostFree(Q); (void)hipFree(Hd); (void)hipHostFree(Hstage);
     (void)hipFree(Hscratch); (void)hipFree(partial); (void)hipFree(partial2); (void)hipFree(coef); (void)hipFree(red);
     (void)hipFree(scal); (void)hipHostFree(scal_h); (void)hipHostFree(coef_h); (void)hipFree(st);
     (void)hipHostFree(st_h); (void)hipFree(Qd); (void)hipHostFree(Qstage); (void)hipFree(tmp); (void)hipFree(tmp2);
@@ -532,32 +539,34 @@ template <int NC4, int RPL> int launch_axpy_dots_nc(ks_workspace* ws, int j, dou
                                                               static_cast<double*>(ws->partial), ws->pnb, ws->partial2, ws->st);
   return nb;
 }
-template <int NCW, int U> int launch_axpy_dots_cs_nc(ks_workspace* ws, int j, double* w) {
+template <int NCW, int U> int launch_axpy_dots_cs_nc(ks_workspace* ws, int j, double* w, int defer) {
   static int cache = -1;
   const int nb = cap_blocks(ws, resident_blocks(ws->ctx, ksd::k_axpy_dots_cs<NCW, U>, 0, cache), 64 * U);
   ksd::k_axpy_dots_cs<NCW, U><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const double*>(ws->V), ws->ld, j, w,
                                                                static_cast<const double*>(ws->coef),
-                                                               static_cast<double*>(ws->partial), ws->pnb, ws->partial2, ws->st);
+                                                               static_cast<double*>(ws->partial), ws->pnb, ws->partial2, ws->st,
+                                                               defer);
   return nb;
 }
-template <int U> int launch_axpy_dots_cs(ks_workspace* ws, int j, double* w) {
+template <int U> int launch_axpy_dots_cs(ks_workspace* ws, int j, double* w, int defer) {
   switch ((j + 3) / 4) {
-    case 1: return launch_axpy_dots_cs_nc<1, U>(ws, j, w);
-    case 2: return launch_axpy_dots_cs_nc<2, U>(ws, j, w);
-    case 3: return launch_axpy_dots_cs_nc<3, U>(ws, j, w);
-    case 4: return launch_axpy_dots_cs_nc<4, U>(ws, j, w);
-    case 5: return launch_axpy_dots_cs_nc<5, U>(ws, j, w);
-    case 6: return launch_axpy_dots_cs_nc<6, U>(ws, j, w);
-    case 7: return launch_axpy_dots_cs_nc<7, U>(ws, j, w);
-    case 8: return launch_axpy_dots_cs_nc<8, U>(ws, j, w);
-    case 9: return launch_axpy_dots_cs_nc<9, U>(ws, j, w);
-    default: return launch_axpy_dots_cs_nc<10, U>(ws, j, w);
+    case 1: return launch_axpy_dots_cs_nc<1, U>(ws, j, w, defer);
+    case 2: return launch_axpy_dots_cs_nc<2, U>(ws, j, w, defer);
+    case 3: return launch_axpy_dots_cs_nc<3, U>(ws, j, w, defer);
+    case 4: return launch_axpy_dots_cs_nc<4, U>(ws, j, w, defer);
+    case 5: return launch_axpy_dots_cs_nc<5, U>(ws, j, w, defer);
+    case 6: return launch_axpy_dots_cs_nc<6, U>(ws, j, w, defer);
+    case 7: return launch_axpy_dots_cs_nc<7, U>(ws, j, w, defer);
+    case 8: return launch_axpy_dots_cs_nc<8, U>(ws, j, w, defer);
+    case 9: return launch_axpy_dots_cs_nc<9, U>(ws, j, w, defer);
+    default: return launch_axpy_dots_cs_nc<10, U>(ws, j, w, defer);
   }
 }
-inline int launch_axpy_dots(ks_workspace* ws, int j, double* w) {
+inline int launch_axpy_dots(ks_workspace* ws, int j, double* w, int defer = 0) {
   static const int variant = env_int("KS_FUSED_VARIANT", 2);  // 0: per-lane columns, 1: column split U=1, 2: U=2
-  if (variant == 1) return launch_axpy_dots_cs<1>(ws, j, w);
-  if (variant == 2) return launch_axpy_dots_cs<2>(ws, j, w);
+  if (variant == 1 || (defer && variant == 0)) return launch_axpy_dots_cs<1>(ws, j, w, defer);
+  if (variant == 2) return launch_axpy_dots_cs<2>(ws, j, w, defer);
+  KS_REQUIRE(!defer, KS_ERR_INTERNAL, "per-lane fused variant does not support deferred normalisation");
   switch ((j + 3) / 4) {
     case 1: return launch_axpy_dots_nc<1, 2>(ws, j, w);
     case 2: return launch_axpy_dots_nc<2, 2>(ws, j, w);
@@ -658,6 +667,101 @@ template <class D> void enqueue_orthogonalize(ks_workspace* ws, int j) {
   KS_HIP(hipGetLastError());
 }
 
+// Lazy columns -> ordinary columns: one scaling pass per lazy column (only needed when something other than
+// the expansion / restart-rotation pair is about to read V).
+inline void reset_lazy(ks_workspace* ws) {
+  if (!ws->has_lazy()) return;
+  for (int c = ws->lazy_lo; c <= ws->lazy_hi; ++c) ws->hostscale[c] = 1.0;
+  KS_HIP(hipMemcpyAsync(ws->colscale, ws->ones.data(), (size_t)(ws->maxdim + 2) * 8, hipMemcpyHostToDevice, ws->ctx->stream));
+  KS_HIP(hipStreamSynchronize(ws->ctx->stream));
+  ws->lazy_lo = 1 << 30;
+  ws->lazy_hi = -1;
+}
+inline void materialize(ks_workspace* ws) {
+  if (!ws->has_lazy()) return;
+  for (int c = ws->lazy_lo; c <= ws->lazy_hi; ++c)
+    if (ws->hostscale[c] != 1.0)
+      ksd::k_scale<double><<<ws->nb, kBlock, 0, ws->ctx->stream>>>(static_cast<double*>(ws->col(c)), ws->ld, ws->hostscale[c], nullptr);
+  KS_HIP(hipGetLastError());
+  reset_lazy(ws);
+}
+
+// Fused Float64 expansion steps from..to with LAZY NORMALISATION (see ks_kernels.hpp): per step
+//   SpMV -> DOTS -> FIN_DOTS_DEF -> AXPY+DOTS -> FIN_MID_DEF -> AXPY
+// (6 launches, 2 reductions, 3 passes over V, no v ./= wnorm pass) and one FIN_PEND at the end of the batch.  `op` may be null
+// (ks_orthogonalize: the column is already there).
+inline void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op, int from, int to) {
+  using D = double;
+  ks_ctx* cx = ws->ctx;
+  hipStream_t s = cx->stream;
+  const int ldh = ws->maxdim + 1;
+  D* Hd = static_cast<D*>(ws->Hd);
+  const D* V = static_cast<const D*>(ws->V);
+  D* red = static_cast<D*>(ws->red);
+  D* coef = static_cast<D*>(ws->coef);
+  const D* part = static_cast<const D*>(ws->partial);
+  const double nb8 = (double)ws->n * sizeof(D);
+  const bool dist = cx->distributed();
+  for (int j = from; j <= to; ++j) {
+    D* w = static_cast<D*>(ws->col(j));
+    D* Hcol = Hd + (size_t)(j - 1) * ldh;
+    D* Hsub_prev = (j >= 2) ? Hd + (size_t)(j - 2) * ldh + (j - 1) : Hcol;  // only touched when a norm is pending
+    if (op) op->apply(ws->col(j - 1), w, ws->st);
+    int nbd;
+    {
+      ProfScope ps(cx, KSP_DOTS, nb8 * (j + 1));
+      nbd = launch_dots<D>(ws, j, w, 1, ws->st);
+    }
+    {
+      ProfScope ps(cx, KSP_FIN, 0.0);
+      if (!dist) {
+        ksd::k_fin_dots_def<<<j + 1, kBlock, 0, s>>>(part, nbd, ws->pnb, ws->partial2, ws->nb, j, red, Hcol, Hsub_prev, coef, ws->colscale, 0, ws->st);
+      } else {
+        ksd::k_fin_dots_def<<<j + 2, kBlock, 0, s>>>(part, nbd, ws->pnb, ws->partial2, ws->nb, j, red, Hcol, Hsub_prev, coef, ws->colscale, 1, ws->st);
+        cx->allreduce(red, j + 2);
+        ksd::k_fin_dots_def<<<j + 1, 64, 0, s>>>(part, nbd, ws->pnb, ws->partial2, ws->nb, j, red, Hcol, Hsub_prev, coef, ws->colscale, 2, ws->st);
+      }
+    }
+    int nbf;
+    {
+      ProfScope ps(cx, KSP_FUSED, nb8 * (j + 2));  // reads V[:,0:j) and y, writes w'
+      nbf = launch_axpy_dots(ws, j, w, 1);
+    }
+    {
+      ProfScope ps(cx, KSP_FIN, 0.0);
+      if (!dist) {
+        ksd::k_fin_mid_def<<<j + 1, kBlock, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hcol, coef, ws->colscale, 0, ws->st);
+      } else {
+        ksd::k_fin_mid_def<<<j + 1, kBlock, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hcol, coef, ws->colscale, 1, ws->st);
+        cx->allreduce(red, j + 1);
+        ksd::k_fin_mid_def<<<j + 1, 64, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hcol, coef, ws->colscale, 2, ws->st);
+      }
+    }
+    {
+      ProfScope ps(cx, KSP_AXPY, nb8 * (j + 2));
+      ksd::k_axpy<D><<<ws->nb, kBlock, 0, s>>>(V, ws->ld, j, w, coef, ws->partial2, 2, ws->st);
+    }
+    if (j == to) {  // settle the norm of the last column (it stays unnormalised in HBM: colscale)
+      {
+        ProfScope ps(cx, KSP_FIN, 0.0);
+        if (!dist) {
+          ksd::k_fin_pend<<<1, kBlock, 0, s>>>(ws->partial2, ws->nb, red, Hcol + j, j, ws->colscale, 0, ws->st);
+        } else {
+          ksd::k_fin_pend<<<1, kBlock, 0, s>>>(ws->partial2, ws->nb, red, Hcol + j, j, ws->colscale, 1, ws->st);
+          cx->allreduce(red, 1);
+          ksd::k_fin_pend<<<1, 64, 0, s>>>(ws->partial2, ws->nb, red, Hcol + j, j, ws->colscale, 2, ws->st);
+        }
+      }
+    }
+  }
+  KS_HIP(hipGetLastError());
+}
+
+inline bool use_deferred(const ks_workspace* ws, int to) {
+  static const int no_fuse = env_int("KS_NO_FUSE", 0), no_defer = env_int("KS_NO_DEFER", 0);
+  return ws->dtype == KS_F64 && to <= 40 && !no_fuse && !no_defer;
+}
+
 inline void reset_state(ks_workspace* ws) {
   std::memset(ws->st_h, 0, sizeof(DevState));
   ws->st_h->breakdown = -1;
@@ -734,6 +838,7 @@ template <class D> void col_upload(ks_workspace* ws, int j, const void* host) {
 // reinitialize!(arnoldi, j, populate!)  src/expansion.jl:12-59 (synchronous; rare)
 template <class D> bool reinit_column(ks_workspace* ws, int j, const void* v1_host) {
   ks_ctx* c = ws->ctx;
+  materialize(ws);
   D* v = static_cast<D*>(ws->col(j));
   if (v1_host) {
     col_upload<D>(ws, j, v1_host);
@@ -763,7 +868,7 @@ template <class D> bool reinit_column(ks_workspace* ws, int j, const void* v1_ho
 }
 
 // copy the H columns produced on the device for steps from..to into the host H
-template <class T> void fetch_H_columns(ks_workspace* ws, int from, int to, const ks::Mat<T>& H) {
+template <class T> void fetch_H_columns(ks_workspace* ws, int from, int to, const ks::Mat<T>& H, bool lazy = false) {
   if (to < from) return;
   const int ldh = ws->maxdim + 1;
   const size_t off = (size_t)(from - 1) * ldh * sizeof(T);
@@ -774,6 +879,17 @@ template <class T> void fetch_H_columns(ks_workspace* ws, int from, int to, cons
   const T* hs = static_cast<const T*>(ws->Hstage);
   for (int j = from; j <= to; ++j)
     for (int i = 0; i <= j; ++i) H(i, j - 1) = hs[(size_t)(j - 1) * ldh + i];
+  if (lazy) {
+    // columns built by a lazily-normalised batch are stored as beta * v with beta = H[j, j-1]
+    for (int j = from; j <= to; ++j) {
+      const double beta = ks::real_(H(j, j - 1));
+      if (beta != 0.0) {
+        ws->hostscale[j] = 1.0 / beta;
+        ws->lazy_lo = std::min(ws->lazy_lo, j);
+        ws->lazy_hi = std::max(ws->lazy_hi, j);
+      }
+    }
+  }
 }
 
 // out[:, 0:r) = V[:, 0:c) * Y[0:c, 0:r)  (device Y, column-major ldy) for any c, r: the coefficient block
@@ -846,14 +962,20 @@ template <class T> struct HipBackend : ks::Backend<T> {
       reset_state(ws);
       int jend = to;
       if (!op->async_capable) jend = j0;  // host operators: one step per batch
-      for (int j = j0; j <= jend; ++j) {
-        op->apply(ws->col(j - 1), ws->col(j), ws->st);
-        enqueue_orthogonalize<D>(ws, j);
+      const bool lazy = use_deferred(ws, jend);
+      if (lazy) {
+        enqueue_steps_deferred(ws, op, j0, jend);
+      } else {
+        materialize(ws);  // the eager kernels expect ordinary columns
+        for (int j = j0; j <= jend; ++j) {
+          op->apply(ws->col(j - 1), ws->col(j), ws->st);
+          enqueue_orthogonalize<D>(ws, j);
+        }
       }
       fetch_state(ws);
       const int bd = ws->st_h->breakdown;
       const int last_done = bd >= 0 ? bd : jend;
-      fetch_H_columns<T>(ws, j0, last_done, H);
+      fetch_H_columns<T>(ws, j0, last_done, H, lazy);
       stats.steps += last_done - j0 + 1;
       stats.reorth += ws->st_h->n_reorth;
       if (bd >= 0) {
@@ -878,16 +1000,26 @@ template <class T> struct HipBackend : ks::Backend<T> {
     ws->ctx->use();
     KS_HIP(hipStreamSynchronize(ws->ctx->stream));  // Qstage may still be in flight from a previous rotation
     T* qs = static_cast<T*>(ws->Qstage);
+    // lazily normalised columns are stored as beta*v: V Q = (stored) diag(1/beta) Q  -> scale the rows of Q
     for (int jj = 0; jj < r; ++jj)
-      for (int ii = 0; ii < c; ++ii) qs[ii + (size_t)jj * c] = Q(c0 + ii, c0 + jj);
+      for (int ii = 0; ii < c; ++ii) qs[ii + (size_t)jj * c] = Q(c0 + ii, c0 + jj) * ws->hostscale[c0 + ii];
     KS_HIP(hipMemcpyAsync(ws->Qd, qs, (size_t)c * r * sizeof(T), hipMemcpyHostToDevice, ws->ctx->stream));
     rotate_device<D>(ws, c0, c, r);
+    for (int ii = 0; ii < r; ++ii) ws->hostscale[c0 + ii] = 1.0;  // the rotated columns are ordinary again
   }
 
+  // V[:, dst] <- V[:, src]: the last act of a restart (src = maxdim holds the residual direction).  Every
+  // column that is still lazy afterwards is dead (it lies beyond the truncated basis) -> reset the factors.
   void col_copy(int dst, int src) override {
-    if (dst == src) return;
-    ksd::k_copy<D><<<ws->nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const D*>(ws->col(src)), static_cast<D*>(ws->col(dst)), ws->ld);
-    KS_HIP(hipGetLastError());
+    const double copy_factor = ws->hostscale[src];
+    if (dst != src || copy_factor != 1.0) {
+      if (dst == src)
+        ksd::k_scale<D><<<ws->nb, kBlock, 0, ws->ctx->stream>>>(static_cast<D*>(ws->col(src)), ws->ld, copy_factor, nullptr);
+      else
+        ksd::k_copy<D><<<ws->nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const D*>(ws->col(src)), static_cast<D*>(ws->col(dst)), ws->ld, copy_factor);
+      KS_HIP(hipGetLastError());
+    }
+    reset_lazy(ws);
   }
 };
 
@@ -1198,6 +1330,10 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     KS_HIP(hipMalloc(&w->st, sizeof(DevState)));
     KS_HIP(hipHostMalloc(&w->st_h, sizeof(DevState)));
     KS_HIP(hipMalloc(&w->Qd, std::max<size_t>(qbytes, 16)));
+    w->hostscale.assign(maxdim + 2, 1.0);
+    w->ones.assign(maxdim + 2, 1.0);
+    KS_HIP(hipMalloc(&w->colscale, (size_t)(maxdim + 2) * 8));
+    KS_HIP(hipMemcpy(w->colscale, w->ones.data(), (size_t)(maxdim + 2) * 8, hipMemcpyHostToDevice));
     reset_state(w.get());
     KS_HIP(hipStreamSynchronize(ctx->stream));
     *out = w.release();
@@ -1243,6 +1379,8 @@ int ks_workspace_col_ptr(ks_workspace* ws, int j, void** dev_ptr) {
   return guarded([&] {
     check_col(ws, j);
     KS_REQUIRE(dev_ptr, KS_ERR_ARGUMENT, "null argument");
+    ws->ctx->use();
+    materialize(ws);
     *dev_ptr = ws->col(j);
   });
 }
@@ -1261,6 +1399,7 @@ int ks_col_upload(ks_workspace* ws, int j, const void* host) {
     check_col(ws, j);
     KS_REQUIRE(host, KS_ERR_ARGUMENT, "null host pointer");
     ws->ctx->use();
+    materialize(ws);
     dispatch_dtype(ws->dtype, [&](auto tag) { col_upload<typename DevT<decltype(tag)>::type>(ws, j, host); });
   });
 }
@@ -1270,6 +1409,7 @@ int ks_col_download(ks_workspace* ws, int j, void* host) {
     check_col(ws, j);
     KS_REQUIRE(host, KS_ERR_ARGUMENT, "null host pointer");
     ws->ctx->use();
+    materialize(ws);
     KS_HIP(hipMemcpyAsync(host, ws->col(j), (size_t)ws->n * ws->esz, hipMemcpyDeviceToHost, ws->ctx->stream));
     KS_HIP(hipStreamSynchronize(ws->ctx->stream));
   });
@@ -1282,6 +1422,7 @@ int ks_cols_download(ks_workspace* ws, int j0, int ncols, void* host, int64_t ld
     KS_REQUIRE(ldhost >= ws->n, KS_ERR_ARGUMENT, "ldhost too small");
     if (ncols == 0 || ws->n == 0) return;
     ws->ctx->use();
+    materialize(ws);
     KS_HIP(hipMemcpy2DAsync(host, (size_t)ldhost * ws->esz, ws->col(j0), (size_t)ws->ld * ws->esz,
                             (size_t)ws->n * ws->esz, (size_t)ncols, hipMemcpyDeviceToHost, ws->ctx->stream));
     KS_HIP(hipStreamSynchronize(ws->ctx->stream));
@@ -1295,6 +1436,7 @@ int ks_cols_upload(ks_workspace* ws, int j0, int ncols, const void* host, int64_
     KS_REQUIRE(ldhost >= ws->n, KS_ERR_ARGUMENT, "ldhost too small");
     if (ncols == 0 || ws->n == 0) return;
     ws->ctx->use();
+    materialize(ws);
     KS_HIP(hipMemcpy2DAsync(ws->col(j0), (size_t)ws->ld * ws->esz, host, (size_t)ldhost * ws->esz,
                             (size_t)ws->n * ws->esz, (size_t)ncols, hipMemcpyHostToDevice, ws->ctx->stream));
     KS_HIP(hipStreamSynchronize(ws->ctx->stream));
@@ -1305,6 +1447,7 @@ int ks_col_fill_uniform(ks_workspace* ws, int j, uint64_t seed) {
   return guarded([&] {
     check_col(ws, j);
     ws->ctx->use();
+    materialize(ws);
     const int gb = (int)std::min<int64_t>((ws->ld + kBlock - 1) / kBlock, 8192);
     dispatch_dtype(ws->dtype, [&](auto tag) {
       using D = typename DevT<decltype(tag)>::type;
@@ -1321,6 +1464,7 @@ int ks_col_norm(ks_workspace* ws, int j, double* out) {
     check_col(ws, j);
     KS_REQUIRE(out, KS_ERR_ARGUMENT, "null out");
     ws->ctx->use();
+    materialize(ws);
     dispatch_dtype(ws->dtype, [&](auto tag) { *out = col_norm<typename DevT<decltype(tag)>::type>(ws, j); });
   });
 }
@@ -1329,6 +1473,7 @@ int ks_col_div(ks_workspace* ws, int j, double s) {
   return guarded([&] {
     check_col(ws, j);
     ws->ctx->use();
+    materialize(ws);
     dispatch_dtype(ws->dtype, [&](auto tag) { col_scale<typename DevT<decltype(tag)>::type>(ws, j, 1.0 / s); });
     KS_HIP(hipStreamSynchronize(ws->ctx->stream));
   });
@@ -1339,10 +1484,11 @@ int ks_col_copy(ks_workspace* ws, int dst, int src) {
     check_col(ws, dst);
     check_col(ws, src);
     ws->ctx->use();
+    materialize(ws);
     if (dst == src) return;
     dispatch_dtype(ws->dtype, [&](auto tag) {
       using D = typename DevT<decltype(tag)>::type;
-      ksd::k_copy<D><<<ws->nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const D*>(ws->col(src)), static_cast<D*>(ws->col(dst)), ws->ld);
+      ksd::k_copy<D><<<ws->nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const D*>(ws->col(src)), static_cast<D*>(ws->col(dst)), ws->ld, 1.0);
     });
     KS_HIP(hipGetLastError());
     KS_HIP(hipStreamSynchronize(ws->ctx->stream));
@@ -1357,6 +1503,7 @@ int ks_apply(ks_operator* A, ks_workspace* ws, int jsrc, int jdst) {
     KS_REQUIRE(jsrc != jdst, KS_ERR_ARGUMENT, "source and destination columns must differ");
     KS_REQUIRE(A->n_local == ws->n && A->dtype == ws->dtype, KS_ERR_DIMENSION, "operator / workspace mismatch");
     ws->ctx->use();
+    materialize(ws);
     A->apply(ws->col(jsrc), ws->col(jdst), nullptr);
     KS_HIP(hipStreamSynchronize(ws->ctx->stream));
   });
@@ -1367,6 +1514,7 @@ int ks_gemv_t(ks_workspace* ws, int j, int jv, void* h_host) {
     check_col(ws, jv);
     KS_REQUIRE(j >= 1 && j <= ws->maxdim + 1 && h_host, KS_ERR_ARGUMENT, "bad arguments");
     ws->ctx->use();
+    materialize(ws);
     reset_state(ws);
     dispatch_dtype(ws->dtype, [&](auto tag) { gemv_t<typename DevT<decltype(tag)>::type>(ws, j, jv, h_host); });
   });
@@ -1378,6 +1526,7 @@ int ks_gemv_n_sub(ks_workspace* ws, int j, int jv, const void* h_host) {
     KS_REQUIRE(j >= 1 && j <= ws->maxdim + 1 && h_host, KS_ERR_ARGUMENT, "bad arguments");
     KS_REQUIRE(jv >= j, KS_ERR_ARGUMENT, "the updated column must not be one of the projected-out columns");
     ws->ctx->use();
+    materialize(ws);
     dispatch_dtype(ws->dtype, [&](auto tag) { gemv_n_sub<typename DevT<decltype(tag)>::type>(ws, j, jv, h_host); });
   });
 }
@@ -1389,6 +1538,7 @@ int ks_rotate(ks_workspace* ws, int c0, int c, int r, const void* Q_host, int ld
                "bad rotation shape");
     KS_REQUIRE((size_t)c * r <= (size_t)ws->maxdim * ws->maxdim, KS_ERR_ARGUMENT, "rotation larger than the workspace Q");
     ws->ctx->use();
+    materialize(ws);
     KS_HIP(hipStreamSynchronize(ws->ctx->stream));
     dispatch_dtype(ws->dtype, [&](auto tag) {
       using T = decltype(tag);
@@ -1411,6 +1561,7 @@ int ks_basis_times(ks_workspace* ws, int c, int r, const void* Y_host, int ldy, 
     KS_REQUIRE(c >= 1 && r >= 1 && c <= ws->maxdim + 1 && ldy >= c && ldout >= ws->n, KS_ERR_ARGUMENT, "bad shape");
     KS_REQUIRE(ydtype == KS_C64 || ydtype == ws->dtype, KS_ERR_ARGUMENT, "coefficient dtype must be complex or match the basis");
     ws->ctx->use();
+    materialize(ws);
     hipStream_t s = ws->ctx->stream;
     const size_t yes = ydtype == KS_F64 ? 8 : 16;
     const size_t smem = (size_t)c * r * yes;
@@ -1444,10 +1595,14 @@ int ks_orthogonalize(ks_workspace* ws, int j, int* ok) {
     dispatch_dtype(ws->dtype, [&](auto tag) {
       using T = decltype(tag);
       using D = typename DevT<T>::type;
-      enqueue_orthogonalize<D>(ws, j);
+      materialize(ws);
+      const bool lazy = use_deferred(ws, j);
+      if (lazy) enqueue_steps_deferred(ws, nullptr, j, j);
+      else enqueue_orthogonalize<D>(ws, j);
       fetch_state(ws);
       ks::Mat<T> H(static_cast<T*>(ws->H), ws->maxdim + 1, ws->maxdim, ws->maxdim + 1);
-      fetch_H_columns<T>(ws, j, j, H);
+      fetch_H_columns<T>(ws, j, j, H, lazy && ws->st_h->breakdown < 0);
+      materialize(ws);
     });
     if (ok) *ok = ws->st_h->breakdown < 0;
   });
@@ -1457,6 +1612,7 @@ int ks_reinitialize(ks_workspace* ws, int j, const void* v1_host, int* ok) {
   return guarded([&] {
     check_col(ws, j);
     ws->ctx->use();
+    materialize(ws);
     bool good = true;
     dispatch_dtype(ws->dtype, [&](auto tag) { good = reinit_column<typename DevT<decltype(tag)>::type>(ws, j, v1_host); });
     if (ok) *ok = good ? 1 : 0;
@@ -1510,6 +1666,7 @@ int ks_partialschur(ks_operator* A, ks_workspace* ws, const ks_params* p, const 
     std::string msg;
     if (ks::check_params(ws->n_global, ws->maxdim + 1, prm, msg)) throw KsError{KS_ERR_ARGUMENT, msg};
     ws->ctx->use();
+    materialize(ws);
     dispatch_dtype(ws->dtype, [&](auto tag) {
       using T = decltype(tag);
       const int ldh = ws->maxdim + 1;
@@ -1523,6 +1680,7 @@ int ks_partialschur(ks_operator* A, ks_workspace* ws, const ks_params* p, const 
       if (prm.initialize) be.reinitialize(prm.start_from - 1, prm.start_from == 1 ? static_cast<const T*>(v1_host) : nullptr);
       std::vector<cplx> lams(prm.maxdim);
       ks::History h = ks::partialschur_driver<T>(be, H, Q, prm, prm.start_from - 1, lams.data());
+      materialize(ws);
       KS_HIP(hipStreamSynchronize(ws->ctx->stream));
       if (eigenvalues_c64)
         for (int i = 0; i < h.nconverged; ++i) {
@@ -1613,6 +1771,7 @@ int ks_residual_norms(ks_operator* A, ks_workspace* ws, int ncols, double* resid
     KS_REQUIRE(A && ws && resid && orth, KS_ERR_ARGUMENT, "null argument");
     KS_REQUIRE(ncols >= 0 && ncols <= ws->maxdim, KS_ERR_ARGUMENT, "bad ncols");
     ws->ctx->use();
+    materialize(ws);
     *resid = 0.0;
     *orth = 0.0;
     if (ncols == 0) return;
@@ -1628,6 +1787,7 @@ int ks_arnoldi_relation(ks_operator* A, ks_workspace* ws, int k, double* resid, 
     KS_REQUIRE(A && ws && resid && orth, KS_ERR_ARGUMENT, "null argument");
     KS_REQUIRE(k >= 1 && k <= ws->maxdim, KS_ERR_ARGUMENT, "bad k");
     ws->ctx->use();
+    materialize(ws);
     dispatch_dtype(ws->dtype, [&](auto tag) {
       using T = decltype(tag);
       relation_norms<T>(A, ws, k, k + 1, static_cast<const T*>(ws->H), ws->maxdim + 1, resid, orth);

@@ -37,8 +37,13 @@ struct DevState {
   int32_t breakdown;  // step index j at which orthogonalize! returned false, else -1
   int32_t n_reorth;   // number of second passes taken in this batch
   int32_t n_steps;    // steps completed in this batch
-  int32_t pad[2];
-  int32_t pad2[2];
+  // deferred normalisation (fused Float64 path): the column produced by the previous step of the batch is
+  // still unnormalised when the next step starts; its norm is folded into that step's first reduction.
+  int32_t pend;        // 1: the input column of the current step is unnormalised
+  int32_t pend_reorth; // 1: its squared norm is the (block-partial) result of the second-pass update,
+                       // 0: it is `wnorm` (already reduced) of the first pass
+  double rnorm_p;      // reference norm of the pending breakdown test (src/expansion.jl:99)
+  double invb;         // 1 / norm of the pending column (1 when none)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -557,12 +562,14 @@ __global__ void __launch_bounds__(kBlock)
 // second-pass inner products then need no cross-wave reduction at all, because every column belongs to
 // exactly one wave.  Summation order is fixed (wave 0..3), so results are run-to-run deterministic.
 // ------------------------------------------------------------------------------------------------
-template <int NCW, int U>
-__global__ void __launch_bounds__(kBlock)
+template <int NCW, int U, bool NTS = true, int MINW = 1>
+__global__ void __launch_bounds__(kBlock, MINW)
     k_axpy_dots_cs(const double* __restrict__ V, int64_t ldv, int j, double* __restrict__ w,
                    const double* __restrict__ coef, double* __restrict__ partial, int pnb,
-                   double* __restrict__ partial2, const DevState* __restrict__ st) {
+                   double* __restrict__ partial2, const DevState* __restrict__ st, int defer) {
   if (st && st->breakdown >= 0) return;
+  // lazy normalisation: y (= w on entry) = A * (unnormalised column j-1) carries the factor beta_{j-1}
+  const double invb = (defer && st) ? st->invb : 1.0;
   __shared__ double2 tbuf[2][4][U][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -604,7 +611,11 @@ __global__ void __launch_bounds__(kBlock)
       }
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) wv[u] = ld_pack(w + r[u]);
+    for (int u = 0; u < U; ++u) {
+      wv[u] = ld_pack(w + r[u]);
+      wv[u].x *= invb;
+      wv[u].y *= invb;
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       double2 t = make_double2(0.0, 0.0);
@@ -622,7 +633,7 @@ __global__ void __launch_bounds__(kBlock)
       wn.y = wv[u].y - ((t0.y + t1.y) + (t2.y + t3.y));
       if (!ok[u]) wn = make_double2(0.0, 0.0);
       if (wave == 0 && ok[u]) {
-        st_pack_nt(w + r[u], wn);
+        if (NTS) st_pack_nt(w + r[u], wn); else st_pack(w + r[u], wn);
         nrm += fma(wn.x, wn.x, wn.y * wn.y);
       }
 #pragma unroll
@@ -710,6 +721,159 @@ __global__ void __launch_bounds__(kBlock)
   } else {
     Hcol[j] = wnorm;
     st->inv_norm = 1.0 / wnorm;
+    st->n_steps += 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lazy normalisation (fused Float64 path).  The column a step produces is NOT normalised by a streaming
+// pass (v ./= wnorm, src/expansion.jl:106): it stays in HBM as w~ = beta * v together with a per-column
+// factor cs[c] = 1/beta (device array `colscale`, 1 for ordinary columns), and every consumer folds the
+// factor into the small quantities instead of touching n-sized data:
+//     y = A w~                      carries beta_{j-1}:      y/beta is formed on the fly in k_axpy_dots_cs
+//     h[c]    = cs[c] * (w~_c . y) / beta_{j-1}              (k_fin_dots_def)
+//     w -= sum_c w~_c * (cs[c] h[c])                          (coefficient vector handed to the kernels)
+//     V Q  ->  rows of Q scaled by cs[c] on the host          (restart rotation)
+// The norm of the newest column is not even reduced by its own stage: its block partials are folded into
+// the NEXT step's first reduction (multi-GPU: one all-reduce and two launches fewer per step).  The
+// breakdown test of the previous step (src/expansion.jl:99) is therefore evaluated one step late, which
+// the host cannot observe: it only sees the state after the batch.  Columns are materialised (scaled
+// once) before anything outside the expansion/rotation pair reads them.
+// FIN_DOTS_DEF: workgroup c <= j: column c of the partials (column j = |y|^2); in reduce-only mode an extra
+// workgroup j+1 delivers the pending norm so that ONE all-reduce of j+2 doubles serves everything.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+    k_fin_dots_def(const double* __restrict__ partial, int nb, int pnb, const double* __restrict__ partial2, int nb2,
+                   int j, double* __restrict__ red, double* __restrict__ Hcol, double* __restrict__ Hsub_prev,
+                   double* __restrict__ coef, double* __restrict__ colscale, int mode, DevState* __restrict__ st) {
+  if (st->breakdown >= 0) return;
+  __shared__ double sm[kBlock];
+  const int c = blockIdx.x;  // 0..j (mode 1: ..j+1)
+  const bool pend = st->pend != 0;
+  const bool pre = st->pend_reorth != 0;
+  double s = 0.0, b2 = 1.0;
+  if (mode != 2) {
+    if (c <= j) s = block_sum(partial + (int64_t)c * pnb, nb, sm);
+    if (mode == 1) {
+      if (c == j + 1) s = (pend && pre) ? block_sum(partial2, nb2, sm) : 0.0;
+      if (threadIdx.x == 0) red[c] = s;
+      return;
+    }
+    if (pend) b2 = pre ? block_sum(partial2, nb2, sm) : st->wnorm * st->wnorm;
+  } else {
+    s = red[c];
+    if (pend) b2 = pre ? red[j + 1] : st->wnorm * st->wnorm;
+  }
+  if (threadIdx.x != 0) return;
+  // factor of the input column: settled earlier (1 if the column is normalised) or established right now
+  double invb = pend ? 0.0 : colscale[j - 1];
+  if (pend) {
+    const double beta = pre ? sqrt(b2) : st->wnorm;
+    if (beta <= kEta * st->rnorm_p) {  // breakdown of the PREVIOUS step, src/expansion.jl:99-102
+      if (c == j) {
+        *Hsub_prev = 0.0;
+        st->breakdown = j - 1;
+        st->inv_norm = 0.0;
+      }
+      return;
+    }
+    invb = 1.0 / beta;
+    if (c == j) {
+      *Hsub_prev = beta;  // H[j, j-1] of the previous step, src/expansion.jl:105
+      st->n_steps += 1;
+    }
+  }
+  if (c < j) {
+    const double cs = (c == j - 1) ? invb : colscale[c];
+    const double h = s * invb * cs;  // true coefficient w.r.t. the NORMALISED column c
+    Hcol[c] = h;
+    coef[c] = h * cs;                // what multiplies the stored (possibly unnormalised) column
+  } else {
+    st->rnorm = sqrt(s) * invb;
+    st->invb = invb;
+    if (pend) colscale[j - 1] = invb;  // only workgroup j writes; the others derived the same value themselves
+  }
+}
+
+// FIN_MID for the deferred path: like k_fin_mid, but when no second pass is needed it does not finalise
+// the step (no H[j+1,j], no 1/wnorm): it records what the next k_fin_dots_def / k_fin_pend needs.
+__global__ void __launch_bounds__(kBlock)
+    k_fin_mid_def(const double* __restrict__ partial, const double* __restrict__ partial2, int nb, int pnb, int j,
+                  double* __restrict__ red, double* __restrict__ Hcol, double* __restrict__ coef,
+                  const double* __restrict__ colscale, int mode, DevState* __restrict__ st) {
+  if (st->breakdown >= 0) return;
+  __shared__ double sm[kBlock];
+  const int c = blockIdx.x;  // 0..j
+  double s = 0.0, nrm2 = 0.0;
+  if (mode != 2) {
+    s = block_sum(c < j ? partial + (int64_t)c * pnb : partial2, nb, sm);
+    if (mode == 1) {
+      if (threadIdx.x == 0) red[c] = s;
+      return;
+    }
+    nrm2 = (c == j) ? s : block_sum(partial2, nb, sm);
+  } else {
+    s = red[c];
+    nrm2 = red[j];
+  }
+  if (threadIdx.x != 0) return;
+  const double wnorm = sqrt(nrm2);
+  const double rnorm = st->rnorm;
+  const bool reorth = wnorm < kEta * rnorm;  // src/expansion.jl:91
+  if (c < j) {
+    if (reorth) {
+      const double cs = colscale[c];
+      Hcol[c] += s * cs;      // h .+= correction, :95
+      coef[c] = s * cs * cs;
+    }
+    return;
+  }
+  st->wnorm = wnorm;
+  st->pend = 1;
+  if (reorth) {
+    st->reorth = 1;
+    st->pend_reorth = 1;
+    st->rnorm_p = wnorm;  // :92  rnorm <- wnorm; the final norm comes out of the second-pass update
+    st->n_reorth += 1;
+  } else {
+    st->reorth = 0;
+    st->pend_reorth = 0;
+    st->rnorm_p = rnorm;
+  }
+}
+
+// FIN_PEND (end of a batch): settle the pending normalisation of the last column: beta, breakdown test,
+// H[j+1,j] and 1/beta for the k_scale that follows.
+__global__ void __launch_bounds__(kBlock)
+    k_fin_pend(const double* __restrict__ partial2, int nb2, double* __restrict__ red, double* __restrict__ Hsub, int j,
+               double* __restrict__ colscale, int mode, DevState* __restrict__ st) {
+  if (st->breakdown >= 0) return;
+  if (!st->pend) return;
+  __shared__ double sm[kBlock];
+  const bool pre = st->pend_reorth != 0;
+  double b2 = 0.0;
+  if (mode != 2) {
+    b2 = pre ? block_sum(partial2, nb2, sm) : 0.0;
+    if (mode == 1) {
+      if (threadIdx.x == 0) red[0] = b2;
+      return;
+    }
+  } else {
+    b2 = red[0];
+  }
+  if (threadIdx.x != 0) return;
+  const double beta = pre ? sqrt(b2) : st->wnorm;
+  st->pend = 0;
+  st->reorth = 0;
+  if (beta <= kEta * st->rnorm_p) {
+    *Hsub = 0.0;
+    st->breakdown = j;
+    st->inv_norm = 0.0;
+  } else {
+    *Hsub = beta;
+    st->inv_norm = 1.0 / beta;
+    colscale[j] = 1.0 / beta;  // the column stays unnormalised in HBM
+    st->wnorm = beta;
     st->n_steps += 1;
   }
 }
@@ -1022,13 +1186,13 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-// y = x (column copy), pads included
+// y = f * x (column copy with an optional factor), pads included
 template <class T>
-__global__ void __launch_bounds__(kBlock) k_copy(const T* __restrict__ x, T* __restrict__ y, int64_t ld) {
+__global__ void __launch_bounds__(kBlock) k_copy(const T* __restrict__ x, T* __restrict__ y, int64_t ld, double f) {
   constexpr int R = Pack<T>::R;
   int64_t pb, pe;
   block_range(ld / R, blockIdx.x, gridDim.x, pb, pe);
-  for (int64_t p = pb + threadIdx.x; p < pe; p += kBlock) st_pack(y + p * R, ld_pack(x + p * R));
+  for (int64_t p = pb + threadIdx.x; p < pe; p += kBlock) st_pack(y + p * R, scale_pack(ld_pack(x + p * R), f));
 }
 
 // w = A*x - (combination) helpers for the residual checks:  y -= sum_c X[:,c] * coef[c]
