@@ -445,9 +445,11 @@ template <class K> int resident_blocks(ks_ctx* ctx, K kernel, size_t smem, int& 
 // Small problems (n = 1e6, or 1/8 of 1e7 per GPU): do not launch more workgroups than there are
 // `packs_per_iter`-sized pieces of work, two iterations each.
 
+// (k_dots with 2 / 4 packs per lane measured 3 % / 70 % slower than 1: the accumulators already fill the
+// register file; the update kernels on the other hand gain 8 % from 8 packs per lane.)
 template <class D, int NC4> int dots_blocks(ks_workspace* ws) {
   static int cache = -1;
-  return resident_blocks(ws->ctx, ksd::k_dots<D, NC4>, 0, cache);
+  return resident_blocks(ws->ctx, ksd::k_dots<D, NC4, 1>, 0, cache);
 }
 
 template <class D> int dots_blocks_for(ks_workspace* ws, int nc4) {
@@ -468,7 +470,7 @@ template <class D> int dots_blocks_for(ks_workspace* ws, int nc4) {
 template <class D, int NC4>
 void launch_dots_nc(ks_workspace* ws, int nb, const D* V, int jc, const D* w, D* partial, int norm_slot, int pass,
                     const DevState* st) {
-  ksd::k_dots<D, NC4><<<nb, kBlock, 0, ws->ctx->stream>>>(V, ws->ld, jc, w, partial, ws->pnb, norm_slot, pass, st);
+  ksd::k_dots<D, NC4, 1><<<nb, kBlock, 0, ws->ctx->stream>>>(V, ws->ld, jc, w, partial, ws->pnb, norm_slot, pass, st);
 }
 
 // partial[b][0..j) = V[:,0:j)^H w (block-local), partial[b][j] = |w|^2 (block-local); returns the
@@ -563,9 +565,10 @@ template <int U> int launch_axpy_dots_cs(ks_workspace* ws, int j, double* w, int
   }
 }
 inline int launch_axpy_dots(ks_workspace* ws, int j, double* w, int defer = 0) {
-  static const int variant = env_int("KS_FUSED_VARIANT", 2);  // 0: per-lane columns, 1: column split U=1, 2: U=2
+  static const int variant = env_int("KS_FUSED_VARIANT", 4);  // 0: per-lane columns, 1: column split U=1, 2: U=2
   if (variant == 1 || (defer && variant == 0)) return launch_axpy_dots_cs<1>(ws, j, w, defer);
   if (variant == 2) return launch_axpy_dots_cs<2>(ws, j, w, defer);
+  if (variant == 4) return launch_axpy_dots_cs<4>(ws, j, w, defer);
   KS_REQUIRE(!defer, KS_ERR_INTERNAL, "per-lane fused variant does not support deferred normalisation");
   switch ((j + 3) / 4) {
     case 1: return launch_axpy_dots_nc<1, 2>(ws, j, w);
@@ -739,7 +742,11 @@ inline void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op, int from, 
     }
     {
       ProfScope ps(cx, KSP_AXPY, nb8 * (j + 2));
-      ksd::k_axpy<D><<<ws->nb, kBlock, 0, s>>>(V, ws->ld, j, w, coef, ws->partial2, 2, ws->st);
+      // packs per lane per iteration: at n = 1e7 going 2 -> 4 -> 8 gained 3 % + 8 % (16 lost 18 %); small
+      // problems (<= 3072 packs per workgroup) are ~1 % better off with 4
+      const int64_t ppb = (ws->ld / 2) / std::max(1, ws->nb);
+      if (ppb >= 3072) ksd::k_axpy<D, 8><<<ws->nb, kBlock, 0, s>>>(V, ws->ld, j, w, coef, ws->partial2, 2, ws->st);
+      else ksd::k_axpy<D, 4><<<ws->nb, kBlock, 0, s>>>(V, ws->ld, j, w, coef, ws->partial2, 2, ws->st);
     }
     if (j == to) {  // settle the norm of the last column (it stays unnormalised in HBM: colscale)
       {
@@ -1303,7 +1310,7 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     w->pstride = (int)round_up(maxdim + 2, 8);
     w->esz = dtype == KS_F64 ? 8 : 16;
     w->pnb = ctx->nblocks();
-    w->nb = cap_blocks(w.get(), w->pnb, 2 * kBlock);  // generic streaming grid (axpy: 4 packs per lane)
+    w->nb = cap_blocks(w.get(), w->pnb, 2 * kBlock);  // generic streaming grid
     const size_t esz = w->esz;
     const size_t vbytes = (size_t)w->ld * (maxdim + 1) * esz;
     KS_HIP(hipMalloc(&w->V, vbytes));

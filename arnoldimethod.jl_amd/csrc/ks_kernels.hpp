@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(kBlock)
 // re-reads column j-1 (an L1/L2 hit) instead of branching so all loads of a pack issue back to back.
 // `pass` 1: first projection; 2: DGKS correction (skipped unless st->reorth).
 // ------------------------------------------------------------------------------------------------
-template <class T, int NC4>
+template <class T, int NC4, int U = 1>
 __global__ void __launch_bounds__(kBlock)
     k_dots(const T* __restrict__ V, int64_t ldv, int j, const T* __restrict__ w, T* __restrict__ partial,
            int pnb, int norm_slot, int pass, const DevState* __restrict__ st) {
@@ -286,15 +286,35 @@ __global__ void __launch_bounds__(kBlock)
 
   int64_t pb, pe;
   block_range(ldv / R, blockIdx.x, gridDim.x, pb, pe);
-  for (int64_t p = pb + threadIdx.x; p < pe; p += kBlock) {
-    const int64_t r = p * R;
-    const P wv = ld_pack(w + r);
-    nrm += nrm2_pack(wv);
+  int64_t p = pb + threadIdx.x;
+  // U packs per lane per iteration: U x 4 KiB contiguous per column and workgroup
+  for (; p + (int64_t)(U - 1) * kBlock < pe; p += (int64_t)kBlock * U) {
+    P wv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      wv[u] = ld_pack(w + (p + (int64_t)u * kBlock) * R);
+      nrm += nrm2_pack(wv[u]);
+    }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       // only the last 3 columns of the 4-wide template granule can be absent; `c < j` is wave-uniform,
       // so the ragged tail costs a scalar branch and NO extra memory traffic (non-temporal loads of a
       // clamped duplicate column would go back to HBM).
+      if (c < NC - 3 || c < j) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const P v = ld_pack_nt(V + (int64_t)c * ldv + (p + (int64_t)u * kBlock) * R);
+          dot_acc(acc[c], v, wv[u]);
+        }
+      }
+    }
+  }
+  for (; p < pe; p += kBlock) {  // remainder, one pack at a time
+    const int64_t r = p * R;
+    const P wv = ld_pack(w + r);
+    nrm += nrm2_pack(wv);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
       if (c < NC - 3 || c < j) {
         const P v = ld_pack_nt(V + (int64_t)c * ldv + r);
         dot_acc(acc[c], v, wv);
@@ -430,7 +450,7 @@ __device__ __forceinline__ double axpy_body(const T* __restrict__ V, int64_t ldv
   return nrm;
 }
 
-template <class T>
+template <class T, int U = 4>
 __global__ void __launch_bounds__(kBlock)
     k_axpy(const T* __restrict__ V, int64_t ldv, int j, T* __restrict__ w, const T* __restrict__ coef,
            double* __restrict__ partial2, int pass, const DevState* __restrict__ st) {
@@ -439,7 +459,7 @@ __global__ void __launch_bounds__(kBlock)
     if (pass == 2 && !st->reorth) return;
   }
   constexpr int R = Pack<T>::R;
-  constexpr int U = 4;  // packs per lane per iteration: 4 x 4 KiB contiguous per column and workgroup
+  // U packs per lane per iteration: U x 4 KiB contiguous per column and workgroup
   __shared__ T g[128];
   __shared__ double red[kBlock / 64];
   int64_t pb, pe;
