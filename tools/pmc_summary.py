@@ -61,7 +61,7 @@ def main():
         if k == "spmv":
             alg = 12.0 * nnz + 4.0 * (n + 1) + 2 * col
         elif k == "dots":
-            nc4 = int(re.search(r"k_dots<double, (\d+)>", name).group(1))
+            nc4 = int(re.search(r"k_dots<double, (\d+)", name).group(1))
             # first step of an expansion: smallest j of the granule is unknown -> track by sequence
             if j is None or nc4 < (last_nc4 or 0):
                 j = None
