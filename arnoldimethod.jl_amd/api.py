@@ -498,8 +498,13 @@ def partialschur(A, v1=None, nev=None, which="LM", tol=None, mindim=None, maxdim
     _which_code(which)
     if v1 is not None and len(v1) != n:
         raise ArgumentError("v1 should have the same dimension as A")
+    v1_complex = v1 is not None and np.asarray(v1).dtype.kind == "c"
+    if v1_complex and not isinstance(A, Operator) and np.dtype(getattr(A, "dtype", np.float64)).kind != "c" and hasattr(A, "astype"):
+        # ArnoldiWorkspace(v1, maxdim) takes the element type of v1 (src/ArnoldiMethod.jl:71-79): a real matrix
+        # with a complex start vector runs in complex arithmetic
+        A = A.astype(np.complex128)
     op = as_operator(A, ctx)
-    dtype = np.complex128 if (op.dtype.kind == "c" or (v1 is not None and np.asarray(v1).dtype.kind == "c")) else np.float64
+    dtype = np.complex128 if (op.dtype.kind == "c" or v1_complex) else np.float64
     if np.dtype(dtype) != op.dtype:
         raise ArgumentError("a complex start vector needs a complex operator")
     ws = ArnoldiWorkspace(n, maxdim, dtype, ctx=op.ctx)

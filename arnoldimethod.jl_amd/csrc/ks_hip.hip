@@ -1007,6 +1007,8 @@ template <class T> struct HipBackend : ks::Backend<T> {
     ws->ctx->use();
     KS_HIP(hipStreamSynchronize(ws->ctx->stream));  // Qstage may still be in flight from a previous rotation
     T* qs = static_cast<T*>(ws->Qstage);
+    // lazy columns below the rotated range are not absorbed by this rotation: make them ordinary first
+    if (ws->has_lazy() && ws->lazy_lo < c0) materialize(ws);
     // lazily normalised columns are stored as beta*v: V Q = (stored) diag(1/beta) Q  -> scale the rows of Q
     for (int jj = 0; jj < r; ++jj)
       for (int ii = 0; ii < c; ++ii) qs[ii + (size_t)jj * c] = Q(c0 + ii, c0 + jj) * ws->hostscale[c0 + ii];

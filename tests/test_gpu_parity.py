@@ -577,3 +577,36 @@ def test_identity_and_one_by_one():
     check_schur(sp.identity(50, format="csr") * 3.0, dec, 1e-12)
     dec, hist = pkg.partialschur(np.array([[2.5]]), nev=1)
     assert hist.converged and hist.mvproducts == 1 and dec.eigenvalues[0] == pytest.approx(2.5)
+
+
+def test_real_matrix_complex_start_vector():
+    """ArnoldiWorkspace(v1, maxdim) follows the element type of v1 (src/ArnoldiMethod.jl:71-79)."""
+    A = laplace1d(60)
+    v1 = oa.uniform_hash(1, np.arange(60)) + 1j * oa.uniform_hash(2, np.arange(60))
+    dec, hist = pkg.partialschur(A, v1=v1, nev=4, which="LR", tol=1e-10)
+    assert hist.converged and dec.Q.dtype == np.complex128
+    exact = np.sort(2 - 2 * np.cos(np.arange(1, 61) * np.pi / 61))[::-1][:4]
+    np.testing.assert_allclose(np.sort(dec.eigenvalues.real)[::-1][:4], exact, atol=1e-9)
+
+
+def test_lazy_columns_are_materialised_for_every_reader():
+    """The fused Float64 expansion leaves its new columns unnormalised in HBM (factor kept aside); any
+    reader outside the expansion/rotation pair must see ordinary orthonormal columns."""
+    A = laplace3d(10, 11, 12)
+    n = A.shape[0]
+    op = pkg.csr_operator(A)
+    ws = pkg.ArnoldiWorkspace(n, 30)
+    ws.reinitialize(0, oa.uniform_hash(7, np.arange(n)))
+    ws.iterate_arnoldi(op, 1, 12)      # lazy columns 1..12
+    ws.iterate_arnoldi(op, 13, 30)     # a second batch on top of lazy columns
+    H = np.array(ws.H)
+    for j in (1, 5, 12, 13, 30):       # per-column readers
+        assert ws.norm(j) == pytest.approx(1.0, abs=1e-13)
+    V = ws.V
+    assert np.linalg.norm(V.T @ V - np.eye(31)) < 1e-12
+    np.testing.assert_allclose(A @ V[:, :30], V @ H, atol=1e-12)
+    # and the verbs keep working on the now ordinary columns
+    h = ws.gemv_t(30, 30)
+    assert np.abs(h).max() < 1e-12
+    res, orth = ws.arnoldi_relation(op, 30)
+    assert res < 1e-12 and orth < 1e-12
