@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scripts_bench_env.sh "ENV1=.. ENV2=.." ...   (one bench run per argument; prints per-class GB/s)
+# usage: tools/bench_env.sh "ENV1=.. ENV2=.." ...   (one bench run per argument; prints per-class GB/s)
 for envs in "$@"; do
   echo "=== $envs"
   env $envs timeout 600 python bench.py --no-cpu-baseline --steps 6 --warmup 1 | python -c "
