@@ -7,12 +7,12 @@ API call dlopens `libkschur_hip.so` and fails loudly if it (or a gfx950 device) 
 from ._lib import ArgumentError, DimensionMismatch, HipError, QRDidNotConverge  # noqa: F401
 from .api import (  # noqa: F401
     LI, LM, LR, SI, SR, ArnoldiWorkspace, Context, History, Operator, PartialSchur, Target, as_operator,
-    csr_operator, default_context, host_operator, partialeigen, partialschur, partialschur_, vtype,
+    csr_operator, default_context, device_operator, host_operator, partialeigen, partialschur, partialschur_, vtype,
 )
 from . import matrices  # noqa: F401
 
 __all__ = [
     "partialschur", "partialschur_", "partialeigen", "ArnoldiWorkspace", "PartialSchur", "History",
-    "LM", "LR", "SR", "LI", "SI", "Context", "Operator", "csr_operator", "host_operator", "as_operator",
+    "LM", "LR", "SR", "LI", "SI", "Context", "Operator", "csr_operator", "host_operator", "device_operator", "as_operator",
     "ArgumentError", "DimensionMismatch", "matrices",
 ]

@@ -230,6 +230,46 @@ def host_operator(fn, n: int, dtype=np.float64, ctx: Context | None = None) -> O
     return op
 
 
+class _DevArray:
+    """Minimal __cuda_array_interface__ carrier so torch can wrap a raw device pointer without copying."""
+
+    def __init__(self, ptr: int, n: int, dt: np.dtype):
+        self.__cuda_array_interface__ = {
+            "shape": (n,), "typestr": "<c16" if dt.kind == "c" else "<f8", "data": (ptr, False), "version": 2, "strides": None,
+        }
+
+
+def device_operator(fn, n: int, dtype=np.float64, ctx: Context | None = None) -> Operator:
+    """Opaque DEVICE operator: `fn(y, x)` receives two torch tensors that alias columns of V in HBM and must
+    enqueue y = A*x on the current torch stream (which is the library's stream while `fn` runs).  This is the
+    device-resident form of the `mul!(y, A, x)` seam (src/expansion.jl:121): e.g. a dense matrix via
+    `torch.mv`, a matrix-free stencil, a preconditioned solve.  torch is only plumbing here."""
+    import torch
+
+    ctx = ctx or default_context()
+    L = _lib.load()
+    dt = np.dtype(vtype(np.empty(0, dtype=dtype)))
+    err = []
+
+    def _cb(_user, xp, yp, stream):
+        try:
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=torch.device("cuda", ctx.device))):
+                x = torch.as_tensor(_DevArray(xp, n, dt), device=torch.device("cuda", ctx.device))
+                y = torch.as_tensor(_DevArray(yp, n, dt), device=torch.device("cuda", ctx.device))
+                fn(y, x)
+            return 0
+        except Exception as e:  # noqa: BLE001 - must not propagate through C
+            err.append(e)
+            return 1
+
+    cb = _lib.DEVICE_APPLY_FN(_cb)
+    h = C.c_void_p()
+    check(L.ks_operator_device_callback(ctx._h, n, _dtype_code(dt), cb, None, C.byref(h)))
+    op = Operator(ctx, h, (n, n), dt, keep=(cb, err))
+    op.errors = err
+    return op
+
+
 def as_operator(A, ctx: Context | None = None) -> Operator:
     import scipy.sparse as sp
 

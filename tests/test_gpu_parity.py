@@ -610,3 +610,28 @@ def test_lazy_columns_are_materialised_for_every_reader():
     assert np.abs(h).max() < 1e-12
     res, orth = ws.arnoldi_relation(op, 30)
     assert res < 1e-12 and orth < 1e-12
+
+
+def test_device_callback_operator_dense_matrix():
+    """Opaque device operator (third operator mode of include/kschur.h): a dense matrix applied with torch.mv
+    on the library's stream; columns of V are handed over as zero-copy tensors."""
+    import torch
+
+    rng = np.random.default_rng(41)
+    n = 300
+    A = rng.standard_normal((n, n))
+    A = A + A.T + np.diag(np.linspace(0, 40, n))
+    Ad = torch.as_tensor(A, device="cuda")
+
+    def mul(y, x):
+        torch.mv(Ad, x, out=y)
+
+    op = pkg.device_operator(mul, n)
+    v1 = oa.uniform_hash(5, np.arange(n))
+    ws = pkg.ArnoldiWorkspace(v1, 30, ctx=op.ctx)
+    F, hist = pkg.partialschur_(op, ws, nev=5, which="LR", tol=1e-10, mindim=10, maxdim=30)
+    ref, rhist = oa.partialschur(A, v1=v1, nev=5, which="LR", tol=1e-10, mindim=10, maxdim=30)
+    assert hist.converged and hist.mvproducts == rhist.mvproducts
+    np.testing.assert_allclose(np.sort(F.eigenvalues.real), np.sort(ref.eigenvalues.real), atol=1e-9)
+    Q, R = F.Q, np.array(F.R)
+    assert np.linalg.norm(A @ Q - Q @ R) < 1e-8 and np.linalg.norm(Q.T @ Q - np.eye(Q.shape[1])) < 1e-12
