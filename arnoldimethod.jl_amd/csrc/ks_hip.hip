@@ -207,6 +207,9 @@ template <class D> struct CsrOp : ks_operator {
   int32_t* send_idx = nullptr;
   std::vector<int> neigh;
   std::vector<int64_t> send_ptr, recv_ptr;
+  std::vector<int64_t> send_first;  // >= 0: neighbour p's rows are the contiguous run starting here (no packing)
+  std::vector<int64_t> pack_ptr;    // offset of neighbour p's packed values in sendbuf (scattered lists only)
+  int64_t nscatter = 0;             // number of packed entries (send_idx holds only these)
 
   ~CsrOp() override {
     (void)hipFree(rowptr); (void)hipFree(colidx); (void)hipFree(val);
@@ -217,16 +220,20 @@ template <class D> struct CsrOp : ks_operator {
     D* y = static_cast<D*>(yv);
     hipStream_t s = ctx->stream;
     if (!neigh.empty()) {
-      const int64_t nsend = send_ptr.back();
-      if (nsend > 0) {
-        const int gb = (int)std::min<int64_t>((nsend + kBlock - 1) / kBlock, 4096);
-        ksd::k_gather<D><<<gb, kBlock, 0, s>>>(x, send_idx, sendbuf, nsend, st);
+      // neighbours whose send list is one contiguous run of rows (grid planes of a slab partition) are sent
+      // straight out of x; only genuinely scattered lists go through the pack kernel
+      if (nscatter > 0) {
+        const int gb = (int)std::min<int64_t>((nscatter + kBlock - 1) / kBlock, 4096);
+        ksd::k_gather<D><<<gb, kBlock, 0, s>>>(x, send_idx, sendbuf, nscatter, st);
       }
       constexpr int dpe = sizeof(D) / 8;  // doubles per element
       KS_NCCL(ncclGroupStart());
       for (size_t p = 0; p < neigh.size(); ++p) {
         const int64_t sc = send_ptr[p + 1] - send_ptr[p], rc = recv_ptr[p + 1] - recv_ptr[p];
-        if (sc > 0) KS_NCCL(ncclSend(sendbuf + send_ptr[p], (size_t)sc * dpe, ncclDouble, neigh[p], ctx->comm, s));
+        if (sc > 0) {
+          const D* src = send_first[p] >= 0 ? x + send_first[p] : sendbuf + pack_ptr[p];
+          KS_NCCL(ncclSend(src, (size_t)sc * dpe, ncclDouble, neigh[p], ctx->comm, s));
+        }
         if (rc > 0) KS_NCCL(ncclRecv(ghost + recv_ptr[p], (size_t)rc * dpe, ncclDouble, neigh[p], ctx->comm, s));
       }
       KS_NCCL(ncclGroupEnd());
@@ -1226,10 +1233,25 @@ int ks_operator_csr_dist(ks_ctx* ctx, int64_t nrows_local, int64_t nghost, int64
       op->recv_ptr.assign(nneigh + 1, 0);
       for (int p = 0; p < nneigh; ++p) op->recv_ptr[p + 1] = op->recv_ptr[p] + recv_cnt[p];
       KS_REQUIRE(op->recv_ptr[nneigh] == nghost, KS_ERR_ARGUMENT, "recv counts do not add up to nghost");
-      const int64_t nsend = nneigh ? op->send_ptr[nneigh] : 0;
-      KS_HIP(hipMalloc(&op->sendbuf, std::max<size_t>((size_t)nsend * sizeof(D), 16)));
-      KS_HIP(hipMalloc(&op->send_idx, std::max<size_t>((size_t)nsend * 4, 16)));
-      if (nsend) KS_HIP(hipMemcpy(op->send_idx, send_idx, (size_t)nsend * 4, hipMemcpyHostToDevice));
+      // split the send lists into contiguous runs (sent in place) and scattered ones (packed)
+      std::vector<int32_t> packed;
+      op->send_first.assign(nneigh, -1);
+      op->pack_ptr.assign(nneigh + 1, 0);
+      for (int p = 0; p < nneigh; ++p) {
+        const int64_t a = send_ptr[p], b = send_ptr[p + 1];
+        bool contiguous = b > a;
+        for (int64_t q = a; q < b; ++q) {
+          KS_REQUIRE(send_idx[q] >= 0 && send_idx[q] < nrows_local, KS_ERR_ARGUMENT, "send index out of range");
+          if (q > a && send_idx[q] != send_idx[q - 1] + 1) contiguous = false;
+        }
+        if (contiguous) op->send_first[p] = send_idx[a];
+        else packed.insert(packed.end(), send_idx + a, send_idx + b);
+        op->pack_ptr[p + 1] = (int64_t)packed.size();
+      }
+      op->nscatter = (int64_t)packed.size();
+      KS_HIP(hipMalloc(&op->sendbuf, std::max<size_t>(packed.size() * sizeof(D), 16)));
+      KS_HIP(hipMalloc(&op->send_idx, std::max<size_t>(packed.size() * 4, 16)));
+      if (!packed.empty()) KS_HIP(hipMemcpy(op->send_idx, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
       KS_REQUIRE(nneigh == 0 || ctx->comm != nullptr, KS_ERR_ARGUMENT, "halo plan needs a distributed context");
       *out = guard.release();
     });

@@ -481,7 +481,8 @@ def test_full_size_properties_1e6():
 
 
 # ------------------------------------------------------------------ RCCL code path on one GPU
-def test_rccl_path_single_rank_communicator():
+@pytest.mark.parametrize("pattern", ["contiguous", "scattered"])
+def test_rccl_path_single_rank_communicator(pattern):
     """A 1-rank RCCL communicator drives the distributed code path of the library on a single GPU:
     reduce-only / all-reduce / post kernels of the DGKS step, and the halo plan executed with
     ncclSend/ncclRecv (here: a self exchange that copies own rows into ghost slots)."""
@@ -494,8 +495,11 @@ def test_rccl_path_single_rank_communicator():
     # periodic closure in z implemented through GHOSTS: row i also couples (-1) to row (i + n/2) mod n,
     # addressed as a ghost column that the plan fills from this very rank.
     half = n // 2
-    extra_cols = (np.arange(n) + half) % n
-    ghosts = np.unique(extra_cols)                     # all rows, each once
+    if pattern == "contiguous":   # ghosts = all rows in order -> sent straight out of x
+        extra_cols = (np.arange(n) + half) % n
+    else:                         # ghosts = the odd rows only -> packed by k_gather
+        extra_cols = ((np.arange(n) * 7 + 3) % n) | 1
+    ghosts = np.unique(extra_cols)
     ip = np.zeros(n + 1, dtype=np.int64)
     rows_idx, rows_val = [], []
     Ac = A.tocsr()
