@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkschur_hip.so")
 
-KS_OK, KS_ERR_ARGUMENT, KS_ERR_DIMENSION, KS_ERR_HIP, KS_ERR_RCCL, KS_ERR_QR, KS_ERR_INTERNAL, KS_ERR_NO_DEVICE, KS_ERR_OPERATOR = range(9)
+KS_OK, KS_ERR_ARGUMENT, KS_ERR_DIMENSION, KS_ERR_HIP, KS_ERR_RCCL, KS_ERR_QR, KS_ERR_INTERNAL, KS_ERR_NO_DEVICE, KS_ERR_OPERATOR, KS_ERR_COMM = range(10)
 KS_F64, KS_C64 = 0, 1
 KS_I32, KS_I64 = 0, 1
 KS_CSR, KS_CSC = 0, 1
@@ -33,6 +33,10 @@ class QRDidNotConverge(RuntimeError):
 
 class HipError(RuntimeError):
     pass
+
+
+class CommTimeout(HipError):
+    """A peer rank did not take part in an exchange within KS_P2P_TIMEOUT_S (peer-to-peer transport)."""
 
 
 class ks_params(C.Structure):
@@ -65,6 +69,9 @@ PROTOTYPES = {
     "ks_ctx_create": [i32, P(vp)],
     "ks_comm_unique_id": [vp],
     "ks_ctx_create_dist": [i32, i32, i32, vp, P(vp)],
+    "ks_ctx_create_p2p": [i32, i32, i32, P(vp)],
+    "ks_ctx_p2p_handle": [vp, vp],
+    "ks_ctx_p2p_attach": [vp, vp],
     "ks_ctx_destroy": [vp],
     "ks_ctx_synchronize": [vp],
     "ks_ctx_rank": [vp, P(C.c_int), P(C.c_int)],
@@ -147,4 +154,6 @@ def check(rc: int):
         raise DimensionMismatch(msg)
     if rc == KS_ERR_QR:
         raise QRDidNotConverge(msg)
+    if rc == KS_ERR_COMM:
+        raise CommTimeout(msg)
     raise HipError(f"libkschur_hip error {rc}: {msg}")

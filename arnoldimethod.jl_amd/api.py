@@ -81,12 +81,14 @@ def _dtype_code(dt) -> int:
 
 # ------------------------------------------------------------------ context
 class Context:
-    """One GPU (+ optionally one rank of an RCCL communicator)."""
+    """One GPU (+ optionally one rank of a multi-GPU job: RCCL communicator or peer-to-peer regions)."""
 
-    def __init__(self, device: int = 0, rank: int = 0, nranks: int = 1, unique_id: bytes | None = None):
+    def __init__(self, device: int = 0, rank: int = 0, nranks: int = 1, unique_id: bytes | None = None, p2p: bool = False):
         L = _lib.load()
         h = C.c_void_p()
-        if nranks > 1 or unique_id is not None:
+        if p2p:
+            check(L.ks_ctx_create_p2p(device, rank, nranks, C.byref(h)))
+        elif nranks > 1 or unique_id is not None:
             assert unique_id is not None and len(unique_id) == 128
             buf = C.create_string_buffer(unique_id, 128)
             check(L.ks_ctx_create_dist(device, rank, nranks, buf, C.byref(h)))
@@ -94,6 +96,17 @@ class Context:
             check(L.ks_ctx_create(device, C.byref(h)))
         self._h = h
         self.device, self.rank, self.nranks = device, rank, nranks
+
+    # peer-to-peer transport: export this rank's region handle / map everybody else's (include/kschur.h)
+    def p2p_handle(self) -> bytes:
+        buf = C.create_string_buffer(64)
+        check(_lib.load().ks_ctx_p2p_handle(self._h, buf))
+        return buf.raw
+
+    def p2p_attach(self, handles: list[bytes]):
+        assert len(handles) == self.nranks and all(len(x) == 64 for x in handles)
+        buf = C.create_string_buffer(b"".join(handles), 64 * self.nranks)
+        check(_lib.load().ks_ctx_p2p_attach(self._h, buf))
 
     @staticmethod
     def unique_id() -> bytes:

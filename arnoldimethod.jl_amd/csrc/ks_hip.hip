@@ -111,16 +111,40 @@ struct ks_ctx {
   hipStream_t stream = nullptr;
   int rank = 0, nranks = 1;
   ncclComm_t comm = nullptr;
+  // peer-to-peer transport (ks_p2p.hpp): one uncached, IPC-shared region per rank
+  struct P2p {
+    bool allocated = false, attached = false;
+    void* region = nullptr;
+    size_t region_bytes = 0, arena_off = 0, arena_bytes = 0, arena_used = 0;
+    void* peer[ksd::kP2pMaxRanks] = {};
+    uint32_t* seqc = nullptr;
+    uint32_t* hstate = nullptr;
+    int* err_h = nullptr;
+    int cap = 0;
+    ksd::P2pDev dev{};
+  } p2p;
   int num_cu = 256;
   int bpc = 6;  // streaming workgroups per CU (KS_BPC; 6 measured best on MI355X, tools/streambench.hip)
   int nblocks() const { return num_cu * bpc; }
   void use() const { KS_HIP(hipSetDevice(device)); }
+  // A context created with ks_ctx_create_dist / ks_ctx_create_p2p always takes the collective code path
+  // (even with nranks == 1, which is how that path is exercised on a single-GPU box).
+  bool distributed() const { return comm != nullptr || p2p.attached; }
   // in-place sum over ranks of `count` doubles living in device memory
-  // A context created with ks_ctx_create_dist always goes through RCCL (even with nranks == 1, which is
-  // how the collective code path is exercised on a single-GPU box).
-  bool distributed() const { return comm != nullptr; }
   void allreduce(double* dev, int count) {
-    if (comm) KS_NCCL(ncclAllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, comm, stream));
+    if (p2p.attached) {
+      KS_REQUIRE(count <= p2p.cap, KS_ERR_ARGUMENT, "reduction longer than the peer-to-peer window (KS_P2P_CAP)");
+      const int waves = (count + 3) / 4;
+      ksd::k_p2p_allreduce<<<(waves + 3) / 4, 256, 0, stream>>>(dev, count, p2p.dev);
+    } else if (comm) {
+      KS_NCCL(ncclAllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, comm, stream));
+    }
+  }
+  // a bounded spin of the peer-to-peer kernels gave up: report instead of computing on garbage
+  void check_comm() const {
+    if (p2p.err_h && *p2p.err_h != 0)
+      throw KsError{KS_ERR_COMM, "peer-to-peer exchange timed out waiting for a peer (first reported by rank " +
+                                     std::to_string(*p2p.err_h - 1) + ")"};
   }
 };
 
@@ -178,6 +202,83 @@ static void ctx_init_device(ks_ctx* c, int device) {
   KS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 }
 
+// ---- peer-to-peer region ---------------------------------------------------------------------------
+static void p2p_alloc(ks_ctx* c) {
+  auto& P = c->p2p;
+  KS_REQUIRE(c->nranks <= ksd::kP2pMaxRanks, KS_ERR_ARGUMENT, "peer-to-peer transport supports at most 16 ranks");
+  P.cap = env_int("KS_P2P_CAP", 2048);
+  P.arena_bytes = (size_t)env_int("KS_P2P_ARENA_MB", 64) << 20;
+  P.arena_off = (size_t)round_up((int64_t)(ksd::p2p_ll_words(c->nranks, P.cap) + ksd::p2p_flag_words(c->nranks)) * 8, 4096);
+  P.region_bytes = P.arena_off + P.arena_bytes;
+  // uncached (fine-grained) device memory: remote stores of the peers must not be shadowed by stale L2 lines
+  KS_HIP(hipExtMallocWithFlags(&P.region, P.region_bytes, hipDeviceMallocUncached));
+  KS_HIP(hipMemset(P.region, 0, P.region_bytes));
+  KS_HIP(hipMalloc(&P.seqc, (size_t)P.cap * 4));
+  KS_HIP(hipMemset(P.seqc, 0, (size_t)P.cap * 4));
+  KS_HIP(hipMalloc(&P.hstate, 16));
+  KS_HIP(hipMemset(P.hstate, 0, 16));
+  KS_HIP(hipHostMalloc(&P.err_h, sizeof(int), hipHostMallocMapped));
+  *P.err_h = 0;
+  KS_HIP(hipDeviceSynchronize());
+  P.allocated = true;
+}
+
+// `handles`: nranks x 64 bytes in rank order (this rank's own entry is ignored)
+static void p2p_attach(ks_ctx* c, const void* handles) {
+  auto& P = c->p2p;
+  KS_REQUIRE(P.allocated && !P.attached, KS_ERR_ARGUMENT, "context has no (or an already attached) peer-to-peer region");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  for (int q = 0; q < c->nranks; ++q) {
+    if (q == c->rank) { P.peer[q] = P.region; continue; }
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, static_cast<const char*>(handles) + (size_t)q * 64, 64);
+    KS_HIP(hipIpcOpenMemHandle(&P.peer[q], h, hipIpcMemLazyEnablePeerAccess));
+  }
+  ksd::P2pDev d{};
+  for (int q = 0; q < c->nranks; ++q) d.region[q] = static_cast<uint64_t*>(P.peer[q]);
+  d.seqc = P.seqc;
+  int* err_d = nullptr;
+  KS_HIP(hipHostGetDevicePointer((void**)&err_d, P.err_h, 0));
+  d.err = err_d;
+  d.rank = c->rank;
+  d.nranks = c->nranks;
+  d.cap = P.cap;
+  d.timeout_ticks = (long long)env_int("KS_P2P_TIMEOUT_S", 30) * 100000000LL;  // wall_clock64 runs at 100 MHz
+  P.dev = d;
+  P.attached = true;
+}
+
+static void p2p_release(ks_ctx* c) {
+  auto& P = c->p2p;
+  if (!P.allocated) return;
+  for (int q = 0; q < c->nranks; ++q)
+    if (q != c->rank && P.peer[q]) (void)hipIpcCloseMemHandle(P.peer[q]);
+  (void)hipFree(P.region);
+  (void)hipFree(P.seqc);
+  (void)hipFree(P.hstate);
+  (void)hipHostFree(P.err_h);
+  P = ks_ctx::P2p{};
+}
+
+// gather `k` small non-negative integers (< 2^53) from every rank: rank r contributes row r of a
+// nranks x k table of doubles, the others add zeros -- the sum IS the all-gather (exact in Float64)
+static std::vector<int64_t> p2p_allgather_i64(ks_ctx* c, const std::vector<int64_t>& mine) {
+  const int k = (int)mine.size(), total = k * c->nranks;
+  std::vector<double> h((size_t)total, 0.0);
+  for (int i = 0; i < k; ++i) h[(size_t)c->rank * k + i] = (double)mine[i];
+  double* d = nullptr;
+  KS_HIP(hipMalloc(&d, (size_t)total * 8));
+  KS_HIP(hipMemcpyAsync(d, h.data(), (size_t)total * 8, hipMemcpyHostToDevice, c->stream));
+  c->allreduce(d, total);
+  KS_HIP(hipMemcpyAsync(h.data(), d, (size_t)total * 8, hipMemcpyDeviceToHost, c->stream));
+  KS_HIP(hipStreamSynchronize(c->stream));
+  (void)hipFree(d);
+  c->check_comm();
+  std::vector<int64_t> out((size_t)total);
+  for (int i = 0; i < total; ++i) out[i] = (int64_t)h[i];
+  return out;
+}
+
 // ------------------------------------------------------------------------------------------------
 // operators
 // ------------------------------------------------------------------------------------------------
@@ -210,16 +311,35 @@ template <class D> struct CsrOp : ks_operator {
   std::vector<int64_t> send_first;  // >= 0: neighbour p's rows are the contiguous run starting here (no packing)
   std::vector<int64_t> pack_ptr;    // offset of neighbour p's packed values in sendbuf (scattered lists only)
   int64_t nscatter = 0;             // number of packed entries (send_idx holds only these)
+  // peer-to-peer halo (ks_p2p.hpp): ghost lives (double-buffered) in this rank's shared arena, neighbours
+  // store into it directly
+  bool p2p_halo = false;
+  int64_t ghost_stride = 0;         // elements between the two ghost slots
+  size_t arena_lo = 0, arena_hi = 0;
+  int32_t* send_idx_all = nullptr;  // every send entry (contiguous runs included), neighbour by neighbour
+  ksd::HaloArgs hargs{};
 
   ~CsrOp() override {
     (void)hipFree(rowptr); (void)hipFree(colidx); (void)hipFree(val);
-    (void)hipFree(ghost); (void)hipFree(sendbuf); (void)hipFree(send_idx);
+    if (p2p_halo) {
+      if (ctx->p2p.arena_used == arena_hi) ctx->p2p.arena_used = arena_lo;  // stack discipline; otherwise kept until the context dies
+    } else {
+      (void)hipFree(ghost);
+    }
+    (void)hipFree(sendbuf); (void)hipFree(send_idx); (void)hipFree(send_idx_all);
   }
   void apply(const void* xv, void* yv, const DevState* st) override {
     const D* x = static_cast<const D*>(xv);
     D* y = static_cast<D*>(yv);
     hipStream_t s = ctx->stream;
-    if (!neigh.empty()) {
+    if (p2p_halo) {
+      if (!neigh.empty()) {
+        const int64_t total = send_ptr.back();
+        const int gb = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 512));
+        ksd::k_halo_push<D><<<gb, 256, 0, s>>>(x, send_idx_all, hargs, ctx->p2p.dev, ctx->p2p.hstate,
+                                                 st ? &st->breakdown : nullptr);
+      }
+    } else if (!neigh.empty()) {
       // neighbours whose send list is one contiguous run of rows (grid planes of a slab partition) are sent
       // straight out of x; only genuinely scattered lists go through the pack kernel
       if (nscatter > 0) {
@@ -244,8 +364,9 @@ template <class D> struct CsrOp : ks_operator {
       // (a variant reading the non-zeros as aligned pairs with non-temporal loads measured 15 % slower)
       static const int nt = env_int("KS_SPMV_NT", 0);
       const size_t smem = (size_t)lds_cap * sizeof(D);
-      if (nt) ksd::k_spmv_csr<D, true><<<ntiles, kBlock, smem, s>>>(rowptr, colidx, val, x, ghost, y, n_local, ntiles, lds_cap, st);
-      else ksd::k_spmv_csr<D, false><<<ntiles, kBlock, smem, s>>>(rowptr, colidx, val, x, ghost, y, n_local, ntiles, lds_cap, st);
+      const uint32_t* hseq = (p2p_halo && !neigh.empty()) ? ctx->p2p.hstate : nullptr;
+      if (nt) ksd::k_spmv_csr<D, true><<<ntiles, kBlock, smem, s>>>(rowptr, colidx, val, x, ghost, y, n_local, ntiles, lds_cap, st, hseq, ghost_stride);
+      else ksd::k_spmv_csr<D, false><<<ntiles, kBlock, smem, s>>>(rowptr, colidx, val, x, ghost, y, n_local, ntiles, lds_cap, st, hseq, ghost_stride);
     }
     KS_HIP(hipGetLastError());
   }
@@ -712,6 +833,8 @@ inline void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op, int from, 
   const D* part = static_cast<const D*>(ws->partial);
   const double nb8 = (double)ws->n * sizeof(D);
   const bool dist = cx->distributed();
+  const bool p2p = cx->p2p.attached;  // exchange folded into the reduction kernels (mode 3)
+  const ksd::P2pDev pd = cx->p2p.dev;
   for (int j = from; j <= to; ++j) {
     D* w = static_cast<D*>(ws->col(j));
     D* Hcol = Hd + (size_t)(j - 1) * ldh;
@@ -724,12 +847,12 @@ inline void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op, int from, 
     }
     {
       ProfScope ps(cx, KSP_FIN, 0.0);
-      if (!dist) {
-        ksd::k_fin_dots_def<<<j + 1, kBlock, 0, s>>>(part, nbd, ws->pnb, ws->partial2, ws->nb, j, red, Hcol, Hsub_prev, coef, ws->colscale, 0, ws->st);
+      if (!dist || p2p) {
+        ksd::k_fin_dots_def<<<j + 1, kBlock, 0, s>>>(part, nbd, ws->pnb, ws->partial2, ws->nb, j, red, Hcol, Hsub_prev, coef, ws->colscale, p2p ? 3 : 0, ws->st, pd);
       } else {
-        ksd::k_fin_dots_def<<<j + 2, kBlock, 0, s>>>(part, nbd, ws->pnb, ws->partial2, ws->nb, j, red, Hcol, Hsub_prev, coef, ws->colscale, 1, ws->st);
+        ksd::k_fin_dots_def<<<j + 2, kBlock, 0, s>>>(part, nbd, ws->pnb, ws->partial2, ws->nb, j, red, Hcol, Hsub_prev, coef, ws->colscale, 1, ws->st, pd);
         cx->allreduce(red, j + 2);
-        ksd::k_fin_dots_def<<<j + 1, 64, 0, s>>>(part, nbd, ws->pnb, ws->partial2, ws->nb, j, red, Hcol, Hsub_prev, coef, ws->colscale, 2, ws->st);
+        ksd::k_fin_dots_def<<<j + 1, 64, 0, s>>>(part, nbd, ws->pnb, ws->partial2, ws->nb, j, red, Hcol, Hsub_prev, coef, ws->colscale, 2, ws->st, pd);
       }
     }
     int nbf;
@@ -739,12 +862,12 @@ inline void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op, int from, 
     }
     {
       ProfScope ps(cx, KSP_FIN, 0.0);
-      if (!dist) {
-        ksd::k_fin_mid_def<<<j + 1, kBlock, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hcol, coef, ws->colscale, 0, ws->st);
+      if (!dist || p2p) {
+        ksd::k_fin_mid_def<<<j + 1, kBlock, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hcol, coef, ws->colscale, p2p ? 3 : 0, ws->st, pd);
       } else {
-        ksd::k_fin_mid_def<<<j + 1, kBlock, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hcol, coef, ws->colscale, 1, ws->st);
+        ksd::k_fin_mid_def<<<j + 1, kBlock, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hcol, coef, ws->colscale, 1, ws->st, pd);
         cx->allreduce(red, j + 1);
-        ksd::k_fin_mid_def<<<j + 1, 64, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hcol, coef, ws->colscale, 2, ws->st);
+        ksd::k_fin_mid_def<<<j + 1, 64, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hcol, coef, ws->colscale, 2, ws->st, pd);
       }
     }
     {
@@ -758,12 +881,12 @@ inline void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op, int from, 
     if (j == to) {  // settle the norm of the last column (it stays unnormalised in HBM: colscale)
       {
         ProfScope ps(cx, KSP_FIN, 0.0);
-        if (!dist) {
-          ksd::k_fin_pend<<<1, kBlock, 0, s>>>(ws->partial2, ws->nb, red, Hcol + j, j, ws->colscale, 0, ws->st);
+        if (!dist || p2p) {
+          ksd::k_fin_pend<<<1, kBlock, 0, s>>>(ws->partial2, ws->nb, red, Hcol + j, j, ws->colscale, p2p ? 3 : 0, ws->st, pd);
         } else {
-          ksd::k_fin_pend<<<1, kBlock, 0, s>>>(ws->partial2, ws->nb, red, Hcol + j, j, ws->colscale, 1, ws->st);
+          ksd::k_fin_pend<<<1, kBlock, 0, s>>>(ws->partial2, ws->nb, red, Hcol + j, j, ws->colscale, 1, ws->st, pd);
           cx->allreduce(red, 1);
-          ksd::k_fin_pend<<<1, 64, 0, s>>>(ws->partial2, ws->nb, red, Hcol + j, j, ws->colscale, 2, ws->st);
+          ksd::k_fin_pend<<<1, 64, 0, s>>>(ws->partial2, ws->nb, red, Hcol + j, j, ws->colscale, 2, ws->st, pd);
         }
       }
     }
@@ -785,6 +908,7 @@ inline void fetch_state(ks_workspace* ws) {
   KS_HIP(hipMemcpyAsync(ws->st_h, ws->st, sizeof(DevState), hipMemcpyDeviceToHost, ws->ctx->stream));
   KS_HIP(hipStreamSynchronize(ws->ctx->stream));
   if (ws->ctx->profiling) prof_collect(ws->ctx);
+  ws->ctx->check_comm();
 }
 
 // global 2-norm of column j (synchronous)
@@ -795,6 +919,7 @@ template <class D> double col_norm(ks_workspace* ws, int j) {
   c->allreduce(ws->scal, 1);
   KS_HIP(hipMemcpyAsync(ws->scal_h, ws->scal, 8, hipMemcpyDeviceToHost, c->stream));
   KS_HIP(hipStreamSynchronize(c->stream));
+  c->check_comm();
   return std::sqrt(ws->scal_h[0]);
 }
 
@@ -836,6 +961,7 @@ template <class D> double norm_from_partial2(ks_workspace* ws) {
   c->allreduce(ws->scal, 1);
   KS_HIP(hipMemcpyAsync(ws->scal_h, ws->scal, 8, hipMemcpyDeviceToHost, c->stream));
   KS_HIP(hipStreamSynchronize(c->stream));
+  c->check_comm();
   return std::sqrt(ws->scal_h[0]);
 }
 
@@ -1146,7 +1272,57 @@ int ks_ctx_create_dist(int device, int rank, int nranks, const void* unique_id12
     ncclUniqueId id;
     std::memcpy(&id, unique_id128, 128);
     KS_NCCL(ncclCommInitRank(&c->comm, nranks, id, rank));
+    // KS_TRANSPORT=p2p: keep RCCL for bootstrap only (IPC handles travel through one all-gather) and run
+    // the solver's reductions and halo over the peer-to-peer region
+    const char* tr = std::getenv("KS_TRANSPORT");
+    if (tr && std::string(tr) == "p2p") {
+      p2p_alloc(c.get());
+      hipIpcMemHandle_t mine;
+      KS_HIP(hipIpcGetMemHandle(&mine, c->p2p.region));
+      char* dbuf = nullptr;
+      KS_HIP(hipMalloc(&dbuf, (size_t)64 * nranks));
+      KS_HIP(hipMemcpy(dbuf + (size_t)64 * rank, &mine, 64, hipMemcpyHostToDevice));
+      KS_NCCL(ncclAllGather(dbuf + (size_t)64 * rank, dbuf, 64, ncclChar, c->comm, c->stream));
+      std::vector<char> all((size_t)64 * nranks);
+      KS_HIP(hipMemcpyAsync(all.data(), dbuf, all.size(), hipMemcpyDeviceToHost, c->stream));
+      KS_HIP(hipStreamSynchronize(c->stream));
+      (void)hipFree(dbuf);
+      p2p_attach(c.get(), all.data());
+    }
     *out = c.release();
+  });
+}
+
+int ks_ctx_create_p2p(int device, int rank, int nranks, ks_ctx** out) {
+  return guarded([&] {
+    KS_REQUIRE(out, KS_ERR_ARGUMENT, "null out");
+    KS_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, KS_ERR_ARGUMENT, "bad rank/nranks");
+    auto c = std::make_unique<ks_ctx>();
+    ctx_init_device(c.get(), device);
+    c->rank = rank;
+    c->nranks = nranks;
+    p2p_alloc(c.get());
+    if (nranks == 1) p2p_attach(c.get(), nullptr);
+    *out = c.release();
+  });
+}
+
+int ks_ctx_p2p_handle(ks_ctx* ctx, void* out64) {
+  return guarded([&] {
+    KS_REQUIRE(ctx && out64, KS_ERR_ARGUMENT, "null argument");
+    KS_REQUIRE(ctx->p2p.allocated, KS_ERR_ARGUMENT, "context was not created with ks_ctx_create_p2p");
+    ctx->use();
+    hipIpcMemHandle_t h;
+    KS_HIP(hipIpcGetMemHandle(&h, ctx->p2p.region));
+    std::memcpy(out64, &h, 64);
+  });
+}
+
+int ks_ctx_p2p_attach(ks_ctx* ctx, const void* handles) {
+  return guarded([&] {
+    KS_REQUIRE(ctx && handles, KS_ERR_ARGUMENT, "null argument");
+    ctx->use();
+    p2p_attach(ctx, handles);
   });
 }
 
@@ -1156,6 +1332,7 @@ int ks_ctx_destroy(ks_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
+    p2p_release(ctx);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
   });
@@ -1166,6 +1343,7 @@ int ks_ctx_synchronize(ks_ctx* ctx) {
     KS_REQUIRE(ctx, KS_ERR_ARGUMENT, "null ctx");
     ctx->use();
     KS_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->check_comm();
   });
 }
 
@@ -1226,8 +1404,11 @@ int ks_operator_csr_dist(ks_ctx* ctx, int64_t nrows_local, int64_t nghost, int64
       CsrOp<D>* op = make_csr<D>(ctx, nrows_local, nnz, rp, ci, vv);
       std::unique_ptr<CsrOp<D>> guard(op);
       op->nghost = nghost;
-      KS_HIP(hipMalloc(&op->ghost, std::max<size_t>((size_t)nghost * sizeof(D), 16)));
-      KS_HIP(hipMemset(op->ghost, 0, std::max<size_t>((size_t)nghost * sizeof(D), 16)));
+      op->p2p_halo = ctx->p2p.attached;
+      if (!op->p2p_halo) {
+        KS_HIP(hipMalloc(&op->ghost, std::max<size_t>((size_t)nghost * sizeof(D), 16)));
+        KS_HIP(hipMemset(op->ghost, 0, std::max<size_t>((size_t)nghost * sizeof(D), 16)));
+      }
       op->neigh.assign(neigh, neigh + nneigh);
       op->send_ptr.assign(send_ptr, send_ptr + nneigh + 1);
       op->recv_ptr.assign(nneigh + 1, 0);
@@ -1252,7 +1433,56 @@ int ks_operator_csr_dist(ks_ctx* ctx, int64_t nrows_local, int64_t nghost, int64
       KS_HIP(hipMalloc(&op->sendbuf, std::max<size_t>(packed.size() * sizeof(D), 16)));
       KS_HIP(hipMalloc(&op->send_idx, std::max<size_t>(packed.size() * 4, 16)));
       if (!packed.empty()) KS_HIP(hipMemcpy(op->send_idx, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
-      KS_REQUIRE(nneigh == 0 || ctx->comm != nullptr, KS_ERR_ARGUMENT, "halo plan needs a distributed context");
+      KS_REQUIRE(nneigh == 0 || ctx->distributed(), KS_ERR_ARGUMENT, "halo plan needs a distributed context");
+      if (op->p2p_halo) {
+        // COLLECTIVE in peer-to-peer mode: every rank publishes where its ghost vector lives in its shared
+        // arena and, per sender, at which offset that sender's entries go (and how many it expects)
+        auto& P = ctx->p2p;
+        const int R = ctx->nranks;
+        KS_REQUIRE(nneigh <= ksd::kP2pMaxNeigh, KS_ERR_ARGUMENT, "peer-to-peer halo supports at most 16 neighbours per rank");
+        op->ghost_stride = round_up(std::max<int64_t>(nghost, 1), 32);
+        const size_t bytes = (size_t)round_up(2 * op->ghost_stride * (int64_t)sizeof(D), 256);
+        KS_REQUIRE(P.arena_used + bytes <= P.arena_bytes, KS_ERR_ARGUMENT,
+                   "ghost vectors do not fit the shared arena (raise KS_P2P_ARENA_MB)");
+        op->arena_lo = P.arena_used;
+        op->arena_hi = P.arena_used + bytes;
+        P.arena_used = op->arena_hi;
+        op->ghost = reinterpret_cast<D*>(static_cast<char*>(P.region) + P.arena_off + op->arena_lo);
+        KS_HIP(hipMemset(op->ghost, 0, bytes));
+        KS_HIP(hipDeviceSynchronize());
+        std::vector<int64_t> row((size_t)2 + 2 * R, 0);
+        row[0] = (int64_t)(P.arena_off + op->arena_lo);
+        row[1] = op->ghost_stride;
+        for (int p = 0; p < nneigh; ++p) {
+          KS_REQUIRE(neigh[p] >= 0 && neigh[p] < R, KS_ERR_ARGUMENT, "bad neighbour rank");
+          row[2 + 2 * neigh[p]] = op->recv_ptr[p];
+          row[3 + 2 * neigh[p]] = recv_cnt[p];
+        }
+        const std::vector<int64_t> tab = p2p_allgather_i64(ctx, row);
+        const size_t K = row.size();
+        ksd::HaloArgs a{};
+        a.nneigh = nneigh;
+        a.nrecv = 0;
+        std::vector<int32_t> all;
+        for (int p = 0; p < nneigh; ++p) {
+          const int q = neigh[p];
+          const int64_t sc = send_ptr[p + 1] - send_ptr[p];
+          a.send_ptr[p] = send_ptr[p];
+          a.send_ptr[p + 1] = send_ptr[p + 1];
+          const int64_t* tq = tab.data() + (size_t)q * K;
+          KS_REQUIRE(tq[3 + 2 * ctx->rank] == sc, KS_ERR_ARGUMENT,
+                     "halo plans disagree: rank " + std::to_string(q) + " expects " + std::to_string(tq[3 + 2 * ctx->rank]) +
+                         " entries from rank " + std::to_string(ctx->rank) + ", which sends " + std::to_string(sc));
+          a.dst[p] = static_cast<char*>(P.peer[q]) + tq[0] + tq[2 + 2 * ctx->rank] * (int64_t)sizeof(D);
+          a.dst_stride[p] = tq[1];
+          a.flag_dst[p] = static_cast<uint64_t*>(P.peer[q]) + ksd::p2p_ll_words(R, P.cap) + ctx->rank;
+          if (recv_cnt[p] > 0) a.recv_from[a.nrecv++] = q;
+          all.insert(all.end(), send_idx + send_ptr[p], send_idx + send_ptr[p + 1]);
+        }
+        op->hargs = a;
+        KS_HIP(hipMalloc(&op->send_idx_all, std::max<size_t>(all.size() * 4, 16)));
+        if (!all.empty()) KS_HIP(hipMemcpy(op->send_idx_all, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+      }
       *out = guard.release();
     });
   });

@@ -18,6 +18,8 @@
 
 #include <type_traits>
 
+#include "ks_p2p.hpp"
+
 namespace ksd {
 
 struct cd {
@@ -185,7 +187,7 @@ __global__ void __launch_bounds__(kBlock) k_fill_uniform(T* __restrict__ v, int6
 // 3-D stencil hit in the same L2).
 //
 // Distributed mode: column indices >= n_local address the ghost buffer `xg` (filled by the halo
-// exchange) instead of the local column.
+// exchange: RCCL send/recv, or remote stores of the neighbours in peer-to-peer mode) instead of the local column.
 // ------------------------------------------------------------------------------------------------
 constexpr int kSpmvRows = 256;
 constexpr int kSpmvCapMax = 4096;  // upper bound of products held in LDS per tile (32 KiB of f64)
@@ -205,8 +207,11 @@ template <class T, bool NT>
 __global__ void __launch_bounds__(kBlock)
     k_spmv_csr(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const T* __restrict__ val,
                const T* __restrict__ x, const T* __restrict__ xg, T* __restrict__ y, int64_t n, int ntiles, int cap,
-               const DevState* __restrict__ st) {
+               const DevState* __restrict__ st, const uint32_t* __restrict__ hseq, int64_t gstride) {
   if (st && st->breakdown >= 0) return;
+  // peer-to-peer halo (ks_p2p.hpp): the ghost vector is double-buffered, the parity of the halo sequence
+  // number the push kernel just published selects the slot
+  if (hseq) xg += (int64_t)(*hseq & 1u) * gstride;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* prod = reinterpret_cast<T*>(smem_raw);
   const int tile = xcd_remap(blockIdx.x, ntiles);
@@ -765,14 +770,24 @@ __global__ void __launch_bounds__(kBlock)
 __global__ void __launch_bounds__(kBlock)
     k_fin_dots_def(const double* __restrict__ partial, int nb, int pnb, const double* __restrict__ partial2, int nb2,
                    int j, double* __restrict__ red, double* __restrict__ Hcol, double* __restrict__ Hsub_prev,
-                   double* __restrict__ coef, double* __restrict__ colscale, int mode, DevState* __restrict__ st) {
+                   double* __restrict__ coef, double* __restrict__ colscale, int mode, DevState* __restrict__ st,
+                   P2pDev p2p) {
   if (st->breakdown >= 0) return;
   __shared__ double sm[kBlock];
   const int c = blockIdx.x;  // 0..j (mode 1: ..j+1)
   const bool pend = st->pend != 0;
   const bool pre = st->pend_reorth != 0;
   double s = 0.0, b2 = 1.0;
-  if (mode != 2) {
+  if (mode == 3) {
+    // peer-to-peer: reduce, exchange and post-process in ONE kernel -- workgroup c sums its column over the
+    // ranks itself (elements 2c, 2c+1 of the LL window: its column and the pending norm every workgroup needs)
+    const double x[2] = {block_sum(partial + (int64_t)c * pnb, nb, sm), (pend && pre) ? block_sum(partial2, nb2, sm) : 0.0};
+    if (threadIdx.x >= 64) return;
+    double g[2];
+    p2p_sum_wave<2>(p2p, 2 * c, x, g);
+    s = g[0];
+    if (pend) b2 = pre ? g[1] : st->wnorm * st->wnorm;
+  } else if (mode != 2) {
     if (c <= j) s = block_sum(partial + (int64_t)c * pnb, nb, sm);
     if (mode == 1) {
       if (c == j + 1) s = (pend && pre) ? block_sum(partial2, nb2, sm) : 0.0;
@@ -820,12 +835,20 @@ __global__ void __launch_bounds__(kBlock)
 __global__ void __launch_bounds__(kBlock)
     k_fin_mid_def(const double* __restrict__ partial, const double* __restrict__ partial2, int nb, int pnb, int j,
                   double* __restrict__ red, double* __restrict__ Hcol, double* __restrict__ coef,
-                  const double* __restrict__ colscale, int mode, DevState* __restrict__ st) {
+                  const double* __restrict__ colscale, int mode, DevState* __restrict__ st, P2pDev p2p) {
   if (st->breakdown >= 0) return;
   __shared__ double sm[kBlock];
   const int c = blockIdx.x;  // 0..j
   double s = 0.0, nrm2 = 0.0;
-  if (mode != 2) {
+  if (mode == 3) {  // peer-to-peer: see k_fin_dots_def
+    const double own = block_sum(c < j ? partial + (int64_t)c * pnb : partial2, nb, sm);
+    const double x[2] = {own, (c == j) ? own : block_sum(partial2, nb, sm)};
+    if (threadIdx.x >= 64) return;
+    double g[2];
+    p2p_sum_wave<2>(p2p, 2 * c, x, g);
+    s = g[0];
+    nrm2 = g[1];
+  } else if (mode != 2) {
     s = block_sum(c < j ? partial + (int64_t)c * pnb : partial2, nb, sm);
     if (mode == 1) {
       if (threadIdx.x == 0) red[c] = s;
@@ -866,13 +889,19 @@ __global__ void __launch_bounds__(kBlock)
 // H[j+1,j] and 1/beta for the k_scale that follows.
 __global__ void __launch_bounds__(kBlock)
     k_fin_pend(const double* __restrict__ partial2, int nb2, double* __restrict__ red, double* __restrict__ Hsub, int j,
-               double* __restrict__ colscale, int mode, DevState* __restrict__ st) {
+               double* __restrict__ colscale, int mode, DevState* __restrict__ st, P2pDev p2p) {
   if (st->breakdown >= 0) return;
   if (!st->pend) return;
   __shared__ double sm[kBlock];
   const bool pre = st->pend_reorth != 0;
   double b2 = 0.0;
-  if (mode != 2) {
+  if (mode == 3) {  // peer-to-peer: see k_fin_dots_def
+    const double x[1] = {pre ? block_sum(partial2, nb2, sm) : 0.0};
+    if (threadIdx.x >= 64) return;
+    double g[1];
+    p2p_sum_wave<1>(p2p, 0, x, g);
+    b2 = g[0];
+  } else if (mode != 2) {
     b2 = pre ? block_sum(partial2, nb2, sm) : 0.0;
     if (mode == 1) {
       if (threadIdx.x == 0) red[0] = b2;

@@ -118,15 +118,31 @@ def dist_operator(api, ctx, indptr, data, plan: HaloPlan, n_global: int):
     return api.Operator(ctx, h, (n_global, n_global), dt)
 
 
-def make_context(api, dist, local_rank: int):
-    """One library context per rank; rank 0's RCCL unique id is broadcast through the process group."""
+def make_context(api, dist, local_rank: int, transport: str | None = None):
+    """One library context per rank.
+
+    transport "rccl" (default): rank 0's RCCL unique id is broadcast through the process group.
+    transport "p2p": no RCCL at all -- every rank allocates its shared region, the 64-byte IPC handles are
+    all-gathered through the process group (any backend) and mapped (csrc/ks_p2p.hpp).  KS_TRANSPORT
+    selects the default."""
+    import os
+
     rank, world = dist.get_rank(), dist.get_world_size()
+    transport = transport or os.environ.get("KS_TRANSPORT", "rccl")
+    if transport == "p2p":
+        ctx = api.Context(local_rank, rank, world, p2p=True)
+        if world > 1:
+            handles = [None] * world
+            dist.all_gather_object(handles, ctx.p2p_handle())
+            ctx.p2p_attach(handles)
+            dist.barrier()
+        return ctx
     box = [api.Context.unique_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
     return api.Context(local_rank, rank, world, box[0])
 
 
-def setup_laplace3d(pkg, dist, m: int, maxdim: int, local_rank: int):
+def setup_laplace3d(pkg, dist, m: int, maxdim: int, local_rank: int, transport: str | None = None):
     """bench.py N > 1: slab partition of the m^3 Laplacian along z, one slab of whole planes per rank."""
     from . import api
 
@@ -136,7 +152,7 @@ def setup_laplace3d(pkg, dist, m: int, maxdim: int, local_rank: int):
     r0, r1 = int(offs[rank]), int(offs[rank + 1])
     ip, ix, dv = pkg.matrices.laplace3d_csr(m, m, m, r0, r1, index_dtype=np.int64)
     plan = build_halo_plan(ix, offs, rank, dist)
-    ctx = make_context(api, dist, local_rank)
+    ctx = make_context(api, dist, local_rank, transport)
     op = dist_operator(api, ctx, ip, dv, plan, n)
     ws = api.ArnoldiWorkspace(r1 - r0, maxdim, np.float64, ctx=ctx, n_global=n, row_begin=r0)
     v1 = pkg.matrices.start_vector(r1 - r0, row_begin=r0)

@@ -45,7 +45,8 @@ enum {
   KS_ERR_QR = 5,        /* "QR algorithm did not converge" (src/schurfact.jl:406)           */
   KS_ERR_INTERNAL = 6,
   KS_ERR_NO_DEVICE = 7, /* no gfx950 device visible: the product path has NO CPU fallback   */
-  KS_ERR_OPERATOR = 8   /* user operator callback reported failure                          */
+  KS_ERR_OPERATOR = 8,  /* user operator callback reported failure                          */
+  KS_ERR_COMM = 9       /* a peer did not show up within KS_P2P_TIMEOUT_S (peer-to-peer mode) */
 };
 
 enum { KS_F64 = 0, KS_C64 = 1 };                 /* element type of A, V, H, Q              */
@@ -70,6 +71,17 @@ int ks_ctx_create(int device, ks_ctx** out);
  * single process. */
 int ks_comm_unique_id(void* out128);
 int ks_ctx_create_dist(int device, int rank, int nranks, const void* unique_id128, ks_ctx** out);
+/* Multi-GPU context on the peer-to-peer transport (csrc/ks_p2p.hpp): the per-step reductions and the
+ * ghost exchange of the SpMV run as remote stores into IPC-shared, uncached regions over xGMI instead of
+ * RCCL calls (same results; sums are formed in rank order on every rank).  Protocol: every rank calls
+ * ks_ctx_create_p2p, exports its 64-byte region handle with ks_ctx_p2p_handle, the host language
+ * all-gathers the handles, and every rank passes the nranks x 64 bytes (rank order) to ks_ctx_p2p_attach.
+ * Needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this image.  ks_ctx_create_dist with KS_TRANSPORT=p2p does the
+ * same through one RCCL all-gather.  In this mode ks_operator_csr_dist is a collective call.
+ * KS_P2P_CAP (2048 doubles per reduction), KS_P2P_ARENA_MB (64), KS_P2P_TIMEOUT_S (30) tune the region. */
+int ks_ctx_create_p2p(int device, int rank, int nranks, ks_ctx** out);
+int ks_ctx_p2p_handle(ks_ctx* ctx, void* out64);
+int ks_ctx_p2p_attach(ks_ctx* ctx, const void* handles);
 int ks_ctx_destroy(ks_ctx* ctx);
 int ks_ctx_synchronize(ks_ctx* ctx);
 int ks_ctx_rank(const ks_ctx* ctx, int* rank, int* nranks);

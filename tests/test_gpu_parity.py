@@ -7,6 +7,9 @@ the arithmetic is Float64 / ComplexF64 and differs from the oracle only by summa
   * end to end: the reference's own tests (test/expansion.jl, test/partial_schur.jl,
     test/schur_to_eigen.jl, readme example) replayed on the HIP path
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -18,6 +21,7 @@ from oracle.matrices import hashed_nonsymmetric, laplace1d, laplace3d, laplace3d
 
 pytestmark = pytest.mark.gpu
 pkg = import_package()
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 EPS = np.finfo(np.float64).eps
 DTYPES = [np.float64, np.complex128]
 
@@ -481,14 +485,16 @@ def test_full_size_properties_1e6():
 
 
 # ------------------------------------------------------------------ RCCL code path on one GPU
+@pytest.mark.parametrize("transport", ["rccl", "p2p"])
 @pytest.mark.parametrize("pattern", ["contiguous", "scattered"])
-def test_rccl_path_single_rank_communicator(pattern):
-    """A 1-rank RCCL communicator drives the distributed code path of the library on a single GPU:
-    reduce-only / all-reduce / post kernels of the DGKS step, and the halo plan executed with
-    ncclSend/ncclRecv (here: a self exchange that copies own rows into ghost slots)."""
+def test_collective_path_single_rank(pattern, transport):
+    """A 1-rank communicator drives the distributed code path of the library on a single GPU:
+    reduce-only / all-reduce / post kernels of the DGKS step, and the halo plan -- executed with
+    ncclSend/ncclRecv ("rccl") or with remote stores into the shared ghost arena ("p2p", csrc/ks_p2p.hpp);
+    here: a self exchange that copies own rows into ghost slots."""
     from arnoldimethod_jl_amd import api, dist as ksd
 
-    ctx = pkg.Context(0, 0, 1, pkg.Context.unique_id())
+    ctx = pkg.Context(0, 0, 1, pkg.Context.unique_id()) if transport == "rccl" else pkg.Context(0, 0, 1, p2p=True)
     mx, my, mz = 6, 7, 8
     A = laplace3d(mx, my, mz)
     n = A.shape[0]
@@ -639,3 +645,37 @@ def test_device_callback_operator_dense_matrix():
     np.testing.assert_allclose(np.sort(F.eigenvalues.real), np.sort(ref.eigenvalues.real), atol=1e-9)
     Q, R = F.Q, np.array(F.R)
     assert np.linalg.norm(A @ Q - Q @ R) < 1e-8 and np.linalg.norm(Q.T @ Q - np.eye(Q.shape[1])) < 1e-12
+
+
+# ------------------------------------------------------------------ several RANKS on one GPU (peer-to-peer transport)
+def _run_ranks(nproc, mode, m=16, extra_env=None, timeout=420):
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, KS_SAME_DEVICE="1", KS_TRANSPORT="p2p", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tools", "dist_gpu_check.py"), mode, str(m)]
+    return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("nproc,mode", [(2, "laplace"), (3, "laplace"), (2, "hashed"), (4, "hashed")])
+def test_row_partitioned_solver_several_ranks_one_gpu(nproc, mode):
+    """The multi-rank product path with REAL peers: `nproc` processes share device 0 and exchange through
+    IPC-mapped regions (csrc/ks_p2p.hpp).  Every rank must converge with a small device-side residual and
+    rank 0's single-GPU repeat of the same problem must need the same number of matrix-vector products
+    and find the same Ritz values (tools/dist_gpu_check.py).  laplace: plane ghosts, contiguous send
+    runs; hashed: every rank neighbours every other, scattered send lists."""
+    r = _run_ranks(nproc, mode)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("[rank")]
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert sum("-> OK" in ln for ln in lines) == nproc and any("same: True" in ln for ln in lines), "\n".join(lines)
+
+
+def test_lost_peer_is_reported_not_hung():
+    """A rank that never joins an exchange makes the others fail with KS_ERR_COMM after
+    KS_P2P_TIMEOUT_S seconds (bounded spins in the kernels) instead of hanging the GPU."""
+    r = _run_ranks(2, "timeout", extra_env={"KS_P2P_TIMEOUT_S": "2"}, timeout=180)
+    assert r.returncode == 0 and "expected CommTimeout" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

@@ -1,12 +1,26 @@
 #!/usr/bin/env python3
-"""Multi-process check of the distributed GPU path.  On a multi-GPU node: one rank per GPU.  On a
-single-GPU box it can only run if RCCL accepts several ranks on one device (KS_SAME_DEVICE=1).
-Each rank solves its slab of a 3-D Laplacian; rank 0 compares eigenvalues with the analytic spectrum
-and checks the device-side residual."""
+"""Multi-process check of the distributed GPU path (also driven by tests/test_gpu_parity.py).
+
+On a multi-GPU node: one rank per GPU.  On a single-GPU box: KS_SAME_DEVICE=1 KS_TRANSPORT=p2p puts all
+ranks on device 0 (RCCL refuses several ranks per device, the peer-to-peer transport does not care).
+
+    KS_SAME_DEVICE=1 KS_TRANSPORT=p2p python -m torch.distributed.run --nproc-per-node 2 \\
+        --master-addr 127.0.0.1 --master-port 29517 tools/dist_gpu_check.py MODE [m]
+
+MODE
+  laplace  every rank solves its slab of an m x (m+1) x (m+2w) Laplacian (ghosts = whole grid planes, sent
+           as contiguous runs); eigenvalues vs the analytic spectrum, device-side residual, and rank 0
+           repeats the solve on a single-GPU context: same mvproducts, same Ritz values.
+  hashed   nonsymmetric matrix with hashed columns (every rank is everybody's neighbour, scattered
+           send lists); distributed vs single-GPU run: same mvproducts, same Ritz values, ||AQ - QR||.
+  timeout  rank 1 never joins; rank 0 must get CommTimeout (KS_ERR_COMM) after KS_P2P_TIMEOUT_S
+           seconds instead of hanging.
+"""
 import os
 import sys
 
 import numpy as np
+import scipy.sparse as sp
 import torch
 import torch.distributed as dist
 
@@ -15,33 +29,74 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import import_package  # noqa: E402
 
 ks = import_package()
-from arnoldimethod_jl_amd import dist as ksd  # noqa: E402
+from arnoldimethod_jl_amd import _lib, api, dist as ksd  # noqa: E402
 
 
 def main():
     rank = int(os.environ["RANK"])
     local_rank = 0 if os.environ.get("KS_SAME_DEVICE") == "1" else int(os.environ["LOCAL_RANK"])
     torch.cuda.set_device(local_rank)
-    dist.init_process_group("gloo")  # rendezvous only; the solver's collectives are RCCL inside the library
-    m = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-    mx, my, mz = m, m + 1, m + 2 * dist.get_world_size()
-    n = mx * my * mz
-    offs = ksd.partition_rows(n, dist.get_world_size(), granule=mx * my)
-    r0, r1 = int(offs[rank]), int(offs[rank + 1])
-    ip, ix, dv = ks.matrices.laplace3d_csr(mx, my, mz, r0, r1, index_dtype=np.int64)
-    plan = ksd.build_halo_plan(ix, offs, rank, dist)
-    from arnoldimethod_jl_amd import api
-
+    dist.init_process_group("gloo")  # rendezvous only; the solver's exchanges happen inside the library
+    world = dist.get_world_size()
+    mode = sys.argv[1] if len(sys.argv) > 1 else "laplace"
+    m = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     ctx = ksd.make_context(api, dist, local_rank)
+
+    if mode == "timeout":
+        ok = True
+        if rank == 0:
+            try:
+                wsx = api.ArnoldiWorkspace(64, 4, np.float64, ctx=ctx, n_global=64 * world, row_begin=0)
+                wsx.set_col(0, np.ones(64))
+                wsx.norm(0)  # an all-reduce nobody else joins
+                ok = False
+            except _lib.CommTimeout as e:
+                print(f"[rank 0] got the expected CommTimeout: {e}", flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(0 if ok else 1)
+
+    if mode == "laplace":
+        mx, my, mz = m, m + 1, m + 2 * world
+        n = mx * my * mz
+        offs = ksd.partition_rows(n, world, granule=mx * my)
+        r0, r1 = int(offs[rank]), int(offs[rank + 1])
+        ip, ix, dv = ks.matrices.laplace3d_csr(mx, my, mz, r0, r1, index_dtype=np.int64)
+        kw = dict(nev=6, which="SR", tol=1e-10, mindim=12, maxdim=30, restarts=300)
+        full = lambda: sp.csr_matrix(ks.matrices.laplace3d_csr(mx, my, mz, 0, n, index_dtype=np.int64)[::-1], shape=(n, n))  # noqa: E731
+    else:
+        n = m * m * m
+        A = (ks.matrices.hashed_nonsymmetric_csr(n, seed=11) + sp.diags(np.linspace(1.0, 40.0, n))).tocsr()
+        A.sort_indices()
+        offs = ksd.partition_rows(n, world)
+        r0, r1 = int(offs[rank]), int(offs[rank + 1])
+        B = A[r0:r1]
+        ip, ix, dv = B.indptr.astype(np.int64), B.indices.astype(np.int64), B.data
+        kw = dict(nev=5, which="LR", tol=1e-10, mindim=10, maxdim=25, restarts=300)
+        full = lambda: A  # noqa: E731
+
+    plan = ksd.build_halo_plan(ix, offs, rank, dist)
     op = ksd.dist_operator(api, ctx, ip, dv, plan, n)
-    ws = api.ArnoldiWorkspace(r1 - r0, 30, np.float64, ctx=ctx, n_global=n, row_begin=r0)
+    ws = api.ArnoldiWorkspace(r1 - r0, kw["maxdim"], np.float64, ctx=ctx, n_global=n, row_begin=r0)
     ws._v1 = ks.matrices.start_vector(r1 - r0, row_begin=r0)
-    F, hist = ks.partialschur_(op, ws, nev=6, which="SR", tol=1e-10, mindim=12, maxdim=30, restarts=300)
+    F, hist = ks.partialschur_(op, ws, **kw)
     res, orth = ws.residual_norms(op, F.nconverged)
-    exact = ks.matrices.laplace3d_eigs(mx, my, mz, 6)
-    err = np.abs(np.sort(F.eigenvalues.real)[:6] - exact).max() if F.nconverged >= 6 else float("nan")
-    ok = hist.converged and res < 1e-8 and orth < 1e-12 and err < 1e-8
-    print(f"[rank {rank}] {hist} resid={res:.2e} orth={orth:.2e} eig_err={err:.2e} rows {r0}:{r1} -> {'OK' if ok else 'FAIL'}", flush=True)
+    ok = bool(hist.converged and res < 1e-8 and orth < 1e-12)
+    msg = f"{hist} resid={res:.2e} orth={orth:.2e} neighbours={len(plan.neigh)} rows {r0}:{r1}"
+    if mode == "laplace":
+        exact = ks.matrices.laplace3d_eigs(mx, my, mz, 6)
+        err = np.abs(np.sort(F.eigenvalues.real)[:6] - exact).max() if F.nconverged >= 6 else float("nan")
+        ok = ok and err < 1e-8
+        msg += f" eig_err={err:.2e}"
+    if rank == 0:  # same problem on one GPU: the row partition must not change what the solver does
+        ws1 = ks.ArnoldiWorkspace(n, kw["maxdim"], np.float64)
+        ws1._v1 = ks.matrices.start_vector(n)
+        F1, h1 = ks.partialschur_(full(), ws1, **kw)
+        dv_ = np.abs(np.sort_complex(F1.eigenvalues) - np.sort_complex(F.eigenvalues)).max()
+        same = h1.mvproducts == hist.mvproducts and dv_ < 1e-9
+        print(f"[rank 0] single-GPU run: {h1}; max Ritz value difference {dv_:.2e}; same: {same}", flush=True)
+        ok = ok and same
+    print(f"[rank {rank}] {msg} -> {'OK' if ok else 'FAIL'}", flush=True)
     dist.barrier()
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)

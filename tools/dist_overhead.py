@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Single-GPU probe of the distributed code path's fixed costs: the same slab problem solved (a) on a plain
 context and (b) on a 1-rank RCCL context whose halo plan exchanges two planes with itself (so the pack kernel,
-the ncclSend/ncclRecv group, the reduce-only / all-reduce / post kernel variants all run).  Prints ms per Arnoldi
-iteration for both; the difference is what the multi-GPU structure costs before any real link latency."""
+the ncclSend/ncclRecv group, the reduce-only / all-reduce / post kernel variants all run) and (c) on a 1-rank
+peer-to-peer context (csrc/ks_p2p.hpp).  Prints ms per Arnoldi iteration; the differences are what the
+multi-GPU structure costs before any real link latency."""
 import os
 import sys
 import time
@@ -39,22 +40,31 @@ def run(ctx, op, n, label, cycles=10):
 
 def main():
     m = int(sys.argv[1]) if len(sys.argv) > 1 else 108
+    legs = sys.argv[2].split(",") if len(sys.argv) > 2 else ["plain", "rccl", "p2p"]
     mx = my = m
     mz = m
     n = mx * my * mz
     ip, ix, dv = ks.matrices.laplace3d_csr(mx, my, mz, index_dtype=np.int64)
-    ctx0 = ks.Context(0)
-    op0 = ks.csr_operator(ks.matrices.to_scipy(ip, ix.astype(np.int32), dv, n), ctx0)
-    run(ctx0, op0, n, f"plain context      n={n}")
-    # 1-rank communicator + a plan that sends the first and last plane to itself (values unused: the ghost
-    # columns are referenced by nobody, so the operator is unchanged but every exchange step executes)
-    ctx1 = ks.Context(0, 0, 1, ks.Context.unique_id())
+    # a plan that sends the first and last plane to this very rank (values unused: the ghost columns are
+    # referenced by nobody, so the operator is unchanged but every exchange step executes)
     plane = mx * my
     send_idx = np.concatenate([np.arange(plane), np.arange(n - plane, n)]).astype(np.int32)
     plan = ksd.HaloPlan(n_local=n, nghost=2 * plane, neigh=np.array([0], dtype=np.int32), send_ptr=np.array([0, 2 * plane], dtype=np.int64),
                         send_idx=send_idx, recv_cnt=np.array([2 * plane], dtype=np.int64), ghost_global=np.zeros(0), colidx_local=ix.astype(np.int32))
-    op1 = ksd.dist_operator(api, ctx1, ip, dv, plan, n)
-    run(ctx1, op1, n, f"1-rank RCCL context n={n}")
+    # (memory placement differs between allocations of one process by a few per cent: compare legs run in
+    # SEPARATE processes -- `dist_overhead.py 108 plain`, `... rccl`, `... p2p`)
+    for leg in legs:
+        if leg == "plain":
+            ctx = ks.Context(0)
+            op = ks.csr_operator(ks.matrices.to_scipy(ip, ix.astype(np.int32), dv, n), ctx)
+        elif leg == "rccl":   # pack kernel / ncclSend+ncclRecv group, reduce-only -> all-reduce -> post kernels
+            ctx = ks.Context(0, 0, 1, ks.Context.unique_id())
+            op = ksd.dist_operator(api, ctx, ip, dv, plan, n)
+        else:                 # one push kernel, exchange folded into the reduction kernels
+            ctx = ks.Context(0, 0, 1, p2p=True)
+            op = ksd.dist_operator(api, ctx, ip, dv, plan, n)
+        run(ctx, op, n, f"{leg:5s} context n={n}")
+        del op, ctx
 
 
 if __name__ == "__main__":
