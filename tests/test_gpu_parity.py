@@ -669,9 +669,9 @@ def test_row_partitioned_solver_several_ranks_one_gpu(nproc, mode):
     and find the same Ritz values (tools/dist_gpu_check.py).  laplace: plane ghosts, contiguous send
     runs; hashed: every rank neighbours every other, scattered send lists."""
     r = _run_ranks(nproc, mode)
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("[rank")]
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert sum("-> OK" in ln for ln in lines) == nproc and any("same: True" in ln for ln in lines), "\n".join(lines)
+    # (ranks print concurrently, lines may interleave: count occurrences)
+    assert r.stdout.count("-> OK") == nproc and "same: True" in r.stdout, r.stdout[-3000:]
 
 
 def test_lost_peer_is_reported_not_hung():
