@@ -82,6 +82,7 @@ PROTOTYPES = {
     "ks_operator_device_callback": [vp, i64, i32, DEVICE_APPLY_FN, vp, P(vp)],
     "ks_operator_destroy": [vp],
     "ks_operator_size": [vp, P(i64), P(i64), P(C.c_int)],
+    "ks_operator_format": [vp, P(C.c_double), P(C.c_int)],
     "ks_operator_apply_raw": [vp, vp, vp],
     "ks_workspace_create": [vp, i64, i64, i64, i32, i32, P(vp)],
     "ks_workspace_destroy": [vp],

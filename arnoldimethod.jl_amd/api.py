@@ -167,6 +167,13 @@ class Operator:
     def __init__(self, ctx, handle, shape, dtype, keep=()):
         self.ctx, self._h, self.shape, self.dtype, self._keep = ctx, handle, shape, np.dtype(dtype), keep
 
+    @property
+    def format(self) -> dict:
+        """Device layout of a stored matrix: bytes streamed per non-zero and dictionary size (0 = plain CSR)."""
+        b, d = C.c_double(), C.c_int()
+        check(_lib.load().ks_operator_format(self._h, C.byref(b), C.byref(d)))
+        return dict(bytes_per_nnz=b.value, ndict=d.value)
+
     def close(self):
         # never touch a handle whose context is already gone (interpreter shutdown order is arbitrary)
         if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):

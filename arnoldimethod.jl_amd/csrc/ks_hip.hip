@@ -12,6 +12,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/kschur.h"
@@ -287,6 +288,7 @@ struct ks_operator {
   int64_t n_local = 0, nnz = 0;
   int dtype = KS_F64;
   bool async_capable = true;  // may be enqueued ahead without host involvement
+  double bytes_per_nnz = 0.0;  // what the SpMV streams per stored non-zero (0: not a stored-matrix operator)
   virtual ~ks_operator() = default;
   // y = A x on device pointers, enqueued on ctx->stream; `st` lets the kernels of a batch skip work
   // after a breakdown.
@@ -301,6 +303,7 @@ template <class D> struct CsrOp : ks_operator {
   D* val = nullptr;
   int ntiles = 0;
   int lds_cap = 256;  // products per tile held in LDS (largest tile of this matrix, capped)
+  int ndict = 0;      // > 0: value-indexed layout (k_spmv_csr<.., VI>): colidx = (dict index << 24) | column, val = dictionary
   // halo plan (distributed)
   int64_t nghost = 0;
   D* ghost = nullptr;
@@ -359,14 +362,36 @@ template <class D> struct CsrOp : ks_operator {
       KS_NCCL(ncclGroupEnd());
     }
     if (ntiles > 0) {
-      // algorithmic bytes: 12 nnz + 4 (n+1) + 16 n   (8 -> 16 for complex)
-      ProfScope ps(ctx, KSP_SPMV, (double)nnz * (4 + sizeof(D)) + 4.0 * (n_local + 1) + 2.0 * sizeof(D) * n_local);
+      // algorithmic bytes: 12 nnz + 4 (n+1) + 16 n   (8 -> 16 for complex); 4 nnz in the
+      // value-indexed layout
+      ProfScope ps(ctx, KSP_SPMV, (double)nnz * bytes_per_nnz + 4.0 * (n_local + 1) + 2.0 * sizeof(D) * n_local);
       // (a variant reading the non-zeros as aligned pairs with non-temporal loads measured 15 % slower)
       static const int nt = env_int("KS_SPMV_NT", 0);
       const size_t smem = (size_t)lds_cap * sizeof(D);
       const uint32_t* hseq = (p2p_halo && !neigh.empty()) ? ctx->p2p.hstate : nullptr;
-      if (nt) ksd::k_spmv_csr<D, true><<<ntiles, kBlock, smem, s>>>(rowptr, colidx, val, x, ghost, y, n_local, ntiles, lds_cap, st, hseq, ghost_stride);
-      else ksd::k_spmv_csr<D, false><<<ntiles, kBlock, smem, s>>>(rowptr, colidx, val, x, ghost, y, n_local, ntiles, lds_cap, st, hseq, ghost_stride);
+      // full-unroll depth: smallest instantiated NI with NI * 256 >= lds_cap (0 = rolled loop; KS_SPMV_NI overrides)
+      static const int ni_env = env_int("KS_SPMV_NI", -1);
+      const int need = (lds_cap + kBlock - 1) / kBlock;
+      int ni = need <= 4 ? 4 : need <= 7 ? 7 : need <= 8 ? 8 : need <= 12 ? 12 : need <= 16 ? 16 : 0;
+      if (ni_env >= 0) ni = (ni_env >= need) ? ni_env : 0;
+      auto launch = [&](auto vi_tag, auto ni_tag) {
+        constexpr bool VI = decltype(vi_tag)::value;
+        constexpr int NI = decltype(ni_tag)::value;
+        if (nt && !VI) ksd::k_spmv_csr<D, true, false, NI><<<ntiles, kBlock, smem, s>>>(rowptr, colidx, val, x, ghost, y, n_local, ntiles, lds_cap, st, hseq, ghost_stride, ndict);
+        else ksd::k_spmv_csr<D, false, VI, NI><<<ntiles, kBlock, smem, s>>>(rowptr, colidx, val, x, ghost, y, n_local, ntiles, lds_cap, st, hseq, ghost_stride, ndict);
+      };
+      auto by_ni = [&](auto vi_tag) {
+        switch (ni) {
+          case 4: launch(vi_tag, std::integral_constant<int, 4>{}); break;
+          case 7: launch(vi_tag, std::integral_constant<int, 7>{}); break;
+          case 8: launch(vi_tag, std::integral_constant<int, 8>{}); break;
+          case 12: launch(vi_tag, std::integral_constant<int, 12>{}); break;
+          case 16: launch(vi_tag, std::integral_constant<int, 16>{}); break;
+          default: launch(vi_tag, std::integral_constant<int, 0>{}); break;
+        }
+      };
+      if (ndict > 0) by_ni(std::true_type{});
+      else by_ni(std::false_type{});
     }
     KS_HIP(hipGetLastError());
   }
@@ -460,13 +485,66 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
     int cap = (int)std::min<int64_t>(capmax, std::max<int64_t>(256, round_up(mx, 256)));
     op->lds_cap = env_int("KS_SPMV_CAP", cap);
   }
+  // Value-indexed layout (k_spmv_csr<.., VI>): at most 256 distinct stored values (compared bit for bit, so
+  // -0.0 and NaN payloads survive) and every column index below 2^24.  KS_SPMV_FORMAT=csr keeps plain CSR.
+  std::vector<D> dict;
+  std::vector<int32_t> packed;
+  {
+    const char* fmt = std::getenv("KS_SPMV_FORMAT");
+    bool try_vi = nnz > 0 && !(fmt && std::string(fmt) == "csr");
+    if (try_vi) {
+      struct Key {
+        uint64_t a, b;
+        bool operator==(const Key& o) const { return a == o.a && b == o.b; }
+      };
+      struct KeyHash {
+        size_t operator()(const Key& k) const { return std::hash<uint64_t>()(k.a * 0x9E3779B97F4A7C15ull ^ k.b); }
+      };
+      std::unordered_map<Key, int, KeyHash> index;
+      Key last_key{0, 0};
+      int last_id = 0;
+      packed.resize((size_t)nnz);
+      for (int64_t p = 0; p < nnz && try_vi; ++p) {
+        Key k{0, 0};
+        std::memcpy(&k, &vv[p], sizeof(D));
+        int id;
+        if (p > 0 && k == last_key) {  // runs of equal values are the common case
+          if (ci[p] >= (1 << 24)) { try_vi = false; break; }
+          packed[p] = (int32_t)(((uint32_t)last_id << 24) | (uint32_t)ci[p]);
+          continue;
+        }
+        auto it = index.find(k);
+        if (it == index.end()) {
+          if (dict.size() == 256) { try_vi = false; break; }
+          id = (int)dict.size();
+          index.emplace(k, id);
+          dict.push_back(vv[p]);
+        } else {
+          id = it->second;
+        }
+        if (ci[p] >= (1 << 24)) { try_vi = false; break; }
+        packed[p] = (int32_t)(((uint32_t)id << 24) | (uint32_t)ci[p]);
+        last_key = k;
+        last_id = id;
+      }
+    }
+    if (!try_vi) { dict.clear(); packed.clear(); }
+  }
+  op->ndict = (int)dict.size();
+  op->bytes_per_nnz = op->ndict > 0 ? 4.0 : 4.0 + sizeof(D);
   KS_HIP(hipMalloc(&op->rowptr, (size_t)(nrows + 1) * 4));
   KS_HIP(hipMalloc(&op->colidx, (size_t)(nnz + 2) * 4 + 16));
-  KS_HIP(hipMalloc(&op->val, (size_t)(nnz + 2) * sizeof(D) + 16));
   KS_HIP(hipMemcpy(op->rowptr, rp.data(), (size_t)(nrows + 1) * 4, hipMemcpyHostToDevice));
-  if (nnz) {
-    KS_HIP(hipMemcpy(op->colidx, ci.data(), (size_t)nnz * 4, hipMemcpyHostToDevice));
-    KS_HIP(hipMemcpy(op->val, vv.data(), (size_t)nnz * sizeof(D), hipMemcpyHostToDevice));
+  if (op->ndict > 0) {
+    KS_HIP(hipMalloc(&op->val, 256 * sizeof(D)));
+    KS_HIP(hipMemcpy(op->colidx, packed.data(), (size_t)nnz * 4, hipMemcpyHostToDevice));
+    KS_HIP(hipMemcpy(op->val, dict.data(), dict.size() * sizeof(D), hipMemcpyHostToDevice));
+  } else {
+    KS_HIP(hipMalloc(&op->val, (size_t)(nnz + 2) * sizeof(D) + 16));
+    if (nnz) {
+      KS_HIP(hipMemcpy(op->colidx, ci.data(), (size_t)nnz * 4, hipMemcpyHostToDevice));
+      KS_HIP(hipMemcpy(op->val, vv.data(), (size_t)nnz * sizeof(D), hipMemcpyHostToDevice));
+    }
   }
   return op.release();
 }
@@ -1530,6 +1608,18 @@ int ks_operator_size(const ks_operator* op, int64_t* n_local, int64_t* nnz, int*
     if (n_local) *n_local = op->n_local;
     if (nnz) *nnz = op->nnz;
     if (dtype) *dtype = op->dtype;
+  });
+}
+
+int ks_operator_format(const ks_operator* op, double* bytes_per_nnz, int* ndict) {
+  return guarded([&] {
+    KS_REQUIRE(op, KS_ERR_ARGUMENT, "null operator");
+    if (bytes_per_nnz) *bytes_per_nnz = op->bytes_per_nnz;
+    if (ndict) {
+      *ndict = 0;
+      if (op->dtype == KS_F64) { if (auto* c = dynamic_cast<const CsrOp<double>*>(op)) *ndict = c->ndict; }
+      else if (auto* c = dynamic_cast<const CsrOp<cd>*>(op)) *ndict = c->ndict;
+    }
   });
 }
 

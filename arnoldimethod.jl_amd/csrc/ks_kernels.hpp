@@ -203,50 +203,116 @@ __device__ __forceinline__ cd ld_val(const cd* p, bool nt) { return nt ? ld_pack
 
 // `cap` = products the dynamic LDS buffer holds (chosen per matrix at upload: the largest 256-row tile,
 // so that regular matrices never take the fallback and occupancy is not wasted on unused LDS).
-template <class T, bool NT>
+//
+// VI = true: value-indexed CSR ("CSR-VI").  Matrices with at most 256 distinct stored values (stencils,
+// unweighted graphs, uniform finite-element meshes) and fewer than 2^24 local-extended columns are
+// uploaded as ONE 32-bit word per non-zero, (dictionary index << 24) | column, plus the dictionary:
+// 4 B instead of 12 B per non-zero on the dominant stream of this HBM-bound kernel.  The products and their
+// summation order are exactly those of the plain layout, so y is bit-identical.
+// NI > 0: the tile's non-zeros are loaded by a fully unrolled, predicated loop of NI iterations (NI * 256 >=
+// cap): all index loads issue back to back, then all gathers -- no serial remainder loop.
+template <class T, bool NT, bool VI = false, int NI = 0>
 __global__ void __launch_bounds__(kBlock)
     k_spmv_csr(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const T* __restrict__ val,
                const T* __restrict__ x, const T* __restrict__ xg, T* __restrict__ y, int64_t n, int ntiles, int cap,
-               const DevState* __restrict__ st, const uint32_t* __restrict__ hseq, int64_t gstride) {
+               const DevState* __restrict__ st, const uint32_t* __restrict__ hseq, int64_t gstride, int ndict) {
   if (st && st->breakdown >= 0) return;
   // peer-to-peer halo (ks_p2p.hpp): the ghost vector is double-buffered, the parity of the halo sequence
   // number the push kernel just published selects the slot
   if (hseq) xg += (int64_t)(*hseq & 1u) * gstride;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* prod = reinterpret_cast<T*>(smem_raw);
+  // VI: the dictionary is staged in LDS (gathering it from global memory per non-zero measured 10 % slower);
+  // the fully unrolled path issues its index loads BEFORE the staging barrier so the two latencies overlap
+  __shared__ T dict[VI ? 256 : 1];
+  const int tid = threadIdx.x;
+  T dmine = zero_of(T{});
+  if (VI && tid < ndict) dmine = val[tid];
+  if (VI && NI == 0) {
+    dict[tid] = dmine;
+    __syncthreads();
+  }
   const int tile = xcd_remap(blockIdx.x, ntiles);
   const int64_t r0 = (int64_t)tile * kSpmvRows;
   const int64_t r1 = (r0 + kSpmvRows < n) ? r0 + kSpmvRows : n;
-  const int tid = threadIdx.x;
   const int32_t p0 = rowptr[r0];
   const int32_t p1 = rowptr[r1];
   const int32_t cnt = p1 - p0;
+  // this thread's row bounds for phase 2: issued now, so their latency hides behind phase 1
+  const int64_t rmine = (r0 + tid < r1) ? r0 + tid : r1 - 1;
+  const int32_t ra = rowptr[rmine], rb = rowptr[rmine + 1];
   if (cnt <= cap) {
+    if constexpr (NI > 0) {
+      int32_t c[NI];
+      T a[NI];
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int32_t p = tid + k * kBlock;
+        c[k] = (p < cnt) ? ld_i32(colidx + p0 + p, NT) : 0;
+        if (!VI) a[k] = (p < cnt) ? ld_val(val + p0 + p, NT) : zero_of(T{});
+      }
+      if (VI) {
+        dict[tid] = dmine;
+        __syncthreads();
+      }
+      T xv[NI];
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        if (VI) {
+          a[k] = dict[(uint32_t)c[k] >> 24];
+          c[k] &= 0xffffff;
+        }
+        xv[k] = (c[k] < n) ? x[c[k]] : xg[c[k] - n];
+      }
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int32_t p = tid + k * kBlock;
+        if (p < cnt) prod[p] = mul_(a[k], xv[k]);
+      }
+    } else {
 #pragma unroll 4
-    for (int32_t p = tid; p < cnt; p += kBlock) {
-      const int32_t c = ld_i32(colidx + p0 + p, NT);
-      const T a = ld_val(val + p0 + p, NT);
-      const T xv = (c < n) ? x[c] : xg[c - n];
-      prod[p] = mul_(a, xv);
+      for (int32_t p = tid; p < cnt; p += kBlock) {
+        int32_t c = ld_i32(colidx + p0 + p, NT);
+        T a;
+        if (VI) {
+          a = dict[(uint32_t)c >> 24];
+          c &= 0xffffff;
+        } else {
+          a = ld_val(val + p0 + p, NT);
+        }
+        const T xv = (c < n) ? x[c] : xg[c - n];
+        prod[p] = mul_(a, xv);
+      }
     }
     __syncthreads();
     const int64_t r = r0 + tid;
     if (r < r1) {
-      const int32_t a = rowptr[r] - p0, b = rowptr[r + 1] - p0;
+      const int32_t a = ra - p0, b = rb - p0;
       T s = zero_of(T{});
       for (int32_t p = a; p < b; ++p) s = add_(s, prod[p]);
       y[r] = s;
     }
   } else {
     // long-row fallback: one wave per row, lanes stride over the row's non-zeros
+    if (VI && NI > 0) {
+      dict[tid] = dmine;
+      __syncthreads();
+    }
     const int wave = tid >> 6, lane = tid & 63;
     for (int64_t r = r0 + wave; r < r1; r += kBlock / 64) {
       const int32_t a = rowptr[r], b = rowptr[r + 1];
       T s = zero_of(T{});
       for (int32_t p = a + lane; p < b; p += 64) {
-        const int32_t c = colidx[p];
+        int32_t c = colidx[p];
+        T av;
+        if (VI) {
+          av = dict[(uint32_t)c >> 24];
+          c &= 0xffffff;
+        } else {
+          av = val[p];
+        }
         const T xv = (c < n) ? x[c] : xg[c - n];
-        s = fma_(val[p], xv, s);
+        s = fma_(av, xv, s);
       }
       s = wave_sum(s);
       if (lane == 0) y[r] = s;
@@ -586,6 +652,8 @@ __global__ void __launch_bounds__(kBlock)
 // projection are exchanged through a double-buffered 8 KiB LDS array (one barrier per iteration); the
 // second-pass inner products then need no cross-wave reduction at all, because every column belongs to
 // exactly one wave.  Summation order is fixed (wave 0..3), so results are run-to-run deterministic.
+// (A software-pipelined form -- two register sets, loads of tile t+1 issued before the barrier of tile t --
+// measured the same 5.2 TB/s: the kernel is not stalled on its barrier.)
 // ------------------------------------------------------------------------------------------------
 template <int NCW, int U, bool NTS = true, int MINW = 1>
 __global__ void __launch_bounds__(kBlock, MINW)

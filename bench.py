@@ -62,9 +62,11 @@ def pmc_traffic(kernel_class):
         return None
 
 
-def step_bytes(n, nnz, j, reorth):
-    """Algorithmic bytes of one Arnoldi step at basis size j (SURVEY.md 8d / BASELINE.md section 4)."""
-    b = 12.0 * nnz + 4.0 * (n + 1) + 8.0 * n * (2 * j + 2)
+def step_bytes(n, nnz, j, reorth, bpn=12.0):
+    """Algorithmic bytes of one Arnoldi step at basis size j (SURVEY.md 8d / BASELINE.md section 4);
+    `bpn` = bytes the SpMV streams per stored non-zero in the layout the library chose (12 plain CSR,
+    4 value-indexed)."""
+    b = bpn * nnz + 4.0 * (n + 1) + 8.0 * n * (2 * j + 2)
     if reorth:
         b += 16.0 * j * n + 16.0 * n
     return b
@@ -141,6 +143,7 @@ def main():
 
             ctx, op, ws, v1, nnz_global = ksdist.setup_laplace3d(pkg, dist, m, maxdim, local_rank, transport)
             A_host = None
+        fmt = op.format
         ws.reinitialize(0, v1)
         ws.iterate_arnoldi(op, 1, mindim)  # initial expansion, src/run.jl:267 (untimed)
 
@@ -161,7 +164,7 @@ def main():
                 # all steps of this workload take the DGKS second pass; attribute per step when they do
                 all_re = st["reorth"] == nst
                 for j in range(k + 1, maxdim + 1):
-                    state["bytes"] += step_bytes(n, nnz_global, j, all_re)
+                    state["bytes"] += step_bytes(n, nnz_global, j, all_re, fmt["bytes_per_nnz"])
                 if not all_re:
                     jm = (k + 1 + maxdim) / 2.0
                     state["bytes"] += st["reorth"] * (16.0 * jm * n + 16.0 * n)
@@ -198,7 +201,7 @@ def main():
         ws.close()
         op.close()
         ctx.close()
-        return dict(elapsed=elapsed, state=state, prof=prof, nnz_global=nnz_global, A_host=A_host)
+        return dict(elapsed=elapsed, state=state, prof=prof, nnz_global=nnz_global, A_host=A_host, fmt=fmt)
 
     # N > 1: the row-partitioned solver has two transports for its per-step exchanges -- RCCL collectives
     # and the library's own peer-to-peer regions over xGMI (csrc/ks_p2p.hpp).  Both are measured with the
@@ -258,6 +261,8 @@ def main():
             "arnoldi_iterations_timed": state["steps"],
             "dgks_second_passes": state["reorth"],
             "parallelism": f"rows/{world}" if world > 1 else "single-gpu",
+            "spmv_layout": ("csr-vi: %d-entry value dictionary, 4 B per non-zero (bit-identical products)" % passes[chosen]["fmt"]["ndict"])
+                           if passes[chosen]["fmt"]["ndict"] else "csr: 12 B per non-zero",
         },
     }
     if chosen != "single":

@@ -120,6 +120,11 @@ int ks_operator_device_callback(ks_ctx* ctx, int64_t n_local, int dtype, ks_devi
                                 void* user, ks_operator** out);
 int ks_operator_destroy(ks_operator* op);
 int ks_operator_size(const ks_operator* op, int64_t* n_local, int64_t* nnz, int* dtype);
+/* Device layout chosen for a stored matrix: bytes streamed per non-zero by the SpMV (12 / 20 for plain
+ * CSR Float64 / ComplexF64; 4 for the value-indexed layout, used automatically when the matrix has at
+ * most 256 distinct stored values and fewer than 2^24 columns -- bit-identical products; KS_SPMV_FORMAT=csr
+ * disables it) and the dictionary size (0 = plain CSR).  0 / 0 for callback operators. */
+int ks_operator_format(const ks_operator* op, double* bytes_per_nnz, int* ndict);
 /* y = A*x on raw device pointers (bench / tests; the solver uses ks_apply below). */
 int ks_operator_apply_raw(ks_operator* op, const void* x_dev, void* y_dev);
 

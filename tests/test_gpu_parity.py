@@ -679,3 +679,54 @@ def test_lost_peer_is_reported_not_hung():
     KS_P2P_TIMEOUT_S seconds (bounded spins in the kernels) instead of hanging the GPU."""
     r = _run_ranks(2, "timeout", extra_env={"KS_P2P_TIMEOUT_S": "2"}, timeout=180)
     assert r.returncode == 0 and "expected CommTimeout" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+# ------------------------------------------------------------------ value-indexed SpMV layout
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_value_indexed_layout_is_bit_identical(dtype, monkeypatch):
+    """Matrices with <= 256 distinct stored values are uploaded as one 32-bit word per non-zero
+    (dictionary index << 24 | column).  y = A x must be BIT-identical to the plain CSR layout (same products,
+    same summation order), -0.0 entries must survive, and 257 distinct values must fall back."""
+    rng = np.random.default_rng(17)
+    n = 3000
+    vals = rnd(rng, dtype, 200)
+    vals[0] = -0.0
+    M = sprand(rng, dtype, n, 0.004).tocsr()
+    M.data = vals[rng.integers(0, 200, M.nnz)]
+    x = rnd(rng, dtype, n)
+
+    def spmv(A):
+        op = pkg.csr_operator(A)
+        ws = pkg.ArnoldiWorkspace(n, 4, dtype)
+        ws.set_col(0, x)
+        ws.apply(op, 0, 1)
+        return ws.col(1), op.format
+
+    y_vi, f_vi = spmv(M)
+    assert f_vi["ndict"] == len(np.unique(M.data.view(np.uint64).reshape(M.nnz, -1), axis=0)) and f_vi["bytes_per_nnz"] == 4.0
+    monkeypatch.setenv("KS_SPMV_FORMAT", "csr")
+    y_csr, f_csr = spmv(M)
+    assert f_csr["ndict"] == 0 and f_csr["bytes_per_nnz"] == 4.0 + np.dtype(dtype).itemsize
+    monkeypatch.delenv("KS_SPMV_FORMAT")
+    assert np.array_equal(y_vi.view(np.uint64), y_csr.view(np.uint64))
+    np.testing.assert_allclose(y_vi, M @ x, rtol=1e-12, atol=1e-12)
+    # one value too many -> plain CSR
+    M2 = M.copy()
+    M2.data = rnd(rng, dtype, 257)[np.arange(M2.nnz) % 257]
+    y2, f2 = spmv(M2)
+    assert f2["ndict"] == 0
+    np.testing.assert_allclose(y2, M2 @ x, rtol=1e-12, atol=1e-12)
+
+
+def test_value_indexed_layout_long_rows():
+    """Tiles above the LDS cap take the wave-per-row path; it must decode the packed words too."""
+    n = 600
+    rng = np.random.default_rng(5)
+    D = sp.csr_matrix(np.where(rng.random((n, n)) < 0.9, rng.integers(1, 4, (n, n)).astype(np.float64), 0.0))
+    x = rng.standard_normal(n)
+    op = pkg.csr_operator(D)
+    assert op.format["ndict"] == 3
+    ws = pkg.ArnoldiWorkspace(n, 4)
+    ws.set_col(0, x)
+    ws.apply(op, 0, 1)
+    np.testing.assert_allclose(ws.col(1), D @ x, rtol=1e-12, atol=1e-10)
