@@ -304,6 +304,11 @@ template <class D> struct CsrOp : ks_operator {
   int ntiles = 0;
   int lds_cap = 256;  // products per tile held in LDS (largest tile of this matrix, capped)
   int ndict = 0;      // > 0: value-indexed layout (k_spmv_csr<.., VI>): colidx = (dict index << 24) | column, val = dictionary
+  // delta-value-indexed layout (k_spmv_dvi): one byte per non-zero into a dictionary of (column - row, value)
+  int ndvi = 0;
+  uint8_t* codes = nullptr;
+  int32_t* ddelta = nullptr;
+  int dvi_unroll = 8;
   // halo plan (distributed)
   int64_t nghost = 0;
   D* ghost = nullptr;
@@ -330,6 +335,7 @@ template <class D> struct CsrOp : ks_operator {
       (void)hipFree(ghost);
     }
     (void)hipFree(sendbuf); (void)hipFree(send_idx); (void)hipFree(send_idx_all);
+    (void)hipFree(codes); (void)hipFree(ddelta);
   }
   void apply(const void* xv, void* yv, const DevState* st) override {
     const D* x = static_cast<const D*>(xv);
@@ -366,6 +372,14 @@ template <class D> struct CsrOp : ks_operator {
       // value-indexed layout
       ProfScope ps(ctx, KSP_SPMV, (double)nnz * bytes_per_nnz + 4.0 * (n_local + 1) + 2.0 * sizeof(D) * n_local);
       // (a variant reading the non-zeros as aligned pairs with non-temporal loads measured 15 % slower)
+      if (ndvi > 0) {
+        const int nt256 = (int)((n_local + kBlock - 1) / kBlock);
+        const uint32_t* hseq = (p2p_halo && !neigh.empty()) ? ctx->p2p.hstate : nullptr;
+        if (dvi_unroll == 4) ksd::k_spmv_dvi<D, 4><<<nt256, kBlock, 0, s>>>(rowptr, codes, ddelta, val, x, ghost, y, n_local, nt256, ndvi, st, hseq, ghost_stride);
+        else ksd::k_spmv_dvi<D, 8><<<nt256, kBlock, 0, s>>>(rowptr, codes, ddelta, val, x, ghost, y, n_local, nt256, ndvi, st, hseq, ghost_stride);
+        KS_HIP(hipGetLastError());
+        return;
+      }
       static const int nt = env_int("KS_SPMV_NT", 0);
       const size_t smem = (size_t)lds_cap * sizeof(D);
       const uint32_t* hseq = (p2p_halo && !neigh.empty()) ? ctx->p2p.hstate : nullptr;
@@ -485,13 +499,70 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
     int cap = (int)std::min<int64_t>(capmax, std::max<int64_t>(256, round_up(mx, 256)));
     op->lds_cap = env_int("KS_SPMV_CAP", cap);
   }
+  // Delta-value-indexed layout (k_spmv_dvi): at most 256 distinct (column - row, value) pairs -> one byte per
+  // non-zero.  KS_SPMV_FORMAT = csr | vi | dvi restricts the choice (default: the most compact that applies).
+  {
+    const char* fmt = std::getenv("KS_SPMV_FORMAT");
+    const bool try_dvi = nnz > 0 && (!fmt || std::string(fmt) == "dvi");
+    if (try_dvi) {
+      struct Key {
+        uint64_t a, b;
+        int64_t d;
+        bool operator==(const Key& o) const { return a == o.a && b == o.b && d == o.d; }
+      };
+      struct KeyHash {
+        size_t operator()(const Key& k) const {
+          return std::hash<uint64_t>()((k.a * 0x9E3779B97F4A7C15ull ^ k.b) + (uint64_t)k.d * 0xC2B2AE3D27D4EB4Full);
+        }
+      };
+      std::unordered_map<Key, int, KeyHash> index;
+      std::vector<uint8_t> codes((size_t)nnz);
+      std::vector<int32_t> dd;
+      std::vector<D> dv;
+      bool ok = true;
+      int max_row = 0;
+      for (int64_t r = 0; r < nrows && ok; ++r) {
+        max_row = std::max(max_row, rp[r + 1] - rp[r]);
+        for (int32_t p = rp[r]; p < rp[r + 1]; ++p) {
+          Key k{0, 0, (int64_t)ci[p] - r};
+          std::memcpy(&k, &vv[p], sizeof(D));
+          auto it = index.find(k);
+          int id;
+          if (it == index.end()) {
+            if (dd.size() == 256) { ok = false; break; }
+            id = (int)dd.size();
+            index.emplace(k, id);
+            dd.push_back((int32_t)k.d);
+            dv.push_back(vv[p]);
+          } else {
+            id = it->second;
+          }
+          codes[p] = (uint8_t)id;
+        }
+      }
+      if (ok) {
+        op->ndvi = (int)dd.size();
+        op->dvi_unroll = max_row <= 4 ? 4 : 8;
+        op->bytes_per_nnz = 1.0;
+        KS_HIP(hipMalloc(&op->rowptr, (size_t)(nrows + 1) * 4));
+        KS_HIP(hipMalloc(&op->codes, (size_t)nnz + 64));
+        KS_HIP(hipMalloc(&op->ddelta, 256 * 4));
+        KS_HIP(hipMalloc(&op->val, 256 * sizeof(D)));
+        KS_HIP(hipMemcpy(op->rowptr, rp.data(), (size_t)(nrows + 1) * 4, hipMemcpyHostToDevice));
+        KS_HIP(hipMemcpy(op->codes, codes.data(), (size_t)nnz, hipMemcpyHostToDevice));
+        KS_HIP(hipMemcpy(op->ddelta, dd.data(), dd.size() * 4, hipMemcpyHostToDevice));
+        KS_HIP(hipMemcpy(op->val, dv.data(), dv.size() * sizeof(D), hipMemcpyHostToDevice));
+        return op.release();
+      }
+    }
+  }
   // Value-indexed layout (k_spmv_csr<.., VI>): at most 256 distinct stored values (compared bit for bit, so
   // -0.0 and NaN payloads survive) and every column index below 2^24.  KS_SPMV_FORMAT=csr keeps plain CSR.
   std::vector<D> dict;
   std::vector<int32_t> packed;
   {
     const char* fmt = std::getenv("KS_SPMV_FORMAT");
-    bool try_vi = nnz > 0 && !(fmt && std::string(fmt) == "csr");
+    bool try_vi = nnz > 0 && !(fmt && (std::string(fmt) == "csr" || std::string(fmt) == "dvi"));
     if (try_vi) {
       struct Key {
         uint64_t a, b;
@@ -1617,8 +1688,8 @@ int ks_operator_format(const ks_operator* op, double* bytes_per_nnz, int* ndict)
     if (bytes_per_nnz) *bytes_per_nnz = op->bytes_per_nnz;
     if (ndict) {
       *ndict = 0;
-      if (op->dtype == KS_F64) { if (auto* c = dynamic_cast<const CsrOp<double>*>(op)) *ndict = c->ndict; }
-      else if (auto* c = dynamic_cast<const CsrOp<cd>*>(op)) *ndict = c->ndict;
+      if (op->dtype == KS_F64) { if (auto* c = dynamic_cast<const CsrOp<double>*>(op)) *ndict = c->ndvi > 0 ? c->ndvi : c->ndict; }
+      else if (auto* c = dynamic_cast<const CsrOp<cd>*>(op)) *ndict = c->ndvi > 0 ? c->ndvi : c->ndict;
     }
   });
 }

@@ -201,6 +201,23 @@ __device__ __forceinline__ int32_t ld_i32(const int32_t* p, bool nt) { return nt
 __device__ __forceinline__ double ld_val(const double* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
 __device__ __forceinline__ cd ld_val(const cd* p, bool nt) { return nt ? ld_pack_nt(p) : *p; }
 
+// The product a * x of one stored entry with every partial result rounded on its own (no fused
+// multiply-add across the complex cross terms): all SpMV layouts compute exactly this, which is what makes
+// their results bit-identical to each other.
+__device__ __forceinline__ void keep(double& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ double mul_nc(double a, double b) {
+  double p = a * b;
+  keep(p);
+  return p;
+}
+__device__ __forceinline__ cd mul_nc(cd a, cd b) {
+  double p1 = a.x * b.x, p2 = a.y * b.y, p3 = a.x * b.y, p4 = a.y * b.x;
+  keep(p1); keep(p2); keep(p3); keep(p4);
+  cd r{p1 - p2, p3 + p4};
+  keep(r.x); keep(r.y);
+  return r;
+}
+
 // `cap` = products the dynamic LDS buffer holds (chosen per matrix at upload: the largest 256-row tile,
 // so that regular matrices never take the fallback and occupancy is not wasted on unused LDS).
 //
@@ -267,10 +284,9 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
       for (int k = 0; k < NI; ++k) {
         const int32_t p = tid + k * kBlock;
-        if (p < cnt) prod[p] = mul_(a[k], xv[k]);
+        if (p < cnt) prod[p] = mul_nc(a[k], xv[k]);
       }
-    } else {
-#pragma unroll 4
+    } else {  // rolled loop: only reached with KS_SPMV_NI=0 / an oversized KS_SPMV_CAP (experiments)
       for (int32_t p = tid; p < cnt; p += kBlock) {
         int32_t c = ld_i32(colidx + p0 + p, NT);
         T a;
@@ -281,7 +297,7 @@ __global__ void __launch_bounds__(kBlock)
           a = ld_val(val + p0 + p, NT);
         }
         const T xv = (c < n) ? x[c] : xg[c - n];
-        prod[p] = mul_(a, xv);
+        prod[p] = mul_nc(a, xv);
       }
     }
     __syncthreads();
@@ -318,6 +334,56 @@ __global__ void __launch_bounds__(kBlock)
       if (lane == 0) y[r] = s;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SpMV, delta-value-indexed layout ("CSR-DVI").  When the set of distinct (column - row, value) pairs of a
+// matrix has at most 256 members -- stencils on structured grids, banded Toeplitz-like operators, regular
+// graph Laplacians -- every stored entry is ONE byte indexing that dictionary: the matrix stream shrinks
+// from 12 to 1 byte per non-zero and, because lane = row, the x gathers of one instruction read
+// consecutive addresses x[r + delta] (coalesced, unlike the CSR-stream gather).  One thread per row, row
+// entries visited in CSR order with a separate multiply and add, so y is bit-identical to the plain layout.
+// ------------------------------------------------------------------------------------------------
+
+template <class T, int UN>
+__global__ void __launch_bounds__(kBlock)
+    k_spmv_dvi(const int32_t* __restrict__ rowptr, const uint8_t* __restrict__ codes, const int32_t* __restrict__ ddelta,
+               const T* __restrict__ dval, const T* __restrict__ x, const T* __restrict__ xg, T* __restrict__ y,
+               int64_t n, int ntiles, int ndict, const DevState* __restrict__ st, const uint32_t* __restrict__ hseq,
+               int64_t gstride) {
+  if (st && st->breakdown >= 0) return;
+  if (hseq) xg += (int64_t)(*hseq & 1u) * gstride;
+  __shared__ int32_t sd[256];
+  __shared__ T sv[256];
+  const int tid = threadIdx.x;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int64_t r = (int64_t)tile * kBlock + tid;
+  const bool live = r < n;
+  const int32_t a = live ? rowptr[r] : 0, b = live ? rowptr[r + 1] : 0;  // in flight while the dictionary is staged
+  if (tid < ndict) {
+    sd[tid] = ddelta[tid];
+    sv[tid] = dval[tid];
+  }
+  __syncthreads();
+  T s = zero_of(T{});
+  for (int32_t p = a; p < b; p += UN) {
+    uint8_t code[UN];
+#pragma unroll
+    for (int k = 0; k < UN; ++k) code[k] = (p + k < b) ? codes[p + k] : (uint8_t)0;
+    T xv[UN];
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+      const int64_t c = (p + k < b) ? r + sd[code[k]] : r;
+      xv[k] = (c < n) ? x[c] : xg[c - n];
+    }
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+      if (p + k < b) {
+        s = add_(s, mul_nc(sv[code[k]], xv[k]));  // rounded product first, then the add: as the LDS-staged kernel
+      }
+    }
+  }
+  if (live) y[r] = s;
 }
 
 // gather x[idx[i]] into a contiguous send buffer (halo exchange pack)

@@ -261,8 +261,9 @@ def main():
             "arnoldi_iterations_timed": state["steps"],
             "dgks_second_passes": state["reorth"],
             "parallelism": f"rows/{world}" if world > 1 else "single-gpu",
-            "spmv_layout": ("csr-vi: %d-entry value dictionary, 4 B per non-zero (bit-identical products)" % passes[chosen]["fmt"]["ndict"])
-                           if passes[chosen]["fmt"]["ndict"] else "csr: 12 B per non-zero",
+            "spmv_layout": {1.0: "csr-dvi: %d-entry (column-row, value) dictionary, 1 B per non-zero (bit-identical products)",
+                            4.0: "csr-vi: %d-entry value dictionary, 4 B per non-zero (bit-identical products)"}.get(
+                                passes[chosen]["fmt"]["bytes_per_nnz"], "csr: 12 B per non-zero%.0s") % passes[chosen]["fmt"]["ndict"],
         },
     }
     if chosen != "single":

@@ -730,3 +730,34 @@ def test_value_indexed_layout_long_rows():
     ws.set_col(0, x)
     ws.apply(op, 0, 1)
     np.testing.assert_allclose(ws.col(1), D @ x, rtol=1e-12, atol=1e-10)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_delta_value_indexed_layout_is_bit_identical(dtype, monkeypatch):
+    """<= 256 distinct (column - row, value) pairs -> one byte per non-zero, one thread per row.  Stencil and
+    banded matrices qualify; y must be BIT-identical to the plain CSR layout and to the value-indexed one."""
+    cplx = np.dtype(dtype).kind == "c"
+    A = laplace3d(9, 10, 11).astype(dtype)
+    n = A.shape[0]
+    # (at most 8 entries per row: a ComplexF64 tile of 256 rows must fit the 2048-product LDS buffer, else the
+    # plain layouts take their wave-per-row path, which sums in a different order)
+    band = sp.diags([2.5 + (0.1j if cplx else 0), -0.0 + (0.3j if cplx else 0)], [0, 5], shape=(n, n), dtype=dtype)
+    M = (A + band).tocsr()
+    M.sort_indices()
+    rng = np.random.default_rng(23)
+    x = rnd(rng, dtype, n)
+    out = {}
+    for fmt in ("dvi", "vi", "csr"):
+        monkeypatch.setenv("KS_SPMV_FORMAT", fmt)
+        op = pkg.csr_operator(M)
+        ws = pkg.ArnoldiWorkspace(n, 4, dtype)
+        ws.set_col(0, x)
+        ws.apply(op, 0, 1)
+        out[fmt] = (ws.col(1), op.format)
+    monkeypatch.delenv("KS_SPMV_FORMAT")
+    assert out["dvi"][1]["bytes_per_nnz"] == 1.0 and 0 < out["dvi"][1]["ndict"] <= 256
+    assert out["vi"][1]["bytes_per_nnz"] == 4.0 and out["csr"][1]["ndict"] == 0
+    assert pkg.csr_operator(M).format["bytes_per_nnz"] == 1.0   # the default picks the most compact layout
+    for fmt in ("dvi", "vi"):
+        assert np.array_equal(out[fmt][0].view(np.uint64), out["csr"][0].view(np.uint64)), fmt
+    np.testing.assert_allclose(out["dvi"][0], M @ x, rtol=1e-13, atol=1e-13)
