@@ -2,7 +2,9 @@
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (collected in SEPARATE runs, each with only
 --kernel-trace next to --pmc) per kernel, and write profiles/pmc_traffic.json for bench.py.
 
-usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <n> <nnz> [out.json]
+usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <n> <nnz> [out.json] [bytes_per_nnz]
+(bytes_per_nnz: what the SpMV layout in use streams per stored entry -- 12 plain CSR, 4 value-indexed, 1
+delta-value-indexed; `bench.py` prints it as config.spmv_layout)
 
 gfx950 corrections (MI355X_MICROARCH.md, section HBM): FETCH_SIZE is in KiB and reports exactly 1/2 of the
 bytes of a wide (16 B/lane) coalesced streaming read -> x2 for the streaming kernels (k_dots, k_axpy*,
@@ -46,6 +48,7 @@ def klass(name):
 def main():
     fpath, wpath, n, nnz = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
     out = sys.argv[5] if len(sys.argv) > 5 else None
+    bpn = float(sys.argv[6]) if len(sys.argv) > 6 else 12.0
     F, W = load(fpath), load(wpath)
     assert [x[1] for x in F] == [x[1] for x in W], "the two passes must replay the same launch sequence"
     col = 8.0 * n
@@ -59,7 +62,7 @@ def main():
         if k is None:
             continue
         if k == "spmv":
-            alg = 12.0 * nnz + 4.0 * (n + 1) + 2 * col
+            alg = bpn * nnz + 4.0 * (n + 1) + 2 * col
         elif k == "dots":
             nc4 = int(re.search(r"k_dots<double, (\d+)", name).group(1))
             # first step of an expansion: smallest j of the granule is unknown -> track by sequence
@@ -74,6 +77,8 @@ def main():
             alg = col * (j + 2)
         elif k == "scale":
             alg = 2 * col
+        elif k == "rotate":
+            alg = col * 60  # the restart of the bench workload reads 40 columns and writes 20
         else:
             alg = None
         e = per[k]
