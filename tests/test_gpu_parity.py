@@ -661,13 +661,14 @@ def _run_ranks(nproc, mode, m=16, extra_env=None, timeout=420):
     return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
 
 
-@pytest.mark.parametrize("nproc,mode", [(2, "laplace"), (3, "laplace"), (2, "hashed"), (4, "hashed")])
+@pytest.mark.parametrize("nproc,mode", [(2, "laplace"), (3, "laplace"), (2, "hashed"), (4, "hashed"), (2, "wide"), (3, "complex")])
 def test_row_partitioned_solver_several_ranks_one_gpu(nproc, mode):
     """The multi-rank product path with REAL peers: `nproc` processes share device 0 and exchange through
     IPC-mapped regions (csrc/ks_p2p.hpp).  Every rank must converge with a small device-side residual and
     rank 0's single-GPU repeat of the same problem must need the same number of matrix-vector products
     and find the same Ritz values (tools/dist_gpu_check.py).  laplace: plane ghosts, contiguous send
-    runs; hashed: every rank neighbours every other, scattered send lists."""
+    runs; hashed: every rank neighbours every other, scattered send lists; wide: maxdim 60 (eager DGKS
+    sequence, stand-alone reductions); complex: ComplexF64 elements."""
     r = _run_ranks(nproc, mode)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     # (ranks print concurrently, lines may interleave: count occurrences)

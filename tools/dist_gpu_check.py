@@ -13,6 +13,9 @@ MODE
            repeats the solve on a single-GPU context: same mvproducts, same Ritz values.
   hashed   nonsymmetric matrix with hashed columns (every rank is everybody's neighbour, scattered
            send lists); distributed vs single-GPU run: same mvproducts, same Ritz values, ||AQ - QR||.
+  wide     the same matrix with maxdim = 60 > 40: the eager (un-fused) DGKS sequence with stand-alone
+           reductions (k_p2p_allreduce), chunked inner products, out-of-place rotation.
+  complex  ComplexF64 variant (complex diagonal shift): 16-byte elements through halo and reductions.
   timeout  rank 1 never joins; rank 0 must get CommTimeout (KS_ERR_COMM) after KS_P2P_TIMEOUT_S
            seconds instead of hanging.
 """
@@ -66,19 +69,23 @@ def main():
         full = lambda: sp.csr_matrix(ks.matrices.laplace3d_csr(mx, my, mz, 0, n, index_dtype=np.int64)[::-1], shape=(n, n))  # noqa: E731
     else:
         n = m * m * m
-        A = (ks.matrices.hashed_nonsymmetric_csr(n, seed=11) + sp.diags(np.linspace(1.0, 40.0, n))).tocsr()
+        diag = np.linspace(1.0, 40.0, n) + (0.5j * np.cos(np.arange(n)) if mode == "complex" else 0.0)
+        A = (ks.matrices.hashed_nonsymmetric_csr(n, seed=11) + sp.diags(diag)).tocsr()
         A.sort_indices()
         offs = ksd.partition_rows(n, world)
         r0, r1 = int(offs[rank]), int(offs[rank + 1])
         B = A[r0:r1]
         ip, ix, dv = B.indptr.astype(np.int64), B.indices.astype(np.int64), B.data
         kw = dict(nev=5, which="LR", tol=1e-10, mindim=10, maxdim=25, restarts=300)
+        if mode == "wide":
+            kw = dict(nev=12, which="LR", tol=1e-10, mindim=30, maxdim=60, restarts=300)
         full = lambda: A  # noqa: E731
+    dtype = np.complex128 if mode == "complex" else np.float64
 
     plan = ksd.build_halo_plan(ix, offs, rank, dist)
     op = ksd.dist_operator(api, ctx, ip, dv, plan, n)
-    ws = api.ArnoldiWorkspace(r1 - r0, kw["maxdim"], np.float64, ctx=ctx, n_global=n, row_begin=r0)
-    ws._v1 = ks.matrices.start_vector(r1 - r0, row_begin=r0)
+    ws = api.ArnoldiWorkspace(r1 - r0, kw["maxdim"], dtype, ctx=ctx, n_global=n, row_begin=r0)
+    ws._v1 = ks.matrices.start_vector(r1 - r0, row_begin=r0).astype(dtype)
     F, hist = ks.partialschur_(op, ws, **kw)
     res, orth = ws.residual_norms(op, F.nconverged)
     ok = bool(hist.converged and res < 1e-8 and orth < 1e-12)
@@ -89,8 +96,8 @@ def main():
         ok = ok and err < 1e-8
         msg += f" eig_err={err:.2e}"
     if rank == 0:  # same problem on one GPU: the row partition must not change what the solver does
-        ws1 = ks.ArnoldiWorkspace(n, kw["maxdim"], np.float64)
-        ws1._v1 = ks.matrices.start_vector(n)
+        ws1 = ks.ArnoldiWorkspace(n, kw["maxdim"], dtype)
+        ws1._v1 = ks.matrices.start_vector(n).astype(dtype)
         F1, h1 = ks.partialschur_(full(), ws1, **kw)
         dv_ = np.abs(np.sort_complex(F1.eigenvalues) - np.sort_complex(F.eigenvalues)).max()
         same = h1.mvproducts == hist.mvproducts and dv_ < 1e-9
