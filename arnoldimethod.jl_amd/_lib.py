@@ -78,6 +78,7 @@ PROTOTYPES = {
     "ks_ctx_stream": [vp, P(vp)],
     "ks_operator_csr": [vp, i64, i64, i64, vp, vp, vp, i32, i32, i32, i32, P(vp)],
     "ks_operator_csr_dist": [vp, i64, i64, i64, vp, vp, vp, i32, i32, vp, vp, vp, vp, P(vp)],
+    "ks_operator_dense": [vp, i64, vp, i64, i32, i32, P(vp)],
     "ks_operator_host_callback": [vp, i64, i32, HOST_APPLY_FN, vp, P(vp)],
     "ks_operator_device_callback": [vp, i64, i32, DEVICE_APPLY_FN, vp, P(vp)],
     "ks_operator_destroy": [vp],

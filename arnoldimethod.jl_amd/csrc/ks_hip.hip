@@ -411,6 +411,20 @@ template <class D> struct CsrOp : ks_operator {
   }
 };
 
+// dense matrix resident in HBM, row-major with padded rows
+template <class D> struct DenseOp : ks_operator {
+  D* A = nullptr;
+  int64_t lda = 0;
+  ~DenseOp() override { (void)hipFree(A); }
+  void apply(const void* xv, void* yv, const DevState* st) override {
+    ProfScope ps(ctx, KSP_SPMV, (double)n_local * n_local * sizeof(D) + 2.0 * sizeof(D) * n_local);
+    const int64_t want = (n_local + 3) / 4;
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cu * 8));
+    ksd::k_gemv_rows<D><<<nb, kBlock, 0, ctx->stream>>>(A, lda, n_local, n_local, static_cast<const D*>(xv), static_cast<D*>(yv), st);
+    KS_HIP(hipGetLastError());
+  }
+};
+
 struct HostCallbackOp : ks_operator {
   ks_host_apply_fn fn = nullptr;
   void* user = nullptr;
@@ -1633,6 +1647,42 @@ int ks_operator_csr_dist(ks_ctx* ctx, int64_t nrows_local, int64_t nghost, int64
         if (!all.empty()) KS_HIP(hipMemcpy(op->send_idx_all, all.data(), all.size() * 4, hipMemcpyHostToDevice));
       }
       *out = guard.release();
+    });
+  });
+}
+
+int ks_operator_dense(ks_ctx* ctx, int64_t n, const void* a, int64_t ld, int layout, int dtype, ks_operator** out) {
+  return guarded([&] {
+    KS_REQUIRE(ctx && out && (a || n == 0), KS_ERR_ARGUMENT, "null argument");
+    KS_REQUIRE(n >= 0 && ld >= n, KS_ERR_ARGUMENT, "leading dimension smaller than the matrix order");
+    KS_REQUIRE(layout == KS_ROW_MAJOR || layout == KS_COL_MAJOR, KS_ERR_ARGUMENT, "bad layout");
+    KS_REQUIRE(ctx->nranks == 1, KS_ERR_ARGUMENT, "the dense operator is single-GPU (shard a dense matrix through a device callback)");
+    ctx->use();
+    dispatch_dtype(dtype, [&](auto tag) {
+      using T = decltype(tag);
+      using D = typename DevT<T>::type;
+      auto op = std::make_unique<DenseOp<D>>();
+      op->ctx = ctx; op->n_local = n; op->nnz = n * n; op->dtype = dtype;
+      op->bytes_per_nnz = sizeof(D);
+      op->lda = round_up(std::max<int64_t>(n, 1), 2);
+      const size_t bytes = (size_t)op->lda * std::max<int64_t>(n, 1) * sizeof(D);
+      KS_HIP(hipMalloc(&op->A, bytes));
+      KS_HIP(hipMemset(op->A, 0, bytes));
+      const D* src = static_cast<const D*>(a);
+      if (n > 0 && layout == KS_ROW_MAJOR) {
+        KS_HIP(hipMemcpy2D(op->A, (size_t)op->lda * sizeof(D), src, (size_t)ld * sizeof(D), (size_t)n * sizeof(D), (size_t)n, hipMemcpyHostToDevice));
+      } else if (n > 0) {  // column-major (Julia): transpose on the host in row panels, upload panel by panel
+        const int64_t panel = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(64 << 20) / (int64_t)(op->lda * sizeof(D))));
+        std::vector<D> buf((size_t)panel * op->lda);
+        for (int64_t r0 = 0; r0 < n; r0 += panel) {
+          const int64_t rows = std::min(panel, n - r0);
+          std::memset(buf.data(), 0, (size_t)rows * op->lda * sizeof(D));
+          for (int64_t c = 0; c < n; ++c)
+            for (int64_t r = 0; r < rows; ++r) buf[(size_t)r * op->lda + c] = src[(size_t)c * ld + r0 + r];
+          KS_HIP(hipMemcpy(op->A + (size_t)r0 * op->lda, buf.data(), (size_t)rows * op->lda * sizeof(D), hipMemcpyHostToDevice));
+        }
+      }
+      *out = op.release();
     });
   });
 }

@@ -392,6 +392,50 @@ __global__ void __launch_bounds__(kBlock)
   if (live) st_elem_nt(y + r, s);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Dense operator  y = A x  (mul!(y, A::Matrix, x), src/expansion.jl:121 with a dense A): A row-major with a
+// padded leading dimension (multiple of 2 elements, so every row starts 16-byte aligned).  One wave per row
+// and trip: lanes stride over the row with 16-byte non-temporal loads (the matrix is the HBM stream, x stays
+// in cache), fixed-order wave reduction -> deterministic.  HBM-bound at 8 (16) bytes per entry.
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+    k_gemv_rows(const T* __restrict__ A, int64_t lda, int64_t nrows, int64_t ncols, const T* __restrict__ x,
+                T* __restrict__ y, const DevState* __restrict__ st) {
+  if (st && st->breakdown >= 0) return;
+  using P = typename Pack<T>::type;
+  constexpr int R = Pack<T>::R;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+  const int64_t npack = ncols / R;  // full packs per row; a real row of odd length has one scalar tail entry
+  for (int64_t r = wave0; r < nrows; r += nwaves) {
+    const T* row = A + r * lda;
+    T acc0 = zero_of(T{}), acc1 = zero_of(T{});
+    int64_t p = lane;
+    for (; p + 64 < npack; p += 128) {  // two independent accumulators, two loads in flight per lane
+      const P a0 = ld_pack_nt(row + p * R), a1 = ld_pack_nt(row + (p + 64) * R);
+      const P x0 = ld_pack(x + p * R), x1 = ld_pack(x + (p + 64) * R);
+      if constexpr (R == 2) {
+        acc0 = fma(a0.x, x0.x, fma(a0.y, x0.y, acc0));
+        acc1 = fma(a1.x, x1.x, fma(a1.y, x1.y, acc1));
+      } else {
+        acc0 = fma_(a0, x0, acc0);
+        acc1 = fma_(a1, x1, acc1);
+      }
+    }
+    for (; p < npack; p += 64) {
+      const P a0 = ld_pack_nt(row + p * R);
+      const P x0 = ld_pack(x + p * R);
+      if constexpr (R == 2) acc0 = fma(a0.x, x0.x, fma(a0.y, x0.y, acc0));
+      else acc0 = fma_(a0, x0, acc0);
+    }
+    if (R == 2 && (ncols & 1) && lane == 0) acc1 = fma_(row[ncols - 1], x[ncols - 1], acc1);
+    const T s = wave_sum(add_(acc0, acc1));
+    if (lane == 0) st_elem_nt(y + r, s);
+  }
+}
+
 // gather x[idx[i]] into a contiguous send buffer (halo exchange pack)
 template <class T>
 __global__ void __launch_bounds__(kBlock)

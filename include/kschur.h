@@ -106,6 +106,13 @@ int ks_operator_csr_dist(ks_ctx* ctx, int64_t nrows_local, int64_t nghost, int64
                          const int64_t* rowptr, const int32_t* colidx, const void* val, int dtype,
                          int nneigh, const int32_t* neigh, const int64_t* send_ptr,
                          const int32_t* send_idx, const int64_t* recv_cnt, ks_operator** out);
+/* (i') dense matrix (mul!(y, A::Matrix, x)): n x n elements of `dtype`, leading dimension `ld` elements,
+ * KS_COL_MAJOR (Julia / Fortran) or KS_ROW_MAJOR (C / numpy).  Kept row-major in HBM; y = A*x streams it
+ * once per product (8 or 16 bytes per entry).  Single-GPU contexts only. */
+#define KS_ROW_MAJOR 0
+#define KS_COL_MAJOR 1
+int ks_operator_dense(ks_ctx* ctx, int64_t n, const void* a, int64_t ld, int layout, int dtype,
+                      ks_operator** out);
 /* (ii) opaque host operator (e.g. a LinearMap wrapping ldiv! with a host LU,
  * docs/src/index.md:246-249): `apply(user, x_host, y_host)` computes y = A*x on n_local
  * elements of `dtype`; return nonzero to signal failure.  The library stages the two columns

@@ -762,3 +762,39 @@ def test_delta_value_indexed_layout_is_bit_identical(dtype, monkeypatch):
     for fmt in ("dvi", "vi"):
         assert np.array_equal(out[fmt][0].view(np.uint64), out["csr"][0].view(np.uint64)), fmt
     np.testing.assert_allclose(out["dvi"][0], M @ x, rtol=1e-13, atol=1e-13)
+
+
+# ------------------------------------------------------------------ dense operator (mul!(y, A::Matrix, x))
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("order", ["C", "F"])
+@pytest.mark.parametrize("n", [1, 7, 130, 1001])
+def test_dense_operator_matvec(dtype, order, n):
+    """ks_operator_dense: row-/column-major input, odd orders (scalar tail of a real row), y = A x vs numpy.
+    Tolerance: summation order differs from numpy's (64 lane partials + wave tree)."""
+    rng = np.random.default_rng(n)
+    A = np.array(rnd(rng, dtype, n, n), order=order)
+    x = rnd(rng, dtype, n)
+    op = pkg.dense_operator(A)
+    assert op.format["bytes_per_nnz"] == np.dtype(dtype).itemsize
+    ws = pkg.ArnoldiWorkspace(n, 1 if n == 1 else 2, dtype)
+    ws.set_col(0, x)
+    ws.apply(op, 0, 1)
+    np.testing.assert_allclose(ws.col(1), A @ x, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(A).sum(axis=1).max()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dense_matrix_end_to_end_matches_oracle(dtype):
+    """partialschur on a dense ndarray goes through the dense operator (as_operator) and makes the same
+    decisions as the oracle: same mvproducts, Ritz values to 1e-9, small residual."""
+    rng = np.random.default_rng(41)
+    n = 300
+    A = rnd(rng, dtype, n, n) / np.sqrt(n) + np.diag(np.linspace(1, 8, n)).astype(dtype)
+    v1 = oa.uniform_hash(9, np.arange(n)).astype(dtype)
+    kw = dict(nev=6, which="LR", tol=1e-10, mindim=12, maxdim=30, restarts=200)
+    assert pkg.as_operator(A).format["bytes_per_nnz"] == np.dtype(dtype).itemsize   # dense layout, not CSR
+    dec, hist = pkg.partialschur(A, v1=v1, **kw)
+    ref, rhist = oa.partialschur(A, v1=v1, **kw)
+    assert hist.converged and hist.mvproducts == rhist.mvproducts
+    np.testing.assert_allclose(np.sort_complex(dec.eigenvalues), np.sort_complex(ref.eigenvalues), atol=1e-9)
+    Q, R = dec.Q, np.array(dec.R)
+    assert np.linalg.norm(A @ Q - Q @ R) < 1e-8 and np.linalg.norm(Q.conj().T @ Q - np.eye(Q.shape[1])) < 1e-12
