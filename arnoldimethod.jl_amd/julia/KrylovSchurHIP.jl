@@ -87,6 +87,27 @@ function HipOperator(ctx::HipContext, A::SparseMatrixCSC{T,Int64}) where {T<:Uni
     op
 end
 
+# mul!(y, A, x) for a dense A::Matrix (column-major; the library keeps a row-major copy in HBM and streams it
+# once per product).
+function HipOperator(ctx::HipContext, A::Matrix{T}) where {T<:Union{Float64,ComplexF64}}
+    n = LinearAlgebra.checksquare(A)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve A begin
+        check(ccall((:ks_operator_dense, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Cint, Cint, Ref{Ptr{Cvoid}}),
+                    ctx.h, n, pointer(A), stride(A, 2), #=KS_COL_MAJOR=# 1, dtype_code(T), r))
+    end
+    op = HipOperator{T}(r[], n, ctx)
+    finalizer(x -> ccall((:ks_operator_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), op)
+    op
+end
+
+# Device layout the library chose for a stored matrix: (bytes streamed per non-zero, dictionary size).
+function operator_format(A::HipOperator)
+    b = Ref{Cdouble}(0); d = Ref{Cint}(0)
+    check(ccall((:ks_operator_format, LIB), Cint, (Ptr{Cvoid}, Ref{Cdouble}, Ref{Cint}), A.h, b, d))
+    (bytes_per_nnz = b[], ndict = Int(d[]))
+end
+
 # Opaque operators (LinearMaps etc., docs/src/index.md:246-249): the library calls back with two host
 # pointers per application.  `@cfunction` is safe here: the call is synchronous on the calling task.
 function _host_apply(user::Ptr{Cvoid}, x::Ptr{Cvoid}, y::Ptr{Cvoid})::Cint
