@@ -209,9 +209,9 @@ def main():
     # reproduced the RCCL pass (same (k, nlock) sequence of the restarts, same Ritz values).  Every pass is
     # reported under "transports".  KS_BENCH_TRANSPORTS=rccl restricts the run.
     passes = {}
-    if dist is None or world == 1:
+    if dist is None or (world == 1 and "KS_BENCH_TRANSPORTS" not in os.environ):
         order = ["single"]
-    else:
+    else:  # (KS_FORCE_DIST=1 KS_BENCH_TRANSPORTS=rccl,p2p exercises this selection logic on a single rank)
         order = [t for t in os.environ.get("KS_BENCH_TRANSPORTS", "rccl,p2p").split(",") if t in ("rccl", "p2p")] or ["rccl"]
     for tr in order:
         ok, res, err = 1, None, ""
@@ -325,10 +325,17 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["cpu_baseline"] = {"value": None, "unit": "iters/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
 
-    if rank == 0:
-        print(json.dumps(out))
+    # Tear everything down first and flush the C stdio buffers (RCCL prints a version banner through printf,
+    # which sits in the C buffer until exit when stdout is a pipe): the JSON line must be the LAST line on stdout.
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    import ctypes
+
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
