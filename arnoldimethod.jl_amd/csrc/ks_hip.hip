@@ -996,7 +996,11 @@ inline void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op, int from, 
   const D* part = static_cast<const D*>(ws->partial);
   const double nb8 = (double)ws->n * sizeof(D);
   const bool dist = cx->distributed();
-  const bool p2p = cx->p2p.attached;  // exchange folded into the reduction kernels (mode 3)
+  // peer-to-peer: exchange folded into the reduction kernels (mode 3).  KS_P2P_NO_FOLD=1 keeps the three-launch
+  // structure of the RCCL transport (reduce -> all-reduce -> post) on the peer-to-peer all-reduce kernel, which
+  // is how that structure is exercised with several real ranks on a one-GPU box.
+  static const int no_fold = env_int("KS_P2P_NO_FOLD", 0);
+  const bool p2p = cx->p2p.attached && !no_fold;
   const ksd::P2pDev pd = cx->p2p.dev;
   for (int j = from; j <= to; ++j) {
     D* w = static_cast<D*>(ws->col(j));

@@ -675,6 +675,14 @@ def test_row_partitioned_solver_several_ranks_one_gpu(nproc, mode):
     assert r.stdout.count("-> OK") == nproc and "same: True" in r.stdout, r.stdout[-3000:]
 
 
+def test_reduce_allreduce_post_structure_with_real_ranks():
+    """The RCCL transport's launch structure of the lazy path (reduce-only kernel -> all-reduce -> post kernel)
+    with 3 real ranks: KS_P2P_NO_FOLD=1 runs exactly those kernel modes on the peer-to-peer all-reduce kernel."""
+    r = _run_ranks(3, "laplace", extra_env={"KS_P2P_NO_FOLD": "1"})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("-> OK") == 3 and "same: True" in r.stdout, r.stdout[-3000:]
+
+
 def test_lost_peer_is_reported_not_hung():
     """A rank that never joins an exchange makes the others fail with KS_ERR_COMM after
     KS_P2P_TIMEOUT_S seconds (bounded spins in the kernels) instead of hanging the GPU."""
