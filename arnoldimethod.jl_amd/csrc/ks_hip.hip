@@ -832,6 +832,29 @@ template <int NC4, int RPL> int launch_axpy_dots_nc(ks_workspace* ws, int j, dou
                                                               static_cast<double*>(ws->partial), ws->pnb, ws->partial2, ws->st);
   return nb;
 }
+template <int NCW, int U, int WB> int launch_axpy_dots_cswb_nc(ks_workspace* ws, int j, double* w, int defer) {
+  static int cache = -1;
+  const int nb = cap_blocks(ws, resident_blocks(ws->ctx, ksd::k_axpy_dots_cs<NCW, U, true, 1, WB>, 0, cache), 64 * U);
+  ksd::k_axpy_dots_cs<NCW, U, true, 1, WB><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const double*>(ws->V), ws->ld, j, w,
+                                                                            static_cast<const double*>(ws->coef),
+                                                                            static_cast<double*>(ws->partial), ws->pnb, ws->partial2,
+                                                                            ws->st, defer);
+  return nb;
+}
+template <int U, int WB> int launch_axpy_dots_cswb(ks_workspace* ws, int j, double* w, int defer) {
+  switch ((j + 3) / 4) {
+    case 1: return launch_axpy_dots_cswb_nc<1, U, WB>(ws, j, w, defer);
+    case 2: return launch_axpy_dots_cswb_nc<2, U, WB>(ws, j, w, defer);
+    case 3: return launch_axpy_dots_cswb_nc<3, U, WB>(ws, j, w, defer);
+    case 4: return launch_axpy_dots_cswb_nc<4, U, WB>(ws, j, w, defer);
+    case 5: return launch_axpy_dots_cswb_nc<5, U, WB>(ws, j, w, defer);
+    case 6: return launch_axpy_dots_cswb_nc<6, U, WB>(ws, j, w, defer);
+    case 7: return launch_axpy_dots_cswb_nc<7, U, WB>(ws, j, w, defer);
+    case 8: return launch_axpy_dots_cswb_nc<8, U, WB>(ws, j, w, defer);
+    case 9: return launch_axpy_dots_cswb_nc<9, U, WB>(ws, j, w, defer);
+    default: return launch_axpy_dots_cswb_nc<10, U, WB>(ws, j, w, defer);
+  }
+}
 template <int NCW, int U> int launch_axpy_dots_cs_nc(ks_workspace* ws, int j, double* w, int defer) {
   static int cache = -1;
   const int nb = cap_blocks(ws, resident_blocks(ws->ctx, ksd::k_axpy_dots_cs<NCW, U>, 0, cache), 64 * U);
@@ -856,10 +879,11 @@ template <int U> int launch_axpy_dots_cs(ks_workspace* ws, int j, double* w, int
   }
 }
 inline int launch_axpy_dots(ks_workspace* ws, int j, double* w, int defer = 0) {
-  static const int variant = env_int("KS_FUSED_VARIANT", 4);  // 0: per-lane columns, 1: column split U=1, 2: U=2
+  static const int variant = env_int("KS_FUSED_VARIANT", 48);  // 0: per-lane columns, 1: column split U=1, 2: U=2
   if (variant == 1 || (defer && variant == 0)) return launch_axpy_dots_cs<1>(ws, j, w, defer);
   if (variant == 2) return launch_axpy_dots_cs<2>(ws, j, w, defer);
   if (variant == 4) return launch_axpy_dots_cs<4>(ws, j, w, defer);
+  if (variant == 48) return launch_axpy_dots_cswb<4, 8>(ws, j, w, defer);   // U = 4, write-back every 8 tiles (32 KiB bursts)
   KS_REQUIRE(!defer, KS_ERR_INTERNAL, "per-lane fused variant does not support deferred normalisation");
   switch ((j + 3) / 4) {
     case 1: return launch_axpy_dots_nc<1, 2>(ws, j, w);

@@ -771,7 +771,9 @@ __global__ void __launch_bounds__(kBlock)
 // (A software-pipelined form -- two register sets, loads of tile t+1 issued before the barrier of tile t --
 // measured the same 5.2 TB/s: the kernel is not stalled on its barrier.)
 // ------------------------------------------------------------------------------------------------
-template <int NCW, int U, bool NTS = true, int MINW = 1>
+// WB > 1: the updated rows are staged in LDS and written back every WB tiles by all four waves (WB x 4 KiB
+// bursts instead of one wave's 4 KiB per tile).
+template <int NCW, int U, bool NTS = true, int MINW = 1, int WB = 1>
 __global__ void __launch_bounds__(kBlock, MINW)
     k_axpy_dots_cs(const double* __restrict__ V, int64_t ldv, int j, double* __restrict__ w,
                    const double* __restrict__ coef, double* __restrict__ partial, int pnb,
@@ -780,6 +782,7 @@ __global__ void __launch_bounds__(kBlock, MINW)
   // lazy normalisation: y (= w on entry) = A * (unnormalised column j-1) carries the factor beta_{j-1}
   const double invb = (defer && st) ? st->invb : 1.0;
   __shared__ double2 tbuf[2][4][U][64];
+  __shared__ double2 wout[WB > 1 ? WB * U * 64 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const double* colp[NCW];
@@ -842,11 +845,22 @@ __global__ void __launch_bounds__(kBlock, MINW)
       wn.y = wv[u].y - ((t0.y + t1.y) + (t2.y + t3.y));
       if (!ok[u]) wn = make_double2(0.0, 0.0);
       if (wave == 0 && ok[u]) {
-        if (NTS) st_pack_nt(w + r[u], wn); else st_pack(w + r[u], wn);
+        if constexpr (WB > 1) wout[((it % WB) * U + u) * 64 + lane] = wn;
+        else if (NTS) st_pack_nt(w + r[u], wn);
+        else st_pack(w + r[u], wn);
         nrm += fma(wn.x, wn.x, wn.y * wn.y);
       }
 #pragma unroll
       for (int i = 0; i < NCW; ++i) acc[i] = fma(v[i][u].x, wn.x, fma(v[i][u].y, wn.y, acc[i]));
+    }
+    if constexpr (WB > 1) {
+      const bool lastt = base + 64 * U >= pe;
+      if ((it % WB) == WB - 1 || lastt) {  // workgroup-uniform
+        __syncthreads();
+        const int64_t fb = base - (int64_t)(it % WB) * 64 * U;  // first pack staged
+        const int64_t fe = (base + 64 * U < pe) ? base + 64 * U : pe;
+        for (int64_t o = fb + threadIdx.x; o < fe; o += kBlock) st_pack_nt(w + o * 2, wout[o - fb]);
+      }
     }
   }
 #pragma unroll
