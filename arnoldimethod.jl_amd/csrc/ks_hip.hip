@@ -1421,6 +1421,75 @@ void relation_norms(ks_operator* A, ks_workspace* ws, int nx, int ny, const T* C
 
 }  // namespace
 
+namespace {
+// Placement tuning.  How fast the streaming kernels run on a basis of several GB depends on WHICH physical
+// pages back it: K simultaneous allocations of the same size in one process differ reproducibly by 6-8 %
+// (tools/placement_probe2.hip; the launches of three real steps take 5.31..5.67 ms on eight candidates at
+// n = 1e7) while offsets inside one allocation and the leading dimension make no difference
+// (tools/placement_probe.hip).  This is what made identical runs land on two plateaus 4 % apart.  So a large
+// workspace allocates a few candidates for V, times the launches of real steps at three basis sizes on each
+// (zeros in, zeros out) and keeps the fastest: KS_PLACE_TRIALS candidates (8; 1 disables), never more than
+// half of the free memory, ~20 ms per candidate.
+template <class D> double placement_trio_ms(ks_workspace* w, hipEvent_t a, hipEvent_t b) {
+  ks_ctx* c = w->ctx;
+  const int jmax = std::min(w->maxdim, 40);
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {  // rep 0 warms up
+    KS_HIP(hipEventRecord(a, c->stream));
+    for (int j = jmax; j >= 1 && j > jmax - 20; j -= 6) {  // the launches of real steps at a few basis sizes
+      D* col = static_cast<D*>(w->col(j));
+      launch_dots<D>(w, j, col, 1, nullptr);
+      if constexpr (sizeof(D) == 8) launch_axpy_dots(w, j, col, 0);
+      const int64_t ppb = (w->ld / 2) / std::max(1, w->nb);
+      if (sizeof(D) == 8 && ppb >= 3072)
+        ksd::k_axpy<D, 8><<<w->nb, kBlock, 0, c->stream>>>(static_cast<const D*>(w->V), w->ld, j, col, static_cast<const D*>(w->coef), w->partial2, 1, nullptr);
+      else
+        ksd::k_axpy<D, 4><<<w->nb, kBlock, 0, c->stream>>>(static_cast<const D*>(w->V), w->ld, j, col, static_cast<const D*>(w->coef), w->partial2, 1, nullptr);
+    }
+    KS_HIP(hipEventRecord(b, c->stream));
+    KS_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    KS_HIP(hipEventElapsedTime(&ms, a, b));
+    if (rep > 0) best = std::min(best, ms);
+  }
+  return best;
+}
+
+template <class D> void tune_placement(ks_workspace* w, size_t vbytes) {
+  static const int trials = env_int("KS_PLACE_TRIALS", 8);
+  if (trials <= 1 || vbytes < ((size_t)256 << 20)) return;
+  size_t free_b = 0, total_b = 0;
+  KS_HIP(hipMemGetInfo(&free_b, &total_b));
+  const int extra = (int)std::min<size_t>((size_t)trials - 1, free_b / 2 / vbytes);  // never take more than half of what is free
+  if (extra < 1) return;
+  ks_ctx* c = w->ctx;
+  std::vector<void*> cand{w->V};
+  for (int k = 0; k < extra; ++k) {
+    void* p = nullptr;
+    if (hipMalloc(&p, vbytes) != hipSuccess) { (void)hipGetLastError(); break; }
+    KS_HIP(hipMemsetAsync(p, 0, vbytes, c->stream));
+    cand.push_back(p);
+  }
+  hipEvent_t a, b;
+  KS_HIP(hipEventCreate(&a));
+  KS_HIP(hipEventCreate(&b));
+  size_t best = 0;
+  double best_ms = 1e30;
+  for (size_t k = 0; k < cand.size(); ++k) {
+    w->V = cand[k];
+    const double ms = placement_trio_ms<D>(w, a, b);
+    if (env_int("KS_PLACE_DEBUG", 0)) std::fprintf(stderr, "[ks] placement candidate %zu @%p: %.3f ms\n", k, cand[k], ms);
+    if (ms < best_ms) { best_ms = ms; best = k; }
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  for (size_t k = 0; k < cand.size(); ++k)
+    if (k != best) (void)hipFree(cand[k]);
+  w->V = cand[best];
+  // the calibration wrote (zeros) into the scratch of the reductions only; V is still all zero
+}
+}  // namespace
+
 // ================================================================================================
 // C ABI
 // ================================================================================================
@@ -1834,6 +1903,10 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     w->ones.assign(maxdim + 2, 1.0);
     KS_HIP(hipMalloc(&w->colscale, (size_t)(maxdim + 2) * 8));
     KS_HIP(hipMemcpy(w->colscale, w->ones.data(), (size_t)(maxdim + 2) * 8, hipMemcpyHostToDevice));
+    reset_state(w.get());
+    KS_HIP(hipStreamSynchronize(ctx->stream));
+    if (dtype == KS_F64) tune_placement<double>(w.get(), vbytes);
+    else tune_placement<cd>(w.get(), vbytes);
     reset_state(w.get());
     KS_HIP(hipStreamSynchronize(ctx->stream));
     *out = w.release();
