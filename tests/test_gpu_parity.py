@@ -806,3 +806,23 @@ def test_dense_matrix_end_to_end_matches_oracle(dtype):
     np.testing.assert_allclose(np.sort_complex(dec.eigenvalues), np.sort_complex(ref.eigenvalues), atol=1e-9)
     Q, R = dec.Q, np.array(dec.R)
     assert np.linalg.norm(A @ Q - Q @ R) < 1e-8 and np.linalg.norm(Q.conj().T @ Q - np.eye(Q.shape[1])) < 1e-12
+
+
+# ------------------------------------------------------------------ placement tuning of large workspaces
+def test_large_workspace_goes_through_placement_tuning(monkeypatch):
+    """Workspaces whose basis exceeds 256 MB time a few candidate allocations and keep the fastest
+    (ks_workspace_create); the basis that comes out must be zero-initialised and fully functional:
+    Arnoldi relation and orthonormality of a 20-step expansion on the 96^3 Laplacian (V = 290 MB)."""
+    m = 96
+    n = m ** 3
+    ip, ix, dv = pkg.matrices.laplace3d_csr(m, m, m)
+    A = pkg.matrices.to_scipy(ip, ix, dv, n)
+    op = pkg.csr_operator(A)
+    monkeypatch.setenv("KS_PLACE_TRIALS", "4")
+    ws = pkg.ArnoldiWorkspace(n, 40)
+    assert not np.any(ws.col(7)) and not np.any(ws.col(40))
+    ws.reinitialize(0, pkg.matrices.start_vector(n))
+    st = ws.iterate_arnoldi(op, 1, 20)
+    assert st["steps"] == 20 and st["breakdowns"] == 0
+    rel, orth = ws.arnoldi_relation(op, 20)
+    assert rel < 1e-10 * 12 * np.sqrt(20) and orth < 1e-13   # ||A V_k - V_{k+1} H||_F, ||V'V - I||_F
