@@ -1429,7 +1429,7 @@ namespace {
 // (tools/placement_probe.hip).  This is what made identical runs land on two plateaus 4 % apart.  So a large
 // workspace allocates a few candidates for V, times the launches of real steps at three basis sizes on each
 // (zeros in, zeros out) and keeps the fastest: KS_PLACE_TRIALS candidates (8; 1 disables), never more than
-// half of the free memory, ~20 ms per candidate.
+// half of the free memory, ~20 ms per candidate; only for a basis of at least KS_PLACE_MIN_MB (1024) MB.
 template <class D> double placement_trio_ms(ks_workspace* w, hipEvent_t a, hipEvent_t b) {
   ks_ctx* c = w->ctx;
   const int jmax = std::min(w->maxdim, 40);
@@ -1457,7 +1457,10 @@ template <class D> double placement_trio_ms(ks_workspace* w, hipEvent_t a, hipEv
 
 template <class D> void tune_placement(ks_workspace* w, size_t vbytes) {
   static const int trials = env_int("KS_PLACE_TRIALS", 8);
-  if (trials <= 1 || vbytes < ((size_t)256 << 20)) return;
+  // measured: +3 % at 3.3 GB, +1.5 % at 1.6 GB, nothing at 0.8 GB, -2 % at 0.4 GB (there the calibration, which
+  // revisits the same columns, sees the memory-side cache more than the placement)
+  static const int min_mb = env_int("KS_PLACE_MIN_MB", 1024);
+  if (trials <= 1 || vbytes < ((size_t)min_mb << 20)) return;
   size_t free_b = 0, total_b = 0;
   KS_HIP(hipMemGetInfo(&free_b, &total_b));
   const int extra = (int)std::min<size_t>((size_t)trials - 1, free_b / 2 / vbytes);  // never take more than half of what is free

@@ -810,7 +810,7 @@ def test_dense_matrix_end_to_end_matches_oracle(dtype):
 
 # ------------------------------------------------------------------ placement tuning of large workspaces
 def test_large_workspace_goes_through_placement_tuning(monkeypatch):
-    """Workspaces whose basis exceeds 256 MB time a few candidate allocations and keep the fastest
+    """Workspaces whose basis exceeds KS_PLACE_MIN_MB (default 1 GB) time a few candidate allocations and keep the fastest
     (ks_workspace_create); the basis that comes out must be zero-initialised and fully functional:
     Arnoldi relation and orthonormality of a 20-step expansion on the 96^3 Laplacian (V = 290 MB)."""
     m = 96
@@ -819,6 +819,7 @@ def test_large_workspace_goes_through_placement_tuning(monkeypatch):
     A = pkg.matrices.to_scipy(ip, ix, dv, n)
     op = pkg.csr_operator(A)
     monkeypatch.setenv("KS_PLACE_TRIALS", "4")
+    monkeypatch.setenv("KS_PLACE_MIN_MB", "128")
     ws = pkg.ArnoldiWorkspace(n, 40)
     assert not np.any(ws.col(7)) and not np.any(ws.col(40))
     ws.reinitialize(0, pkg.matrices.start_vector(n))
