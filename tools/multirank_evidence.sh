@@ -1,3 +1,7 @@
+#!/bin/bash
+# Produces profiles/r01_multirank_one_gpu.txt: the row-partitioned solver with 2-4 real ranks on ONE GPU
+# (peer-to-peer transport), the lost-peer timeout, and the fixed cost of the distributed structure.
+#   gpurun -- 'bash tools/multirank_evidence.sh > gpurun_out/multirank.txt 2>&1'
 export KS_SAME_DEVICE=1 KS_TRANSPORT=p2p
 port=29900
 echo "# multi-rank product path on ONE MI355X (all ranks on device 0, peer-to-peer transport), tools/dist_gpu_check.py"

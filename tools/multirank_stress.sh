@@ -1,3 +1,5 @@
+#!/bin/bash
+# Repeats several multi-rank configurations on one GPU (determinism / race hunting).
 export KS_SAME_DEVICE=1 KS_TRANSPORT=p2p
 port=29700
 for rep in 1 2 3; do for cfg in "4 hashed 22" "3 laplace 30" "4 complex 16" "2 wide 20"; do

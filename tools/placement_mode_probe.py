@@ -1,3 +1,6 @@
+"""Per-class kernel times of the bench workload for workspaces created after growing amounts of other
+allocations: shows the performance plateaus that the physical placement of V causes (run with
+KS_PLACE_TRIALS=1 to see them; the default placement tuning removes them)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.getcwd())
