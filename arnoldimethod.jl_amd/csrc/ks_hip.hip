@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1428,8 +1429,8 @@ namespace {
 // n = 1e7) while offsets inside one allocation and the leading dimension make no difference
 // (tools/placement_probe.hip).  This is what made identical runs land on two plateaus 4 % apart.  So a large
 // workspace allocates a few candidates for V, times the launches of real steps at three basis sizes on each
-// (zeros in, zeros out) and keeps the fastest: KS_PLACE_TRIALS candidates (8; 1 disables), never more than
-// half of the free memory, ~20 ms per candidate; only for a basis of at least KS_PLACE_MIN_MB (1024) MB.
+// (zeros in, zeros out) and keeps the fastest (search policy: tune_placement below); only for a basis of at
+// least KS_PLACE_MIN_MB (1024) MB; KS_PLACE_TRIALS=1 disables.
 template <class D> double placement_trio_ms(ks_workspace* w, hipEvent_t a, hipEvent_t b) {
   ks_ctx* c = w->ctx;
   const int jmax = std::min(w->maxdim, 40);
@@ -1456,39 +1457,49 @@ template <class D> double placement_trio_ms(ks_workspace* w, hipEvent_t a, hipEv
 }
 
 template <class D> void tune_placement(ks_workspace* w, size_t vbytes) {
-  static const int trials = env_int("KS_PLACE_TRIALS", 8);
+  static const int trials = env_int("KS_PLACE_TRIALS", 40);
   // measured: +3 % at 3.3 GB, +1.5 % at 1.6 GB, nothing at 0.8 GB, -2 % at 0.4 GB (there the calibration, which
   // revisits the same columns, sees the memory-side cache more than the placement)
   static const int min_mb = env_int("KS_PLACE_MIN_MB", 1024);
+  static const int budget_ms = env_int("KS_PLACE_BUDGET_MS", 1500);
+  static const int debug = env_int("KS_PLACE_DEBUG", 0);
   if (trials <= 1 || vbytes < ((size_t)min_mb << 20)) return;
-  size_t free_b = 0, total_b = 0;
-  KS_HIP(hipMemGetInfo(&free_b, &total_b));
-  const int extra = (int)std::min<size_t>((size_t)trials - 1, free_b / 2 / vbytes);  // never take more than half of what is free
-  if (extra < 1) return;
   ks_ctx* c = w->ctx;
+  hipEvent_t a, b;
+  KS_HIP(hipEventCreate(&a));
+  KS_HIP(hipEventCreate(&b));
+  // Candidates are HELD until the search ends (a freed block would simply be handed out again).  The timings
+  // fall into clusters ~3 % apart that follow the position in physical memory: a freshly booted device hands
+  // out ~60 GB of the slowest kind first.  Stop as soon as a candidate beats the slowest one seen by 4.5 %
+  // (the gap between the outer clusters), when KS_PLACE_TRIALS candidates or KS_PLACE_BUDGET_MS are spent, or
+  // when another candidate would take more than half of the free memory.
   std::vector<void*> cand{w->V};
-  for (int k = 0; k < extra; ++k) {
+  size_t best = 0;
+  double best_ms = 1e30, worst_ms = 0.0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (size_t k = 0;; ++k) {
+    w->V = cand[k];
+    const double ms = placement_trio_ms<D>(w, a, b);
+    if (debug) std::fprintf(stderr, "[ks] placement candidate %zu @%p: %.3f ms\n", k, cand[k], ms);
+    if (ms < best_ms) { best_ms = ms; best = k; }
+    worst_ms = std::max(worst_ms, ms);
+    const double spent = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if ((int)cand.size() >= trials || spent > budget_ms) break;
+    if (cand.size() >= 4 && best_ms <= 0.955 * worst_ms) break;
+    size_t free_b = 0, total_b = 0;
+    KS_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (free_b / 2 < vbytes) break;
     void* p = nullptr;
     if (hipMalloc(&p, vbytes) != hipSuccess) { (void)hipGetLastError(); break; }
     KS_HIP(hipMemsetAsync(p, 0, vbytes, c->stream));
     cand.push_back(p);
-  }
-  hipEvent_t a, b;
-  KS_HIP(hipEventCreate(&a));
-  KS_HIP(hipEventCreate(&b));
-  size_t best = 0;
-  double best_ms = 1e30;
-  for (size_t k = 0; k < cand.size(); ++k) {
-    w->V = cand[k];
-    const double ms = placement_trio_ms<D>(w, a, b);
-    if (env_int("KS_PLACE_DEBUG", 0)) std::fprintf(stderr, "[ks] placement candidate %zu @%p: %.3f ms\n", k, cand[k], ms);
-    if (ms < best_ms) { best_ms = ms; best = k; }
   }
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);
   for (size_t k = 0; k < cand.size(); ++k)
     if (k != best) (void)hipFree(cand[k]);
   w->V = cand[best];
+  if (debug) std::fprintf(stderr, "[ks] placement: kept candidate %zu of %zu (%.3f ms, slowest %.3f ms)\n", best, cand.size(), best_ms, worst_ms);
   // the calibration wrote (zeros) into the scratch of the reductions only; V is still all zero
 }
 }  // namespace
