@@ -101,7 +101,9 @@ __device__ __forceinline__ void p2p_sum_wave(const P2pDev& p, int elem0, const d
       hi = ll_load(src + 1);
       if ((uint32_t)(lo >> 32) == seq && (uint32_t)(hi >> 32) == seq) break;
       if (p2p_expired(p, t0, spins++)) { lo = 0; hi = 0x7ff80000u; break; }  // NaN marks the failure
-      __builtin_amdgcn_s_sleep(1);
+      // (polling uncached memory goes out to the memory side every time: a little backoff keeps a thousand polling
+      // lanes from saturating the one or two channels the LL window lives in)
+      __builtin_amdgcn_s_sleep(3);
     }
     got = __longlong_as_double((long long)(((hi & 0xffffffffull) << 32) | (lo & 0xffffffffull)));
   }
