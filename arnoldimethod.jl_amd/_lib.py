@@ -135,7 +135,9 @@ def load():
             f"{LIB_PATH} is missing: the MI355X HIP library has not been built (run `python __graft_entry__.py build`). "
             "There is no CPU fallback for the product path."
         )
-    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    # default (RTLD_LOCAL) on purpose: with RTLD_GLOBAL the ROCm runtime's symbols interpose other extension
+    # modules of the process and the interpreter aborted at exit ("double free or corruption") in a GPU-less run
+    L = C.CDLL(LIB_PATH)
     L.ks_last_error_string.restype = C.c_char_p
     L.ks_last_error_string.argtypes = []
     for name, args in PROTOTYPES.items():
