@@ -476,6 +476,12 @@ class ArnoldiWorkspace:
         check(_lib.load().ks_arnoldi_relation(A._h, self._h, k, C.byref(r), C.byref(o)))
         return r.value, o.value
 
+    def guard_intact(self) -> bool:
+        """KS_GUARD=1 debugging: True unless a kernel wrote outside the basis."""
+        ok = C.c_int()
+        check(_lib.load().ks_workspace_check_guard(self._h, C.byref(ok)))
+        return bool(ok.value)
+
     def close(self):
         if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
             _lib.load().ks_workspace_destroy(self._h)

@@ -647,6 +647,8 @@ struct ks_workspace {
   int maxdim = 0;
   size_t esz = 8;
   void* V = nullptr;        // device, ld x (maxdim+1)
+  void* Vbase = nullptr;    // what hipFree gets: == V, or V - guard when KS_GUARD=1 put canary zones around the basis
+  size_t guard = 0, vbytes = 0;
   void* H = nullptr;        // pinned host, (maxdim+1) x maxdim
   void* Q = nullptr;        // pinned host, maxdim x maxdim
   void* Hd = nullptr;       // device mirror the expansion kernels write into
@@ -700,7 +702,7 @@ struct ks_workspace {
     return tmp2;
   }
   ~ks_workspace() {
-    (void)hipFree(colscale); (void)hipFree(V); (void)hipHostFree(H); (void)hipHostFree(Q); (void)hipFree(Hd); (void)hipHostFree(Hstage);
+    (void)hipFree(colscale); (void)hipFree(Vbase ? Vbase : V); (void)hipHostFree(H); (void)hipHostFree(Q); (void)hipFree(Hd); (void)hipHostFree(Hstage);
     (void)hipFree(Hscratch); (void)hipFree(partial); (void)hipFree(partial2); (void)hipFree(coef); (void)hipFree(red);
     (void)hipFree(scal); (void)hipHostFree(scal_h); (void)hipHostFree(coef_h); (void)hipFree(st);
     (void)hipHostFree(st_h); (void)hipFree(Qd); (void)hipHostFree(Qstage); (void)hipFree(tmp); (void)hipFree(tmp2);
@@ -1463,7 +1465,7 @@ template <class D> void tune_placement(ks_workspace* w, size_t vbytes) {
   static const int min_mb = env_int("KS_PLACE_MIN_MB", 1024);
   static const int budget_ms = env_int("KS_PLACE_BUDGET_MS", 1500);
   static const int debug = env_int("KS_PLACE_DEBUG", 0);
-  if (trials <= 1 || vbytes < ((size_t)min_mb << 20)) return;
+  if (trials <= 1 || vbytes < ((size_t)min_mb << 20) || w->guard) return;
   ks_ctx* c = w->ctx;
   hipEvent_t a, b;
   KS_HIP(hipEventCreate(&a));
@@ -1499,6 +1501,7 @@ template <class D> void tune_placement(ks_workspace* w, size_t vbytes) {
   for (size_t k = 0; k < cand.size(); ++k)
     if (k != best) (void)hipFree(cand[k]);
   w->V = cand[best];
+  w->Vbase = w->V;
   if (debug) std::fprintf(stderr, "[ks] placement: kept candidate %zu of %zu (%.3f ms, slowest %.3f ms)\n", best, cand.size(), best_ms, worst_ms);
   // the calibration wrote (zeros) into the scratch of the reductions only; V is still all zero
 }
@@ -1889,7 +1892,16 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     w->nb = cap_blocks(w.get(), w->pnb, 2 * kBlock);  // generic streaming grid
     const size_t esz = w->esz;
     const size_t vbytes = (size_t)w->ld * (maxdim + 1) * esz;
-    KS_HIP(hipMalloc(&w->V, vbytes));
+    w->vbytes = vbytes;
+    if (env_int("KS_GUARD", 0)) {  // debugging: 1 MiB of 0xA5 on both sides of V, verified by ks_workspace_check_guard
+      w->guard = (size_t)1 << 20;
+      KS_HIP(hipMalloc(&w->Vbase, vbytes + 2 * w->guard));
+      KS_HIP(hipMemsetAsync(w->Vbase, 0xA5, vbytes + 2 * w->guard, ctx->stream));
+      w->V = static_cast<char*>(w->Vbase) + w->guard;
+    } else {
+      KS_HIP(hipMalloc(&w->V, vbytes));
+      w->Vbase = w->V;
+    }
     KS_HIP(hipMemsetAsync(w->V, 0, vbytes, ctx->stream));
     const size_t hbytes = (size_t)(maxdim + 1) * maxdim * esz, qbytes = (size_t)maxdim * maxdim * esz;
     KS_HIP(hipHostMalloc(&w->H, hbytes));
@@ -1924,6 +1936,23 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     reset_state(w.get());
     KS_HIP(hipStreamSynchronize(ctx->stream));
     *out = w.release();
+  });
+}
+
+int ks_workspace_check_guard(ks_workspace* ws, int* intact) {
+  return guarded([&] {
+    KS_REQUIRE(ws && intact, KS_ERR_ARGUMENT, "null argument");
+    *intact = 1;
+    if (!ws->guard) return;
+    ws->ctx->use();
+    KS_HIP(hipStreamSynchronize(ws->ctx->stream));
+    std::vector<unsigned char> h(ws->guard);
+    for (int side = 0; side < 2; ++side) {
+      const char* src = static_cast<const char*>(ws->Vbase) + (side ? ws->guard + ws->vbytes : 0);
+      KS_HIP(hipMemcpy(h.data(), src, ws->guard, hipMemcpyDeviceToHost));
+      for (unsigned char b : h)
+        if (b != 0xA5) { *intact = 0; return; }
+    }
   });
 }
 

@@ -827,3 +827,33 @@ def test_large_workspace_goes_through_placement_tuning(monkeypatch):
     assert st["steps"] == 20 and st["breakdowns"] == 0
     rel, orth = ws.arnoldi_relation(op, 20)
     assert rel < 1e-10 * 12 * np.sqrt(20) and orth < 1e-13   # ||A V_k - V_{k+1} H||_F, ||V'V - I||_F
+
+
+# ------------------------------------------------------------------ no kernel writes outside the basis
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_no_writes_outside_the_basis(dtype, monkeypatch):
+    """KS_GUARD=1 surrounds V with canary zones.  Whole solves on awkward shapes (n not a multiple of anything,
+    ragged column counts, wide Krylov spaces, breakdown + reinitialize!, partialeigen, resume) must leave them
+    untouched."""
+    monkeypatch.setenv("KS_GUARD", "1")
+    rng = np.random.default_rng(77)
+    cplx = np.dtype(dtype).kind == "c"
+    for n, nev, mindim, maxdim in [(1237, 5, 11, 23), (4099, 7, 13, 41), (777, 12, 30, 61), (65, 3, 6, 13)]:
+        d = np.linspace(1, 9, n) + (0.3j * np.cos(np.arange(n)) if cplx else 0.0)
+        A = (sp.diags(d) + 0.05 * sprand(rng, dtype, n, min(0.02, 20.0 / n))).tocsr().astype(dtype)
+        ws = pkg.ArnoldiWorkspace(oa.uniform_hash(n, np.arange(n)).astype(dtype), maxdim)
+        F, hist = pkg.partialschur_(A, ws, nev=nev, which="LR", tol=1e-9, mindim=mindim, maxdim=maxdim, restarts=40)
+        vals, vecs = pkg.partialeigen(F)
+        assert ws.guard_intact(), (n, maxdim)
+        if hist.nconverged >= 1:
+            pkg.partialschur_(A, ws, nev=min(nev + 2, maxdim - 2), which="LR", tol=1e-9, mindim=mindim, maxdim=maxdim, restarts=5,
+                              start_from=hist.nconverged + 1)
+            assert ws.guard_intact(), ("resume", n, maxdim)
+    # breakdown path: block-diagonal operator, start vector in the small invariant subspace
+    n = 300
+    B = sp.block_diag([sp.diags(np.arange(1.0, 5.0)), sp.diags(np.linspace(10, 20, n - 4))]).tocsr().astype(dtype)
+    v1 = np.zeros(n, dtype=dtype)
+    v1[:4] = 1.0
+    ws = pkg.ArnoldiWorkspace(v1, 12)
+    pkg.partialschur_(B, ws, nev=3, which="LR", tol=1e-10, mindim=6, maxdim=12, restarts=20)
+    assert ws.guard_intact()
