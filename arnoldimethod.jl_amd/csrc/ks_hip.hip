@@ -1492,7 +1492,13 @@ template <class D> void tune_placement(ks_workspace* w, size_t vbytes) {
     KS_HIP(hipMemGetInfo(&free_b, &total_b));
     if (free_b / 2 < vbytes) break;
     void* p = nullptr;
-    if (hipMalloc(&p, vbytes) != hipSuccess) { (void)hipGetLastError(); break; }
+    // the second candidate asks for physically contiguous memory: consistently in the middle cluster (measured),
+    // which bounds the damage on a fresh device where everything else sampled within the budget may be slow
+    if (cand.size() == 1 && hipExtMallocWithFlags(&p, vbytes, hipDeviceMallocContiguous) != hipSuccess) {
+      (void)hipGetLastError();
+      p = nullptr;
+    }
+    if (!p && hipMalloc(&p, vbytes) != hipSuccess) { (void)hipGetLastError(); break; }
     KS_HIP(hipMemsetAsync(p, 0, vbytes, c->stream));
     cand.push_back(p);
   }

@@ -15,7 +15,12 @@ int main(int argc, char** argv) {
   const size_t vbytes = (size_t)ld * ncol * 8;
   const int K = argc > 1 ? atoi(argv[1]) : 8;
   std::vector<char*> bufs(K);
-  for (int k = 0; k < K; ++k) { CK(hipMalloc(&bufs[k], vbytes)); CK(hipMemset(bufs[k], 0, vbytes)); }
+  const int contig = argc > 3 ? atoi(argv[3]) : 0;  // 1: hipDeviceMallocContiguous for the odd-numbered buffers
+  for (int k = 0; k < K; ++k) {
+    if (contig && (k & 1)) { hipError_t e = hipExtMallocWithFlags((void**)&bufs[k], vbytes, hipDeviceMallocContiguous); if (e != hipSuccess) { printf("contiguous alloc failed: %s\n", hipGetErrorString(e)); CK(hipMalloc(&bufs[k], vbytes)); } }
+    else CK(hipMalloc(&bufs[k], vbytes));
+    CK(hipMemset(bufs[k], 0, vbytes));
+  }
   double *coef, *partial2, *partial;
   CK(hipMalloc(&coef, 1024)); CK(hipMemset(coef, 0, 1024));
   CK(hipMalloc(&partial2, 8 * 4096)); CK(hipMalloc(&partial, 8 * 4096 * 48));
