@@ -476,6 +476,13 @@ class ArnoldiWorkspace:
         check(_lib.load().ks_arnoldi_relation(A._h, self._h, k, C.byref(r), C.byref(o)))
         return r.value, o.value
 
+    @property
+    def placement(self) -> dict:
+        """Outcome of the placement search at creation: candidates timed, calibration ms of the kept / slowest one."""
+        k, b, w = C.c_int(), C.c_double(), C.c_double()
+        check(_lib.load().ks_workspace_placement(self._h, C.byref(k), C.byref(b), C.byref(w)))
+        return dict(candidates=k.value, kept_ms=b.value, slowest_ms=w.value)
+
     def guard_intact(self) -> bool:
         """KS_GUARD=1 debugging: True unless a kernel wrote outside the basis."""
         ok = C.c_int()

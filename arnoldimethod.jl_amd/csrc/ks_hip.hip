@@ -649,6 +649,8 @@ struct ks_workspace {
   void* V = nullptr;        // device, ld x (maxdim+1)
   void* Vbase = nullptr;    // what hipFree gets: == V, or V - guard when KS_GUARD=1 put canary zones around the basis
   size_t guard = 0, vbytes = 0;
+  int place_candidates = 0;     // placement search of ks_workspace_create: candidates timed, fastest / slowest calibration time
+  double place_best_ms = 0.0, place_worst_ms = 0.0;
   void* H = nullptr;        // pinned host, (maxdim+1) x maxdim
   void* Q = nullptr;        // pinned host, maxdim x maxdim
   void* Hd = nullptr;       // device mirror the expansion kernels write into
@@ -1508,6 +1510,9 @@ template <class D> void tune_placement(ks_workspace* w, size_t vbytes) {
     if (k != best) (void)hipFree(cand[k]);
   w->V = cand[best];
   w->Vbase = w->V;
+  w->place_candidates = (int)cand.size();
+  w->place_best_ms = best_ms;
+  w->place_worst_ms = worst_ms;
   if (debug) std::fprintf(stderr, "[ks] placement: kept candidate %zu of %zu (%.3f ms, slowest %.3f ms)\n", best, cand.size(), best_ms, worst_ms);
   // the calibration wrote (zeros) into the scratch of the reductions only; V is still all zero
 }
@@ -1942,6 +1947,15 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     reset_state(w.get());
     KS_HIP(hipStreamSynchronize(ctx->stream));
     *out = w.release();
+  });
+}
+
+int ks_workspace_placement(const ks_workspace* ws, int* candidates, double* best_ms, double* worst_ms) {
+  return guarded([&] {
+    KS_REQUIRE(ws, KS_ERR_ARGUMENT, "null workspace");
+    if (candidates) *candidates = ws->place_candidates;
+    if (best_ms) *best_ms = ws->place_best_ms;
+    if (worst_ms) *worst_ms = ws->place_worst_ms;
   });
 }
 

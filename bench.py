@@ -144,6 +144,7 @@ def main():
             ctx, op, ws, v1, nnz_global = ksdist.setup_laplace3d(pkg, dist, m, maxdim, local_rank, transport)
             A_host = None
         fmt = op.format
+        placement = ws.placement
         ws.reinitialize(0, v1)
         ws.iterate_arnoldi(op, 1, mindim)  # initial expansion, src/run.jl:267 (untimed)
 
@@ -201,7 +202,7 @@ def main():
         ws.close()
         op.close()
         ctx.close()
-        return dict(elapsed=elapsed, state=state, prof=prof, nnz_global=nnz_global, A_host=A_host, fmt=fmt)
+        return dict(elapsed=elapsed, state=state, prof=prof, nnz_global=nnz_global, A_host=A_host, fmt=fmt, placement=placement)
 
     # N > 1: the row-partitioned solver has two transports for its per-step exchanges -- RCCL collectives
     # and the library's own peer-to-peer regions over xGMI (csrc/ks_p2p.hpp).  Both are measured with the
@@ -266,6 +267,7 @@ def main():
                                 passes[chosen]["fmt"]["bytes_per_nnz"], "csr: 12 B per non-zero%.0s") % passes[chosen]["fmt"]["ndict"],
         },
     }
+    out["config"]["basis_placement"] = passes[chosen]["placement"]  # placement search of the workspace
     if chosen != "single":
         out["config"]["transport"] = chosen
         out["transports"] = {
