@@ -187,6 +187,22 @@ class Operator:
             pass
 
 
+def _check_op(rc: int, op):
+    """`check(rc)` for calls that may run a Python operator callback: an exception raised inside the callback
+    cannot cross the C ABI (the callback returns 1 -> KS_ERR_OPERATOR); re-raise THAT exception here instead
+    of the generic library error, chained to it."""
+    errs = getattr(op, "errors", None)
+    if errs:
+        e = errs.pop(0)
+        del errs[:]
+        try:
+            check(rc)
+        except Exception as lib_err:  # noqa: BLE001
+            raise e from lib_err
+        raise e
+    check(rc)
+
+
 def csr_operator(A, ctx: Context | None = None) -> Operator:
     """Device CSR operand from a scipy.sparse matrix (CSR or CSC; CSC is what Julia hands over) or a
     dense ndarray.  Integer/bool matrices are promoted like `vtype` does (test/partial_schur.jl:41-45)."""
@@ -409,7 +425,7 @@ class ArnoldiWorkspace:
         check(_lib.load().ks_col_copy(self._h, dst, src))
 
     def apply(self, A: Operator, jsrc: int, jdst: int):
-        check(_lib.load().ks_apply(A._h, self._h, jsrc, jdst))
+        _check_op(_lib.load().ks_apply(A._h, self._h, jsrc, jdst), A)
 
     def gemv_t(self, j: int, jv: int) -> np.ndarray:
         h = np.empty(j, dtype=self.dtype)
@@ -449,7 +465,7 @@ class ArnoldiWorkspace:
 
     def iterate_arnoldi(self, A: Operator, frm: int, to: int):
         st = _lib.ks_expand_stats()
-        check(_lib.load().ks_iterate_arnoldi(A._h, self._h, frm, to, C.byref(st)))
+        _check_op(_lib.load().ks_iterate_arnoldi(A._h, self._h, frm, to, C.byref(st)), A)
         return dict(steps=st.steps, reorth=st.reorth, breakdowns=st.breakdowns)
 
     def restart(self, active: int, nev: int, which="LM", tol=None, mindim=None, maxdim=None):
@@ -468,20 +484,20 @@ class ArnoldiWorkspace:
 
     def residual_norms(self, A: Operator, ncols: int):
         r, o = C.c_double(), C.c_double()
-        check(_lib.load().ks_residual_norms(A._h, self._h, ncols, C.byref(r), C.byref(o)))
+        _check_op(_lib.load().ks_residual_norms(A._h, self._h, ncols, C.byref(r), C.byref(o)), A)
         return r.value, o.value
 
     def arnoldi_relation(self, A: Operator, k: int):
         r, o = C.c_double(), C.c_double()
-        check(_lib.load().ks_arnoldi_relation(A._h, self._h, k, C.byref(r), C.byref(o)))
+        _check_op(_lib.load().ks_arnoldi_relation(A._h, self._h, k, C.byref(r), C.byref(o)), A)
         return r.value, o.value
 
     @property
     def placement(self) -> dict:
         """Outcome of the placement search at creation: candidates timed, calibration ms of the kept / slowest one."""
-        k, b, w = C.c_int(), C.c_double(), C.c_double()
-        check(_lib.load().ks_workspace_placement(self._h, C.byref(k), C.byref(b), C.byref(w)))
-        return dict(candidates=k.value, kept_ms=b.value, slowest_ms=w.value)
+        k, b, w, r = C.c_int(), C.c_double(), C.c_double(), C.c_int()
+        check(_lib.load().ks_workspace_placement(self._h, C.byref(k), C.byref(b), C.byref(w), C.byref(r)))
+        return dict(candidates=k.value, kept_ms=b.value, slowest_ms=w.value, refused=r.value)
 
     def guard_intact(self) -> bool:
         """KS_GUARD=1 debugging: True unless a kernel wrote outside the basis."""
@@ -556,9 +572,7 @@ def _run(op: Operator, ws: ArnoldiWorkspace, nev, which, tol, mindim, maxdim, re
     if v1 is not None:
         v1 = np.ascontiguousarray(np.asarray(v1, dtype=ws.dtype))
         v1p = v1.ctypes.data
-    check(L.ks_partialschur(op._h, ws._h, C.byref(p), v1p, eig.ctypes.data, C.byref(h)))
-    if getattr(op, "errors", None):
-        raise op.errors[0]
+    _check_op(L.ks_partialschur(op._h, ws._h, C.byref(p), v1p, eig.ctypes.data, C.byref(h)), op)
     lam = (eig[0::2] + 1j * eig[1::2])[: h.nconverged].copy()
     hist = History(h.mvproducts, h.nconverged, bool(h.converged), h.nev, h.restarts, h.reorth, h.breakdowns,
                    h.seconds_expand, h.seconds_host, h.seconds_rotate)

@@ -462,6 +462,20 @@ void build_csr_host(int64_t nrows, int64_t ncols, int64_t nnz, const void* ptr, 
   auto J = [&](int64_t i) { return (itype == KS_I32 ? idx_at<int32_t>(idx, i) : idx_at<int64_t>(idx, i)) - base; };
   const D* v = static_cast<const D*>(val);
   KS_REQUIRE(nnz < (int64_t)2147483647, KS_ERR_ARGUMENT, "nnz must fit int32");
+  KS_REQUIRE(nrows < (int64_t)2147483647 && ncols < (int64_t)2147483647, KS_ERR_ARGUMENT, "matrix order must fit int32");
+  {
+    // the pointer array must be monotone and stay inside [0, nnz]: a malformed one would index host (CSC
+    // conversion) or device (SpMV) arrays out of bounds
+    const int64_t np = (layout == KS_CSR ? nrows : ncols);
+    int64_t prev = P(0);
+    KS_REQUIRE(prev == 0, KS_ERR_ARGUMENT, layout == KS_CSR ? "row pointer does not match nnz" : "column pointer does not match nnz");
+    for (int64_t i = 1; i <= np; ++i) {
+      const int64_t cur = P(i);
+      KS_REQUIRE(cur >= prev && cur <= nnz, KS_ERR_ARGUMENT, "pointer array is not monotone within [0, nnz]");
+      prev = cur;
+    }
+    KS_REQUIRE(prev == nnz, KS_ERR_ARGUMENT, layout == KS_CSR ? "row pointer does not match nnz" : "column pointer does not match nnz");
+  }
   rp.assign(nrows + 1, 0);
   ci.resize(nnz);
   vv.resize(nnz);
@@ -649,6 +663,7 @@ struct ks_workspace {
   void* V = nullptr;        // device, ld x (maxdim+1)
   void* Vbase = nullptr;    // what hipFree gets: == V, or V - guard when KS_GUARD=1 put canary zones around the basis
   size_t guard = 0, vbytes = 0;
+  int place_failed = 0;         // candidate allocations the search was refused
   int place_candidates = 0;     // placement search of ks_workspace_create: candidates timed, fastest / slowest calibration time
   double place_best_ms = 0.0, place_worst_ms = 0.0;
   void* H = nullptr;        // pinned host, (maxdim+1) x maxdim
@@ -825,87 +840,44 @@ template <class D> void launch_fin_norm(ks_workspace* ws, int nbp, int j, D* Hsu
   }
 }
 
-// fused first projection + second-pass inner products (Float64, j <= 40); returns workgroups used
-template <int NC4, int RPL> int axpy_dots_blocks(ks_workspace* ws) {
+// fused first projection + second-pass inner products (k_axpy_dots_cs, j <= 64); returns workgroups used.
+// NCW = ceil(j/4) columns per wave; U packs per lane and iteration: 4 up to NCW = 10, 2 above (register budget).
+constexpr int kFusedMaxJ = 64;
+template <class D, int NCW, int U, int WB> int launch_axpy_dots_nc(ks_workspace* ws, int j, D* w, int defer) {
   static int cache = -1;
-  return resident_blocks(ws->ctx, ksd::k_axpy_dots<NC4, RPL>, 0, cache);
-}
-template <int NC4, int RPL> int launch_axpy_dots_nc(ks_workspace* ws, int j, double* w) {
-  const int nb = axpy_dots_blocks<NC4, RPL>(ws);
-  ksd::k_axpy_dots<NC4, RPL><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const double*>(ws->V), ws->ld, j, w,
-                                                              static_cast<const double*>(ws->coef),
-                                                              static_cast<double*>(ws->partial), ws->pnb, ws->partial2, ws->st);
+  const int nb = cap_blocks(ws, resident_blocks(ws->ctx, ksd::k_axpy_dots_cs<D, NCW, U, WB>, 0, cache), 64 * U);
+  ksd::k_axpy_dots_cs<D, NCW, U, WB><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const D*>(ws->V), ws->ld, j, w,
+                                                                       static_cast<const D*>(ws->coef),
+                                                                       static_cast<D*>(ws->partial), ws->pnb, ws->partial2,
+                                                                       ws->st, defer);
   return nb;
 }
-template <int NCW, int U, int WB> int launch_axpy_dots_cswb_nc(ks_workspace* ws, int j, double* w, int defer) {
-  static int cache = -1;
-  const int nb = cap_blocks(ws, resident_blocks(ws->ctx, ksd::k_axpy_dots_cs<NCW, U, true, 1, WB>, 0, cache), 64 * U);
-  ksd::k_axpy_dots_cs<NCW, U, true, 1, WB><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const double*>(ws->V), ws->ld, j, w,
-                                                                            static_cast<const double*>(ws->coef),
-                                                                            static_cast<double*>(ws->partial), ws->pnb, ws->partial2,
-                                                                            ws->st, defer);
-  return nb;
-}
-template <int U, int WB> int launch_axpy_dots_cswb(ks_workspace* ws, int j, double* w, int defer) {
+template <class D> int launch_axpy_dots(ks_workspace* ws, int j, D* w, int defer) {
+  KS_REQUIRE(j >= 1 && j <= kFusedMaxJ, KS_ERR_INTERNAL, "fused projection kernel covers 1 <= j <= 64");
   switch ((j + 3) / 4) {
-    case 1: return launch_axpy_dots_cswb_nc<1, U, WB>(ws, j, w, defer);
-    case 2: return launch_axpy_dots_cswb_nc<2, U, WB>(ws, j, w, defer);
-    case 3: return launch_axpy_dots_cswb_nc<3, U, WB>(ws, j, w, defer);
-    case 4: return launch_axpy_dots_cswb_nc<4, U, WB>(ws, j, w, defer);
-    case 5: return launch_axpy_dots_cswb_nc<5, U, WB>(ws, j, w, defer);
-    case 6: return launch_axpy_dots_cswb_nc<6, U, WB>(ws, j, w, defer);
-    case 7: return launch_axpy_dots_cswb_nc<7, U, WB>(ws, j, w, defer);
-    case 8: return launch_axpy_dots_cswb_nc<8, U, WB>(ws, j, w, defer);
-    case 9: return launch_axpy_dots_cswb_nc<9, U, WB>(ws, j, w, defer);
-    default: return launch_axpy_dots_cswb_nc<10, U, WB>(ws, j, w, defer);
-  }
-}
-template <int NCW, int U> int launch_axpy_dots_cs_nc(ks_workspace* ws, int j, double* w, int defer) {
-  static int cache = -1;
-  const int nb = cap_blocks(ws, resident_blocks(ws->ctx, ksd::k_axpy_dots_cs<NCW, U>, 0, cache), 64 * U);
-  ksd::k_axpy_dots_cs<NCW, U><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const double*>(ws->V), ws->ld, j, w,
-                                                               static_cast<const double*>(ws->coef),
-                                                               static_cast<double*>(ws->partial), ws->pnb, ws->partial2, ws->st,
-                                                               defer);
-  return nb;
-}
-template <int U> int launch_axpy_dots_cs(ks_workspace* ws, int j, double* w, int defer) {
-  switch ((j + 3) / 4) {
-    case 1: return launch_axpy_dots_cs_nc<1, U>(ws, j, w, defer);
-    case 2: return launch_axpy_dots_cs_nc<2, U>(ws, j, w, defer);
-    case 3: return launch_axpy_dots_cs_nc<3, U>(ws, j, w, defer);
-    case 4: return launch_axpy_dots_cs_nc<4, U>(ws, j, w, defer);
-    case 5: return launch_axpy_dots_cs_nc<5, U>(ws, j, w, defer);
-    case 6: return launch_axpy_dots_cs_nc<6, U>(ws, j, w, defer);
-    case 7: return launch_axpy_dots_cs_nc<7, U>(ws, j, w, defer);
-    case 8: return launch_axpy_dots_cs_nc<8, U>(ws, j, w, defer);
-    case 9: return launch_axpy_dots_cs_nc<9, U>(ws, j, w, defer);
-    default: return launch_axpy_dots_cs_nc<10, U>(ws, j, w, defer);
-  }
-}
-inline int launch_axpy_dots(ks_workspace* ws, int j, double* w, int defer = 0) {
-  static const int variant = env_int("KS_FUSED_VARIANT", 48);  // 0: per-lane columns, 1: column split U=1, 2: U=2
-  if (variant == 1 || (defer && variant == 0)) return launch_axpy_dots_cs<1>(ws, j, w, defer);
-  if (variant == 2) return launch_axpy_dots_cs<2>(ws, j, w, defer);
-  if (variant == 4) return launch_axpy_dots_cs<4>(ws, j, w, defer);
-  if (variant == 48) return launch_axpy_dots_cswb<4, 8>(ws, j, w, defer);   // U = 4, write-back every 8 tiles (32 KiB bursts)
-  KS_REQUIRE(!defer, KS_ERR_INTERNAL, "per-lane fused variant does not support deferred normalisation");
-  switch ((j + 3) / 4) {
-    case 1: return launch_axpy_dots_nc<1, 2>(ws, j, w);
-    case 2: return launch_axpy_dots_nc<2, 2>(ws, j, w);
-    case 3: return launch_axpy_dots_nc<3, 2>(ws, j, w);
-    case 4: return launch_axpy_dots_nc<4, 2>(ws, j, w);
-    case 5: return launch_axpy_dots_nc<5, 2>(ws, j, w);
-    case 6: return launch_axpy_dots_nc<6, 1>(ws, j, w);
-    case 7: return launch_axpy_dots_nc<7, 1>(ws, j, w);
-    case 8: return launch_axpy_dots_nc<8, 1>(ws, j, w);
-    case 9: return launch_axpy_dots_nc<9, 1>(ws, j, w);
-    default: return launch_axpy_dots_nc<10, 1>(ws, j, w);
+    case 1: return launch_axpy_dots_nc<D, 1, 4, 8>(ws, j, w, defer);
+    case 2: return launch_axpy_dots_nc<D, 2, 4, 8>(ws, j, w, defer);
+    case 3: return launch_axpy_dots_nc<D, 3, 4, 8>(ws, j, w, defer);
+    case 4: return launch_axpy_dots_nc<D, 4, 4, 8>(ws, j, w, defer);
+    case 5: return launch_axpy_dots_nc<D, 5, 4, 8>(ws, j, w, defer);
+    case 6: return launch_axpy_dots_nc<D, 6, 4, 8>(ws, j, w, defer);
+    case 7: return launch_axpy_dots_nc<D, 7, 4, 8>(ws, j, w, defer);
+    case 8: return launch_axpy_dots_nc<D, 8, 4, 8>(ws, j, w, defer);
+    case 9: return launch_axpy_dots_nc<D, 9, 4, 8>(ws, j, w, defer);
+    case 10: return launch_axpy_dots_nc<D, 10, 4, 8>(ws, j, w, defer);
+    case 11: return launch_axpy_dots_nc<D, 11, 2, 8>(ws, j, w, defer);
+    case 12: return launch_axpy_dots_nc<D, 12, 2, 8>(ws, j, w, defer);
+    case 13: return launch_axpy_dots_nc<D, 13, 2, 8>(ws, j, w, defer);
+    case 14: return launch_axpy_dots_nc<D, 14, 2, 8>(ws, j, w, defer);
+    case 15: return launch_axpy_dots_nc<D, 15, 2, 8>(ws, j, w, defer);
+    default: return launch_axpy_dots_nc<D, 16, 2, 8>(ws, j, w, defer);
   }
 }
 
-// Enqueue orthogonalize!(arnoldi, j) (src/expansion.jl:69-109) entirely on the device: two DGKS
-// passes (the second one skips itself unless the first requested it), H column into Hd, v ./= wnorm.
+// Enqueue orthogonalize!(arnoldi, j) (src/expansion.jl:69-109) entirely on the device, EAGER form (maxdim > 64, or
+// KS_NO_DEFER=1 for debugging): two un-fused DGKS passes (the second one skips itself unless the first requested
+// it), H column into Hd, v ./= wnorm.  Four passes over V plus the scaling pass; everything up to maxdim = 64
+// takes the fused, lazily normalised path below instead.
 template <class D> void enqueue_orthogonalize(ks_workspace* ws, int j) {
   hipStream_t s = ws->ctx->stream;
   D* w = static_cast<D*>(ws->col(j));
@@ -914,73 +886,23 @@ template <class D> void enqueue_orthogonalize(ks_workspace* ws, int j) {
   D* Hcol = Hd + (size_t)(j - 1) * ldh;
   const D* V = static_cast<const D*>(ws->V);
   const double nb8 = (double)ws->n * sizeof(D);  // bytes of one column
-  const bool fused = sizeof(D) == 8 && j <= 40 && env_int("KS_NO_FUSE", 0) == 0;
-  if constexpr (sizeof(D) == 8) {
-    if (fused) {
-      // pass 1 inner products
-      int nbd;
-      {
-        ProfScope ps(ws->ctx, KSP_DOTS, nb8 * (j + 1));
-        nbd = launch_dots<D>(ws, j, w, 1, ws->st);
-      }
-      {
-        ProfScope ps(ws->ctx, KSP_FIN, 0.0);
-        launch_fin_dots<D>(ws, nbd, j, Hcol, 1, ws->st);
-      }
-      // pass 1 projection + (speculative) pass 2 inner products: V is read once for both.
-      // per-kernel roofline bytes = what the fused op must move (read V[:,0:j) and w, write w); the
-      // un-fused pair it replaces would move (j+2) + (j+1) columns -- that gain shows up in the
-      // fused-step figure of bench.py, not here.
-      int nbf;
-      {
-        ProfScope ps(ws->ctx, KSP_FUSED, nb8 * (j + 2));
-        nbf = launch_axpy_dots(ws, j, w);
-      }
-      {
-        // one reduction stage (one all-reduce of j+1 doubles when distributed) for |w'|^2 AND c
-        ProfScope ps(ws->ctx, KSP_FIN, 0.0);
-        ks_ctx* cx = ws->ctx;
-        double* red = reinterpret_cast<double*>(ws->red);
-        const double* part = reinterpret_cast<const double*>(ws->partial);
-        double* Hc = reinterpret_cast<double*>(Hcol);
-        double* cf = reinterpret_cast<double*>(ws->coef);
-        if (!cx->distributed()) {
-          ksd::k_fin_mid<<<j + 1, kBlock, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hc, cf, 0, ws->st);
-        } else {
-          ksd::k_fin_mid<<<j + 1, kBlock, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hc, cf, 1, ws->st);
-          cx->allreduce(red, j + 1);
-          ksd::k_fin_mid<<<j + 1, 64, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hc, cf, 2, ws->st);
-        }
-      }
-      {
-        ProfScope ps(ws->ctx, KSP_AXPY, nb8 * (j + 2));
-        ksd::k_axpy<D><<<ws->nb, kBlock, 0, s>>>(V, ws->ld, j, w, static_cast<const D*>(ws->coef), ws->partial2, 2, ws->st);
-      }
-      {
-        ProfScope ps(ws->ctx, KSP_FIN, 0.0);
-        launch_fin_norm<D>(ws, ws->nb, j, Hcol + j, 2, ws->st);
-      }
+  for (int pass = 1; pass <= 2; ++pass) {
+    int nbd;
+    {
+      ProfScope ps(ws->ctx, KSP_DOTS, nb8 * (j + 1));       // read V[:,0:j) and w
+      nbd = launch_dots<D>(ws, j, w, pass, ws->st);
     }
-  }
-  if (!fused) {
-    for (int pass = 1; pass <= 2; ++pass) {
-      int nbd;
-      {
-        ProfScope ps(ws->ctx, KSP_DOTS, nb8 * (j + 1));       // read V[:,0:j) and w
-        nbd = launch_dots<D>(ws, j, w, pass, ws->st);
-      }
-      {
-        ProfScope ps(ws->ctx, KSP_FIN, 0.0);
-        launch_fin_dots<D>(ws, nbd, j, Hcol, pass, ws->st);
-      }
-      {
-        ProfScope ps(ws->ctx, KSP_AXPY, nb8 * (j + 2));       // read V[:,0:j), read + write w
-        ksd::k_axpy<D><<<ws->nb, kBlock, 0, s>>>(V, ws->ld, j, w, static_cast<const D*>(ws->coef), ws->partial2, pass, ws->st);
-      }
-      {
-        ProfScope ps(ws->ctx, KSP_FIN, 0.0);
-        launch_fin_norm<D>(ws, ws->nb, j, Hcol + j, pass, ws->st);
-      }
+    {
+      ProfScope ps(ws->ctx, KSP_FIN, 0.0);
+      launch_fin_dots<D>(ws, nbd, j, Hcol, pass, ws->st);
+    }
+    {
+      ProfScope ps(ws->ctx, KSP_AXPY, nb8 * (j + 2));       // read V[:,0:j), read + write w
+      ksd::k_axpy<D><<<ws->nb, kBlock, 0, s>>>(V, ws->ld, j, w, static_cast<const D*>(ws->coef), ws->partial2, pass, ws->st);
+    }
+    {
+      ProfScope ps(ws->ctx, KSP_FIN, 0.0);
+      launch_fin_norm<D>(ws, ws->nb, j, Hcol + j, pass, ws->st);
     }
   }
   {
@@ -1003,18 +925,19 @@ inline void reset_lazy(ks_workspace* ws) {
 inline void materialize(ks_workspace* ws) {
   if (!ws->has_lazy()) return;
   for (int c = ws->lazy_lo; c <= ws->lazy_hi; ++c)
-    if (ws->hostscale[c] != 1.0)
-      ksd::k_scale<double><<<ws->nb, kBlock, 0, ws->ctx->stream>>>(static_cast<double*>(ws->col(c)), ws->ld, ws->hostscale[c], nullptr);
+    if (ws->hostscale[c] != 1.0) {
+      if (ws->dtype == KS_F64) ksd::k_scale<double><<<ws->nb, kBlock, 0, ws->ctx->stream>>>(static_cast<double*>(ws->col(c)), ws->ld, ws->hostscale[c], nullptr);
+      else ksd::k_scale<cd><<<ws->nb, kBlock, 0, ws->ctx->stream>>>(static_cast<cd*>(ws->col(c)), ws->ld, ws->hostscale[c], nullptr);
+    }
   KS_HIP(hipGetLastError());
   reset_lazy(ws);
 }
 
-// Fused Float64 expansion steps from..to with LAZY NORMALISATION (see ks_kernels.hpp): per step
+// Fused expansion steps from..to with LAZY NORMALISATION (see ks_kernels.hpp; Float64 and ComplexF64, to <= 64): per step
 //   SpMV -> DOTS -> FIN_DOTS_DEF -> AXPY+DOTS -> FIN_MID_DEF -> AXPY
 // (6 launches, 2 reductions, 3 passes over V, no v ./= wnorm pass) and one FIN_PEND at the end of the batch.  `op` may be null
 // (ks_orthogonalize: the column is already there).
-inline void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op, int from, int to) {
-  using D = double;
+template <class D> void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op, int from, int to) {
   ks_ctx* cx = ws->ctx;
   hipStream_t s = cx->stream;
   const int ldh = ws->maxdim + 1;
@@ -1023,11 +946,12 @@ inline void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op, int from, 
   D* red = static_cast<D*>(ws->red);
   D* coef = static_cast<D*>(ws->coef);
   const D* part = static_cast<const D*>(ws->partial);
+  double* redd = reinterpret_cast<double*>(ws->red);
+  constexpr int dpe = (int)(sizeof(D) / 8);  // doubles per element (all-reduce counts)
   const double nb8 = (double)ws->n * sizeof(D);
   const bool dist = cx->distributed();
   // peer-to-peer: exchange folded into the reduction kernels (mode 3).  KS_P2P_NO_FOLD=1 keeps the three-launch
-  // structure of the RCCL transport (reduce -> all-reduce -> post) on the peer-to-peer all-reduce kernel, which
-  // is how that structure is exercised with several real ranks on a one-GPU box.
+  // structure of the collective transports (reduce -> all-reduce -> post) on the peer-to-peer all-reduce kernel.
   static const int no_fold = env_int("KS_P2P_NO_FOLD", 0);
   const bool p2p = cx->p2p.attached && !no_fold;
   const ksd::P2pDev pd = cx->p2p.dev;
@@ -1044,33 +968,33 @@ inline void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op, int from, 
     {
       ProfScope ps(cx, KSP_FIN, 0.0);
       if (!dist || p2p) {
-        ksd::k_fin_dots_def<<<j + 1, kBlock, 0, s>>>(part, nbd, ws->pnb, ws->partial2, ws->nb, j, red, Hcol, Hsub_prev, coef, ws->colscale, p2p ? 3 : 0, ws->st, pd);
+        ksd::k_fin_dots_def<D><<<j + 1, kBlock, 0, s>>>(part, nbd, ws->pnb, ws->partial2, ws->nb, j, red, Hcol, Hsub_prev, coef, ws->colscale, p2p ? 3 : 0, ws->st, pd);
       } else {
-        ksd::k_fin_dots_def<<<j + 2, kBlock, 0, s>>>(part, nbd, ws->pnb, ws->partial2, ws->nb, j, red, Hcol, Hsub_prev, coef, ws->colscale, 1, ws->st, pd);
-        cx->allreduce(red, j + 2);
-        ksd::k_fin_dots_def<<<j + 1, 64, 0, s>>>(part, nbd, ws->pnb, ws->partial2, ws->nb, j, red, Hcol, Hsub_prev, coef, ws->colscale, 2, ws->st, pd);
+        ksd::k_fin_dots_def<D><<<j + 2, kBlock, 0, s>>>(part, nbd, ws->pnb, ws->partial2, ws->nb, j, red, Hcol, Hsub_prev, coef, ws->colscale, 1, ws->st, pd);
+        cx->allreduce(redd, (j + 2) * dpe);
+        ksd::k_fin_dots_def<D><<<j + 1, 64, 0, s>>>(part, nbd, ws->pnb, ws->partial2, ws->nb, j, red, Hcol, Hsub_prev, coef, ws->colscale, 2, ws->st, pd);
       }
     }
     int nbf;
     {
       ProfScope ps(cx, KSP_FUSED, nb8 * (j + 2));  // reads V[:,0:j) and y, writes w'
-      nbf = launch_axpy_dots(ws, j, w, 1);
+      nbf = launch_axpy_dots<D>(ws, j, w, 1);
     }
     {
       ProfScope ps(cx, KSP_FIN, 0.0);
       if (!dist || p2p) {
-        ksd::k_fin_mid_def<<<j + 1, kBlock, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hcol, coef, ws->colscale, p2p ? 3 : 0, ws->st, pd);
+        ksd::k_fin_mid_def<D><<<j + 1, kBlock, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hcol, coef, ws->colscale, p2p ? 3 : 0, ws->st, pd);
       } else {
-        ksd::k_fin_mid_def<<<j + 1, kBlock, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hcol, coef, ws->colscale, 1, ws->st, pd);
-        cx->allreduce(red, j + 1);
-        ksd::k_fin_mid_def<<<j + 1, 64, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hcol, coef, ws->colscale, 2, ws->st, pd);
+        ksd::k_fin_mid_def<D><<<j + 1, kBlock, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hcol, coef, ws->colscale, 1, ws->st, pd);
+        cx->allreduce(redd, (j + 1) * dpe);
+        ksd::k_fin_mid_def<D><<<j + 1, 64, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hcol, coef, ws->colscale, 2, ws->st, pd);
       }
     }
     {
       ProfScope ps(cx, KSP_AXPY, nb8 * (j + 2));
       // packs per lane per iteration: at n = 1e7 going 2 -> 4 -> 8 gained 3 % + 8 % (16 lost 18 %); small
       // problems (<= 3072 packs per workgroup) are ~1 % better off with 4
-      const int64_t ppb = (ws->ld / 2) / std::max(1, ws->nb);
+      const int64_t ppb = (ws->ld * (int64_t)sizeof(D) / 16) / std::max(1, ws->nb);
       if (ppb >= 3072) ksd::k_axpy<D, 8><<<ws->nb, kBlock, 0, s>>>(V, ws->ld, j, w, coef, ws->partial2, 2, ws->st);
       else ksd::k_axpy<D, 4><<<ws->nb, kBlock, 0, s>>>(V, ws->ld, j, w, coef, ws->partial2, 2, ws->st);
     }
@@ -1078,11 +1002,11 @@ inline void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op, int from, 
       {
         ProfScope ps(cx, KSP_FIN, 0.0);
         if (!dist || p2p) {
-          ksd::k_fin_pend<<<1, kBlock, 0, s>>>(ws->partial2, ws->nb, red, Hcol + j, j, ws->colscale, p2p ? 3 : 0, ws->st, pd);
+          ksd::k_fin_pend<D><<<1, kBlock, 0, s>>>(ws->partial2, ws->nb, redd, Hcol + j, j, ws->colscale, p2p ? 3 : 0, ws->st, pd);
         } else {
-          ksd::k_fin_pend<<<1, kBlock, 0, s>>>(ws->partial2, ws->nb, red, Hcol + j, j, ws->colscale, 1, ws->st, pd);
-          cx->allreduce(red, 1);
-          ksd::k_fin_pend<<<1, 64, 0, s>>>(ws->partial2, ws->nb, red, Hcol + j, j, ws->colscale, 2, ws->st, pd);
+          ksd::k_fin_pend<D><<<1, kBlock, 0, s>>>(ws->partial2, ws->nb, redd, Hcol + j, j, ws->colscale, 1, ws->st, pd);
+          cx->allreduce(redd, 1);
+          ksd::k_fin_pend<D><<<1, 64, 0, s>>>(ws->partial2, ws->nb, redd, Hcol + j, j, ws->colscale, 2, ws->st, pd);
         }
       }
     }
@@ -1092,7 +1016,7 @@ inline void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op, int from, 
 
 inline bool use_deferred(const ks_workspace* ws, int to) {
   static const int no_fuse = env_int("KS_NO_FUSE", 0), no_defer = env_int("KS_NO_DEFER", 0);
-  return ws->dtype == KS_F64 && to <= 40 && !no_fuse && !no_defer;
+  return to <= kFusedMaxJ && !no_fuse && !no_defer;
 }
 
 inline void reset_state(ks_workspace* ws) {
@@ -1292,6 +1216,20 @@ template <class T> struct HipBackend : ks::Backend<T> {
   int64_t n_global() const override { return ws->n_global; }
 
   void iterate_arnoldi(int from, int to, const ks::Mat<T>& H, ks::ExpandStats& stats) override {
+    try {
+      iterate_arnoldi_impl(from, to, H, stats);
+    } catch (...) {
+      // an operator callback (or a HIP / transport error) aborted a batch midway: steps were enqueued whose H columns
+      // and lazy-normalisation factors were never fetched.  Drain the stream and return the bookkeeping to "every
+      // column is ordinary"; the factorisation itself is undefined from here on -- the caller must re-initialise
+      // (ks_reinitialize(ws, 0, ...) or ks_partialschur with initialize = 1) before using the workspace again.
+      (void)hipStreamSynchronize(ws->ctx->stream);
+      try { reset_lazy(ws); } catch (...) {}
+      throw;
+    }
+  }
+
+  void iterate_arnoldi_impl(int from, int to, const ks::Mat<T>& H, ks::ExpandStats& stats) {
     ws->ctx->use();
     int j0 = from;
     while (j0 <= to) {
@@ -1300,7 +1238,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
       if (!op->async_capable) jend = j0;  // host operators: one step per batch
       const bool lazy = use_deferred(ws, jend);
       if (lazy) {
-        enqueue_steps_deferred(ws, op, j0, jend);
+        enqueue_steps_deferred<D>(ws, op, j0, jend);
       } else {
         materialize(ws);  // the eager kernels expect ordinary columns
         for (int j = j0; j <= jend; ++j) {
@@ -1444,7 +1382,7 @@ template <class D> double placement_trio_ms(ks_workspace* w, hipEvent_t a, hipEv
     for (int j = jmax; j >= 1 && j > jmax - 20; j -= 6) {  // the launches of real steps at a few basis sizes
       D* col = static_cast<D*>(w->col(j));
       launch_dots<D>(w, j, col, 1, nullptr);
-      if constexpr (sizeof(D) == 8) launch_axpy_dots(w, j, col, 0);
+      launch_axpy_dots<D>(w, std::min(j, kFusedMaxJ), col, 0);
       const int64_t ppb = (w->ld / 2) / std::max(1, w->nb);
       if (sizeof(D) == 8 && ppb >= 3072)
         ksd::k_axpy<D, 8><<<w->nb, kBlock, 0, c->stream>>>(static_cast<const D*>(w->V), w->ld, j, col, static_cast<const D*>(w->coef), w->partial2, 1, nullptr);
@@ -1460,61 +1398,76 @@ template <class D> double placement_trio_ms(ks_workspace* w, hipEvent_t a, hipEv
   return best;
 }
 
+// Search policy (round 2: bounded and exception-safe).  Default: TWO candidates -- the plain allocation and a
+// physically contiguous one (hipDeviceMallocContiguous: consistently in the middle cluster, which bounds the damage
+// on a freshly booted device whose first ~60 GB are of the slowest kind) -- so the transient footprint is at most
+// 2 x V, and only when at least that much memory is free.  KS_PLACE_TRIALS=N (N > 2) opts into a longer search that
+// HOLDS its candidates (a freed block would simply be handed out again) within KS_PLACE_MAX_X (default 2) times the
+// basis size and KS_PLACE_BUDGET_MS; KS_PLACE_TRIALS=1 disables the search.  Candidates live in an RAII holder:
+// whatever happens, every loser is freed and w->V / w->Vbase name the kept allocation.
+struct PlacementCandidates {
+  ks_workspace* w;
+  std::vector<void*> cand;
+  size_t keep = 0;
+  int failed = 0;  // allocations that were refused (reported through ks_workspace_placement)
+  explicit PlacementCandidates(ks_workspace* ws) : w(ws), cand{ws->V} {}
+  ~PlacementCandidates() {
+    for (size_t k = 0; k < cand.size(); ++k)
+      if (k != keep) (void)hipFree(cand[k]);
+    w->V = cand[keep];
+    w->Vbase = w->V;
+  }
+};
+
 template <class D> void tune_placement(ks_workspace* w, size_t vbytes) {
-  static const int trials = env_int("KS_PLACE_TRIALS", 40);
+  static const int trials = env_int("KS_PLACE_TRIALS", 2);
   // measured: +3 % at 3.3 GB, +1.5 % at 1.6 GB, nothing at 0.8 GB, -2 % at 0.4 GB (there the calibration, which
   // revisits the same columns, sees the memory-side cache more than the placement)
   static const int min_mb = env_int("KS_PLACE_MIN_MB", 1024);
   static const int budget_ms = env_int("KS_PLACE_BUDGET_MS", 1500);
+  static const int max_x = std::max(2, env_int("KS_PLACE_MAX_X", 2));  // total footprint of held candidates / basis size
   static const int debug = env_int("KS_PLACE_DEBUG", 0);
   if (trials <= 1 || vbytes < ((size_t)min_mb << 20) || w->guard) return;
   ks_ctx* c = w->ctx;
-  hipEvent_t a, b;
-  KS_HIP(hipEventCreate(&a));
-  KS_HIP(hipEventCreate(&b));
-  // Candidates are HELD until the search ends (a freed block would simply be handed out again).  The timings
-  // fall into clusters ~3 % apart that follow the position in physical memory: a freshly booted device hands
-  // out ~60 GB of the slowest kind first.  Stop as soon as a candidate beats the slowest one seen by 4.5 %
-  // (the gap between the outer clusters), when KS_PLACE_TRIALS candidates or KS_PLACE_BUDGET_MS are spent, or
-  // when another candidate would take more than half of the free memory.
-  std::vector<void*> cand{w->V};
-  size_t best = 0;
+  struct Events {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  } ev;
+  KS_HIP(hipEventCreate(&ev.a));
+  KS_HIP(hipEventCreate(&ev.b));
+  PlacementCandidates pc(w);
   double best_ms = 1e30, worst_ms = 0.0;
   const auto t0 = std::chrono::steady_clock::now();
   for (size_t k = 0;; ++k) {
-    w->V = cand[k];
-    const double ms = placement_trio_ms<D>(w, a, b);
-    if (debug) std::fprintf(stderr, "[ks] placement candidate %zu @%p: %.3f ms\n", k, cand[k], ms);
-    if (ms < best_ms) { best_ms = ms; best = k; }
+    w->V = pc.cand[k];
+    const double ms = placement_trio_ms<D>(w, ev.a, ev.b);
+    if (debug) std::fprintf(stderr, "[ks] placement candidate %zu @%p: %.3f ms\n", k, pc.cand[k], ms);
+    if (ms < best_ms) { best_ms = ms; pc.keep = k; }
     worst_ms = std::max(worst_ms, ms);
     const double spent = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if ((int)cand.size() >= trials || spent > budget_ms) break;
-    if (cand.size() >= 4 && best_ms <= 0.955 * worst_ms) break;
+    if ((int)pc.cand.size() >= trials || spent > budget_ms) break;
+    if ((int)pc.cand.size() + 1 > max_x) break;                      // footprint cap: held candidates <= max_x * V
+    if (pc.cand.size() >= 4 && best_ms <= 0.955 * worst_ms) break;   // a candidate from the fast cluster was found
     size_t free_b = 0, total_b = 0;
     KS_HIP(hipMemGetInfo(&free_b, &total_b));
-    if (free_b / 2 < vbytes) break;
+    if (free_b / 2 < vbytes) { pc.failed++; break; }                 // never take more than half of what is left
     void* p = nullptr;
-    // the second candidate asks for physically contiguous memory: consistently in the middle cluster (measured),
-    // which bounds the damage on a fresh device where everything else sampled within the budget may be slow
-    if (cand.size() == 1 && hipExtMallocWithFlags(&p, vbytes, hipDeviceMallocContiguous) != hipSuccess) {
+    if (pc.cand.size() == 1 && hipExtMallocWithFlags(&p, vbytes, hipDeviceMallocContiguous) != hipSuccess) {
       (void)hipGetLastError();
+      pc.failed++;
       p = nullptr;
     }
-    if (!p && hipMalloc(&p, vbytes) != hipSuccess) { (void)hipGetLastError(); break; }
+    if (!p && hipMalloc(&p, vbytes) != hipSuccess) { (void)hipGetLastError(); pc.failed++; break; }
+    pc.cand.push_back(p);  // owned by the holder from here on
     KS_HIP(hipMemsetAsync(p, 0, vbytes, c->stream));
-    cand.push_back(p);
   }
-  (void)hipEventDestroy(a);
-  (void)hipEventDestroy(b);
-  for (size_t k = 0; k < cand.size(); ++k)
-    if (k != best) (void)hipFree(cand[k]);
-  w->V = cand[best];
-  w->Vbase = w->V;
-  w->place_candidates = (int)cand.size();
+  w->place_candidates = (int)pc.cand.size();
+  w->place_failed = pc.failed;
   w->place_best_ms = best_ms;
   w->place_worst_ms = worst_ms;
-  if (debug) std::fprintf(stderr, "[ks] placement: kept candidate %zu of %zu (%.3f ms, slowest %.3f ms)\n", best, cand.size(), best_ms, worst_ms);
-  // the calibration wrote (zeros) into the scratch of the reductions only; V is still all zero
+  if (debug) std::fprintf(stderr, "[ks] placement: kept candidate %zu of %zu (%.3f ms, slowest %.3f ms, %d refused)\n", pc.keep, pc.cand.size(), best_ms, worst_ms, pc.failed);
+  // ~PlacementCandidates frees the losers and points w->V at the kept one; the calibration wrote (zeros) into the
+  // scratch of the reductions only, V is still all zero
 }
 }  // namespace
 
@@ -1680,8 +1633,15 @@ int ks_operator_csr_dist(ks_ctx* ctx, int64_t nrows_local, int64_t nghost, int64
     KS_REQUIRE(ctx && out && rowptr, KS_ERR_ARGUMENT, "null argument");
     KS_REQUIRE(nnz < (int64_t)2147483647, KS_ERR_ARGUMENT, "nnz must fit int32");
     ctx->use();
+    KS_REQUIRE(nrows_local < (int64_t)2147483647 && nghost < (int64_t)2147483647 - nrows_local, KS_ERR_ARGUMENT,
+               "local-extended column range must fit int32");
     std::vector<int32_t> rp(nrows_local + 1);
-    for (int64_t i = 0; i <= nrows_local; ++i) rp[i] = (int32_t)rowptr[i];
+    KS_REQUIRE(rowptr[0] == 0 && rowptr[nrows_local] == nnz, KS_ERR_ARGUMENT, "row pointer does not match nnz");
+    for (int64_t i = 0; i <= nrows_local; ++i) {
+      KS_REQUIRE(i == 0 || (rowptr[i] >= rowptr[i - 1] && rowptr[i] <= nnz), KS_ERR_ARGUMENT,
+                 "pointer array is not monotone within [0, nnz]");
+      rp[i] = (int32_t)rowptr[i];
+    }
     std::vector<int32_t> ci(colidx, colidx + nnz);
     for (int64_t p = 0; p < nnz; ++p)
       KS_REQUIRE(ci[p] >= 0 && ci[p] < nrows_local + nghost, KS_ERR_ARGUMENT, "local-extended column index out of range");
@@ -1950,9 +1910,10 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
   });
 }
 
-int ks_workspace_placement(const ks_workspace* ws, int* candidates, double* best_ms, double* worst_ms) {
+int ks_workspace_placement(const ks_workspace* ws, int* candidates, double* best_ms, double* worst_ms, int* refused) {
   return guarded([&] {
     KS_REQUIRE(ws, KS_ERR_ARGUMENT, "null workspace");
+    if (refused) *refused = ws->place_failed;
     if (candidates) *candidates = ws->place_candidates;
     if (best_ms) *best_ms = ws->place_best_ms;
     if (worst_ms) *worst_ms = ws->place_worst_ms;
@@ -2233,7 +2194,7 @@ int ks_orthogonalize(ks_workspace* ws, int j, int* ok) {
       using D = typename DevT<T>::type;
       materialize(ws);
       const bool lazy = use_deferred(ws, j);
-      if (lazy) enqueue_steps_deferred(ws, nullptr, j, j);
+      if (lazy) enqueue_steps_deferred<D>(ws, nullptr, j, j);
       else enqueue_orthogonalize<D>(ws, j);
       fetch_state(ws);
       ks::Mat<T> H(static_cast<T*>(ws->H), ws->maxdim + 1, ws->maxdim, ws->maxdim + 1);

@@ -679,138 +679,80 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // ------------------------------------------------------------------------------------------------
-// AXPY+DOTS (Float64): the first DGKS projection fused with the inner products of the second one.
-//     w' = w - V[:,0:j) h                 (mul!(v, Vprev, h, -1, 1),  src/expansion.jl:85)
-//     partial2[b]  = sum |w'|^2            (norm(v),                   src/expansion.jl:88)
-//     partial[c][b] = sum V[r,c] w'[r]     (correction = Vprev' * v,   src/expansion.jl:93)
+// AXPY+DOTS: the first DGKS projection fused with the inner products of the second one.
+//     w' = w - V[:,0:j) h                       (mul!(v, Vprev, h, -1, 1),  src/expansion.jl:85)
+//     partial2[b]  = sum |w'|^2                  (norm(v),                   src/expansion.jl:88)
+//     partial[c][b] = sum conj(V[r,c]) w'[r]     (correction = Vprev' * v,   src/expansion.jl:93)
 // The correction inner products are row-local once w' is known, so each lane keeps its slice of V in
 // registers between the two uses and V is streamed from HBM ONCE for both -- the step reads V three
 // times instead of the reference's four whenever the DGKS test asks for the second pass (it always
 // does for operators with a dominant diagonal such as the Laplacian).  The correction is speculative:
-// k_fin_norm decides afterwards whether it is used (src/expansion.jl:91).
-// RPL = rows per lane: 2 (16-byte loads) while 4*NC4 <= 20 columns, 1 above (register budget).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double ldp(const double* p, double) { return *p; }
-__device__ __forceinline__ double2 ldp(const double* p, double2) { return *reinterpret_cast<const double2*>(p); }
-__device__ __forceinline__ double ldp_nt(const double* p, double) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ double2 ldp_nt(const double* p, double2) { return ld_pack_nt(p); }
-__device__ __forceinline__ void stp_nt(double* p, double v) { __builtin_nontemporal_store(v, p); }
-__device__ __forceinline__ void stp_nt(double* p, double2 v) { st_pack_nt(p, v); }
-__device__ __forceinline__ void fma_p(double& s, double v, double g) { s = fma(v, g, s); }
-__device__ __forceinline__ void fma_p(double2& s, double2 v, double g) { s.x = fma(v.x, g, s.x); s.y = fma(v.y, g, s.y); }
-__device__ __forceinline__ double sub_p(double a, double b) { return a - b; }
-__device__ __forceinline__ double2 sub_p(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ double nrm_p(double a) { return a * a; }
-__device__ __forceinline__ double nrm_p(double2 a) { return fma(a.x, a.x, a.y * a.y); }
-__device__ __forceinline__ void dot_p(double& acc, double v, double w) { acc = fma(v, w, acc); }
-__device__ __forceinline__ void dot_p(double& acc, double2 v, double2 w) { acc = fma(v.x, w.x, fma(v.y, w.y, acc)); }
-
-template <int NC4, int RPL>
-__global__ void __launch_bounds__(kBlock)
-    k_axpy_dots(const double* __restrict__ V, int64_t ldv, int j, double* __restrict__ w, const double* __restrict__ coef,
-                double* __restrict__ partial, int pnb, double* __restrict__ partial2, const DevState* __restrict__ st) {
-  if (st && st->breakdown >= 0) return;
-  using P = typename std::conditional<RPL == 2, double2, double>::type;
-  constexpr int NC = 4 * NC4;
-  __shared__ double g[NC];
-  __shared__ double red[kBlock / 64][NC + 1];
-  if (threadIdx.x < NC) g[threadIdx.x] = threadIdx.x < j ? coef[threadIdx.x] : 0.0;
-  __syncthreads();
-  double acc[NC];
-#pragma unroll
-  for (int c = 0; c < NC; ++c) acc[c] = 0.0;
-  double nrm = 0.0;
-  int64_t pb, pe;
-  block_range(ldv / RPL, blockIdx.x, gridDim.x, pb, pe);
-  const int jm1 = j - 1;
-  for (int64_t p = pb + threadIdx.x; p < pe; p += kBlock) {
-    const int64_t r = p * RPL;
-    P v[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int cc = c < jm1 ? c : jm1;
-      v[c] = ldp_nt(V + (int64_t)cc * ldv + r, P{});
-    }
-    P s = ldp(w + r, P{});
-    P t = P{};
-#pragma unroll
-    for (int c = 0; c < NC; ++c) fma_p(t, v[c], g[c]);  // padded coefficients are zero
-    s = sub_p(s, t);
-    stp_nt(w + r, s);
-    nrm += nrm_p(s);
-#pragma unroll
-    for (int c = 0; c < NC; ++c) dot_p(acc[c], v[c], s);
-  }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const double sred = wave_sum(acc[c]);
-    if (lane == 0) red[wave][c] = sred;
-  }
-  {
-    const double sred = wave_sum(nrm);
-    if (lane == 0) red[wave][NC] = sred;
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c <= j; c += kBlock) {
-    const int src = c < j ? c : NC;
-    const double sred = (red[0][src] + red[1][src]) + (red[2][src] + red[3][src]);
-    if (c < j) partial[(int64_t)c * pnb + blockIdx.x] = sred;
-    else partial2[blockIdx.x] = sred;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// AXPY+DOTS, column-split form (Float64): same contract as k_axpy_dots, but the j columns are dealt
-// round-robin to the 4 waves of the workgroup (wave q owns columns q, q+4, ...), all waves walk the SAME
-// rows.  Each lane therefore keeps only NCW = ceil(j/4) column slices (16-byte loads, 2 rows per lane)
-// instead of j, which lifts occupancy from 2 to 4-6 waves per SIMD.  The per-row partial sums of the
-// projection are exchanged through a double-buffered 8 KiB LDS array (one barrier per iteration); the
-// second-pass inner products then need no cross-wave reduction at all, because every column belongs to
-// exactly one wave.  Summation order is fixed (wave 0..3), so results are run-to-run deterministic.
+// k_fin_mid_def decides afterwards whether it is used (src/expansion.jl:91).
+//
+// Column-split form: the j columns are dealt round-robin to the 4 waves of the workgroup (wave q owns
+// columns q, q+4, ...), all waves walk the SAME rows.  Each lane therefore keeps only NCW = ceil(j/4)
+// column slices (16-byte packs: 2 rows of a Float64 column or 1 row of a ComplexF64 column) instead of j,
+// which lifts occupancy from 2 to 4-6 waves per SIMD.  The per-row partial sums of the projection are
+// exchanged through a double-buffered 8 KiB LDS array (one barrier per iteration); the second-pass inner
+// products then need no cross-wave reduction at all, because every column belongs to exactly one wave.
+// Summation order is fixed (wave 0..3), so results are run-to-run deterministic.
 // (A software-pipelined form -- two register sets, loads of tile t+1 issued before the barrier of tile t --
 // measured the same 5.2 TB/s: the kernel is not stalled on its barrier.)
+// The updated rows are staged in LDS and written back every WB tiles by all four waves (WB x U x 1 KiB bursts
+// instead of one wave's U KiB per tile).  NCW <= 10 runs U = 4 packs per lane, NCW 11..16 (40 < j <= 64) U = 2.
 // ------------------------------------------------------------------------------------------------
-// WB > 1: the updated rows are staged in LDS and written back every WB tiles by all four waves (WB x 4 KiB
-// bursts instead of one wave's 4 KiB per tile).
-template <int NCW, int U, bool NTS = true, int MINW = 1, int WB = 1>
-__global__ void __launch_bounds__(kBlock, MINW)
-    k_axpy_dots_cs(const double* __restrict__ V, int64_t ldv, int j, double* __restrict__ w,
-                   const double* __restrict__ coef, double* __restrict__ partial, int pnb,
-                   double* __restrict__ partial2, const DevState* __restrict__ st, int defer) {
+__device__ __forceinline__ double2 addp(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cd addp(cd a, cd b) { return cd{a.x + b.x, a.y + b.y}; }
+// acc += sum over the pack of conj(v) * w, in the association the Float64 kernel has always used
+__device__ __forceinline__ void dotp(double& acc, double2 v, double2 w) { acc = fma(v.x, w.x, fma(v.y, w.y, acc)); }
+__device__ __forceinline__ void dotp(cd& acc, cd v, cd w) { dot_acc(acc, v, w); }
+__device__ __forceinline__ double real_of(double a) { return a; }
+__device__ __forceinline__ double real_of(cd a) { return a.x; }
+__device__ __forceinline__ double scl(double a, double s) { return a * s; }
+__device__ __forceinline__ cd scl(cd a, double s) { return cd{a.x * s, a.y * s}; }
+__device__ __forceinline__ double from_real(double v, double) { return v; }
+__device__ __forceinline__ cd from_real(double v, cd) { return cd{v, 0.0}; }
+
+template <class T, int NCW, int U, int WB>
+__global__ void __launch_bounds__(kBlock)
+    k_axpy_dots_cs(const T* __restrict__ V, int64_t ldv, int j, T* __restrict__ w, const T* __restrict__ coef,
+                   T* __restrict__ partial, int pnb, double* __restrict__ partial2, const DevState* __restrict__ st,
+                   int defer) {
   if (st && st->breakdown >= 0) return;
+  using P = typename Pack<T>::type;
+  constexpr int R = Pack<T>::R;
   // lazy normalisation: y (= w on entry) = A * (unnormalised column j-1) carries the factor beta_{j-1}
   const double invb = (defer && st) ? st->invb : 1.0;
-  __shared__ double2 tbuf[2][4][U][64];
-  __shared__ double2 wout[WB > 1 ? WB * U * 64 : 1];
+  __shared__ P tbuf[2][4][U][64];
+  __shared__ P wout[WB > 1 ? WB * U * 64 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const double* colp[NCW];
-  double g[NCW];
-  double acc[NCW];
+  const T* colp[NCW];
+  T g[NCW];
+  T acc[NCW];
 #pragma unroll
   for (int i = 0; i < NCW; ++i) {
     const int c = wave + 4 * i;
     const bool valid = c < j;
     colp[i] = V + (int64_t)(valid ? c : j - 1) * ldv;
-    g[i] = valid ? coef[c] : 0.0;
-    acc[i] = 0.0;
+    g[i] = valid ? coef[c] : zero_of(T{});
+    acc[i] = zero_of(T{});
   }
   const bool last_valid = (wave + 4 * (NCW - 1)) < j;
   double nrm = 0.0;
   int64_t pb, pe;
-  block_range(ldv / 2, blockIdx.x, gridDim.x, pb, pe);
+  block_range(ldv / R, blockIdx.x, gridDim.x, pb, pe);
   int it = 0;
   for (int64_t base = pb; base < pe; base += 64 * U, ++it) {
     int64_t r[U];
     bool ok[U];
-    double2 v[NCW][U];
-    double2 wv[U];
+    P v[NCW][U];
+    P wv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t q = base + u * 64 + lane;
       ok[u] = q < pe;
-      r[u] = (ok[u] ? q : pb) * 2;
+      r[u] = (ok[u] ? q : pb) * R;
     }
 #pragma unroll
     for (int i = 0; i < NCW; ++i) {
@@ -819,39 +761,32 @@ __global__ void __launch_bounds__(kBlock, MINW)
         for (int u = 0; u < U; ++u) v[i][u] = ld_pack_nt(colp[i] + r[u]);
       } else {
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[i][u] = make_double2(0.0, 0.0);
+        for (int u = 0; u < U; ++u) v[i][u] = zero_pack(T{});
       }
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      wv[u] = ld_pack(w + r[u]);
-      wv[u].x *= invb;
-      wv[u].y *= invb;
-    }
+    for (int u = 0; u < U; ++u) wv[u] = scale_pack(ld_pack(w + r[u]), invb);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      double2 t = make_double2(0.0, 0.0);
+      P t = zero_pack(T{});
 #pragma unroll
-      for (int i = 0; i < NCW; ++i) { t.x = fma(v[i][u].x, g[i], t.x); t.y = fma(v[i][u].y, g[i], t.y); }
+      for (int i = 0; i < NCW; ++i) axpy_acc(t, v[i][u], g[i]);
       tbuf[it & 1][wave][u][lane] = t;
     }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const double2 t0 = tbuf[it & 1][0][u][lane], t1 = tbuf[it & 1][1][u][lane];
-      const double2 t2 = tbuf[it & 1][2][u][lane], t3 = tbuf[it & 1][3][u][lane];
-      double2 wn;
-      wn.x = wv[u].x - ((t0.x + t1.x) + (t2.x + t3.x));
-      wn.y = wv[u].y - ((t0.y + t1.y) + (t2.y + t3.y));
-      if (!ok[u]) wn = make_double2(0.0, 0.0);
+      const P t0 = tbuf[it & 1][0][u][lane], t1 = tbuf[it & 1][1][u][lane];
+      const P t2 = tbuf[it & 1][2][u][lane], t3 = tbuf[it & 1][3][u][lane];
+      P wn = sub_pack(wv[u], addp(addp(t0, t1), addp(t2, t3)));
+      if (!ok[u]) wn = zero_pack(T{});
       if (wave == 0 && ok[u]) {
         if constexpr (WB > 1) wout[((it % WB) * U + u) * 64 + lane] = wn;
-        else if (NTS) st_pack_nt(w + r[u], wn);
-        else st_pack(w + r[u], wn);
-        nrm += fma(wn.x, wn.x, wn.y * wn.y);
+        else st_pack_nt(w + r[u], wn);
+        nrm += nrm2_pack(wn);
       }
 #pragma unroll
-      for (int i = 0; i < NCW; ++i) acc[i] = fma(v[i][u].x, wn.x, fma(v[i][u].y, wn.y, acc[i]));
+      for (int i = 0; i < NCW; ++i) dotp(acc[i], v[i][u], wn);
     }
     if constexpr (WB > 1) {
       const bool lastt = base + 64 * U >= pe;
@@ -859,13 +794,13 @@ __global__ void __launch_bounds__(kBlock, MINW)
         __syncthreads();
         const int64_t fb = base - (int64_t)(it % WB) * 64 * U;  // first pack staged
         const int64_t fe = (base + 64 * U < pe) ? base + 64 * U : pe;
-        for (int64_t o = fb + threadIdx.x; o < fe; o += kBlock) st_pack_nt(w + o * 2, wout[o - fb]);
+        for (int64_t o = fb + threadIdx.x; o < fe; o += kBlock) st_pack_nt(w + o * R, wout[o - fb]);
       }
     }
   }
 #pragma unroll
   for (int i = 0; i < NCW; ++i) {
-    const double sred = wave_sum(acc[i]);
+    const T sred = wave_sum(acc[i]);
     const int c = wave + 4 * i;
     if (lane == 0 && c < j) partial[(int64_t)c * pnb + blockIdx.x] = sred;
   }
@@ -875,14 +810,6 @@ __global__ void __launch_bounds__(kBlock, MINW)
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// FIN_MID (fused path): after k_axpy_dots* both ||w'||^2 and the speculative second-pass inner
-// products c are known, so ONE reduction stage (and, multi-GPU, ONE all-reduce of j+1 doubles) serves
-// the DGKS test and the correction:   workgroup c < j reduces column c, workgroup j reduces |w'|^2.
-//   wnorm = sqrt(sum |w'|^2);   wnorm < eta * rnorm  ->  second pass: H[0:j, j-1] += c, coef = c,
-//   rnorm2 = wnorm (src/expansion.jl:91-95);  otherwise finalize like k_fin_norm (src/expansion.jl:99-108).
-// Every workgroup evaluates the (identical) test itself from read-only inputs; only workgroup j writes state.
-// ------------------------------------------------------------------------------------------------
 template <class T>
 __device__ __forceinline__ T block_sum(const T* __restrict__ p, int nb, T* sm) {
   const int tid = threadIdx.x;
@@ -899,62 +826,31 @@ __device__ __forceinline__ T block_sum(const T* __restrict__ p, int nb, T* sm) {
   return r;
 }
 
-__global__ void __launch_bounds__(kBlock)
-    k_fin_mid(const double* __restrict__ partial, const double* __restrict__ partial2, int nb, int pnb, int j,
-              double* __restrict__ red, double* __restrict__ Hcol, double* __restrict__ coef, int mode,
-              DevState* __restrict__ st) {
-  if (st->breakdown >= 0) return;
-  __shared__ double sm[kBlock];
-  const int c = blockIdx.x;  // 0..j
-  double s = 0.0, nrm2 = 0.0;
-  if (mode != 2) {
-    s = block_sum(c < j ? partial + (int64_t)c * pnb : partial2, nb, sm);
-    if (mode == 1) {
-      if (threadIdx.x == 0) red[c] = s;
-      return;
-    }
-    nrm2 = (c == j) ? s : block_sum(partial2, nb, sm);
-  } else {
-    s = red[c];
-    nrm2 = red[j];
-  }
-  if (threadIdx.x != 0) return;
-  const double wnorm = sqrt(nrm2);
-  const double rnorm = st->rnorm;  // written by the previous kernel, read-only here
-  const bool reorth = wnorm < kEta * rnorm;  // src/expansion.jl:91
-  if (c < j) {
-    if (reorth) {
-      coef[c] = s;
-      Hcol[c] += s;  // h .+= correction, src/expansion.jl:95
-    }
-    return;
-  }
-  st->wnorm = wnorm;
-  if (reorth) {
-    st->reorth = 1;
-    st->rnorm2 = wnorm;  // :92
-    st->n_reorth += 1;
-    return;
-  }
-  st->reorth = 0;
-  if (wnorm <= kEta * rnorm) {  // :99
-    Hcol[j] = 0.0;
-    st->breakdown = j;
-    st->inv_norm = 0.0;
-  } else {
-    Hcol[j] = wnorm;
-    st->inv_norm = 1.0 / wnorm;
-    st->n_steps += 1;
-  }
+// peer-to-peer exchange of one element of type T plus one real: the sums over ranks of (x, extra).
+// Elements of the LL window: NV = sizeof(T)/8 + 1 consecutive doubles per workgroup (ks_p2p.hpp).
+template <class T> struct P2pNV { static constexpr int value = (int)(sizeof(T) / 8) + 1; };
+__device__ __forceinline__ void p2p_pair(const P2pDev& p, int c, double x, double extra, double& gx, double& gextra) {
+  const double in[2] = {x, extra};
+  double out[2];
+  p2p_sum_wave<2>(p, 2 * c, in, out);
+  gx = out[0];
+  gextra = out[1];
+}
+__device__ __forceinline__ void p2p_pair(const P2pDev& p, int c, cd x, double extra, cd& gx, double& gextra) {
+  const double in[3] = {x.x, x.y, extra};
+  double out[3];
+  p2p_sum_wave<3>(p, 3 * c, in, out);
+  gx = cd{out[0], out[1]};
+  gextra = out[2];
 }
 
 // ------------------------------------------------------------------------------------------------
-// Lazy normalisation (fused Float64 path).  The column a step produces is NOT normalised by a streaming
-// pass (v ./= wnorm, src/expansion.jl:106): it stays in HBM as w~ = beta * v together with a per-column
-// factor cs[c] = 1/beta (device array `colscale`, 1 for ordinary columns), and every consumer folds the
-// factor into the small quantities instead of touching n-sized data:
+// Lazy normalisation (fused path, Float64 and ComplexF64, maxdim <= 64).  The column a step produces is NOT
+// normalised by a streaming pass (v ./= wnorm, src/expansion.jl:106): it stays in HBM as w~ = beta * v together
+// with a per-column REAL factor cs[c] = 1/beta (device array `colscale`, 1 for ordinary columns), and every
+// consumer folds the factor into the small quantities instead of touching n-sized data:
 //     y = A w~                      carries beta_{j-1}:      y/beta is formed on the fly in k_axpy_dots_cs
-//     h[c]    = cs[c] * (w~_c . y) / beta_{j-1}              (k_fin_dots_def)
+//     h[c]    = cs[c] * (w~_c^H y) / beta_{j-1}              (k_fin_dots_def)
 //     w -= sum_c w~_c * (cs[c] h[c])                          (coefficient vector handed to the kernels)
 //     V Q  ->  rows of Q scaled by cs[c] on the host          (restart rotation)
 // The norm of the newest column is not even reduced by its own stage: its block partials are folded into
@@ -963,39 +859,52 @@ __global__ void __launch_bounds__(kBlock)
 // the host cannot observe: it only sees the state after the batch.  Columns are materialised (scaled
 // once) before anything outside the expansion/rotation pair reads them.
 // FIN_DOTS_DEF: workgroup c <= j: column c of the partials (column j = |y|^2); in reduce-only mode an extra
-// workgroup j+1 delivers the pending norm so that ONE all-reduce of j+2 doubles serves everything.
+// workgroup j+1 delivers the pending norm so that ONE all-reduce of j+2 elements serves everything.
+//   mode 0: reduce + post (single GPU);  mode 1: reduce only -> red[c] (then all-reduce over the ranks);
+//   mode 2: post only from red;  mode 3: peer-to-peer -- reduce, exchange and post in ONE kernel.
+//
+// Entry test.  Workgroup j of THIS launch may set st->breakdown = j-1 (pending breakdown of the previous step)
+// while other workgroups of the same launch have not started yet; in mode 3 a workgroup that then left early
+// would withhold its contribution from the peers, which spin for it until the transport times out.  A value
+// written by an EARLIER launch is always < j-1 in this batch, so "breakdown >= 0 and != j-1" is exactly
+// "a previous launch broke down" and only that ends the workgroup before the exchange.
 // ------------------------------------------------------------------------------------------------
+template <class T>
 __global__ void __launch_bounds__(kBlock)
-    k_fin_dots_def(const double* __restrict__ partial, int nb, int pnb, const double* __restrict__ partial2, int nb2,
-                   int j, double* __restrict__ red, double* __restrict__ Hcol, double* __restrict__ Hsub_prev,
-                   double* __restrict__ coef, double* __restrict__ colscale, int mode, DevState* __restrict__ st,
+    k_fin_dots_def(const T* __restrict__ partial, int nb, int pnb, const double* __restrict__ partial2, int nb2,
+                   int j, T* __restrict__ red, T* __restrict__ Hcol, T* __restrict__ Hsub_prev,
+                   T* __restrict__ coef, double* __restrict__ colscale, int mode, DevState* __restrict__ st,
                    P2pDev p2p) {
-  if (st->breakdown >= 0) return;
-  __shared__ double sm[kBlock];
+  {
+    const int bd = st->breakdown;
+    if (bd >= 0 && bd != j - 1) return;
+  }
+  __shared__ T sm[kBlock];
+  double* smd = reinterpret_cast<double*>(sm);
   const int c = blockIdx.x;  // 0..j (mode 1: ..j+1)
   const bool pend = st->pend != 0;
   const bool pre = st->pend_reorth != 0;
-  double s = 0.0, b2 = 1.0;
+  T s = zero_of(T{});
+  double b2 = 1.0;
   if (mode == 3) {
-    // peer-to-peer: reduce, exchange and post-process in ONE kernel -- workgroup c sums its column over the
-    // ranks itself (elements 2c, 2c+1 of the LL window: its column and the pending norm every workgroup needs)
-    const double x[2] = {block_sum(partial + (int64_t)c * pnb, nb, sm), (pend && pre) ? block_sum(partial2, nb2, sm) : 0.0};
+    // workgroup c sums its column over the ranks itself (its column and the pending norm every workgroup needs)
+    const T own = block_sum(partial + (int64_t)c * pnb, nb, sm);
+    const double pn = (pend && pre) ? block_sum(partial2, nb2, smd) : 0.0;
     if (threadIdx.x >= 64) return;
-    double g[2];
-    p2p_sum_wave<2>(p2p, 2 * c, x, g);
-    s = g[0];
-    if (pend) b2 = pre ? g[1] : st->wnorm * st->wnorm;
+    double gp;
+    p2p_pair(p2p, c, own, pn, s, gp);
+    if (pend) b2 = pre ? gp : st->wnorm * st->wnorm;
   } else if (mode != 2) {
     if (c <= j) s = block_sum(partial + (int64_t)c * pnb, nb, sm);
     if (mode == 1) {
-      if (c == j + 1) s = (pend && pre) ? block_sum(partial2, nb2, sm) : 0.0;
+      if (c == j + 1) s = from_real((pend && pre) ? block_sum(partial2, nb2, smd) : 0.0, T{});
       if (threadIdx.x == 0) red[c] = s;
       return;
     }
-    if (pend) b2 = pre ? block_sum(partial2, nb2, sm) : st->wnorm * st->wnorm;
+    if (pend) b2 = pre ? block_sum(partial2, nb2, smd) : st->wnorm * st->wnorm;
   } else {
     s = red[c];
-    if (pend) b2 = pre ? red[j + 1] : st->wnorm * st->wnorm;
+    if (pend) b2 = pre ? real_of(red[j + 1]) : st->wnorm * st->wnorm;
   }
   if (threadIdx.x != 0) return;
   // factor of the input column: settled earlier (1 if the column is normalised) or established right now
@@ -1004,7 +913,7 @@ __global__ void __launch_bounds__(kBlock)
     const double beta = pre ? sqrt(b2) : st->wnorm;
     if (beta <= kEta * st->rnorm_p) {  // breakdown of the PREVIOUS step, src/expansion.jl:99-102
       if (c == j) {
-        *Hsub_prev = 0.0;
+        *Hsub_prev = zero_of(T{});
         st->breakdown = j - 1;
         st->inv_norm = 0.0;
       }
@@ -1012,50 +921,58 @@ __global__ void __launch_bounds__(kBlock)
     }
     invb = 1.0 / beta;
     if (c == j) {
-      *Hsub_prev = beta;  // H[j, j-1] of the previous step, src/expansion.jl:105
+      *Hsub_prev = from_real(beta, T{});  // H[j, j-1] of the previous step, src/expansion.jl:105
       st->n_steps += 1;
     }
   }
   if (c < j) {
     const double cs = (c == j - 1) ? invb : colscale[c];
-    const double h = s * invb * cs;  // true coefficient w.r.t. the NORMALISED column c
+    const T h = scl(scl(s, invb), cs);  // true coefficient w.r.t. the NORMALISED column c
     Hcol[c] = h;
-    coef[c] = h * cs;                // what multiplies the stored (possibly unnormalised) column
+    coef[c] = scl(h, cs);               // what multiplies the stored (possibly unnormalised) column
   } else {
-    st->rnorm = sqrt(s) * invb;
+    st->rnorm = sqrt(real_of(s)) * invb;
     st->invb = invb;
     if (pend) colscale[j - 1] = invb;  // only workgroup j writes; the others derived the same value themselves
   }
 }
 
-// FIN_MID for the deferred path: like k_fin_mid, but when no second pass is needed it does not finalise
-// the step (no H[j+1,j], no 1/wnorm): it records what the next k_fin_dots_def / k_fin_pend needs.
+// ------------------------------------------------------------------------------------------------
+// FIN_MID_DEF: after k_axpy_dots_cs both ||w'||^2 and the speculative second-pass inner products c are
+// known, so ONE reduction stage (and, multi-GPU, ONE all-reduce of j+1 elements) serves the DGKS test and the
+// correction:   workgroup c < j reduces column c, workgroup j reduces |w'|^2.
+//   wnorm = sqrt(sum |w'|^2);   wnorm < eta * rnorm  ->  second pass: H[0:j, j-1] += c, coef = c (src/expansion.jl:91-95)
+// When no second pass is needed it does not finalise the step (no H[j+1,j], no 1/wnorm): it records what the
+// next k_fin_dots_def / k_fin_pend needs.  Every workgroup evaluates the (identical) test itself from read-only
+// inputs; only workgroup j writes state.  (This kernel never writes st->breakdown, so its entry test is safe.)
+// ------------------------------------------------------------------------------------------------
+template <class T>
 __global__ void __launch_bounds__(kBlock)
-    k_fin_mid_def(const double* __restrict__ partial, const double* __restrict__ partial2, int nb, int pnb, int j,
-                  double* __restrict__ red, double* __restrict__ Hcol, double* __restrict__ coef,
+    k_fin_mid_def(const T* __restrict__ partial, const double* __restrict__ partial2, int nb, int pnb, int j,
+                  T* __restrict__ red, T* __restrict__ Hcol, T* __restrict__ coef,
                   const double* __restrict__ colscale, int mode, DevState* __restrict__ st, P2pDev p2p) {
   if (st->breakdown >= 0) return;
-  __shared__ double sm[kBlock];
+  __shared__ T sm[kBlock];
+  double* smd = reinterpret_cast<double*>(sm);
   const int c = blockIdx.x;  // 0..j
-  double s = 0.0, nrm2 = 0.0;
+  T s = zero_of(T{});
+  double nrm2 = 0.0;
   if (mode == 3) {  // peer-to-peer: see k_fin_dots_def
-    const double own = block_sum(c < j ? partial + (int64_t)c * pnb : partial2, nb, sm);
-    const double x[2] = {own, (c == j) ? own : block_sum(partial2, nb, sm)};
+    const double n2 = block_sum(partial2, nb, smd);
+    const T own = (c < j) ? block_sum(partial + (int64_t)c * pnb, nb, sm) : from_real(n2, T{});
     if (threadIdx.x >= 64) return;
-    double g[2];
-    p2p_sum_wave<2>(p2p, 2 * c, x, g);
-    s = g[0];
-    nrm2 = g[1];
+    p2p_pair(p2p, c, own, n2, s, nrm2);
   } else if (mode != 2) {
-    s = block_sum(c < j ? partial + (int64_t)c * pnb : partial2, nb, sm);
+    const double n2 = (c == j || mode == 0) ? block_sum(partial2, nb, smd) : 0.0;
+    s = (c < j) ? block_sum(partial + (int64_t)c * pnb, nb, sm) : from_real(n2, T{});
     if (mode == 1) {
       if (threadIdx.x == 0) red[c] = s;
       return;
     }
-    nrm2 = (c == j) ? s : block_sum(partial2, nb, sm);
+    nrm2 = n2;
   } else {
     s = red[c];
-    nrm2 = red[j];
+    nrm2 = real_of(red[j]);
   }
   if (threadIdx.x != 0) return;
   const double wnorm = sqrt(nrm2);
@@ -1064,8 +981,8 @@ __global__ void __launch_bounds__(kBlock)
   if (c < j) {
     if (reorth) {
       const double cs = colscale[c];
-      Hcol[c] += s * cs;      // h .+= correction, :95
-      coef[c] = s * cs * cs;
+      Hcol[c] = add_(Hcol[c], scl(s, cs));  // h .+= correction, :95
+      coef[c] = scl(scl(s, cs), cs);
     }
     return;
   }
@@ -1083,10 +1000,11 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-// FIN_PEND (end of a batch): settle the pending normalisation of the last column: beta, breakdown test,
-// H[j+1,j] and 1/beta for the k_scale that follows.
+// FIN_PEND (end of a batch, ONE workgroup): settle the pending normalisation of the last column: beta, breakdown
+// test, H[j+1,j] and the column's factor.
+template <class T>
 __global__ void __launch_bounds__(kBlock)
-    k_fin_pend(const double* __restrict__ partial2, int nb2, double* __restrict__ red, double* __restrict__ Hsub, int j,
+    k_fin_pend(const double* __restrict__ partial2, int nb2, double* __restrict__ red, T* __restrict__ Hsub, int j,
                double* __restrict__ colscale, int mode, DevState* __restrict__ st, P2pDev p2p) {
   if (st->breakdown >= 0) return;
   if (!st->pend) return;
@@ -1113,11 +1031,11 @@ __global__ void __launch_bounds__(kBlock)
   st->pend = 0;
   st->reorth = 0;
   if (beta <= kEta * st->rnorm_p) {
-    *Hsub = 0.0;
+    *Hsub = zero_of(T{});
     st->breakdown = j;
     st->inv_norm = 0.0;
   } else {
-    *Hsub = beta;
+    *Hsub = from_real(beta, T{});
     st->inv_norm = 1.0 / beta;
     colscale[j] = 1.0 / beta;  // the column stays unnormalised in HBM
     st->wnorm = beta;

@@ -22,9 +22,11 @@ un-fused op sequence on the host cores (oracle/cpu_backend.cpp, kind "port") on 
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -148,7 +150,7 @@ def main():
         ws.reinitialize(0, v1)
         ws.iterate_arnoldi(op, 1, mindim)  # initial expansion, src/run.jl:267 (untimed)
 
-        state = dict(k=mindim, active=0, steps=0, bytes=0.0, t_expand=0.0, t_restart=0.0, reorth=0, trail=[], ritz=None)
+        state = dict(k=mindim, active=0, steps=0, bytes=0.0, moved=0.0, t_expand=0.0, t_restart=0.0, reorth=0, trail=[], ritz=None)
 
         def cycle(timed):
             k = state["k"]
@@ -169,6 +171,12 @@ def main():
                 if not all_re:
                     jm = (k + 1 + maxdim) / 2.0
                     state["bytes"] += st["reorth"] * (16.0 * jm * n + 16.0 * n)
+                # bytes the launched kernels MUST move (three passes over V when the second DGKS pass is taken:
+                # k_dots, k_axpy_dots_cs, k_axpy; no normalisation pass) -- the traffic-true figure
+                spmv_b = fmt["bytes_per_nnz"] * nnz_global + 4.0 * (n + 1) + 16.0 * n
+                for j in range(k + 1, maxdim + 1):
+                    state["moved"] += spmv_b + 8.0 * n * (j + 1) + 8.0 * n * (j + 2)
+                state["moved"] += st["reorth"] * 8.0 * n * ((k + 1 + maxdim) / 2.0 + 2)
                 state["t_expand"] += t1 - t0
                 state["t_restart"] += t2 - t1
                 state["trail"].append((r["k"], r["nlock"]))
@@ -206,29 +214,86 @@ def main():
 
     # N > 1: the row-partitioned solver has two transports for its per-step exchanges -- RCCL collectives
     # and the library's own peer-to-peer regions over xGMI (csrc/ks_p2p.hpp).  Both are measured with the
-    # full W + K protocol, back to back; `value` is the faster pass that completed on every rank AND
-    # reproduced the RCCL pass (same (k, nlock) sequence of the restarts, same Ritz values).  Every pass is
-    # reported under "transports".  KS_BENCH_TRANSPORTS=rccl restricts the run.
+    # full W + K protocol, back to back; `value` is the faster pass that completed on every rank; when both
+    # completed they must agree (same (k, nlock) sequence of the restarts, same Ritz values) or the slower-to-
+    # verify one (p2p) is dropped.  A failure of EITHER transport -- an exception on any rank, or a pass that does
+    # not finish within its deadline (a hung collective) -- is reported under "transports" and the line is printed
+    # from the survivor; if nothing survives the line still appears, with value null and exit status 3.
+    # KS_BENCH_TRANSPORTS=rccl restricts the run; KS_BENCH_INJECT_FAIL=rccl|p2p[:hang] makes that pass fail or
+    # hang on purpose (tests/test_bench_line.py).
     passes = {}
     if dist is None or (world == 1 and "KS_BENCH_TRANSPORTS" not in os.environ):
         order = ["single"]
     else:  # (KS_FORCE_DIST=1 KS_BENCH_TRANSPORTS=rccl,p2p exercises this selection logic on a single rank)
-        order = [t for t in os.environ.get("KS_BENCH_TRANSPORTS", "rccl,p2p").split(",") if t in ("rccl", "p2p")] or ["rccl"]
+        order = [t for t in os.environ.get("KS_BENCH_TRANSPORTS", "p2p,rccl").split(",") if t in ("rccl", "p2p")] or ["rccl"]
+    inject = os.environ.get("KS_BENCH_INJECT_FAIL", "")
+    deadline_s = float(os.environ.get("KS_BENCH_PASS_DEADLINE_S", "300"))
+
+    def emit(out):
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+
+    def build_line(with_cpu_baseline=True):
+        return make_line(args, pkg, passes, order, world, rank, force_dist, dict(m=m, n=n, nev=nev, mindim=mindim, maxdim=maxdim, which=which),
+                         with_cpu_baseline)
+
     for tr in order:
         ok, res, err = 1, None, ""
+        done = threading.Event()
+
+        def watchdog(tr=tr, done=done):
+            # a pass that hangs inside a collective cannot be interrupted from Python: report what we have and leave
+            if done.wait(deadline_s):
+                return
+            passes[tr] = {"error": f"pass did not finish within {deadline_s:.0f} s (hung exchange?)"}
+            line = build_line(with_cpu_baseline=False)
+            try:
+                emit(line)
+            finally:
+                os._exit(0 if line["value"] is not None else 3)
+
+        if tr != "single":
+            threading.Thread(target=watchdog, daemon=True).start()
         try:
+            if inject.split(":")[0] == tr:
+                if inject.endswith(":hang"):
+                    time.sleep(10 * deadline_s)
+                raise RuntimeError(f"injected failure of the {tr} pass (KS_BENCH_INJECT_FAIL)")
             res = measure(None if tr == "single" else tr)
         except Exception as e:  # noqa: BLE001
-            if tr != "p2p" or order == ["p2p"]:
+            if tr == "single":
                 raise
             ok, err = 0, f"{type(e).__name__}: {e}"
         if dist is not None and world > 1:
-            t = torch.tensor([ok], dtype=torch.int32, device=red_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            if int(t.item()) == 0:
-                ok, err = 0, err or "failed on another rank"
+            try:
+                t = torch.tensor([ok], dtype=torch.int32, device=red_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                if int(t.item()) == 0:
+                    ok, err = 0, err or "failed on another rank"
+            except Exception as e:  # noqa: BLE001 - the process group itself is broken
+                ok, err = 0, err or f"{type(e).__name__}: {e}"
         passes[tr] = res if ok else {"error": err}
-    valid = [t for t in order if "error" not in passes[t]]
+        done.set()
+    out = build_line()
+    # Tear everything down first and flush the C stdio buffers (RCCL prints a version banner through printf,
+    # which sits in the C buffer until exit when stdout is a pipe): the JSON line must be the LAST line on stdout.
+    if dist is not None:
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001 - a broken transport must not eat the line
+            pass
+    emit(out)
+    if out["value"] is None:
+        sys.exit(3)
+
+
+def make_line(args, pkg, passes, order, world, rank, force_dist, wl, with_cpu_baseline):
+    """The ONE JSON line, from whatever passes completed."""
+    m, n, nev, mindim, maxdim, which = wl["m"], wl["n"], wl["nev"], wl["mindim"], wl["maxdim"], wl["which"]
+    valid = [t for t in order if t in passes and "error" not in passes[t]]
     if "p2p" in valid and "rccl" in valid:
         a, b = passes["rccl"]["state"], passes["p2p"]["state"]
         same = a["trail"] == b["trail"] and a["ritz"].shape == b["ritz"].shape and \
@@ -236,54 +301,54 @@ def main():
         if not same:
             passes["p2p"] = {"error": "results differ from the RCCL pass", **{k: v for k, v in passes["p2p"].items() if k == "elapsed"}}
             valid.remove("p2p")
-    chosen = min(valid, key=lambda t: passes[t]["elapsed"])
-    elapsed, state, prof = passes[chosen]["elapsed"], passes[chosen]["state"], passes[chosen]["prof"]
-    nnz_global, A_host = passes[chosen]["nnz_global"], passes[chosen]["A_host"]
-
-    iters_per_s = state["steps"] / elapsed
     out = {
-        "metric": "arnoldi_iters_per_sec",
-        "value": iters_per_s,
-        "unit": "iters/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
-        "higher_is_better": True,
-        "scaling": "strong",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
-        "config": {
-            "workload": f"laplace3d-7pt {m}^3 (n={n}, nnz={nnz_global}), nev={nev}, which=SR, mindim={mindim}, maxdim={maxdim}, "
-                        f"tol=sqrt(eps), explicit v1 (splitmix64 seed 20240917); step = one Krylov-Schur restart cycle",
-            "n": n,
-            "nnz": nnz_global,
-            "arnoldi_iterations_timed": state["steps"],
-            "dgks_second_passes": state["reorth"],
-            "parallelism": f"rows/{world}" if world > 1 else "single-gpu",
-            "spmv_layout": {1.0: "csr-dvi: %d-entry (column-row, value) dictionary, 1 B per non-zero (bit-identical products)",
-                            4.0: "csr-vi: %d-entry value dictionary, 4 B per non-zero (bit-identical products)"}.get(
-                                passes[chosen]["fmt"]["bytes_per_nnz"], "csr: 12 B per non-zero%.0s") % passes[chosen]["fmt"]["ndict"],
-        },
+        "metric": "arnoldi_iters_per_sec", "value": None, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"laplace3d-7pt {m}^3 (n={n}), nev={nev}, which=SR, mindim={mindim}, maxdim={maxdim}, tol=sqrt(eps), "
+                               f"explicit v1 (splitmix64 seed 20240917); step = one Krylov-Schur restart cycle",
+                   "n": n, "parallelism": f"rows/{world}" if world > 1 else "single-gpu"},
     }
-    out["config"]["basis_placement"] = passes[chosen]["placement"]  # placement search of the workspace
-    if chosen != "single":
-        out["config"]["transport"] = chosen
+    if order != ["single"]:
         out["transports"] = {
             t: ({"error": p["error"]} if "error" in p else
                 {"value": p["state"]["steps"] / p["elapsed"], "ms_per_step": 1e3 * p["elapsed"] / max(args.steps, 1)})
             for t, p in passes.items()
         }
+    if not valid:
+        return out
+    chosen = min(valid, key=lambda t: passes[t]["elapsed"])
+    elapsed, state, prof = passes[chosen]["elapsed"], passes[chosen]["state"], passes[chosen]["prof"]
+    nnz_global, A_host, fmt = passes[chosen]["nnz_global"], passes[chosen]["A_host"], passes[chosen]["fmt"]
+    out["value"] = state["steps"] / elapsed
+    out["ms_per_step"] = 1e3 * elapsed / max(args.steps, 1)
+    layout = {1.0: "csr-dvi", 4.0: "csr-vi"}.get(fmt["bytes_per_nnz"], "csr")
+    out["config"].update({
+        "workload": f"laplace3d-7pt {m}^3 (n={n}, nnz={nnz_global}), nev={nev}, which=SR, mindim={mindim}, maxdim={maxdim}, "
+                    f"tol=sqrt(eps), explicit v1 (splitmix64 seed 20240917); step = one Krylov-Schur restart cycle",
+        "nnz": nnz_global,
+        "arnoldi_iterations_timed": state["steps"],
+        "dgks_second_passes": state["reorth"],
+        "spmv_layout": {"csr-dvi": "csr-dvi: %d-entry (column-row, value) dictionary, 1 B per non-zero (bit-identical products)",
+                        "csr-vi": "csr-vi: %d-entry value dictionary, 4 B per non-zero (bit-identical products)",
+                        "csr": "csr: 12 B per non-zero%.0s"}[layout] % fmt["ndict"],
+        "basis_placement": passes[chosen]["placement"],  # placement search of the workspace (off unless KS_PLACE_TRIALS > 1)
+    })
+    if chosen != "single":
+        out["config"]["transport"] = chosen
 
     # ---- roofline ----
     fused_gbs = state["bytes"] / max(state["t_expand"], 1e-12) / 1e9 / world  # per GPU
+    moved_gbs = state["moved"] / max(state["t_expand"], 1e-12) / 1e9 / world
     roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
     if prof:
         classes = {k: v for k, v in prof.items() if k != "fin" and v["count"] > 0}
         dom = max(classes, key=lambda k: classes[k]["ms"])
         d = classes[dom]
         ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        traffic = pmc_traffic(dom) if (m == 216 and world == 1 and not force_dist) else None
+        if traffic is not None:
+            traffic["measured_in_run"] = False  # read from the committed PMC passes (profiles/), not collected by this run
         roof.update({
             "kernel": KERNEL_NAMES[dom],
             "achieved": ach,
@@ -291,53 +356,61 @@ def main():
             "launches": d["count"],
             "avg_launch_ms": d["ms"] / d["count"],
             "algorithmic_bytes_per_launch": d["bytes"] / d["count"],
-            "traffic": pmc_traffic(dom) if (m == 216 and world == 1 and not force_dist) else None,
+            "traffic": traffic,
             "per_class": {k: {"ms_total": v["ms"], "launches": v["count"],
                               "GBps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 and v["bytes"] > 0 else None}
                           for k, v in prof.items()},
         })
+        sp = prof.get("spmv")
+        if sp and sp["count"] > 0 and sp["ms"] > 0:
+            gbs = sp["bytes"] / (sp["ms"] * 1e-3) / 1e9
+            # BASELINE.json's metric names "SpMV GB/s vs HBM peak": bytes = what THIS layout streams
+            # (bytes_per_nnz * nnz + 4 (n+1) + 16 n) / HIP-event time; `csr_equivalent_GBps` prices the same
+            # launch at the 12 B/nnz of plain CSR (SURVEY 8d's formula) -- a speed, not a traffic figure
+            roof["spmv"] = {"layout": layout, "GBps": gbs, "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms": sp["ms"] / sp["count"],
+                            "bytes_per_launch": sp["bytes"] / sp["count"],
+                            "csr_equivalent_GBps": (12.0 * nnz_global + 4.0 * (n + 1) + 16.0 * n) / world / (sp["ms"] / sp["count"] * 1e-3) / 1e9}
     else:
-        roof.update({"kernel": "fused step (no per-kernel events)", "achieved": fused_gbs, "frac": fused_gbs / HBM_PEAK_GBS})
+        roof.update({"kernel": "fused step (no per-kernel events)", "achieved": moved_gbs, "frac": moved_gbs / HBM_PEAK_GBS})
     roof["fused_step"] = {
-        "what": "algorithmic bytes of SpMV + DGKS (both passes when taken) per Arnoldi step / expansion wall time, per GPU",
-        "achieved": fused_gbs,
-        "frac": fused_gbs / HBM_PEAK_GBS,
-        "frac_of_measured_copy_ceiling": fused_gbs / 6290.0,
+        "what": "SpMV + DGKS per Arnoldi step over the expansion wall time, per GPU.  moved_*: bytes the launched kernels must "
+                "move (three passes over V when the second DGKS pass is taken) -- the traffic-true figure, quote this one; "
+                "algorithmic_*: SURVEY 8d's four-pass formula of the un-fused sequence divided by the same time (rewards "
+                "fusion, can exceed what a copy reaches)",
+        "moved_bytes": state["moved"],
+        "moved_GBps": moved_gbs,
+        "moved_frac": moved_gbs / HBM_PEAK_GBS,
+        "moved_frac_of_measured_copy_ceiling": moved_gbs / 6290.0,
+        "algorithmic_GBps": fused_gbs,
+        "algorithmic_frac": fused_gbs / HBM_PEAK_GBS,
         "expand_seconds": state["t_expand"],
         "restart_seconds": state["t_restart"],
     }
     out["roofline"] = roof
 
     # ---- CPU baseline: the reference's op sequence on the host cores (rank 0, N = 1 only) ----
-    if world == 1 and rank == 0 and not args.no_cpu_baseline and A_host is not None:
-        try:
-            from oracle import cpuref
+    if with_cpu_baseline and world == 1 and rank == 0 and not args.no_cpu_baseline and A_host is not None:
+        out["cpu_baseline"] = cpu_baseline(pkg, A_host, n, nev, which, mindim, maxdim)
+    return out
 
-            A = pkg.matrices.to_scipy(*A_host, n)
-            tb = cpuref.timed_cycles_csr(A, nev=nev, which=which, mindim=mindim, maxdim=maxdim, cycles=3)
-            out["cpu_baseline"] = {
-                "value": tb["steps"] / tb["seconds"],
-                "unit": "iters/s",
-                "cores": tb["threads"],
-                "kind": "port",
-                "sample": f"same matrix and parameters; 3 restart cycles = {tb['steps']} Arnoldi iterations after the initial "
-                          f"expansion (untimed), {tb['seconds']:.1f} s; un-fused reference op sequence with OpenMP over rows "
-                          f"(spmv {tb['t_spmv']:.1f} s, orthogonalize {tb['t_orth']:.1f} s, rotation {tb['t_rot']:.1f} s)",
-            }
-        except Exception as e:  # noqa: BLE001
-            out["cpu_baseline"] = {"value": None, "unit": "iters/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
 
-    # Tear everything down first and flush the C stdio buffers (RCCL prints a version banner through printf,
-    # which sits in the C buffer until exit when stdout is a pipe): the JSON line must be the LAST line on stdout.
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    import ctypes
+def cpu_baseline(pkg, A_host, n, nev, which, mindim, maxdim):
+    try:
+        from oracle import cpuref
 
-    sys.stdout.flush()
-    ctypes.CDLL(None).fflush(None)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+        A = pkg.matrices.to_scipy(*A_host, n)
+        tb = cpuref.timed_cycles_csr(A, nev=nev, which=which, mindim=mindim, maxdim=maxdim, cycles=3)
+        return {
+            "value": tb["steps"] / tb["seconds"],
+            "unit": "iters/s",
+            "cores": tb["threads"],
+            "kind": "port",
+            "sample": f"same matrix and parameters; 3 restart cycles = {tb['steps']} Arnoldi iterations after the initial "
+                      f"expansion (untimed), {tb['seconds']:.1f} s; un-fused reference op sequence with OpenMP over rows "
+                      f"(spmv {tb['t_spmv']:.1f} s, orthogonalize {tb['t_orth']:.1f} s, rotation {tb['t_rot']:.1f} s)",
+        }
+    except Exception as e:  # noqa: BLE001
+        return {"value": None, "unit": "iters/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
 
 
 if __name__ == "__main__":

@@ -145,9 +145,11 @@ int ks_operator_apply_raw(ks_operator* op, const void* x_dev, void* y_dev);
 int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t row_begin,
                         int maxdim, int dtype, ks_workspace** out);
 int ks_workspace_destroy(ks_workspace* ws);
-/* What the placement search of ks_workspace_create did: candidates timed (0: basis too small,
- * search skipped) and the calibration time of the kept / the slowest candidate. */
-int ks_workspace_placement(const ks_workspace* ws, int* candidates, double* best_ms, double* worst_ms);
+/* What the placement search of ks_workspace_create did: candidates timed (0: basis too small or
+ * KS_PLACE_TRIALS=1, search skipped), the calibration time of the kept / the slowest candidate, and how many
+ * candidate allocations were refused or skipped for lack of free memory.  The search holds at most
+ * KS_PLACE_MAX_X (default 2) times the basis size at once. */
+int ks_workspace_placement(const ks_workspace* ws, int* candidates, double* best_ms, double* worst_ms, int* refused);
 /* Debugging aid: with KS_GUARD=1 in the environment a workspace puts 1 MiB canary zones on both sides of the
  * basis; *intact = 0 if any kernel wrote outside V (always 1 without KS_GUARD). */
 int ks_workspace_check_guard(ks_workspace* ws, int* intact);
