@@ -60,6 +60,9 @@ class ks_expand_stats(C.Structure):
 
 HOST_APPLY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 DEVICE_APPLY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+HOST_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                               C.POINTER(C.c_void_p), C.POINTER(C.c_int64))
 
 # name -> argtypes ; every function returns int except ks_last_error_string
 vp, i32, i64, u64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_double
@@ -69,6 +72,7 @@ PROTOTYPES = {
     "ks_ctx_create": [i32, P(vp)],
     "ks_comm_unique_id": [vp],
     "ks_ctx_create_dist": [i32, i32, i32, vp, P(vp)],
+    "ks_ctx_create_hostcomm": [i32, i32, i32, HOST_ALLREDUCE_FN, HOST_EXCHANGE_FN, vp, P(vp)],
     "ks_ctx_create_p2p": [i32, i32, i32, P(vp)],
     "ks_ctx_p2p_handle": [vp, vp],
     "ks_ctx_p2p_attach": [vp, vp],

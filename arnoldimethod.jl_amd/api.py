@@ -83,10 +83,44 @@ def _dtype_code(dt) -> int:
 class Context:
     """One GPU (+ optionally one rank of a multi-GPU job: RCCL communicator or peer-to-peer regions)."""
 
-    def __init__(self, device: int = 0, rank: int = 0, nranks: int = 1, unique_id: bytes | None = None, p2p: bool = False):
+    def __init__(self, device: int = 0, rank: int = 0, nranks: int = 1, unique_id: bytes | None = None, p2p: bool = False,
+                 hostcomm=None):
+        """`hostcomm = (allreduce(buf: np.ndarray) -> None, exchange(peers, sendbufs, recvbufs) -> None)` selects the
+        host-staged transport (ks_ctx_create_hostcomm): numpy views of the pinned staging buffers are handed to the
+        two callables, which must sum `buf` in place over all ranks / fill `recvbufs[i]` from rank `peers[i]`."""
         L = _lib.load()
         h = C.c_void_p()
-        if p2p:
+        self._keep = ()
+        if hostcomm is not None:
+            allreduce, exchange = hostcomm
+            errs = []
+
+            def _ar(_user, buf, count):
+                try:
+                    allreduce(np.ctypeslib.as_array(buf, shape=(count,)))
+                    return 0
+                except Exception as e:  # noqa: BLE001 - must not propagate through C
+                    errs.append(e)
+                    return 1
+
+            def _ex(_user, npeers, peers, sbufs, sbytes, rbufs, rbytes):
+                try:
+                    pl = [int(peers[i]) for i in range(npeers)]
+                    sb = [np.ctypeslib.as_array(C.cast(sbufs[i], C.POINTER(C.c_uint8)), shape=(int(sbytes[i]),)) if sbytes[i] else np.zeros(0, np.uint8)
+                          for i in range(npeers)]
+                    rb = [np.ctypeslib.as_array(C.cast(rbufs[i], C.POINTER(C.c_uint8)), shape=(int(rbytes[i]),)) if rbytes[i] else np.zeros(0, np.uint8)
+                          for i in range(npeers)]
+                    exchange(pl, sb, rb)
+                    return 0
+                except Exception as e:  # noqa: BLE001
+                    errs.append(e)
+                    return 1
+
+            cb1, cb2 = _lib.HOST_ALLREDUCE_FN(_ar), _lib.HOST_EXCHANGE_FN(_ex)
+            self._keep = (cb1, cb2, errs)
+            self.comm_errors = errs
+            check(L.ks_ctx_create_hostcomm(device, rank, nranks, cb1, cb2, None, C.byref(h)))
+        elif p2p:
             check(L.ks_ctx_create_p2p(device, rank, nranks, C.byref(h)))
         elif nranks > 1 or unique_id is not None:
             assert unique_id is not None and len(unique_id) == 128

@@ -125,13 +125,26 @@ struct ks_ctx {
     int cap = 0;
     ksd::P2pDev dev{};
   } p2p;
+  // host-staged transport (ks_ctx_create_hostcomm): the SAME launch structure as the RCCL transport (reduce-only
+  // kernels -> all-reduce -> post kernels; pack kernel -> neighbour exchange -> SpMV on the ghost buffer), but each
+  // exchange is staged through pinned host memory and executed by two caller-supplied functions (MPI, gloo, ...).
+  // Exists so that the sequence around every ncclAllReduce / ncclSend / ncclRecv call site can run with several real
+  // ranks on a ONE-GPU box (RCCL refuses two ranks per device) and as a transport of last resort on fabrics RCCL
+  // does not cover.  Communication only: no arithmetic ever happens on the host.
+  struct HostComm {
+    ks_host_allreduce_fn allreduce = nullptr;
+    ks_host_exchange_fn exchange = nullptr;
+    void* user = nullptr;
+    double* stage = nullptr;  // pinned
+    size_t stage_doubles = 0;
+  } hc;
   int num_cu = 256;
   int bpc = 6;  // streaming workgroups per CU (KS_BPC; 6 measured best on MI355X, tools/streambench.hip)
   int nblocks() const { return num_cu * bpc; }
   void use() const { KS_HIP(hipSetDevice(device)); }
   // A context created with ks_ctx_create_dist / ks_ctx_create_p2p always takes the collective code path
   // (even with nranks == 1, which is how that path is exercised on a single-GPU box).
-  bool distributed() const { return comm != nullptr || p2p.attached; }
+  bool distributed() const { return comm != nullptr || p2p.attached || hc.allreduce != nullptr; }
   // in-place sum over ranks of `count` doubles living in device memory
   void allreduce(double* dev, int count) {
     if (p2p.attached) {
@@ -140,6 +153,17 @@ struct ks_ctx {
       ksd::k_p2p_allreduce<<<(waves + 3) / 4, 256, 0, stream>>>(dev, count, p2p.dev);
     } else if (comm) {
       KS_NCCL(ncclAllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, comm, stream));
+    } else if (hc.allreduce) {
+      if ((size_t)count > hc.stage_doubles) {
+        if (hc.stage) { KS_HIP(hipStreamSynchronize(stream)); (void)hipHostFree(hc.stage); hc.stage = nullptr; }
+        hc.stage_doubles = (size_t)std::max(count, 256);
+        KS_HIP(hipHostMalloc(&hc.stage, hc.stage_doubles * 8));
+      }
+      KS_HIP(hipMemcpyAsync(hc.stage, dev, (size_t)count * 8, hipMemcpyDeviceToHost, stream));
+      KS_HIP(hipStreamSynchronize(stream));
+      const int rc = hc.allreduce(hc.user, hc.stage, count);
+      KS_REQUIRE(rc == 0, KS_ERR_COMM, "host all-reduce callback returned " + std::to_string(rc));
+      KS_HIP(hipMemcpyAsync(dev, hc.stage, (size_t)count * 8, hipMemcpyHostToDevice, stream));
     }
   }
   // a bounded spin of the peer-to-peer kernels gave up: report instead of computing on garbage
@@ -322,6 +346,9 @@ template <class D> struct CsrOp : ks_operator {
   int64_t nscatter = 0;             // number of packed entries (send_idx holds only these)
   // peer-to-peer halo (ks_p2p.hpp): ghost lives (double-buffered) in this rank's shared arena, neighbours
   // store into it directly
+  // host-staged halo (ks_ctx_create_hostcomm): pinned send / receive images of the plan
+  D* hsend = nullptr;
+  D* hrecv = nullptr;
   bool p2p_halo = false;
   int64_t ghost_stride = 0;         // elements between the two ghost slots
   size_t arena_lo = 0, arena_hi = 0;
@@ -335,6 +362,7 @@ template <class D> struct CsrOp : ks_operator {
     } else {
       (void)hipFree(ghost);
     }
+    (void)hipHostFree(hsend); (void)hipHostFree(hrecv);
     (void)hipFree(sendbuf); (void)hipFree(send_idx); (void)hipFree(send_idx_all);
     (void)hipFree(codes); (void)hipFree(ddelta);
   }
@@ -357,6 +385,26 @@ template <class D> struct CsrOp : ks_operator {
         ksd::k_gather<D><<<gb, kBlock, 0, s>>>(x, send_idx, sendbuf, nscatter, st);
       }
       constexpr int dpe = sizeof(D) / 8;  // doubles per element
+      if (ctx->hc.exchange) {
+        // host-staged: the same plan (in-place runs, packed lists, consecutive ghost slots) through pinned memory
+        const size_t np_ = neigh.size();
+        std::vector<const void*> sp_(np_);
+        std::vector<void*> rp_(np_);
+        std::vector<int64_t> sb_(np_), rb_(np_);
+        for (size_t p = 0; p < np_; ++p) {
+          const int64_t sc = send_ptr[p + 1] - send_ptr[p], rc = recv_ptr[p + 1] - recv_ptr[p];
+          if (sc > 0) {
+            const D* src = send_first[p] >= 0 ? x + send_first[p] : sendbuf + pack_ptr[p];
+            KS_HIP(hipMemcpyAsync(hsend + send_ptr[p], src, (size_t)sc * sizeof(D), hipMemcpyDeviceToHost, s));
+          }
+          sp_[p] = hsend + send_ptr[p]; sb_[p] = sc * (int64_t)sizeof(D);
+          rp_[p] = hrecv + recv_ptr[p]; rb_[p] = rc * (int64_t)sizeof(D);
+        }
+        KS_HIP(hipStreamSynchronize(s));
+        const int rc = ctx->hc.exchange(ctx->hc.user, (int)np_, neigh.data(), sp_.data(), sb_.data(), rp_.data(), rb_.data());
+        KS_REQUIRE(rc == 0, KS_ERR_COMM, "host exchange callback returned " + std::to_string(rc));
+        if (nghost > 0) KS_HIP(hipMemcpyAsync(ghost, hrecv, (size_t)nghost * sizeof(D), hipMemcpyHostToDevice, s));
+      } else {
       KS_NCCL(ncclGroupStart());
       for (size_t p = 0; p < neigh.size(); ++p) {
         const int64_t sc = send_ptr[p + 1] - send_ptr[p], rc = recv_ptr[p + 1] - recv_ptr[p];
@@ -367,6 +415,7 @@ template <class D> struct CsrOp : ks_operator {
         if (rc > 0) KS_NCCL(ncclRecv(ghost + recv_ptr[p], (size_t)rc * dpe, ncclDouble, neigh[p], ctx->comm, s));
       }
       KS_NCCL(ncclGroupEnd());
+      }
     }
     if (ntiles > 0) {
       // algorithmic bytes: 12 nnz + 4 (n+1) + 16 n   (8 -> 16 for complex); 4 nnz in the
@@ -550,11 +599,19 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
       std::vector<D> dv;
       bool ok = true;
       int max_row = 0;
+      Key ckey[8];
+      int cid[8], ncache = 0, cnext = 0;
       for (int64_t r = 0; r < nrows && ok; ++r) {
         max_row = std::max(max_row, rp[r + 1] - rp[r]);
         for (int32_t p = rp[r]; p < rp[r + 1]; ++p) {
           Key k{0, 0, (int64_t)ci[p] - r};
           std::memcpy(&k, &vv[p], sizeof(D));
+          // stencils cycle through a handful of keys: a tiny recent-key cache in front of the hash map
+          // (n = 1e8 rows / 7e8 non-zeros convert in seconds instead of half a minute)
+          bool hit = false;
+          for (int q = 0; q < ncache; ++q)
+            if (ckey[q] == k) { codes[p] = (uint8_t)cid[q]; hit = true; break; }
+          if (hit) continue;
           auto it = index.find(k);
           int id;
           if (it == index.end()) {
@@ -567,6 +624,10 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
             id = it->second;
           }
           codes[p] = (uint8_t)id;
+          ckey[cnext] = k;
+          cid[cnext] = id;
+          cnext = (cnext + 1) & 7;
+          if (ncache < 8) ++ncache;
         }
       }
       if (ok) {
@@ -1534,6 +1595,22 @@ int ks_ctx_create_dist(int device, int rank, int nranks, const void* unique_id12
   });
 }
 
+int ks_ctx_create_hostcomm(int device, int rank, int nranks, ks_host_allreduce_fn allreduce, ks_host_exchange_fn exchange,
+                           void* user, ks_ctx** out) {
+  return guarded([&] {
+    KS_REQUIRE(out && allreduce && exchange, KS_ERR_ARGUMENT, "null argument");
+    KS_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, KS_ERR_ARGUMENT, "bad rank/nranks");
+    auto c = std::make_unique<ks_ctx>();
+    ctx_init_device(c.get(), device);
+    c->rank = rank;
+    c->nranks = nranks;
+    c->hc.allreduce = allreduce;
+    c->hc.exchange = exchange;
+    c->hc.user = user;
+    *out = c.release();
+  });
+}
+
 int ks_ctx_create_p2p(int device, int rank, int nranks, ks_ctx** out) {
   return guarded([&] {
     KS_REQUIRE(out, KS_ERR_ARGUMENT, "null out");
@@ -1573,6 +1650,7 @@ int ks_ctx_destroy(ks_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
+    if (ctx->hc.stage) (void)hipHostFree(ctx->hc.stage);
     p2p_release(ctx);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1682,6 +1760,10 @@ int ks_operator_csr_dist(ks_ctx* ctx, int64_t nrows_local, int64_t nghost, int64
       KS_HIP(hipMalloc(&op->send_idx, std::max<size_t>(packed.size() * 4, 16)));
       if (!packed.empty()) KS_HIP(hipMemcpy(op->send_idx, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
       KS_REQUIRE(nneigh == 0 || ctx->distributed(), KS_ERR_ARGUMENT, "halo plan needs a distributed context");
+      if (ctx->hc.exchange) {
+        KS_HIP(hipHostMalloc(&op->hsend, std::max<size_t>((size_t)send_ptr[nneigh] * sizeof(D), 16)));
+        KS_HIP(hipHostMalloc(&op->hrecv, std::max<size_t>((size_t)nghost * sizeof(D), 16)));
+      }
       if (op->p2p_halo) {
         // COLLECTIVE in peer-to-peer mode: every rank publishes where its ghost vector lives in its shared
         // arena and, per sender, at which offset that sender's entries go (and how many it expects)

@@ -122,6 +122,7 @@ def make_context(api, dist, local_rank: int, transport: str | None = None):
     """One library context per rank.
 
     transport "rccl" (default): rank 0's RCCL unique id is broadcast through the process group.
+    transport "host": the host-staged transport on the same process group (debugging / RCCL-free fabrics).
     transport "p2p": no RCCL at all -- every rank allocates its shared region, the 64-byte IPC handles are
     all-gathered through the process group (any backend) and mapped (csrc/ks_p2p.hpp).  KS_TRANSPORT
     selects the default."""
@@ -137,9 +138,34 @@ def make_context(api, dist, local_rank: int, transport: str | None = None):
             ctx.p2p_attach(handles)
             dist.barrier()
         return ctx
+    if transport == "host":
+        return api.Context(local_rank, rank, world, hostcomm=host_transport(dist))
     box = [api.Context.unique_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
     return api.Context(local_rank, rank, world, box[0])
+
+
+def host_transport(dist):
+    """The two callables of the host-staged transport (ks_ctx_create_hostcomm) on a torch.distributed process group
+    of any backend with CPU tensors (gloo): sum in place / grouped neighbour exchange.  gloo's all-reduce is
+    deterministic and delivers the same bits to every rank, which the replicated DGKS decisions need."""
+    import torch
+
+    def allreduce(buf):
+        t = torch.from_numpy(buf)
+        dist.all_reduce(t)
+
+    def exchange(peers, sendbufs, recvbufs):
+        reqs = []
+        for q, sb, rb in zip(peers, sendbufs, recvbufs):
+            if len(sb):
+                reqs.append(dist.isend(torch.from_numpy(sb), q))
+            if len(rb):
+                reqs.append(dist.irecv(torch.from_numpy(rb), q))
+        for r in reqs:
+            r.wait()
+
+    return allreduce, exchange
 
 
 def setup_laplace3d(pkg, dist, m: int, maxdim: int, local_rank: int, transport: str | None = None):

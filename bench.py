@@ -112,7 +112,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         if world > 1 and same_device:
             dist.init_process_group("gloo")
-            os.environ["KS_BENCH_TRANSPORTS"] = "p2p"
+            # RCCL cannot run here: measure the peer-to-peer transport and the host-staged one (which executes the RCCL
+            # transport's launch structure with the exchanges staged through gloo)
+            os.environ["KS_BENCH_TRANSPORTS"] = ",".join(
+                t for t in os.environ.get("KS_BENCH_TRANSPORTS", "p2p,host").split(",") if t in ("p2p", "host")) or "p2p"
         elif world > 1:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -225,7 +228,7 @@ def main():
     if dist is None or (world == 1 and "KS_BENCH_TRANSPORTS" not in os.environ):
         order = ["single"]
     else:  # (KS_FORCE_DIST=1 KS_BENCH_TRANSPORTS=rccl,p2p exercises this selection logic on a single rank)
-        order = [t for t in os.environ.get("KS_BENCH_TRANSPORTS", "p2p,rccl").split(",") if t in ("rccl", "p2p")] or ["rccl"]
+        order = [t for t in os.environ.get("KS_BENCH_TRANSPORTS", "p2p,rccl").split(",") if t in ("rccl", "p2p", "host")] or ["rccl"]
     inject = os.environ.get("KS_BENCH_INJECT_FAIL", "")
     deadline_s = float(os.environ.get("KS_BENCH_PASS_DEADLINE_S", "300"))
 
@@ -294,12 +297,15 @@ def make_line(args, pkg, passes, order, world, rank, force_dist, wl, with_cpu_ba
     """The ONE JSON line, from whatever passes completed."""
     m, n, nev, mindim, maxdim, which = wl["m"], wl["n"], wl["nev"], wl["mindim"], wl["maxdim"], wl["which"]
     valid = [t for t in order if t in passes and "error" not in passes[t]]
-    if "p2p" in valid and "rccl" in valid:
-        a, b = passes["rccl"]["state"], passes["p2p"]["state"]
+    # passes that completed must agree with each other (same restart trail, same Ritz values); the collective
+    # transports (rccl, host) are the reference, a deviating peer-to-peer pass is dropped
+    ref = next((t for t in ("rccl", "host") if t in valid), None)
+    if ref is not None and "p2p" in valid:
+        a, b = passes[ref]["state"], passes["p2p"]["state"]
         same = a["trail"] == b["trail"] and a["ritz"].shape == b["ritz"].shape and \
             float(np.abs(a["ritz"] - b["ritz"]).max()) <= 1e-8 * max(1.0, float(np.abs(a["ritz"]).max()))
         if not same:
-            passes["p2p"] = {"error": "results differ from the RCCL pass", **{k: v for k, v in passes["p2p"].items() if k == "elapsed"}}
+            passes["p2p"] = {"error": f"results differ from the {ref} pass", **{k: v for k, v in passes["p2p"].items() if k == "elapsed"}}
             valid.remove("p2p")
     out = {
         "metric": "arnoldi_iters_per_sec", "value": None, "unit": "iters/s", "n_gpus": world, "steps": args.steps,

@@ -82,6 +82,23 @@ int ks_ctx_create_dist(int device, int rank, int nranks, const void* unique_id12
 int ks_ctx_create_p2p(int device, int rank, int nranks, ks_ctx** out);
 int ks_ctx_p2p_handle(ks_ctx* ctx, void* out64);
 int ks_ctx_p2p_attach(ks_ctx* ctx, const void* handles);
+/* Multi-GPU context on a HOST-STAGED transport: the library runs exactly the launch structure of the RCCL
+ * transport (reduce-only kernels -> all-reduce -> post kernels, src/expansion.jl:84,88,93,96 sharded by rows;
+ * pack kernel -> neighbour exchange -> SpMV on the ghost buffer, src/expansion.jl:121), but every exchange is
+ * copied to pinned host memory and handed to two caller-supplied functions, e.g. MPI_Allreduce /
+ * MPI_Sendrecv or torch.distributed on gloo:
+ *   allreduce(user, buf, count)            in-place sum over all ranks of `count` doubles; every rank must
+ *                                          obtain the bit-identical result (the DGKS branches depend on it)
+ *   exchange(user, npeers, peers, sendbufs, send_bytes, recvbufs, recv_bytes)
+ *                                          one grouped neighbour exchange (send i -> peers[i], receive from it)
+ * Both return 0 on success; anything else surfaces as KS_ERR_COMM.  No arithmetic happens on the host.  This is how
+ * the code around every RCCL call site is exercised with several real ranks on a one-GPU box (RCCL refuses two
+ * ranks per device), and a transport of last resort where RCCL is unavailable.  No reference equivalent. */
+typedef int (*ks_host_allreduce_fn)(void* user, double* buf, int count);
+typedef int (*ks_host_exchange_fn)(void* user, int npeers, const int32_t* peers, const void* const* sendbufs,
+                                   const int64_t* send_bytes, void* const* recvbufs, const int64_t* recv_bytes);
+int ks_ctx_create_hostcomm(int device, int rank, int nranks, ks_host_allreduce_fn allreduce,
+                           ks_host_exchange_fn exchange, void* user, ks_ctx** out);
 int ks_ctx_destroy(ks_ctx* ctx);
 int ks_ctx_synchronize(ks_ctx* ctx);
 int ks_ctx_rank(const ks_ctx* ctx, int* rank, int* nranks);

@@ -103,7 +103,8 @@ def test_wide_fused_and_first_eager_size_end_to_end(dtype, maxdim):
     assert hist.converged and hist.mvproducts == rhist.mvproducts and hist.nconverged == rhist.nconverged
     np.testing.assert_allclose(np.sort_complex(dec.eigenvalues), np.sort_complex(ref.eigenvalues), atol=1e-8)
     Q, R = dec.Q, np.array(dec.R)
-    assert np.linalg.norm(A @ Q - Q @ R) < 1e-7
+    # per-vector criterion tol * |lambda| (src/run.jl:206-208), |lambda| <= 60, Frobenius norm over nconverged columns
+    assert np.linalg.norm(A @ Q - Q @ R) < 10 * 1e-9 * 60 * np.sqrt(Q.shape[1])
     assert np.linalg.norm(Q.conj().T @ Q - np.eye(Q.shape[1])) < 100 * EPS * Q.shape[1]
 
 

@@ -655,20 +655,22 @@ def _run_ranks(nproc, mode, m=16, extra_env=None, timeout=420):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, KS_SAME_DEVICE="1", KS_TRANSPORT="p2p", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    env = dict(os.environ, KS_SAME_DEVICE="1", KS_TRANSPORT="p2p", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tools", "dist_gpu_check.py"), mode, str(m)]
     return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
 
 
-@pytest.mark.parametrize("nproc,mode", [(2, "laplace"), (3, "laplace"), (2, "hashed"), (4, "hashed"), (2, "wide"), (3, "complex")])
+@pytest.mark.parametrize("nproc,mode", [(2, "laplace"), (3, "laplace"), (2, "hashed"), (4, "hashed"), (2, "wide"), (3, "complex"), (2, "eager")])
 def test_row_partitioned_solver_several_ranks_one_gpu(nproc, mode):
     """The multi-rank product path with REAL peers: `nproc` processes share device 0 and exchange through
     IPC-mapped regions (csrc/ks_p2p.hpp).  Every rank must converge with a small device-side residual and
     rank 0's single-GPU repeat of the same problem must need the same number of matrix-vector products
     and find the same Ritz values (tools/dist_gpu_check.py).  laplace: plane ghosts, contiguous send
-    runs; hashed: every rank neighbours every other, scattered send lists; wide: maxdim 60 (eager DGKS
-    sequence, stand-alone reductions); complex: ComplexF64 elements."""
+    runs; hashed: every rank neighbours every other, scattered send lists; wide: maxdim 60 (fused path with 15 columns
+    per wave, inner products in two launches); complex: ComplexF64 elements (fused, three doubles per exchange);
+    eager: maxdim 70 (un-fused DGKS sequence, stand-alone reductions)."""
     r = _run_ranks(nproc, mode)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     # (ranks print concurrently, lines may interleave: count occurrences)
@@ -681,6 +683,31 @@ def test_reduce_allreduce_post_structure_with_real_ranks():
     r = _run_ranks(3, "laplace", extra_env={"KS_P2P_NO_FOLD": "1"})
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("-> OK") == 3 and "same: True" in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("nproc,mode", [(2, "laplace"), (3, "hashed"), (2, "complex"), (2, "wide"), (3, "eager")])
+def test_collective_launch_structure_with_real_ranks_host_staged(nproc, mode):
+    """The RCCL transport's code path -- reduce-only kernels -> all-reduce -> post kernels; pack kernel -> grouped
+    neighbour exchange -> SpMV on the ghost buffer -- with REAL ranks: RCCL refuses two ranks per device, so the
+    exchanges run on the host-staged transport (ks_ctx_create_hostcomm over gloo), which sits at exactly the call
+    sites of ncclAllReduce / ncclSend / ncclRecv.  Same acceptance as the peer-to-peer runs: every rank converges,
+    rank 0's single-GPU repeat needs the same number of products and finds the same Ritz values.  `eager`:
+    maxdim 70 > 64, the un-fused sequence with its own reductions."""
+    r = _run_ranks(nproc, mode, extra_env={"KS_TRANSPORT": "host"})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("-> OK") == nproc and "same: True" in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("m,transport", [(96, "host"), (464, "p2p")])
+def test_config5_row_partition_8_ranks(m, transport):
+    """BASELINE config 5 (3-D Laplacian n = 464^3 ~ 10^8 over 8 ranks, nev = 20): 8 processes on device 0, each owning
+    464 x 464 x 58 rows (4.1 GB of basis) -- the true per-rank size -- against rank 0's single-process run of the
+    WHOLE problem (V = 33 GB on one GPU): identical restart trail, Ritz values to 1e-9, and the reference's two
+    invariants ||A V_k - V_{k+1} H_k||_F <= 1e-11 ||H||_F, ||V'V - I|| <= sqrt(eps)/100 (test/expansion.jl:29-30)
+    evaluated on the device for both runs.  m = 96 repeats it small on the host-staged (RCCL-structured) transport."""
+    r = _run_ranks(8, "shard5", m=m, extra_env={"KS_TRANSPORT": transport}, timeout=1000)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-3000:]
+    assert r.stdout.count("-> OK") == 8 and "same: True" in r.stdout and "invariants: True" in r.stdout, r.stdout[-4000:]
 
 
 def test_lost_peer_is_reported_not_hung():

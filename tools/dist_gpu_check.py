@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Multi-process check of the distributed GPU path (also driven by tests/test_gpu_parity.py).
 
-On a multi-GPU node: one rank per GPU.  On a single-GPU box: KS_SAME_DEVICE=1 KS_TRANSPORT=p2p puts all
-ranks on device 0 (RCCL refuses several ranks per device, the peer-to-peer transport does not care).
+On a multi-GPU node: one rank per GPU.  On a single-GPU box: KS_SAME_DEVICE=1 KS_TRANSPORT=p2p|host puts all
+ranks on device 0 (RCCL refuses several ranks per device; the peer-to-peer transport does not care, and the
+host-staged transport runs the RCCL transport's launch structure with the exchanges going through gloo).
 
     KS_SAME_DEVICE=1 KS_TRANSPORT=p2p python -m torch.distributed.run --nproc-per-node 2 \\
         --master-addr 127.0.0.1 --master-port 29517 tools/dist_gpu_check.py MODE [m]
@@ -13,9 +14,13 @@ MODE
            repeats the solve on a single-GPU context: same mvproducts, same Ritz values.
   hashed   nonsymmetric matrix with hashed columns (every rank is everybody's neighbour, scattered
            send lists); distributed vs single-GPU run: same mvproducts, same Ritz values, ||AQ - QR||.
-  wide     the same matrix with maxdim = 60 > 40: the eager (un-fused) DGKS sequence with stand-alone
-           reductions (k_p2p_allreduce), chunked inner products, out-of-place rotation.
+  wide     the same matrix with maxdim = 60: fused path at 15 columns per wave, inner products in two launches.
+  eager    maxdim = 70 > 64: the eager (un-fused) DGKS sequence with stand-alone reductions, chunked inner
+           products, out-of-place rotation.
   complex  ComplexF64 variant (complex diagonal shift): 16-byte elements through halo and reductions.
+  shard5   BASELINE config 5: m^3 Laplacian (m = 464 with 8 ranks = the true per-rank size 464 x 464 x 58), nev = 20,
+           mindim/maxdim = 20/40, two restart cycles: same restart trail and Ritz values as rank 0's single-process
+           run of the whole problem, Arnoldi relation and orthogonality evaluated on the device for both.
   timeout  rank 1 never joins; rank 0 must get CommTimeout (KS_ERR_COMM) after KS_P2P_TIMEOUT_S
            seconds instead of hanging.
 """
@@ -33,6 +38,72 @@ from __graft_entry__ import import_package  # noqa: E402
 
 ks = import_package()
 from arnoldimethod_jl_amd import _lib, api, dist as ksd  # noqa: E402
+
+
+def run_cycles(op, ws, v1, cycles, nev=20, mindim=20, maxdim=40):
+    """bench.py's state machine (src/run.jl:267-368): initial expansion, then `cycles` restart cycles.  Returns the
+    restart trail [(k, nlock)], the Ritz values entering the last restart and the device-side invariants."""
+    tol = float(np.sqrt(np.finfo(np.float64).eps))
+    ws.reinitialize(0, v1)
+    ws.iterate_arnoldi(op, 1, mindim)
+    k, active, trail, ritz, steps = mindim, 0, [], None, mindim
+    for _ in range(cycles):
+        ws.iterate_arnoldi(op, k + 1, maxdim)
+        steps += maxdim - k
+        r = ws.restart(active, nev, "SR", tol, mindim, maxdim)
+        k, active = r["k"], r["nlock"]
+        trail.append((k, active))
+        ritz = np.sort_complex(r["eigenvalues"][:k])
+    H = np.array(ws.H)
+    rel, orth = ws.arnoldi_relation(op, k)  # ||A V_k - V_{k+1} H_k||_F and ||V'V - I||_F on the device (collective)
+    return dict(trail=trail, ritz=ritz, steps=steps, rel=rel, orth=orth, hnorm=float(np.linalg.norm(H[: k + 1, :k])), k=k)
+
+
+def shard5(rank, world, ctx, m, cycles=2):
+    """BASELINE config 5 at TRUE per-rank size when m = 464 and world = 8 (464 x 464 x 58 rows per rank, 4.1 GB of
+    basis each): the row-partitioned run must walk the same restart trail and find the same Ritz values as the
+    single-process run of the whole m^3 problem (rank 0 repeats it: V = 33 GB on one GPU), and both must satisfy the
+    reference's two invariants (test/expansion.jl:29-30) evaluated on the device."""
+    import time
+
+    n = m ** 3
+    offs = ksd.partition_rows(n, world, granule=m * m)
+    r0, r1 = int(offs[rank]), int(offs[rank + 1])
+    t0 = time.time()
+    ip, ix, dv = ks.matrices.laplace3d_csr(m, m, m, r0, r1, index_dtype=np.int64)
+    plan = ksd.build_halo_plan(ix, offs, rank, dist)
+    op = ksd.dist_operator(api, ctx, ip, dv, plan, n)
+    del ip, ix, dv
+    ws = api.ArnoldiWorkspace(r1 - r0, 40, np.float64, ctx=ctx, n_global=n, row_begin=r0)
+    d = run_cycles(op, ws, ks.matrices.start_vector(r1 - r0, row_begin=r0), cycles)
+    t1 = time.time()
+    ok = d["rel"] <= 1e-12 * d["hnorm"] * 10 and d["orth"] <= np.sqrt(np.finfo(np.float64).eps) / 100
+    msg = (f"rows {r0}:{r1} ({r1 - r0}) trail={d['trail']} steps={d['steps']} rel={d['rel']:.2e} (|H|={d['hnorm']:.2e}) "
+           f"orth={d['orth']:.2e} [{t1 - t0:.1f} s]")
+    ws.close()
+    op.close()
+    if rank == 0:
+        t0 = time.time()
+        A = ks.matrices.to_scipy(*ks.matrices.laplace3d_csr_chunked(m, m, m), n)
+        op1 = ks.csr_operator(A)
+        del A
+        t1 = time.time()
+        ws1 = ks.ArnoldiWorkspace(n, 40, np.float64)
+        s = run_cycles(op1, ws1, ks.matrices.start_vector(n), cycles)
+        t2 = time.time()
+        dv_ = float(np.abs(s["ritz"] - d["ritz"]).max()) if s["ritz"].shape == d["ritz"].shape else float("nan")
+        ok1 = s["rel"] <= 1e-12 * s["hnorm"] * 10 and s["orth"] <= np.sqrt(np.finfo(np.float64).eps) / 100
+        same = s["trail"] == d["trail"] and s["steps"] == d["steps"] and dv_ <= 1e-9 * max(1.0, float(np.abs(s["ritz"]).max()))
+        print(f"[rank 0] single-GPU run of the whole {m}^3 problem (n={n}, V={8 * n * 41 / 1e9:.1f} GB): trail={s['trail']} "
+              f"rel={s['rel']:.2e} (|H|={s['hnorm']:.2e}) orth={s['orth']:.2e} invariants: {ok1}; assembly+upload {t1 - t0:.1f} s, "
+              f"{s['steps']} iterations {t2 - t1:.1f} s; max Ritz value difference {dv_:.2e}; same: {same}", flush=True)
+        ok = ok and ok1 and same
+        ws1.close()
+        op1.close()
+    print(f"[rank {rank}] {msg} -> {'OK' if ok else 'FAIL'}", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 def main():
@@ -59,6 +130,9 @@ def main():
         dist.destroy_process_group()
         sys.exit(0 if ok else 1)
 
+    if mode == "shard5":
+        sys.exit(shard5(rank, world, ctx, m))
+
     if mode == "laplace":
         mx, my, mz = m, m + 1, m + 2 * world
         n = mx * my * mz
@@ -79,6 +153,8 @@ def main():
         kw = dict(nev=5, which="LR", tol=1e-10, mindim=10, maxdim=25, restarts=300)
         if mode == "wide":
             kw = dict(nev=12, which="LR", tol=1e-10, mindim=30, maxdim=60, restarts=300)
+        if mode == "eager":
+            kw = dict(nev=12, which="LR", tol=1e-10, mindim=35, maxdim=70, restarts=300)
         full = lambda: A  # noqa: E731
     dtype = np.complex128 if mode == "complex" else np.float64
 
