@@ -1,0 +1,55 @@
+"""`-m gpu`: bench.py must print its ONE JSON line whatever happens to a transport ("make the N > 1 bench
+un-killable").  Two ranks share device 0 (KS_SAME_DEVICE=1: peer-to-peer + host-staged transports, RCCL refuses two
+ranks per device); one pass is made to fail, or to hang, on purpose."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _bench(extra_env, nproc=2, grid=64, timeout=420):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, KS_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1",
+           "--grid", str(grid)]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    return r, json.loads(lines[0])
+
+
+def test_both_transports_measured_and_agree():
+    r, d = _bench({})
+    assert r.returncode == 0
+    assert set(d["transports"]) == {"p2p", "host"} and all("value" in v for v in d["transports"].values()), d["transports"]
+    assert d["value"] == max(v["value"] for v in d["transports"].values()) and d["n_gpus"] == 2
+    assert d["roofline"]["fused_step"]["moved_frac"] > 0 and d["scaling"] == "strong"
+
+
+@pytest.mark.parametrize("victim,survivor", [("host", "p2p"), ("p2p", "host")])
+def test_line_survives_a_failing_transport(victim, survivor):
+    r, d = _bench({"KS_BENCH_INJECT_FAIL": victim})
+    assert r.returncode == 0
+    assert "error" in d["transports"][victim] and "value" in d["transports"][survivor]
+    assert d["config"]["transport"] == survivor and d["value"] == d["transports"][survivor]["value"]
+
+
+def test_line_survives_a_hung_transport():
+    r, d = _bench({"KS_BENCH_TRANSPORTS": "host,p2p", "KS_BENCH_INJECT_FAIL": "p2p:hang", "KS_BENCH_PASS_DEADLINE_S": "20"})
+    assert "did not finish" in d["transports"]["p2p"]["error"]
+    assert d["value"] == d["transports"]["host"]["value"] and d["value"] > 0
+
+
+def test_line_appears_even_when_nothing_survives():
+    r, d = _bench({"KS_BENCH_TRANSPORTS": "p2p", "KS_BENCH_INJECT_FAIL": "p2p"})
+    assert r.returncode != 0 and d["value"] is None and "error" in d["transports"]["p2p"]
