@@ -16,6 +16,7 @@ KS_OK, KS_ERR_ARGUMENT, KS_ERR_DIMENSION, KS_ERR_HIP, KS_ERR_RCCL, KS_ERR_QR, KS
 KS_F64, KS_C64 = 0, 1
 KS_I32, KS_I64 = 0, 1
 KS_CSR, KS_CSC = 0, 1
+LAYOUTS = {-1: "none", 0: "csr", 1: "csr-vi", 2: "csr-dvi", 3: "sell", 4: "sell-vi"}
 WHICH = {"LM": 0, "LR": 1, "SR": 2, "LI": 3, "SI": 4}
 
 
@@ -87,7 +88,7 @@ PROTOTYPES = {
     "ks_operator_device_callback": [vp, i64, i32, DEVICE_APPLY_FN, vp, P(vp)],
     "ks_operator_destroy": [vp],
     "ks_operator_size": [vp, P(i64), P(i64), P(C.c_int)],
-    "ks_operator_format": [vp, P(C.c_double), P(C.c_int)],
+    "ks_operator_format": [vp, P(C.c_double), P(C.c_int), P(C.c_int)],
     "ks_operator_apply_raw": [vp, vp, vp],
     "ks_workspace_create": [vp, i64, i64, i64, i32, i32, P(vp)],
     "ks_workspace_placement": [vp, P(C.c_int), P(C.c_double), P(C.c_double), P(C.c_int)],

@@ -204,9 +204,9 @@ class Operator:
     @property
     def format(self) -> dict:
         """Device layout of a stored matrix: bytes streamed per non-zero and dictionary size (0 = plain CSR)."""
-        b, d = C.c_double(), C.c_int()
-        check(_lib.load().ks_operator_format(self._h, C.byref(b), C.byref(d)))
-        return dict(bytes_per_nnz=b.value, ndict=d.value)
+        b, d, lay = C.c_double(), C.c_int(), C.c_int()
+        check(_lib.load().ks_operator_format(self._h, C.byref(b), C.byref(d), C.byref(lay)))
+        return dict(bytes_per_nnz=b.value, ndict=d.value, layout=_lib.LAYOUTS.get(lay.value, "?"))
 
     def close(self):
         # never touch a handle whose context is already gone (interpreter shutdown order is arbitrary)

@@ -7,7 +7,9 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -314,6 +316,8 @@ struct ks_operator {
   int dtype = KS_F64;
   bool async_capable = true;  // may be enqueued ahead without host involvement
   double bytes_per_nnz = 0.0;  // what the SpMV streams per stored non-zero (0: not a stored-matrix operator)
+  double aux_bytes = 0.0;      // index structures next to the non-zeros (row pointers, slice offsets, permutation)
+  int layout = -1;             // KS_LAYOUT_* of include/kschur.h (-1: not a stored sparse matrix)
   virtual ~ks_operator() = default;
   // y = A x on device pointers, enqueued on ctx->stream; `st` lets the kernels of a batch skip work
   // after a breakdown.
@@ -323,17 +327,33 @@ struct ks_operator {
 namespace {
 
 template <class D> struct CsrOp : ks_operator {
-  int32_t* rowptr = nullptr;
+  void* rowptr = nullptr;   // int32[n+1], or int64[n+1] when ptr64 (nnz >= 2^31: int64-nnz CSR)
+  bool ptr64 = false;
   int32_t* colidx = nullptr;
   D* val = nullptr;
-  int ntiles = 0;
-  int lds_cap = 256;  // products per tile held in LDS (largest tile of this matrix, capped)
+  // row blocks of k_spmv_csr (CSR-adaptive tiling): rows [blkrow[b], blkrow[b+1]), non-zeros [blkptr[b], blkptr[b+1])
+  void* blkptr = nullptr;   // same integer type as rowptr
+  int32_t* blkrow = nullptr;
+  int nblk = 0;
+  int ni = 7;               // non-zeros per thread and block: a block holds at most ni * 256 entries in LDS
+  int nlong = 0;            // rows longer than that: cut into chunk blocks, partial sums added by k_spmv_longfix
+  int32_t* blkpart = nullptr;  // per block: -1, or the index of the chunk's partial sum
+  D* lpart = nullptr;
+  int32_t* lrow = nullptr;
+  int32_t* lfirst = nullptr;
+  // sliced-ELLPACK layout (k_spmv_sell): slices of 64 rows, column-major, padded to the slice's longest row
+  void* sliceptr = nullptr;  // entry offsets of the slices, same integer type as rowptr
+  int32_t* sperm = nullptr;  // slice position -> row (sigma > 1 only)
+  int nslices = 0;
+  int sell_un = 8;
+  int64_t sell_entries = 0;  // stored entries including padding
   int ndict = 0;      // > 0: value-indexed layout (k_spmv_csr<.., VI>): colidx = (dict index << 24) | column, val = dictionary
   // delta-value-indexed layout (k_spmv_dvi): one byte per non-zero into a dictionary of (column - row, value)
   int ndvi = 0;
   uint8_t* codes = nullptr;
   int32_t* ddelta = nullptr;
   int dvi_unroll = 8;
+  int dvi_rpt = 4;          // rows per thread of k_spmv_dvi
   // halo plan (distributed)
   int64_t nghost = 0;
   D* ghost = nullptr;
@@ -356,7 +376,7 @@ template <class D> struct CsrOp : ks_operator {
   ksd::HaloArgs hargs{};
 
   ~CsrOp() override {
-    (void)hipFree(rowptr); (void)hipFree(colidx); (void)hipFree(val);
+    (void)hipFree(rowptr); (void)hipFree(colidx); (void)hipFree(val); (void)hipFree(blkptr); (void)hipFree(blkrow); (void)hipFree(sliceptr); (void)hipFree(sperm); (void)hipFree(blkpart); (void)hipFree(lpart); (void)hipFree(lrow); (void)hipFree(lfirst);
     if (p2p_halo) {
       if (ctx->p2p.arena_used == arena_hi) ctx->p2p.arena_used = arena_lo;  // stack discipline; otherwise kept until the context dies
     } else {
@@ -417,45 +437,86 @@ template <class D> struct CsrOp : ks_operator {
       KS_NCCL(ncclGroupEnd());
       }
     }
-    if (ntiles > 0) {
+    if (n_local > 0) {
       // algorithmic bytes: 12 nnz + 4 (n+1) + 16 n   (8 -> 16 for complex); 4 nnz in the
-      // value-indexed layout
-      ProfScope ps(ctx, KSP_SPMV, (double)nnz * bytes_per_nnz + 4.0 * (n_local + 1) + 2.0 * sizeof(D) * n_local);
-      // (a variant reading the non-zeros as aligned pairs with non-temporal loads measured 15 % slower)
+      // value-indexed layout, 1 nnz in the delta-value-indexed one
+      ProfScope ps(ctx, KSP_SPMV, (double)nnz * bytes_per_nnz + aux_bytes + 2.0 * sizeof(D) * n_local);
+      const uint32_t* hseq = (p2p_halo && !neigh.empty()) ? ctx->p2p.hstate : nullptr;
+      auto with_ip = [&](auto f) {
+        if (ptr64) f(int64_t{});
+        else f(int32_t{});
+      };
       if (ndvi > 0) {
-        const int nt256 = (int)((n_local + kBlock - 1) / kBlock);
-        const uint32_t* hseq = (p2p_halo && !neigh.empty()) ? ctx->p2p.hstate : nullptr;
-        if (dvi_unroll == 4) ksd::k_spmv_dvi<D, 4><<<nt256, kBlock, 0, s>>>(rowptr, codes, ddelta, val, x, ghost, y, n_local, nt256, ndvi, st, hseq, ghost_stride);
-        else ksd::k_spmv_dvi<D, 8><<<nt256, kBlock, 0, s>>>(rowptr, codes, ddelta, val, x, ghost, y, n_local, nt256, ndvi, st, hseq, ghost_stride);
+        with_ip([&](auto ip_tag) {
+          using IP = decltype(ip_tag);
+          const IP* rp = static_cast<const IP*>(rowptr);
+          auto go = [&](auto un_tag, auto rpt_tag) {
+            constexpr int UN = decltype(un_tag)::value, RPT = decltype(rpt_tag)::value;
+            const int nt = (int)((n_local + kBlock * RPT - 1) / (kBlock * RPT));
+            ksd::k_spmv_dvi<D, IP, UN, RPT><<<nt, kBlock, 0, s>>>(rp, codes, ddelta, val, x, ghost, y, n_local, nt, ndvi, st, hseq, ghost_stride);
+          };
+          using I = std::integral_constant<int, 0>;
+          (void)sizeof(I);
+          if (dvi_unroll == 4) {
+            if (dvi_rpt == 1) go(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
+            else if (dvi_rpt == 2) go(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
+            else go(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
+          } else {
+            if (dvi_rpt == 1) go(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{});
+            else if (dvi_rpt == 2) go(std::integral_constant<int, 8>{}, std::integral_constant<int, 2>{});
+            else go(std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{});
+          }
+        });
         KS_HIP(hipGetLastError());
         return;
       }
-      static const int nt = env_int("KS_SPMV_NT", 0);
-      const size_t smem = (size_t)lds_cap * sizeof(D);
-      const uint32_t* hseq = (p2p_halo && !neigh.empty()) ? ctx->p2p.hstate : nullptr;
-      // full-unroll depth: smallest instantiated NI with NI * 256 >= lds_cap (0 = rolled loop; KS_SPMV_NI overrides)
-      static const int ni_env = env_int("KS_SPMV_NI", -1);
-      const int need = (lds_cap + kBlock - 1) / kBlock;
-      int ni = need <= 4 ? 4 : need <= 7 ? 7 : need <= 8 ? 8 : need <= 12 ? 12 : need <= 16 ? 16 : 0;
-      if (ni_env >= 0) ni = (ni_env >= need) ? ni_env : 0;
-      auto launch = [&](auto vi_tag, auto ni_tag) {
-        constexpr bool VI = decltype(vi_tag)::value;
-        constexpr int NI = decltype(ni_tag)::value;
-        if (nt && !VI) ksd::k_spmv_csr<D, true, false, NI><<<ntiles, kBlock, smem, s>>>(rowptr, colidx, val, x, ghost, y, n_local, ntiles, lds_cap, st, hseq, ghost_stride, ndict);
-        else ksd::k_spmv_csr<D, false, VI, NI><<<ntiles, kBlock, smem, s>>>(rowptr, colidx, val, x, ghost, y, n_local, ntiles, lds_cap, st, hseq, ghost_stride, ndict);
-      };
-      auto by_ni = [&](auto vi_tag) {
-        switch (ni) {
-          case 4: launch(vi_tag, std::integral_constant<int, 4>{}); break;
-          case 7: launch(vi_tag, std::integral_constant<int, 7>{}); break;
-          case 8: launch(vi_tag, std::integral_constant<int, 8>{}); break;
-          case 12: launch(vi_tag, std::integral_constant<int, 12>{}); break;
-          case 16: launch(vi_tag, std::integral_constant<int, 16>{}); break;
-          default: launch(vi_tag, std::integral_constant<int, 0>{}); break;
-        }
-      };
-      if (ndict > 0) by_ni(std::true_type{});
-      else by_ni(std::false_type{});
+      if (nslices > 0) {
+        with_ip([&](auto ip_tag) {
+          using IP = decltype(ip_tag);
+          const int ng = (nslices + 3) / 4;
+          auto go = [&](auto vi_tag, auto un_tag) {
+            constexpr bool VI = decltype(vi_tag)::value;
+            constexpr int UN = decltype(un_tag)::value;
+            static const int plain_loads = env_int("KS_SELL_PLAIN_LOADS", 0);  // experiment: default-policy loads of the matrix streams
+            if (plain_loads)
+              ksd::k_spmv_sell<D, IP, VI, UN, false><<<ng, kBlock, 0, s>>>(static_cast<const IP*>(sliceptr), colidx, val, sperm, x, ghost, y,
+                                                                           n_local, nslices, ng, st, hseq, ghost_stride, ndict);
+            else
+              ksd::k_spmv_sell<D, IP, VI, UN, true><<<ng, kBlock, 0, s>>>(static_cast<const IP*>(sliceptr), colidx, val, sperm, x, ghost, y,
+                                                                          n_local, nslices, ng, st, hseq, ghost_stride, ndict);
+          };
+          auto by_un = [&](auto vi_tag) {
+            if (sell_un <= 4) go(vi_tag, std::integral_constant<int, 4>{});
+            else go(vi_tag, std::integral_constant<int, 8>{});
+          };
+          if (ndict > 0) by_un(std::true_type{});
+          else by_un(std::false_type{});
+        });
+        KS_HIP(hipGetLastError());
+        return;
+      }
+      with_ip([&](auto ip_tag) {
+        using IP = decltype(ip_tag);
+        auto launch = [&](auto vi_tag, auto ni_tag) {
+          constexpr bool VI = decltype(vi_tag)::value;
+          constexpr int NI = decltype(ni_tag)::value;
+          if constexpr ((size_t)NI * kBlock * sizeof(D) <= (size_t)ksd::kSpmvCapBytes)
+            ksd::k_spmv_csr<D, IP, VI, NI><<<nblk, kBlock, 0, s>>>(static_cast<const IP*>(blkptr), blkrow, static_cast<const IP*>(rowptr), colidx,
+                                                                   val, x, ghost, y, n_local, nblk, st, hseq, ghost_stride, ndict, blkpart, lpart);
+        };
+        auto by_ni = [&](auto vi_tag) {
+          switch (ni) {
+            case 4: launch(vi_tag, std::integral_constant<int, 4>{}); break;
+            case 7: launch(vi_tag, std::integral_constant<int, 7>{}); break;
+            case 8: launch(vi_tag, std::integral_constant<int, 8>{}); break;
+            case 12: launch(vi_tag, std::integral_constant<int, 12>{}); break;
+            default: launch(vi_tag, std::integral_constant<int, 16>{}); break;
+          }
+        };
+        if (ndict > 0) by_ni(std::true_type{});
+        else by_ni(std::false_type{});
+      });
+      if (nlong > 0) ksd::k_spmv_longfix<D><<<(nlong + kBlock - 1) / kBlock, kBlock, 0, s>>>(lrow, lfirst, lpart, y, nlong, st);
     }
     KS_HIP(hipGetLastError());
   }
@@ -505,12 +566,12 @@ template <class I> inline int64_t idx_at(const void* p, int64_t i) { return (int
 
 template <class D>
 void build_csr_host(int64_t nrows, int64_t ncols, int64_t nnz, const void* ptr, const void* idx, const void* val,
-                    int layout, int base, int itype, std::vector<int32_t>& rp, std::vector<int32_t>& ci,
+                    int layout, int base, int itype, std::vector<int64_t>& rp, std::vector<int32_t>& ci,
                     std::vector<D>& vv) {
   auto P = [&](int64_t i) { return (itype == KS_I32 ? idx_at<int32_t>(ptr, i) : idx_at<int64_t>(ptr, i)) - base; };
   auto J = [&](int64_t i) { return (itype == KS_I32 ? idx_at<int32_t>(idx, i) : idx_at<int64_t>(idx, i)) - base; };
   const D* v = static_cast<const D*>(val);
-  KS_REQUIRE(nnz < (int64_t)2147483647, KS_ERR_ARGUMENT, "nnz must fit int32");
+  // column indices are 32-bit on the device; the non-zero offsets (rowptr) switch to 64 bits when nnz >= 2^31
   KS_REQUIRE(nrows < (int64_t)2147483647 && ncols < (int64_t)2147483647, KS_ERR_ARGUMENT, "matrix order must fit int32");
   {
     // the pointer array must be monotone and stay inside [0, nnz]: a malformed one would index host (CSC
@@ -529,8 +590,7 @@ void build_csr_host(int64_t nrows, int64_t ncols, int64_t nnz, const void* ptr, 
   ci.resize(nnz);
   vv.resize(nnz);
   if (layout == KS_CSR) {
-    for (int64_t i = 0; i <= nrows; ++i) rp[i] = (int32_t)P(i);
-    KS_REQUIRE(rp[0] == 0 && rp[nrows] == nnz, KS_ERR_ARGUMENT, "row pointer does not match nnz");
+    for (int64_t i = 0; i <= nrows; ++i) rp[i] = P(i);
     for (int64_t p = 0; p < nnz; ++p) {
       const int64_t c = J(p);
       KS_REQUIRE(c >= 0 && c < ncols, KS_ERR_ARGUMENT, "column index out of range");
@@ -538,45 +598,48 @@ void build_csr_host(int64_t nrows, int64_t ncols, int64_t nnz, const void* ptr, 
       vv[p] = v[p];
     }
   } else {  // CSC (Julia SparseMatrixCSC: colptr, rowval, nzval) -> CSR by counting sort
-    KS_REQUIRE(P(0) == 0 && P(ncols) == nnz, KS_ERR_ARGUMENT, "column pointer does not match nnz");
     for (int64_t p = 0; p < nnz; ++p) {
       const int64_t r = J(p);
       KS_REQUIRE(r >= 0 && r < nrows, KS_ERR_ARGUMENT, "row index out of range");
       rp[r + 1]++;
     }
     for (int64_t i = 0; i < nrows; ++i) rp[i + 1] += rp[i];
-    std::vector<int32_t> fill(rp.begin(), rp.end() - 1);
+    std::vector<int64_t> fill(rp.begin(), rp.end() - 1);
     for (int64_t c = 0; c < ncols; ++c)
       for (int64_t p = P(c); p < P(c + 1); ++p) {
         const int64_t r = J(p);
-        const int32_t q = fill[r]++;
+        const int64_t q = fill[r]++;
         ci[q] = (int32_t)c;
         vv[q] = v[p];
       }
   }
 }
 
+// device copy of the non-zero offsets in the width the kernels will use
+inline void* upload_ptr(const std::vector<int64_t>& v, bool ptr64) {
+  void* d = nullptr;
+  const size_t cnt = v.size();
+  if (ptr64) {
+    KS_HIP(hipMalloc(&d, std::max<size_t>(cnt * 8, 16)));
+    KS_HIP(hipMemcpy(d, v.data(), cnt * 8, hipMemcpyHostToDevice));
+  } else {
+    std::vector<int32_t> t(v.begin(), v.end());
+    KS_HIP(hipMalloc(&d, std::max<size_t>(cnt * 4, 16)));
+    KS_HIP(hipMemcpy(d, t.data(), cnt * 4, hipMemcpyHostToDevice));
+  }
+  return d;
+}
+
 template <class D>
-CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<int32_t>& rp,
+CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<int64_t>& rp,
                    const std::vector<int32_t>& ci, const std::vector<D>& vv) {
   auto op = std::make_unique<CsrOp<D>>();
   op->ctx = ctx;
   op->n_local = nrows;
   op->nnz = nnz;
   op->dtype = sizeof(D) == 8 ? KS_F64 : KS_C64;
-  op->ntiles = (int)((nrows + ksd::kSpmvRows - 1) / ksd::kSpmvRows);
-  {
-    // LDS buffer = the largest 256-row tile (multiple of 256 products), at most kSpmvCapMax; tiles above
-    // the cap take the wave-per-row path.  KS_SPMV_CAP overrides (experiments).
-    int64_t mx = 0;
-    for (int64_t r0 = 0; r0 < nrows; r0 += ksd::kSpmvRows) {
-      const int64_t r1 = std::min<int64_t>(nrows, r0 + ksd::kSpmvRows);
-      mx = std::max<int64_t>(mx, (int64_t)rp[r1] - rp[r0]);
-    }
-    const int capmax = ksd::kSpmvCapMax / (int)(sizeof(D) / 8);
-    int cap = (int)std::min<int64_t>(capmax, std::max<int64_t>(256, round_up(mx, 256)));
-    op->lds_cap = env_int("KS_SPMV_CAP", cap);
-  }
+  // int64-nnz CSR: offsets need 64 bits from 2^31 stored entries on (KS_SPMV_PTR64=1 forces it, for tests)
+  op->ptr64 = nnz >= (int64_t)2147483647 || env_int("KS_SPMV_PTR64", 0) != 0;
   // Delta-value-indexed layout (k_spmv_dvi): at most 256 distinct (column - row, value) pairs -> one byte per
   // non-zero.  KS_SPMV_FORMAT = csr | vi | dvi restricts the choice (default: the most compact that applies).
   {
@@ -598,12 +661,12 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
       std::vector<int32_t> dd;
       std::vector<D> dv;
       bool ok = true;
-      int max_row = 0;
+      int64_t max_row = 0;
       Key ckey[8];
       int cid[8], ncache = 0, cnext = 0;
       for (int64_t r = 0; r < nrows && ok; ++r) {
         max_row = std::max(max_row, rp[r + 1] - rp[r]);
-        for (int32_t p = rp[r]; p < rp[r + 1]; ++p) {
+        for (int64_t p = rp[r]; p < rp[r + 1]; ++p) {
           Key k{0, 0, (int64_t)ci[p] - r};
           std::memcpy(&k, &vv[p], sizeof(D));
           // stencils cycle through a handful of keys: a tiny recent-key cache in front of the hash map
@@ -633,12 +696,20 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
       if (ok) {
         op->ndvi = (int)dd.size();
         op->dvi_unroll = max_row <= 4 ? 4 : 8;
+        // rows per thread: 4 once there are enough 1024-row tiles to fill the device twice over, else fewer
+        // (KS_DVI_RPT overrides: 1, 2 or 4)
+        // rows per thread (KS_DVI_RPT = 1, 2 or 4).  Measured on the 216^3 Laplacian: 77.8 / 78.7 / 117 us for
+        // 1 / 2 / 4 -- the kernel is bound by instruction issue (byte decode, two dictionary reads and one gather per
+        // entry), not by memory latency, so more rows per thread only cost occupancy.
+        op->dvi_rpt = env_int("KS_DVI_RPT", 1);
         op->bytes_per_nnz = 1.0;
-        KS_HIP(hipMalloc(&op->rowptr, (size_t)(nrows + 1) * 4));
+        op->layout = KS_LAYOUT_DVI;
+        op->aux_bytes = (op->ptr64 ? 8.0 : 4.0) * (double)(nrows + 1);
+        op->rowptr = upload_ptr(rp, op->ptr64);
         KS_HIP(hipMalloc(&op->codes, (size_t)nnz + 64));
+        KS_HIP(hipMemset(op->codes, 0, (size_t)nnz + 64));
         KS_HIP(hipMalloc(&op->ddelta, 256 * 4));
         KS_HIP(hipMalloc(&op->val, 256 * sizeof(D)));
-        KS_HIP(hipMemcpy(op->rowptr, rp.data(), (size_t)(nrows + 1) * 4, hipMemcpyHostToDevice));
         KS_HIP(hipMemcpy(op->codes, codes.data(), (size_t)nnz, hipMemcpyHostToDevice));
         KS_HIP(hipMemcpy(op->ddelta, dd.data(), dd.size() * 4, hipMemcpyHostToDevice));
         KS_HIP(hipMemcpy(op->val, dv.data(), dv.size() * sizeof(D), hipMemcpyHostToDevice));
@@ -652,7 +723,7 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
   std::vector<int32_t> packed;
   {
     const char* fmt = std::getenv("KS_SPMV_FORMAT");
-    bool try_vi = nnz > 0 && !(fmt && (std::string(fmt) == "csr" || std::string(fmt) == "dvi"));
+    bool try_vi = nnz > 0 && !(fmt && (std::string(fmt) == "csr" || std::string(fmt) == "dvi" || std::string(fmt) == "sell"));
     if (try_vi) {
       struct Key {
         uint64_t a, b;
@@ -692,10 +763,155 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
     if (!try_vi) { dict.clear(); packed.clear(); }
   }
   op->ndict = (int)dict.size();
+  // Storage order.  Sliced ELLPACK (k_spmv_sell, lane = row: coalesced index / value loads and, for banded matrices,
+  // coalesced gathers) when slicing the rows 64 at a time pads the matrix by at most 15 % -- uniform row lengths:
+  // stencils with variable coefficients, structured finite-element meshes, banded matrices; otherwise (ragged rows,
+  // where a lane per row would idle and the gathers are scattered anyway) the non-zero-parallel CSR blocks of k_spmv_csr.
+  // KS_SPMV_FORMAT=sell / sellvi force it (KS_SELL_SIGMA = window for sorting rows by length, multiple of 64, default:
+  // 1 = no permutation); csr / vi force the CSR blocks.
+  {
+    const char* fmt = std::getenv("KS_SPMV_FORMAT");
+    const std::string f = fmt ? fmt : "";
+    const bool force_sell = f == "sell" || f == "sellvi";
+    const bool allow_sell = force_sell || f.empty();
+    int sigma = std::max(1, env_int("KS_SELL_SIGMA", 1));
+    if (sigma > 1) sigma = (int)round_up(sigma, 64);
+    if (f == "sell") { dict.clear(); packed.clear(); op->ndict = 0; }
+    if (allow_sell && nrows > 0 && nnz > 0) {
+      // slice position -> row (identity unless sigma > 1: stable sort by descending length inside each window)
+      std::vector<int32_t> perm;
+      if (sigma > 1) {
+        perm.resize((size_t)nrows);
+        for (int64_t i = 0; i < nrows; ++i) perm[i] = (int32_t)i;
+        for (int64_t w0 = 0; w0 < nrows; w0 += sigma) {
+          const int64_t w1 = std::min<int64_t>(nrows, w0 + sigma);
+          std::stable_sort(perm.begin() + w0, perm.begin() + w1,
+                           [&](int32_t x_, int32_t y_) { return rp[x_ + 1] - rp[x_] > rp[y_ + 1] - rp[y_]; });
+        }
+      }
+      auto row_at = [&](int64_t pos) { return sigma > 1 ? (int64_t)perm[pos] : pos; };
+      const int64_t nsl = (nrows + 63) / 64;
+      std::vector<int64_t> sp((size_t)nsl + 1, 0);
+      int64_t wmax = 0;
+      for (int64_t sl = 0; sl < nsl; ++sl) {
+        int64_t w = 0;
+        for (int64_t pos = sl * 64; pos < std::min<int64_t>(nrows, sl * 64 + 64); ++pos) {
+          const int64_t r = row_at(pos);
+          w = std::max(w, rp[r + 1] - rp[r]);
+        }
+        wmax = std::max(wmax, w);
+        sp[sl + 1] = sp[sl] + 64 * w;
+      }
+      const int64_t padded = sp[nsl];
+      if (force_sell || (double)padded <= 1.15 * (double)nnz + 64.0) {
+        KS_REQUIRE(padded < ((int64_t)1 << 40), KS_ERR_ARGUMENT, "sliced-ELLPACK padding explodes: use KS_SPMV_FORMAT=csr");
+        if (padded >= (int64_t)2147483647) op->ptr64 = true;
+        const bool vi = op->ndict > 0;
+        std::vector<int32_t> sc((size_t)padded, -1);
+        std::vector<D> sv(vi ? 0 : (size_t)padded);
+        for (int64_t sl = 0; sl < nsl; ++sl)
+          for (int64_t pos = sl * 64; pos < std::min<int64_t>(nrows, sl * 64 + 64); ++pos) {
+            const int64_t r = row_at(pos);
+            const int64_t lane = pos - sl * 64;
+            for (int64_t p = rp[r], k = 0; p < rp[r + 1]; ++p, ++k) {
+              const int64_t q = sp[sl] + k * 64 + lane;
+              sc[q] = vi ? packed[p] : ci[p];
+              if (!vi) sv[q] = vv[p];
+            }
+          }
+        op->nslices = (int)nsl;
+        op->sell_un = wmax <= 4 ? 4 : 8;
+        op->sell_entries = padded;
+        op->layout = vi ? KS_LAYOUT_SELL_VI : KS_LAYOUT_SELL;
+        op->bytes_per_nnz = (vi ? 4.0 : 4.0 + sizeof(D)) * (double)padded / (double)nnz;
+        op->aux_bytes = (op->ptr64 ? 8.0 : 4.0) * (double)(nsl + 1) + (sigma > 1 ? 4.0 * (double)nrows : 0.0);
+        op->sliceptr = upload_ptr(sp, op->ptr64);
+        KS_HIP(hipMalloc(&op->colidx, (size_t)padded * 4 + 16));
+        KS_HIP(hipMemcpy(op->colidx, sc.data(), (size_t)padded * 4, hipMemcpyHostToDevice));
+        if (vi) {
+          KS_HIP(hipMalloc(&op->val, 256 * sizeof(D)));
+          KS_HIP(hipMemcpy(op->val, dict.data(), dict.size() * sizeof(D), hipMemcpyHostToDevice));
+        } else {
+          KS_HIP(hipMalloc(&op->val, (size_t)padded * sizeof(D) + 16));
+          KS_HIP(hipMemcpy(op->val, sv.data(), (size_t)padded * sizeof(D), hipMemcpyHostToDevice));
+        }
+        if (sigma > 1) {
+          KS_HIP(hipMalloc(&op->sperm, (size_t)nrows * 4));
+          KS_HIP(hipMemcpy(op->sperm, perm.data(), (size_t)nrows * 4, hipMemcpyHostToDevice));
+        }
+        return op.release();
+      }
+    }
+  }
+  // Row blocks of k_spmv_csr.  A block holds at most ni * 256 products in LDS (<= 32 KiB; KS_SPMV_NI overrides), so
+  // regular matrices get full 256-row blocks and the LDS footprint (occupancy) follows the matrix.  Greedy pass over the
+  // rows: close the block at 256 rows or when the next row would overflow it; a row longer than the capacity becomes a
+  // block of its own (handled by all 256 threads).
+  {
+    const int nimax = (int)(ksd::kSpmvCapBytes / (kBlock * sizeof(D)));  // 16 (Float64) / 8 (ComplexF64)
+    // depth from the 90th percentile of the non-zeros of fixed 256-row tiles: a regular matrix gets exactly what its
+    // tiles need (7-point stencil: 1792 -> 7; 12 measured 14 % slower than 7 or 8 there: LDS footprint), the heavy tail
+    // of a skewed one gets shorter blocks instead of inflating everybody's LDS
+    std::vector<int64_t> tile_nnz;
+    for (int64_t r0 = 0; r0 < nrows; r0 += ksd::kSpmvRows) tile_nnz.push_back(rp[std::min<int64_t>(nrows, r0 + ksd::kSpmvRows)] - rp[r0]);
+    int64_t t90 = 0;
+    if (!tile_nnz.empty()) {
+      const size_t k = (tile_nnz.size() - 1) * 9 / 10;
+      std::nth_element(tile_nnz.begin(), tile_nnz.begin() + k, tile_nnz.end());
+      t90 = tile_nnz[k];
+    }
+    const int need = (int)((t90 + kBlock - 1) / kBlock);
+    int ni = need <= 4 ? 4 : need <= 7 ? 7 : need <= 8 ? 8 : need <= 12 ? 12 : 16;
+    ni = env_int("KS_SPMV_NI", ni);
+    if (ni != 4 && ni != 7 && ni != 8 && ni != 12 && ni != 16) ni = 16;
+    ni = std::min(ni, nimax);
+    op->ni = ni;
+    const int64_t cap = (int64_t)ni * kBlock;
+    std::vector<int64_t> bp{0};
+    std::vector<int32_t> br{0}, part, lrow, lfirst{0};
+    int64_t r = 0;
+    while (r < nrows) {
+      const int64_t first = rp[r + 1] - rp[r];
+      if (first > cap) {  // long row: chunk blocks of <= cap entries, all with row range [r, r+1)
+        for (int64_t q = rp[r]; q < rp[r + 1]; q += cap) {
+          part.push_back((int32_t)lfirst.back() + (int32_t)((q - rp[r]) / cap));
+          br.push_back((int32_t)(r + 1));
+          bp.push_back(std::min(q + cap, rp[r + 1]));
+          if (q + cap < rp[r + 1]) br.back() = (int32_t)r;  // the next chunk starts at the same row
+        }
+        lrow.push_back((int32_t)r);
+        lfirst.push_back(lfirst.back() + (int32_t)((first + cap - 1) / cap));
+        op->nlong++;
+        r += 1;
+        continue;
+      }
+      int64_t e = r + 1;
+      while (e < nrows && e - r < ksd::kSpmvRows && rp[e + 1] - rp[r] <= cap && rp[e + 1] - rp[e] <= cap) ++e;
+      part.push_back(-1);
+      br.push_back((int32_t)e);
+      bp.push_back(rp[e]);
+      r = e;
+    }
+    op->nblk = (int)br.size() - 1;
+    KS_REQUIRE((int64_t)br.size() - 1 < (int64_t)2147483647, KS_ERR_ARGUMENT, "too many row blocks");
+    op->blkptr = upload_ptr(bp, op->ptr64);
+    KS_HIP(hipMalloc(&op->blkrow, std::max<size_t>(br.size() * 4, 16)));
+    KS_HIP(hipMemcpy(op->blkrow, br.data(), br.size() * 4, hipMemcpyHostToDevice));
+    if (op->nlong > 0) {
+      KS_HIP(hipMalloc(&op->blkpart, part.size() * 4));
+      KS_HIP(hipMemcpy(op->blkpart, part.data(), part.size() * 4, hipMemcpyHostToDevice));
+      KS_HIP(hipMalloc(&op->lpart, (size_t)lfirst.back() * sizeof(D)));
+      KS_HIP(hipMalloc(&op->lrow, lrow.size() * 4));
+      KS_HIP(hipMemcpy(op->lrow, lrow.data(), lrow.size() * 4, hipMemcpyHostToDevice));
+      KS_HIP(hipMalloc(&op->lfirst, lfirst.size() * 4));
+      KS_HIP(hipMemcpy(op->lfirst, lfirst.data(), lfirst.size() * 4, hipMemcpyHostToDevice));
+    }
+  }
+  op->layout = op->ndict > 0 ? KS_LAYOUT_CSR_VI : KS_LAYOUT_CSR;
   op->bytes_per_nnz = op->ndict > 0 ? 4.0 : 4.0 + sizeof(D);
-  KS_HIP(hipMalloc(&op->rowptr, (size_t)(nrows + 1) * 4));
+  op->aux_bytes = (op->ptr64 ? 8.0 : 4.0) * (double)(nrows + 1 + 2 * ((int64_t)op->nblk + 1));
+  op->rowptr = upload_ptr(rp, op->ptr64);
   KS_HIP(hipMalloc(&op->colidx, (size_t)(nnz + 2) * 4 + 16));
-  KS_HIP(hipMemcpy(op->rowptr, rp.data(), (size_t)(nrows + 1) * 4, hipMemcpyHostToDevice));
   if (op->ndict > 0) {
     KS_HIP(hipMalloc(&op->val, 256 * sizeof(D)));
     KS_HIP(hipMemcpy(op->colidx, packed.data(), (size_t)nnz * 4, hipMemcpyHostToDevice));
@@ -1693,7 +1909,8 @@ int ks_operator_csr(ks_ctx* ctx, int64_t nrows_local, int64_t ncols, int64_t nnz
     KS_REQUIRE(layout == KS_CSR || layout == KS_CSC, KS_ERR_ARGUMENT, "bad layout");
     KS_REQUIRE(index_type == KS_I32 || index_type == KS_I64, KS_ERR_ARGUMENT, "bad index type");
     ctx->use();
-    std::vector<int32_t> rp, ci;
+    std::vector<int64_t> rp;
+    std::vector<int32_t> ci;
     dispatch_dtype(dtype, [&](auto tag) {
       using T = decltype(tag);
       using D = typename DevT<T>::type;
@@ -1709,16 +1926,15 @@ int ks_operator_csr_dist(ks_ctx* ctx, int64_t nrows_local, int64_t nghost, int64
                          const int64_t* send_ptr, const int32_t* send_idx, const int64_t* recv_cnt, ks_operator** out) {
   return guarded([&] {
     KS_REQUIRE(ctx && out && rowptr, KS_ERR_ARGUMENT, "null argument");
-    KS_REQUIRE(nnz < (int64_t)2147483647, KS_ERR_ARGUMENT, "nnz must fit int32");
     ctx->use();
     KS_REQUIRE(nrows_local < (int64_t)2147483647 && nghost < (int64_t)2147483647 - nrows_local, KS_ERR_ARGUMENT,
                "local-extended column range must fit int32");
-    std::vector<int32_t> rp(nrows_local + 1);
+    std::vector<int64_t> rp(nrows_local + 1);
     KS_REQUIRE(rowptr[0] == 0 && rowptr[nrows_local] == nnz, KS_ERR_ARGUMENT, "row pointer does not match nnz");
     for (int64_t i = 0; i <= nrows_local; ++i) {
       KS_REQUIRE(i == 0 || (rowptr[i] >= rowptr[i - 1] && rowptr[i] <= nnz), KS_ERR_ARGUMENT,
                  "pointer array is not monotone within [0, nnz]");
-      rp[i] = (int32_t)rowptr[i];
+      rp[i] = rowptr[i];
     }
     std::vector<int32_t> ci(colidx, colidx + nnz);
     for (int64_t p = 0; p < nnz; ++p)
@@ -1899,9 +2115,10 @@ int ks_operator_size(const ks_operator* op, int64_t* n_local, int64_t* nnz, int*
   });
 }
 
-int ks_operator_format(const ks_operator* op, double* bytes_per_nnz, int* ndict) {
+int ks_operator_format(const ks_operator* op, double* bytes_per_nnz, int* ndict, int* layout) {
   return guarded([&] {
     KS_REQUIRE(op, KS_ERR_ARGUMENT, "null operator");
+    if (layout) *layout = op->layout;
     if (bytes_per_nnz) *bytes_per_nnz = op->bytes_per_nnz;
     if (ndict) {
       *ndict = 0;

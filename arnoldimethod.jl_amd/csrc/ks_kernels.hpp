@@ -195,8 +195,8 @@ __global__ void __launch_bounds__(kBlock) k_fill_uniform(T* __restrict__ v, int6
 // Distributed mode: column indices >= n_local address the ghost buffer `xg` (filled by the halo
 // exchange: RCCL send/recv, or remote stores of the neighbours in peer-to-peer mode) instead of the local column.
 // ------------------------------------------------------------------------------------------------
-constexpr int kSpmvRows = 256;
-constexpr int kSpmvCapMax = 4096;  // upper bound of products held in LDS per tile (32 KiB of f64)
+constexpr int kSpmvRows = 256;       // rows per block at most
+constexpr int kSpmvCapBytes = 32768;  // LDS for the products of a block: NI * 256 * sizeof(T) <= 32 KiB
 
 __device__ __forceinline__ int xcd_remap(int b, int nt) {
   const int q = nt >> 3, r = nt & 7, xcd = b & 7;
@@ -224,122 +224,197 @@ __device__ __forceinline__ cd mul_nc(cd a, cd b) {
   return r;
 }
 
-// `cap` = products the dynamic LDS buffer holds (chosen per matrix at upload: the largest 256-row tile,
-// so that regular matrices never take the fallback and occupancy is not wasted on unused LDS).
+// Row blocks ("CSR-adaptive" tiling, built once at upload by make_csr): block b owns rows [blkrow[b], blkrow[b+1]) and
+// non-zeros [blkptr[b], blkptr[b+1]); a block has at most 256 rows and at most CAP = NI * 256 non-zeros.  A row with
+// more than CAP entries is cut into CHUNK blocks of <= CAP entries (blkpart[b] >= 0: index of the chunk's partial sum).
+// Regular matrices get 256-row blocks (the 7-point stencil: 1792 non-zeros); skewed matrices get short blocks around
+// their heavy rows instead of dragging a whole tile onto a slow path, and a very long row is spread over many workgroups.
+// IP = type of the non-zero offsets (rowptr / blkptr): int32_t, or int64_t when nnz >= 2^31 (int64-nnz CSR).
 //
 // VI = true: value-indexed CSR ("CSR-VI").  Matrices with at most 256 distinct stored values (stencils,
 // unweighted graphs, uniform finite-element meshes) and fewer than 2^24 local-extended columns are
 // uploaded as ONE 32-bit word per non-zero, (dictionary index << 24) | column, plus the dictionary:
 // 4 B instead of 12 B per non-zero on the dominant stream of this HBM-bound kernel.  The products and their
 // summation order are exactly those of the plain layout, so y is bit-identical.
-// NI > 0: the tile's non-zeros are loaded by a fully unrolled, predicated loop of NI iterations (NI * 256 >=
-// cap): all index loads issue back to back, then all gathers -- no serial remainder loop.
-template <class T, bool NT, bool VI = false, int NI = 0>
+// The block's non-zeros are loaded by a fully unrolled, predicated loop of NI iterations: all index loads issue
+// back to back, then all gathers -- no serial remainder loop.
+template <class T, class IP, bool VI, int NI>
 __global__ void __launch_bounds__(kBlock)
-    k_spmv_csr(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx, const T* __restrict__ val,
-               const T* __restrict__ x, const T* __restrict__ xg, T* __restrict__ y, int64_t n, int ntiles, int cap,
-               const DevState* __restrict__ st, const uint32_t* __restrict__ hseq, int64_t gstride, int ndict) {
+    k_spmv_csr(const IP* __restrict__ blkptr, const int32_t* __restrict__ blkrow, const IP* __restrict__ rowptr,
+               const int32_t* __restrict__ colidx, const T* __restrict__ val, const T* __restrict__ x,
+               const T* __restrict__ xg, T* __restrict__ y, int64_t n, int nblk, const DevState* __restrict__ st,
+               const uint32_t* __restrict__ hseq, int64_t gstride, int ndict, const int32_t* __restrict__ blkpart,
+               T* __restrict__ lpart) {
   if (st && st->breakdown >= 0) return;
   // peer-to-peer halo (ks_p2p.hpp): the ghost vector is double-buffered, the parity of the halo sequence
   // number the push kernel just published selects the slot
   if (hseq) xg += (int64_t)(*hseq & 1u) * gstride;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* prod = reinterpret_cast<T*>(smem_raw);
+  constexpr int CAP = NI * kBlock;
+  __shared__ T prod[CAP];
   // VI: the dictionary is staged in LDS (gathering it from global memory per non-zero measured 10 % slower);
-  // the fully unrolled path issues its index loads BEFORE the staging barrier so the two latencies overlap
+  // the index loads are issued BEFORE the staging barrier so the two latencies overlap
   __shared__ T dict[VI ? 256 : 1];
   const int tid = threadIdx.x;
   T dmine = zero_of(T{});
   if (VI && tid < ndict) dmine = val[tid];
-  if (VI && NI == 0) {
-    dict[tid] = dmine;
-    __syncthreads();
-  }
-  const int tile = xcd_remap(blockIdx.x, ntiles);
-  const int64_t r0 = (int64_t)tile * kSpmvRows;
-  const int64_t r1 = (r0 + kSpmvRows < n) ? r0 + kSpmvRows : n;
-  const int32_t p0 = rowptr[r0];
-  const int32_t p1 = rowptr[r1];
-  const int32_t cnt = p1 - p0;
-  // this thread's row bounds for phase 2: issued now, so their latency hides behind phase 1
-  const int64_t rmine = (r0 + tid < r1) ? r0 + tid : r1 - 1;
-  const int32_t ra = rowptr[rmine], rb = rowptr[rmine + 1];
-  if (cnt <= cap) {
-    if constexpr (NI > 0) {
-      int32_t c[NI];
-      T a[NI];
+  const int b = xcd_remap(blockIdx.x, nblk);
+  const int32_t r0 = blkrow[b], r1 = blkrow[b + 1];
+  const IP p0 = blkptr[b], p1 = blkptr[b + 1];
+  const int32_t cnt = (int32_t)(p1 - p0);  // <= CAP by construction
+  const int32_t part = blkpart ? blkpart[b] : -1;
+  if (part < 0) {
+    // this thread's row bounds for phase 2: issued now, so their latency hides behind phase 1
+    const int32_t rmine = (r0 + tid < r1) ? r0 + tid : r1 - 1;
+    const int32_t ra = (int32_t)(rowptr[rmine] - p0), rb = (int32_t)(rowptr[rmine + 1] - p0);
+    const int32_t* ci = colidx + p0;
+    const T* va = val + (VI ? (IP)0 : p0);
+    int32_t c[NI];
+    T a[NI];
 #pragma unroll
-      for (int k = 0; k < NI; ++k) {
-        const int32_t p = tid + k * kBlock;
-        c[k] = (p < cnt) ? ld_i32(colidx + p0 + p, NT) : 0;
-        if (!VI) a[k] = (p < cnt) ? ld_val(val + p0 + p, NT) : zero_of(T{});
-      }
-      if (VI) {
-        dict[tid] = dmine;
-        __syncthreads();
-      }
-      T xv[NI];
-#pragma unroll
-      for (int k = 0; k < NI; ++k) {
-        if (VI) {
-          a[k] = dict[(uint32_t)c[k] >> 24];
-          c[k] &= 0xffffff;
-        }
-        xv[k] = (c[k] < n) ? x[c[k]] : xg[c[k] - n];
-      }
-#pragma unroll
-      for (int k = 0; k < NI; ++k) {
-        const int32_t p = tid + k * kBlock;
-        if (p < cnt) prod[p] = mul_nc(a[k], xv[k]);
-      }
-    } else {  // rolled loop: only reached with KS_SPMV_NI=0 / an oversized KS_SPMV_CAP (experiments)
-      for (int32_t p = tid; p < cnt; p += kBlock) {
-        int32_t c = ld_i32(colidx + p0 + p, NT);
-        T a;
-        if (VI) {
-          a = dict[(uint32_t)c >> 24];
-          c &= 0xffffff;
-        } else {
-          a = ld_val(val + p0 + p, NT);
-        }
-        const T xv = (c < n) ? x[c] : xg[c - n];
-        prod[p] = mul_nc(a, xv);
-      }
+    for (int k = 0; k < NI; ++k) {
+      const int32_t p = tid + k * kBlock;
+      c[k] = (p < cnt) ? ci[p] : 0;
+      if (!VI) a[k] = (p < cnt) ? va[p] : zero_of(T{});
     }
-    __syncthreads();
-    const int64_t r = r0 + tid;
-    if (r < r1) {
-      const int32_t a = ra - p0, b = rb - p0;
-      T s = zero_of(T{});
-      for (int32_t p = a; p < b; ++p) s = add_(s, prod[p]);
-      st_elem_nt(y + r, s);
-    }
-  } else {
-    // long-row fallback: one wave per row, lanes stride over the row's non-zeros
-    if (VI && NI > 0) {
+    if (VI) {
       dict[tid] = dmine;
       __syncthreads();
     }
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int64_t r = r0 + wave; r < r1; r += kBlock / 64) {
-      const int32_t a = rowptr[r], b = rowptr[r + 1];
-      T s = zero_of(T{});
-      for (int32_t p = a + lane; p < b; p += 64) {
-        int32_t c = colidx[p];
-        T av;
-        if (VI) {
-          av = dict[(uint32_t)c >> 24];
-          c &= 0xffffff;
-        } else {
-          av = val[p];
-        }
-        const T xv = (c < n) ? x[c] : xg[c - n];
-        s = fma_(av, xv, s);
+    T xv[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      if (VI) {
+        a[k] = dict[(uint32_t)c[k] >> 24];
+        c[k] &= 0xffffff;
       }
-      s = wave_sum(s);
-      if (lane == 0) y[r] = s;
+      xv[k] = (c[k] < n) ? x[c[k]] : xg[c[k] - n];
     }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const int32_t p = tid + k * kBlock;
+      if (p < cnt) prod[p] = mul_nc(a[k], xv[k]);
+    }
+    __syncthreads();
+    if (r0 + tid < r1) {
+      T s = zero_of(T{});
+      for (int32_t p = ra; p < rb; ++p) s = add_(s, prod[p]);
+      st_elem_nt(y + r0 + tid, s);
+    }
+  } else {
+    // one CHUNK (<= CAP entries) of a row too long for a block: the same coalesced loads, then every thread adds up
+    // its NI products and a fixed-shape LDS tree leaves the chunk's partial sum in lpart[part]; k_spmv_longfix adds
+    // the partials of a row in chunk order.  (A long row processed by ONE workgroup was a latency chain of
+    // L / 1024 dependent round trips: 64 rows of 40 000 entries cost 100 us.)
+    const int32_t* ci = colidx + p0;
+    const T* va = val + (VI ? (IP)0 : p0);
+    int32_t c[NI];
+    T a[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const int32_t p = tid + k * kBlock;
+      c[k] = (p < cnt) ? ci[p] : 0;
+      if (!VI) a[k] = (p < cnt) ? va[p] : zero_of(T{});
+    }
+    if (VI) {
+      dict[tid] = dmine;
+      __syncthreads();
+    }
+    T xv[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      if (VI) {
+        a[k] = dict[(uint32_t)c[k] >> 24];
+        c[k] &= 0xffffff;
+      }
+      xv[k] = (c[k] < n) ? x[c[k]] : xg[c[k] - n];
+    }
+    T s = zero_of(T{});
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+      if (tid + k * kBlock < cnt) s = add_(s, mul_nc(a[k], xv[k]));
+    prod[tid] = s;
+    __syncthreads();
+    for (int off = kBlock / 2; off >= 1; off >>= 1) {
+      if (tid < off) prod[tid] = add_(prod[tid], prod[tid + off]);
+      __syncthreads();
+    }
+    if (tid == 0) lpart[part] = prod[0];
   }
+}
+
+// y[lrow[i]] = sum of the chunk partials of long row i, in chunk order (deterministic)
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+    k_spmv_longfix(const int32_t* __restrict__ lrow, const int32_t* __restrict__ lfirst, const T* __restrict__ lpart,
+                   T* __restrict__ y, int nlong, const DevState* __restrict__ st) {
+  if (st && st->breakdown >= 0) return;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nlong) return;
+  T s = zero_of(T{});
+  for (int32_t q = lfirst[i]; q < lfirst[i + 1]; ++q) s = add_(s, lpart[q]);
+  y[lrow[i]] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SpMV, sliced-ELLPACK layout ("SELL-64-sigma").  The CSR-stream kernel above assigns consecutive LANES to consecutive
+// NON-ZEROS: its x gathers touch ~64 different cache lines per wave instruction even for a banded matrix, and the
+// texture-address path (one line per cycle and CU) caps it at ~4.8 TB/s on the 7-point Laplacian.  Here a slice of 64
+// consecutive rows is stored column-major -- entry k of all 64 rows contiguous -- so lane = row: index and value loads
+// are 256/512-byte coalesced and, for banded / stencil matrices, so are the gathers x[r + delta].  A slice is as wide
+// as its longest row; padding entries carry column -1 and are skipped (never multiplied: 0 * Inf must not appear).
+// Entries are visited in CSR order with a separately rounded product and add, so y is bit-identical to the CSR kernels.
+// sigma > 1: rows are sorted by length inside windows of sigma rows before slicing (less padding for ragged
+// matrices); `perm` maps slice position -> row.  Chosen at upload when the padding is small (make_csr).
+// VI as for k_spmv_csr: one 32-bit word per entry (dictionary index << 24 | column), padding = 0xFFFFFFFF.
+// ------------------------------------------------------------------------------------------------
+template <class T, class IP, bool VI, int UN, bool NTL = true>
+__global__ void __launch_bounds__(kBlock)
+    k_spmv_sell(const IP* __restrict__ sliceptr, const int32_t* __restrict__ scol, const T* __restrict__ sval,
+                const int32_t* __restrict__ perm, const T* __restrict__ x, const T* __restrict__ xg, T* __restrict__ y,
+                int64_t n, int nslices, int ngroups, const DevState* __restrict__ st, const uint32_t* __restrict__ hseq,
+                int64_t gstride, int ndict) {
+  if (st && st->breakdown >= 0) return;
+  if (hseq) xg += (int64_t)(*hseq & 1u) * gstride;
+  __shared__ T dict[VI ? 256 : 1];
+  if (VI) {
+    if ((int)threadIdx.x < ndict) dict[threadIdx.x] = sval[threadIdx.x];
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63;
+  const int slice = xcd_remap(blockIdx.x, ngroups) * (kBlock / 64) + (threadIdx.x >> 6);
+  if (slice >= nslices) return;
+  const IP p0 = sliceptr[slice], p1 = sliceptr[slice + 1];
+  const int32_t w = (int32_t)((p1 - p0) >> 6);
+  const int64_t pos = (int64_t)slice * 64 + lane;
+  const int32_t* ci = scol + p0 + lane;
+  const T* va = sval + (VI ? (IP)0 : p0) + (VI ? 0 : lane);
+  T s = zero_of(T{});
+  for (int32_t k0 = 0; k0 < w; k0 += UN) {
+    int32_t c[UN];
+    T a[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const bool in = k0 + u < w;  // wave-uniform
+      c[u] = in ? ld_i32(ci + (int64_t)(k0 + u) * 64, NTL) : -1;  // the matrix is touched once per application: streaming loads
+      if (!VI) a[u] = in ? ld_val(va + (int64_t)(k0 + u) * 64, NTL) : zero_of(T{});
+    }
+    T xv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      int32_t cc = c[u];
+      if (VI) {
+        a[u] = dict[(uint32_t)cc >> 24 & 0xffu];
+        cc = (cc == -1) ? -1 : (cc & 0xffffff);
+        c[u] = cc;
+      }
+      const int32_t cl = cc < 0 ? 0 : cc;
+      xv[u] = (cl < n) ? x[cl] : xg[cl - n];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+      if (c[u] >= 0) s = add_(s, mul_nc(a[u], xv[u]));
+  }
+  if (pos < n) st_elem_nt(y + (perm ? perm[pos] : pos), s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -347,13 +422,21 @@ __global__ void __launch_bounds__(kBlock)
 // matrix has at most 256 members -- stencils on structured grids, banded Toeplitz-like operators, regular
 // graph Laplacians -- every stored entry is ONE byte indexing that dictionary: the matrix stream shrinks
 // from 12 to 1 byte per non-zero and, because lane = row, the x gathers of one instruction read
-// consecutive addresses x[r + delta] (coalesced, unlike the CSR-stream gather).  One thread per row, row
-// entries visited in CSR order with a separate multiply and add, so y is bit-identical to the plain layout.
+// consecutive addresses x[r + delta] (coalesced, unlike the CSR-stream gather).  Row entries are visited in CSR
+// order with a separate multiply and add, so y is bit-identical to the plain layout.
+//
+// A workgroup owns 256 * RPT consecutive rows; thread t handles rows base + k*256 + t, k < RPT (RPT independent
+// dependency chains per thread: rowptr -> codes -> x).  At one row per thread the kernel was LATENCY-bound (three
+// dependent memory round trips per 27 bytes of a row: 3.1-3.3 TB/s); RPT = 4 puts four times the bytes in flight.
+// The tile's code bytes are contiguous in memory: they are staged into LDS with 16-byte coalesced loads (a row's
+// 7 single-byte global loads become 7/16 of one wide load); tiles whose codes do not fit kDviLds take them from
+// global memory directly.
 // ------------------------------------------------------------------------------------------------
+constexpr int kDviLds = 16384;  // bytes of staged codes per tile (1024 rows x up to 16 entries)
 
-template <class T, int UN>
+template <class T, class IP, int UN, int RPT>
 __global__ void __launch_bounds__(kBlock)
-    k_spmv_dvi(const int32_t* __restrict__ rowptr, const uint8_t* __restrict__ codes, const int32_t* __restrict__ ddelta,
+    k_spmv_dvi(const IP* __restrict__ rowptr, const uint8_t* __restrict__ codes, const int32_t* __restrict__ ddelta,
                const T* __restrict__ dval, const T* __restrict__ x, const T* __restrict__ xg, T* __restrict__ y,
                int64_t n, int ntiles, int ndict, const DevState* __restrict__ st, const uint32_t* __restrict__ hseq,
                int64_t gstride) {
@@ -361,35 +444,68 @@ __global__ void __launch_bounds__(kBlock)
   if (hseq) xg += (int64_t)(*hseq & 1u) * gstride;
   __shared__ int32_t sd[256];
   __shared__ T sv[256];
+  __shared__ __attribute__((aligned(16))) uint8_t sc[kDviLds + 16];
   const int tid = threadIdx.x;
   const int tile = xcd_remap(blockIdx.x, ntiles);
-  const int64_t r = (int64_t)tile * kBlock + tid;
-  const bool live = r < n;
-  const int32_t a = live ? rowptr[r] : 0, b = live ? rowptr[r + 1] : 0;  // in flight while the dictionary is staged
+  const int64_t rbase = (int64_t)tile * (kBlock * RPT);
+  const int64_t rend = (rbase + kBlock * RPT < n) ? rbase + kBlock * RPT : n;
+  const IP p0 = rowptr[rbase], p1 = rowptr[rend];
+  int64_t r[RPT];
+  IP a[RPT];
+  int32_t len[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    r[k] = rbase + k * kBlock + tid;
+    const bool live = r[k] < n;
+    a[k] = live ? rowptr[r[k]] : p0;
+    len[k] = live ? (int32_t)(rowptr[r[k] + 1] - a[k]) : 0;
+  }
+  // stage the tile's codes (16-byte loads from the 16-byte aligned address at or below p0; the buffer is padded)
+  const IP q0 = p0 & ~(IP)15;
+  const int64_t nbytes = (int64_t)(p1 - q0);
+  const bool staged = nbytes <= kDviLds;
+  if (staged) {
+    for (int32_t i = tid * 16; i < nbytes; i += kBlock * 16)
+      *reinterpret_cast<uint4*>(sc + i) = *reinterpret_cast<const uint4*>(codes + q0 + i);
+  }
   if (tid < ndict) {
     sd[tid] = ddelta[tid];
     sv[tid] = dval[tid];
   }
   __syncthreads();
-  T s = zero_of(T{});
-  for (int32_t p = a; p < b; p += UN) {
-    uint8_t code[UN];
+  T s[RPT];
+  int32_t maxlen = 0;
 #pragma unroll
-    for (int k = 0; k < UN; ++k) code[k] = (p + k < b) ? codes[p + k] : (uint8_t)0;
-    T xv[UN];
-#pragma unroll
-    for (int k = 0; k < UN; ++k) {
-      const int64_t c = (p + k < b) ? r + sd[code[k]] : r;
-      xv[k] = (c < n) ? x[c] : xg[c - n];
-    }
-#pragma unroll
-    for (int k = 0; k < UN; ++k) {
-      if (p + k < b) {
-        s = add_(s, mul_nc(sv[code[k]], xv[k]));  // rounded product first, then the add: as the LDS-staged kernel
-      }
-    }
+  for (int k = 0; k < RPT; ++k) {
+    s[k] = zero_of(T{});
+    maxlen = len[k] > maxlen ? len[k] : maxlen;
   }
-  if (live) st_elem_nt(y + r, s);
+  for (int32_t e0 = 0; e0 < maxlen; e0 += UN) {
+    uint8_t code[RPT][UN];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k)
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const bool in = e0 + u < len[k];
+        code[k][u] = in ? (staged ? sc[(int32_t)(a[k] - q0) + e0 + u] : codes[a[k] + e0 + u]) : (uint8_t)0;
+      }
+    T xv[RPT][UN];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k)
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int64_t c = (e0 + u < len[k]) ? r[k] + sd[code[k][u]] : (r[k] < n ? r[k] : 0);
+        xv[k][u] = (c < n) ? x[c] : xg[c - n];
+      }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k)
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+        if (e0 + u < len[k]) s[k] = add_(s[k], mul_nc(sv[code[k][u]], xv[k][u]));  // rounded product first, then the add: as the LDS-staged kernel
+  }
+#pragma unroll
+  for (int k = 0; k < RPT; ++k)
+    if (r[k] < n) st_elem_nt(y + r[k], s[k]);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -328,7 +328,7 @@ def make_line(args, pkg, passes, order, world, rank, force_dist, wl, with_cpu_ba
     nnz_global, A_host, fmt = passes[chosen]["nnz_global"], passes[chosen]["A_host"], passes[chosen]["fmt"]
     out["value"] = state["steps"] / elapsed
     out["ms_per_step"] = 1e3 * elapsed / max(args.steps, 1)
-    layout = {1.0: "csr-dvi", 4.0: "csr-vi"}.get(fmt["bytes_per_nnz"], "csr")
+    layout = fmt["layout"]
     out["config"].update({
         "workload": f"laplace3d-7pt {m}^3 (n={n}, nnz={nnz_global}), nev={nev}, which=SR, mindim={mindim}, maxdim={maxdim}, "
                     f"tol=sqrt(eps), explicit v1 (splitmix64 seed 20240917); step = one Krylov-Schur restart cycle",
@@ -337,7 +337,9 @@ def make_line(args, pkg, passes, order, world, rank, force_dist, wl, with_cpu_ba
         "dgks_second_passes": state["reorth"],
         "spmv_layout": {"csr-dvi": "csr-dvi: %d-entry (column-row, value) dictionary, 1 B per non-zero (bit-identical products)",
                         "csr-vi": "csr-vi: %d-entry value dictionary, 4 B per non-zero (bit-identical products)",
-                        "csr": "csr: 12 B per non-zero%.0s"}[layout] % fmt["ndict"],
+                        "sell": "sell-64: sliced ELLPACK, 12 B per stored entry%.0s",
+                        "sell-vi": "sell-64-vi: sliced ELLPACK with a %d-entry value dictionary, 4 B per stored entry",
+                        "csr": "csr: 12 B per non-zero%.0s"}.get(layout, layout + "%.0s") % fmt["ndict"],
         "basis_placement": passes[chosen]["placement"],  # placement search of the workspace (off unless KS_PLACE_TRIALS > 1)
     })
     if chosen != "single":

@@ -755,7 +755,7 @@ def test_value_indexed_layout_is_bit_identical(dtype, monkeypatch):
 
 
 def test_value_indexed_layout_long_rows():
-    """Tiles above the LDS cap take the wave-per-row path; it must decode the packed words too."""
+    """Rows above a block's capacity get a block of their own (all 256 threads); it must decode the packed words too."""
     n = 600
     rng = np.random.default_rng(5)
     D = sp.csr_matrix(np.where(rng.random((n, n)) < 0.9, rng.integers(1, 4, (n, n)).astype(np.float64), 0.0))
@@ -783,7 +783,7 @@ def test_delta_value_indexed_layout_is_bit_identical(dtype, monkeypatch):
     rng = np.random.default_rng(23)
     x = rnd(rng, dtype, n)
     out = {}
-    for fmt in ("dvi", "vi", "csr"):
+    for fmt in ("dvi", "vi", "csr", "sell", "sellvi"):
         monkeypatch.setenv("KS_SPMV_FORMAT", fmt)
         op = pkg.csr_operator(M)
         ws = pkg.ArnoldiWorkspace(n, 4, dtype)
@@ -794,7 +794,7 @@ def test_delta_value_indexed_layout_is_bit_identical(dtype, monkeypatch):
     assert out["dvi"][1]["bytes_per_nnz"] == 1.0 and 0 < out["dvi"][1]["ndict"] <= 256
     assert out["vi"][1]["bytes_per_nnz"] == 4.0 and out["csr"][1]["ndict"] == 0
     assert pkg.csr_operator(M).format["bytes_per_nnz"] == 1.0   # the default picks the most compact layout
-    for fmt in ("dvi", "vi"):
+    for fmt in ("dvi", "vi", "sell", "sellvi"):
         assert np.array_equal(out[fmt][0].view(np.uint64), out["csr"][0].view(np.uint64)), fmt
     np.testing.assert_allclose(out["dvi"][0], M @ x, rtol=1e-13, atol=1e-13)
 

@@ -1,0 +1,165 @@
+"""`-m gpu`: the device layouts of a stored matrix (mul!(y, A, x), src/expansion.jl:121) -- CSR row blocks
+(skewed rows, rows longer than a block, 64-bit offsets), sliced ELLPACK (padding, sigma-window sorting), the
+delta-value-indexed kernel's rows-per-thread variants -- against scipy and against each other BIT for bit
+(every layout rounds each product on its own and adds in CSR order).  All through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from __graft_entry__ import import_package
+from oracle import arnoldi as oa
+from oracle.matrices import laplace3d
+
+pytestmark = pytest.mark.gpu
+pkg = import_package()
+DTYPES = [np.float64, np.complex128]
+
+
+def rnd(rng, dtype, *shape):
+    a = rng.standard_normal(shape)
+    if np.dtype(dtype).kind == "c":
+        a = a + 1j * rng.standard_normal(shape)
+    return a.astype(dtype)
+
+
+def _skewed(rng, dtype, n):
+    """Short random rows + empty rows + a band of 300-entry rows + rows far longer than any block capacity."""
+    cplx = np.dtype(dtype).kind == "c"
+    A = sp.random(n, n, density=4.0 / n, random_state=rng, format="lil", dtype=np.float64)
+    for r, cnt in ((3, 4097), (n // 3, 9000), (n - 2, 9000)):
+        c = rng.choice(n, cnt, replace=False)
+        A[r, c] = rng.standard_normal(cnt)
+    for r in range(n // 2, n // 2 + 40):
+        c = rng.choice(n, 300, replace=False)
+        A[r, c] = rng.standard_normal(300)
+    A[10:30, :] = 0
+    A = A.tocsr()
+    if cplx:
+        B = A.copy()
+        B.data = rng.standard_normal(B.nnz)
+        A = (A + 1j * B).tocsr()
+    A.sort_indices()
+    return A.astype(dtype)
+
+
+def _apply(A, x, dtype, ctx=None):
+    op = pkg.csr_operator(A, ctx)
+    ws = pkg.ArnoldiWorkspace(A.shape[0], 2, dtype, ctx=op.ctx)
+    ws.set_col(0, x)
+    ws.apply(op, 0, 1)
+    return ws.col(1), op.format, op
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ptr64", ["0", "1"])
+def test_csr_row_blocks_long_rows_and_64bit_offsets(dtype, ptr64, monkeypatch):
+    """k_spmv_csr on a skewed matrix: blocks closed by the non-zero budget, rows with more entries than a block holds
+    (all-threads path), empty rows -- vs scipy to 1e-13 relative; the int64-offset instantiation (what a matrix with
+    nnz >= 2^31 gets, forced by KS_SPMV_PTR64=1) must be BIT-identical to the int32 one; and the same matrix handed
+    over as CSC / Int64 / 1-based (Julia's SparseMatrixCSC) builds the same operator."""
+    rng = np.random.default_rng(101)
+    n = 20011
+    A = _skewed(rng, dtype, n)
+    x = rnd(rng, dtype, n)
+    monkeypatch.setenv("KS_SPMV_PTR64", ptr64)
+    monkeypatch.setenv("KS_SPMV_FORMAT", "csr")
+    y, fmt, op = _apply(A, x, dtype)
+    assert fmt["layout"] == "csr"
+    ref = A @ x
+    scale = np.abs(A) @ np.abs(x)
+    assert np.all(np.abs(y - ref) <= 1e-13 * (scale + 1e-300))
+    assert np.all(y[10:30] == 0)
+    monkeypatch.setenv("KS_SPMV_PTR64", "0")
+    y0, _, _ = _apply(A, x, dtype, op.ctx)
+    assert np.array_equal(y0, y)
+    Ac = A.tocsc()
+    L = pkg._lib.load()
+    h = C.c_void_p()
+    ptr, idx, val = (Ac.indptr.astype(np.int64) + 1), (Ac.indices.astype(np.int64) + 1), np.ascontiguousarray(Ac.data)
+    pkg._lib.check(L.ks_operator_csr(op.ctx._h, n, n, Ac.nnz, ptr.ctypes.data, idx.ctypes.data, val.ctypes.data, pkg._lib.KS_CSC, 1,
+                                     pkg._lib.KS_I64, pkg._lib.KS_C64 if np.dtype(dtype).kind == "c" else pkg._lib.KS_F64, C.byref(h)))
+    opj = pkg.Operator(op.ctx, h, (n, n), dtype)
+    ws = pkg.ArnoldiWorkspace(n, 2, dtype, ctx=op.ctx)
+    ws.set_col(0, x)
+    ws.apply(opj, 0, 1)
+    assert np.array_equal(ws.col(1), y)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_sliced_ellpack_is_bit_identical_and_chosen_for_uniform_rows(dtype, monkeypatch):
+    """A 7-point stencil with VARIABLE coefficients (no dictionary layout applies) is stored as sliced ELLPACK by
+    default; y must equal the CSR-block kernel's bit for bit.  Forced on a ragged matrix (heavy padding, empty rows,
+    Inf in x next to padding) with and without sigma-window sorting it must still agree; a value-indexed SELL too."""
+    cplx = np.dtype(dtype).kind == "c"
+    rng = np.random.default_rng(55)
+    A = laplace3d(13, 14, 15).astype(dtype)
+    A.data = A.data * (1.0 + 0.5 * rng.random(A.nnz)) + (0.1j * rng.random(A.nnz) if cplx else 0)
+    n = A.shape[0]
+    x = rnd(rng, dtype, n)
+    y, fmt, op = _apply(A, x, dtype)
+    assert fmt["layout"] == "sell" and fmt["ndict"] == 0 and fmt["bytes_per_nnz"] < 1.15 * (4 + np.dtype(dtype).itemsize)
+    monkeypatch.setenv("KS_SPMV_FORMAT", "csr")
+    y_csr, f_csr, _ = _apply(A, x, dtype, op.ctx)
+    assert f_csr["layout"] == "csr" and np.array_equal(y.view(np.uint64), y_csr.view(np.uint64))
+    np.testing.assert_allclose(y, A @ x, rtol=1e-13, atol=1e-13)
+    # ragged: rows of 0..40 entries, a few distinct values
+    m = 5003
+    R = sp.random(m, m, density=8.0 / m, random_state=rng, format="csr", dtype=np.float64)
+    R.data = np.array([1.5, -2.0, 0.25, -0.0])[rng.integers(0, 4, R.nnz)]
+    R = R.tolil()
+    R[100:164, :] = 0
+    R[7, rng.choice(m, 40, replace=False)] = 3.0
+    R = R.tocsr().astype(dtype)
+    R.sort_indices()
+    xr = rnd(rng, dtype, m)
+    xr[rng.choice(m, 5, replace=False)] = np.inf  # a padding entry must never be multiplied
+    ref, _, op2 = _apply(R, xr, dtype)
+    assert _["layout"] == "csr"
+    for fmt_name, sigma in (("sell", "1"), ("sell", "256"), ("sellvi", "1"), ("sellvi", "640")):
+        monkeypatch.setenv("KS_SPMV_FORMAT", fmt_name)
+        monkeypatch.setenv("KS_SELL_SIGMA", sigma)
+        got, f, _o = _apply(R, xr, dtype, op2.ctx)
+        assert f["layout"] == ("sell-vi" if fmt_name == "sellvi" else "sell"), f
+        assert np.array_equal(got.view(np.uint64), ref.view(np.uint64)), (fmt_name, sigma)
+    monkeypatch.setenv("KS_SPMV_PTR64", "1")
+    got, f, _o = _apply(R, xr, dtype, op2.ctx)
+    assert np.array_equal(got.view(np.uint64), ref.view(np.uint64))
+
+
+@pytest.mark.parametrize("rpt", ["1", "2", "4"])
+@pytest.mark.parametrize("shape", [(37, 41, 43), (5, 3, 2), (300, 7, 1)])
+def test_dvi_rows_per_thread_variants_bit_identical(rpt, shape, monkeypatch):
+    """k_spmv_dvi with 1 / 2 / 4 rows per thread (LDS-staged codes) vs the CSR blocks and sliced ELLPACK: bit-identical
+    y, including grids whose row count is not a multiple of the tile and tiles with ragged rows (stencil boundaries)."""
+    A = laplace3d(*shape)
+    n = A.shape[0]
+    x = oa.uniform_hash(9, np.arange(n)) - 0.5
+    monkeypatch.setenv("KS_SPMV_FORMAT", "csr")
+    y0, f0, op0 = _apply(A, x, np.float64)
+    assert f0["bytes_per_nnz"] == 12.0
+    monkeypatch.setenv("KS_SPMV_FORMAT", "dvi")
+    monkeypatch.setenv("KS_DVI_RPT", rpt)
+    y1, f1, _ = _apply(A, x, np.float64, op0.ctx)
+    assert f1["layout"] == "csr-dvi" and f1["bytes_per_nnz"] == 1.0
+    assert np.array_equal(y1, y0)
+    monkeypatch.setenv("KS_SPMV_FORMAT", "sellvi")
+    y2, f2, _ = _apply(A, x, np.float64, op0.ctx)
+    assert f2["layout"] == "sell-vi" and np.array_equal(y2, y0)
+    np.testing.assert_allclose(y0, A @ x, rtol=0, atol=1e-14 * 12)
+
+
+def test_solver_end_to_end_on_each_layout(monkeypatch):
+    """The layout must not change what the solver does: same mat-vec count and Ritz values on every layout."""
+    A = laplace3d(14, 15, 16)
+    n = A.shape[0]
+    v1 = oa.uniform_hash(oa.DEFAULT_SEED, np.arange(n))
+    out = {}
+    for f in ("dvi", "vi", "csr", "sell", "sellvi"):
+        monkeypatch.setenv("KS_SPMV_FORMAT", f)
+        dec, hist = pkg.partialschur(A, v1=v1, nev=5, which="SR", tol=1e-10, maxdim=25)
+        out[f] = (hist.mvproducts, np.sort(dec.eigenvalues.real))
+        assert hist.converged
+    for f in out:
+        assert out[f][0] == out["csr"][0] and np.array_equal(out[f][1], out["csr"][1]), f
