@@ -1481,6 +1481,48 @@ template <class D> void rotate_device(ks_workspace* ws, int c0, int c, int r) {
   KS_HIP(hipGetLastError());
 }
 
+// V[:, c0:c0+r) <- V[:, c0:c0+c) * Q with Q on the HOST (column-major, leading dimension ldq), aware of lazily
+// normalised columns: a lazy column is stored as beta * v, so  V Q = (stored) diag(1/beta) Q  -- the factors are
+// folded into the rows of Q instead of touching n-sized data, and the rotated columns come out ordinary.  Lazy columns
+// BELOW the rotated range are not absorbed by this rotation and are made ordinary first.
+template <class T> void rotate_lazy(ks_workspace* ws, int c0, int c, int r, const T* Qh, int ldq, bool update_device_factors = true) {
+  using D = typename DevT<T>::type;
+  if (c <= 0 || r <= 0) return;
+  ws->ctx->use();
+  KS_HIP(hipStreamSynchronize(ws->ctx->stream));  // Qstage may still be in flight from a previous rotation
+  if (ws->has_lazy() && ws->lazy_lo < c0) materialize(ws);
+  T* qs = static_cast<T*>(ws->Qstage);
+  for (int jj = 0; jj < r; ++jj)
+    for (int ii = 0; ii < c; ++ii) qs[ii + (size_t)jj * c] = Qh[ii + (size_t)jj * ldq] * ws->hostscale[c0 + ii];
+  KS_HIP(hipMemcpyAsync(ws->Qd, qs, (size_t)c * r * sizeof(T), hipMemcpyHostToDevice, ws->ctx->stream));
+  rotate_device<D>(ws, c0, c, r);
+  // the rotated columns are ordinary again; the factors of columns c0+r .. c0+c-1 (inputs only) stay as they are
+  bool any = false;
+  for (int ii = 0; ii < r; ++ii) {
+    any = any || ws->hostscale[c0 + ii] != 1.0;
+    ws->hostscale[c0 + ii] = 1.0;
+  }
+  if (any && update_device_factors)
+    KS_HIP(hipMemcpyAsync(ws->colscale + c0, ws->ones.data(), (size_t)r * 8, hipMemcpyHostToDevice, ws->ctx->stream));
+}
+
+// V[:, dst] <- V[:, src] (src/run.jl:365), lazy-aware: the factor of a lazy source is applied on the way, the
+// destination comes out ordinary, every other column keeps its state.
+template <class D> void col_copy_lazy(ks_workspace* ws, int dst, int src) {
+  ws->ctx->use();
+  const double f = ws->hostscale[src];
+  if (dst == src) {
+    if (f != 1.0) ksd::k_scale<D><<<ws->nb, kBlock, 0, ws->ctx->stream>>>(static_cast<D*>(ws->col(src)), ws->ld, f, nullptr);
+  } else {
+    ksd::k_copy<D><<<ws->nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const D*>(ws->col(src)), static_cast<D*>(ws->col(dst)), ws->ld, f);
+  }
+  KS_HIP(hipGetLastError());
+  if (ws->hostscale[dst] != 1.0 || (dst == src && f != 1.0)) {
+    ws->hostscale[dst] = 1.0;
+    KS_HIP(hipMemcpyAsync(ws->colscale + dst, ws->ones.data(), 8, hipMemcpyHostToDevice, ws->ctx->stream));
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // the HIP backend of the driver
 // ------------------------------------------------------------------------------------------------
@@ -1548,17 +1590,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
 
   void rotate(int c0, int c, int r, const ks::Mat<T>& Q) override {
     if (c <= 0 || r <= 0) return;
-    ws->ctx->use();
-    KS_HIP(hipStreamSynchronize(ws->ctx->stream));  // Qstage may still be in flight from a previous rotation
-    T* qs = static_cast<T*>(ws->Qstage);
-    // lazy columns below the rotated range are not absorbed by this rotation: make them ordinary first
-    if (ws->has_lazy() && ws->lazy_lo < c0) materialize(ws);
-    // lazily normalised columns are stored as beta*v: V Q = (stored) diag(1/beta) Q  -> scale the rows of Q
-    for (int jj = 0; jj < r; ++jj)
-      for (int ii = 0; ii < c; ++ii) qs[ii + (size_t)jj * c] = Q(c0 + ii, c0 + jj) * ws->hostscale[c0 + ii];
-    KS_HIP(hipMemcpyAsync(ws->Qd, qs, (size_t)c * r * sizeof(T), hipMemcpyHostToDevice, ws->ctx->stream));
-    rotate_device<D>(ws, c0, c, r);
-    for (int ii = 0; ii < r; ++ii) ws->hostscale[c0 + ii] = 1.0;  // the rotated columns are ordinary again
+    rotate_lazy<T>(ws, c0, c, r, &Q(c0, c0), Q.ld, /*update_device_factors=*/false);  // col_copy resets them right after
   }
 
   // V[:, dst] <- V[:, src]: the last act of a restart (src = maxdim holds the residual direction).  Every
@@ -2379,14 +2411,8 @@ int ks_col_copy(ks_workspace* ws, int dst, int src) {
   return guarded([&] {
     check_col(ws, dst);
     check_col(ws, src);
-    ws->ctx->use();
-    materialize(ws);
-    if (dst == src) return;
-    dispatch_dtype(ws->dtype, [&](auto tag) {
-      using D = typename DevT<decltype(tag)>::type;
-      ksd::k_copy<D><<<ws->nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const D*>(ws->col(src)), static_cast<D*>(ws->col(dst)), ws->ld, 1.0);
-    });
-    KS_HIP(hipGetLastError());
+    // lazy-aware: a lazily normalised source is scaled on the way, nothing else is touched
+    dispatch_dtype(ws->dtype, [&](auto tag) { col_copy_lazy<typename DevT<decltype(tag)>::type>(ws, dst, src); });
     KS_HIP(hipStreamSynchronize(ws->ctx->stream));
   });
 }
@@ -2433,18 +2459,10 @@ int ks_rotate(ks_workspace* ws, int c0, int c, int r, const void* Q_host, int ld
     KS_REQUIRE(c0 >= 0 && c >= 1 && r >= 1 && r <= c && c0 + c <= ws->maxdim + 1 && ldq >= c, KS_ERR_ARGUMENT,
                "bad rotation shape");
     KS_REQUIRE((size_t)c * r <= (size_t)ws->maxdim * ws->maxdim, KS_ERR_ARGUMENT, "rotation larger than the workspace Q");
-    ws->ctx->use();
-    materialize(ws);
-    KS_HIP(hipStreamSynchronize(ws->ctx->stream));
+    // lazily normalised columns inside the rotated range are absorbed into Q (no scaling passes), see rotate_lazy
     dispatch_dtype(ws->dtype, [&](auto tag) {
       using T = decltype(tag);
-      using D = typename DevT<T>::type;
-      const T* Qh = static_cast<const T*>(Q_host);
-      T* qs = static_cast<T*>(ws->Qstage);
-      for (int jj = 0; jj < r; ++jj)
-        for (int ii = 0; ii < c; ++ii) qs[ii + (size_t)jj * c] = Qh[ii + (size_t)jj * ldq];
-      KS_HIP(hipMemcpyAsync(ws->Qd, qs, (size_t)c * r * sizeof(T), hipMemcpyHostToDevice, ws->ctx->stream));
-      rotate_device<D>(ws, c0, c, r);
+      rotate_lazy<T>(ws, c0, c, r, static_cast<const T*>(Q_host), ldq);
     });
     KS_HIP(hipStreamSynchronize(ws->ctx->stream));
   });

@@ -1,35 +1,57 @@
-# KrylovSchurHIP.jl -- the Julia side of the drop-in boundary (UNTESTED: no Julia runtime exists in the
-# build image; every `ccall` below mirrors one prototype of include/kschur.h one-to-one and the same
-# entry points are exercised from Python/ctypes by tests/test_gpu_parity.py).
+# KrylovSchurHIP.jl -- the Julia side of the drop-in boundary.
 #
-# Two levels of integration with ArnoldiMethod.jl:
+# NOT EXECUTED in the build image (no Julia runtime exists there).  What IS checked without Julia: every
+# `ccall((:name, LIB), ret, (argtypes...), ...)` below is parsed by tests/test_julia_glue.py and compared -- name,
+# arity, every argument type, the KsParams / KsHistory / KsExpandStats field layouts -- against include/kschur.h, and
+# the same entry points are exercised from Python/ctypes by the `-m gpu` tests.
 #
-#   (1) whole-solver drop-in:   hip_partialschur(A; nev, which, tol, ...)  ->  (PartialSchur, History)
-#       one ccall into ks_partialschur; Q stays in HBM and is downloaded lazily.
+# Three levels of integration with ArnoldiMethod.jl (v0.4.0), most faithful first:
 #
-#   (2) array-type seam (src/ArnoldiMethod.jl:81-92): `HipBasis <: AbstractMatrix{T}` plugged into
-#       `ArnoldiWorkspace(V, H; V_tmp, Q)`.  ArnoldiMethod's own `_partialschur` then runs unchanged and
-#       only `iterate_arnoldi!` (src/expansion.jl:116-133) and the restart rotation (src/run.jl:363-365,
-#       382-383) are specialised below to call the fused device paths.
+#   (1) ARRAY-TYPE SEAM (src/ArnoldiMethod.jl:81-92, advertised use "custom array type for the basis", src/run.jl:142-143):
+#       `HipBasis{T} <: AbstractMatrix{T}` lives in HBM.  `ArnoldiWorkspace(V::HipBasis, H)` is the reference's own
+#       constructor, and the reference's own `partialschur!` / `_partialschur` (src/run.jl:152-392) run UNCHANGED:
+#       every verb they apply to V or to a view of V is a method below that forwards to one C entry point
+#           view(V, :, j) / view(V, :, a:b)              -> HipColumn / HipColumns        (no data movement)
+#           rand!(v), copyto!(v, v1)                     -> ks_col_fill_uniform / ks_col_upload     expansion.jl:21, run.jl:121,126
+#           norm(v)                                      -> ks_col_norm                             expansion.jl:24,41,48,81,88,96
+#           v ./= s                                      -> ks_col_div                              expansion.jl:28,56,106
+#           mul!(w, A, v)                                -> ks_apply                                expansion.jl:121
+#           mul!(h, Vprev', v),  Vprev' * v              -> ks_gemv_t                               expansion.jl:37,46,84,93
+#           mul!(v, Vprev, h, -1, 1)                     -> ks_gemv_n_sub                           expansion.jl:38,47,85,94
+#           mul!(V_tmp[:, a:b], V[:, a:c], Q[a:c, a:b])  -> ks_rotate (in place; V_tmp is an alias)  run.jl:363,382
+#           copyto!(V[:, a:b], V_tmp[:, a:b])            -> nothing (already in place)              run.jl:364,383
+#           copyto!(V[:, k+1], V[:, maxdim+1])           -> ks_col_copy                             run.jl:365
+#           P.Q * vecs                                   -> ks_basis_times                          eigvals.jl:94
+#   (2) FUSED EXPANSION: `ArnoldiMethod.iterate_arnoldi!(A::HipOperator, arnoldi{<:HipBasis}, range)` replaces the
+#       verb-by-verb loop of src/expansion.jl:116-133 by ONE call (ks_iterate_arnoldi: the whole range enqueued, DGKS
+#       decisions on the device, three passes over V per step, lazy normalisation).  Everything else of
+#       `_partialschur` still runs in Julia; the rotation verbs above absorb the lazy column factors.
+#   (3) `ArnoldiMethod.partialschur(A::HipOperator; ...)`: builds the HipBasis workspace and calls the reference's
+#       `partialschur!`; `hip_partialschur` is the whole solver as one C call (ks_partialschur), for comparison.
 #
-# Usage sketch:
+# Usage:
 #     using ArnoldiMethod, SparseArrays
 #     include("KrylovSchurHIP.jl"); using .KrylovSchurHIP
-#     A = ...::SparseMatrixCSC{Float64,Int64}
-#     decomp, history = hip_partialschur(A; nev = 20, which = :SR, tol = 1e-10)
-#     λ, X = hip_partialeigen(decomp)
+#     ctx = HipContext(0)
+#     A   = HipOperator(ctx, sprand(10^6, 10^6, 5e-6) + I)       # SparseMatrixCSC{Float64,Int64} goes over as it is
+#     decomp, history = partialschur(A; nev = 20, which = :SR, tol = 1e-10)   # ArnoldiMethod's own driver on HipBasis
+#     λ, X = partialeigen(decomp)
 module KrylovSchurHIP
 
-using LinearAlgebra, SparseArrays
+using LinearAlgebra, SparseArrays, Random
+import ArnoldiMethod
+import ArnoldiMethod: ArnoldiWorkspace, PartialSchur
 
-export HipContext, HipOperator, HipWorkspace, hip_partialschur, hip_partialschur!, hip_partialeigen
+export HipContext, HipOperator, HipWorkspace, HipBasis, HipColumn, HipColumns, hip_partialschur, hip_partialschur!, hip_partialeigen
 
 const LIB = get(ENV, "KSCHUR_LIB", joinpath(@__DIR__, "..", "libkschur_hip.so"))
 
 const KS_F64, KS_C64 = Cint(0), Cint(1)
 const KS_I32, KS_I64 = Cint(0), Cint(1)
 const KS_CSR, KS_CSC = Cint(0), Cint(1)
+const KS_ROW_MAJOR, KS_COL_MAJOR = Cint(0), Cint(1)
 const WHICH = Dict(:LM => Cint(0), :LR => Cint(1), :SR => Cint(2), :LI => Cint(3), :SI => Cint(4))
+const HipScalar = Union{Float64,ComplexF64}
 
 dtype_code(::Type{Float64}) = KS_F64
 dtype_code(::Type{ComplexF64}) = KS_C64
@@ -49,93 +71,135 @@ function check(rc::Cint)
 end
 
 # ---------------------------------------------------------------------------------------------- context
+# Children (operators, workspaces) hold a reference to their context and register themselves, so the context is
+# destroyed only after every child handle: finalizer order is unspecified in Julia.
 mutable struct HipContext
     h::Ptr{Cvoid}
+    live::Int            # child handles still alive
+    dead::Bool           # finalizer ran while children were alive: the last child destroys the context
     function HipContext(device::Integer = 0)
         r = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:ks_ctx_create, LIB), Cint, (Cint, Ref{Ptr{Cvoid}}), device, r))
-        c = new(r[])
-        finalizer(x -> ccall((:ks_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), c)
+        c = new(r[], 0, false)
+        finalizer(_ctx_finalize, c)
         c
     end
+end
+function _ctx_destroy(c::HipContext)
+    if c.h != C_NULL
+        ccall((:ks_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), c.h)
+        c.h = C_NULL
+    end
+    nothing
+end
+_ctx_finalize(c::HipContext) = c.live == 0 ? _ctx_destroy(c) : (c.dead = true; nothing)
+_adopt(c::HipContext) = (c.live += 1; nothing)
+function _release(c::HipContext)
+    c.live -= 1
+    (c.live == 0 && c.dead) && _ctx_destroy(c)
+    nothing
 end
 
 # ---------------------------------------------------------------------------------------------- operator
 # mul!(y, A, x) for A::SparseMatrixCSC (stdlib SparseArrays; call site src/expansion.jl:121):
-# colptr / rowval / nzval are handed over as they are (CSC, 1-based, Int64) and converted once to
-# int32 0-based CSR in HBM by the library.
+# colptr / rowval / nzval are handed over as they are (CSC, 1-based, Int64 or Int32) and converted once into the
+# device layout the library picks (ks_operator_format).
 mutable struct HipOperator{T}
     h::Ptr{Cvoid}
     n::Int
     ctx::HipContext
+    keep::Any            # what a callback operator must keep alive (Ref to the user's operator)
 end
 Base.eltype(::HipOperator{T}) where {T} = T
+Base.eltype(::Type{HipOperator{T}}) where {T} = T
 Base.size(A::HipOperator) = (A.n, A.n)
 Base.size(A::HipOperator, i::Integer) = i <= 2 ? A.n : 1
 
-function HipOperator(ctx::HipContext, A::SparseMatrixCSC{T,Int64}) where {T<:Union{Float64,ComplexF64}}
+function _finish_operator(::Type{T}, h::Ptr{Cvoid}, n::Int, ctx::HipContext, keep) where {T}
+    op = HipOperator{T}(h, n, ctx, keep)
+    _adopt(ctx)
+    finalizer(op) do x
+        if x.h != C_NULL
+            ccall((:ks_operator_destroy, LIB), Cint, (Ptr{Cvoid},), x.h)
+            x.h = C_NULL
+            _release(x.ctx)
+        end
+    end
+    op
+end
+
+index_code(::Type{Int64}) = KS_I64
+index_code(::Type{Int32}) = KS_I32
+
+function HipOperator(ctx::HipContext, A::SparseMatrixCSC{T,Ti}) where {T<:HipScalar,Ti<:Union{Int32,Int64}}
     n = LinearAlgebra.checksquare(A)
     r = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve A begin
         check(ccall((:ks_operator_csr, LIB), Cint,
                     (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Cint, Cint, Ref{Ptr{Cvoid}}),
                     ctx.h, n, n, nnz(A), pointer(A.colptr), pointer(A.rowval), pointer(A.nzval),
-                    KS_CSC, 1, KS_I64, dtype_code(T), r))
+                    KS_CSC, 1, index_code(Ti), dtype_code(T), r))
     end
-    op = HipOperator{T}(r[], n, ctx)
-    finalizer(x -> ccall((:ks_operator_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), op)
-    op
+    _finish_operator(T, r[], n, ctx, nothing)
 end
+# integer / Float32 / other element types are promoted like `vtype` does (src/run.jl:9-12)
+HipOperator(ctx::HipContext, A::SparseMatrixCSC{Tv,Ti}) where {Tv<:Real,Ti} = HipOperator(ctx, SparseMatrixCSC{Float64,Int64}(A))
+HipOperator(ctx::HipContext, A::SparseMatrixCSC{Tv,Ti}) where {Tv<:Complex,Ti} = HipOperator(ctx, SparseMatrixCSC{ComplexF64,Int64}(A))
 
-# mul!(y, A, x) for a dense A::Matrix (column-major; the library keeps a row-major copy in HBM and streams it
-# once per product).
-function HipOperator(ctx::HipContext, A::Matrix{T}) where {T<:Union{Float64,ComplexF64}}
+# mul!(y, A, x) for a dense A::Matrix (column-major; the library keeps a row-major copy in HBM).
+function HipOperator(ctx::HipContext, A::Matrix{T}) where {T<:HipScalar}
     n = LinearAlgebra.checksquare(A)
     r = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve A begin
         check(ccall((:ks_operator_dense, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Cint, Cint, Ref{Ptr{Cvoid}}),
-                    ctx.h, n, pointer(A), stride(A, 2), #=KS_COL_MAJOR=# 1, dtype_code(T), r))
+                    ctx.h, n, pointer(A), stride(A, 2), KS_COL_MAJOR, dtype_code(T), r))
     end
-    op = HipOperator{T}(r[], n, ctx)
-    finalizer(x -> ccall((:ks_operator_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), op)
-    op
+    _finish_operator(T, r[], n, ctx, nothing)
 end
 
-# Device layout the library chose for a stored matrix: (bytes streamed per non-zero, dictionary size).
+"Device layout the library chose for a stored matrix: (bytes streamed per non-zero, dictionary size, layout code)."
 function operator_format(A::HipOperator)
-    b = Ref{Cdouble}(0); d = Ref{Cint}(0)
-    check(ccall((:ks_operator_format, LIB), Cint, (Ptr{Cvoid}, Ref{Cdouble}, Ref{Cint}), A.h, b, d))
-    (bytes_per_nnz = b[], ndict = Int(d[]))
+    b = Ref{Cdouble}(0); d = Ref{Cint}(0); l = Ref{Cint}(0)
+    check(ccall((:ks_operator_format, LIB), Cint, (Ptr{Cvoid}, Ref{Cdouble}, Ref{Cint}, Ref{Cint}), A.h, b, d, l))
+    (bytes_per_nnz = b[], ndict = Int(d[]), layout = (:csr, :csr_vi, :dvi, :sell, :sell_vi)[l[] + 1])
 end
 
-# Opaque operators (LinearMaps etc., docs/src/index.md:246-249): the library calls back with two host
-# pointers per application.  `@cfunction` is safe here: the call is synchronous on the calling task.
+# Opaque operators (LinearMaps etc., docs/src/index.md:246-249): the library calls back with two host pointers per
+# application; `user` is the address of a `Ref{Any}` that the HipOperator keeps alive (field `keep`) -- a mutable box,
+# so the pointer is stable, unlike the address of an immutable tuple passed as `Any`.
+struct _HostOp
+    A::Any
+    T::DataType
+    n::Int
+end
 function _host_apply(user::Ptr{Cvoid}, x::Ptr{Cvoid}, y::Ptr{Cvoid})::Cint
-    st = unsafe_pointer_to_objref(user)::Tuple
-    A, T, n = st
+    st = unsafe_pointer_to_objref(user)[]::_HostOp
     try
-        mul!(unsafe_wrap(Array, Ptr{T}(y), n), A, unsafe_wrap(Array, Ptr{T}(x), n))
+        _host_apply_typed(st.A, st.T, st.n, x, y)
         return Cint(0)
     catch
         return Cint(1)
     end
 end
-
-function HipOperator(ctx::HipContext, A, ::Type{T}) where {T}
-    n = size(A, 1)
-    st = (A, T, n)
-    r = Ref{Ptr{Cvoid}}(C_NULL)
-    cb = @cfunction(_host_apply, Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}))
-    check(ccall((:ks_operator_host_callback, LIB), Cint, (Ptr{Cvoid}, Int64, Cint, Ptr{Cvoid}, Any, Ref{Ptr{Cvoid}}),
-                ctx.h, n, dtype_code(T), cb, st, r))
-    op = HipOperator{T}(r[], n, ctx)
-    # keep `st` alive as long as the operator
-    finalizer(x -> (st; ccall((:ks_operator_destroy, LIB), Cint, (Ptr{Cvoid},), x.h)), op)
-    op
+function _host_apply_typed(A, ::Type{T}, n::Int, x::Ptr{Cvoid}, y::Ptr{Cvoid}) where {T}
+    mul!(unsafe_wrap(Array, Ptr{T}(y), n), A, unsafe_wrap(Array, Ptr{T}(x), n))
+    nothing
 end
 
-# ---------------------------------------------------------------------------------------------- workspace
-# ArnoldiWorkspace{T}: V in HBM, H and Q as Julia views of the library's pinned host arrays.
+function HipOperator(ctx::HipContext, A, ::Type{T}) where {T<:HipScalar}
+    n = size(A, 1)
+    box = Ref{Any}(_HostOp(A, T, n))
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    cb = @cfunction(_host_apply, Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}))
+    GC.@preserve box begin
+        check(ccall((:ks_operator_host_callback, LIB), Cint, (Ptr{Cvoid}, Int64, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}),
+                    ctx.h, n, dtype_code(T), cb, pointer_from_objref(box), r))
+    end
+    _finish_operator(T, r[], n, ctx, box)   # `box` stays reachable through the operator for as long as the handle lives
+end
+
+# ---------------------------------------------------------------------------------------------- workspace handle
+# The library's ArnoldiWorkspace: V in HBM; its own pinned host H and Q (used by the fused paths) wrapped without copies.
 mutable struct HipWorkspace{T}
     h::Ptr{Cvoid}
     n::Int
@@ -145,7 +209,8 @@ mutable struct HipWorkspace{T}
     ctx::HipContext
 end
 
-function HipWorkspace(ctx::HipContext, ::Type{T}, n::Integer, maxdim::Integer) where {T}
+function HipWorkspace(ctx::HipContext, ::Type{T}, n::Integer, maxdim::Integer) where {T<:HipScalar}
+    maxdim <= n || throw(ArgumentError("Krylov dimension should be less than matrix order."))  # src/ArnoldiMethod.jl:62-63
     r = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:ks_workspace_create, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Int64, Cint, Cint, Ref{Ptr{Cvoid}}),
                 ctx.h, n, n, 0, maxdim, dtype_code(T), r))
@@ -155,43 +220,234 @@ function HipWorkspace(ctx::HipContext, ::Type{T}, n::Integer, maxdim::Integer) w
     check(ccall((:ks_workspace_Q, LIB), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ref{Cint}), r[], hp, ld))
     Q = unsafe_wrap(Array, Ptr{T}(hp[]), (maxdim, maxdim))
     w = HipWorkspace{T}(r[], n, maxdim, H, Q, ctx)
-    finalizer(x -> ccall((:ks_workspace_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), w)
+    _adopt(ctx)
+    finalizer(w) do x
+        if x.h != C_NULL
+            ccall((:ks_workspace_destroy, LIB), Cint, (Ptr{Cvoid},), x.h)
+            x.h = C_NULL
+            _release(x.ctx)
+        end
+    end
     w
 end
 
-"Array(view(V, :, j0+1:j0+ncols)) -- results are views of V (src/run.jl:375,389)"
+"Array(view(V, :, j0+1:j0+ncols)): host copy of device columns"
 function columns(w::HipWorkspace{T}, j0::Integer, ncols::Integer) where {T}
     out = Matrix{T}(undef, w.n, ncols)
-    check(ccall((:ks_cols_download, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Int64), w.h, j0, ncols, out, w.n))
+    ncols == 0 && return out
+    GC.@preserve out check(ccall((:ks_cols_download, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Int64), w.h, j0, ncols, pointer(out), w.n))
     out
 end
 
-# --- the verbs of src/expansion.jl on device columns (0-based column index j) ---
-col_norm(w::HipWorkspace, j) = (r = Ref{Cdouble}(0); check(ccall((:ks_col_norm, LIB), Cint, (Ptr{Cvoid}, Cint, Ref{Cdouble}), w.h, j, r)); r[])
-col_div!(w::HipWorkspace, j, s) = check(ccall((:ks_col_div, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble), w.h, j, s))
-apply!(A::HipOperator, w::HipWorkspace, jsrc, jdst) = check(ccall((:ks_apply, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint), A.h, w.h, jsrc, jdst))
-function gemv_t!(h::AbstractVector{T}, w::HipWorkspace{T}, j, jv) where {T}
-    check(ccall((:ks_gemv_t, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}), w.h, j, jv, h))
+# ---------------------------------------------------------------------------------------------- (1) the array-type seam
+"""
+    HipBasis{T}(ctx, n, ncols)            # n x ncols basis in HBM; ncols = krylov_dimension + 1
+
+`AbstractMatrix{T}` whose storage is the `V` of a library workspace.  Plug it into the reference's own constructor,
+`ArnoldiWorkspace(V, zeros(T, ncols, ncols - 1))` (src/ArnoldiMethod.jl:81-92).  `similar(V)` -- what that constructor
+uses for `V_tmp` -- returns an ALIAS of the same storage: the restart rotation runs in place on the device, a second
+n-sized array is never allocated (DESIGN.md section 2).
+"""
+struct HipBasis{T} <: AbstractMatrix{T}
+    ws::HipWorkspace{T}
+    alias::Bool        # true: this is the V_tmp stand-in
+end
+HipBasis{T}(ctx::HipContext, n::Integer, ncols::Integer) where {T<:HipScalar} = HipBasis{T}(HipWorkspace(ctx, T, n, ncols - 1), false)
+Base.size(V::HipBasis) = (V.ws.n, V.ws.maxdim + 1)
+Base.similar(V::HipBasis{T}) where {T} = HipBasis{T}(V.ws, true)
+# H and Q of `ArnoldiWorkspace(v1, k)` / defaults are `similar(V, k+1, k)`: small HOST matrices (src/ArnoldiMethod.jl:74-77)
+Base.similar(V::HipBasis{T}, dims::Tuple{Int,Int}) where {T} = Matrix{T}(undef, dims)
+Base.similar(V::HipBasis{T}, m::Int, n::Int) where {T} = Matrix{T}(undef, m, n)
+
+"view(V, :, j): one column in HBM (0-based index `j`)"
+struct HipColumn{T} <: AbstractVector{T}
+    ws::HipWorkspace{T}
+    j::Int
+end
+"view(V, :, a:b): consecutive columns in HBM, starting at 0-based column `j0`"
+struct HipColumns{T} <: AbstractMatrix{T}
+    ws::HipWorkspace{T}
+    j0::Int
+    ncols::Int
+    alias::Bool
+end
+Base.size(v::HipColumn) = (v.ws.n,)
+Base.size(V::HipColumns) = (V.ws.n, V.ncols)
+Base.view(V::HipBasis{T}, ::Colon, j::Integer) where {T} = HipColumn{T}(V.ws, Int(j) - 1)
+Base.view(V::HipBasis{T}, ::Colon, r::AbstractUnitRange{<:Integer}) where {T} = HipColumns{T}(V.ws, Int(first(r)) - 1, length(r), V.alias)
+Base.view(V::HipColumns{T}, ::Colon, j::Integer) where {T} = HipColumn{T}(V.ws, V.j0 + Int(j) - 1)
+Base.view(V::HipColumns{T}, ::Colon, r::AbstractUnitRange{<:Integer}) where {T} = HipColumns{T}(V.ws, V.j0 + Int(first(r)) - 1, length(r), V.alias)
+
+# scalar indexing exists for `show` and debugging only (one PCIe round trip per element)
+Base.getindex(v::HipColumn, i::Int) = Array(v)[i]
+Base.getindex(V::HipColumns, i::Int, j::Int) = Array(view(V, :, j))[i]
+Base.getindex(V::HipBasis, i::Int, j::Int) = Array(view(V, :, j))[i]
+Base.Array(v::HipColumn) = vec(columns(v.ws, v.j, 1))
+Base.Array(V::HipColumns) = columns(V.ws, V.j0, V.ncols)
+Base.Array(V::HipBasis) = columns(V.ws, 0, V.ws.maxdim + 1)
+Base.Matrix(V::HipColumns) = Array(V)
+Base.Matrix(V::HipBasis) = Array(V)
+Base.Vector(v::HipColumn) = Array(v)
+Base.collect(V::Union{HipColumn,HipColumns,HipBasis}) = Array(V)
+
+# populate!(v): rand!(v) (src/expansion.jl:15,21) and copyto!(v, v1) (src/run.jl:126)
+function Random.rand!(rng::Random.AbstractRNG, v::HipColumn)
+    check(ccall((:ks_col_fill_uniform, LIB), Cint, (Ptr{Cvoid}, Cint, UInt64), v.ws.h, v.j, rand(rng, UInt64)))
+    v
+end
+Random.rand!(v::HipColumn) = Random.rand!(Random.default_rng(), v)
+function Base.copyto!(v::HipColumn{T}, src::AbstractVector) where {T}
+    length(src) == v.ws.n || throw(DimensionMismatch("source has length $(length(src)), the column has $(v.ws.n)"))
+    buf = convert(Vector{T}, src)
+    GC.@preserve buf check(ccall((:ks_col_upload, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}), v.ws.h, v.j, pointer(buf)))
+    v
+end
+# copyto!(view(V, :, k+1), view(V, :, maxdim+1))   src/run.jl:365
+function Base.copyto!(dst::HipColumn{T}, src::HipColumn{T}) where {T}
+    dst.ws === src.ws || return copyto!(dst, Array(src))
+    check(ccall((:ks_col_copy, LIB), Cint, (Ptr{Cvoid}, Cint, Cint), dst.ws.h, dst.j, src.j))
+    dst
+end
+# copyto!(view(V, :, a:b), view(V_tmp, :, a:b))   src/run.jl:364,383: the rotation already happened in place
+function Base.copyto!(dst::HipColumns{T}, src::HipColumns{T}) where {T}
+    size(dst) == size(src) || throw(DimensionMismatch("column blocks differ in size"))
+    if dst.ws === src.ws && dst.j0 == src.j0
+        return dst
+    end
+    for c in 1:dst.ncols
+        copyto!(view(dst, :, c), view(src, :, c))
+    end
+    dst
+end
+
+# norm(v)   src/expansion.jl:24,41,48,81,88,96
+function LinearAlgebra.norm(v::HipColumn)
+    r = Ref{Cdouble}(0)
+    check(ccall((:ks_col_norm, LIB), Cint, (Ptr{Cvoid}, Cint, Ref{Cdouble}), v.ws.h, v.j, r))
+    r[]
+end
+LinearAlgebra.norm(v::HipColumn, p::Real) = p == 2 ? norm(v) : norm(Array(v), p)
+
+# v ./= s   src/expansion.jl:28,56,106  (lowers to materialize!(v, broadcasted(/, v, s)))
+function Base.Broadcast.materialize!(dest::HipColumn{T}, bc::Base.Broadcast.Broadcasted{S,Ax,typeof(/),Tuple{HipColumn{T},N}}) where {T,S,Ax,N<:Number}
+    src, s = bc.args
+    (src.ws === dest.ws && src.j == dest.j) || throw(ArgumentError("only the in-place form v ./= s is supported on device columns"))
+    check(ccall((:ks_col_div, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble), dest.ws.h, dest.j, Float64(real(s))))
+    dest
+end
+
+# mul!(view(V, :, j+1), A, view(V, :, j))   src/expansion.jl:121
+function LinearAlgebra.mul!(y::HipColumn{T}, A::HipOperator{T}, x::HipColumn{T}) where {T}
+    y.ws === x.ws || throw(ArgumentError("source and destination columns must belong to the same basis"))
+    check(ccall((:ks_apply, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint), A.h, y.ws.h, x.j, y.j))
+    y
+end
+# any other operator with a host mul!: one column over PCIe each way (what the reference does for LinearMaps, but
+# prefer HipOperator(ctx, A, T), which lets the library batch the transfers)
+function _host_mul!(y::HipColumn{T}, A, x::HipColumn{T}) where {T}
+    xh = Array(x)
+    yh = similar(xh)
+    mul!(yh, A, xh)
+    copyto!(y, yh)
+end
+LinearAlgebra.mul!(y::HipColumn{T}, A::AbstractMatrix, x::HipColumn{T}) where {T} = _host_mul!(y, A, x)
+LinearAlgebra.mul!(y::HipColumn{T}, A, x::HipColumn{T}) where {T} = _host_mul!(y, A, x)
+
+# mul!(h, Vprev', v) with h a HOST vector (a view of H)   src/expansion.jl:46,84;   Vprev' * v   src/expansion.jl:37,93
+function _gemv_t(Vp::HipColumns{T}, v::HipColumn{T}) where {T}
+    Vp.j0 == 0 || throw(ArgumentError("the projected-out block must start at the first column"))
+    Vp.ws === v.ws || throw(ArgumentError("Vprev and v must belong to the same basis"))
+    h = Vector{T}(undef, Vp.ncols)
+    Vp.ncols == 0 && return h
+    GC.@preserve h check(ccall((:ks_gemv_t, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}), v.ws.h, Vp.ncols, v.j, pointer(h)))
     h
 end
-gemv_n_sub!(w::HipWorkspace{T}, j, jv, h::AbstractVector{T}) where {T} =
-    check(ccall((:ks_gemv_n_sub, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}), w.h, j, jv, h))
-
-"iterate_arnoldi!(A, arnoldi, from:to)  (src/expansion.jl:116-133), fused and asynchronous on the device"
-function iterate_arnoldi!(A::HipOperator, w::HipWorkspace, range::UnitRange{Int})
-    stats = zeros(Int32, 4)
-    check(ccall((:ks_iterate_arnoldi, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Ptr{Int32}), A.h, w.h, first(range), last(range), stats))
-    w
+Base.:*(Va::Adjoint{T,HipColumns{T}}, v::HipColumn{T}) where {T} = _gemv_t(parent(Va), v)
+function LinearAlgebra.mul!(h::AbstractVector, Va::Adjoint{T,HipColumns{T}}, v::HipColumn{T}) where {T}
+    copyto!(h, _gemv_t(parent(Va), v))
+    h
 end
 
-"V[:, purge:k] = V[:, purge:maxdim] * Q[purge:maxdim, purge:k]  (src/run.jl:363-364), in place, MFMA"
-function rotate!(w::HipWorkspace{T}, purge::Int, k::Int, maxdim::Int) where {T}
-    c, r = maxdim - purge + 1, k - purge + 1
-    Qb = w.Q[purge:maxdim, purge:k]             # small host copy, column-major, ld = c
-    check(ccall((:ks_rotate, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cvoid}, Cint), w.h, purge - 1, c, r, Qb, c))
+# mul!(v, Vprev, h, -one(T), one(T))   src/expansion.jl:38,47,85,94
+function LinearAlgebra.mul!(v::HipColumn{T}, Vp::HipColumns{T}, h::AbstractVector, α::Number, β::Number) where {T}
+    (α == -1 && β == 1) || throw(ArgumentError("device columns support mul!(v, Vprev, h, -1, 1) only (the Gram-Schmidt update)"))
+    (Vp.j0 == 0 && Vp.ws === v.ws) || throw(ArgumentError("the projected-out block must start at the first column of the same basis"))
+    Vp.ncols == 0 && return v
+    hb = convert(Vector{T}, h)
+    GC.@preserve hb check(ccall((:ks_gemv_n_sub, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}), v.ws.h, Vp.ncols, v.j, pointer(hb)))
+    v
 end
 
-# ---------------------------------------------------------------------------------------------- drivers
+# mul!(view(V_tmp, :, a:b), view(V, :, a:c), view(Q, a:c, a:b))   src/run.jl:363, 382: in place on the device.
+# The destination must be a block of the alias (V_tmp = similar(V)) starting at the same column as the source.
+function LinearAlgebra.mul!(dst::HipColumns{T}, src::HipColumns{T}, Qb::AbstractMatrix) where {T}
+    (dst.ws === src.ws && dst.j0 == src.j0) ||
+        throw(ArgumentError("device rotation is in place: destination and source blocks must start at the same column of the same basis"))
+    c, r = src.ncols, dst.ncols
+    size(Qb) == (c, r) || throw(DimensionMismatch("Q block is $(size(Qb)), expected ($c, $r)"))
+    (c == 0 || r == 0) && return dst
+    Qh = Matrix{T}(Qb)                     # small host copy, column-major, leading dimension c
+    GC.@preserve Qh check(ccall((:ks_rotate, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cvoid}, Cint), src.ws.h, src.j0, c, r, pointer(Qh), c))
+    dst
+end
+
+# P.Q * vecs   src/eigvals.jl:94  (real basis x complex coefficients -> complex result)
+function Base.:*(Qv::HipColumns{T}, Y::AbstractMatrix) where {T}
+    Qv.j0 == 0 || throw(ArgumentError("the Schur basis starts at the first column"))
+    size(Y, 1) == Qv.ncols || throw(DimensionMismatch("inner dimensions differ"))
+    Ty = (T <: Complex || eltype(Y) <: Complex) ? ComplexF64 : Float64
+    Yh = Matrix{Ty}(Y)
+    out = Matrix{Ty}(undef, Qv.ws.n, size(Yh, 2))
+    (Qv.ncols == 0 || size(Yh, 2) == 0) && return fill!(out, zero(Ty))
+    GC.@preserve Yh out check(ccall((:ks_basis_times, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Int64),
+                                    Qv.ws.h, Qv.ncols, size(Yh, 2), pointer(Yh), size(Yh, 1), dtype_code(Ty), pointer(out), Qv.ws.n))
+    out
+end
+
+# ---------------------------------------------------------------------------------------------- (2) fused expansion
+struct KsExpandStats
+    steps::Int32; reorth::Int32; breakdowns::Int32; reserved::Int32
+end
+
+"""
+iterate_arnoldi!(A, arnoldi, from:to) (src/expansion.jl:116-133) as ONE device call when the operator and the basis
+both live in HBM.  The Hessenberg columns the device produced are copied into `arnoldi.H` (the caller's host matrix).
+"""
+function ArnoldiMethod.iterate_arnoldi!(A::HipOperator{T}, arnoldi::ArnoldiWorkspace{T,<:HipBasis{T}}, range::UnitRange{Int}) where {T}
+    isempty(range) && return arnoldi
+    w = arnoldi.V.ws
+    st = Ref(KsExpandStats(0, 0, 0, 0))
+    check(ccall((:ks_iterate_arnoldi, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Ref{KsExpandStats}), A.h, w.h, first(range), last(range), st))
+    H = arnoldi.H
+    if H !== w.H
+        for j in range
+            @views copyto!(H[1:j+1, j], w.H[1:j+1, j])
+        end
+    end
+    arnoldi
+end
+
+# ---------------------------------------------------------------------------------------------- (3) drivers
+"""
+    partialschur(A::HipOperator; v1, nev, which, tol, mindim, maxdim, restarts)
+
+src/run.jl:100-129 with the workspace on the device: builds `ArnoldiWorkspace(HipBasis, H)` and runs the REFERENCE's
+`partialschur!` on it.  `decomp.Q` is a `HipColumns` view of V in HBM (`Array(decomp.Q)` downloads it),
+`decomp.R` a view of the host `H` -- no copies, as documented at src/run.jl:149-150.
+"""
+function ArnoldiMethod.partialschur(A::HipOperator{T}; v1::Union{AbstractVector,Nothing} = nothing,
+                                    nev::Int = min(6, size(A, 1)), maxdim::Int = min(max(20, 2nev), size(A, 1)), kw...) where {T}
+    n = size(A, 1)
+    V = HipBasis{T}(A.ctx, n, maxdim + 1)
+    arnoldi = ArnoldiWorkspace(V, zeros(T, maxdim + 1, maxdim))
+    if v1 === nothing
+        return ArnoldiMethod.partialschur!(A, arnoldi; nev = nev, maxdim = maxdim, kw...)
+    end
+    length(v1) == n || throw(ArgumentError("v1 should have the same dimension as A"))
+    ArnoldiMethod.reinitialize!(arnoldi, 0, v -> copyto!(v, v1))       # src/run.jl:126
+    ArnoldiMethod.partialschur!(A, arnoldi; initialize = false, nev = nev, maxdim = maxdim, kw...)
+end
+
 struct KsParams
     nev::Int32; which::Int32; tol::Float64; mindim::Int32; maxdim::Int32
     restarts::Int32; start_from::Int32; initialize::Int32; reserved::Int32
@@ -202,16 +458,7 @@ struct KsHistory
     seconds_expand::Float64; seconds_host::Float64; seconds_rotate::Float64
 end
 
-struct HipPartialSchur{T}
-    workspace::HipWorkspace{T}
-    nconverged::Int
-    R::SubArray                 # view(H, 1:nconv, 1:nconv): no copy (src/run.jl:149-150)
-    eigenvalues::Vector{ComplexF64}
-end
-Base.getproperty(P::HipPartialSchur, s::Symbol) =
-    s === :Q ? columns(getfield(P, :workspace), 0, getfield(P, :nconverged)) : getfield(P, s)
-
-"partialschur!(A, arnoldi; start_from, initialize, nev, which, tol, mindim, maxdim, restarts)  src/run.jl:152-179"
+"partialschur!(A, arnoldi; ...) (src/run.jl:152-179) as ONE C call: the library's own driver (ks_partialschur)"
 function hip_partialschur!(A::HipOperator{T}, w::HipWorkspace{T};
                            start_from::Int = 1, initialize::Bool = start_from == 1,
                            nev::Int = min(6, A.n), which::Symbol = :LM,
@@ -223,40 +470,30 @@ function hip_partialschur!(A::HipOperator{T}, w::HipWorkspace{T};
     p = Ref(KsParams(nev, WHICH[which], tol, mindim, maxdim, restarts, start_from, initialize, 0))
     h = Ref(KsHistory(0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0))
     eig = zeros(ComplexF64, maxdim)
-    v1c = v1 === nothing ? C_NULL : convert(Vector{T}, v1)
-    GC.@preserve v1c begin
+    v1c = v1 === nothing ? T[] : convert(Vector{T}, v1)
+    GC.@preserve v1c eig begin
         check(ccall((:ks_partialschur, LIB), Cint,
-                    (Ptr{Cvoid}, Ptr{Cvoid}, Ref{KsParams}, Ptr{Cvoid}, Ptr{ComplexF64}, Ref{KsHistory}),
-                    A.h, w.h, p, v1c === C_NULL ? C_NULL : pointer(v1c), eig, h))
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ref{KsParams}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{KsHistory}),
+                    A.h, w.h, p, v1 === nothing ? C_NULL : pointer(v1c), pointer(eig), h))
     end
     hh = h[]
     nconv = Int(hh.nconverged)
-    HipPartialSchur{T}(w, nconv, view(w.H, 1:nconv, 1:nconv), eig[1:nconv]),
-    ArnoldiMethodHistory(hh.mvproducts, hh.nconverged, hh.converged != 0, hh.nev)
+    V = HipBasis{T}(w, false)
+    PartialSchur(view(V, :, 1:nconv), view(w.H, 1:nconv, 1:nconv), eig[1:nconv]),
+    ArnoldiMethod.History(Int(hh.mvproducts), nconv, hh.converged != 0, Int(hh.nev))
 end
 
-"History(mvproducts, nconverged, converged, nev)  src/run.jl:217-222"
-struct ArnoldiMethodHistory
-    mvproducts::Int; nconverged::Int; converged::Bool; nev::Int
+"partialschur(A; ...) (src/run.jl:100-129) through the library's own driver"
+function hip_partialschur(A::HipOperator{T}; v1 = nothing, nev::Int = min(6, A.n), maxdim::Int = min(max(20, 2nev), A.n), kw...) where {T}
+    w = HipWorkspace(A.ctx, T, A.n, maxdim)
+    hip_partialschur!(A, w; nev = nev, maxdim = maxdim, v1 = v1, kw...)
 end
+hip_partialschur(A::SparseMatrixCSC; ctx::HipContext = HipContext(), kw...) = hip_partialschur(HipOperator(ctx, A); kw...)
 
-"partialschur(A; v1, nev, which, tol, mindim, maxdim, restarts)  src/run.jl:100-129"
-function hip_partialschur(A::SparseMatrixCSC{T}; ctx::HipContext = HipContext(), v1 = nothing,
-                          nev::Int = min(6, size(A, 1)), maxdim::Int = min(max(20, 2nev), size(A, 1)), kw...) where {T}
-    op = HipOperator(ctx, SparseMatrixCSC{T,Int64}(A))
-    w = HipWorkspace(ctx, T, size(A, 1), maxdim)
-    hip_partialschur!(op, w; nev = nev, maxdim = maxdim, v1 = v1, kw...)
-end
-
-"partialeigen(P)  src/eigvals.jl:92-95: eigen(R) on the host, the tall-skinny Q*vecs on the device"
-function hip_partialeigen(P::HipPartialSchur{T}) where {T}
+"partialeigen(P) (src/eigvals.jl:92-95): eigen(R) on the host, the tall-skinny Q*vecs on the device"
+function hip_partialeigen(P::PartialSchur)
     vals, vecs = eigen(Matrix(P.R))
-    Y = convert(Matrix{ComplexF64}, vecs)
-    w = P.workspace
-    out = Matrix{ComplexF64}(undef, w.n, size(Y, 2))
-    check(ccall((:ks_basis_times, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Int64),
-                w.h, P.nconverged, size(Y, 2), Y, size(Y, 1), KS_C64, out, w.n))
-    vals, out
+    vals, P.Q * vecs
 end
 
 end # module

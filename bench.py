@@ -350,6 +350,10 @@ def make_line(args, pkg, passes, order, world, rank, force_dist, wl, with_cpu_ba
     moved_gbs = state["moved"] / max(state["t_expand"], 1e-12) / 1e9 / world
     roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
     if prof:
+        # the second-pass update (class "axpy") skips itself on the device when the DGKS test did not ask for it
+        # (src/expansion.jl:91); its bytes were booked at enqueue time -> scale by the fraction of steps that ran it
+        if prof["axpy"]["count"]:
+            prof["axpy"]["bytes"] *= min(1.0, state["reorth"] / max(1, state["steps"]))
         classes = {k: v for k, v in prof.items() if k != "fin" and v["count"] > 0}
         dom = max(classes, key=lambda k: classes[k]["ms"])
         d = classes[dom]

@@ -1,0 +1,222 @@
+"""`-m "not gpu"`: static check of the Julia side of the boundary (arnoldimethod.jl_amd/julia/KrylovSchurHIP.jl) against
+include/kschur.h -- no Julia runtime exists in the build image, so the glue cannot be executed; what CAN be verified
+without one is verified here:
+
+  * every `ccall((:name, LIB), ret, (argtypes...), ...)` names a function the header declares, with the same arity, the
+    same return type and an argument of the same machine class (32/64-bit integer, double, pointer) in every position;
+  * the Julia mirrors of the by-value structs (KsParams, KsHistory, KsExpandStats) have the header's fields in the
+    header's order with the header's widths;
+  * no ccall passes a Julia object as `Any` (the GC-unsafe form ADVICE r1 flagged);
+  * the method set of the array-type seam that SURVEY.md section 8b enumerates is present;
+  * (same machinery) the ctypes prototype table of _lib.py agrees with the header argument by argument.
+"""
+import os
+import re
+
+from __graft_entry__ import ROOT, import_package
+
+pkg = import_package()
+JL = os.path.join(ROOT, "arnoldimethod.jl_amd", "julia", "KrylovSchurHIP.jl")
+HDR = os.path.join(ROOT, "include", "kschur.h")
+
+
+# ------------------------------------------------------------------ header side
+def _c_class(t: str) -> str:
+    t = t.strip()
+    if "*" in t or re.search(r"\bks_\w+_fn\b", t):
+        return "ptr"
+    t = re.sub(r"\bconst\b", "", t).strip()
+    base = t.split()[0] if t else t
+    return {"int": "i32", "int32_t": "i32", "int64_t": "i64", "uint64_t": "u64", "double": "f64", "void": "void"}[base]
+
+
+def header_prototypes():
+    txt = open(HDR).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"^\s*(const\s+char\s*\*|int)\s+(ks_[A-Za-z0-9_]+)\s*\(([^;]*?)\)\s*;", txt, flags=re.M | re.S):
+        ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
+        if args in ("void", ""):
+            cls = []
+        else:
+            cls = []
+            for a in args.split(","):
+                a = a.strip()
+                # drop the parameter name (last identifier) unless the declarator is a bare type
+                mm = re.match(r"^(.*?[\s\*])([A-Za-z_]\w*)$", a)
+                cls.append(_c_class(mm.group(1) if mm else a))
+        protos[name] = ("ptr" if "char" in ret else "i32", cls)
+    return protos
+
+
+def header_structs():
+    txt = open(HDR).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    out = {}
+    for m in re.finditer(r"typedef\s+struct\s+(\w+)\s*\{(.*?)\}\s*\1\s*;", txt, flags=re.S):
+        fields = []
+        for f in m.group(2).split(";"):
+            f = f.strip()
+            if f:
+                ty, nm = f.rsplit(None, 1)
+                fields.append((nm, _c_class(ty)))
+        out[m.group(1)] = fields
+    return out
+
+
+# ------------------------------------------------------------------ Julia side
+_JL_CLASS = {"Cint": "i32", "Int32": "i32", "Int64": "i64", "UInt64": "u64", "Cdouble": "f64", "Float64": "f64", "Cstring": "ptr"}
+
+
+def _jl_class(t: str) -> str:
+    t = t.strip()
+    if t.startswith("Ptr{") or t.startswith("Ref{"):
+        return "ptr"
+    return _JL_CLASS[t]  # KeyError == a type this checker does not know == fail loudly
+
+
+def _split_top(s: str):
+    parts, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "{(":
+            depth += 1
+        elif ch in "})":
+            depth -= 1
+        if ch == "," and depth == 0:
+            parts.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        parts.append(cur)
+    return [p.strip() for p in parts if p.strip()]
+
+
+def julia_ccalls():
+    src = open(JL).read()
+    src = "\n".join(ln.split("#=")[0] if "#=" in ln and "=#" not in ln else ln for ln in src.splitlines())
+    src = re.sub(r"#=.*?=#", "", src)
+    src = "\n".join(ln for ln in src.splitlines() if not ln.lstrip().startswith("#"))
+    calls = []
+    for m in re.finditer(r"ccall\(\(:(\w+),\s*LIB\),\s*(\w+),\s*\(", src):
+        i = m.end()
+        depth, j = 1, i
+        while depth:
+            ch = src[j]
+            depth += ch in "({"
+            depth -= ch in ")}"
+            j += 1
+        argt = src[i : j - 1]
+        # the actual arguments follow up to the closing paren of ccall
+        k, depth = j, 1
+        while depth:
+            ch = src[k]
+            depth += ch in "([{"
+            depth -= ch in ")]}"
+            k += 1
+        actual = _split_top(src[j : k - 1].lstrip(", \n"))
+        calls.append((m.group(1), m.group(2), _split_top(argt), actual))
+    return calls
+
+
+def julia_structs():
+    src = open(JL).read()
+    out = {}
+    for m in re.finditer(r"^struct (Ks\w+)\n(.*?)^end", src, flags=re.M | re.S):
+        fields = []
+        for f in re.split(r"[;\n]", m.group(2)):
+            f = f.strip()
+            if f and "::" in f:
+                nm, ty = f.split("::")
+                fields.append((nm.strip(), _jl_class(ty)))
+        out[m.group(1)] = fields
+    return out
+
+
+# ------------------------------------------------------------------ tests
+def test_every_ccall_matches_the_header():
+    protos = header_prototypes()
+    calls = julia_ccalls()
+    assert len(calls) >= 25, "the glue lost its ccalls?"
+    used = set()
+    for name, ret, argt, actual in calls:
+        assert name in protos, f"ccall to {name}, which include/kschur.h does not declare"
+        used.add(name)
+        want_ret, want_args = protos[name]
+        assert _jl_class(ret) == want_ret, f"{name}: return type {ret}"
+        assert len(argt) == len(want_args), f"{name}: {len(argt)} argument types, header has {len(want_args)}"
+        assert len(actual) == len(want_args), f"{name}: {len(actual)} actual arguments for {len(want_args)} parameters ({actual})"
+        for pos, (jt, cc) in enumerate(zip(argt, want_args)):
+            assert jt != "Any", f"{name}: argument {pos + 1} passed as `Any`"
+            assert _jl_class(jt) == cc, f"{name}: argument {pos + 1} is {jt} in Julia, class {cc} in the header"
+    # the seam's verbs and the drivers are all bound
+    for need in ("ks_ctx_create", "ks_ctx_destroy", "ks_operator_csr", "ks_operator_dense", "ks_operator_host_callback", "ks_operator_destroy",
+                 "ks_operator_format", "ks_workspace_create", "ks_workspace_destroy", "ks_workspace_H", "ks_workspace_Q", "ks_cols_download",
+                 "ks_col_fill_uniform", "ks_col_upload", "ks_col_copy", "ks_col_norm", "ks_col_div", "ks_apply", "ks_gemv_t",
+                 "ks_gemv_n_sub", "ks_rotate", "ks_basis_times", "ks_iterate_arnoldi", "ks_partialschur", "ks_last_error_string"):
+        assert need in used, f"{need} is not bound by the Julia glue"
+
+
+def test_struct_mirrors_match_the_header():
+    hs, js = header_structs(), julia_structs()
+    for cname, jname in (("ks_params", "KsParams"), ("ks_history", "KsHistory"), ("ks_expand_stats", "KsExpandStats")):
+        assert jname in js, f"{jname} missing in the Julia glue"
+        assert js[jname] == hs[cname], f"{jname} != {cname}: {js[jname]} vs {hs[cname]}"
+
+
+def test_array_type_seam_method_set_is_present():
+    """the complete set of operations the reference applies to V / views of V."""
+    src = open(JL).read()
+    for pat, why in [
+        (r"struct HipBasis\{T\} <: AbstractMatrix\{T\}", "the basis type"),
+        (r"struct HipColumn\{T\} <: AbstractVector\{T\}", "view(V, :, j)"),
+        (r"struct HipColumns\{T\} <: AbstractMatrix\{T\}", "view(V, :, a:b)"),
+        (r"Base\.view\(V::HipBasis\{T\}, ::Colon, j::Integer\)", "view(V, :, j), expansion.jl:18,77"),
+        (r"Base\.view\(V::HipBasis\{T\}, ::Colon, r::AbstractUnitRange", "view(V, :, 1:j), expansion.jl:34,76"),
+        (r"Base\.size\(V::HipBasis\)", "size(V, 1), size(V, 2)"),
+        (r"Base\.similar\(V::HipBasis\{T\}\)", "V_tmp = similar(V), ArnoldiMethod.jl:84"),
+        (r"Random\.rand!\(v::HipColumn\)", "rand!(v), expansion.jl:15,21"),
+        (r"Base\.copyto!\(v::HipColumn\{T\}, src::AbstractVector\)", "copyto!(v, v1), run.jl:126"),
+        (r"LinearAlgebra\.norm\(v::HipColumn\)", "norm(v)"),
+        (r"Base\.Broadcast\.materialize!\(dest::HipColumn\{T\}", "v ./= s"),
+        (r"LinearAlgebra\.mul!\(y::HipColumn\{T\}, A::HipOperator\{T\}, x::HipColumn\{T\}\)", "mul!(w, A, v), expansion.jl:121"),
+        (r"LinearAlgebra\.mul!\(h::AbstractVector, Va::Adjoint\{T,HipColumns\{T\}\}, v::HipColumn\{T\}\)", "mul!(h, Vprev', v)"),
+        (r"Base\.:\*\(Va::Adjoint\{T,HipColumns\{T\}\}, v::HipColumn\{T\}\)", "Vprev' * v"),
+        (r"LinearAlgebra\.mul!\(v::HipColumn\{T\}, Vp::HipColumns\{T\}, h::AbstractVector, α::Number, β::Number\)", "mul!(v, Vprev, h, -1, 1)"),
+        (r"LinearAlgebra\.mul!\(dst::HipColumns\{T\}, src::HipColumns\{T\}, Qb::AbstractMatrix\)", "mul!(V_tmp, V, Q), run.jl:363,382"),
+        (r"Base\.copyto!\(dst::HipColumns\{T\}, src::HipColumns\{T\}\)", "copyto!(V, V_tmp), run.jl:364,383"),
+        (r"Base\.copyto!\(dst::HipColumn\{T\}, src::HipColumn\{T\}\)", "copyto!(V[:,k+1], V[:,maxdim+1]), run.jl:365"),
+        (r"Base\.:\*\(Qv::HipColumns\{T\}, Y::AbstractMatrix\)", "P.Q * vecs, eigvals.jl:94"),
+        (r"function ArnoldiMethod\.iterate_arnoldi!\(A::HipOperator\{T\}, arnoldi::ArnoldiWorkspace\{T,<:HipBasis\{T\}\}", "fused expansion"),
+        (r"function ArnoldiMethod\.partialschur\(A::HipOperator\{T\}", "partialschur on a device operator"),
+    ]:
+        assert re.search(pat, src), f"missing method for {why}: /{pat}/"
+    assert "unsafe_pointer_to_objref(user)[]" in src and "pointer_from_objref(box)" in src  # Ref{Any} box, not a tuple as `Any`
+
+
+def test_ctypes_prototype_table_matches_header_argument_by_argument():
+    import ctypes as C
+
+    protos = header_prototypes()
+
+    def cls(t):
+        if t in (C.c_int, C.c_int32):
+            return "i32"
+        if t is C.c_int64:
+            return "i64"
+        if t is C.c_uint64:
+            return "u64"
+        if t is C.c_double:
+            return "f64"
+        return "ptr"  # c_void_p, POINTER(...), CFUNCTYPE(...)
+
+    for name, args in pkg._lib.PROTOTYPES.items():
+        want = protos[name][1]
+        assert len(args) == len(want), f"{name}: ctypes table has {len(args)} arguments, header {len(want)}"
+        for pos, (a, w) in enumerate(zip(args, want)):
+            assert cls(a) == w, f"{name}: argument {pos + 1} is {a} in the ctypes table, class {w} in the header"
+    # struct layouts
+    hs = header_structs()
+    for cname, ct in (("ks_params", pkg._lib.ks_params), ("ks_history", pkg._lib.ks_history), ("ks_expand_stats", pkg._lib.ks_expand_stats)):
+        got = [(n, cls(t)) for n, t in ct._fields_]
+        assert got == hs[cname], (cname, got, hs[cname])

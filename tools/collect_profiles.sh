@@ -1,21 +1,16 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh'
-# Output: gpurun_out/prof/ {bench.json, bench_under_rocprof.json, kernel_stats.csv, pmc_fetch.csv, pmc_write.csv}
-# --pmc passes are separate runs with --kernel-trace only (gpurun refuses other combinations).
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh'
+# Output: gpurun_out/prof/ {bench.json, bench_under_rocprof.json, kernel_stats.csv, pmc_fetch.csv, pmc_write.csv} for
+# the headline (bench.py) and <cfg>_{bench.json,kernel_stats.csv,pmc_fetch.csv,pmc_write.csv} for configs 3 and 4
+# (tools/config_bench.py).  --pmc passes are separate runs with --kernel-trace only (gpurun refuses other combinations).
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $REPO/bench.py > $OUT/bench_under_rocprof.json 2>> $OUT/bench.err
-cp "$(find /tmp/kt -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats.csv
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2>> $OUT/bench.err
-  f=$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)
-  # keep only what pmc_summary.py reads (the raw file is tens of MB)
-  python - "$f" "$OUT/pmc_$(echo $c | tr A-Z a-z | sed s/_size//).csv" <<PY
+trim() {  # keep only what the summarisers read (the raw file is tens of MB)
+  python - "$1" "$2" <<PY
 import csv, sys
 r = csv.DictReader(open(sys.argv[1]))
 w = csv.writer(open(sys.argv[2], "w"))
@@ -23,5 +18,22 @@ w.writerow(["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"])
 for x in r:
     w.writerow([x["Dispatch_Id"], x["Kernel_Name"], x["Counter_Name"], x["Counter_Value"]])
 PY
+}
+python $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err
+KS_PLACE_TRIALS=1 python $REPO/bench.py --no-cpu-baseline > $OUT/bench_no_placement_search.json 2>> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $REPO/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2>> $OUT/bench.err
+cp "$(find /tmp/kt -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2>> $OUT/bench.err
+  trim "$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)" "$OUT/pmc_$(echo $c | tr A-Z a-z | sed s/_size//).csv"
+done
+for cfg in cfg3 cfg4 cfg4big; do
+  python $REPO/tools/config_bench.py $cfg > $OUT/${cfg}_bench.json 2> $OUT/${cfg}.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$cfg -- python $REPO/tools/config_bench.py $cfg > /dev/null 2>> $OUT/${cfg}.err
+  cp "$(find /tmp/kt_$cfg -name '*kernel_stats.csv' | head -1)" $OUT/${cfg}_kernel_stats.csv
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_${cfg}_$c -- python $REPO/tools/config_bench.py $cfg --steps 3 --warmup 1 > /dev/null 2>> $OUT/${cfg}.err
+    trim "$(find /tmp/pmc_${cfg}_$c -name '*counter_collection.csv' | head -1)" "$OUT/${cfg}_pmc_$(echo $c | tr A-Z a-z | sed s/_size//).csv"
+  done
 done
 ls -la $OUT
