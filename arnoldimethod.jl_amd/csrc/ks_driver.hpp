@@ -63,19 +63,42 @@ struct RestartResult {
   int k, nlock, purge, effective_nev;
 };
 
+inline double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Optional stage timers of the restart step (tools/host_step_profile.cpp compiles with -DKS_TIME_STAGES; the product
+// build does not define it and the macro vanishes).
+#ifdef KS_TIME_STAGES
+inline double g_stage_s[8] = {};
+#define KS_STAGE(i, t0)                         \
+  do {                                          \
+    const double t1__ = now_s();                \
+    g_stage_s[i] += t1__ - (t0);                \
+    (t0) = t1__;                                \
+  } while (0)
+#else
+#define KS_STAGE(i, t0) ((void)0)
+#endif
+
 // One restart's host work: src/run.jl:278-360.  `active` 0-based.  H is the full (maxdim+1) x maxdim
 // array, Q is maxdim x maxdim.
 template <class T>
 inline RestartResult restart_host_step(const Mat<T>& H, const Mat<T>& Q, int maxdim, int mindim, int nev,
                                        const Ordering& ordering, double tol, int active, RestartScratch<T>& s) {
+#ifdef KS_TIME_STAGES
+  double t0__ = now_s();
+#endif
   // Q <- I  (:278)
   for (int j = 0; j < maxdim; ++j)
     for (int i = 0; i < maxdim; ++i) Q(i, j) = (i == j) ? T(1) : T(0);
   // Schur form of the active block of H[0:maxdim, :]  (:281)
   local_schurfact(H.top(maxdim), active, maxdim - 1, Q);
+  KS_STAGE(0, t0__);
   for (int i = 0; i < maxdim; ++i) s.ord[i] = i;                       // :284
   copy_eigenvalues(s.lams.data(), H, 0, maxdim - 1);                   // :285
   copy_residuals(s.rs.data(), H, Q, H(maxdim, maxdim - 1), s.x.data(), active, maxdim - 1);  // :286
+  KS_STAGE(1, t0__);
   sort_perm(s.ord.data(), maxdim, s.lams.data(), ordering);            // :289
   double fro = 0.0;                                                    // :292 norm(H), whole array
   for (int j = 0; j < H.n; ++j)
@@ -104,13 +127,12 @@ inline RestartResult restart_host_step(const Mat<T>& H, const Mat<T>& Q, int max
   }
   int purge = 0;                                                       // :350-353
   while (purge < active && groups[purge] == 1) ++purge;
+  KS_STAGE(2, t0__);
   partition_schur_three_way(H, Q, groups, maxdim);                     // :355
+  KS_STAGE(3, t0__);
   restore_arnoldi(H, nlock, k - 1, Q, s.G);                            // :360
+  KS_STAGE(4, t0__);
   return RestartResult{k, nlock, purge, effective_nev};
-}
-
-inline double now_s() {
-  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 // _partialschur, src/run.jl:224-392.  H: (maxdim+1) x maxdim host, Q: maxdim x maxdim host.

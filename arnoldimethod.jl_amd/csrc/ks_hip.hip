@@ -931,6 +931,8 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
 // ------------------------------------------------------------------------------------------------
 // workspace
 // ------------------------------------------------------------------------------------------------
+constexpr size_t kCtlStateSlot = 128;  // bytes reserved for the DevState inside the control block
+
 struct ks_workspace {
   ks_ctx* ctx = nullptr;
   int dtype = KS_F64;
@@ -955,8 +957,15 @@ struct ks_workspace {
   double* scal = nullptr;   // device, 8 doubles
   double* scal_h = nullptr; // pinned host, 8 doubles
   void* coef_h = nullptr;   // pinned host, pstride elements
-  DevState* st = nullptr;   // device
-  DevState* st_h = nullptr; // pinned host
+  // CONTROL BLOCK: one device allocation [ Hd | DevState | colscale ] mirrored by one pinned host allocation
+  // [ Hstage | st_h | cs_h ], so that what an expansion batch needs from / hands back to the host travels in ONE copy
+  // each way (each hipMemcpyAsync is a blit kernel plus a launch gap; round 1 issued four per restart cycle with two
+  // host synchronisations in between: profiles/r02_restart_bubble.txt)
+  size_t hd_bytes = 0;      // bytes of Hd up to the DevState (64-byte aligned)
+  DevState* st = nullptr;   // device, inside the Hd allocation
+  DevState* st_h = nullptr; // pinned host, inside the Hstage allocation
+  double* cs_h = nullptr;   // pinned host image of colscale, inside the Hstage allocation
+  bool colscale_dirty = false;  // hostscale changed on the host side: upload with the next batch's state
   void* Qd = nullptr;       // device, maxdim x maxdim
   void* Qstage = nullptr;   // pinned host
   void* tmp = nullptr;      // device scratch, lazily sized
@@ -996,10 +1005,10 @@ struct ks_workspace {
     return tmp2;
   }
   ~ks_workspace() {
-    (void)hipFree(colscale); (void)hipFree(Vbase ? Vbase : V); (void)hipHostFree(H); (void)hipHostFree(Q); (void)hipFree(Hd); (void)hipHostFree(Hstage);
+    (void)hipFree(Vbase ? Vbase : V); (void)hipHostFree(H); (void)hipHostFree(Q); (void)hipFree(Hd); (void)hipHostFree(Hstage);
     (void)hipFree(Hscratch); (void)hipFree(partial); (void)hipFree(partial2); (void)hipFree(coef); (void)hipFree(red);
-    (void)hipFree(scal); (void)hipHostFree(scal_h); (void)hipHostFree(coef_h); (void)hipFree(st);
-    (void)hipHostFree(st_h); (void)hipFree(Qd); (void)hipHostFree(Qstage); (void)hipFree(tmp); (void)hipFree(tmp2);
+    (void)hipFree(scal); (void)hipHostFree(scal_h); (void)hipHostFree(coef_h);
+    (void)hipFree(Qd); (void)hipHostFree(Qstage); (void)hipFree(tmp); (void)hipFree(tmp2);
   }
 };
 
@@ -1194,8 +1203,7 @@ template <class D> void enqueue_orthogonalize(ks_workspace* ws, int j) {
 inline void reset_lazy(ks_workspace* ws) {
   if (!ws->has_lazy()) return;
   for (int c = ws->lazy_lo; c <= ws->lazy_hi; ++c) ws->hostscale[c] = 1.0;
-  KS_HIP(hipMemcpyAsync(ws->colscale, ws->ones.data(), (size_t)(ws->maxdim + 2) * 8, hipMemcpyHostToDevice, ws->ctx->stream));
-  KS_HIP(hipStreamSynchronize(ws->ctx->stream));
+  ws->colscale_dirty = true;  // the device copy is only read inside expansion batches: uploaded with the next one's state
   ws->lazy_lo = 1 << 30;
   ws->lazy_hi = -1;
 }
@@ -1296,13 +1304,26 @@ inline bool use_deferred(const ks_workspace* ws, int to) {
   return to <= kFusedMaxJ && !no_fuse && !no_defer;
 }
 
+// Start of a batch: fresh DevState and, when the host changed column factors since the last batch, the factors --
+// one asynchronous copy from the pinned control block, no synchronisation.
 inline void reset_state(ks_workspace* ws) {
+  // (no synchronisation: the state image is always the same bytes, and the factor image is only rewritten after a
+  // host-side change, which follows the synchronising fetch of the previous batch)
   std::memset(ws->st_h, 0, sizeof(DevState));
   ws->st_h->breakdown = -1;
-  KS_HIP(hipMemcpyAsync(ws->st, ws->st_h, sizeof(DevState), hipMemcpyHostToDevice, ws->ctx->stream));
+  size_t bytes = sizeof(DevState);
+  if (ws->colscale_dirty) {
+    std::memcpy(ws->cs_h, ws->hostscale.data(), (size_t)(ws->maxdim + 2) * 8);
+    bytes = kCtlStateSlot + (size_t)(ws->maxdim + 2) * 8;
+    ws->colscale_dirty = false;
+  }
+  KS_HIP(hipMemcpyAsync(ws->st, ws->st_h, bytes, hipMemcpyHostToDevice, ws->ctx->stream));
 }
-inline void fetch_state(ks_workspace* ws) {
-  KS_HIP(hipMemcpyAsync(ws->st_h, ws->st, sizeof(DevState), hipMemcpyDeviceToHost, ws->ctx->stream));
+// End of a batch: the H columns of steps from.. (to the end of Hd) and the DevState in ONE copy, one synchronisation.
+inline void fetch_state(ks_workspace* ws, int from = 0) {
+  const size_t off = from >= 1 ? (size_t)(from - 1) * (ws->maxdim + 1) * ws->esz : ws->hd_bytes;
+  KS_HIP(hipMemcpyAsync(static_cast<char*>(ws->Hstage) + off, static_cast<char*>(ws->Hd) + off, ws->hd_bytes + sizeof(DevState) - off,
+                        hipMemcpyDeviceToHost, ws->ctx->stream));
   KS_HIP(hipStreamSynchronize(ws->ctx->stream));
   if (ws->ctx->profiling) prof_collect(ws->ctx);
   ws->ctx->check_comm();
@@ -1404,16 +1425,11 @@ template <class D> bool reinit_column(ks_workspace* ws, int j, const void* v1_ho
   return true;
 }
 
-// copy the H columns produced on the device for steps from..to into the host H
+// copy the H columns produced on the device for steps from..to (already staged by fetch_state(ws, from)) into the host H
 template <class T> void fetch_H_columns(ks_workspace* ws, int from, int to, const ks::Mat<T>& H, bool lazy = false) {
   if (to < from) return;
   const int ldh = ws->maxdim + 1;
-  const size_t off = (size_t)(from - 1) * ldh * sizeof(T);
-  const size_t bytes = (size_t)(to - from + 1) * ldh * sizeof(T);
-  KS_HIP(hipMemcpyAsync(static_cast<char*>(ws->Hstage) + off, static_cast<char*>(ws->Hd) + off, bytes,
-                        hipMemcpyDeviceToHost, ws->ctx->stream));
-  KS_HIP(hipStreamSynchronize(ws->ctx->stream));
-  const T* hs = static_cast<const T*>(ws->Hstage);
+  const T* hs = static_cast<const T*>(ws->Hstage);  // filled by fetch_state(ws, from) together with the DevState
   for (int j = from; j <= to; ++j)
     for (int i = 0; i <= j; ++i) H(i, j - 1) = hs[(size_t)(j - 1) * ldh + i];
   if (lazy) {
@@ -1502,8 +1518,8 @@ template <class T> void rotate_lazy(ks_workspace* ws, int c0, int c, int r, cons
     any = any || ws->hostscale[c0 + ii] != 1.0;
     ws->hostscale[c0 + ii] = 1.0;
   }
-  if (any && update_device_factors)
-    KS_HIP(hipMemcpyAsync(ws->colscale + c0, ws->ones.data(), (size_t)r * 8, hipMemcpyHostToDevice, ws->ctx->stream));
+  if (any) ws->colscale_dirty = true;
+  (void)update_device_factors;
 }
 
 // V[:, dst] <- V[:, src] (src/run.jl:365), lazy-aware: the factor of a lazy source is applied on the way, the
@@ -1519,7 +1535,7 @@ template <class D> void col_copy_lazy(ks_workspace* ws, int dst, int src) {
   KS_HIP(hipGetLastError());
   if (ws->hostscale[dst] != 1.0 || (dst == src && f != 1.0)) {
     ws->hostscale[dst] = 1.0;
-    KS_HIP(hipMemcpyAsync(ws->colscale + dst, ws->ones.data(), 8, hipMemcpyHostToDevice, ws->ctx->stream));
+    ws->colscale_dirty = true;
   }
 }
 
@@ -1565,7 +1581,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
           enqueue_orthogonalize<D>(ws, j);
         }
       }
-      fetch_state(ws);
+      fetch_state(ws, j0);
       const int bd = ws->st_h->breakdown;
       const int last_done = bd >= 0 ? bd : jend;
       fetch_H_columns<T>(ws, j0, last_done, H, lazy);
@@ -2208,13 +2224,21 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     const size_t hbytes = (size_t)(maxdim + 1) * maxdim * esz, qbytes = (size_t)maxdim * maxdim * esz;
     KS_HIP(hipHostMalloc(&w->H, hbytes));
     KS_HIP(hipHostMalloc(&w->Q, qbytes));
-    KS_HIP(hipHostMalloc(&w->Hstage, hbytes));
+    // control block: [ Hd | DevState (128-byte slot) | colscale ] on the device, the same layout pinned on the host
+    w->hd_bytes = (size_t)round_up((int64_t)hbytes, 64);
+    const size_t ctl_bytes = w->hd_bytes + kCtlStateSlot + (size_t)(maxdim + 2) * 8;
+    static_assert(sizeof(DevState) <= kCtlStateSlot, "DevState must fit its slot of the control block");
+    KS_HIP(hipHostMalloc(&w->Hstage, ctl_bytes));
     KS_HIP(hipHostMalloc(&w->Qstage, qbytes));
     std::memset(w->H, 0, hbytes);   // zeros(T, k+1, k), src/ArnoldiMethod.jl:66
     std::memset(w->Q, 0, qbytes);
-    std::memset(w->Hstage, 0, hbytes);
-    KS_HIP(hipMalloc(&w->Hd, hbytes));
-    KS_HIP(hipMemsetAsync(w->Hd, 0, hbytes, ctx->stream));
+    std::memset(w->Hstage, 0, ctl_bytes);
+    KS_HIP(hipMalloc(&w->Hd, ctl_bytes));
+    KS_HIP(hipMemsetAsync(w->Hd, 0, ctl_bytes, ctx->stream));
+    w->st = reinterpret_cast<DevState*>(static_cast<char*>(w->Hd) + w->hd_bytes);
+    w->st_h = reinterpret_cast<DevState*>(static_cast<char*>(w->Hstage) + w->hd_bytes);
+    w->colscale = reinterpret_cast<double*>(static_cast<char*>(w->Hd) + w->hd_bytes + kCtlStateSlot);
+    w->cs_h = reinterpret_cast<double*>(static_cast<char*>(w->Hstage) + w->hd_bytes + kCtlStateSlot);
     KS_HIP(hipMalloc(&w->Hscratch, (size_t)(maxdim + 2) * esz));
     KS_HIP(hipMalloc(&w->partial, (size_t)w->pnb * w->pstride * esz));
     KS_HIP(hipMalloc(&w->partial2, (size_t)std::max(w->pnb, ctx->num_cu * 8) * 8));
@@ -2224,13 +2248,10 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     KS_HIP(hipMalloc(&w->scal, 64));
     KS_HIP(hipHostMalloc(&w->scal_h, 64));
     KS_HIP(hipHostMalloc(&w->coef_h, (size_t)w->pstride * esz));
-    KS_HIP(hipMalloc(&w->st, sizeof(DevState)));
-    KS_HIP(hipHostMalloc(&w->st_h, sizeof(DevState)));
     KS_HIP(hipMalloc(&w->Qd, std::max<size_t>(qbytes, 16)));
     w->hostscale.assign(maxdim + 2, 1.0);
     w->ones.assign(maxdim + 2, 1.0);
-    KS_HIP(hipMalloc(&w->colscale, (size_t)(maxdim + 2) * 8));
-    KS_HIP(hipMemcpy(w->colscale, w->ones.data(), (size_t)(maxdim + 2) * 8, hipMemcpyHostToDevice));
+    w->colscale_dirty = true;  // first reset_state uploads the (all-one) factors
     reset_state(w.get());
     KS_HIP(hipStreamSynchronize(ctx->stream));
     if (dtype == KS_F64) tune_placement<double>(w.get(), vbytes);
@@ -2513,7 +2534,7 @@ int ks_orthogonalize(ks_workspace* ws, int j, int* ok) {
       const bool lazy = use_deferred(ws, j);
       if (lazy) enqueue_steps_deferred<D>(ws, nullptr, j, j);
       else enqueue_orthogonalize<D>(ws, j);
-      fetch_state(ws);
+      fetch_state(ws, j);
       ks::Mat<T> H(static_cast<T*>(ws->H), ws->maxdim + 1, ws->maxdim, ws->maxdim + 1);
       fetch_H_columns<T>(ws, j, j, H, lazy && ws->st_h->breakdown < 0);
       materialize(ws);

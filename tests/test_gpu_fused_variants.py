@@ -184,3 +184,39 @@ def test_operator_callback_exception_is_reraised():
     assert st["steps"] == 10
     V = ws.V
     assert np.linalg.norm(V[:, :11].T @ V[:, :11] - np.eye(11)) < 1e-12
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_rotation_and_column_copy_verbs_on_lazy_columns(dtype):
+    """ks_rotate / ks_col_copy called right after a fused expansion (what the Julia array-type seam does with the
+    reference's own restart code, src/run.jl:363-365): the lazily normalised columns must be absorbed (rows of Q scaled,
+    copy with the factor), not corrupted -- compare with numpy on the orthonormal basis."""
+    A, n = _operator(dtype, (10, 11, 12))
+    op = pkg.csr_operator(A)
+    m = 24
+    ws = pkg.ArnoldiWorkspace(n, m, dtype)
+    ws.reinitialize(0, _start(dtype, n, seed=3))
+    ws.iterate_arnoldi(op, 1, m)
+    ws2 = pkg.ArnoldiWorkspace(n, m, dtype, ctx=ws.ctx)       # reference copy of the same basis, materialised
+    ws2.reinitialize(0, _start(dtype, n, seed=3))
+    ws2.iterate_arnoldi(op, 1, m)
+    V = ws2.V                                                  # reading V materialises ws2's lazy columns
+    rng = np.random.default_rng(12)
+    c0, c, r = 2, m - 2, 9
+    Qb = rng.standard_normal((c, r)) + (1j * rng.standard_normal((c, r)) if np.dtype(dtype).kind == "c" else 0)
+    ws.rotate(c0, Qb.astype(dtype))                            # ws still has lazy columns 1..m
+    ws.copy_col(c0 + r, m)
+    got = ws.V
+    want = V.copy()
+    want[:, c0 : c0 + r] = V[:, c0 : c0 + c] @ Qb
+    want[:, c0 + r] = V[:, m]
+    np.testing.assert_allclose(got[:, : c0 + r + 1], want[:, : c0 + r + 1], atol=1e-12)
+    # columns beyond the copied one are untouched orthonormal vectors (still valid after being materialised by the read)
+    np.testing.assert_allclose(got[:, c0 + r + 1 :], V[:, c0 + r + 1 :], atol=1e-12)
+    # and the expansion can continue on top: Arnoldi relation of the next steps holds w.r.t. the new basis
+    ws.set_cols(0, np.linalg.qr(got[:, : c0 + r + 1])[0])
+    ws.iterate_arnoldi(op, c0 + r + 1, m)
+    Vn, H = ws.V, np.array(ws.H)
+    assert np.linalg.norm(Vn.conj().T @ Vn - np.eye(m + 1)) < 1e-11
+    for j in range(c0 + r + 1, m + 1):
+        np.testing.assert_allclose(A @ Vn[:, j - 1], Vn[:, : j + 1] @ H[: j + 1, j - 1], atol=1e-11)
