@@ -29,13 +29,35 @@ import sys
 import threading
 import time
 
-import numpy as np
+
+
+def _cpu_budget():
+    """CPUs this process may actually USE: the cgroup CFS quota when there is one (a container that sees 256 logical
+    CPUs but is limited to 16 CPUs' worth of time runs a 128-thread OpenMP team SLOWER than a 16-thread one: the
+    spinning threads burn the quota -- measured on the GPU box: 5.3 vs 35 iterations/s for the CPU baseline)."""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+# the CPU baseline's OpenMP team (and OpenBLAS behind scipy's ARPACK): as many threads as the container may run, one per
+# core, pinned -- all of this must be in the environment before libgomp / OpenBLAS are loaded
+CPU_BUDGET = _cpu_budget()
+if CPU_BUDGET < (os.cpu_count() or 1):
+    os.environ.setdefault("OMP_NUM_THREADS", str(CPU_BUDGET))
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", str(CPU_BUDGET))
+os.environ.setdefault("OMP_PROC_BIND", "spread")
+os.environ.setdefault("OMP_PLACES", "cores")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# the CPU baseline's OpenMP team: one thread per core, pinned (must be set before libgomp starts)
-os.environ.setdefault("OMP_PROC_BIND", "spread")
-os.environ.setdefault("OMP_PLACES", "cores")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
 
@@ -407,22 +429,66 @@ def make_line(args, pkg, passes, order, world, rank, force_dist, wl, with_cpu_ba
 
 
 def cpu_baseline(pkg, A_host, n, nev, which, mindim, maxdim):
+    """The reference's op sequence on the host cores (oracle/cpu_backend.cpp, kind "port": Julia is not in the image --
+    `julia_on_box` records whether the GPU box has one).  Bounded samples of the same workload:
+      value                     all cores for every verb (what a threaded BLAS + a threaded SpMV would give)
+      serial_spmv               the same with ONE thread in the SpMV: Julia's SparseMatrixCSC mul! is serial
+      scipy_eigs                scipy.sparse.linalg.eigs (ARPACK, implicitly restarted Arnoldi) on the same matrix, one
+                                restart: operator applications per second, informational
+      host_stream_triad_GBps    STREAM triad of the same OpenMP team: the ceiling of this bandwidth-bound baseline"""
+    import shutil
+
+    out = {"value": None, "unit": "iters/s", "cores": 0, "kind": "port", "sample": "", "julia_on_box": shutil.which("julia"),
+           "logical_cpus": os.cpu_count(), "cpu_quota": CPU_BUDGET}
     try:
         from oracle import cpuref
 
         A = pkg.matrices.to_scipy(*A_host, n)
         tb = cpuref.timed_cycles_csr(A, nev=nev, which=which, mindim=mindim, maxdim=maxdim, cycles=3)
-        return {
+        out.update({
             "value": tb["steps"] / tb["seconds"],
-            "unit": "iters/s",
             "cores": tb["threads"],
-            "kind": "port",
             "sample": f"same matrix and parameters; 3 restart cycles = {tb['steps']} Arnoldi iterations after the initial "
                       f"expansion (untimed), {tb['seconds']:.1f} s; un-fused reference op sequence with OpenMP over rows "
                       f"(spmv {tb['t_spmv']:.1f} s, orthogonalize {tb['t_orth']:.1f} s, rotation {tb['t_rot']:.1f} s)",
-        }
+        })
+        # bytes the un-fused sequence streams per step (SURVEY 8d): 12 nnz + 4 (n+1) + 8 n (2 j + 9) + second pass 16 j n + 32 n
+        jm = (mindim + maxdim) / 2 + 0.5
+        step_b = 12.0 * A.nnz + 4.0 * (n + 1) + 8.0 * n * (2 * jm + 9) + 16.0 * jm * n + 32.0 * n
+        out["effective_GBps"] = step_b * tb["steps"] / tb["seconds"] / 1e9
+        try:
+            out["host_stream_triad_GBps"] = cpuref.stream_triad_gbs()
+        except Exception as e:  # noqa: BLE001
+            out["host_stream_triad_GBps"] = f"failed: {e}"
+        try:
+            t1 = cpuref.timed_cycles_csr(A, nev=nev, which=which, mindim=mindim, maxdim=maxdim, cycles=1, spmv_threads=1)
+            out["serial_spmv"] = {"value": t1["steps"] / t1["seconds"], "unit": "iters/s",
+                                  "sample": f"1 restart cycle = {t1['steps']} iterations, {t1['seconds']:.1f} s (spmv {t1['t_spmv']:.1f} s on one thread)"}
+        except Exception as e:  # noqa: BLE001
+            out["serial_spmv"] = {"value": None, "sample": f"failed: {e}"}
+        try:
+            import scipy.sparse.linalg as spla
+
+            cnt = [0]
+
+            def mv(x):
+                cnt[0] += 1
+                return A @ x
+
+            op = spla.LinearOperator(A.shape, matvec=mv, dtype=np.float64)
+            t0 = time.perf_counter()
+            try:
+                spla.eigs(op, k=nev, which="SR", ncv=maxdim + 1, maxiter=1, tol=1e-8, v0=pkg.matrices.start_vector(n))
+            except spla.ArpackNoConvergence:
+                pass
+            dt = time.perf_counter() - t0
+            out["scipy_eigs"] = {"value": cnt[0] / dt, "unit": "operator applications/s",
+                                 "sample": f"ARPACK dnaupd through scipy, ncv={maxdim + 1}, one restart: {cnt[0]} applications in {dt:.1f} s"}
+        except Exception as e:  # noqa: BLE001
+            out["scipy_eigs"] = {"value": None, "sample": f"failed: {e}"}
     except Exception as e:  # noqa: BLE001
-        return {"value": None, "unit": "iters/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        out["sample"] = f"failed: {e}"
+    return out
 
 
 if __name__ == "__main__":

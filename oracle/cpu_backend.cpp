@@ -297,6 +297,23 @@ extern "C" {
 const char* ksref_last_error(void) { return g_err.c_str(); }
 int ksref_num_threads(void) { return omp_get_max_threads(); }
 
+// STREAM-triad bandwidth of the host (a[i] = b[i] + s * c[i] over three arrays of `n` doubles, first-touched by the
+// threads that stream them, best of `reps`): the ceiling the bandwidth-bound CPU baseline can be judged against.
+// Returns GB/s counting 24 bytes per element.
+double ksref_stream_triad_gbs(int64_t n, int reps) {
+  std::unique_ptr<double[]> a(new double[n]), b(new double[n]), c(new double[n]);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) { a[i] = 0.0; b[i] = 1.0; c[i] = 2.0; }
+  double best = 1e30;
+  for (int r = 0; r < reps; ++r) {
+    const double t0 = ks::now_s();
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) a[i] = b[i] + 3.0 * c[i];
+    best = std::min(best, ks::now_s() - t0);
+  }
+  return 24.0 * (double)n / best / 1e9 + 0.0 * a[n / 2];
+}
+
 // dtype 0 = f64, 1 = c64.  CSR int32 0-based.  H: (maxdim+1) x maxdim, V: n x (maxdim+1), column-major.
 int ksref_partialschur_csr(int dtype, int64_t n, const int32_t* rowptr, const int32_t* colidx, const void* val, int nev,
                            int which, double tol, int mindim, int maxdim, int restarts, const void* v1, uint64_t seed,

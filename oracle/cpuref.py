@@ -93,3 +93,10 @@ def timed_cycles_csr(A, nev, which, mindim, maxdim, cycles, seed=20240917, spmv_
         raise RuntimeError("ksref_timed_cycles_csr failed")
     return dict(seconds=od[0], t_spmv=od[1], t_orth=od[2], t_rot=od[3], t_host=od[4], steps=int(oi[0]), reorth=int(oi[1]),
                 threads=int(L.ksref_num_threads()))
+
+
+def stream_triad_gbs(n=1 << 27, reps=4):
+    """STREAM-triad bandwidth (GB/s) of the host cores with the OpenMP team the baseline uses."""
+    L = lib()
+    L.ksref_stream_triad_gbs.restype = C.c_double
+    return float(L.ksref_stream_triad_gbs(C.c_int64(n), C.c_int(reps)))
