@@ -341,6 +341,11 @@ template <class D> struct CsrOp : ks_operator {
   D* lpart = nullptr;
   int32_t* lrow = nullptr;
   int32_t* lfirst = nullptr;
+  // stencil-mask layout (k_spmv_stencil): one bit per dictionary slot and row, the dictionary in the kernel arguments
+  int nstencil = 0;          // slots (0: layout not in use)
+  int stencil_mask_bytes = 1;
+  void* smask = nullptr;
+  ksd::StencilDict<D> sdict{};
   // sliced-ELLPACK layout (k_spmv_sell): slices of 64 rows, column-major, padded to the slice's longest row
   void* sliceptr = nullptr;  // entry offsets of the slices, same integer type as rowptr
   int32_t* sperm = nullptr;  // slice position -> row (sigma > 1 only)
@@ -376,7 +381,7 @@ template <class D> struct CsrOp : ks_operator {
   ksd::HaloArgs hargs{};
 
   ~CsrOp() override {
-    (void)hipFree(rowptr); (void)hipFree(colidx); (void)hipFree(val); (void)hipFree(blkptr); (void)hipFree(blkrow); (void)hipFree(sliceptr); (void)hipFree(sperm); (void)hipFree(blkpart); (void)hipFree(lpart); (void)hipFree(lrow); (void)hipFree(lfirst);
+    (void)hipFree(rowptr); (void)hipFree(colidx); (void)hipFree(val); (void)hipFree(blkptr); (void)hipFree(blkrow); (void)hipFree(smask); (void)hipFree(sliceptr); (void)hipFree(sperm); (void)hipFree(blkpart); (void)hipFree(lpart); (void)hipFree(lrow); (void)hipFree(lfirst);
     if (p2p_halo) {
       if (ctx->p2p.arena_used == arena_hi) ctx->p2p.arena_used = arena_lo;  // stack discipline; otherwise kept until the context dies
     } else {
@@ -446,6 +451,15 @@ template <class D> struct CsrOp : ks_operator {
         if (ptr64) f(int64_t{});
         else f(int32_t{});
       };
+      if (nstencil > 0) {
+        const int nt = (int)((n_local + kBlock - 1) / kBlock);
+        if (stencil_mask_bytes == 1)
+          ksd::k_spmv_stencil<D, uint8_t><<<nt, kBlock, 0, s>>>(static_cast<const uint8_t*>(smask), sdict, nstencil, x, ghost, y, n_local, nt, st, hseq, ghost_stride);
+        else
+          ksd::k_spmv_stencil<D, uint32_t><<<nt, kBlock, 0, s>>>(static_cast<const uint32_t*>(smask), sdict, nstencil, x, ghost, y, n_local, nt, st, hseq, ghost_stride);
+        KS_HIP(hipGetLastError());
+        return;
+      }
       if (ndvi > 0) {
         with_ip([&](auto ip_tag) {
           using IP = decltype(ip_tag);
@@ -644,7 +658,7 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
   // non-zero.  KS_SPMV_FORMAT = csr | vi | dvi restricts the choice (default: the most compact that applies).
   {
     const char* fmt = std::getenv("KS_SPMV_FORMAT");
-    const bool try_dvi = nnz > 0 && (!fmt || std::string(fmt) == "dvi");
+    const bool try_dvi = nnz > 0 && (!fmt || std::string(fmt) == "dvi" || std::string(fmt) == "stencil");
     if (try_dvi) {
       struct Key {
         uint64_t a, b;
@@ -692,6 +706,68 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
           cnext = (cnext + 1) & 7;
           if (ncache < 8) ++ncache;
         }
+      }
+      // Stencil-mask layout: <= 32 dictionary entries and every row a sub-sequence of ONE ordering of them (a
+      // topological order of "entry a precedes entry b in some row"): one bit per slot and row.  KS_SPMV_FORMAT=dvi
+      // keeps the byte-per-entry layout, =stencil insists on this one.
+      if (ok && dd.size() <= (size_t)ksd::kStencilSlots && !(fmt && std::string(fmt) == "dvi")) {
+        const int ns = (int)dd.size();
+        std::vector<uint32_t> succ((size_t)ns, 0u);  // succ[a] bit b: a directly precedes b in some row
+        for (int64_t r = 0; r < nrows; ++r)
+          for (int64_t p = rp[r] + 1; p < rp[r + 1]; ++p) succ[codes[p - 1]] |= 1u << codes[p];
+        // Kahn's algorithm on <= 32 nodes; ties broken by dictionary id (first appearance) -> deterministic
+        std::vector<int> indeg((size_t)ns, 0), order;
+        for (int a = 0; a < ns; ++a)
+          for (int b = 0; b < ns; ++b)
+            if (succ[a] >> b & 1u) indeg[b]++;
+        std::vector<char> done((size_t)ns, 0);
+        for (int it = 0; it < ns; ++it) {
+          int pick = -1;
+          for (int a = 0; a < ns; ++a)
+            if (!done[a] && indeg[a] == 0) { pick = a; break; }
+          if (pick < 0) break;  // a cycle: no common order
+          done[pick] = 1;
+          order.push_back(pick);
+          for (int b = 0; b < ns; ++b)
+            if (succ[pick] >> b & 1u) indeg[b]--;
+        }
+        bool sten = (int)order.size() == ns;
+        std::vector<int> slot((size_t)ns, 0);
+        for (int k = 0; k < (int)order.size(); ++k) slot[order[k]] = k;
+        const int mbytes = ns <= 8 ? 1 : 4;
+        std::vector<uint8_t> m8;
+        std::vector<uint32_t> m32;
+        if (sten) {
+          if (mbytes == 1) m8.assign((size_t)nrows, 0); else m32.assign((size_t)nrows, 0u);
+          for (int64_t r = 0; r < nrows && sten; ++r) {
+            uint32_t m = 0;
+            int last = -1;
+            for (int64_t p = rp[r]; p < rp[r + 1]; ++p) {
+              const int k = slot[codes[p]];
+              if (k <= last) { sten = false; break; }  // (a repeated entry in one row: not a sub-sequence)
+              last = k;
+              m |= 1u << k;
+            }
+            if (mbytes == 1) m8[r] = (uint8_t)m; else m32[r] = m;
+          }
+        }
+        if (sten) {
+          op->nstencil = ns;
+          op->stencil_mask_bytes = mbytes;
+          for (int k = 0; k < ns; ++k) {
+            op->sdict.delta[k] = dd[order[k]];
+            op->sdict.val[k] = dv[order[k]];
+          }
+          for (int k = ns; k < ksd::kStencilSlots; ++k) { op->sdict.delta[k] = 0; op->sdict.val[k] = D{}; }
+          op->ndvi = 0;
+          op->layout = KS_LAYOUT_STENCIL;
+          op->bytes_per_nnz = (double)mbytes * (double)nrows / (double)nnz;
+          op->aux_bytes = 0.0;
+          KS_HIP(hipMalloc(&op->smask, std::max<size_t>((size_t)nrows * mbytes, 16)));
+          KS_HIP(hipMemcpy(op->smask, mbytes == 1 ? (const void*)m8.data() : (const void*)m32.data(), (size_t)nrows * mbytes, hipMemcpyHostToDevice));
+          return op.release();
+        }
+        KS_REQUIRE(!(fmt && std::string(fmt) == "stencil"), KS_ERR_ARGUMENT, "KS_SPMV_FORMAT=stencil: the rows are not sub-sequences of one entry order");
       }
       if (ok) {
         op->ndvi = (int)dd.size();
@@ -2170,8 +2246,8 @@ int ks_operator_format(const ks_operator* op, double* bytes_per_nnz, int* ndict,
     if (bytes_per_nnz) *bytes_per_nnz = op->bytes_per_nnz;
     if (ndict) {
       *ndict = 0;
-      if (op->dtype == KS_F64) { if (auto* c = dynamic_cast<const CsrOp<double>*>(op)) *ndict = c->ndvi > 0 ? c->ndvi : c->ndict; }
-      else if (auto* c = dynamic_cast<const CsrOp<cd>*>(op)) *ndict = c->ndvi > 0 ? c->ndvi : c->ndict;
+      if (op->dtype == KS_F64) { if (auto* c = dynamic_cast<const CsrOp<double>*>(op)) *ndict = c->nstencil > 0 ? c->nstencil : c->ndvi > 0 ? c->ndvi : c->ndict; }
+      else if (auto* c = dynamic_cast<const CsrOp<cd>*>(op)) *ndict = c->nstencil > 0 ? c->nstencil : c->ndvi > 0 ? c->ndvi : c->ndict;
     }
   });
 }

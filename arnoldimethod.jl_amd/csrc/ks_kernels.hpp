@@ -509,6 +509,59 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // ------------------------------------------------------------------------------------------------
+// SpMV, stencil-mask layout.  A matrix whose delta-value dictionary has at most 32 entries and whose rows are all
+// SUB-SEQUENCES of one ordered list of those entries (constant-coefficient stencils on structured grids with truncated
+// boundary rows: the 3-D 7-point Laplacian has 7 slots, interior rows use all of them, boundary rows a subset) is stored
+// as ONE BIT PER SLOT AND ROW: bit k of mask[r] says whether row r has slot k = (delta_k, value_k).  The dictionary
+// travels in the kernel arguments (scalar registers), so the matrix stream is 1 byte per ROW (7 slots: 17 bytes per row
+// in total with x and y, against 27 for the delta-value-indexed and 104 for the plain CSR layout) and the inner loop is a
+// handful of vector instructions per entry with no LDS at all -- k_spmv_dvi is bound by instruction issue (byte decode +
+// two dictionary reads per entry), this kernel by the memory system.  lane = row, so the gathers x[r + delta_k] are
+// coalesced.  Slots are visited in the common order (= CSR order of every row), products rounded separately, absent
+// slots skipped (never multiplied): y is bit-identical to the other layouts.
+// ------------------------------------------------------------------------------------------------
+constexpr int kStencilSlots = 32;
+template <class T> struct StencilDict {
+  int32_t delta[kStencilSlots];
+  T val[kStencilSlots];
+};
+
+template <class T, class MT>
+__global__ void __launch_bounds__(kBlock)
+    k_spmv_stencil(const MT* __restrict__ mask, const StencilDict<T> d, int nslots, const T* __restrict__ x,
+                   const T* __restrict__ xg, T* __restrict__ y, int64_t n, int ntiles, const DevState* __restrict__ st,
+                   const uint32_t* __restrict__ hseq, int64_t gstride) {
+  if (st && st->breakdown >= 0) return;
+  if (hseq) xg += (int64_t)(*hseq & 1u) * gstride;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int64_t r = (int64_t)tile * kBlock + threadIdx.x;
+  const bool live = r < n;
+  const uint32_t m = live ? (uint32_t)mask[r] : 0u;
+  const int64_t rc = live ? r : 0;
+  T s = zero_of(T{});
+  constexpr int UN = 8;
+#pragma unroll
+  for (int k0 = 0; k0 < kStencilSlots; k0 += UN) {
+    if (k0 < nslots) {  // uniform
+      T xv[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const bool on = (k0 + u < nslots) && ((m >> (k0 + u)) & 1u);
+        const int64_t c = on ? rc + d.delta[k0 + u] : rc;
+        xv[u] = (c < n) ? x[c] : xg[c - n];
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const bool on = (k0 + u < nslots) && ((m >> (k0 + u)) & 1u);
+        const T p = mul_nc(d.val[k0 + u], xv[u]);
+        s = on ? add_(s, p) : s;
+      }
+    }
+  }
+  if (live) st_elem_nt(y + r, s);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Dense operator  y = A x  (mul!(y, A::Matrix, x), src/expansion.jl:121 with a dense A): A row-major with a
 // padded leading dimension (multiple of 2 elements, so every row starts 16-byte aligned).  One wave per row
 // and trip: lanes stride over the row with 16-byte non-temporal loads (the matrix is the HBM stream, x stays

@@ -161,7 +161,7 @@ end
 function operator_format(A::HipOperator)
     b = Ref{Cdouble}(0); d = Ref{Cint}(0); l = Ref{Cint}(0)
     check(ccall((:ks_operator_format, LIB), Cint, (Ptr{Cvoid}, Ref{Cdouble}, Ref{Cint}, Ref{Cint}), A.h, b, d, l))
-    (bytes_per_nnz = b[], ndict = Int(d[]), layout = (:csr, :csr_vi, :dvi, :sell, :sell_vi)[l[] + 1])
+    (bytes_per_nnz = b[], ndict = Int(d[]), layout = (:csr, :csr_vi, :dvi, :sell, :sell_vi, :stencil)[l[] + 1])
 end
 
 # Opaque operators (LinearMaps etc., docs/src/index.md:246-249): the library calls back with two host pointers per

@@ -359,6 +359,7 @@ def make_line(args, pkg, passes, order, world, rank, force_dist, wl, with_cpu_ba
         "dgks_second_passes": state["reorth"],
         "spmv_layout": {"csr-dvi": "csr-dvi: %d-entry (column-row, value) dictionary, 1 B per non-zero (bit-identical products)",
                         "csr-vi": "csr-vi: %d-entry value dictionary, 4 B per non-zero (bit-identical products)",
+                        "stencil": "stencil-mask: %d-slot (column-row, value) dictionary in the kernel arguments, 1 bit per slot and row (bit-identical products)",
                         "sell": "sell-64: sliced ELLPACK, 12 B per stored entry%.0s",
                         "sell-vi": "sell-64-vi: sliced ELLPACK with a %d-entry value dictionary, 4 B per stored entry",
                         "csr": "csr: 12 B per non-zero%.0s"}.get(layout, layout + "%.0s") % fmt["ndict"],

@@ -145,6 +145,9 @@ int ks_operator_device_callback(ks_ctx* ctx, int64_t n_local, int dtype, ks_devi
 int ks_operator_destroy(ks_operator* op);
 int ks_operator_size(const ks_operator* op, int64_t* n_local, int64_t* nnz, int* dtype);
 /* Device layout chosen for a stored matrix at upload (mul!(y, A, x), src/expansion.jl:121; all layouts give bit-identical y):
+ *   KS_LAYOUT_STENCIL  one BIT per dictionary slot and row: matrices whose (column - row, value) dictionary has <= 32 entries
+ *                      and whose rows are sub-sequences of one ordering of them (constant-coefficient stencils with
+ *                      truncated boundary rows); the dictionary travels in the kernel arguments
  *   KS_LAYOUT_DVI      one byte per non-zero into a <= 256-entry dictionary of (column - row, value) pairs (stencils)
  *   KS_LAYOUT_SELL     sliced ELLPACK, 64-row slices stored column-major (lane = row: coalesced loads and, for banded
  *                      matrices, coalesced gathers); taken when slicing pads the matrix by <= 15 % (uniform row lengths)
@@ -152,12 +155,12 @@ int ks_operator_size(const ks_operator* op, int64_t* n_local, int64_t* nnz, int*
  *                      row is a block of its own (ragged and skewed matrices)
  *   ..._VI             the same storage orders with ONE 32-bit word per non-zero (dictionary index << 24 | column):
  *                      matrices with <= 256 distinct stored values and < 2^24 columns
- * KS_SPMV_FORMAT = dvi | sell | sellvi | csr | vi pins one; KS_SELL_SIGMA sorts rows by length inside windows.
+ * KS_SPMV_FORMAT = stencil | dvi | sell | sellvi | csr | vi pins one; KS_SELL_SIGMA sorts rows by length inside windows.
  * Non-zero offsets are 32-bit, 64-bit once nnz >= 2^31 (KS_SPMV_PTR64=1 forces them).
  * *bytes_per_nnz = what the SpMV streams per stored non-zero (padding included: 12 / 20 for plain CSR Float64 /
  * ComplexF64, 4 value-indexed, 1 delta-value-indexed), *ndict the dictionary size, *layout one of the codes below
  * (0 / 0 / -1 for dense and callback operators). */
-enum { KS_LAYOUT_CSR = 0, KS_LAYOUT_CSR_VI = 1, KS_LAYOUT_DVI = 2, KS_LAYOUT_SELL = 3, KS_LAYOUT_SELL_VI = 4 };
+enum { KS_LAYOUT_CSR = 0, KS_LAYOUT_CSR_VI = 1, KS_LAYOUT_DVI = 2, KS_LAYOUT_SELL = 3, KS_LAYOUT_SELL_VI = 4, KS_LAYOUT_STENCIL = 5 };
 int ks_operator_format(const ks_operator* op, double* bytes_per_nnz, int* ndict, int* layout);
 /* y = A*x on raw device pointers (bench / tests; the solver uses ks_apply below). */
 int ks_operator_apply_raw(ks_operator* op, const void* x_dev, void* y_dev);

@@ -783,7 +783,7 @@ def test_delta_value_indexed_layout_is_bit_identical(dtype, monkeypatch):
     rng = np.random.default_rng(23)
     x = rnd(rng, dtype, n)
     out = {}
-    for fmt in ("dvi", "vi", "csr", "sell", "sellvi"):
+    for fmt in ("stencil", "dvi", "vi", "csr", "sell", "sellvi"):
         monkeypatch.setenv("KS_SPMV_FORMAT", fmt)
         op = pkg.csr_operator(M)
         ws = pkg.ArnoldiWorkspace(n, 4, dtype)
@@ -793,8 +793,9 @@ def test_delta_value_indexed_layout_is_bit_identical(dtype, monkeypatch):
     monkeypatch.delenv("KS_SPMV_FORMAT")
     assert out["dvi"][1]["bytes_per_nnz"] == 1.0 and 0 < out["dvi"][1]["ndict"] <= 256
     assert out["vi"][1]["bytes_per_nnz"] == 4.0 and out["csr"][1]["ndict"] == 0
-    assert pkg.csr_operator(M).format["bytes_per_nnz"] == 1.0   # the default picks the most compact layout
-    for fmt in ("dvi", "vi", "sell", "sellvi"):
+    assert out["stencil"][1]["layout"] == "stencil" and out["stencil"][1]["bytes_per_nnz"] < 0.5
+    assert pkg.csr_operator(M).format["layout"] == "stencil"   # the default picks the most compact layout
+    for fmt in ("stencil", "dvi", "vi", "sell", "sellvi"):
         assert np.array_equal(out[fmt][0].view(np.uint64), out["csr"][0].view(np.uint64)), fmt
     np.testing.assert_allclose(out["dvi"][0], M @ x, rtol=1e-13, atol=1e-13)
 

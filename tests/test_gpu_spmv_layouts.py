@@ -147,6 +147,9 @@ def test_dvi_rows_per_thread_variants_bit_identical(rpt, shape, monkeypatch):
     monkeypatch.setenv("KS_SPMV_FORMAT", "sellvi")
     y2, f2, _ = _apply(A, x, np.float64, op0.ctx)
     assert f2["layout"] == "sell-vi" and np.array_equal(y2, y0)
+    monkeypatch.setenv("KS_SPMV_FORMAT", "stencil")
+    y3, f3, _ = _apply(A, x, np.float64, op0.ctx)
+    assert f3["layout"] == "stencil" and f3["ndict"] <= 7 and np.array_equal(y3, y0)
     np.testing.assert_allclose(y0, A @ x, rtol=0, atol=1e-14 * 12)
 
 
@@ -156,10 +159,99 @@ def test_solver_end_to_end_on_each_layout(monkeypatch):
     n = A.shape[0]
     v1 = oa.uniform_hash(oa.DEFAULT_SEED, np.arange(n))
     out = {}
-    for f in ("dvi", "vi", "csr", "sell", "sellvi"):
+    for f in ("stencil", "dvi", "vi", "csr", "sell", "sellvi"):
         monkeypatch.setenv("KS_SPMV_FORMAT", f)
         dec, hist = pkg.partialschur(A, v1=v1, nev=5, which="SR", tol=1e-10, maxdim=25)
         out[f] = (hist.mvproducts, np.sort(dec.eigenvalues.real))
         assert hist.converged
     for f in out:
         assert out[f][0] == out["csr"][0] and np.array_equal(out[f][1], out["csr"][1]), f
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_stencil_mask_layout(dtype, monkeypatch):
+    """One bit per dictionary slot and row.  (i) 27-point-like stencil with 19 slots (32-bit masks), complex values,
+    boundary rows = sub-sequences: bit-identical to the CSR blocks.  (ii) x containing Inf next to ABSENT slots: a
+    skipped slot must never be multiplied.  (iii) a matrix whose rows cannot be embedded in one entry order (two rows
+    using the same two dictionary entries in opposite orders) falls back to the delta-value-indexed layout;
+    KS_SPMV_FORMAT=stencil then refuses.  (iv) 33 dictionary entries: too many slots -> DVI."""
+    cplx = np.dtype(dtype).kind == "c"
+    rng = np.random.default_rng(91)
+    mx, my, mz = 9, 8, 7
+    n = mx * my * mz
+    rows, cols, vals = [], [], []
+    offs = [(dx, dy, dz) for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1) if abs(dx) + abs(dy) + abs(dz) <= 2]
+    coef = {o: (rng.standard_normal() + (1j * rng.standard_normal() if cplx else 0)) for o in offs}
+    for z in range(mz):
+        for y in range(my):
+            for x_ in range(mx):
+                r = x_ + mx * (y + my * z)
+                for (dx, dy, dz) in offs:
+                    if 0 <= x_ + dx < mx and 0 <= y + dy < my and 0 <= z + dz < mz:
+                        rows.append(r); cols.append(r + dx + mx * (dy + my * dz)); vals.append(coef[(dx, dy, dz)])
+    A = sp.csr_matrix((np.array(vals, dtype=dtype), (rows, cols)), shape=(n, n))
+    A.sort_indices()
+    xv = rnd(rng, dtype, n)
+    y, f, op = _apply(A, xv, dtype)
+    assert f["layout"] == "stencil" and f["ndict"] == len(offs) == 19
+    monkeypatch.setenv("KS_SPMV_FORMAT", "csr")
+    y0, f0, _ = _apply(A, xv, dtype, op.ctx)
+    assert f0["layout"] == "csr" and np.array_equal(y.view(np.uint64), y0.view(np.uint64))
+    # (ii)
+    monkeypatch.delenv("KS_SPMV_FORMAT")
+    L = laplace3d(6, 5, 4).astype(dtype)
+    m = L.shape[0]
+    xi = rnd(rng, dtype, m)
+    xi[5] = np.inf                      # x index 5 = right neighbour of row 4... and NOT a neighbour of row 6 (x = 0 of the next line)
+    yi, fi, opi = _apply(L, xi, dtype)
+    assert fi["layout"] == "stencil"
+    ref = L @ xi
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(yi), fin) and np.allclose(yi[fin], ref[fin], rtol=1e-13, atol=1e-13)
+    # (iii)
+    B = sp.csr_matrix(np.array([[0, 2.0, 0, 3.0], [0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0.0]]))  # row 0: deltas (+1: 2.0), (+3: 3.0)
+    B = sp.lil_matrix((6, 6))
+    B[0, 1], B[0, 3] = 2.0, 3.0        # entries (delta 1, 2.0) then (delta 3, 3.0)
+    B[2, 3], B[2, 5] = 3.0, 2.0        # entries (delta 1, 3.0) then (delta 3, 2.0): fine so far (4 distinct entries)
+    B[3, 4], B[3, 5] = 2.0, 9.0        # (delta 1, 2.0) then (delta 2, 9.0)
+    B[1, 3], B[1, 4] = 9.0, 3.0        # (delta 2, 9.0) then (delta 3, 3.0)  -> 2.0@1 < 9.0@2 < 3.0@3 consistent
+    C2 = sp.lil_matrix((6, 6))
+    C2[0, 1], C2[0, 2] = 5.0, 7.0      # (delta 1, 5.0) precedes (delta 2, 7.0)
+    C2[3, 5] = 7.0                      # (delta 2, 7.0) alone
+    C2[2, 4], C2[2, 3] = 7.0, 5.0      # row 2: (delta 1, 5.0) then (delta 2, 7.0) again -- consistent; make a cycle instead:
+    D = sp.csr_matrix((np.array([5.0, 7.0, 7.0, 5.0]), (np.array([0, 0, 2, 2]), np.array([1, 2, 3, 5]))), shape=(6, 6))
+    # row 0: (delta 1, 5.0), (delta 2, 7.0);  row 2: (delta 1, 7.0), (delta 3, 5.0) -> four distinct entries, still acyclic
+    E = sp.csr_matrix((np.array([5.0, 7.0, 7.0, 5.0]), (np.array([0, 0, 3, 3]), np.array([1, 2, 4, 5]))), shape=(6, 6))
+    # row 0: (d1, 5), (d2, 7);  row 3: (d1, 7), (d2, 5): distinct entries (d1,5) (d2,7) (d1,7) (d2,5): acyclic as well.
+    # A genuine conflict needs the SAME two entries in both orders, which sorted columns forbid (same deltas, same order);
+    # unsorted CSR input can do it:
+    ptr = np.array([0, 2, 2, 4, 4, 4, 4], dtype=np.int64)
+    idx = np.array([1, 2, 4, 3], dtype=np.int64)            # row 0: cols 1, 2;  row 2: cols 4, 3 (unsorted)
+    val = np.array([5.0, 7.0, 7.0, 5.0]).astype(dtype)       # row 0: (d1,5),(d2,7); row 2: (d2,7),(d1,5)  -> cycle
+    import ctypes as C
+
+    Lh = pkg._lib.load()
+    h = C.c_void_p()
+    code = pkg._lib.KS_C64 if cplx else pkg._lib.KS_F64
+    pkg._lib.check(Lh.ks_operator_csr(op.ctx._h, 6, 6, 4, ptr.ctypes.data, idx.ctypes.data, val.ctypes.data, pkg._lib.KS_CSR, 0, pkg._lib.KS_I64, code, C.byref(h)))
+    opc = pkg.Operator(op.ctx, h, (6, 6), dtype)
+    assert opc.format["layout"] == "csr-dvi"
+    ws6 = pkg.ArnoldiWorkspace(6, 2, dtype, ctx=op.ctx)
+    x6 = rnd(rng, dtype, 6)
+    ws6.set_col(0, x6)
+    ws6.apply(opc, 0, 1)
+    want = np.zeros(6, dtype=dtype)
+    want[0] = 5.0 * x6[1] + 7.0 * x6[2]
+    want[2] = 7.0 * x6[4] + 5.0 * x6[3]
+    np.testing.assert_allclose(ws6.col(1), want, rtol=1e-14)
+    monkeypatch.setenv("KS_SPMV_FORMAT", "stencil")
+    h2 = C.c_void_p()
+    rc = Lh.ks_operator_csr(op.ctx._h, 6, 6, 4, ptr.ctypes.data, idx.ctypes.data, val.ctypes.data, pkg._lib.KS_CSR, 0, pkg._lib.KS_I64, code, C.byref(h2))
+    assert rc == pkg._lib.KS_ERR_ARGUMENT
+    monkeypatch.delenv("KS_SPMV_FORMAT")
+    # (iv) a banded matrix with 33 distinct diagonals
+    n4 = 400
+    diags = [np.full(n4 - k, 1.0 + k) for k in range(33)]
+    G = sp.diags(diags, list(range(33)), format="csr").astype(dtype)
+    y4, f4, _ = _apply(G, rnd(rng, dtype, n4), dtype, op.ctx)
+    assert f4["layout"] == "csr-dvi" and f4["ndict"] == 33

@@ -46,8 +46,8 @@ def skewed(n, seed=3):
 
 
 def cases():
-    yield "lap216", lambda: M.to_scipy(*M.laplace3d_csr(216, 216, 216), 216 ** 3), ("csr", "vi", "sell", "sellvi", "dvi")
-    yield "lap100", lambda: M.to_scipy(*M.laplace3d_csr(100, 100, 100), 100 ** 3), ("csr", "vi", "sell", "sellvi", "dvi")
+    yield "lap216", lambda: M.to_scipy(*M.laplace3d_csr(216, 216, 216), 216 ** 3), ("csr", "vi", "sell", "sellvi", "dvi", "stencil")
+    yield "lap100", lambda: M.to_scipy(*M.laplace3d_csr(100, 100, 100), 100 ** 3), ("csr", "vi", "sell", "sellvi", "dvi", "stencil")
     def lapvar():
         """7-point stencil with VARIABLE coefficients (more than 256 distinct values: no dictionary layout applies) --
         what the default selection turns into sliced ELLPACK"""
