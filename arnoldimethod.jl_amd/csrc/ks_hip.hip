@@ -345,6 +345,7 @@ template <class D> struct CsrOp : ks_operator {
   int nstencil = 0;          // slots (0: layout not in use)
   int stencil_mask_bytes = 1;
   void* smask = nullptr;
+  void* smask2 = nullptr;    // == smask (the array is padded to an even number of rows): masks of rows 2t, 2t+1 in one word
   ksd::StencilDict<D> sdict{};
   // sliced-ELLPACK layout (k_spmv_sell): slices of 64 rows, column-major, padded to the slice's longest row
   void* sliceptr = nullptr;  // entry offsets of the slices, same integer type as rowptr
@@ -451,12 +452,32 @@ template <class D> struct CsrOp : ks_operator {
         if (ptr64) f(int64_t{});
         else f(int32_t{});
       };
-      if (nstencil > 0) {
-        const int nt = (int)((n_local + kBlock - 1) / kBlock);
+      if (nstencil > 0 && nghost == 0 && smask2 && n_local >= 2 && env_int("KS_STENCIL_PAIRS", 1)) {
+        // two rows per lane, 16-byte gathers (no ghost columns: single GPU)
+        const int nt = (int)(((n_local + 1) / 2 + kBlock - 1) / kBlock);
         if (stencil_mask_bytes == 1)
-          ksd::k_spmv_stencil<D, uint8_t><<<nt, kBlock, 0, s>>>(static_cast<const uint8_t*>(smask), sdict, nstencil, x, ghost, y, n_local, nt, st, hseq, ghost_stride);
+          ksd::k_spmv_stencil2<D, uint16_t><<<nt, kBlock, 0, s>>>(static_cast<const uint16_t*>(smask2), sdict, nstencil, x, y, n_local, nt, st);
         else
-          ksd::k_spmv_stencil<D, uint32_t><<<nt, kBlock, 0, s>>>(static_cast<const uint32_t*>(smask), sdict, nstencil, x, ghost, y, n_local, nt, st, hseq, ghost_stride);
+          ksd::k_spmv_stencil2<D, uint64_t><<<nt, kBlock, 0, s>>>(static_cast<const uint64_t*>(smask2), sdict, nstencil, x, y, n_local, nt, st);
+        KS_HIP(hipGetLastError());
+        return;
+      }
+      if (nstencil > 0) {
+        static const int rpt_env = env_int("KS_STENCIL_RPT", 1);
+        auto go = [&](auto mt_tag, auto rpt_tag) {
+          using MT = decltype(mt_tag);
+          constexpr int RPT = decltype(rpt_tag)::value;
+          const int nt = (int)((n_local + kBlock * RPT - 1) / (kBlock * RPT));
+          ksd::k_spmv_stencil<D, MT, RPT><<<nt, kBlock, 0, s>>>(static_cast<const MT*>(smask), sdict, nstencil, x, ghost, y, n_local,
+                                                                std::max<int64_t>(nghost, 0), nt, st, hseq, ghost_stride);
+        };
+        auto by_rpt = [&](auto mt_tag) {
+          if (rpt_env <= 1) go(mt_tag, std::integral_constant<int, 1>{});
+          else if (rpt_env == 2) go(mt_tag, std::integral_constant<int, 2>{});
+          else go(mt_tag, std::integral_constant<int, 4>{});
+        };
+        if (stencil_mask_bytes == 1) by_rpt(uint8_t{});
+        else by_rpt(uint32_t{});
         KS_HIP(hipGetLastError());
         return;
       }
@@ -763,8 +784,11 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
           op->layout = KS_LAYOUT_STENCIL;
           op->bytes_per_nnz = (double)mbytes * (double)nrows / (double)nnz;
           op->aux_bytes = 0.0;
-          KS_HIP(hipMalloc(&op->smask, std::max<size_t>((size_t)nrows * mbytes, 16)));
+          const size_t mbytes_al = (size_t)round_up((int64_t)nrows + 2, 8) * mbytes;
+          KS_HIP(hipMalloc(&op->smask, mbytes_al));
+          KS_HIP(hipMemset(op->smask, 0, mbytes_al));
           KS_HIP(hipMemcpy(op->smask, mbytes == 1 ? (const void*)m8.data() : (const void*)m32.data(), (size_t)nrows * mbytes, hipMemcpyHostToDevice));
+          op->smask2 = op->smask;
           return op.release();
         }
         KS_REQUIRE(!(fmt && std::string(fmt) == "stencil"), KS_ERR_ARGUMENT, "KS_SPMV_FORMAT=stencil: the rows are not sub-sequences of one entry order");

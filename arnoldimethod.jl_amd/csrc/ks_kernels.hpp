@@ -526,39 +526,118 @@ template <class T> struct StencilDict {
   T val[kStencilSlots];
 };
 
-template <class T, class MT>
+// The x loads do NOT wait for the mask: every lane loads x at the clamped address r + delta_k for every slot and the
+// mask only selects which products are added (one memory round trip per row instead of two; measured 54 -> see
+// profiles/).  RPT rows per thread (rows r, r + 256, ...) put more independent loads in flight.
+template <class T, class MT, int RPT>
 __global__ void __launch_bounds__(kBlock)
     k_spmv_stencil(const MT* __restrict__ mask, const StencilDict<T> d, int nslots, const T* __restrict__ x,
-                   const T* __restrict__ xg, T* __restrict__ y, int64_t n, int ntiles, const DevState* __restrict__ st,
-                   const uint32_t* __restrict__ hseq, int64_t gstride) {
+                   const T* __restrict__ xg, T* __restrict__ y, int64_t n, int64_t nghost, int ntiles,
+                   const DevState* __restrict__ st, const uint32_t* __restrict__ hseq, int64_t gstride) {
   if (st && st->breakdown >= 0) return;
   if (hseq) xg += (int64_t)(*hseq & 1u) * gstride;
   const int tile = xcd_remap(blockIdx.x, ntiles);
-  const int64_t r = (int64_t)tile * kBlock + threadIdx.x;
-  const bool live = r < n;
-  const uint32_t m = live ? (uint32_t)mask[r] : 0u;
-  const int64_t rc = live ? r : 0;
-  T s = zero_of(T{});
+  const int64_t cmax = n + nghost - 1;
+  int64_t r[RPT];
+  uint32_t m[RPT];
+  T s[RPT];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    r[q] = (int64_t)tile * (kBlock * RPT) + q * kBlock + threadIdx.x;
+    m[q] = r[q] < n ? (uint32_t)mask[r[q]] : 0u;
+    s[q] = zero_of(T{});
+  }
   constexpr int UN = 8;
 #pragma unroll
   for (int k0 = 0; k0 < kStencilSlots; k0 += UN) {
     if (k0 < nslots) {  // uniform
-      T xv[UN];
+      T xv[RPT][UN];
+#pragma unroll
+      for (int q = 0; q < RPT; ++q)
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          // clamped, mask-independent address (slots beyond nslots have delta 0)
+          int64_t c = r[q] + d.delta[k0 + u];
+          c = c < 0 ? 0 : (c > cmax ? cmax : c);
+          xv[q][u] = (c < n) ? x[c] : xg[c - n];
+        }
+#pragma unroll
+      for (int q = 0; q < RPT; ++q)
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const bool on = (m[q] >> (k0 + u)) & 1u;  // bits of slots >= nslots are never set
+          const T p = mul_nc(d.val[k0 + u], xv[q][u]);
+          s[q] = on ? add_(s[q], p) : s[q];
+        }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < RPT; ++q)
+    if (r[q] < n) st_elem_nt(y + r[q], s[q]);
+}
+
+// Paired form (single GPU, no ghost columns): a lane owns the two consecutive rows 2t, 2t+1 and fetches x[r + delta_k],
+// x[r + 1 + delta_k] with ONE 16-byte load (8-byte aligned: global loads only need dword alignment).  The 8-byte form
+// above is bound by the vector-memory path -- seven 8-byte loads per row through an L1 that moves 8-byte accesses at
+// about half the 16-byte rate (MI355X_MICROARCH.md) -- not by HBM: 171 MB took 54 us, a copy of the same bytes takes 28.
+// Addresses are clamped so that the pair stays inside x; `sh` says where the wanted elements sit in a clamped pair.
+typedef double f64x2u __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ void ld_pair_u(const double* p, double& a, double& b) {
+  const f64x2u v = *reinterpret_cast<const f64x2u*>(p);
+  a = v.x;
+  b = v.y;
+}
+__device__ __forceinline__ void ld_pair_u(const cd* p, cd& a, cd& b) {  // complex: two 16-byte elements
+  a = p[0];
+  b = p[1];
+}
+
+template <class T, class MT2>
+__global__ void __launch_bounds__(kBlock)
+    k_spmv_stencil2(const MT2* __restrict__ mask2, const StencilDict<T> d, int nslots, const T* __restrict__ x,
+                    T* __restrict__ y, int64_t n, int ntiles, const DevState* __restrict__ st) {
+  if (st && st->breakdown >= 0) return;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int64_t r = 2 * ((int64_t)tile * kBlock + threadIdx.x);  // rows r, r + 1
+  if (r >= n) return;
+  const bool two = r + 1 < n;
+  constexpr int MB = (int)sizeof(MT2) * 4;  // mask bits per row
+  const MT2 mm = mask2[r >> 1];             // masks of both rows (the mask array is padded to an even row count)
+  const uint32_t m0 = (uint32_t)(mm & (MT2)((((uint64_t)1) << MB) - 1)), m1 = (uint32_t)((uint64_t)mm >> MB);
+  const int64_t cmax = n - 2;               // last admissible pair start
+  T s0 = zero_of(T{}), s1 = zero_of(T{});
+  constexpr int UN = 8;
+#pragma unroll
+  for (int k0 = 0; k0 < kStencilSlots; k0 += UN) {
+    if (k0 < nslots) {  // uniform
+      T xa[UN], xb[UN];
+      int sh[UN];
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
-        const bool on = (k0 + u < nslots) && ((m >> (k0 + u)) & 1u);
-        const int64_t c = on ? rc + d.delta[k0 + u] : rc;
-        xv[u] = (c < n) ? x[c] : xg[c - n];
+        const int64_t c = r + d.delta[k0 + u];
+        int64_t lo = c < 0 ? 0 : (c > cmax ? cmax : c);
+        if (cmax < 0) lo = 0;
+        sh[u] = (int)(c - lo);
+        if (n >= 2) ld_pair_u(x + lo, xa[u], xb[u]);
+        else { xa[u] = x[0]; xb[u] = x[0]; }
       }
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
-        const bool on = (k0 + u < nslots) && ((m >> (k0 + u)) & 1u);
-        const T p = mul_nc(d.val[k0 + u], xv[u]);
-        s = on ? add_(s, p) : s;
+        // wanted: row r -> x[c] = pair[sh], row r+1 -> x[c+1] = pair[sh+1]; out-of-pair positions belong to absent slots
+        const T v0 = sh[u] == 1 ? xb[u] : xa[u];
+        const T v1 = sh[u] == -1 ? xa[u] : xb[u];
+        const T p0 = mul_nc(d.val[k0 + u], v0), p1 = mul_nc(d.val[k0 + u], v1);
+        s0 = ((m0 >> (k0 + u)) & 1u) ? add_(s0, p0) : s0;
+        s1 = ((m1 >> (k0 + u)) & 1u) ? add_(s1, p1) : s1;
       }
     }
   }
-  if (live) st_elem_nt(y + r, s);
+  if (two) {
+    if constexpr (sizeof(T) == 8) st_pack_nt(y + r, make_double2(s0, s1));
+    else { st_elem_nt(y + r, s0); st_elem_nt(y + r + 1, s1); }
+  } else {
+    st_elem_nt(y + r, s0);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
