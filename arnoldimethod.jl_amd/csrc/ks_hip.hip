@@ -1823,12 +1823,10 @@ template <class D> double placement_trio_ms(ks_workspace* w, hipEvent_t a, hipEv
   return best;
 }
 
-// Search policy (round 2: bounded and exception-safe).  Default: TWO candidates -- the plain allocation and a
-// physically contiguous one (hipDeviceMallocContiguous: consistently in the middle cluster, which bounds the damage
-// on a freshly booted device whose first ~60 GB are of the slowest kind) -- so the transient footprint is at most
-// 2 x V, and only when at least that much memory is free.  KS_PLACE_TRIALS=N (N > 2) opts into a longer search that
-// HOLDS its candidates (a freed block would simply be handed out again) within KS_PLACE_MAX_X (default 2) times the
-// basis size and KS_PLACE_BUDGET_MS; KS_PLACE_TRIALS=1 disables the search.  Candidates live in an RAII holder:
+// Search policy (round 2: opt-in, bounded and exception-safe).  KS_PLACE_TRIALS=N (N >= 2) times N candidate
+// allocations of V and keeps the fastest; it HOLDS its candidates while it runs (a freed block would simply be handed
+// out again), at most KS_PLACE_MAX_X (default 2) times the basis size and only while half of the free memory stays
+// untouched, within KS_PLACE_BUDGET_MS.  Default KS_PLACE_TRIALS=1: no search.  Candidates live in an RAII holder:
 // whatever happens, every loser is freed and w->V / w->Vbase name the kept allocation.
 struct PlacementCandidates {
   ks_workspace* w;
@@ -1845,7 +1843,12 @@ struct PlacementCandidates {
 };
 
 template <class D> void tune_placement(ks_workspace* w, size_t vbytes) {
-  static const int trials = env_int("KS_PLACE_TRIALS", 2);
+  // OFF by default (round 2).  The gain of round 1 (+3 % on the streaming kernels) came from ONE kind of candidate, a
+  // physically contiguous allocation (hipDeviceMallocContiguous, now behind KS_PLACE_CONTIGUOUS=1) -- and in such memory
+  // the SpMV, which re-reads every x element seven times and lives on L2 hits, runs 2.3x SLOWER (42 -> 96 us): the
+  // solver as a whole loses (669 vs 677 iterations/s, profiles/r02_placement_ab.txt).  Plain candidates are
+  // indistinguishable from each other on the boxes measured.  KS_PLACE_TRIALS >= 2 opts in.
+  static const int trials = env_int("KS_PLACE_TRIALS", 1);
   // measured: +3 % at 3.3 GB, +1.5 % at 1.6 GB, nothing at 0.8 GB, -2 % at 0.4 GB (there the calibration, which
   // revisits the same columns, sees the memory-side cache more than the placement)
   static const int min_mb = env_int("KS_PLACE_MIN_MB", 1024);
@@ -1877,7 +1880,8 @@ template <class D> void tune_placement(ks_workspace* w, size_t vbytes) {
     KS_HIP(hipMemGetInfo(&free_b, &total_b));
     if (free_b / 2 < vbytes) { pc.failed++; break; }                 // never take more than half of what is left
     void* p = nullptr;
-    if (pc.cand.size() == 1 && hipExtMallocWithFlags(&p, vbytes, hipDeviceMallocContiguous) != hipSuccess) {
+    static const int try_contig = env_int("KS_PLACE_CONTIGUOUS", 0);
+    if (try_contig && pc.cand.size() == 1 && hipExtMallocWithFlags(&p, vbytes, hipDeviceMallocContiguous) != hipSuccess) {
       (void)hipGetLastError();
       pc.failed++;
       p = nullptr;
