@@ -2,6 +2,15 @@
 // compute backend.  The backend owns the n-sized data (V in HBM) and implements the three verbs
 // that scale with n -- expansion, reinitialise, rotation -- the host code in this file only
 // touches H ((maxdim+1) x maxdim) and Q (maxdim x maxdim).
+//
+// ATTRIBUTION.  The algorithms in this file restate, routine by routine, the host-side code of ArnoldiMethod.jl v0.4.0
+// (https://github.com/JuliaLinearAlgebra/ArnoldiMethod.jl; MIT License, Copyright (c) 2018 Harmen Stoppels): the Julia
+// runtime the reference needs does not exist in the build image, and north_star keeps this O(maxdim^3) part on the
+// host.  It is support code for running the hot path end to end, not claimed as hot-path coverage.  The MIT licence
+// requires this notice to travel with substantial portions of the original: "Permission is hereby granted, free of
+// charge, to any person obtaining a copy of this software and associated documentation files (the "Software"), to deal
+// in the Software without restriction ... THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND" (full text:
+// the reference's LICENSE file).
 #pragma once
 
 #include <chrono>

@@ -7,6 +7,15 @@
 //
 // Each routine cites the reference file:line whose behaviour it reproduces.  Indices are 0-based
 // and ranges inclusive unless stated; matrices are column-major views.
+//
+// ATTRIBUTION.  The algorithms in this file restate, routine by routine, the host-side code of ArnoldiMethod.jl v0.4.0
+// (https://github.com/JuliaLinearAlgebra/ArnoldiMethod.jl; MIT License, Copyright (c) 2018 Harmen Stoppels): the Julia
+// runtime the reference needs does not exist in the build image, and north_star keeps this O(maxdim^3) part on the
+// host.  It is support code for running the hot path end to end, not claimed as hot-path coverage.  The MIT licence
+// requires this notice to travel with substantial portions of the original: "Permission is hereby granted, free of
+// charge, to any person obtaining a copy of this software and associated documentation files (the "Software"), to deal
+// in the Software without restriction ... THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND" (full text:
+// the reference's LICENSE file).
 #pragma once
 
 #include <algorithm>

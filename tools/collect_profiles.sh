@@ -20,7 +20,7 @@ for x in r:
 PY
 }
 python $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err
-KS_PLACE_TRIALS=1 python $REPO/bench.py --no-cpu-baseline > $OUT/bench_no_placement_search.json 2>> $OUT/bench.err
+KS_PLACE_TRIALS=2 KS_PLACE_CONTIGUOUS=1 python $REPO/bench.py --no-cpu-baseline > $OUT/bench_placement_contiguous.json 2>> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $REPO/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2>> $OUT/bench.err
 cp "$(find /tmp/kt -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -2,7 +2,7 @@
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (collected in SEPARATE runs, each with only
 --kernel-trace next to --pmc) per kernel, and write profiles/pmc_traffic.json for bench.py.
 
-usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <n> <nnz> [out.json] [bytes_per_nnz]
+usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <n> <nnz> [out.json] [bytes_per_nnz] [index_bytes_per_row]
 (bytes_per_nnz: what the SpMV layout in use streams per stored entry -- 12 plain CSR, 4 value-indexed, 1
 delta-value-indexed; `bench.py` prints it as config.spmv_layout)
 
@@ -49,6 +49,7 @@ def main():
     fpath, wpath, n, nnz = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
     out = sys.argv[5] if len(sys.argv) > 5 else None
     bpn = float(sys.argv[6]) if len(sys.argv) > 6 else 12.0
+    aux = float(sys.argv[7]) if len(sys.argv) > 7 else 4.0  # index bytes per row next to the non-zeros (4: rowptr; 0: stencil-mask layout)
     def after_calibration(rows):
         # the launches before the first SpMV are the placement search of ks_workspace_create; their number
         # differs from process to process
@@ -75,7 +76,7 @@ def main():
         if not started:
             continue
         if k == "spmv":
-            alg = bpn * nnz + 4.0 * (n + 1) + 2 * col
+            alg = bpn * nnz + aux * (n + 1) + 2 * col
         elif k == "dots":
             nc4 = int(re.search(r"k_dots<double, (\d+)", name).group(1))
             # first step of an expansion: smallest j of the granule is unknown -> track by sequence
