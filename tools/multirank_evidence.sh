@@ -18,7 +18,7 @@ for cfg in "2 laplace 20" "3 hashed 18" "2 complex 16" "3 eager 16"; do
 done
 echo "# BASELINE config 5 at true per-rank size: 8 ranks x (464 x 464 x 58 rows) on device 0 vs the single-process 464^3 run"
 port=$((port+1))
-timeout 900 python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 --master-port $port tools/dist_gpu_check.py shard5 464 2>&1 | grep -o "\[rank [0-9]\][^[]*"
+timeout 900 python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 --master-port $port tools/dist_gpu_check.py shard5 464 2>&1 | grep "^\[rank"
 echo "## lost peer (KS_P2P_TIMEOUT_S=2)"
 KS_P2P_TIMEOUT_S=2 timeout 120 python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29999 tools/dist_gpu_check.py timeout 2>&1 | grep "^\[rank"
 unset KS_SAME_DEVICE KS_TRANSPORT
