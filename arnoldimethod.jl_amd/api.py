@@ -382,7 +382,13 @@ def as_operator(A, ctx: Context | None = None) -> Operator:
 class ArnoldiWorkspace:
     """V (n x (k+1), in HBM), H ((k+1) x k, host, zero-initialised), Q (k x k, host).
 
-    ArnoldiWorkspace(n, k [, dtype])  or  ArnoldiWorkspace(v1, k)  (the array type follows v1)."""
+    ArnoldiWorkspace(n, k [, dtype])  or  ArnoldiWorkspace(v1, k)  (the array type follows v1).
+
+    Deviation from the reference, on purpose: `ArnoldiWorkspace(v1, k)` (src/ArnoldiMethod.jl:71-79) only takes the ARRAY
+    TYPE from `v1` and `partialschur!` then starts from `rand!` (src/run.jl:177); here the workspace remembers `v1` and
+    `partialschur_(A, ws)` with `initialize=True, start_from=1` starts from it -- the tests need reproducible start
+    vectors and Python has no array-type dispatch to express the original meaning.  Pass `ArnoldiWorkspace(n, k)` to get
+    the reference's random start (counter-based RNG, `set_seed`)."""
 
     def __init__(self, n_or_v1, krylov_dimension: int, dtype=np.float64, ctx: Context | None = None,
                  n_global: int | None = None, row_begin: int = 0):

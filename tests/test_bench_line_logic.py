@@ -1,0 +1,73 @@
+"""`-m "not gpu"`: the part of bench.py that turns measured passes into the ONE JSON line, on synthetic passes -- a
+failing transport must not take the line down, a deviating peer-to-peer pass is dropped, the roofline block carries the
+moved-bytes figure next to the algorithmic one and marks committed PMC traffic as not measured in the run."""
+import argparse
+import importlib.util
+import json
+import os
+
+import numpy as np
+
+from __graft_entry__ import ROOT
+
+spec = importlib.util.spec_from_file_location("_bench", os.path.join(ROOT, "bench.py"))
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+
+ARGS = argparse.Namespace(steps=10, warmup=2, no_cpu_baseline=True)
+WL = dict(m=216, n=216 ** 3, nev=20, mindim=20, maxdim=40, which="SR")
+
+
+def _pass(elapsed, ritz_shift=0.0, steps=200):
+    prof = {k: dict(ms=100.0, bytes=5e11, count=200) for k in ("spmv", "dots", "axpy", "fused")}
+    prof["fused"]["ms"] = 120.0
+    prof.update(scale=dict(ms=0.0, bytes=0.0, count=0), rotate=dict(ms=9.0, bytes=4.8e10, count=10), fin=dict(ms=2.0, bytes=0.0, count=400))
+    state = dict(steps=steps, bytes=3.0e12, moved=2.4e12, t_expand=0.9 * elapsed, t_restart=0.1 * elapsed, reorth=steps,
+                 trail=[(20, 0)] * 10, ritz=np.sort_complex(np.arange(20.0) + ritz_shift + 0j))
+    return dict(elapsed=elapsed, state=state, prof=prof, nnz_global=70263936, A_host=None,
+                fmt=dict(bytes_per_nnz=0.1434, ndict=7, layout="stencil"), placement=dict(candidates=0))
+
+
+def test_single_gpu_line_has_contract_fields_and_honest_roofline():
+    out = bench.make_line(ARGS, None, {"single": _pass(0.3)}, ["single"], 1, 0, False, WL, False)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in out, k
+    assert out["value"] == 200 / 0.3 and out["dtype"] == "f64" and out["vs_baseline"] is None and "workload" in out["config"]
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and r["kernel"].startswith("k_axpy_dots_cs")
+    fs = r["fused_step"]
+    assert fs["moved_frac"] < fs["algorithmic_frac"] and "moved_bytes" in fs and "quote this one" in fs["what"]
+    assert r["spmv"]["layout"] == "stencil" and r["spmv"]["frac"] == r["spmv"]["GBps"] / 8000.0
+    if r["traffic"] is not None:
+        assert r["traffic"]["measured_in_run"] is False
+    json.dumps(out)
+
+
+def test_line_comes_from_the_survivor_when_a_transport_failed():
+    passes = {"p2p": _pass(0.25), "rccl": {"error": "RuntimeError: ncclAllReduce failed"}}
+    out = bench.make_line(ARGS, None, passes, ["p2p", "rccl"], 8, 0, False, WL, False)
+    assert out["value"] == 200 / 0.25 and out["config"]["transport"] == "p2p" and out["n_gpus"] == 8
+    assert out["transports"]["rccl"] == {"error": "RuntimeError: ncclAllReduce failed"} and "value" in out["transports"]["p2p"]
+    passes = {"p2p": {"error": "pass did not finish within 300 s (hung exchange?)"}, "rccl": _pass(0.31)}
+    out = bench.make_line(ARGS, None, passes, ["p2p", "rccl"], 8, 0, False, WL, False)
+    assert out["config"]["transport"] == "rccl" and out["value"] == 200 / 0.31
+
+
+def test_line_appears_with_null_value_when_nothing_survived():
+    passes = {"p2p": {"error": "x"}, "rccl": {"error": "y"}}
+    out = bench.make_line(ARGS, None, passes, ["p2p", "rccl"], 8, 0, False, WL, False)
+    assert out["value"] is None and out["metric"] == "arnoldi_iters_per_sec" and set(out["transports"]) == {"p2p", "rccl"}
+    json.dumps(out)
+
+
+def test_deviating_peer_to_peer_pass_is_dropped_and_faster_valid_pass_wins():
+    passes = {"p2p": _pass(0.2, ritz_shift=1e-3), "rccl": _pass(0.3)}
+    out = bench.make_line(ARGS, None, passes, ["p2p", "rccl"], 8, 0, False, WL, False)
+    assert out["config"]["transport"] == "rccl" and "differ" in out["transports"]["p2p"]["error"]
+    passes = {"p2p": _pass(0.2), "rccl": _pass(0.3)}
+    out = bench.make_line(ARGS, None, passes, ["p2p", "rccl"], 8, 0, False, WL, False)
+    assert out["config"]["transport"] == "p2p" and out["value"] == 200 / 0.2
+
+
+def test_cpu_budget_respects_cgroup_quota():
+    assert 1 <= bench.CPU_BUDGET <= (os.cpu_count() or 1)
