@@ -255,3 +255,22 @@ def test_stencil_mask_layout(dtype, monkeypatch):
     G = sp.diags(diags, list(range(33)), format="csr").astype(dtype)
     y4, f4, _ = _apply(G, rnd(rng, dtype, n4), dtype, op.ctx)
     assert f4["layout"] == "csr-dvi" and f4["ndict"] == 33
+
+
+def test_malformed_pointer_arrays_are_rejected():
+    """a non-monotone or out-of-range pointer array must be refused at upload (it would index host arrays
+    during the CSC conversion, or device arrays in the SpMV, out of bounds)."""
+    L = pkg._lib.load()
+    ctx = pkg.default_context()
+    val = np.ones(4)
+    idx = np.array([0, 1, 2, 3], dtype=np.int64)
+    for layout in (pkg._lib.KS_CSR, pkg._lib.KS_CSC):
+        for ptr in ([0, 3, 2, 4, 4], [0, 1, 5, 3, 4], [1, 1, 2, 3, 4], [0, 1, 2, 3, 3]):
+            p = np.array(ptr, dtype=np.int64)
+            h = C.c_void_p()
+            rc = L.ks_operator_csr(ctx._h, 4, 4, 4, p.ctypes.data, idx.ctypes.data, val.ctypes.data, layout, 0, pkg._lib.KS_I64, pkg._lib.KS_F64, C.byref(h))
+            assert rc == pkg._lib.KS_ERR_ARGUMENT, (layout, ptr)
+    bad_col = np.array([0, 1, 2, 7], dtype=np.int64)
+    p = np.array([0, 1, 2, 3, 4], dtype=np.int64)
+    h = C.c_void_p()
+    assert L.ks_operator_csr(ctx._h, 4, 4, 4, p.ctypes.data, bad_col.ctypes.data, val.ctypes.data, pkg._lib.KS_CSR, 0, pkg._lib.KS_I64, pkg._lib.KS_F64, C.byref(h)) == pkg._lib.KS_ERR_ARGUMENT

@@ -57,6 +57,9 @@ def cases():
 
     yield "lapvar216", lapvar, ("", "csr")
     yield "hashed1e6", lambda: M.hashed_nonsymmetric_csr(1_000_000, seed=7), ("csr", "sell")
+    yield "hashed2e5", lambda: M.hashed_nonsymmetric_csr(200_000, seed=7), ("csr",)
+    yield "hashed5e5", lambda: M.hashed_nonsymmetric_csr(500_000, seed=7), ("csr",)
+    yield "hashed2e6", lambda: M.hashed_nonsymmetric_csr(2_000_000, seed=7), ("csr",)
     yield "skew1e6", lambda: skewed(1_000_000), ("csr",)
     yield "cplx5e5", lambda: (M.to_scipy(*M.laplace1d_csr(500_000), 500_000) + 1j * sp.diags(0.3 * np.cos(np.arange(500_000)))).tocsr().astype(np.complex128), ("csr",)
     yield "hashed1e7", lambda: M.hashed_nonsymmetric_csr(10_000_000, seed=7), ("csr",)
