@@ -1574,9 +1574,12 @@ template <class D> void rotate_device(ks_workspace* ws, int c0, int c, int r) {
       const int ntile = (r + 15) / 16;
       const int nb = ctx->num_cu * 4;
       auto smem = [&](int KC) { return (size_t)ntile * 16 * (4 * KC + 1) * 8; };
-      if (c <= 24) ksd::k_rotate_mfma<6><<<nb, kBlock, smem(6), s>>>(Vc, ws->ld, c, r, Qd, c);
-      else if (c <= 40) ksd::k_rotate_mfma<10><<<nb, kBlock, smem(10), s>>>(Vc, ws->ld, c, r, Qd, c);
-      else ksd::k_rotate_mfma<16><<<nb, kBlock, smem(16), s>>>(Vc, ws->ld, c, r, Qd, c);
+      static const int rt = env_int("KS_ROTATE_RT", 2);
+      static const int nbm = env_int("KS_ROTATE_BPC", 4);
+      const int nbr = ctx->num_cu * nbm;
+      if (c <= 24) { if (rt == 2) ksd::k_rotate_mfma<6, 2><<<nbr, kBlock, smem(6), s>>>(Vc, ws->ld, c, r, Qd, c); else ksd::k_rotate_mfma<6, 1><<<nbr, kBlock, smem(6), s>>>(Vc, ws->ld, c, r, Qd, c); }
+      else if (c <= 40) { if (rt == 2) ksd::k_rotate_mfma<10, 2><<<nbr, kBlock, smem(10), s>>>(Vc, ws->ld, c, r, Qd, c); else ksd::k_rotate_mfma<10, 1><<<nbr, kBlock, smem(10), s>>>(Vc, ws->ld, c, r, Qd, c); }
+      else ksd::k_rotate_mfma<16, 1><<<nbr, kBlock, smem(16), s>>>(Vc, ws->ld, c, r, Qd, c);
       KS_HIP(hipGetLastError());
       return;
     }

@@ -1491,10 +1491,12 @@ __global__ void __launch_bounds__(kBlock)
 // ------------------------------------------------------------------------------------------------
 typedef double double4v __attribute__((ext_vector_type(4)));
 
-template <int KC>
+// RT = 32-row tiles a wave handles per trip (RT x KC 16-byte loads in flight per lane; RT = 2: 512 B instead of 256 B
+// contiguous per column and wave).
+template <int KC, int RT>
 __global__ void __launch_bounds__(kBlock)
     k_rotate_mfma(double* __restrict__ V, int64_t ldv, int c, int r, const double* __restrict__ Qd, int ldq) {
-  // Q^T tile in LDS: qs[k][n] with k < 4*KC (zero padded), n < NTmax*16 (zero padded); stride 4*KC+... keep simple
+  // Q^T tile in LDS: qs[n][k] with k < 4*KC (zero padded), n < ntile*16 (zero padded)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* qs = reinterpret_cast<double*>(smem_raw);  // [ncol16][4*KC] : qs[n * KP + k]
   constexpr int KP = 4 * KC + 1;                     // +1 pad: lanes of a 16-group read stride-KP -> conflict free
@@ -1509,28 +1511,38 @@ __global__ void __launch_bounds__(kBlock)
   const int wave = threadIdx.x >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int64_t nwt = ldv / 32;  // 32-row wave tiles (ldv is a multiple of 64)
-  for (int64_t wt = (int64_t)blockIdx.x * (kBlock / 64) + wave; wt < nwt; wt += (int64_t)gridDim.x * (kBlock / 64)) {
-    const int64_t row = wt * 32 + 2 * l15;
-    double2 b[KC];
+  const int64_t stride = (int64_t)gridDim.x * (kBlock / 64) * RT;
+  for (int64_t wt0 = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * RT; wt0 < nwt; wt0 += stride) {
+    double2 b[RT][KC];
+    int64_t row[RT];
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-      const int col = 4 * kc + l4;
-      const int c2 = col < c ? col : c - 1;  // padded k rows of Q are zero, value irrelevant
-      b[kc] = ld_pack_nt(V + (int64_t)c2 * ldv + row);
-    }
-    for (int nt = 0; nt < ntile; ++nt) {
-      double4v acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-      const double* qrow = qs + (nt * 16 + l15) * KP + l4;
+    for (int t = 0; t < RT; ++t) {
+      const int64_t wt = wt0 + t < nwt ? wt0 + t : nwt - 1;  // (ldv / 32 is even: with RT = 2 a trip never straddles the end)
+      row[t] = wt * 32 + 2 * l15;
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) {
-        const double a = qrow[4 * kc];
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[kc].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[kc].y, acc1, 0, 0, 0);
+        const int col = 4 * kc + l4;
+        const int c2 = col < c ? col : c - 1;  // padded k rows of Q are zero, value irrelevant
+        b[t][kc] = ld_pack_nt(V + (int64_t)c2 * ldv + row[t]);
       }
+    }
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int col = nt * 16 + l4 + 4 * v;
-        if (col < r) st_pack_nt(V + (int64_t)col * ldv + row, make_double2(acc0[v], acc1[v]));
+    for (int t = 0; t < RT; ++t) {
+      if (wt0 + t >= nwt) break;
+      for (int nt = 0; nt < ntile; ++nt) {
+        double4v acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        const double* qrow = qs + (nt * 16 + l15) * KP + l4;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+          const double a = qrow[4 * kc];
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[t][kc].x, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[t][kc].y, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int col = nt * 16 + l4 + 4 * v;
+          if (col < r) st_pack_nt(V + (int64_t)col * ldv + row[t], make_double2(acc0[v], acc1[v]));
+        }
       }
     }
   }
