@@ -10,6 +10,8 @@ from .api import (  # noqa: F401
     csr_operator, default_context, dense_operator, device_operator, host_operator, partialeigen, partialschur, partialschur_, vtype,
 )
 from . import matrices  # noqa: F401
+# `extras` (ready-made device operators on the callback seam; needs torch + rocSPARSE) is imported on demand:
+#     from arnoldimethod_jl_amd import extras
 
 __all__ = [
     "partialschur", "partialschur_", "partialeigen", "ArnoldiWorkspace", "PartialSchur", "History",

@@ -1,0 +1,85 @@
+"""Ready-made DEVICE operators built on the opaque-operator seam (`ks_operator_device_callback`, include/kschur.h;
+`mul!(y, A, x)` with a user-supplied `A`, src/expansion.jl:121).  These are USER-side operators -- the counterpart of
+the `LinearMap` a Julia user wraps around `ldiv!(factorize(A - sigma*I))` (docs/src/index.md:246-249, 273-287) -- not
+part of the library's hot path: they exist so that BASELINE config 4 (ComplexF64 shift-invert) can run with every
+vector resident in HBM instead of crossing PCIe twice per product.
+
+    TridiagonalShiftInvert(dl, d, du, sigma)   y = (T - sigma I)^{-1} x  with rocSPARSE's pivoting tridiagonal solver
+                                               (rocsparse_[dz]gtsv), on the library's stream.  torch is only plumbing
+                                               (device buffers for the three diagonals and the solver's work space).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import api
+
+
+def _rocsparse():
+    for path in ("/opt/rocm/lib/librocsparse.so", "librocsparse.so"):
+        try:
+            return C.CDLL(path)
+        except OSError:
+            continue
+    raise ImportError("librocsparse.so not found (the tridiagonal shift-invert operator needs rocSPARSE)")
+
+
+class TridiagonalShiftInvert:
+    """Builds `api.Operator` for y = (T - sigma I)^{-1} x, T tridiagonal with sub-/main/super-diagonals dl (n-1), d (n),
+    du (n-1).  The eigenvalues lambda of T closest to sigma are sigma + 1/theta for the largest-magnitude theta."""
+
+    def __init__(self, dl, d, du, sigma=0.0, ctx: api.Context | None = None):
+        import torch
+
+        self.ctx = ctx or api.default_context()
+        cplx = any(np.asarray(a).dtype.kind == "c" for a in (dl, d, du)) or isinstance(sigma, complex)
+        self.dtype = np.complex128 if cplx else np.float64
+        n = len(d)
+        self.n = n
+        dev = torch.device("cuda", self.ctx.device)
+        L = np.zeros(n, dtype=self.dtype)
+        L[1:] = dl                                    # rocSPARSE convention: dl[0] = 0, du[n-1] = 0, all of length n
+        U = np.zeros(n, dtype=self.dtype)
+        U[:-1] = du
+        D = np.asarray(d, dtype=self.dtype) - sigma
+        self._dl, self._d, self._du = (torch.as_tensor(a, device=dev) for a in (L, D, U))
+        self._lib = _rocsparse()
+        self._h = C.c_void_p()
+        self._check(self._lib.rocsparse_create_handle(C.byref(self._h)))
+        self._check(self._lib.rocsparse_set_stream(self._h, C.c_void_p(self.ctx.stream)))
+        pre = "z" if cplx else "d"
+        self._solve = getattr(self._lib, f"rocsparse_{pre}gtsv")
+        size = C.c_size_t(0)
+        probe = torch.zeros(n, dtype=torch.complex128 if cplx else torch.float64, device=dev)
+        self._check(getattr(self._lib, f"rocsparse_{pre}gtsv_buffer_size")(
+            self._h, C.c_int(n), C.c_int(1), C.c_void_p(self._dl.data_ptr()), C.c_void_p(self._d.data_ptr()),
+            C.c_void_p(self._du.data_ptr()), C.c_void_p(probe.data_ptr()), C.c_int(n), C.byref(size)))
+        self._buf = torch.empty(max(int(size.value), 16), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
+
+        def apply(y, x):          # called with two tensors aliasing columns of V, on the library's stream
+            y.copy_(x)
+            self._check(self._solve(self._h, C.c_int(n), C.c_int(1), C.c_void_p(self._dl.data_ptr()), C.c_void_p(self._d.data_ptr()),
+                                    C.c_void_p(self._du.data_ptr()), C.c_void_p(y.data_ptr()), C.c_int(n), C.c_void_p(self._buf.data_ptr())))
+
+        self.operator = api.device_operator(apply, n, self.dtype, self.ctx)
+        self.operator._owner = self      # the diagonals and the rocSPARSE handle live as long as the operator
+
+    @staticmethod
+    def _check(rc):
+        if rc != 0:
+            raise RuntimeError(f"rocSPARSE returned status {rc}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rocsparse_destroy_handle(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

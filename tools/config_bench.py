@@ -12,6 +12,8 @@ CONFIG
   cfg4    ComplexF64, n = 5*10^5, nev = 6, mindim/maxdim 10/20, :LM on a DEVICE-resident complex band operator: the
           device side of config 4 (all expansion kernels in ComplexF64) without the PCIe round trip of the host LU
   cfg4big the same at n = 5*10^6 (column = 80 MB: the ComplexF64 kernels outside the launch-bound regime)
+  cfg4d   config 4 with the shift-invert operator ON THE DEVICE: (A - sigma I)^{-1} x by rocSPARSE's pivoting tridiagonal
+          solver through the device-callback operator (arnoldimethod.jl_amd/extras.py); nothing n-sized crosses PCIe
   cfg4h   config 4 proper: shift-invert through an opaque HOST operator (scipy splu of the shifted tridiagonal matrix),
           every product staged over PCIe (docs/src/index.md:246-249)
 Prints ONE JSON line: iterations/s, per-class {launches, avg us, GB/s, frac of 8 TB/s}, moved-bytes figure of the
@@ -49,9 +51,16 @@ def build(config, ctx):
     prm = dict(nev=6, which="LM", mindim=10, maxdim=20)
     if config in ("cfg4", "cfg4big"):
         return ks.csr_operator(A, ctx), n, A.nnz, np.complex128, prm, f"complex tridiagonal n={n} (device-resident operator)"
+    sigma = 1.7 + 0.1j
+    if config == "cfg4d":
+        import torch  # noqa: F401 - must be loaded before the library touches the device (two HIP runtimes in one process)
+        from arnoldimethod_jl_amd import extras
+
+        T = A.tocsr()
+        si = extras.TridiagonalShiftInvert(T.diagonal(-1), T.diagonal(0), T.diagonal(1), sigma, ctx)
+        return si.operator, n, 0, np.complex128, prm, "shift-invert ON THE DEVICE (rocSPARSE zgtsv through the device-callback operator) n=5e5"
     import scipy.sparse.linalg as spla
 
-    sigma = 1.7 + 0.1j
     lu = spla.splu((A - sigma * sp.identity(n)).tocsc())
 
     def mul(y, x):
@@ -66,6 +75,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     args = ap.parse_args()
+    if args.config == "cfg4d":
+        import torch  # noqa: F401 - before the first HIP call of the library
     ctx = ks.Context(0)
     op, n, nnz, dtype, prm, what = build(args.config, ctx)
     esz = np.dtype(dtype).itemsize
