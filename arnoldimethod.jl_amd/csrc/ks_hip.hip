@@ -1068,6 +1068,8 @@ struct ks_workspace {
   bool colscale_dirty = false;  // hostscale changed on the host side: upload with the next batch's state
   void* Qd = nullptr;       // device, maxdim x maxdim
   void* Qstage = nullptr;   // pinned host
+  void* oop = nullptr;      // device, 2 x ld elements (zero pads): scratch vectors of the out-of-place updates
+  bool oop_full = false;    // the previous batch took the second DGKS pass in >= 90 % of its steps
   void* tmp = nullptr;      // device scratch, lazily sized
   size_t tmp_bytes = 0;
   void* tmp2 = nullptr;
@@ -1108,7 +1110,7 @@ struct ks_workspace {
     (void)hipFree(Vbase ? Vbase : V); (void)hipHostFree(H); (void)hipHostFree(Q); (void)hipFree(Hd); (void)hipHostFree(Hstage);
     (void)hipFree(Hscratch); (void)hipFree(partial); (void)hipFree(partial2); (void)hipFree(coef); (void)hipFree(red);
     (void)hipFree(scal); (void)hipHostFree(scal_h); (void)hipHostFree(coef_h);
-    (void)hipFree(Qd); (void)hipHostFree(Qstage); (void)hipFree(tmp); (void)hipFree(tmp2);
+    (void)hipFree(Qd); (void)hipHostFree(Qstage); (void)hipFree(tmp); (void)hipFree(tmp2); (void)hipFree(oop);
   }
 };
 
@@ -1229,34 +1231,34 @@ template <class D> void launch_fin_norm(ks_workspace* ws, int nbp, int j, D* Hsu
 // fused first projection + second-pass inner products (k_axpy_dots_cs, j <= 64); returns workgroups used.
 // NCW = ceil(j/4) columns per wave; U packs per lane and iteration: 4 up to NCW = 10, 2 above (register budget).
 constexpr int kFusedMaxJ = 64;
-template <class D, int NCW, int U, int WB> int launch_axpy_dots_nc(ks_workspace* ws, int j, D* w, int defer) {
+template <class D, int NCW, int U, int WB> int launch_axpy_dots_nc(ks_workspace* ws, int j, D* w, int defer, D* wdst = nullptr) {
   static int cache = -1;
   const int nb = cap_blocks(ws, resident_blocks(ws->ctx, ksd::k_axpy_dots_cs<D, NCW, U, WB>, 0, cache), 64 * U);
   ksd::k_axpy_dots_cs<D, NCW, U, WB><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const D*>(ws->V), ws->ld, j, w,
                                                                        static_cast<const D*>(ws->coef),
                                                                        static_cast<D*>(ws->partial), ws->pnb, ws->partial2,
-                                                                       ws->st, defer);
+                                                                       ws->st, defer, wdst);
   return nb;
 }
-template <class D> int launch_axpy_dots(ks_workspace* ws, int j, D* w, int defer) {
+template <class D> int launch_axpy_dots(ks_workspace* ws, int j, D* w, int defer, D* wdst = nullptr) {
   KS_REQUIRE(j >= 1 && j <= kFusedMaxJ, KS_ERR_INTERNAL, "fused projection kernel covers 1 <= j <= 64");
   switch ((j + 3) / 4) {
-    case 1: return launch_axpy_dots_nc<D, 1, 4, 8>(ws, j, w, defer);
-    case 2: return launch_axpy_dots_nc<D, 2, 4, 8>(ws, j, w, defer);
-    case 3: return launch_axpy_dots_nc<D, 3, 4, 8>(ws, j, w, defer);
-    case 4: return launch_axpy_dots_nc<D, 4, 4, 8>(ws, j, w, defer);
-    case 5: return launch_axpy_dots_nc<D, 5, 4, 8>(ws, j, w, defer);
-    case 6: return launch_axpy_dots_nc<D, 6, 4, 8>(ws, j, w, defer);
-    case 7: return launch_axpy_dots_nc<D, 7, 4, 8>(ws, j, w, defer);
-    case 8: return launch_axpy_dots_nc<D, 8, 4, 8>(ws, j, w, defer);
-    case 9: return launch_axpy_dots_nc<D, 9, 4, 8>(ws, j, w, defer);
-    case 10: return launch_axpy_dots_nc<D, 10, 4, 8>(ws, j, w, defer);
-    case 11: return launch_axpy_dots_nc<D, 11, 2, 8>(ws, j, w, defer);
-    case 12: return launch_axpy_dots_nc<D, 12, 2, 8>(ws, j, w, defer);
-    case 13: return launch_axpy_dots_nc<D, 13, 2, 8>(ws, j, w, defer);
-    case 14: return launch_axpy_dots_nc<D, 14, 2, 8>(ws, j, w, defer);
-    case 15: return launch_axpy_dots_nc<D, 15, 2, 8>(ws, j, w, defer);
-    default: return launch_axpy_dots_nc<D, 16, 2, 8>(ws, j, w, defer);
+    case 1: return launch_axpy_dots_nc<D, 1, 4, 8>(ws, j, w, defer, wdst);
+    case 2: return launch_axpy_dots_nc<D, 2, 4, 8>(ws, j, w, defer, wdst);
+    case 3: return launch_axpy_dots_nc<D, 3, 4, 8>(ws, j, w, defer, wdst);
+    case 4: return launch_axpy_dots_nc<D, 4, 4, 8>(ws, j, w, defer, wdst);
+    case 5: return launch_axpy_dots_nc<D, 5, 4, 8>(ws, j, w, defer, wdst);
+    case 6: return launch_axpy_dots_nc<D, 6, 4, 8>(ws, j, w, defer, wdst);
+    case 7: return launch_axpy_dots_nc<D, 7, 4, 8>(ws, j, w, defer, wdst);
+    case 8: return launch_axpy_dots_nc<D, 8, 4, 8>(ws, j, w, defer, wdst);
+    case 9: return launch_axpy_dots_nc<D, 9, 4, 8>(ws, j, w, defer, wdst);
+    case 10: return launch_axpy_dots_nc<D, 10, 4, 8>(ws, j, w, defer, wdst);
+    case 11: return launch_axpy_dots_nc<D, 11, 2, 8>(ws, j, w, defer, wdst);
+    case 12: return launch_axpy_dots_nc<D, 12, 2, 8>(ws, j, w, defer, wdst);
+    case 13: return launch_axpy_dots_nc<D, 13, 2, 8>(ws, j, w, defer, wdst);
+    case 14: return launch_axpy_dots_nc<D, 14, 2, 8>(ws, j, w, defer, wdst);
+    case 15: return launch_axpy_dots_nc<D, 15, 2, 8>(ws, j, w, defer, wdst);
+    default: return launch_axpy_dots_nc<D, 16, 2, 8>(ws, j, w, defer, wdst);
   }
 }
 
@@ -1340,15 +1342,30 @@ template <class D> void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op
   static const int no_fold = env_int("KS_P2P_NO_FOLD", 0);
   const bool p2p = cx->p2p.attached && !no_fold;
   const ksd::P2pDev pd = cx->p2p.dev;
+  // OUT-OF-PLACE updates (opt-in, KS_OOP=1).  The two kernels that update the new vector read and write the SAME addresses
+  // (w' = w - V h in place).  The same binary lands in a "slow" or a "fast" mode from process to process (k_axpy_dots_cs
+  // 5.35 vs 5.77 TB/s, 678 vs 702 iterations/s: the physical placement of the basis, round 1's "placement lottery"), and
+  // the slow mode is slow only for in-place read-modify-write streams.  With KS_OOP=1 the product y = A v goes into
+  // scratch vector S0 instead of column j, the first projection reads S0 and writes column j, and -- while the second
+  // DGKS pass is the rule (>= 90 % of the steps of the previous batch took it) -- it writes scratch S1 instead and the
+  // second-pass update reads S1 and writes column j (a step that then does NOT take the second pass just moves S1 home).
+  // Pure data movement: H, V and every decision are bit-identical (tested).  Measured (profiles/r02_out_of_place_ab.txt):
+  // 685-687 iterations/s in BOTH modes (dominant kernel 0.70 of spec either way) against 678 / 702 in place -- it removes
+  // the lottery, not the average (the SpMV loses the warm x the in-place update used to leave in the memory-side cache:
+  // 42 -> 53 us), so the default stays in place.  `op == nullptr` (ks_orthogonalize) always runs in place.
+  D* S0 = (op && ws->oop) ? static_cast<D*>(ws->oop) : nullptr;
+  D* S1 = (S0 && ws->oop_full) ? S0 + ws->ld : nullptr;
   for (int j = from; j <= to; ++j) {
     D* w = static_cast<D*>(ws->col(j));
+    D* y = S0 ? S0 : w;           // where the product lands and what the inner products / first projection read
+    D* w1 = S1 ? S1 : w;          // where the first projection writes (and the second-pass update reads)
     D* Hcol = Hd + (size_t)(j - 1) * ldh;
     D* Hsub_prev = (j >= 2) ? Hd + (size_t)(j - 2) * ldh + (j - 1) : Hcol;  // only touched when a norm is pending
-    if (op) op->apply(ws->col(j - 1), w, ws->st);
+    if (op) op->apply(ws->col(j - 1), y, ws->st);
     int nbd;
     {
       ProfScope ps(cx, KSP_DOTS, nb8 * (j + 1));
-      nbd = launch_dots<D>(ws, j, w, 1, ws->st);
+      nbd = launch_dots<D>(ws, j, y, 1, ws->st);
     }
     {
       ProfScope ps(cx, KSP_FIN, 0.0);
@@ -1363,7 +1380,7 @@ template <class D> void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op
     int nbf;
     {
       ProfScope ps(cx, KSP_FUSED, nb8 * (j + 2));  // reads V[:,0:j) and y, writes w'
-      nbf = launch_axpy_dots<D>(ws, j, w, 1);
+      nbf = launch_axpy_dots<D>(ws, j, y, 1, w1 == y ? nullptr : w1);
     }
     {
       ProfScope ps(cx, KSP_FIN, 0.0);
@@ -1380,8 +1397,11 @@ template <class D> void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op
       // packs per lane per iteration: at n = 1e7 going 2 -> 4 -> 8 gained 3 % + 8 % (16 lost 18 %); small
       // problems (<= 3072 packs per workgroup) are ~1 % better off with 4
       const int64_t ppb = (ws->ld * (int64_t)sizeof(D) / 16) / std::max(1, ws->nb);
-      if (ppb >= 3072) ksd::k_axpy<D, 8><<<ws->nb, kBlock, 0, s>>>(V, ws->ld, j, w, coef, ws->partial2, 2, ws->st);
-      else ksd::k_axpy<D, 4><<<ws->nb, kBlock, 0, s>>>(V, ws->ld, j, w, coef, ws->partial2, 2, ws->st);
+      const D* src = w1 == w ? nullptr : w1;
+      static const int plain_st = env_int("KS_OOP_PLAIN_STORE", 0);
+      if (src && plain_st && ppb >= 3072) ksd::k_axpy<D, 8, true><<<ws->nb, kBlock, 0, s>>>(V, ws->ld, j, w, coef, ws->partial2, 2, ws->st, src);
+      else if (ppb >= 3072) ksd::k_axpy<D, 8><<<ws->nb, kBlock, 0, s>>>(V, ws->ld, j, w, coef, ws->partial2, 2, ws->st, src);
+      else ksd::k_axpy<D, 4><<<ws->nb, kBlock, 0, s>>>(V, ws->ld, j, w, coef, ws->partial2, 2, ws->st, src);
     }
     if (j == to) {  // settle the norm of the last column (it stays unnormalised in HBM: colscale)
       {
@@ -1690,6 +1710,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
       fetch_H_columns<T>(ws, j0, last_done, H, lazy);
       stats.steps += last_done - j0 + 1;
       stats.reorth += ws->st_h->n_reorth;
+      if (lazy && jend > j0) ws->oop_full = 10 * ws->st_h->n_reorth >= 9 * (last_done - j0 + 1);  // (batches of one step keep the setting)
       if (bd >= 0) {
         // orthogonalize! returned false at step bd: H[bd, bd-1] = 0 is already in place
         // (src/expansion.jl:99-102); draw a fresh vector unless bd == n (src/expansion.jl:127-129)
@@ -2356,6 +2377,10 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     KS_HIP(hipHostMalloc(&w->scal_h, 64));
     KS_HIP(hipHostMalloc(&w->coef_h, (size_t)w->pstride * esz));
     KS_HIP(hipMalloc(&w->Qd, std::max<size_t>(qbytes, 16)));
+    if (env_int("KS_OOP", 0)) {
+      KS_HIP(hipMalloc(&w->oop, (size_t)2 * w->ld * esz));
+      KS_HIP(hipMemsetAsync(w->oop, 0, (size_t)2 * w->ld * esz, ctx->stream));
+    }
     w->hostscale.assign(maxdim + 2, 1.0);
     w->ones.assign(maxdim + 2, 1.0);
     w->colscale_dirty = true;  // first reset_state uploads the (all-one) factors

@@ -849,9 +849,9 @@ __device__ __forceinline__ void axpy_tail(typename Pack<T>::type (&s)[U], const 
 }
 
 // U packs (rows r[0..U)) of  w -= V[:, jb:jb+jc) g ; returns sum |w_new|^2 of those packs
-template <class T, int U>
+template <class T, int U, bool PLAIN = false>
 __device__ __forceinline__ double axpy_body(const T* __restrict__ V, int64_t ldv, int jb, int jc, T* __restrict__ w,
-                                            const T* g, const int64_t (&r)[U]) {
+                                            const T* g, const int64_t (&r)[U], const T* __restrict__ wsrc) {
   using P = typename Pack<T>::type;
   P s[U];
 #pragma unroll
@@ -877,23 +877,30 @@ __device__ __forceinline__ double axpy_body(const T* __restrict__ V, int64_t ldv
   double nrm = 0.0;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    P wv = ld_pack(w + r[u]);
+    P wv = ld_pack(wsrc + r[u]);
     wv = sub_pack(wv, s[u]);
-    st_pack_nt(w + r[u], wv);
+    if (PLAIN) st_pack(w + r[u], wv); else st_pack_nt(w + r[u], wv);
     nrm += nrm2_pack(wv);
   }
   return nrm;
 }
 
-template <class T, int U = 4>
+template <class T, int U = 4, bool PLAIN = false>
 __global__ void __launch_bounds__(kBlock)
     k_axpy(const T* __restrict__ V, int64_t ldv, int j, T* __restrict__ w, const T* __restrict__ coef,
-           double* __restrict__ partial2, int pass, const DevState* __restrict__ st) {
+           double* __restrict__ partial2, int pass, const DevState* __restrict__ st, const T* __restrict__ wsrc0 = nullptr) {
+  constexpr int R = Pack<T>::R;
   if (st) {
     if (st->breakdown >= 0) return;
-    if (pass == 2 && !st->reorth) return;
+    if (pass == 2 && !st->reorth) {
+      if (wsrc0) {  // out-of-place mode: the first projection left w' in the scratch vector -- move it home
+        int64_t pb0, pe0;
+        block_range(ldv / R, blockIdx.x, gridDim.x, pb0, pe0);
+        for (int64_t p = pb0 + threadIdx.x; p < pe0; p += kBlock) st_pack_nt(w + p * R, ld_pack(wsrc0 + p * R));
+      }
+      return;
+    }
   }
-  constexpr int R = Pack<T>::R;
   // U packs per lane per iteration: U x 4 KiB contiguous per column and workgroup
   __shared__ T g[128];
   __shared__ double red[kBlock / 64];
@@ -911,12 +918,12 @@ __global__ void __launch_bounds__(kBlock)
       int64_t r[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) r[u] = (p + (int64_t)u * kBlock) * R;
-      const double t = axpy_body<T, U>(V, ldv, jb, jc, w, g, r);
+      const double t = axpy_body<T, U, PLAIN>(V, ldv, jb, jc, w, g, r, (wsrc0 && jb == 0) ? wsrc0 : w);
       if (last) nrm += t;
     }
     for (; p < pe; p += kBlock) {  // remainder, one pack at a time
       const int64_t r1[1] = {p * R};
-      const double t = axpy_body<T, 1>(V, ldv, jb, jc, w, g, r1);
+      const double t = axpy_body<T, 1, PLAIN>(V, ldv, jb, jc, w, g, r1, (wsrc0 && jb == 0) ? wsrc0 : w);
       if (last) nrm += t;
     }
   }
@@ -965,8 +972,9 @@ template <class T, int NCW, int U, int WB>
 __global__ void __launch_bounds__(kBlock)
     k_axpy_dots_cs(const T* __restrict__ V, int64_t ldv, int j, T* __restrict__ w, const T* __restrict__ coef,
                    T* __restrict__ partial, int pnb, double* __restrict__ partial2, const DevState* __restrict__ st,
-                   int defer) {
+                   int defer, T* __restrict__ wdst0 = nullptr) {
   if (st && st->breakdown >= 0) return;
+  T* __restrict__ wdst = wdst0 ? wdst0 : w;
   using P = typename Pack<T>::type;
   constexpr int R = Pack<T>::R;
   // lazy normalisation: y (= w on entry) = A * (unnormalised column j-1) carries the factor beta_{j-1}
@@ -1030,7 +1038,7 @@ __global__ void __launch_bounds__(kBlock)
       if (!ok[u]) wn = zero_pack(T{});
       if (wave == 0 && ok[u]) {
         if constexpr (WB > 1) wout[((it % WB) * U + u) * 64 + lane] = wn;
-        else st_pack_nt(w + r[u], wn);
+        else st_pack_nt(wdst + r[u], wn);
         nrm += nrm2_pack(wn);
       }
 #pragma unroll
@@ -1042,7 +1050,7 @@ __global__ void __launch_bounds__(kBlock)
         __syncthreads();
         const int64_t fb = base - (int64_t)(it % WB) * 64 * U;  // first pack staged
         const int64_t fe = (base + 64 * U < pe) ? base + 64 * U : pe;
-        for (int64_t o = fb + threadIdx.x; o < fe; o += kBlock) st_pack_nt(w + o * R, wout[o - fb]);
+        for (int64_t o = fb + threadIdx.x; o < fe; o += kBlock) st_pack_nt(wdst + o * R, wout[o - fb]);
       }
     }
   }
