@@ -1070,6 +1070,7 @@ struct ks_workspace {
   void* Qstage = nullptr;   // pinned host
   void* oop = nullptr;      // device, 2 x ld elements (zero pads): scratch vectors of the out-of-place updates
   bool oop_full = false;    // the previous batch took the second DGKS pass in >= 90 % of its steps
+  int oop_mode = 2;         // KS_OOP at creation: 0 in place, 2 scratch product (default), 1 both projections out of place
   void* tmp = nullptr;      // device scratch, lazily sized
   size_t tmp_bytes = 0;
   void* tmp2 = nullptr;
@@ -1342,19 +1343,22 @@ template <class D> void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op
   static const int no_fold = env_int("KS_P2P_NO_FOLD", 0);
   const bool p2p = cx->p2p.attached && !no_fold;
   const ksd::P2pDev pd = cx->p2p.dev;
-  // OUT-OF-PLACE updates (opt-in, KS_OOP=1).  The two kernels that update the new vector read and write the SAME addresses
-  // (w' = w - V h in place).  The same binary lands in a "slow" or a "fast" mode from process to process (k_axpy_dots_cs
-  // 5.35 vs 5.77 TB/s, 678 vs 702 iterations/s: the physical placement of the basis, round 1's "placement lottery"), and
-  // the slow mode is slow only for in-place read-modify-write streams.  With KS_OOP=1 the product y = A v goes into
-  // scratch vector S0 instead of column j, the first projection reads S0 and writes column j, and -- while the second
-  // DGKS pass is the rule (>= 90 % of the steps of the previous batch took it) -- it writes scratch S1 instead and the
-  // second-pass update reads S1 and writes column j (a step that then does NOT take the second pass just moves S1 home).
-  // Pure data movement: H, V and every decision are bit-identical (tested).  Measured (profiles/r02_out_of_place_ab.txt):
-  // 685-687 iterations/s in BOTH modes (dominant kernel 0.70 of spec either way) against 678 / 702 in place -- it removes
-  // the lottery, not the average (the SpMV loses the warm x the in-place update used to leave in the memory-side cache:
-  // 42 -> 53 us), so the default stays in place.  `op == nullptr` (ks_orthogonalize) always runs in place.
+  // OUT-OF-PLACE first projection (KS_OOP, read at workspace creation).  The two kernels that update the new vector used
+  // to read and write the SAME addresses (w' = w - V h in place).  The same binary lands in a "slow" or a "fast" mode from
+  // process to process (k_axpy_dots_cs 5.35 vs 5.77 TB/s, 678 vs 702 iterations/s: the physical placement of the basis,
+  // round 1's "placement lottery"), and the slow mode is slow only for in-place read-modify-write streams.
+  //   KS_OOP=2 (default): the product y = A v goes into a scratch vector S0 instead of column j; the inner products and
+  //              the first projection read S0, the projection WRITES column j; the second-pass update stays in place.
+  //              One extra n-vector, no data-dependent behaviour.  Slow mode 678 -> 684-685, fast mode within 1 %.
+  //   KS_OOP=1:  additionally, while the second DGKS pass is the rule (>= 90 % of the steps of the previous batch), the
+  //              projection writes a second scratch vector S1 and the second-pass update reads S1 and writes column j (a
+  //              step that then does NOT take the second pass moves S1 home).  Same speed as 2 on the headline; the
+  //              SpMV loses the warm x the in-place update leaves in the memory-side cache (42 -> 53 us).
+  //   KS_OOP=0:  everything in place (round 1).
+  // Pure data movement: H, V and every decision are bit-identical in all forms (tested).  `op == nullptr`
+  // (ks_orthogonalize: the vector already sits in column j) always runs in place.  profiles/r02_out_of_place_ab.txt.
   D* S0 = (op && ws->oop) ? static_cast<D*>(ws->oop) : nullptr;
-  D* S1 = (S0 && ws->oop_full) ? S0 + ws->ld : nullptr;
+  D* S1 = (S0 && ws->oop_full && ws->oop_mode == 1) ? S0 + ws->ld : nullptr;
   for (int j = from; j <= to; ++j) {
     D* w = static_cast<D*>(ws->col(j));
     D* y = S0 ? S0 : w;           // where the product lands and what the inner products / first projection read
@@ -2377,9 +2381,11 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     KS_HIP(hipHostMalloc(&w->scal_h, 64));
     KS_HIP(hipHostMalloc(&w->coef_h, (size_t)w->pstride * esz));
     KS_HIP(hipMalloc(&w->Qd, std::max<size_t>(qbytes, 16)));
-    if (env_int("KS_OOP", 0)) {
-      KS_HIP(hipMalloc(&w->oop, (size_t)2 * w->ld * esz));
-      KS_HIP(hipMemsetAsync(w->oop, 0, (size_t)2 * w->ld * esz, ctx->stream));
+    w->oop_mode = env_int("KS_OOP", 2);
+    if (w->oop_mode == 1 || w->oop_mode == 2) {
+      const size_t ob = (size_t)(w->oop_mode == 1 ? 2 : 1) * w->ld * esz;
+      KS_HIP(hipMalloc(&w->oop, ob));
+      KS_HIP(hipMemsetAsync(w->oop, 0, ob, ctx->stream));
     }
     w->hostscale.assign(maxdim + 2, 1.0);
     w->ones.assign(maxdim + 2, 1.0);

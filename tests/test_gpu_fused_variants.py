@@ -270,12 +270,13 @@ def rnd_c(rng, n):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_out_of_place_update_mode_is_bit_identical(dtype, monkeypatch):
-    """KS_OOP=1 (product into a scratch vector, projections out of place) is pure data movement: H and V of an expansion
+    """KS_OOP=2 (default: product into a scratch vector, first projection out of place) and KS_OOP=1 (both projections out
+    of place) are pure data movement: H and V of an expansion
     with and without second passes, and a whole solve, must equal the in-place run BIT for bit."""
     A, n = _operator(dtype, (11, 12, 13))
     v1 = _start(dtype, n, seed=21)
     out = {}
-    for mode in ("0", "1"):
+    for mode in ("0", "1", "2"):
         monkeypatch.setenv("KS_OOP", mode)
         op = pkg.csr_operator(A)
         ws = pkg.ArnoldiWorkspace(n, 30, dtype, ctx=op.ctx)
@@ -285,14 +286,15 @@ def test_out_of_place_update_mode_is_bit_identical(dtype, monkeypatch):
         H, V = np.array(ws.H), ws.V
         dec, hist = pkg.partialschur(A, v1=v1, nev=4, which="LM" if np.dtype(dtype).kind == "c" else "SR", tol=1e-10, maxdim=24)
         out[mode] = (st1, st2, H, V, hist.mvproducts, dec.eigenvalues.copy())
-    a, b = out["0"], out["1"]
-    assert a[0] == b[0] and a[1] == b[1] and a[4] == b[4]
-    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[5], b[5])
+    for m2 in ("1", "2"):
+        a, b = out["0"], out[m2]
+        assert a[0] == b[0] and a[1] == b[1] and a[4] == b[4]
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[5], b[5])
     # a matrix that never takes the second pass (S1 is moved home by the update kernel when the rule was armed by a previous batch)
     rng = np.random.default_rng(2)
     B = (sp.random(n, n, density=5.0 / n, random_state=rng, format="csr") + 0 * sp.identity(n)).tocsr().astype(dtype)
     res = {}
-    for mode in ("0", "1"):
+    for mode in ("0", "1", "2"):
         monkeypatch.setenv("KS_OOP", mode)
         ws = pkg.ArnoldiWorkspace(n, 20, dtype)
         opA, opB = pkg.csr_operator(A, ws.ctx), pkg.csr_operator(B, ws.ctx)
@@ -300,5 +302,6 @@ def test_out_of_place_update_mode_is_bit_identical(dtype, monkeypatch):
         ws.iterate_arnoldi(opA, 1, 8)           # arms the rule (every step re-orthogonalises)
         s2 = ws.iterate_arnoldi(opB, 9, 20)     # random sparse operator: (almost) no second passes
         res[mode] = (s2, np.array(ws.H), ws.V)
-    assert res["0"][0] == res["1"][0] and np.array_equal(res["0"][1], res["1"][1]) and np.array_equal(res["0"][2], res["1"][2])
+    for m2 in ("1", "2"):
+        assert res["0"][0] == res[m2][0] and np.array_equal(res["0"][1], res[m2][1]) and np.array_equal(res["0"][2], res[m2][2])
     assert res["1"][0]["reorth"] < 6
