@@ -118,6 +118,7 @@ PROTOTYPES = {
     "ks_params_default": [i64, P(ks_params)],
     "ks_partialschur": [vp, vp, P(ks_params), vp, vp, P(ks_history)],
     "ks_restart": [vp, P(ks_params), i32, P(C.c_int), P(C.c_int), P(C.c_int), vp, vp, vp],
+    "ks_expand_restart": [vp, vp, P(ks_params), i32, i32, P(C.c_int), P(C.c_int), P(C.c_int), vp, vp, vp, P(ks_expand_stats), vp],
     "ks_profile_enable": [vp, i32],
     "ks_profile_reset": [vp],
     "ks_profile_get": [vp, i32, vp, vp, vp],

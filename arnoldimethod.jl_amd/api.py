@@ -522,6 +522,24 @@ class ArnoldiWorkspace:
         return dict(k=k.value, nlock=nlock.value, purge=purge.value, eigenvalues=lams[0::2] + 1j * lams[1::2],
                     residuals=rs, groups=groups)
 
+    def expand_restart(self, A: Operator, k: int, active: int, nev: int, which="LM", tol=None, mindim=None, maxdim=None):
+        """One whole cycle of `_partialschur`'s loop (src/run.jl:272-365): iterate_arnoldi!(k+1 : maxdim) and the restart in
+        ONE library call, the early part of the restart's host work overlapped with the tail of the expansion (what
+        `partialschur` does internally; bit-identical to iterate_arnoldi + restart).  `k` = basis size the previous restart
+        left.  Returns restart()'s dict plus steps / reorth / breakdowns and seconds = (expansion, host, rotation enqueue)."""
+        maxdim = self.maxdim if maxdim is None else maxdim
+        mindim = min(max(10, nev), self.n_global) if mindim is None else mindim
+        tol = math.sqrt(EPS) if tol is None else tol
+        p = _lib.ks_params(nev, _which_code(which), float(tol), mindim, maxdim, 1, 1, 0, 0)
+        ko, nlock, purge = C.c_int(), C.c_int(), C.c_int()
+        lams, rs, groups = np.zeros(2 * maxdim), np.zeros(maxdim), np.zeros(maxdim, dtype=np.int32)
+        st = _lib.ks_expand_stats()
+        sec = np.zeros(3)
+        _check_op(_lib.load().ks_expand_restart(A._h, self._h, C.byref(p), active, k, C.byref(ko), C.byref(nlock), C.byref(purge),
+                                                lams.ctypes.data, rs.ctypes.data, groups.ctypes.data, C.byref(st), sec.ctypes.data), A)
+        return dict(k=ko.value, nlock=nlock.value, purge=purge.value, eigenvalues=lams[0::2] + 1j * lams[1::2], residuals=rs,
+                    groups=groups, steps=st.steps, reorth=st.reorth, breakdowns=st.breakdowns, seconds=tuple(sec))
+
     def residual_norms(self, A: Operator, ncols: int):
         r, o = C.c_double(), C.c_double()
         _check_op(_lib.load().ks_residual_norms(A._h, self._h, ncols, C.byref(r), C.byref(o)), A)

@@ -15,6 +15,7 @@
 
 #include <chrono>
 #include <cstring>
+#include <functional>
 
 #include "ks_smalldense.hpp"
 
@@ -31,6 +32,16 @@ template <class T> struct Backend {
   virtual int64_t n_global() const = 0;
   // iterate_arnoldi!(A, arnoldi, from:to)  src/expansion.jl:116-133; fills H[0..j, j-1] for each step.
   virtual void iterate_arnoldi(int from, int to, const Mat<T>& H, ExpandStats& st) = 0;
+  // The same, for the expansion a restart follows (to == maxdim).  H[0:to, 0:to) is final BEFORE the step's last pass over
+  // V and the reduction of H[to, to-1] have run; a backend that can tell may call `early` at that point -- with
+  // H[0:to, 0:to) in place and H[to, to-1] still undefined -- so that the part of the restart's host work that does not
+  // need H[to, to-1] (restart_host_early) runs while the device finishes.  Returns true iff `early` was called and its
+  // effects on H stand (a backend that has to withdraw -- breakdown inside the batch -- restores H and returns false).
+  virtual bool iterate_arnoldi_early(int from, int to, const Mat<T>& H, ExpandStats& st, const std::function<void()>& early) {
+    (void)early;
+    iterate_arnoldi(from, to, H, st);
+    return false;
+  }
   // reinitialize!(arnoldi, j, populate!)  src/expansion.jl:12-59.  v1 == nullptr -> rand!.
   virtual bool reinitialize(int j, const T* v1_host) = 0;
   // V[:, c0:c0+r) <- V[:, c0:c0+c) * Q[c0:c0+c, c0:c0+r)   (src/run.jl:363-364, :382-383); Q host.
@@ -63,9 +74,11 @@ template <class T> struct RestartScratch {
   std::vector<cplx> x, lams;
   std::vector<double> rs;
   std::vector<int> ord, groups;
+  std::vector<cplx> rdot;  // restart_host_early -> restart_host_late: last component of each Ritz vector (unit residual)
+  double fro2 = 0.0;       // sum |H[i,j]|^2 without the entry H[maxdim, maxdim-1]
   Reflector<T> G;
   explicit RestartScratch(int maxdim)
-      : x(maxdim), lams(maxdim), rs(maxdim), ord(maxdim), groups(maxdim, 0), G(maxdim) {}
+      : x(maxdim), lams(maxdim), rs(maxdim), ord(maxdim), groups(maxdim, 0), rdot(maxdim), G(maxdim) {}
 };
 
 struct RestartResult {
@@ -91,10 +104,14 @@ inline double g_stage_s[8] = {};
 #endif
 
 // One restart's host work: src/run.jl:278-360.  `active` 0-based.  H is the full (maxdim+1) x maxdim
-// array, Q is maxdim x maxdim.
+// array, Q is maxdim x maxdim.  Split in two so that a backend can overlap the first part with the tail of the
+// expansion (Backend::iterate_arnoldi_early): restart_host_early touches H[0:maxdim, :] only, restart_host_late is
+// the first to read H[maxdim, maxdim-1].  early + late performs the reference's operations in the reference's order
+// on every quantity (the residual |x . h_last| is formed from the stored dot product, the Frobenius sum gets its
+// last term last), so the split is invisible in the results.
 template <class T>
-inline RestartResult restart_host_step(const Mat<T>& H, const Mat<T>& Q, int maxdim, int mindim, int nev,
-                                       const Ordering& ordering, double tol, int active, RestartScratch<T>& s) {
+inline void restart_host_early(const Mat<T>& H, const Mat<T>& Q, int maxdim, const Ordering& ordering, int active,
+                               RestartScratch<T>& s) {
 #ifdef KS_TIME_STAGES
   double t0__ = now_s();
 #endif
@@ -106,13 +123,25 @@ inline RestartResult restart_host_step(const Mat<T>& H, const Mat<T>& Q, int max
   KS_STAGE(0, t0__);
   for (int i = 0; i < maxdim; ++i) s.ord[i] = i;                       // :284
   copy_eigenvalues(s.lams.data(), H, 0, maxdim - 1);                   // :285
-  copy_residuals(s.rs.data(), H, Q, H(maxdim, maxdim - 1), s.x.data(), active, maxdim - 1);  // :286
+  residual_dots(s.rdot.data(), H, Q, s.x.data(), active, maxdim - 1);  // :286, up to the factor H[maxdim, maxdim-1]
   KS_STAGE(1, t0__);
   sort_perm(s.ord.data(), maxdim, s.lams.data(), ordering);            // :289
-  double fro = 0.0;                                                    // :292 norm(H), whole array
-  for (int j = 0; j < H.n; ++j)
-    for (int i = 0; i < H.m; ++i) fro += abs2_(H(i, j));
-  fro = std::sqrt(fro);
+  double fro2 = 0.0;                                                   // :292 norm(H), whole array, column-major order:
+  for (int j = 0; j < H.n; ++j)                                        // the entry H[maxdim, maxdim-1] is the LAST term
+    for (int i = 0; i < H.m; ++i)
+      if (!(i == H.m - 1 && j == H.n - 1)) fro2 += abs2_(H(i, j));
+  s.fro2 = fro2;
+  KS_STAGE(2, t0__);
+}
+
+template <class T>
+inline RestartResult restart_host_late(const Mat<T>& H, const Mat<T>& Q, int maxdim, int mindim, int nev, double tol,
+                                       int active, RestartScratch<T>& s) {
+#ifdef KS_TIME_STAGES
+  double t0__ = now_s();
+#endif
+  finish_residuals(s.rs.data(), s.rdot.data(), H(maxdim, maxdim - 1), H.n, active, maxdim - 1);  // :286
+  const double fro = std::sqrt(s.fro2 + abs2_(H(H.m - 1, H.n - 1)));
   auto isconverged = [&](int i) {                                      // :206-208
     return s.rs[i] <= std::max(kEps * fro, tol * std::abs(s.lams[i]));
   };
@@ -144,6 +173,13 @@ inline RestartResult restart_host_step(const Mat<T>& H, const Mat<T>& Q, int max
   return RestartResult{k, nlock, purge, effective_nev};
 }
 
+template <class T>
+inline RestartResult restart_host_step(const Mat<T>& H, const Mat<T>& Q, int maxdim, int mindim, int nev,
+                                       const Ordering& ordering, double tol, int active, RestartScratch<T>& s) {
+  restart_host_early(H, Q, maxdim, ordering, active, s);
+  return restart_host_late(H, Q, maxdim, mindim, nev, tol, active, s);
+}
+
 // _partialschur, src/run.jl:224-392.  H: (maxdim+1) x maxdim host, Q: maxdim x maxdim host.
 // eigenvalues: out, at least maxdim entries.  `active` 0-based (= start_from - 1).
 template <class T>
@@ -164,13 +200,15 @@ inline History partialschur_driver(Backend<T>& be, const Mat<T>& H, const Mat<T>
 
   for (int iter = 0; iter < p.restarts; ++iter) {
     t0 = now_s();
-    be.iterate_arnoldi(k + 1, maxdim, H, st);  // :272
-    hist.seconds_expand += now_s() - t0;
+    const bool early_done = be.iterate_arnoldi_early(k + 1, maxdim, H, st,                                   // :272
+                                                     [&] { restart_host_early(H, Q, maxdim, ordering, active, scratch); });
+    hist.seconds_expand += now_s() - t0;  // (includes whatever of the early host part the device did not hide)
     prods += std::max(0, maxdim - k);          // :275
     hist.restarts++;
 
     t0 = now_s();
-    const RestartResult r = restart_host_step(H, Q, maxdim, mindim, nev, ordering, p.tol, active, scratch);
+    if (!early_done) restart_host_early(H, Q, maxdim, ordering, active, scratch);
+    const RestartResult r = restart_host_late(H, Q, maxdim, mindim, nev, p.tol, active, scratch);
     hist.seconds_host += now_s() - t0;
     k = r.k;
 

@@ -1066,6 +1066,18 @@ struct ks_workspace {
   DevState* st_h = nullptr; // pinned host, inside the Hstage allocation
   double* cs_h = nullptr;   // pinned host image of colscale, inside the Hstage allocation
   bool colscale_dirty = false;  // hostscale changed on the host side: upload with the next batch's state
+  // early hand-over of H at the end of the expansion a restart follows (HipBackend::iterate_arnoldi_early): a second
+  // pinned image of [ Hd | DevState ], published by the device right after the last step's k_fin_mid_def
+  void* Hstage_early = nullptr;
+  std::vector<char> Hbackup;    // host H before the early part of the restart step touched it
+  // MAILBOX: the device publishes [ H columns | DevState ] into the pinned images itself (k_publish) and releases a
+  // sequence number; the host spins on it.  mbox[0]: early hand-over, mbox[8]: end of the batch (64 bytes apart).
+  uint64_t* mbox = nullptr;     // pinned host
+  uint64_t* mbox_dev = nullptr; // the same memory through its device pointer
+  void* Hstage_dev = nullptr;   // device pointers of the pinned images
+  void* Hstage_early_dev = nullptr;
+  uint64_t mbox_seq = 0;
+  bool use_mbox = true;         // KS_MAILBOX (read at creation); 0: hipMemcpyAsync + hipStreamSynchronize
   void* Qd = nullptr;       // device, maxdim x maxdim
   void* Qstage = nullptr;   // pinned host
   void* oop = nullptr;      // device, 2 x ld elements (zero pads): scratch vectors of the out-of-place updates
@@ -1112,6 +1124,7 @@ struct ks_workspace {
     (void)hipFree(Hscratch); (void)hipFree(partial); (void)hipFree(partial2); (void)hipFree(coef); (void)hipFree(red);
     (void)hipFree(scal); (void)hipHostFree(scal_h); (void)hipHostFree(coef_h);
     (void)hipFree(Qd); (void)hipHostFree(Qstage); (void)hipFree(tmp); (void)hipFree(tmp2); (void)hipFree(oop);
+    (void)hipHostFree(Hstage_early); (void)hipHostFree(mbox);
   }
 };
 
@@ -1321,11 +1334,40 @@ inline void materialize(ks_workspace* ws) {
   reset_lazy(ws);
 }
 
+// MAILBOX (ks_workspace::mbox).  publish_control: the H columns of steps from.. and the DevState go to the pinned image
+// `image_dev` by a one-workgroup kernel that then releases `seq` in flag slot `slot`; mbox_wait: the host spins on it.
+// Replaces hipMemcpyAsync + hipStreamSynchronize around every expansion batch: the copy cost ~100 us of host enqueue
+// time when issued in mid-stream and stalled the submission of what followed; the synchronisation woke the host
+// 15-20 us after the fact (profiles/r02_restart_bubble.txt).
+inline void publish_control(ks_workspace* ws, int from, void* image_dev, int slot, uint64_t seq) {
+  const size_t off = from >= 1 ? (size_t)(from - 1) * (ws->maxdim + 1) * ws->esz : ws->hd_bytes;
+  const int nwords = (int)((ws->hd_bytes + sizeof(DevState) - off) / 8);
+  ksd::k_publish<<<1, kBlock, 0, ws->ctx->stream>>>(reinterpret_cast<const uint64_t*>(static_cast<const char*>(ws->Hd) + off),
+                                                     reinterpret_cast<uint64_t*>(static_cast<char*>(image_dev) + off), nwords,
+                                                     ws->mbox_dev + 8 * slot, seq);
+  KS_HIP(hipGetLastError());
+}
+inline void mbox_wait(ks_workspace* ws, int slot, uint64_t seq) {
+  const uint64_t* f = ws->mbox + 8 * slot;
+  unsigned spins = 0;
+  while (__atomic_load_n(f, __ATOMIC_ACQUIRE) != seq) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xFFFu) == 0) {  // every ~50 us: is the stream still alive?
+      const hipError_t q = hipStreamQuery(ws->ctx->stream);
+      if (q == hipSuccess) {
+        if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == seq) break;
+        throw KsError{KS_ERR_HIP, "the stream drained without publishing the control block"};
+      }
+      if (q != hipErrorNotReady) KS_HIP(q);
+    }
+  }
+}
+
 // Fused expansion steps from..to with LAZY NORMALISATION (see ks_kernels.hpp; Float64 and ComplexF64, to <= 64): per step
 //   SpMV -> DOTS -> FIN_DOTS_DEF -> AXPY+DOTS -> FIN_MID_DEF -> AXPY
 // (6 launches, 2 reductions, 3 passes over V, no v ./= wnorm pass) and one FIN_PEND at the end of the batch.  `op` may be null
 // (ks_orthogonalize: the column is already there).
-template <class D> void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op, int from, int to) {
+template <class D> void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op, int from, int to, uint64_t early_seq = 0) {
   ks_ctx* cx = ws->ctx;
   hipStream_t s = cx->stream;
   const int ldh = ws->maxdim + 1;
@@ -1396,6 +1438,11 @@ template <class D> void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op
         ksd::k_fin_mid_def<D><<<j + 1, 64, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hcol, coef, ws->colscale, 2, ws->st, pd);
       }
     }
+    if (early_seq && j == to) {
+      // H[0:to, from-1:to) is final here (the second-pass correction is in); what is still to come -- the second-pass
+      // update of the vector and the reduction of H[to, to-1] -- does not touch it: hand it to the host now
+      publish_control(ws, from, ws->Hstage_early_dev, 0, early_seq);
+    }
     {
       ProfScope ps(cx, KSP_AXPY, nb8 * (j + 2));
       // packs per lane per iteration: at n = 1e7 going 2 -> 4 -> 8 gained 3 % + 8 % (16 lost 18 %); small
@@ -1444,13 +1491,19 @@ inline void reset_state(ks_workspace* ws) {
   KS_HIP(hipMemcpyAsync(ws->st, ws->st_h, bytes, hipMemcpyHostToDevice, ws->ctx->stream));
 }
 // End of a batch: the H columns of steps from.. (to the end of Hd) and the DevState in ONE copy, one synchronisation.
-inline void fetch_state(ks_workspace* ws, int from = 0) {
+inline void fetch_state_enqueue(ks_workspace* ws, int from = 0) {
   const size_t off = from >= 1 ? (size_t)(from - 1) * (ws->maxdim + 1) * ws->esz : ws->hd_bytes;
   KS_HIP(hipMemcpyAsync(static_cast<char*>(ws->Hstage) + off, static_cast<char*>(ws->Hd) + off, ws->hd_bytes + sizeof(DevState) - off,
                         hipMemcpyDeviceToHost, ws->ctx->stream));
+}
+inline void fetch_state_wait(ks_workspace* ws) {
   KS_HIP(hipStreamSynchronize(ws->ctx->stream));
   if (ws->ctx->profiling) prof_collect(ws->ctx);
   ws->ctx->check_comm();
+}
+inline void fetch_state(ks_workspace* ws, int from = 0) {
+  fetch_state_enqueue(ws, from);
+  fetch_state_wait(ws);
 }
 
 // global 2-norm of column j (synchronous)
@@ -1549,24 +1602,31 @@ template <class D> bool reinit_column(ks_workspace* ws, int j, const void* v1_ho
   return true;
 }
 
-// copy the H columns produced on the device for steps from..to (already staged by fetch_state(ws, from)) into the host H
-template <class T> void fetch_H_columns(ks_workspace* ws, int from, int to, const ks::Mat<T>& H, bool lazy = false) {
-  if (to < from) return;
+// columns built by a lazily-normalised batch are stored as beta * v with beta = H[j, j-1] (read from the staged image:
+// the host H may already have been transformed by the early part of the restart step)
+template <class T> void lazy_factors_from_stage(ks_workspace* ws, int from, int to, const void* stage) {
   const int ldh = ws->maxdim + 1;
-  const T* hs = static_cast<const T*>(ws->Hstage);  // filled by fetch_state(ws, from) together with the DevState
-  for (int j = from; j <= to; ++j)
-    for (int i = 0; i <= j; ++i) H(i, j - 1) = hs[(size_t)(j - 1) * ldh + i];
-  if (lazy) {
-    // columns built by a lazily-normalised batch are stored as beta * v with beta = H[j, j-1]
-    for (int j = from; j <= to; ++j) {
-      const double beta = ks::real_(H(j, j - 1));
-      if (beta != 0.0) {
-        ws->hostscale[j] = 1.0 / beta;
-        ws->lazy_lo = std::min(ws->lazy_lo, j);
-        ws->lazy_hi = std::max(ws->lazy_hi, j);
-      }
+  const T* hs = static_cast<const T*>(stage);
+  for (int j = from; j <= to; ++j) {
+    const double beta = ks::real_(hs[(size_t)(j - 1) * ldh + j]);
+    if (beta != 0.0) {
+      ws->hostscale[j] = 1.0 / beta;
+      ws->lazy_lo = std::min(ws->lazy_lo, j);
+      ws->lazy_hi = std::max(ws->lazy_hi, j);
     }
   }
+}
+
+// copy the H columns produced on the device for steps from..to (already staged by fetch_state(ws, from), or by the early
+// copy into `stage`) into the host H
+template <class T> void fetch_H_columns(ks_workspace* ws, int from, int to, const ks::Mat<T>& H, bool lazy = false, const void* stage = nullptr) {
+  if (to < from) return;
+  const int ldh = ws->maxdim + 1;
+  if (!stage) stage = ws->Hstage;  // filled by fetch_state(ws, from) together with the DevState
+  const T* hs = static_cast<const T*>(stage);
+  for (int j = from; j <= to; ++j)
+    for (int i = 0; i <= j; ++i) H(i, j - 1) = hs[(size_t)(j - 1) * ldh + i];
+  if (lazy) lazy_factors_from_stage<T>(ws, from, to, stage);
 }
 
 // out[:, 0:r) = V[:, 0:c) * Y[0:c, 0:r)  (device Y, column-major ldy) for any c, r: the coefficient block
@@ -1678,8 +1738,25 @@ template <class T> struct HipBackend : ks::Backend<T> {
   int64_t n_global() const override { return ws->n_global; }
 
   void iterate_arnoldi(int from, int to, const ks::Mat<T>& H, ks::ExpandStats& stats) override {
+    guarded_expand([&] { iterate_arnoldi_impl(from, to, H, stats, nullptr); });
+  }
+
+  // The expansion a restart follows: H[0:to, :] is handed to `early` (restart_host_early: Schur form, Ritz values,
+  // unit residuals, ordering) as soon as the last step's k_fin_mid_def ran, while the device still runs that step's
+  // second-pass update and the reduction of H[to, to-1] -- at n = 1e7 the update alone (0.4 ms) outlasts the whole early
+  // part (0.13 ms), at n = 1e6 about 30 us of it are hidden (profiles/r02_restart_bubble.txt).
+  // KS_EARLY_RESTART=0 keeps the strictly sequential order.  Same operations on the same numbers either way.
+  bool iterate_arnoldi_early(int from, int to, const ks::Mat<T>& H, ks::ExpandStats& stats, const std::function<void()>& early) override {
+    const char* e = std::getenv("KS_EARLY_RESTART");
+    const bool on = !(e && e[0] == '0');
+    bool done = false;
+    guarded_expand([&] { done = iterate_arnoldi_impl(from, to, H, stats, on ? &early : nullptr); });
+    return done;
+  }
+
+  template <class F> void guarded_expand(F&& f) {
     try {
-      iterate_arnoldi_impl(from, to, H, stats);
+      f();
     } catch (...) {
       // an operator callback (or a HIP / transport error) aborted a batch midway: steps were enqueued whose H columns
       // and lazy-normalisation factors were never fetched.  Drain the stream and return the bookkeeping to "every
@@ -1691,16 +1768,22 @@ template <class T> struct HipBackend : ks::Backend<T> {
     }
   }
 
-  void iterate_arnoldi_impl(int from, int to, const ks::Mat<T>& H, ks::ExpandStats& stats) {
+  // returns true iff *early ran and its effects on H stand
+  bool iterate_arnoldi_impl(int from, int to, const ks::Mat<T>& H, ks::ExpandStats& stats, const std::function<void()>* early) {
     ws->ctx->use();
+    bool early_stands = false;
     int j0 = from;
     while (j0 <= to) {
+      const double tb0 = ks::now_s();
       reset_state(ws);
       int jend = to;
       if (!op->async_capable) jend = j0;  // host operators: one step per batch
       const bool lazy = use_deferred(ws, jend);
+      const bool mb = lazy && ws->use_mbox;          // the device publishes the results itself, the host spins
+      const bool do_early = early && mb && jend == to;
+      const uint64_t seq = ++ws->mbox_seq;
       if (lazy) {
-        enqueue_steps_deferred<D>(ws, op, j0, jend);
+        enqueue_steps_deferred<D>(ws, op, j0, jend, do_early ? seq : 0);
       } else {
         materialize(ws);  // the eager kernels expect ordinary columns
         for (int j = j0; j <= jend; ++j) {
@@ -1708,10 +1791,56 @@ template <class T> struct HipBackend : ks::Backend<T> {
           enqueue_orthogonalize<D>(ws, j);
         }
       }
-      fetch_state(ws, j0);
+      bool early_ran = false;
+      static const int dbg = env_int("KS_EARLY_DEBUG", 0);
+      double tq0 = dbg ? ks::now_s() : 0.0, tq1 = 0, tq2 = 0;
+      if (mb) publish_control(ws, j0, ws->Hstage_dev, 1, seq);
+      else fetch_state_enqueue(ws, j0);
+      if (do_early) {
+        mbox_wait(ws, 0, seq);
+        if (dbg) tq1 = ks::now_s();
+        const DevState* se = reinterpret_cast<const DevState*>(static_cast<const char*>(ws->Hstage_early) + ws->hd_bytes);
+        if (se->breakdown < 0) {  // (a breakdown of the LAST step is only known after the final reduction: see below)
+          const size_t hb = (size_t)H.ld * H.n * sizeof(T);
+          ws->Hbackup.resize(hb);
+          std::memcpy(ws->Hbackup.data(), H.p, hb);
+          fetch_H_columns<T>(ws, j0, jend, H, false, ws->Hstage_early);  // H[jend, jend-1] is not final yet, nobody reads it
+          (*early)();
+          early_ran = true;
+        }
+        if (dbg) tq2 = ks::now_s();
+      }
+      if (mb) {
+        mbox_wait(ws, 1, seq);
+        if (ws->ctx->profiling) {
+          KS_HIP(hipStreamSynchronize(ws->ctx->stream));
+          prof_collect(ws->ctx);
+        }
+        ws->ctx->check_comm();
+      } else {
+        fetch_state_wait(ws);
+      }
+      if (dbg && do_early) {
+        const double tq3 = ks::now_s();
+        std::fprintf(stderr, "[early] enqueue %.1f us | wait H %.1f us | early host part %.1f us | final wait %.1f us | batch %.1f us\n", 1e6 * (tq0 - tb0), 1e6 * (tq1 - tq0), 1e6 * (tq2 - tq1), 1e6 * (tq3 - tq2), 1e6 * (tq3 - tb0));
+      } else if (dbg) {
+        const double tq3 = ks::now_s();
+        std::fprintf(stderr, "[early off] enqueue %.1f us | wait %.1f us | batch %.1f us\n", 1e6 * (tq0 - tb0), 1e6 * (tq3 - tq0), 1e6 * (tq3 - tb0));
+      }
       const int bd = ws->st_h->breakdown;
       const int last_done = bd >= 0 ? bd : jend;
-      fetch_H_columns<T>(ws, j0, last_done, H, lazy);
+      if (early_ran && bd >= 0) {  // the last step broke down: withdraw (rare; the caller redoes the early part)
+        std::memcpy(H.p, ws->Hbackup.data(), ws->Hbackup.size());
+        early_ran = false;
+      }
+      if (early_ran) {
+        const T* hs = static_cast<const T*>(ws->Hstage);
+        H(jend, jend - 1) = hs[(size_t)(jend - 1) * (ws->maxdim + 1) + jend];
+        lazy_factors_from_stage<T>(ws, j0, jend, ws->Hstage);
+        early_stands = true;
+      } else {
+        fetch_H_columns<T>(ws, j0, last_done, H, lazy);
+      }
       stats.steps += last_done - j0 + 1;
       stats.reorth += ws->st_h->n_reorth;
       if (lazy && jend > j0) ws->oop_full = 10 * ws->st_h->n_reorth >= 9 * (last_done - j0 + 1);  // (batches of one step keep the setting)
@@ -1725,6 +1854,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
       }
       j0 = last_done + 1;
     }
+    return early_stands;
   }
 
   bool reinitialize(int j, const T* v1_host) override {
@@ -2362,6 +2492,14 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     static_assert(sizeof(DevState) <= kCtlStateSlot, "DevState must fit its slot of the control block");
     KS_HIP(hipHostMalloc(&w->Hstage, ctl_bytes));
     KS_HIP(hipHostMalloc(&w->Qstage, qbytes));
+    KS_HIP(hipHostMalloc(&w->Hstage_early, ctl_bytes));
+    std::memset(w->Hstage_early, 0, ctl_bytes);
+    KS_HIP(hipHostMalloc(reinterpret_cast<void**>(&w->mbox), 128));
+    std::memset(w->mbox, 0, 128);
+    KS_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&w->mbox_dev), w->mbox, 0));
+    KS_HIP(hipHostGetDevicePointer(&w->Hstage_dev, w->Hstage, 0));
+    KS_HIP(hipHostGetDevicePointer(&w->Hstage_early_dev, w->Hstage_early, 0));
+    w->use_mbox = env_int("KS_MAILBOX", 1) != 0;
     std::memset(w->H, 0, hbytes);   // zeros(T, k+1, k), src/ArnoldiMethod.jl:66
     std::memset(w->Q, 0, qbytes);
     std::memset(w->Hstage, 0, ctl_bytes);
@@ -2804,6 +2942,49 @@ int ks_restart(ks_workspace* ws, const ks_params* p, int active, int* k_out, int
         if (rs) rs[i] = sc.rs[i];
         if (groups) groups[i] = sc.groups[i];
       }
+    });
+  });
+}
+
+int ks_expand_restart(ks_operator* A, ks_workspace* ws, const ks_params* p, int active, int k_in, int* k_out, int* nlock_out,
+                      int* purge_out, double* lams_c64, double* rs, int32_t* groups, ks_expand_stats* stats, double* seconds) {
+  return guarded([&] {
+    KS_REQUIRE(A && ws && p, KS_ERR_ARGUMENT, "null argument");
+    KS_REQUIRE(A->n_local == ws->n && A->dtype == ws->dtype, KS_ERR_DIMENSION, "operator / workspace mismatch");
+    ks::Params prm{p->nev, p->which, p->tol, p->mindim, p->maxdim, p->restarts, 1, 0};
+    std::string msg;
+    if (ks::check_params(ws->n_global, ws->maxdim + 1, prm, msg)) throw KsError{KS_ERR_ARGUMENT, msg};
+    KS_REQUIRE(active >= 0 && active < prm.maxdim, KS_ERR_ARGUMENT, "active out of range");
+    KS_REQUIRE(k_in >= 1 && k_in < prm.maxdim, KS_ERR_ARGUMENT, "k_in out of range");
+    ws->ctx->use();
+    dispatch_dtype(ws->dtype, [&](auto tag) {
+      using T = decltype(tag);
+      ks::Mat<T> H(static_cast<T*>(ws->H), prm.maxdim + 1, prm.maxdim, ws->maxdim + 1);
+      ks::Mat<T> Q(static_cast<T*>(ws->Q), prm.maxdim, prm.maxdim, ws->maxdim);
+      ks::RestartScratch<T> sc(prm.maxdim);
+      const ks::Ordering ordering{prm.which};
+      HipBackend<T> be(A, ws);
+      ks::ExpandStats st;
+      double t0 = ks::now_s();
+      const bool early_done = be.iterate_arnoldi_early(k_in + 1, prm.maxdim, H, st,
+                                                       [&] { ks::restart_host_early(H, Q, prm.maxdim, ordering, active, sc); });
+      double t1 = ks::now_s();
+      if (!early_done) ks::restart_host_early(H, Q, prm.maxdim, ordering, active, sc);
+      const ks::RestartResult r = ks::restart_host_late(H, Q, prm.maxdim, prm.mindim, prm.nev, prm.tol, active, sc);
+      double t2 = ks::now_s();
+      be.rotate(r.purge, prm.maxdim - r.purge, r.k - r.purge, Q);  // src/run.jl:363-364
+      be.col_copy(r.k, prm.maxdim);                                 // src/run.jl:365
+      double t3 = ks::now_s();
+      if (k_out) *k_out = r.k;
+      if (nlock_out) *nlock_out = r.nlock;
+      if (purge_out) *purge_out = r.purge;
+      for (int i = 0; i < prm.maxdim; ++i) {
+        if (lams_c64) { lams_c64[2 * i] = sc.lams[i].real(); lams_c64[2 * i + 1] = sc.lams[i].imag(); }
+        if (rs) rs[i] = sc.rs[i];
+        if (groups) groups[i] = sc.groups[i];
+      }
+      if (stats) { stats->steps = st.steps; stats->reorth = st.reorth; stats->breakdowns = st.breakdowns; stats->reserved = 0; }
+      if (seconds) { seconds[0] = t1 - t0; seconds[1] = t2 - t1; seconds[2] = t3 - t2; }
     });
   });
 }

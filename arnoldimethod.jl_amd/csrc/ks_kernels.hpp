@@ -1620,6 +1620,20 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // y = f * x (column copy with an optional factor), pads included
+// ------------------------------------------------------------------------------------------------
+// PUBLISH: hand a piece of the control block (H columns + DevState) to the host WITHOUT the runtime's copy machinery:
+// one workgroup stores it into host-pinned (device-mapped, coherent) memory and then releases a sequence number the host
+// spins on.  A hipMemcpyAsync in its place costs the host ~100 us of enqueue time and stalls the stream's submission;
+// a kernel is 3 us in line.  No early exit: the host must always be woken (the state it reads says what happened).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_publish(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst_host, int nwords,
+                                                    uint64_t* flag_host, uint64_t seq) {
+  for (int i = threadIdx.x; i < nwords; i += kBlock) dst_host[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <class T>
 __global__ void __launch_bounds__(kBlock) k_copy(const T* __restrict__ x, T* __restrict__ y, int64_t ld, double f) {
   constexpr int R = Pack<T>::R;

@@ -171,10 +171,15 @@ template <class T> inline void lmul(const Rot2<T>& G, const Mat<T>& A, int from,
 template <class T> inline void rmul(const Mat<T>& A, const Rot2<T>& G, int from, int to) {
   if (!A.wanted()) return;
   const T sc = conj_(G.s);
+  const double c = G.c;
+  const T ms = -G.s;
+  // two distinct columns: contiguous, non-overlapping -> the loop vectorises (same operations per element, no contraction)
+  T* __restrict__ p1 = &A(0, G.i);
+  T* __restrict__ p2 = &A(0, G.i + 1);
   for (int j = from; j <= to; ++j) {
-    const T a1 = A(j, G.i), a2 = A(j, G.i + 1);
-    A(j, G.i) = a1 * G.c + a2 * sc;
-    A(j, G.i + 1) = a1 * -G.s + a2 * G.c;
+    const T a1 = p1[j], a2 = p2[j];
+    p1[j] = a1 * c + a2 * sc;
+    p2[j] = a1 * ms + a2 * c;
   }
 }
 template <class T> inline void lmul(const Rot3<T>& G, const Mat<T>& A, int from, int to) {
@@ -192,13 +197,18 @@ template <class T> inline void lmul(const Rot3<T>& G, const Mat<T>& A, int from,
 template <class T> inline void rmul(const Mat<T>& A, const Rot3<T>& G, int from, int to) {
   if (!A.wanted()) return;
   const T s1c = conj_(G.s1), s2c = conj_(G.s2);
+  const double c1 = G.c1, c2 = G.c2;
+  const T ms1 = -G.s1, ms2 = -G.s2;
+  T* __restrict__ p1 = &A(0, G.i);
+  T* __restrict__ p2 = &A(0, G.i + 1);
+  T* __restrict__ p3 = &A(0, G.i + 2);
   for (int j = from; j <= to; ++j) {
-    const T a1 = A(j, G.i), a2 = A(j, G.i + 1), a3 = A(j, G.i + 2);
-    const T a2p = a2 * G.c1 + a3 * s1c;
-    const T a3p = a2 * -G.s1 + a3 * G.c1;
-    const T a1pp = a1 * G.c2 + a2p * s2c;
-    const T a2pp = a1 * -G.s2 + a2p * G.c2;
-    A(j, G.i) = a1pp; A(j, G.i + 1) = a2pp; A(j, G.i + 2) = a3p;
+    const T a1 = p1[j], a2 = p2[j], a3 = p3[j];
+    const T a2p = a2 * c1 + a3 * s1c;
+    const T a3p = a2 * ms1 + a3 * c1;
+    const T a1pp = a1 * c2 + a2p * s2c;
+    const T a2pp = a1 * ms2 + a2p * c2;
+    p1[j] = a1pp; p2[j] = a2pp; p3[j] = a3p;
   }
 }
 // whole-range forms, src/schurfact.jl:76-77
@@ -398,6 +408,13 @@ template <class T> inline cplx eigenvalue(const Mat<T>& R, int i) {  // src/eigv
 // ---------------------------------------------------------------------------------------------
 // One eigenvector of a (quasi) upper triangular matrix, src/eigenvector_uppertriangular.jl
 // ---------------------------------------------------------------------------------------------
+// real * complex and complex * complex exactly as Julia forms them (Base: *(x::Real, z::Complex) scales both parts,
+// *(z, w) is the four-product formula) -- std::complex's operator* adds the C99 Annex G infinity recovery, and promoting a
+// real factor to complex first doubles the multiplications.  These loops are a fifth of the restart's host step.
+inline cplx mulx(double r, cplx x) { return cplx(r * x.real(), r * x.imag()); }
+inline cplx mulx(cplx a, cplx b) {
+  return cplx(a.real() * b.real() - a.imag() * b.imag(), a.real() * b.imag() + a.imag() * b.real());
+}
 template <class T> inline void shifted_backward_sub(cplx* x, const Mat<T>& R, cplx lam, int k) {
   // k = number of unknowns (rows 0..k-1).  :6-42 real quasi-triangular, :44-68 generic.
   while (k > 0) {
@@ -409,7 +426,7 @@ template <class T> inline void shifted_backward_sub(cplx* x, const Mat<T>& R, cp
       const cplx a1 = (R22 * x[kk - 1] - R12 * x[kk]) / det;
       const cplx a2 = (-R21 * x[kk - 1] + R11 * x[kk]) / det;
       x[kk - 1] = a1; x[kk] = a2;
-      for (int i = 0; i < kk - 1; ++i) x[i] -= cplx(R(i, kk - 1)) * x[kk - 1] + cplx(R(i, kk)) * x[kk];
+      for (int i = 0; i < kk - 1; ++i) x[i] -= mulx(R(i, kk - 1), x[kk - 1]) + mulx(R(i, kk), x[kk]);
       k -= 2;
     } else {
       const cplx sigma = cplx(R(kk, kk)) - lam;
@@ -417,7 +434,7 @@ template <class T> inline void shifted_backward_sub(cplx* x, const Mat<T>& R, cp
         x[kk] = sigma;
       } else {
         x[kk] /= sigma;
-        for (int i = 0; i < kk; ++i) x[i] -= cplx(R(i, kk)) * x[kk];
+        for (int i = 0; i < kk; ++i) x[i] -= mulx(R(i, kk), x[kk]);
       }
       k -= 1;
     }
@@ -435,7 +452,7 @@ template <class T> inline int collect_eigen(cplx* x, const Mat<T>& R, int j) {
       const cplx lam = (tr + std::sqrt(cplx(tr * tr - 4 * det))) / 2.0;
       x[j - 1] = -R12 / (R11 - lam);
       x[j] = 1.0;
-      for (int i = 0; i < j - 1; ++i) x[i] = -R(i, j - 1) * x[j - 1] - R(i, j);
+      for (int i = 0; i < j - 1; ++i) x[i] = -mulx(R(i, j - 1), x[j - 1]) - R(i, j);
       shifted_backward_sub(x, R, lam, j - 1);
     } else {
       const cplx lam = R(j, j);
@@ -456,18 +473,28 @@ template <class T> inline int collect_eigen(cplx* x, const Mat<T>& R, int j) {
   return j + 1;
 }
 
-// copy_residuals!, src/run.jl:524-545
+// copy_residuals!, src/run.jl:524-545, in two halves: the dot product of the last row of Q with each eigenvector of
+// R (everything but the factor h_last = H[maxdim, maxdim-1]), and the residual |dot * h_last| itself.
 template <class T>
-inline void copy_residuals(double* rs, const Mat<T>& H, const Mat<T>& Q, T h_last, cplx* x, int first, int last) {
+inline void residual_dots(cplx* dots, const Mat<T>& H, const Mat<T>& Q, cplx* x, int first, int last) {
   const int m = H.n;
-  for (int i = 0; i < m; ++i) rs[i] = 0.0;
   for (int i = first; i <= last; ++i) {
     for (int t = 0; t < m; ++t) x[t] = 0.0;
     const int len = collect_eigen(x, H, i);
     cplx tmp = 0.0;
-    for (int j = 0; j < len; ++j) tmp += cplx(Q(m - 1, j)) * x[j];
-    rs[i] = std::abs(tmp * cplx(h_last));
+    for (int j = 0; j < len; ++j) tmp += mulx(Q(m - 1, j), x[j]);
+    dots[i] = tmp;
   }
+}
+template <class T> inline void finish_residuals(double* rs, const cplx* dots, T h_last, int m, int first, int last) {
+  for (int i = 0; i < m; ++i) rs[i] = 0.0;
+  for (int i = first; i <= last; ++i) rs[i] = std::abs(dots[i] * cplx(h_last));
+}
+template <class T>
+inline void copy_residuals(double* rs, const Mat<T>& H, const Mat<T>& Q, T h_last, cplx* x, int first, int last) {
+  std::vector<cplx> dots(H.n);
+  residual_dots(dots.data(), H, Q, x, first, last);
+  finish_residuals(rs, dots.data(), h_last, H.n, first, last);
 }
 
 // ---------------------------------------------------------------------------------------------

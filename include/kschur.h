@@ -288,6 +288,17 @@ int ks_partialschur(ks_operator* A, ks_workspace* ws, const ks_params* p, const 
 int ks_restart(ks_workspace* ws, const ks_params* p, int active, int* k, int* nlock, int* purge,
                double* lams_c64, double* rs, int32_t* groups);
 
+/* One whole cycle of `_partialschur`'s loop (src/run.jl:272-365) in one call: the expansion k_in+1 .. maxdim followed by
+ * the restart, with the part of the restart's host work that does not need H[maxdim+1, maxdim] (Schur form, Ritz values,
+ * unit residuals, ordering: src/run.jl:278-289) running on the host WHILE the device finishes the last expansion step --
+ * what ks_partialschur does internally.  Results are bit-identical to ks_iterate_arnoldi + ks_restart.  `k_in` is the
+ * basis size the previous restart left (mindim after the initial expansion).  seconds[3] (optional): wall time of the
+ * expansion (including whatever of the early host part the device did not hide), of the remaining host part, of
+ * enqueueing the rotation. */
+int ks_expand_restart(ks_operator* A, ks_workspace* ws, const ks_params* p, int active, int k_in, int* k, int* nlock,
+                      int* purge, double* eigenvalues_c64, double* residuals, int32_t* groups, ks_expand_stats* stats,
+                      double* seconds);
+
 /* Per-kernel-class timing with HIP events on the context's stream (bench.py's roofline figures).
  * Classes: 0 SpMV, 1 dots (V'w), 2 axpy (w -= Vh), 3 scale, 4 rotation, 5 reductions/decisions,
  * 6 fused axpy+dots (first projection + second-pass inner products).

@@ -305,3 +305,90 @@ def test_out_of_place_update_mode_is_bit_identical(dtype, monkeypatch):
     for m2 in ("1", "2"):
         assert res["0"][0] == res[m2][0] and np.array_equal(res["0"][1], res[m2][1]) and np.array_equal(res["0"][2], res[m2][2])
     assert res["1"][0]["reorth"] < 6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kind", ["csr", "host_callback"])
+def test_early_restart_handover_is_bit_identical(dtype, kind, monkeypatch):
+    """the part of the restart's host step that does not need H[maxdim+1, maxdim] (Schur form, Ritz values, unit
+    residuals, ordering: src/run.jl:278-289) runs while the device finishes the last expansion step (KS_EARLY_RESTART=1,
+    default).  It performs the same operations on the same numbers as the sequential order: every output of a whole solve
+    -- eigenvalues, Q, R, restart count, products -- must be BIT-identical, with device operators (one batch per
+    expansion) and with host callbacks (one batch per step)."""
+    A, n = _operator(dtype, (12, 13, 14))
+    v1 = _start(dtype, n, seed=33)
+    which = "LM" if np.dtype(dtype).kind == "c" else "SR"
+    out = {}
+    for mode in ("0", "1", "nomb"):
+        monkeypatch.setenv("KS_EARLY_RESTART", "1" if mode == "nomb" else mode)
+        monkeypatch.setenv("KS_MAILBOX", "0" if mode == "nomb" else "1")  # (read at workspace creation)
+        if kind == "csr":
+            op = A
+        else:
+            op = pkg.host_operator(lambda y, x: np.copyto(y, A @ x), n, dtype)
+        dec, hist = pkg.partialschur(op, v1=v1, nev=6, which=which, tol=1e-10, mindim=10, maxdim=24, restarts=60)
+        assert hist.converged and hist.restarts >= 3
+        out[mode] = (dec.eigenvalues.copy(), np.array(dec.Q), np.array(dec.R), hist.mvproducts, hist.restarts, hist.nconverged)
+    for m2 in ("1", "nomb"):
+        a, b = out["0"], out[m2]
+        assert a[3:] == b[3:]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_early_restart_handover_with_breakdown_in_last_step(monkeypatch):
+    """An operator whose Krylov space is exhausted exactly at maxdim: the LAST step of the expansion breaks down (known only
+    after the final reduction), the early part of the restart has already run on H and must be withdrawn."""
+    n, m = 4000, 12
+    # block-diagonal operator: an m x m block acting on the first m coordinates, identity elsewhere; start vector
+    # supported on the first m coordinates -> invariant subspace of dimension m
+    rng = np.random.default_rng(5)
+    B = rng.standard_normal((m, m))
+    A = sp.block_diag([sp.csr_matrix(B), sp.identity(n - m, format="csr")], format="csr")
+    v1 = np.zeros(n)
+    v1[:m] = rng.standard_normal(m)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("KS_EARLY_RESTART", mode)
+        dec, hist = pkg.partialschur(A, v1=v1, nev=3, which="LM", tol=1e-10, mindim=6, maxdim=m, restarts=40)
+        out[mode] = (dec.eigenvalues.copy(), hist.mvproducts, hist.restarts, hist.nconverged, hist.breakdowns)
+    assert out["0"][1:] == out["1"][1:], (out["0"][1:], out["1"][1:])
+    assert np.array_equal(out["0"][0], out["1"][0])
+    assert out["1"][4] >= 1  # the breakdown did happen
+    ref = np.linalg.eigvals(B)
+    ref = ref[np.argsort(-np.abs(ref))][: len(out["1"][0])]
+    assert np.allclose(np.sort_complex(out["1"][0]), np.sort_complex(ref), atol=1e-8)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_expand_restart_equals_the_two_separate_calls(dtype):
+    """ks_expand_restart (one cycle of src/run.jl:272-365 in one call, early part of the host step overlapped with the tail of
+    the expansion) leaves the workspace in the bit-identical state ks_iterate_arnoldi + ks_restart leave it in, cycle after
+    cycle: H, V, basis size, locked count, Ritz values, residual estimates, groups."""
+    A, n = _operator(dtype, (13, 12, 11))
+    v1 = _start(dtype, n, seed=9)
+    which = "LM" if np.dtype(dtype).kind == "c" else "SR"
+    nev, mindim, maxdim = 5, 10, 22
+    trails = []
+    for fused in (False, True):
+        op = pkg.csr_operator(A)
+        ws = pkg.ArnoldiWorkspace(n, maxdim, dtype, ctx=op.ctx)
+        ws.reinitialize(0, v1)
+        ws.iterate_arnoldi(op, 1, mindim)
+        k, active, trail = mindim, 0, []
+        for _ in range(8):
+            if fused:
+                r = ws.expand_restart(op, k, active, nev, which, 1e-10, mindim, maxdim)
+                assert r["steps"] == maxdim - k
+            else:
+                ws.iterate_arnoldi(op, k + 1, maxdim)
+                r = ws.restart(active, nev, which, 1e-10, mindim, maxdim)
+            k, active = r["k"], r["nlock"]
+            trail.append((k, active, r["purge"], r["eigenvalues"].copy(), r["residuals"].copy(), r["groups"].copy(), np.array(ws.H), ws.cols(0, k + 1)))
+            if active >= nev:
+                break
+        trails.append(trail)
+    assert len(trails[0]) == len(trails[1]) >= 3
+    for a, b in zip(*trails):
+        assert a[:3] == b[:3]
+        for x, y in zip(a[3:], b[3:]):
+            assert np.array_equal(x, y)
