@@ -92,6 +92,7 @@ PROTOTYPES = {
     "ks_operator_apply_raw": [vp, vp, vp],
     "ks_workspace_create": [vp, i64, i64, i64, i32, i32, P(vp)],
     "ks_workspace_placement": [vp, P(C.c_int), P(C.c_double), P(C.c_double), P(C.c_int)],
+    "ks_workspace_passes": [vp, P(C.c_int)],
     "ks_workspace_check_guard": [vp, P(C.c_int)],
     "ks_workspace_destroy": [vp],
     "ks_workspace_dims": [vp, P(i64), P(C.c_int), P(C.c_int), P(i64)],

@@ -551,6 +551,13 @@ class ArnoldiWorkspace:
         return r.value, o.value
 
     @property
+    def passes(self) -> int:
+        """Reads of the basis per fused expansion step: 2 (implicit second pass, default) or 3 (KS_PASSES=3)."""
+        k = C.c_int()
+        check(_lib.load().ks_workspace_passes(self._h, C.byref(k)))
+        return k.value
+
+    @property
     def placement(self) -> dict:
         """Outcome of the placement search at creation: candidates timed, calibration ms of the kept / slowest one."""
         k, b, w, r = C.c_int(), C.c_double(), C.c_double(), C.c_int()

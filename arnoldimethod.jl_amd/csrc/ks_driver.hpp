@@ -48,6 +48,11 @@ template <class T> struct Backend {
   virtual void rotate(int c0, int c, int r, const Mat<T>& Q) = 0;
   // V[:, dst] <- V[:, src]   (src/run.jl:365)
   virtual void col_copy(int dst, int src) = 0;
+  // src/run.jl:363-365 in one call (a backend that keeps the basis in factored form does both at once)
+  virtual void rotate_and_move(int c0, int c, int r, const Mat<T>& Q, int dst, int src) {
+    rotate(c0, c, r, Q);
+    col_copy(dst, src);
+  }
 };
 
 struct Params {
@@ -214,8 +219,7 @@ inline History partialschur_driver(Backend<T>& be, const Mat<T>& H, const Mat<T>
 
     // :363-365  V[:, purge:k) <- V[:, purge:maxdim) Q[purge:maxdim, purge:k);  V[:, k] <- V[:, maxdim]
     t0 = now_s();
-    be.rotate(r.purge, maxdim - r.purge, k - r.purge, Q);
-    be.col_copy(k, maxdim);
+    be.rotate_and_move(r.purge, maxdim - r.purge, k - r.purge, Q, k, maxdim);
     hist.seconds_rotate += now_s() - t0;
 
     active = r.nlock;              // :368  (jl: active = nlock + 1)

@@ -82,6 +82,9 @@ template <class F> int guarded(F&& f) {
 template <class T> struct DevT;
 template <> struct DevT<double> { using type = double; };
 template <> struct DevT<cplx> { using type = cd; };
+template <class D> struct HostT;
+template <> struct HostT<double> { using type = double; };
+template <> struct HostT<cd> { using type = cplx; };
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 inline int env_int(const char* name, int dflt) {
@@ -1078,6 +1081,17 @@ struct ks_workspace {
   void* Hstage_early_dev = nullptr;
   uint64_t mbox_seq = 0;
   bool use_mbox = true;         // KS_MAILBOX (read at creation); 0: hipMemcpyAsync + hipStreamSynchronize
+  // IMPLICIT SECOND PASS (ks_kernels.hpp, k_fin_dots_t / k_fin_mid_t): V_true = S * T.  T and the vector g live in the
+  // control block behind the column factors; columns < ntrue are ordinary, columns ntrue..t_hi are "T-lazy".
+  int passes = 2;               // KS_PASSES at creation: 2 = implicit second pass (default), 3 = second pass applied to the vector
+  size_t off_T = 0, off_g = 0, ctl_bytes = 0;
+  int ldt = 0;
+  void* Td = nullptr;           // device, ldt x ldt, inside the Hd allocation
+  void* gd = nullptr;           // device, ldt elements, inside the Hd allocation
+  void* Th = nullptr;           // pinned host image of T, inside the Hstage allocation (valid after a batch)
+  unsigned* ctr = nullptr;      // device: arrival counter of the reduction kernels
+  bool t_lazy = false;
+  int ntrue = 0, t_hi = -1;
   void* Qd = nullptr;       // device, maxdim x maxdim
   void* Qstage = nullptr;   // pinned host
   void* oop = nullptr;      // device, 2 x ld elements (zero pads): scratch vectors of the out-of-place updates
@@ -1094,7 +1108,7 @@ struct ks_workspace {
   std::vector<double> hostscale;
   std::vector<double> ones;
   int lazy_lo = 1 << 30, lazy_hi = -1;
-  bool has_lazy() const { return lazy_hi >= lazy_lo; }
+  bool has_lazy() const { return lazy_hi >= lazy_lo || t_lazy; }
   int nb = 0;               // streaming workgroups (capped for small problems)
   int pnb = 0;              // column stride of `partial` (>= every producer's grid)
   uint64_t seed = 20240917ull;
@@ -1124,7 +1138,7 @@ struct ks_workspace {
     (void)hipFree(Hscratch); (void)hipFree(partial); (void)hipFree(partial2); (void)hipFree(coef); (void)hipFree(red);
     (void)hipFree(scal); (void)hipHostFree(scal_h); (void)hipHostFree(coef_h);
     (void)hipFree(Qd); (void)hipHostFree(Qstage); (void)hipFree(tmp); (void)hipFree(tmp2); (void)hipFree(oop);
-    (void)hipHostFree(Hstage_early); (void)hipHostFree(mbox);
+    (void)hipHostFree(Hstage_early); (void)hipHostFree(mbox); (void)hipFree(ctr);
   }
 };
 
@@ -1317,14 +1331,21 @@ template <class D> void enqueue_orthogonalize(ks_workspace* ws, int j) {
 // Lazy columns -> ordinary columns: one scaling pass per lazy column (only needed when something other than
 // the expansion / restart-rotation pair is about to read V).
 inline void reset_lazy(ks_workspace* ws) {
-  if (!ws->has_lazy()) return;
+  ws->t_lazy = false;
+  ws->t_hi = -1;
+  if (!(ws->lazy_hi >= ws->lazy_lo)) return;
   for (int c = ws->lazy_lo; c <= ws->lazy_hi; ++c) ws->hostscale[c] = 1.0;
   ws->colscale_dirty = true;  // the device copy is only read inside expansion batches: uploaded with the next one's state
   ws->lazy_lo = 1 << 30;
   ws->lazy_hi = -1;
 }
+template <class D> void materialize_t(ks_workspace* ws);
 inline void materialize(ks_workspace* ws) {
-  if (!ws->has_lazy()) return;
+  if (ws->t_lazy) {  // implicit second pass: V_true = S T, one in-place triangular product over the T-lazy columns
+    if (ws->dtype == KS_F64) materialize_t<double>(ws);
+    else materialize_t<cd>(ws);
+  }
+  if (!(ws->lazy_hi >= ws->lazy_lo)) return;
   for (int c = ws->lazy_lo; c <= ws->lazy_hi; ++c)
     if (ws->hostscale[c] != 1.0) {
       if (ws->dtype == KS_F64) ksd::k_scale<double><<<ws->nb, kBlock, 0, ws->ctx->stream>>>(static_cast<double*>(ws->col(c)), ws->ld, ws->hostscale[c], nullptr);
@@ -1339,9 +1360,13 @@ inline void materialize(ks_workspace* ws) {
 // Replaces hipMemcpyAsync + hipStreamSynchronize around every expansion batch: the copy cost ~100 us of host enqueue
 // time when issued in mid-stream and stalled the submission of what followed; the synchronisation woke the host
 // 15-20 us after the fact (profiles/r02_restart_bubble.txt).
-inline void publish_control(ks_workspace* ws, int from, void* image_dev, int slot, uint64_t seq) {
+// end of the range a batch hands back: H columns + DevState, and with the implicit second pass also T
+inline size_t control_end(const ks_workspace* ws, bool with_T) {
+  return with_T ? ws->off_g : ws->hd_bytes + sizeof(DevState);
+}
+inline void publish_control(ks_workspace* ws, int from, void* image_dev, int slot, uint64_t seq, bool with_T = false) {
   const size_t off = from >= 1 ? (size_t)(from - 1) * (ws->maxdim + 1) * ws->esz : ws->hd_bytes;
-  const int nwords = (int)((ws->hd_bytes + sizeof(DevState) - off) / 8);
+  const int nwords = (int)((control_end(ws, with_T) - off) / 8);
   ksd::k_publish<<<1, kBlock, 0, ws->ctx->stream>>>(reinterpret_cast<const uint64_t*>(static_cast<const char*>(ws->Hd) + off),
                                                      reinterpret_cast<uint64_t*>(static_cast<char*>(image_dev) + off), nwords,
                                                      ws->mbox_dev + 8 * slot, seq);
@@ -1470,6 +1495,67 @@ template <class D> void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op
   KS_HIP(hipGetLastError());
 }
 
+// Fused expansion steps from..to with the IMPLICIT SECOND PASS (ks_kernels.hpp): per step
+//   SpMV -> DOTS -> FIN_DOTS_T -> AXPY+DOTS -> FIN_MID_T
+// (5 launches, 2 reductions, TWO passes over the basis whether or not the DGKS test asks for the second projection).
+template <class D> void enqueue_steps_t(ks_workspace* ws, ks_operator* op, int from, int to) {
+  ks_ctx* cx = ws->ctx;
+  hipStream_t s = cx->stream;
+  const int ldh = ws->maxdim + 1;
+  D* Hd = static_cast<D*>(ws->Hd);
+  D* Tm = static_cast<D*>(ws->Td);
+  D* gv = static_cast<D*>(ws->gd);
+  D* red = static_cast<D*>(ws->red);
+  D* coef = static_cast<D*>(ws->coef);
+  const D* part = static_cast<const D*>(ws->partial);
+  double* redd = reinterpret_cast<double*>(ws->red);
+  constexpr int dpe = (int)(sizeof(D) / 8);
+  const double nb8 = (double)ws->n * sizeof(D);
+  const bool dist = cx->distributed();
+  static const int no_fold = env_int("KS_P2P_NO_FOLD", 0);
+  const bool p2p = cx->p2p.attached && !no_fold;
+  const ksd::P2pDev pd = cx->p2p.dev;
+  const int nt = ws->ntrue;
+  D* S0 = ws->oop ? static_cast<D*>(ws->oop) : nullptr;
+  for (int j = from; j <= to; ++j) {
+    D* w = static_cast<D*>(ws->col(j));
+    D* y = S0 ? S0 : w;  // where the product lands; the projection reads it and writes column j
+    D* Hcol = Hd + (size_t)(j - 1) * ldh;
+    op->apply(ws->col(j - 1), y, ws->st);
+    int nbd;
+    {
+      ProfScope ps(cx, KSP_DOTS, nb8 * (j + 1));
+      nbd = launch_dots<D>(ws, j, y, 1, ws->st);
+    }
+    {
+      ProfScope ps(cx, KSP_FIN, 0.0);
+      if (!dist || p2p) {
+        ksd::k_fin_dots_t<D><<<j + 1, kBlock, 0, s>>>(part, nbd, ws->pnb, j, red, Hcol, Tm, ws->ldt, nt, gv, coef, p2p ? 3 : 0, ws->st, pd, ws->ctr);
+      } else {
+        ksd::k_fin_dots_t<D><<<j + 1, kBlock, 0, s>>>(part, nbd, ws->pnb, j, red, Hcol, Tm, ws->ldt, nt, gv, coef, 1, ws->st, pd, ws->ctr);
+        cx->allreduce(redd, (j + 1) * dpe);
+        ksd::k_fin_dots_t<D><<<1, kBlock, 0, s>>>(part, nbd, ws->pnb, j, red, Hcol, Tm, ws->ldt, nt, gv, coef, 2, ws->st, pd, ws->ctr);
+      }
+    }
+    int nbf;
+    {
+      ProfScope ps(cx, KSP_FUSED, nb8 * (j + 2));  // reads S[:,0:j) and y', writes w'
+      nbf = launch_axpy_dots<D>(ws, j, y, 1, y == w ? nullptr : w);
+    }
+    {
+      ProfScope ps(cx, KSP_FIN, 0.0);
+      if (!dist || p2p) {
+        ksd::k_fin_mid_t<D><<<j + 1, kBlock, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hd, ldh, Tm, ws->ldt, nt, gv, p2p ? 3 : 0, ws->st, pd, ws->ctr);
+      } else {
+        ksd::k_fin_mid_t<D><<<j + 1, kBlock, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hd, ldh, Tm, ws->ldt, nt, gv, 1, ws->st, pd, ws->ctr);
+        cx->allreduce(redd, (j + 1) * dpe);
+        ksd::k_fin_mid_t<D><<<1, kBlock, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hd, ldh, Tm, ws->ldt, nt, gv, 2, ws->st, pd, ws->ctr);
+      }
+    }
+  }
+  KS_HIP(hipGetLastError());
+}
+
 inline bool use_deferred(const ks_workspace* ws, int to) {
   static const int no_fuse = env_int("KS_NO_FUSE", 0), no_defer = env_int("KS_NO_DEFER", 0);
   return to <= kFusedMaxJ && !no_fuse && !no_defer;
@@ -1477,11 +1563,18 @@ inline bool use_deferred(const ks_workspace* ws, int to) {
 
 // Start of a batch: fresh DevState and, when the host changed column factors since the last batch, the factors --
 // one asynchronous copy from the pinned control block, no synchronisation.
-inline void reset_state(ks_workspace* ws) {
+inline void reset_state(ks_workspace* ws, bool upload_H = false) {
   // (no synchronisation: the state image is always the same bytes, and the factor image is only rewritten after a
   // host-side change, which follows the synchronising fetch of the previous batch)
   std::memset(ws->st_h, 0, sizeof(DevState));
   ws->st_h->breakdown = -1;
+  if (upload_H) {
+    // implicit second pass: the device needs the CURRENT H (the restart rewrote its leading block on the host) for
+    // g = H c -- the whole array travels with the state, still one copy
+    std::memcpy(ws->Hstage, ws->H, (size_t)(ws->maxdim + 1) * ws->maxdim * ws->esz);
+    KS_HIP(hipMemcpyAsync(ws->Hd, ws->Hstage, ws->hd_bytes + sizeof(DevState), hipMemcpyHostToDevice, ws->ctx->stream));
+    return;  // (the column factors are not used by this path)
+  }
   size_t bytes = sizeof(DevState);
   if (ws->colscale_dirty) {
     std::memcpy(ws->cs_h, ws->hostscale.data(), (size_t)(ws->maxdim + 2) * 8);
@@ -1491,9 +1584,9 @@ inline void reset_state(ks_workspace* ws) {
   KS_HIP(hipMemcpyAsync(ws->st, ws->st_h, bytes, hipMemcpyHostToDevice, ws->ctx->stream));
 }
 // End of a batch: the H columns of steps from.. (to the end of Hd) and the DevState in ONE copy, one synchronisation.
-inline void fetch_state_enqueue(ks_workspace* ws, int from = 0) {
+inline void fetch_state_enqueue(ks_workspace* ws, int from = 0, bool with_T = false) {
   const size_t off = from >= 1 ? (size_t)(from - 1) * (ws->maxdim + 1) * ws->esz : ws->hd_bytes;
-  KS_HIP(hipMemcpyAsync(static_cast<char*>(ws->Hstage) + off, static_cast<char*>(ws->Hd) + off, ws->hd_bytes + sizeof(DevState) - off,
+  KS_HIP(hipMemcpyAsync(static_cast<char*>(ws->Hstage) + off, static_cast<char*>(ws->Hd) + off, control_end(ws, with_T) - off,
                         hipMemcpyDeviceToHost, ws->ctx->stream));
 }
 inline void fetch_state_wait(ks_workspace* ws) {
@@ -1645,8 +1738,10 @@ void gemm_tall_chunked(ks_workspace* ws, const TV* V, int c, int r, const TY* Yd
   KS_HIP(hipGetLastError());
 }
 
-// V[:, c0:c0+r) <- V[:, c0:c0+c) Q  with Q already on the device (column-major, ld = c)
-template <class D> void rotate_device(ks_workspace* ws, int c0, int c, int r) {
+// V[:, c0+out0 : c0+out0+r) <- V[:, c0:c0+c) Q  with Q already on the device (column-major, ld = c); in place.  out0 = 0 is
+// the plain rotation; extra_out >= 0 sends the LAST output to column c0 + extra_out instead (T-folded restart: the
+// residual direction lands next to the truncated basis).
+template <class D> void rotate_device(ks_workspace* ws, int c0, int c, int r, int out0 = 0, int extra_out = -1) {
   ks_ctx* ctx = ws->ctx;
   hipStream_t s = ctx->stream;
   D* Vc = static_cast<D*>(ws->col(c0));
@@ -1656,32 +1751,84 @@ template <class D> void rotate_device(ks_workspace* ws, int c0, int c, int r) {
   if constexpr (sizeof(D) == 8) {
     if (!force_valu && c <= 64) {
       const int ntile = (r + 15) / 16;
-      const int nb = ctx->num_cu * 4;
       auto smem = [&](int KC) { return (size_t)ntile * 16 * (4 * KC + 1) * 8; };
       static const int rt = env_int("KS_ROTATE_RT", 2);
       static const int nbm = env_int("KS_ROTATE_BPC", 4);
       const int nbr = ctx->num_cu * nbm;
-      if (c <= 24) { if (rt == 2) ksd::k_rotate_mfma<6, 2><<<nbr, kBlock, smem(6), s>>>(Vc, ws->ld, c, r, Qd, c); else ksd::k_rotate_mfma<6, 1><<<nbr, kBlock, smem(6), s>>>(Vc, ws->ld, c, r, Qd, c); }
-      else if (c <= 40) { if (rt == 2) ksd::k_rotate_mfma<10, 2><<<nbr, kBlock, smem(10), s>>>(Vc, ws->ld, c, r, Qd, c); else ksd::k_rotate_mfma<10, 1><<<nbr, kBlock, smem(10), s>>>(Vc, ws->ld, c, r, Qd, c); }
-      else ksd::k_rotate_mfma<16, 1><<<nbr, kBlock, smem(16), s>>>(Vc, ws->ld, c, r, Qd, c);
+      if (c <= 24) { if (rt == 2) ksd::k_rotate_mfma<6, 2><<<nbr, kBlock, smem(6), s>>>(Vc, ws->ld, c, r, Qd, c, out0, extra_out); else ksd::k_rotate_mfma<6, 1><<<nbr, kBlock, smem(6), s>>>(Vc, ws->ld, c, r, Qd, c, out0, extra_out); }
+      else if (c <= 40) { if (rt == 2) ksd::k_rotate_mfma<10, 2><<<nbr, kBlock, smem(10), s>>>(Vc, ws->ld, c, r, Qd, c, out0, extra_out); else ksd::k_rotate_mfma<10, 1><<<nbr, kBlock, smem(10), s>>>(Vc, ws->ld, c, r, Qd, c, out0, extra_out); }
+      else if (c <= 44) { if (rt == 2) ksd::k_rotate_mfma<11, 2><<<nbr, kBlock, smem(11), s>>>(Vc, ws->ld, c, r, Qd, c, out0, extra_out); else ksd::k_rotate_mfma<11, 1><<<nbr, kBlock, smem(11), s>>>(Vc, ws->ld, c, r, Qd, c, out0, extra_out); }
+      else ksd::k_rotate_mfma<16, 1><<<nbr, kBlock, smem(16), s>>>(Vc, ws->ld, c, r, Qd, c, out0, extra_out);
       KS_HIP(hipGetLastError());
       return;
     }
   }
   const size_t smem = (size_t)c * r * sizeof(D);
   const int nb = ctx->num_cu * 2;
-  if (c <= 8) ksd::k_rotate_valu<D, 8><<<nb, kBlock, smem, s>>>(Vc, ws->ld, c, r, Qd, c, Vc, ws->ld);
-  else if (c <= 16) ksd::k_rotate_valu<D, 16><<<nb, kBlock, smem, s>>>(Vc, ws->ld, c, r, Qd, c, Vc, ws->ld);
-  else if (c <= 24) ksd::k_rotate_valu<D, 24><<<nb, kBlock, smem, s>>>(Vc, ws->ld, c, r, Qd, c, Vc, ws->ld);
-  else if (c <= 40) ksd::k_rotate_valu<D, 40><<<nb, kBlock, smem, s>>>(Vc, ws->ld, c, r, Qd, c, Vc, ws->ld);
+  D* Vo = Vc + (size_t)out0 * ws->ld;
+  const int xo = extra_out >= 0 ? extra_out - out0 : -1;  // relative to the output base
+  if (c <= 8) ksd::k_rotate_valu<D, 8><<<nb, kBlock, smem, s>>>(Vc, ws->ld, c, r, Qd, c, Vo, ws->ld, xo);
+  else if (c <= 16) ksd::k_rotate_valu<D, 16><<<nb, kBlock, smem, s>>>(Vc, ws->ld, c, r, Qd, c, Vo, ws->ld, xo);
+  else if (c <= 24) ksd::k_rotate_valu<D, 24><<<nb, kBlock, smem, s>>>(Vc, ws->ld, c, r, Qd, c, Vo, ws->ld, xo);
+  else if (c <= 40) ksd::k_rotate_valu<D, 40><<<nb, kBlock, smem, s>>>(Vc, ws->ld, c, r, Qd, c, Vo, ws->ld, xo);
   else {
     // out of place through scratch, then copy back
     D* tmp = static_cast<D*>(ws->ensure_tmp((size_t)ws->ld * r * sizeof(D)));
     KS_HIP(hipMemsetAsync(tmp, 0, (size_t)ws->ld * r * sizeof(D), s));  // keeps the pad rows zero
     gemm_tall_chunked<D, D>(ws, Vc, c, r, Qd, c, tmp, ws->ld);
-    KS_HIP(hipMemcpyAsync(Vc, tmp, (size_t)ws->ld * r * sizeof(D), hipMemcpyDeviceToDevice, s));
+    const int rmain = extra_out >= 0 ? r - 1 : r;
+    if (rmain > 0) KS_HIP(hipMemcpyAsync(Vo, tmp, (size_t)ws->ld * rmain * sizeof(D), hipMemcpyDeviceToDevice, s));
+    if (extra_out >= 0)
+      KS_HIP(hipMemcpyAsync(Vc + (size_t)extra_out * ws->ld, tmp + (size_t)(r - 1) * ws->ld, (size_t)ws->ld * sizeof(D), hipMemcpyDeviceToDevice, s));
   }
   KS_HIP(hipGetLastError());
+}
+
+// T as the host sees it after a batch (pinned image); columns outside ntrue..t_hi are unit vectors
+template <class T> inline T t_entry(const ks_workspace* ws, int k, int i) {
+  if (!ws->t_lazy || i < ws->ntrue || i > ws->t_hi) return k == i ? T(1) : T(0);
+  if (k > i) return T(0);
+  return static_cast<const T*>(ws->Th)[k + (size_t)i * ws->ldt];
+}
+
+// Implicit second pass: V_true[:, a] = S[:, 0:a+1) T[0:a+1, a].  General T-folded product, in place:
+//   V[:, out0 : out0+r) <- V_true[:, c0 : c0+c) Q[0:c, 0:r)      (Q host, column-major ldq; may be null with r == 0)
+//   V[:, dst]           <- V_true[:, src]                         (src < 0: none)
+// computed as S[:, 0:cin) (T Q) with cin = max(c0 + c, src + 1).  Afterwards NO column is T-lazy: every T-lazy column that
+// is not among the outputs is dead (the caller guarantees it: restart, or materialisation of all of them).
+template <class T> void rotate_tfold(ks_workspace* ws, int c0, int c, int r, const T* Qh, int ldq, int out0, int src, int dst) {
+  using D = typename DevT<T>::type;
+  ws->ctx->use();
+  KS_HIP(hipStreamSynchronize(ws->ctx->stream));  // Qstage may still be in flight from a previous rotation
+  const int rr = r + (src >= 0 ? 1 : 0);
+  const int cin = std::max(c0 + c, src + 1);
+  KS_REQUIRE(cin <= ws->maxdim + 1 && rr <= ws->maxdim + 1, KS_ERR_INTERNAL, "T-folded rotation out of range");
+  T* qs = static_cast<T*>(ws->Qstage);  // cin x rr, ld = cin
+  for (int jj = 0; jj < r; ++jj)
+    for (int k = 0; k < cin; ++k) {
+      T a = T(0);
+      for (int i = std::max(k, c0); i < c0 + c; ++i) a += t_entry<T>(ws, k, i) * Qh[(i - c0) + (size_t)jj * ldq];
+      qs[k + (size_t)jj * cin] = a;
+    }
+  if (src >= 0)
+    for (int k = 0; k < cin; ++k) qs[k + (size_t)r * cin] = t_entry<T>(ws, k, src);
+  KS_HIP(hipMemcpyAsync(ws->Qd, qs, (size_t)cin * rr * sizeof(T), hipMemcpyHostToDevice, ws->ctx->stream));
+  const bool extra_elsewhere = src >= 0 && dst != out0 + r;
+  rotate_device<D>(ws, 0, cin, rr, out0, extra_elsewhere ? dst : -1);
+  ws->t_lazy = false;
+  ws->t_hi = -1;
+}
+
+// all T-lazy columns -> ordinary columns, in place (verbs outside the expansion / restart pair are about to read V)
+template <class D> void materialize_t(ks_workspace* ws) {
+  using T = typename HostT<D>::type;
+  if (!ws->t_lazy) return;
+  const int lo = ws->ntrue, hi = ws->t_hi;
+  if (hi < lo) { ws->t_lazy = false; return; }
+  const int c = hi - lo + 1;
+  std::vector<T> I((size_t)c * c, T(0));
+  for (int i = 0; i < c; ++i) I[i + (size_t)i * c] = T(1);
+  rotate_tfold<T>(ws, lo, c, c, I.data(), c, lo, -1, -1);
 }
 
 // V[:, c0:c0+r) <- V[:, c0:c0+c) * Q with Q on the HOST (column-major, leading dimension ldq), aware of lazily
@@ -1692,6 +1839,7 @@ template <class T> void rotate_lazy(ks_workspace* ws, int c0, int c, int r, cons
   using D = typename DevT<T>::type;
   if (c <= 0 || r <= 0) return;
   ws->ctx->use();
+  if (ws->t_lazy) materialize(ws);  // (T-lazy columns outside the rotated range would lose the columns they refer to)
   KS_HIP(hipStreamSynchronize(ws->ctx->stream));  // Qstage may still be in flight from a previous rotation
   if (ws->has_lazy() && ws->lazy_lo < c0) materialize(ws);
   T* qs = static_cast<T*>(ws->Qstage);
@@ -1713,6 +1861,7 @@ template <class T> void rotate_lazy(ks_workspace* ws, int c0, int c, int r, cons
 // destination comes out ordinary, every other column keeps its state.
 template <class D> void col_copy_lazy(ks_workspace* ws, int dst, int src) {
   ws->ctx->use();
+  if (ws->t_lazy) materialize(ws);
   const double f = ws->hostscale[src];
   if (dst == src) {
     if (f != 1.0) ksd::k_scale<D><<<ws->nb, kBlock, 0, ws->ctx->stream>>>(static_cast<D*>(ws->col(src)), ws->ld, f, nullptr);
@@ -1775,14 +1924,22 @@ template <class T> struct HipBackend : ks::Backend<T> {
     int j0 = from;
     while (j0 <= to) {
       const double tb0 = ks::now_s();
-      reset_state(ws);
       int jend = to;
       if (!op->async_capable) jend = j0;  // host operators: one step per batch
       const bool lazy = use_deferred(ws, jend);
+      const bool tpath = lazy && ws->passes == 2;    // implicit second pass: two reads of the basis per step
+      if (tpath && !(ws->t_lazy && j0 == ws->t_hi + 1)) {
+        materialize(ws);   // whatever is lazy (either kind) becomes ordinary: this batch starts a new T
+        ws->ntrue = j0;
+      }
+      reset_state(ws, tpath);
       const bool mb = lazy && ws->use_mbox;          // the device publishes the results itself, the host spins
-      const bool do_early = early && mb && jend == to;
+      const bool do_early = early && mb && !tpath && jend == to;  // (with two passes H is final only at the very end)
       const uint64_t seq = ++ws->mbox_seq;
-      if (lazy) {
+      if (tpath) {
+        enqueue_steps_t<D>(ws, op, j0, jend);
+      } else if (lazy) {
+        if (ws->t_lazy) materialize(ws);
         enqueue_steps_deferred<D>(ws, op, j0, jend, do_early ? seq : 0);
       } else {
         materialize(ws);  // the eager kernels expect ordinary columns
@@ -1794,8 +1951,8 @@ template <class T> struct HipBackend : ks::Backend<T> {
       bool early_ran = false;
       static const int dbg = env_int("KS_EARLY_DEBUG", 0);
       double tq0 = dbg ? ks::now_s() : 0.0, tq1 = 0, tq2 = 0;
-      if (mb) publish_control(ws, j0, ws->Hstage_dev, 1, seq);
-      else fetch_state_enqueue(ws, j0);
+      if (mb) publish_control(ws, j0, ws->Hstage_dev, 1, seq, tpath);
+      else fetch_state_enqueue(ws, j0, tpath);
       if (do_early) {
         mbox_wait(ws, 0, seq);
         if (dbg) tq1 = ks::now_s();
@@ -1839,7 +1996,15 @@ template <class T> struct HipBackend : ks::Backend<T> {
         lazy_factors_from_stage<T>(ws, j0, jend, ws->Hstage);
         early_stands = true;
       } else {
-        fetch_H_columns<T>(ws, j0, last_done, H, lazy);
+        fetch_H_columns<T>(ws, j0, last_done, H, lazy && !tpath);
+      }
+      if (tpath) {
+        // columns j0 .. (last completed step) are T-lazy now; a column that broke down is garbage until reinit_column
+        const int good = bd >= 0 ? bd - 1 : jend;
+        if (good >= ws->ntrue) {
+          ws->t_lazy = true;
+          ws->t_hi = good;
+        }
       }
       stats.steps += last_done - j0 + 1;
       stats.reorth += ws->st_h->n_reorth;
@@ -1870,6 +2035,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
   // V[:, dst] <- V[:, src]: the last act of a restart (src = maxdim holds the residual direction).  Every
   // column that is still lazy afterwards is dead (it lies beyond the truncated basis) -> reset the factors.
   void col_copy(int dst, int src) override {
+    if (ws->t_lazy) materialize(ws);
     const double copy_factor = ws->hostscale[src];
     if (dst != src || copy_factor != 1.0) {
       if (dst == src)
@@ -1879,6 +2045,19 @@ template <class T> struct HipBackend : ks::Backend<T> {
       KS_HIP(hipGetLastError());
     }
     reset_lazy(ws);
+  }
+
+  // src/run.jl:363-365 as ONE operation.  With the implicit second pass the basis is S T: the rotation and the move of
+  // the residual direction are one T-folded product S[:, 0:src+1) [ T Q | T[:, src] ] (the columns it does not write are
+  // the ones the restart discards).
+  void rotate_and_move(int c0, int c, int r, const ks::Mat<T>& Q, int dst, int src) override {
+    if (ws->t_lazy) {
+      rotate_tfold<T>(ws, c0, c, r, r > 0 ? &Q(c0, c0) : nullptr, Q.ld, c0, src, dst);
+      reset_lazy(ws);
+      return;
+    }
+    rotate(c0, c, r, Q);
+    col_copy(dst, src);
   }
 };
 
@@ -2484,14 +2663,19 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     }
     KS_HIP(hipMemsetAsync(w->V, 0, vbytes, ctx->stream));
     const size_t hbytes = (size_t)(maxdim + 1) * maxdim * esz, qbytes = (size_t)maxdim * maxdim * esz;
+    const size_t qxbytes = (size_t)(maxdim + 1) * (maxdim + 1) * esz;  // T-folded rotations: one more row and column
     KS_HIP(hipHostMalloc(&w->H, hbytes));
     KS_HIP(hipHostMalloc(&w->Q, qbytes));
     // control block: [ Hd | DevState (128-byte slot) | colscale ] on the device, the same layout pinned on the host
     w->hd_bytes = (size_t)round_up((int64_t)hbytes, 64);
-    const size_t ctl_bytes = w->hd_bytes + kCtlStateSlot + (size_t)(maxdim + 2) * 8;
+    w->ldt = maxdim + 1;
+    w->off_T = (size_t)round_up((int64_t)(w->hd_bytes + kCtlStateSlot + (size_t)(maxdim + 2) * 8), 64);
+    w->off_g = w->off_T + (size_t)w->ldt * w->ldt * esz;
+    w->ctl_bytes = (size_t)round_up((int64_t)(w->off_g + (size_t)w->ldt * esz), 64);
+    const size_t ctl_bytes = w->ctl_bytes;
     static_assert(sizeof(DevState) <= kCtlStateSlot, "DevState must fit its slot of the control block");
     KS_HIP(hipHostMalloc(&w->Hstage, ctl_bytes));
-    KS_HIP(hipHostMalloc(&w->Qstage, qbytes));
+    KS_HIP(hipHostMalloc(&w->Qstage, qxbytes));
     KS_HIP(hipHostMalloc(&w->Hstage_early, ctl_bytes));
     std::memset(w->Hstage_early, 0, ctl_bytes);
     KS_HIP(hipHostMalloc(reinterpret_cast<void**>(&w->mbox), 128));
@@ -2509,6 +2693,12 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     w->st_h = reinterpret_cast<DevState*>(static_cast<char*>(w->Hstage) + w->hd_bytes);
     w->colscale = reinterpret_cast<double*>(static_cast<char*>(w->Hd) + w->hd_bytes + kCtlStateSlot);
     w->cs_h = reinterpret_cast<double*>(static_cast<char*>(w->Hstage) + w->hd_bytes + kCtlStateSlot);
+    w->Td = static_cast<char*>(w->Hd) + w->off_T;
+    w->gd = static_cast<char*>(w->Hd) + w->off_g;
+    w->Th = static_cast<char*>(w->Hstage) + w->off_T;
+    KS_HIP(hipMalloc(reinterpret_cast<void**>(&w->ctr), 64));
+    KS_HIP(hipMemsetAsync(w->ctr, 0, 64, ctx->stream));
+    w->passes = env_int("KS_PASSES", 2) == 3 ? 3 : 2;
     KS_HIP(hipMalloc(&w->Hscratch, (size_t)(maxdim + 2) * esz));
     KS_HIP(hipMalloc(&w->partial, (size_t)w->pnb * w->pstride * esz));
     KS_HIP(hipMalloc(&w->partial2, (size_t)std::max(w->pnb, ctx->num_cu * 8) * 8));
@@ -2518,7 +2708,7 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     KS_HIP(hipMalloc(&w->scal, 64));
     KS_HIP(hipHostMalloc(&w->scal_h, 64));
     KS_HIP(hipHostMalloc(&w->coef_h, (size_t)w->pstride * esz));
-    KS_HIP(hipMalloc(&w->Qd, std::max<size_t>(qbytes, 16)));
+    KS_HIP(hipMalloc(&w->Qd, std::max<size_t>(qxbytes, 16)));
     w->oop_mode = env_int("KS_OOP", 2);
     if (w->oop_mode == 1 || w->oop_mode == 2) {
       const size_t ob = (size_t)(w->oop_mode == 1 ? 2 : 1) * w->ld * esz;
@@ -2535,6 +2725,13 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     reset_state(w.get());
     KS_HIP(hipStreamSynchronize(ctx->stream));
     *out = w.release();
+  });
+}
+
+int ks_workspace_passes(const ks_workspace* ws, int* passes) {
+  return guarded([&] {
+    KS_REQUIRE(ws && passes, KS_ERR_ARGUMENT, "null argument");
+    *passes = ws->passes;
   });
 }
 
@@ -2932,8 +3129,7 @@ int ks_restart(ks_workspace* ws, const ks_params* p, int active, int* k_out, int
       const ks::RestartResult r =
           ks::restart_host_step(H, Q, prm.maxdim, prm.mindim, prm.nev, ks::Ordering{prm.which}, prm.tol, active, sc);
       HipBackend<T> be(nullptr, ws);
-      be.rotate(r.purge, prm.maxdim - r.purge, r.k - r.purge, Q);  // src/run.jl:363-364
-      be.col_copy(r.k, prm.maxdim);                                 // src/run.jl:365
+      be.rotate_and_move(r.purge, prm.maxdim - r.purge, r.k - r.purge, Q, r.k, prm.maxdim);  // src/run.jl:363-365
       if (k_out) *k_out = r.k;
       if (nlock_out) *nlock_out = r.nlock;
       if (purge_out) *purge_out = r.purge;
@@ -2972,8 +3168,7 @@ int ks_expand_restart(ks_operator* A, ks_workspace* ws, const ks_params* p, int 
       if (!early_done) ks::restart_host_early(H, Q, prm.maxdim, ordering, active, sc);
       const ks::RestartResult r = ks::restart_host_late(H, Q, prm.maxdim, prm.mindim, prm.nev, prm.tol, active, sc);
       double t2 = ks::now_s();
-      be.rotate(r.purge, prm.maxdim - r.purge, r.k - r.purge, Q);  // src/run.jl:363-364
-      be.col_copy(r.k, prm.maxdim);                                 // src/run.jl:365
+      be.rotate_and_move(r.purge, prm.maxdim - r.purge, r.k - r.purge, Q, r.k, prm.maxdim);  // src/run.jl:363-365
       double t3 = ks::now_s();
       if (k_out) *k_out = r.k;
       if (nlock_out) *nlock_out = r.nlock;

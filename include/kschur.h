@@ -180,6 +180,10 @@ int ks_workspace_destroy(ks_workspace* ws);
  * candidate allocations were refused or skipped for lack of free memory.  The search holds at most
  * KS_PLACE_MAX_X (default 2) times the basis size at once. */
 int ks_workspace_placement(const ks_workspace* ws, int* candidates, double* best_ms, double* worst_ms, int* refused);
+/* How many times the fused expansion reads the basis per step on this workspace: 2 = implicit second pass (default:
+ * the DGKS second projection, src/expansion.jl:93-94, is carried in a small triangular factor instead of being applied
+ * to the n-vector), 3 = the second projection is applied to the vector as the reference does (KS_PASSES=3 at creation). */
+int ks_workspace_passes(const ks_workspace* ws, int* passes);
 /* Debugging aid: with KS_GUARD=1 in the environment a workspace puts 1 MiB canary zones on both sides of the
  * basis; *intact = 0 if any kernel wrote outside V (always 1 without KS_GUARD). */
 int ks_workspace_check_guard(ks_workspace* ws, int* intact);
