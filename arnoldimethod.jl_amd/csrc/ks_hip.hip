@@ -1261,11 +1261,12 @@ template <class D> void launch_fin_norm(ks_workspace* ws, int nbp, int j, D* Hsu
 constexpr int kFusedMaxJ = 64;
 template <class D, int NCW, int U, int WB> int launch_axpy_dots_nc(ks_workspace* ws, int j, D* w, int defer, D* wdst = nullptr) {
   static int cache = -1;
+  static const int plain = env_int("KS_FUSED_PLAIN_STORE", 0);
   const int nb = cap_blocks(ws, resident_blocks(ws->ctx, ksd::k_axpy_dots_cs<D, NCW, U, WB>, 0, cache), 64 * U);
   ksd::k_axpy_dots_cs<D, NCW, U, WB><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const D*>(ws->V), ws->ld, j, w,
                                                                        static_cast<const D*>(ws->coef),
                                                                        static_cast<D*>(ws->partial), ws->pnb, ws->partial2,
-                                                                       ws->st, defer, wdst);
+                                                                       ws->st, defer, wdst, plain && ws->passes == 2);
   return nb;
 }
 template <class D> int launch_axpy_dots(ks_workspace* ws, int j, D* w, int defer, D* wdst = nullptr) {

@@ -972,7 +972,7 @@ template <class T, int NCW, int U, int WB>
 __global__ void __launch_bounds__(kBlock)
     k_axpy_dots_cs(const T* __restrict__ V, int64_t ldv, int j, T* __restrict__ w, const T* __restrict__ coef,
                    T* __restrict__ partial, int pnb, double* __restrict__ partial2, const DevState* __restrict__ st,
-                   int defer, T* __restrict__ wdst0 = nullptr) {
+                   int defer, T* __restrict__ wdst0 = nullptr, int plain_store = 0) {
   if (st && st->breakdown >= 0) return;
   T* __restrict__ wdst = wdst0 ? wdst0 : w;
   using P = typename Pack<T>::type;
@@ -1050,7 +1050,10 @@ __global__ void __launch_bounds__(kBlock)
         __syncthreads();
         const int64_t fb = base - (int64_t)(it % WB) * 64 * U;  // first pack staged
         const int64_t fe = (base + 64 * U < pe) ? base + 64 * U : pe;
-        for (int64_t o = fb + threadIdx.x; o < fe; o += kBlock) st_pack_nt(wdst + o * R, wout[o - fb]);
+        // plain_store: the new column is the NEXT kernel's gather source (two-pass expansion: the operator is applied to it
+        // right away) -- a cacheable store leaves it in the memory-side cache instead of streaming it past
+        if (plain_store) for (int64_t o = fb + threadIdx.x; o < fe; o += kBlock) st_pack(wdst + o * R, wout[o - fb]);
+        else for (int64_t o = fb + threadIdx.x; o < fe; o += kBlock) st_pack_nt(wdst + o * R, wout[o - fb]);
       }
     }
   }
@@ -1325,6 +1328,8 @@ __global__ void __launch_bounds__(kBlock)
 //   mode 3: peer-to-peer -- every workgroup exchanges its own element, the last one does the algebra.
 // ------------------------------------------------------------------------------------------------
 constexpr int kTMax = 65;  // kFusedMaxJ + 1
+constexpr int kTLdsBytes = 24576;  // LDS staging area for the non-trivial columns of T
+constexpr int kHLdsBytes = 24576;  // ... and for the block of H that g = H c reads
 __device__ __forceinline__ double conj_(double a) { return a; }
 __device__ __forceinline__ cd conj_(cd a) { return cd{a.x, -a.y}; }
 __device__ __forceinline__ double sub_(double a, double b) { return a - b; }
@@ -1384,24 +1389,39 @@ __global__ void __launch_bounds__(kBlock)
   if (st->breakdown >= 0) return;
   __shared__ T sm[kBlock];
   __shared__ T s_s[kTMax], t_s[kTMax];
+  const int tid = threadIdx.x;
+  // What the algebra stage needs besides the sums is fetched by EVERY workgroup up front (only the last one to arrive will
+  // use it, but nobody knows who that is, and the loads hide behind the reduction instead of adding round trips after
+  // it).  The columns of T that are not unit vectors (ntrue..j-1, rows 0..j-1) go to LDS with coalesced loads: T^H s walks
+  // DOWN a column per thread, which from global memory is one cache line per lane and load.
+  __shared__ __attribute__((aligned(16))) unsigned char tl_raw[kTLdsBytes];
+  T* Tl = reinterpret_cast<T*>(tl_raw);
+  const int nl = j - ntrue;  // > 0 only when factored columns exist
+  const bool use_lds = nl > 0 && nl * j <= (int)(kTLdsBytes / sizeof(T));
+  if (use_lds)
+    for (int e = tid; e < nl * j; e += kBlock) {
+      const int k = e % j, i = ntrue + e / j;
+      Tl[e] = (k <= i) ? Tm[k + (int64_t)i * ldt] : zero_of(T{});
+    }
+  const bool prev_true = (j - 1) < ntrue;
+  T gi = zero_of(T{});
+  if (tid < j && !prev_true) gi = gvec[tid];
   if (mode != 2) {
     const int c = blockIdx.x;  // 0..j: column c of the partials (column j = |y'|^2, accumulated by k_dots as a column)
     if (!fin_t_stage1<T>(partial + (int64_t)c * pnb, nb, false, nullptr, red, mode, p2p, counter, sm)) return;
   }
-  const int tid = threadIdx.x;
   if (tid <= j) s_s[tid] = ld_agent(red + tid);
   __syncthreads();
-  const bool prev_true = (j - 1) < ntrue;
-  const double binv = prev_true ? 1.0 : real_of(Tm[(j - 1) + (int64_t)(j - 1) * ldt]);  // 1 / beta of the input column
-  T ti = zero_of(T{}), gi = zero_of(T{});
+  auto Tat = [&](int k, int i) -> T { return use_lds ? Tl[k + (i - ntrue) * j] : Tm[k + (int64_t)i * ldt]; };  // i >= ntrue
+  const double binv = prev_true ? 1.0 : real_of(Tat(j - 1, j - 1));  // 1 / beta of the input column
+  T ti = zero_of(T{});
   if (tid < j) {
     if (tid < ntrue) {
       ti = s_s[tid];
-    } else {
-      const T* col = Tm + (int64_t)tid * ldt;  // t[i] = sum_{k <= i} conj(T[k,i]) s[k]
-      for (int k = 0; k <= tid; ++k) ti = fma_(conj_(col[k]), s_s[k], ti);
+    } else {  // t[i] = sum_{k <= i} conj(T[k,i]) s[k]
+#pragma unroll 4
+      for (int k = 0; k <= tid; ++k) ti = fma_(conj_(Tat(k, tid)), s_s[k], ti);
     }
-    if (!prev_true) gi = gvec[tid];
     t_s[tid] = ti;
     Hcol[tid] = scl(sub_(ti, gi), binv);  // h = V_true^H (A v_true)
   }
@@ -1423,7 +1443,8 @@ __global__ void __launch_bounds__(kBlock)
       a = t_s[tid];
       k0 = ntrue;
     }
-    for (int k = k0; k < j; ++k) a = fma_(Tm[tid + (int64_t)k * ldt], t_s[k], a);
+#pragma unroll 4
+    for (int k = k0; k < j; ++k) a = fma_(Tat(tid, k), t_s[k], a);
     coef[tid] = scl(a, binv);
   }
 }
@@ -1437,21 +1458,41 @@ __global__ void __launch_bounds__(kBlock)
   __shared__ T sm[kBlock];
   __shared__ T c_s[kTMax];
   __shared__ double scal_s[2];
+  const int tid = threadIdx.x;
+  T* Hcol = Hd + (int64_t)(j - 1) * ldh;
+  // prefetched by every workgroup (see k_fin_dots_t): the non-trivial columns of T, this step's h, and the block of H
+  // that g = H c reads (rows 0..j, columns 0..j-2; column j-1 is being finished right here)
+  __shared__ __attribute__((aligned(16))) unsigned char tl_raw[kTLdsBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char hl_raw[kHLdsBytes];
+  T* Tl = reinterpret_cast<T*>(tl_raw);
+  T* Hl = reinterpret_cast<T*>(hl_raw);
+  const int nl = j - ntrue;
+  const bool use_lds = nl > 0 && nl * j <= (int)(kTLdsBytes / sizeof(T));
+  if (use_lds)
+    for (int e = tid; e < nl * j; e += kBlock) {
+      const int k = e % j, i = ntrue + e / j;
+      Tl[e] = (k <= i) ? Tm[k + (int64_t)i * ldt] : zero_of(T{});
+    }
+  const int hr = j + 1, hc = j - 1;
+  const bool h_lds = hc > 0 && hr * hc <= (int)(kHLdsBytes / sizeof(T));
+  if (h_lds)
+    for (int e = tid; e < hr * hc; e += kBlock) Hl[e] = Hd[(e % hr) + (int64_t)(e / hr) * ldh];
+  T h0 = zero_of(T{});
+  if (tid < j) h0 = Hcol[tid];  // written by this step's k_fin_dots_t
   if (mode != 2) {
     const int c = blockIdx.x;  // c < j: speculative second-pass inner product with stored column c;  c == j: ||w'||^2
     if (!fin_t_stage1<T>(partial + (int64_t)c * pnb, nb, c == j, partial2, red, mode, p2p, counter, sm)) return;
   }
-  const int tid = threadIdx.x;
-  T* Hcol = Hd + (int64_t)(j - 1) * ldh;
   if (tid <= j) c_s[tid] = ld_agent(red + tid);
   __syncthreads();
+  auto Tat = [&](int k, int i) -> T { return use_lds ? Tl[k + (i - ntrue) * j] : Tm[k + (int64_t)i * ldt]; };  // i >= ntrue
   T ci = zero_of(T{});
   if (tid < j) {  // c = T^H c_raw = V_true^H w'
     if (tid < ntrue) {
       ci = c_s[tid];
     } else {
-      const T* col = Tm + (int64_t)tid * ldt;
-      for (int k = 0; k <= tid; ++k) ci = fma_(conj_(col[k]), c_s[k], ci);
+#pragma unroll 4
+      for (int k = 0; k <= tid; ++k) ci = fma_(conj_(Tat(k, tid)), c_s[k], ci);
     }
   }
   const double wn2 = real_of(c_s[j]);
@@ -1484,13 +1525,12 @@ __global__ void __launch_bounds__(kBlock)
       st->inv_norm = 0.0;
       if (reorth) st->n_reorth += 1;
     }
-    if (reorth && tid < j) Hcol[tid] = add_(Hcol[tid], ci);  // h .+= correction happens before the test, :95
+    if (reorth && tid < j) Hcol[tid] = add_(h0, ci);  // h .+= correction happens before the test, :95
     return;
   }
   const double binv = 1.0 / beta;
-  T hi = zero_of(T{});
+  T hi = h0;
   if (tid < j) {
-    hi = Hcol[tid];
     if (reorth) {
       hi = add_(hi, ci);  // :95
       Hcol[tid] = hi;
@@ -1506,14 +1546,17 @@ __global__ void __launch_bounds__(kBlock)
         a = c_s[tid];
         k0 = ntrue;
       }
-      for (int k = k0; k < j; ++k) a = fma_(Tm[tid + (int64_t)k * ldt], c_s[k], a);
+#pragma unroll 4
+      for (int k = k0; k < j; ++k) a = fma_(Tat(tid, k), c_s[k], a);
     }
     Tm[tid + (int64_t)j * ldt] = scl(neg_(a), binv);
   }
   if (tid <= j) {  // g for the next step: H[0:j+1, 0:j] c   (upper Hessenberg: H[i,k] = 0 for k < i-1)
     T g = zero_of(T{});
     if (reorth) {
-      for (int k = (tid > 0 ? tid - 1 : 0); k < j - 1; ++k) g = fma_(Hd[tid + (int64_t)k * ldh], c_s[k], g);
+#pragma unroll 8
+      for (int k = (tid > 0 ? tid - 1 : 0); k < j - 1; ++k)
+        g = fma_(h_lds ? Hl[tid + k * hr] : Hd[tid + (int64_t)k * ldh], c_s[k], g);
       const T hlast = (tid < j) ? hi : from_real(beta, T{});  // column j-1 of H as this step leaves it
       g = fma_(hlast, c_s[j - 1], g);
     }

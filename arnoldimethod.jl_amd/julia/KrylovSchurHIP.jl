@@ -417,8 +417,13 @@ function ArnoldiMethod.iterate_arnoldi!(A::HipOperator{T}, arnoldi::ArnoldiWorks
     isempty(range) && return arnoldi
     w = arnoldi.V.ws
     st = Ref(KsExpandStats(0, 0, 0, 0))
-    check(ccall((:ks_iterate_arnoldi, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Ref{KsExpandStats}), A.h, w.h, first(range), last(range), st))
     H = arnoldi.H
+    if H !== w.H && first(range) > 1
+        # the library's expansion reads the CURRENT Hessenberg matrix (implicit second DGKS pass: g = H c); the reference's
+        # restart code rewrote the leading block of the caller's H on the host -> hand it over first
+        @views copyto!(w.H[:, 1:first(range)-1], H[:, 1:first(range)-1])
+    end
+    check(ccall((:ks_iterate_arnoldi, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Ref{KsExpandStats}), A.h, w.h, first(range), last(range), st))
     if H !== w.H
         for j in range
             @views copyto!(H[1:j+1, j], w.H[1:j+1, j])

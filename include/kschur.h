@@ -239,7 +239,9 @@ int ks_reinitialize(ks_workspace* ws, int j, const void* v1_host, int* ok);
 /* iterate_arnoldi!(A, arnoldi, from:to)   src/expansion.jl:116-133  (from/to as in the
  * reference: step j builds 0-based column j from column j-1).  The whole range is enqueued
  * asynchronously (operator apply + fused DGKS per step, decisions on-device) and the host
- * synchronises once at the end to fetch the new columns of H. */
+ * synchronises once at the end to fetch the new columns of H.  Columns < from of the workspace's host H (ks_workspace_H)
+ * must hold the current Hessenberg matrix on entry: the default expansion (ks_workspace_passes == 2) reads it on the
+ * device (g = H c of the implicit second DGKS pass). */
 typedef struct ks_expand_stats {
   int32_t steps;       /* operator applications performed                                    */
   int32_t reorth;      /* steps whose DGKS test requested the second pass (src/expansion.jl:91) */

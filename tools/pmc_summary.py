@@ -2,7 +2,7 @@
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (collected in SEPARATE runs, each with only
 --kernel-trace next to --pmc) per kernel, and write profiles/pmc_traffic.json for bench.py.
 
-usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <n> <nnz> [out.json] [bytes_per_nnz] [index_bytes_per_row]
+usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <n> <nnz> [out.json] [bytes_per_nnz] [index_bytes_per_row] [rotation_columns]
 (bytes_per_nnz: what the SpMV layout in use streams per stored entry -- 12 plain CSR, 4 value-indexed, 1
 delta-value-indexed; `bench.py` prints it as config.spmv_layout)
 
@@ -50,6 +50,7 @@ def main():
     out = sys.argv[5] if len(sys.argv) > 5 else None
     bpn = float(sys.argv[6]) if len(sys.argv) > 6 else 12.0
     aux = float(sys.argv[7]) if len(sys.argv) > 7 else 4.0  # index bytes per row next to the non-zeros (4: rowptr; 0: stencil-mask layout)
+    rot_cols = float(sys.argv[8]) if len(sys.argv) > 8 else 60.0  # columns the restart rotation reads + writes (T-folded: 41 + 21)
     def after_calibration(rows):
         # the launches before the first SpMV are the placement search of ks_workspace_create; their number
         # differs from process to process
@@ -92,7 +93,7 @@ def main():
         elif k == "scale":
             alg = 2 * col
         elif k == "rotate":
-            alg = col * 60  # the restart of the bench workload reads 40 columns and writes 20
+            alg = col * rot_cols  # the restart of the bench workload reads 40 columns and writes 20 (T-folded form: 41 and 21)
         else:
             alg = None
         e = per[k]
