@@ -321,6 +321,10 @@ struct ks_operator {
   double bytes_per_nnz = 0.0;  // what the SpMV streams per stored non-zero (0: not a stored-matrix operator)
   double aux_bytes = 0.0;      // index structures next to the non-zeros (row pointers, slice offsets, permutation)
   int layout = -1;             // KS_LAYOUT_* of include/kschur.h (-1: not a stored sparse matrix)
+  // Inside an expansion the newest basis column is stored unnormalised (x = beta * v up to a correction in span(V)); the
+  // library's own operators are linear and do not care, a HOST callback is handed the vector scaled to unit norm and its
+  // result is scaled back (a user's inner solver may use absolute tolerances).  Set by the expansion before apply().
+  double in_scale = 1.0;
   virtual ~ks_operator() = default;
   // y = A x on device pointers, enqueued on ctx->stream; `st` lets the kernels of a batch skip work
   // after a breakdown.
@@ -584,8 +588,18 @@ struct HostCallbackOp : ks_operator {
     const size_t bytes = (size_t)n_local * (dtype == KS_F64 ? 8 : 16);
     KS_HIP(hipMemcpyAsync(xh, x, bytes, hipMemcpyDeviceToHost, ctx->stream));
     KS_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t nd = n_local * (dtype == KS_F64 ? 1 : 2);
+    if (in_scale != 1.0) {
+      double* xd = static_cast<double*>(xh);
+      for (int64_t i = 0; i < nd; ++i) xd[i] *= in_scale;
+    }
     const int rc = fn(user, xh, yh);
     KS_REQUIRE(rc == 0, KS_ERR_OPERATOR, "host operator callback returned " + std::to_string(rc));
+    if (in_scale != 1.0) {
+      const double back = 1.0 / in_scale;
+      double* yd = static_cast<double*>(yh);
+      for (int64_t i = 0; i < nd; ++i) yd[i] *= back;
+    }
     KS_HIP(hipMemcpyAsync(y, yh, bytes, hipMemcpyHostToDevice, ctx->stream));
   }
 };
@@ -1433,7 +1447,10 @@ template <class D> void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op
     D* w1 = S1 ? S1 : w;          // where the first projection writes (and the second-pass update reads)
     D* Hcol = Hd + (size_t)(j - 1) * ldh;
     D* Hsub_prev = (j >= 2) ? Hd + (size_t)(j - 2) * ldh + (j - 1) : Hcol;  // only touched when a norm is pending
-    if (op) op->apply(ws->col(j - 1), y, ws->st);
+    if (op) {
+      op->in_scale = op->async_capable ? 1.0 : ws->hostscale[j - 1];
+      op->apply(ws->col(j - 1), y, ws->st);
+    }
     int nbd;
     {
       ProfScope ps(cx, KSP_DOTS, nb8 * (j + 1));
@@ -1522,6 +1539,10 @@ template <class D> void enqueue_steps_t(ks_workspace* ws, ks_operator* op, int f
     D* w = static_cast<D*>(ws->col(j));
     D* y = S0 ? S0 : w;  // where the product lands; the projection reads it and writes column j
     D* Hcol = Hd + (size_t)(j - 1) * ldh;
+    // (host callbacks run one step per batch: the factor of the input column is on the host by now)
+    op->in_scale = (!op->async_capable && ws->t_lazy && j - 1 >= ws->ntrue && j - 1 <= ws->t_hi)
+                       ? reinterpret_cast<const double*>(static_cast<const char*>(ws->Th) + ((size_t)(j - 1) + (size_t)(j - 1) * ws->ldt) * ws->esz)[0]
+                       : 1.0;
     op->apply(ws->col(j - 1), y, ws->st);
     int nbd;
     {
@@ -1945,6 +1966,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
       } else {
         materialize(ws);  // the eager kernels expect ordinary columns
         for (int j = j0; j <= jend; ++j) {
+          op->in_scale = 1.0;
           op->apply(ws->col(j - 1), ws->col(j), ws->st);
           enqueue_orthogonalize<D>(ws, j);
         }
@@ -2088,6 +2110,7 @@ void relation_norms(ks_operator* A, ks_workspace* ws, int nx, int ny, const T* C
   const int nbk = c->num_cu * 4;
   double r2 = 0.0;
   for (int i = 0; i < nx; ++i) {
+    A->in_scale = 1.0;
     A->apply(ws->col(i), y, nullptr);
     std::memcpy(ws->coef_h, C + (size_t)i * ldc, (size_t)ny * sizeof(T));
     KS_HIP(hipMemcpyAsync(ws->coef, ws->coef_h, (size_t)ny * sizeof(T), hipMemcpyHostToDevice, s));
@@ -2622,6 +2645,7 @@ int ks_operator_apply_raw(ks_operator* op, const void* x_dev, void* y_dev) {
   return guarded([&] {
     KS_REQUIRE(op && x_dev && y_dev, KS_ERR_ARGUMENT, "null argument");
     op->ctx->use();
+    op->in_scale = 1.0;
     op->apply(x_dev, y_dev, nullptr);
   });
 }
@@ -2921,6 +2945,7 @@ int ks_apply(ks_operator* A, ks_workspace* ws, int jsrc, int jdst) {
     KS_REQUIRE(A->n_local == ws->n && A->dtype == ws->dtype, KS_ERR_DIMENSION, "operator / workspace mismatch");
     ws->ctx->use();
     materialize(ws);
+    A->in_scale = 1.0;
     A->apply(ws->col(jsrc), ws->col(jdst), nullptr);
     KS_HIP(hipStreamSynchronize(ws->ctx->stream));
   });

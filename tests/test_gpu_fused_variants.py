@@ -476,3 +476,25 @@ def test_implicit_second_pass_when_the_correction_is_not_small():
         V = ws.V
         assert np.linalg.norm(V.T @ V - np.eye(m + 1)) < 200 * EPS * (m + 1), (n, rank)
         assert np.linalg.norm(B @ V[:, :m] - V @ H) < 1e-13 * max(1.0, np.linalg.norm(B)) * (m + 1), (n, rank)
+
+
+@pytest.mark.parametrize("passes", ["2", "3"])
+def test_host_callback_sees_unit_norm_vectors(passes, monkeypatch):
+    """Inside an expansion the newest column is stored unnormalised (and, with the implicit second pass, uncorrected); a
+    HOST callback -- a user's LinearMap, possibly wrapping an inner solver with absolute tolerances -- is nevertheless
+    handed a vector of norm 1 (to rounding), as the reference would hand it (src/expansion.jl:106,121)."""
+    monkeypatch.setenv("KS_PASSES", passes)
+    A, n = _operator(np.float64, (9, 10, 11))
+    A = A * 37.0                                   # sub-diagonal entries of H far from 1
+    norms = []
+
+    def mul(y, x):
+        norms.append(np.linalg.norm(x))
+        np.copyto(y, A @ x)
+
+    op = pkg.host_operator(mul, n, np.float64)
+    dec, hist = pkg.partialschur(op, v1=_start(np.float64, n), nev=4, which="LM", tol=1e-10, mindim=8, maxdim=16, restarts=100)
+    assert hist.converged and len(norms) == hist.mvproducts
+    assert np.abs(np.array(norms) - 1.0).max() < 1e-10
+    ref = np.sort(np.linalg.eigvalsh(A.toarray()))[::-1][:4]
+    np.testing.assert_allclose(np.sort(dec.eigenvalues.real)[::-1], ref, rtol=1e-9)
