@@ -1068,9 +1068,10 @@ struct ks_workspace {
   void* Hstage = nullptr;   // pinned host staging for Hd
   void* Hscratch = nullptr; // device, maxdim+1 elements (verbs that must not touch H)
   void* partial = nullptr;  // device, nblocks x pstride elements
+  void* partial_s = nullptr; // device, same size: k_dots' partial sums in the two-pass expansion (both sets live at once)
   double* partial2 = nullptr;  // device, nblocks doubles
   void* coef = nullptr;     // device, pstride + 136 elements
-  void* red = nullptr;      // device, pstride elements (all-reduce buffer)
+  void* red = nullptr;      // device, 2 pstride + 8 elements (all-reduce buffer)
   double* scal = nullptr;   // device, 8 doubles
   double* scal_h = nullptr; // pinned host, 8 doubles
   void* coef_h = nullptr;   // pinned host, pstride elements
@@ -1149,7 +1150,7 @@ struct ks_workspace {
   }
   ~ks_workspace() {
     (void)hipFree(Vbase ? Vbase : V); (void)hipHostFree(H); (void)hipHostFree(Q); (void)hipFree(Hd); (void)hipHostFree(Hstage);
-    (void)hipFree(Hscratch); (void)hipFree(partial); (void)hipFree(partial2); (void)hipFree(coef); (void)hipFree(red);
+    (void)hipFree(Hscratch); (void)hipFree(partial); (void)hipFree(partial_s); (void)hipFree(partial2); (void)hipFree(coef); (void)hipFree(red);
     (void)hipFree(scal); (void)hipHostFree(scal_h); (void)hipHostFree(coef_h);
     (void)hipFree(Qd); (void)hipHostFree(Qstage); (void)hipFree(tmp); (void)hipFree(tmp2); (void)hipFree(oop);
     (void)hipHostFree(Hstage_early); (void)hipHostFree(mbox); (void)hipFree(ctr);
@@ -1216,9 +1217,9 @@ void launch_dots_nc(ks_workspace* ws, int nb, const D* V, int jc, const D* w, D*
 
 // partial[b][0..j) = V[:,0:j)^H w (block-local), partial[b][j] = |w|^2 (block-local); returns the
 // number of workgroups that wrote partials
-template <class D> int launch_dots(ks_workspace* ws, int j, const D* w, int pass, const DevState* st) {
+template <class D> int launch_dots(ks_workspace* ws, int j, const D* w, int pass, const DevState* st, D* partial_out = nullptr) {
   const D* V = static_cast<const D*>(ws->V);
-  D* partial = static_cast<D*>(ws->partial);
+  D* partial = partial_out ? partial_out : static_cast<D*>(ws->partial);
   const int nb = cap_blocks(ws, dots_blocks_for<D>(ws, (std::min(j, 40) + 3) / 4), kBlock);  // first chunk is the widest
   for (int c0 = 0; c0 < j; c0 += 40) {
     const int jc = std::min(40, j - c0);
@@ -1514,8 +1515,9 @@ template <class D> void enqueue_steps_deferred(ks_workspace* ws, ks_operator* op
 }
 
 // Fused expansion steps from..to with the IMPLICIT SECOND PASS (ks_kernels.hpp): per step
-//   SpMV -> DOTS -> FIN_DOTS_T -> AXPY+DOTS -> FIN_MID_T
-// (5 launches, 2 reductions, TWO passes over the basis whether or not the DGKS test asks for the second projection).
+//   SpMV -> DOTS -> FIN_STEP_T -> AXPY+DOTS            and one more FIN_STEP_T after the last step
+// (4 launches, ONE reduction / exchange, TWO passes over the basis whether or not the DGKS test asks for the second
+// projection).  FIN_STEP_T of step j settles the second reduction of step j-1 together with the first one of step j.
 template <class D> void enqueue_steps_t(ks_workspace* ws, ks_operator* op, int from, int to) {
   ks_ctx* cx = ws->ctx;
   hipStream_t s = cx->stream;
@@ -1525,7 +1527,8 @@ template <class D> void enqueue_steps_t(ks_workspace* ws, ks_operator* op, int f
   D* gv = static_cast<D*>(ws->gd);
   D* red = static_cast<D*>(ws->red);
   D* coef = static_cast<D*>(ws->coef);
-  const D* part = static_cast<const D*>(ws->partial);
+  const D* part_c = static_cast<const D*>(ws->partial);    // written by the projection kernel (c_raw)
+  D* part_s = static_cast<D*>(ws->partial_s);              // written by k_dots (s): must survive next to part_c
   double* redd = reinterpret_cast<double*>(ws->red);
   constexpr int dpe = (int)(sizeof(D) / 8);
   const double nb8 = (double)ws->n * sizeof(D);
@@ -1535,10 +1538,24 @@ template <class D> void enqueue_steps_t(ks_workspace* ws, ks_operator* op, int f
   const ksd::P2pDev pd = cx->p2p.dev;
   const int nt = ws->ntrue;
   D* S0 = ws->oop ? static_cast<D*>(ws->oop) : nullptr;
+  int nbf = 0;  // grid of the previous step's projection kernel (= number of its partial sums per column)
+  auto fin = [&](int jm, int jd, int nbd) {
+    ProfScope ps(cx, KSP_FIN, 0.0);
+    const int nwg = (jm ? jm + 1 : 0) + (jd ? jd + 1 : 0);
+    if (!dist || p2p) {
+      ksd::k_fin_step_t<D><<<nwg, kBlock, 0, s>>>(part_s, nbd, part_c, ws->partial2, nbf, ws->pnb, jm, jd, red, Hd, ldh, Tm, ws->ldt, nt, gv, coef,
+                                                  p2p ? 3 : 0, ws->st, pd, ws->ctr);
+    } else {
+      ksd::k_fin_step_t<D><<<nwg, kBlock, 0, s>>>(part_s, nbd, part_c, ws->partial2, nbf, ws->pnb, jm, jd, red, Hd, ldh, Tm, ws->ldt, nt, gv, coef, 1,
+                                                  ws->st, pd, ws->ctr);
+      cx->allreduce(redd, nwg * dpe);
+      ksd::k_fin_step_t<D><<<1, kBlock, 0, s>>>(part_s, nbd, part_c, ws->partial2, nbf, ws->pnb, jm, jd, red, Hd, ldh, Tm, ws->ldt, nt, gv, coef, 2,
+                                                ws->st, pd, ws->ctr);
+    }
+  };
   for (int j = from; j <= to; ++j) {
     D* w = static_cast<D*>(ws->col(j));
     D* y = S0 ? S0 : w;  // where the product lands; the projection reads it and writes column j
-    D* Hcol = Hd + (size_t)(j - 1) * ldh;
     // (host callbacks run one step per batch: the factor of the input column is on the host by now)
     op->in_scale = (!op->async_capable && ws->t_lazy && j - 1 >= ws->ntrue && j - 1 <= ws->t_hi)
                        ? reinterpret_cast<const double*>(static_cast<const char*>(ws->Th) + ((size_t)(j - 1) + (size_t)(j - 1) * ws->ldt) * ws->esz)[0]
@@ -1547,34 +1564,15 @@ template <class D> void enqueue_steps_t(ks_workspace* ws, ks_operator* op, int f
     int nbd;
     {
       ProfScope ps(cx, KSP_DOTS, nb8 * (j + 1));
-      nbd = launch_dots<D>(ws, j, y, 1, ws->st);
+      nbd = launch_dots<D>(ws, j, y, 1, ws->st, part_s);
     }
-    {
-      ProfScope ps(cx, KSP_FIN, 0.0);
-      if (!dist || p2p) {
-        ksd::k_fin_dots_t<D><<<j + 1, kBlock, 0, s>>>(part, nbd, ws->pnb, j, red, Hcol, Tm, ws->ldt, nt, gv, coef, p2p ? 3 : 0, ws->st, pd, ws->ctr);
-      } else {
-        ksd::k_fin_dots_t<D><<<j + 1, kBlock, 0, s>>>(part, nbd, ws->pnb, j, red, Hcol, Tm, ws->ldt, nt, gv, coef, 1, ws->st, pd, ws->ctr);
-        cx->allreduce(redd, (j + 1) * dpe);
-        ksd::k_fin_dots_t<D><<<1, kBlock, 0, s>>>(part, nbd, ws->pnb, j, red, Hcol, Tm, ws->ldt, nt, gv, coef, 2, ws->st, pd, ws->ctr);
-      }
-    }
-    int nbf;
+    fin(j > from ? j - 1 : 0, j, nbd);
     {
       ProfScope ps(cx, KSP_FUSED, nb8 * (j + 2));  // reads S[:,0:j) and y', writes w'
       nbf = launch_axpy_dots<D>(ws, j, y, 1, y == w ? nullptr : w);
     }
-    {
-      ProfScope ps(cx, KSP_FIN, 0.0);
-      if (!dist || p2p) {
-        ksd::k_fin_mid_t<D><<<j + 1, kBlock, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hd, ldh, Tm, ws->ldt, nt, gv, p2p ? 3 : 0, ws->st, pd, ws->ctr);
-      } else {
-        ksd::k_fin_mid_t<D><<<j + 1, kBlock, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hd, ldh, Tm, ws->ldt, nt, gv, 1, ws->st, pd, ws->ctr);
-        cx->allreduce(redd, (j + 1) * dpe);
-        ksd::k_fin_mid_t<D><<<1, kBlock, 0, s>>>(part, ws->partial2, nbf, ws->pnb, j, red, Hd, ldh, Tm, ws->ldt, nt, gv, 2, ws->st, pd, ws->ctr);
-      }
-    }
   }
+  fin(to, 0, 0);  // settle the last step
   KS_HIP(hipGetLastError());
 }
 
@@ -2726,10 +2724,11 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     w->passes = env_int("KS_PASSES", 2) == 3 ? 3 : 2;
     KS_HIP(hipMalloc(&w->Hscratch, (size_t)(maxdim + 2) * esz));
     KS_HIP(hipMalloc(&w->partial, (size_t)w->pnb * w->pstride * esz));
+    KS_HIP(hipMalloc(&w->partial_s, (size_t)w->pnb * w->pstride * esz));
     KS_HIP(hipMalloc(&w->partial2, (size_t)std::max(w->pnb, ctx->num_cu * 8) * 8));
     KS_HIP(hipMalloc(&w->coef, (size_t)(w->pstride + 136) * esz));
     KS_HIP(hipMemsetAsync(w->coef, 0, (size_t)(w->pstride + 136) * esz, ctx->stream));
-    KS_HIP(hipMalloc(&w->red, (size_t)w->pstride * esz));
+    KS_HIP(hipMalloc(&w->red, (size_t)(2 * w->pstride + 8) * esz));  // two reductions of <= maxdim+2 elements share a launch
     KS_HIP(hipMalloc(&w->scal, 64));
     KS_HIP(hipHostMalloc(&w->scal_h, 64));
     KS_HIP(hipHostMalloc(&w->coef_h, (size_t)w->pstride * esz));

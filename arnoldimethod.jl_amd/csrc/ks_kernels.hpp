@@ -1322,8 +1322,8 @@ __global__ void __launch_bounds__(kBlock)
 // decisions, same quantities as the reference up to rounding: validated against the oracle (same restart trail, products
 // and residuals, Ritz values to 1e-13).  Columns < ntrue are ordinary (T = identity there, never read).
 //
-// FIN_DOTS_T / FIN_MID_T: workgroup c reduces column c of the partial sums (the last one the squared norm), publishes it
-// in red[], and the LAST workgroup to arrive (device-scope counter) does the small algebra with 256 threads.
+// FIN_STEP_T (below): workgroup c reduces one column of the partial sums (the last one of each set the squared norm),
+// publishes it in red[], and the LAST workgroup to arrive (device-scope counter) does the small algebra with 256 threads.
 //   mode 0: single GPU;  mode 1: reduce only -> red (then all-reduce);  mode 2: algebra only from red (one workgroup);
 //   mode 3: peer-to-peer -- every workgroup exchanges its own element, the last one does the algebra.
 // ------------------------------------------------------------------------------------------------
@@ -1350,227 +1350,223 @@ __device__ __forceinline__ cd ld_agent(const cd* p) {
   return cd{ld_agent(q), ld_agent(q + 1)};
 }
 
-// reduce column c -> red[c] (all modes but 2) and elect the last workgroup; returns true in the workgroup that continues
-template <class T>
-__device__ __forceinline__ bool fin_t_stage1(const T* __restrict__ src, int nb, bool as_real, const double* __restrict__ src2,
-                                             T* __restrict__ red, int mode, const P2pDev& p2p, unsigned* __restrict__ counter,
-                                             T* sm) {
-  __shared__ int last_wg;
-  const int c = blockIdx.x;
-  T s;
-  if (as_real) s = from_real(block_sum(src2, nb, reinterpret_cast<double*>(sm)), T{});
-  else s = block_sum(src + 0, nb, sm);
-  if (mode == 3 && threadIdx.x < 64) {
-    T g;
-    double dummy;
-    p2p_pair(p2p, c, s, 0.0, g, dummy);
-    s = g;
-  }
-  if (threadIdx.x == 0) {
-    red[c] = s;
-    if (mode != 1) {
-      __threadfence();
-      last_wg = (atomicAdd(counter, 1u) == gridDim.x - 1) ? 1 : 0;
-    }
-  }
-  if (mode == 1) return false;
-  __syncthreads();
-  if (!last_wg) return false;
-  if (threadIdx.x == 0) *counter = 0u;  // armed for the next launch (stream order)
-  __threadfence();
-  return true;
-}
-
+// FIN_STEP_T: ONE reduction kernel per Arnoldi step.  The second reduction of step jm (c_raw, ||w'||^2 from the projection
+// kernel) is not needed before the NEXT step's first reduction (s = S^H y', |y'|^2 from k_dots): the operator and k_dots of
+// step jm+1 work on stored columns only.  So both are reduced by the same launch -- 2j+3 workgroups, one election, one
+// exchange in the multi-GPU modes -- and the last workgroup runs the algebra of both in order:
+//   MID(jm):  c = T^H c_raw; DGKS test; h += c; beta; breakdown test; H[jm, jm-1] = beta; column jm of T; g
+//   DOTS(jd): t = T^H s; h = (t - g)/beta -> H[0:jd, jd-1]; rnorm; coefficient vector T t / beta       (jd = jm + 1)
+// jm = 0: first step of a batch (nothing pending);  jd = 0: after the last step (settle it).  The breakdown of step jm
+// is thus detected after the operator and k_dots of step jm+1 already ran (on a column that is then discarded).
+// red[0 .. jm] = MID sums (last = ||w'||^2), red[nm .. nm+jd] = DOTS sums (last = |y'|^2), nm = jm ? jm+1 : 0.
 template <class T>
 __global__ void __launch_bounds__(kBlock)
-    k_fin_dots_t(const T* __restrict__ partial, int nb, int pnb, int j, T* __restrict__ red, T* __restrict__ Hcol,
-                 const T* __restrict__ Tm, int ldt, int ntrue, const T* __restrict__ gvec, T* __restrict__ coef, int mode,
-                 DevState* __restrict__ st, P2pDev p2p, unsigned* __restrict__ counter) {
+    k_fin_step_t(const T* __restrict__ part_s, int nb_s, const T* __restrict__ part_c, const double* __restrict__ partial2,
+                 int nb_c, int pnb, int jm, int jd, T* __restrict__ red, T* __restrict__ Hd, int ldh, T* __restrict__ Tm,
+                 int ldt, int ntrue, T* __restrict__ gvec, T* __restrict__ coef, int mode, DevState* __restrict__ st,
+                 P2pDev p2p, unsigned* __restrict__ counter) {
   if (st->breakdown >= 0) return;
   __shared__ T sm[kBlock];
-  __shared__ T s_s[kTMax], t_s[kTMax];
-  const int tid = threadIdx.x;
-  // What the algebra stage needs besides the sums is fetched by EVERY workgroup up front (only the last one to arrive will
-  // use it, but nobody knows who that is, and the loads hide behind the reduction instead of adding round trips after
-  // it).  The columns of T that are not unit vectors (ntrue..j-1, rows 0..j-1) go to LDS with coalesced loads: T^H s walks
-  // DOWN a column per thread, which from global memory is one cache line per lane and load.
-  __shared__ __attribute__((aligned(16))) unsigned char tl_raw[kTLdsBytes];
-  T* Tl = reinterpret_cast<T*>(tl_raw);
-  const int nl = j - ntrue;  // > 0 only when factored columns exist
-  const bool use_lds = nl > 0 && nl * j <= (int)(kTLdsBytes / sizeof(T));
-  if (use_lds)
-    for (int e = tid; e < nl * j; e += kBlock) {
-      const int k = e % j, i = ntrue + e / j;
-      Tl[e] = (k <= i) ? Tm[k + (int64_t)i * ldt] : zero_of(T{});
-    }
-  const bool prev_true = (j - 1) < ntrue;
-  T gi = zero_of(T{});
-  if (tid < j && !prev_true) gi = gvec[tid];
-  if (mode != 2) {
-    const int c = blockIdx.x;  // 0..j: column c of the partials (column j = |y'|^2, accumulated by k_dots as a column)
-    if (!fin_t_stage1<T>(partial + (int64_t)c * pnb, nb, false, nullptr, red, mode, p2p, counter, sm)) return;
-  }
-  if (tid <= j) s_s[tid] = ld_agent(red + tid);
-  __syncthreads();
-  auto Tat = [&](int k, int i) -> T { return use_lds ? Tl[k + (i - ntrue) * j] : Tm[k + (int64_t)i * ldt]; };  // i >= ntrue
-  const double binv = prev_true ? 1.0 : real_of(Tat(j - 1, j - 1));  // 1 / beta of the input column
-  T ti = zero_of(T{});
-  if (tid < j) {
-    if (tid < ntrue) {
-      ti = s_s[tid];
-    } else {  // t[i] = sum_{k <= i} conj(T[k,i]) s[k]
-#pragma unroll 4
-      for (int k = 0; k <= tid; ++k) ti = fma_(conj_(Tat(k, tid)), s_s[k], ti);
-    }
-    t_s[tid] = ti;
-    Hcol[tid] = scl(sub_(ti, gi), binv);  // h = V_true^H (A v_true)
-  }
-  __syncthreads();
-  if (tid < 64) {  // ||A v_true||^2 = (|y'|^2 - 2 Re g^H t + |g|^2) / beta^2     (j <= 64: one wave holds every term)
-    const double term = (tid < j) ? fma(-2.0, redot_(gi, ti), abs2_(gi)) : 0.0;
-    const double tot = wave_sum(term);
-    if (tid == 0) {
-      const double rn2 = real_of(s_s[j]) + tot;
-      st->rnorm = sqrt(rn2 > 0.0 ? rn2 : 0.0) * binv;
-      st->rnorm2 = sqrt(real_of(s_s[j])) * binv;  // norm of what the projection kernel actually works on: y' / beta
-      st->invb = binv;
-    }
-  }
-  if (tid < j) {  // coefficients of the STORED columns: T t / beta
-    T a = zero_of(T{});
-    int k0 = tid;
-    if (tid < ntrue) {
-      a = t_s[tid];
-      k0 = ntrue;
-    }
-#pragma unroll 4
-    for (int k = k0; k < j; ++k) a = fma_(Tat(tid, k), t_s[k], a);
-    coef[tid] = scl(a, binv);
-  }
-}
-
-template <class T>
-__global__ void __launch_bounds__(kBlock)
-    k_fin_mid_t(const T* __restrict__ partial, const double* __restrict__ partial2, int nb, int pnb, int j, T* __restrict__ red,
-                T* __restrict__ Hd, int ldh, T* __restrict__ Tm, int ldt, int ntrue, T* __restrict__ gvec, int mode,
-                DevState* __restrict__ st, P2pDev p2p, unsigned* __restrict__ counter) {
-  if (st->breakdown >= 0) return;
-  __shared__ T sm[kBlock];
-  __shared__ T c_s[kTMax];
+  __shared__ T a_s[kTMax], b_s[kTMax], g_s[kTMax];
   __shared__ double scal_s[2];
-  const int tid = threadIdx.x;
-  T* Hcol = Hd + (int64_t)(j - 1) * ldh;
-  // prefetched by every workgroup (see k_fin_dots_t): the non-trivial columns of T, this step's h, and the block of H
-  // that g = H c reads (rows 0..j, columns 0..j-2; column j-1 is being finished right here)
+  __shared__ int last_wg;
   __shared__ __attribute__((aligned(16))) unsigned char tl_raw[kTLdsBytes];
   __shared__ __attribute__((aligned(16))) unsigned char hl_raw[kHLdsBytes];
   T* Tl = reinterpret_cast<T*>(tl_raw);
   T* Hl = reinterpret_cast<T*>(hl_raw);
-  const int nl = j - ntrue;
-  const bool use_lds = nl > 0 && nl * j <= (int)(kTLdsBytes / sizeof(T));
-  if (use_lds)
-    for (int e = tid; e < nl * j; e += kBlock) {
-      const int k = e % j, i = ntrue + e / j;
-      Tl[e] = (k <= i) ? Tm[k + (int64_t)i * ldt] : zero_of(T{});
+  const int tid = threadIdx.x;
+  const int nm = jm ? jm + 1 : 0, nd = jd ? jd + 1 : 0;
+  const int jt = jd ? jd : jm;       // T[0:jt, 0:jt) is what the algebra touches (column jm is produced here when jd = jm+1)
+  // ---- prefetch (every workgroup; only the last one to arrive uses it, but the loads hide behind the reduction) ----
+  const int nl = jt - ntrue;         // columns ntrue..jt-1 of T are not unit vectors
+  const bool use_lds = nl > 0 && nl * jt <= (int)(kTLdsBytes / sizeof(T));
+  if (use_lds) {
+    const int have = jm ? jm : jt;   // columns < have exist in memory already
+    for (int e = tid; e < nl * jt; e += kBlock) {
+      const int k = e % jt, i = ntrue + e / jt;
+      Tl[e] = (k <= i && i < have) ? Tm[k + (int64_t)i * ldt] : zero_of(T{});
     }
-  const int hr = j + 1, hc = j - 1;
-  const bool h_lds = hc > 0 && hr * hc <= (int)(kHLdsBytes / sizeof(T));
+  }
+  const int hr = jm + 1, hc = jm - 1;
+  const bool h_lds = jm && hc > 0 && hr * hc <= (int)(kHLdsBytes / sizeof(T));
   if (h_lds)
     for (int e = tid; e < hr * hc; e += kBlock) Hl[e] = Hd[(e % hr) + (int64_t)(e / hr) * ldh];
   T h0 = zero_of(T{});
-  if (tid < j) h0 = Hcol[tid];  // written by this step's k_fin_dots_t
+  if (jm && tid < jm) h0 = Hd[tid + (int64_t)(jm - 1) * ldh];  // h of step jm as its DOTS half left it
+  T gpre = zero_of(T{});
+  if (!jm && jd && (jd - 1) >= ntrue && tid < jd) gpre = gvec[tid];  // (only when a batch continues on factored columns)
+  // ---- reduction of this workgroup's column + election ----
   if (mode != 2) {
-    const int c = blockIdx.x;  // c < j: speculative second-pass inner product with stored column c;  c == j: ||w'||^2
-    if (!fin_t_stage1<T>(partial + (int64_t)c * pnb, nb, c == j, partial2, red, mode, p2p, counter, sm)) return;
-  }
-  if (tid <= j) c_s[tid] = ld_agent(red + tid);
-  __syncthreads();
-  auto Tat = [&](int k, int i) -> T { return use_lds ? Tl[k + (i - ntrue) * j] : Tm[k + (int64_t)i * ldt]; };  // i >= ntrue
-  T ci = zero_of(T{});
-  if (tid < j) {  // c = T^H c_raw = V_true^H w'
-    if (tid < ntrue) {
-      ci = c_s[tid];
+    const int c = blockIdx.x;
+    T s;
+    if (c < nm) {
+      if (c == jm) s = from_real(block_sum(partial2, nb_c, reinterpret_cast<double*>(sm)), T{});
+      else s = block_sum(part_c + (int64_t)c * pnb, nb_c, sm);
     } else {
-#pragma unroll 4
-      for (int k = 0; k <= tid; ++k) ci = fma_(conj_(Tat(k, tid)), c_s[k], ci);
+      s = block_sum(part_s + (int64_t)(c - nm) * pnb, nb_s, sm);
     }
-  }
-  const double wn2 = real_of(c_s[j]);
-  const double wnorm = sqrt(wn2), rnorm = st->rnorm;
-  // DGKS test, src/expansion.jl:91 -- against the larger of ||A v_true|| (the reference's rnorm) and ||y'|| / beta, the
-  // norm of the vector the projection was really applied to.  The two differ only when the input column carries a
-  // second-pass correction that is NOT small against it AND A v_true nearly cancels (a basis vector in the null space
-  // of A right after a near-breakdown: test/partial_schur.jl:6-27); there the first projection loses as many digits as
-  // y' - V g did, and the (implicit) second pass is what restores orthogonality.  Everywhere else the maximum is rnorm.
-  const bool reorth = wnorm < kEta * fmax(rnorm, st->rnorm2);
-  if (tid < 64) {
-    const double tot = wave_sum((reorth && tid < j) ? abs2_(ci) : 0.0);
-    if (tid == 0) scal_s[0] = tot;
-  }
-  __syncthreads();  // (also: every thread has read c_s before it is overwritten below)
-  double beta, rnorm_p;
-  if (reorth) {
-    const double b2 = wn2 - scal_s[0];  // ||w' - V c||^2 with V orthonormal
-    beta = sqrt(b2 > 0.0 ? b2 : 0.0);
-    rnorm_p = wnorm;                    // :92
-  } else {
-    beta = wnorm;
-    rnorm_p = rnorm;
-    ci = zero_of(T{});
-  }
-  if (beta <= kEta * rnorm_p) {  // src/expansion.jl:99-102
+    if (mode == 3 && tid < 64) {
+      T g;
+      double dummy;
+      p2p_pair(p2p, c, s, 0.0, g, dummy);
+      s = g;
+    }
     if (tid == 0) {
-      Hcol[j] = zero_of(T{});
-      st->breakdown = j;
-      st->inv_norm = 0.0;
+      red[c] = s;
+      if (mode != 1) {
+        __threadfence();
+        last_wg = (atomicAdd(counter, 1u) == gridDim.x - 1) ? 1 : 0;
+      }
+    }
+    if (mode == 1) return;
+    __syncthreads();
+    if (!last_wg) return;
+    if (tid == 0) *counter = 0u;  // armed for the next launch (stream order)
+    __threadfence();
+  }
+  auto Tat = [&](int k, int i) -> T { return use_lds ? Tl[k + (i - ntrue) * jt] : Tm[k + (int64_t)i * ldt]; };  // i >= ntrue
+  double binv_in = 1.0;  // 1 / beta of the column the DOTS half works on (column jd-1)
+  T gi = gpre;           // g of that column (this thread's entry)
+  // ================================ MID(jm) ================================
+  if (jm) {
+    const int j = jm;
+    T* Hcol = Hd + (int64_t)(j - 1) * ldh;
+    if (tid <= j) a_s[tid] = ld_agent(red + tid);
+    __syncthreads();
+    T ci = zero_of(T{});
+    if (tid < j) {  // c = T^H c_raw = V_true^H w'
+      if (tid < ntrue) {
+        ci = a_s[tid];
+      } else {
+#pragma unroll 4
+        for (int k = 0; k <= tid; ++k) ci = fma_(conj_(Tat(k, tid)), a_s[k], ci);
+      }
+    }
+    const double wn2 = real_of(a_s[j]);
+    const double wnorm = sqrt(wn2), rnorm = st->rnorm;
+    // DGKS test, src/expansion.jl:91 -- against the larger of ||A v_true|| (the reference's rnorm) and ||y'|| / beta, the
+    // norm of the vector the projection was really applied to.  The two differ only when the input column carries a
+    // second-pass correction that is NOT small against it AND A v_true nearly cancels (a basis vector in the null space
+    // of A right after a near-breakdown: test/partial_schur.jl:6-27); there the first projection loses as many digits as
+    // y' - V g did, and the (implicit) second pass is what restores orthogonality.  Everywhere else the maximum is rnorm.
+    const bool reorth = wnorm < kEta * fmax(rnorm, st->rnorm2);
+    if (tid < 64) {
+      const double tot = wave_sum((reorth && tid < j) ? abs2_(ci) : 0.0);
+      if (tid == 0) scal_s[0] = tot;
+    }
+    __syncthreads();  // (also: every thread has read a_s before it is overwritten below)
+    double beta, rnorm_p;
+    if (reorth) {
+      const double b2 = wn2 - scal_s[0];  // ||w' - V c||^2 with V orthonormal
+      beta = sqrt(b2 > 0.0 ? b2 : 0.0);
+      rnorm_p = wnorm;                    // :92
+    } else {
+      beta = wnorm;
+      rnorm_p = rnorm;
+      ci = zero_of(T{});
+    }
+    if (beta <= kEta * rnorm_p) {  // src/expansion.jl:99-102
+      if (tid == 0) {
+        Hcol[j] = zero_of(T{});
+        st->breakdown = j;
+        st->inv_norm = 0.0;
+        if (reorth) st->n_reorth += 1;
+      }
+      if (reorth && tid < j) Hcol[tid] = add_(h0, ci);  // h .+= correction happens before the test, :95
+      return;
+    }
+    const double binv = 1.0 / beta;
+    T hi = h0;
+    if (tid < j) {
+      if (reorth) {
+        hi = add_(hi, ci);  // :95
+        Hcol[tid] = hi;
+      }
+      a_s[tid] = ci;
+    }
+    __syncthreads();
+    if (tid < j) {  // new column of T:  -(T c) / beta
+      T a = zero_of(T{});
+      if (reorth) {
+        int k0 = tid;
+        if (tid < ntrue) {
+          a = a_s[tid];
+          k0 = ntrue;
+        }
+#pragma unroll 4
+        for (int k = k0; k < j; ++k) a = fma_(Tat(tid, k), a_s[k], a);
+      }
+      const T tv = scl(neg_(a), binv);
+      Tm[tid + (int64_t)j * ldt] = tv;
+      if (use_lds && jd) Tl[tid + (j - ntrue) * jt] = tv;
+    }
+    if (tid <= j) {  // g for the next step: H[0:j+1, 0:j] c   (upper Hessenberg: H[i,k] = 0 for k < i-1)
+      T g = zero_of(T{});
+      if (reorth) {
+#pragma unroll 8
+        for (int k = (tid > 0 ? tid - 1 : 0); k < j - 1; ++k)
+          g = fma_(h_lds ? Hl[tid + k * hr] : Hd[tid + (int64_t)k * ldh], a_s[k], g);
+        const T hlast = (tid < j) ? hi : from_real(beta, T{});  // column j-1 of H as this step leaves it
+        g = fma_(hlast, a_s[j - 1], g);
+      }
+      gvec[tid] = g;
+      gi = g;
+    }
+    if (tid == 0) {
+      Hcol[j] = from_real(beta, T{});  // :105
+      Tm[j + (int64_t)j * ldt] = from_real(binv, T{});
+      if (use_lds && jd) Tl[j + (j - ntrue) * jt] = from_real(binv, T{});
+      st->wnorm = beta;
+      st->inv_norm = binv;
+      st->reorth = 0;
+      st->pend = 0;
+      st->n_steps += 1;
       if (reorth) st->n_reorth += 1;
     }
-    if (reorth && tid < j) Hcol[tid] = add_(h0, ci);  // h .+= correction happens before the test, :95
-    return;
+    binv_in = binv;
+    __syncthreads();  // the new column of T (LDS) and a_s are settled before the DOTS half reads / reuses them
+  } else if (jd && (jd - 1) >= ntrue) {
+    binv_in = real_of(Tat(jd - 1, jd - 1));
   }
-  const double binv = 1.0 / beta;
-  T hi = h0;
-  if (tid < j) {
-    if (reorth) {
-      hi = add_(hi, ci);  // :95
-      Hcol[tid] = hi;
+  // ================================ DOTS(jd) ================================
+  if (jd) {
+    const int j = jd;
+    T* Hcol = Hd + (int64_t)(j - 1) * ldh;
+    if (tid <= j) b_s[tid] = ld_agent(red + nm + tid);
+    __syncthreads();
+    T ti = zero_of(T{});
+    if (tid < j) {
+      if (tid < ntrue) {
+        ti = b_s[tid];
+      } else {  // t[i] = sum_{k <= i} conj(T[k,i]) s[k]
+#pragma unroll 4
+        for (int k = 0; k <= tid; ++k) ti = fma_(conj_(Tat(k, tid)), b_s[k], ti);
+      }
+      g_s[tid] = ti;
+      Hcol[tid] = scl(sub_(ti, gi), binv_in);  // h = V_true^H (A v_true)
     }
-    c_s[tid] = ci;
-  }
-  __syncthreads();
-  if (tid < j) {  // new column of T:  -(T c) / beta
-    T a = zero_of(T{});
-    if (reorth) {
+    __syncthreads();
+    if (tid < 64) {  // ||A v_true||^2 = (|y'|^2 - 2 Re g^H t + |g|^2) / beta^2     (j <= 64: one wave holds every term)
+      const double term = (tid < j) ? fma(-2.0, redot_(gi, ti), abs2_(gi)) : 0.0;
+      const double tot = wave_sum(term);
+      if (tid == 0) {
+        const double rn2 = real_of(b_s[j]) + tot;
+        st->rnorm = sqrt(rn2 > 0.0 ? rn2 : 0.0) * binv_in;
+        st->rnorm2 = sqrt(real_of(b_s[j])) * binv_in;  // norm of what the projection kernel actually works on: y' / beta
+        st->invb = binv_in;
+      }
+    }
+    if (tid < j) {  // coefficients of the STORED columns: T t / beta
+      T a = zero_of(T{});
       int k0 = tid;
       if (tid < ntrue) {
-        a = c_s[tid];
+        a = g_s[tid];
         k0 = ntrue;
       }
 #pragma unroll 4
-      for (int k = k0; k < j; ++k) a = fma_(Tat(tid, k), c_s[k], a);
+      for (int k = k0; k < j; ++k) a = fma_(Tat(tid, k), g_s[k], a);
+      coef[tid] = scl(a, binv_in);
     }
-    Tm[tid + (int64_t)j * ldt] = scl(neg_(a), binv);
-  }
-  if (tid <= j) {  // g for the next step: H[0:j+1, 0:j] c   (upper Hessenberg: H[i,k] = 0 for k < i-1)
-    T g = zero_of(T{});
-    if (reorth) {
-#pragma unroll 8
-      for (int k = (tid > 0 ? tid - 1 : 0); k < j - 1; ++k)
-        g = fma_(h_lds ? Hl[tid + k * hr] : Hd[tid + (int64_t)k * ldh], c_s[k], g);
-      const T hlast = (tid < j) ? hi : from_real(beta, T{});  // column j-1 of H as this step leaves it
-      g = fma_(hlast, c_s[j - 1], g);
-    }
-    gvec[tid] = g;
-  }
-  if (tid == 0) {
-    Hcol[j] = from_real(beta, T{});  // :105
-    Tm[j + (int64_t)j * ldt] = from_real(binv, T{});
-    st->wnorm = beta;
-    st->inv_norm = binv;
-    st->reorth = 0;
-    st->pend = 0;
-    st->n_steps += 1;
-    if (reorth) st->n_reorth += 1;
   }
 }
 
