@@ -31,6 +31,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return OUT
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", SRC, "-o", OUT, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    cmd += os.environ.get("KS_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DKS_FIN_TIMING (device-side stage timers of k_fin_step_t)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=os.path.dirname(SRC))

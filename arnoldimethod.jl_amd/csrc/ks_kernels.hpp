@@ -1359,6 +1359,37 @@ __device__ __forceinline__ cd ld_agent(const cd* p) {
 // jm = 0: first step of a batch (nothing pending);  jd = 0: after the last step (settle it).  The breakdown of step jm
 // is thus detected after the operator and k_dots of step jm+1 already ran (on a column that is then discarded).
 // red[0 .. jm] = MID sums (last = ||w'||^2), red[nm .. nm+jd] = DOTS sums (last = |y'|^2), nm = jm ? jm+1 : 0.
+// sum_{k < n} conj(a[k]) x[k]  and  sum_{k0 <= k < n} a[k * stride] x[k]: loads of four terms issued together, two
+// accumulators (a serial fma chain over un-batched LDS loads cost 90 cycles per term: 6 us for the algebra of one step)
+template <class T> __device__ __forceinline__ T dotc_contig(const T* __restrict__ a, const T* __restrict__ x, int n) {
+  T s0 = zero_of(T{}), s1 = zero_of(T{});
+  int k = 0;
+  for (; k + 3 < n; k += 4) {
+    const T a0 = a[k], a1 = a[k + 1], a2 = a[k + 2], a3 = a[k + 3];
+    const T x0 = x[k], x1 = x[k + 1], x2 = x[k + 2], x3 = x[k + 3];
+    s0 = fma_(conj_(a0), x0, s0);
+    s1 = fma_(conj_(a1), x1, s1);
+    s0 = fma_(conj_(a2), x2, s0);
+    s1 = fma_(conj_(a3), x3, s1);
+  }
+  for (; k < n; ++k) s0 = fma_(conj_(a[k]), x[k], s0);
+  return add_(s0, s1);
+}
+template <class T> __device__ __forceinline__ T dot_strided(const T* __restrict__ a, int64_t stride, const T* __restrict__ x, int k0, int n) {
+  T s0 = zero_of(T{}), s1 = zero_of(T{});
+  int k = k0;
+  for (; k + 3 < n; k += 4) {
+    const T a0 = a[k * stride], a1 = a[(k + 1) * stride], a2 = a[(k + 2) * stride], a3 = a[(k + 3) * stride];
+    const T x0 = x[k], x1 = x[k + 1], x2 = x[k + 2], x3 = x[k + 3];
+    s0 = fma_(a0, x0, s0);
+    s1 = fma_(a1, x1, s1);
+    s0 = fma_(a2, x2, s0);
+    s1 = fma_(a3, x3, s1);
+  }
+  for (; k < n; ++k) s0 = fma_(a[k * stride], x[k], s0);
+  return add_(s0, s1);
+}
+
 template <class T>
 __global__ void __launch_bounds__(kBlock)
     k_fin_step_t(const T* __restrict__ part_s, int nb_s, const T* __restrict__ part_c, const double* __restrict__ partial2,
@@ -1366,9 +1397,13 @@ __global__ void __launch_bounds__(kBlock)
                  int ldt, int ntrue, T* __restrict__ gvec, T* __restrict__ coef, int mode, DevState* __restrict__ st,
                  P2pDev p2p, unsigned* __restrict__ counter) {
   if (st->breakdown >= 0) return;
+#ifdef KS_FIN_TIMING
+  const long long tk0 = wall_clock64();
+  long long tk1 = 0, tk2 = 0, tk3 = 0;
+#endif
   __shared__ T sm[kBlock];
-  __shared__ T a_s[kTMax], b_s[kTMax], g_s[kTMax];
-  __shared__ double scal_s[2];
+  __shared__ T r_s[2 * kTMax + 2];          // every reduced value: [MID sums | DOTS sums]
+  __shared__ T c_s[kTMax], t_s[kTMax];
   __shared__ int last_wg;
   __shared__ __attribute__((aligned(16))) unsigned char tl_raw[kTLdsBytes];
   __shared__ __attribute__((aligned(16))) unsigned char hl_raw[kHLdsBytes];
@@ -1377,24 +1412,32 @@ __global__ void __launch_bounds__(kBlock)
   const int tid = threadIdx.x;
   const int nm = jm ? jm + 1 : 0, nd = jd ? jd + 1 : 0;
   const int jt = jd ? jd : jm;       // T[0:jt, 0:jt) is what the algebra touches (column jm is produced here when jd = jm+1)
-  // ---- prefetch (every workgroup; only the last one to arrive uses it, but the loads hide behind the reduction) ----
+  // ---- prefetch INTO REGISTERS (every workgroup; only the last one to arrive uses it, but nobody knows who that is, and
+  // this way the loads are in flight together with those of the reduction instead of adding round trips after it) ----
+  constexpr int PF = (int)(kTLdsBytes / sizeof(T)) / kBlock;  // elements per thread: 12 (Float64) / 6 (ComplexF64)
   const int nl = jt - ntrue;         // columns ntrue..jt-1 of T are not unit vectors
   const bool use_lds = nl > 0 && nl * jt <= (int)(kTLdsBytes / sizeof(T));
-  if (use_lds) {
-    const int have = jm ? jm : jt;   // columns < have exist in memory already
-    for (int e = tid; e < nl * jt; e += kBlock) {
-      const int k = e % jt, i = ntrue + e / jt;
-      Tl[e] = (k <= i && i < have) ? Tm[k + (int64_t)i * ldt] : zero_of(T{});
-    }
-  }
+  const int have = jm ? jm : jt;     // columns < have exist in memory already
   const int hr = jm + 1, hc = jm - 1;
   const bool h_lds = jm && hc > 0 && hr * hc <= (int)(kHLdsBytes / sizeof(T));
-  if (h_lds)
-    for (int e = tid; e < hr * hc; e += kBlock) Hl[e] = Hd[(e % hr) + (int64_t)(e / hr) * ldh];
+  const int nT = use_lds ? nl * jt : 0, nH = h_lds ? hr * hc : 0;
+  T treg[PF], hreg[PF];
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+    const int e = tid + u * kBlock;
+    treg[u] = zero_of(T{});
+    hreg[u] = zero_of(T{});
+    if (e < nT) {
+      const int k = e % jt, i = ntrue + e / jt;
+      if (k <= i && i < have) treg[u] = Tm[k + (int64_t)i * ldt];
+    }
+    if (e < nH) hreg[u] = Hd[(e % hr) + (int64_t)(e / hr) * ldh];
+  }
   T h0 = zero_of(T{});
   if (jm && tid < jm) h0 = Hd[tid + (int64_t)(jm - 1) * ldh];  // h of step jm as its DOTS half left it
-  T gpre = zero_of(T{});
-  if (!jm && jd && (jd - 1) >= ntrue && tid < jd) gpre = gvec[tid];  // (only when a batch continues on factored columns)
+  T gi = zero_of(T{});
+  if (!jm && jd && (jd - 1) >= ntrue && tid < jd) gi = gvec[tid];  // (only when a batch continues on factored columns)
+  const double rnorm = st->rnorm, rnorm2 = st->rnorm2;
   // ---- reduction of this workgroup's column + election ----
   if (mode != 2) {
     const int c = blockIdx.x;
@@ -1411,6 +1454,9 @@ __global__ void __launch_bounds__(kBlock)
       p2p_pair(p2p, c, s, 0.0, g, dummy);
       s = g;
     }
+#ifdef KS_FIN_TIMING
+    tk1 = wall_clock64();
+#endif
     if (tid == 0) {
       red[c] = s;
       if (mode != 1) {
@@ -1423,43 +1469,49 @@ __global__ void __launch_bounds__(kBlock)
     if (!last_wg) return;
     if (tid == 0) *counter = 0u;  // armed for the next launch (stream order)
     __threadfence();
+#ifdef KS_FIN_TIMING
+    tk2 = wall_clock64();
+#endif
   }
-  auto Tat = [&](int k, int i) -> T { return use_lds ? Tl[k + (i - ntrue) * jt] : Tm[k + (int64_t)i * ldt]; };  // i >= ntrue
+  // ---- the last workgroup: ONE round trip for every reduced value, the prefetched blocks go to LDS, then wave 0 alone
+  // does the algebra (<= 64 elements per vector: one lane each; barriers of a single live wave cost nothing) ----
+  if (tid < nm + nd) r_s[tid] = ld_agent(red + tid);
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+    const int e = tid + u * kBlock;
+    if (e < nT) Tl[e] = treg[u];
+    if (e < nH) Hl[e] = hreg[u];
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+  // T as the algebra sees it: element (k, i), i >= ntrue, at tb[k + (i - ntrue) * tld]
+  const T* tb = use_lds ? Tl : Tm + (int64_t)ntrue * ldt;
+  const int64_t tld = use_lds ? jt : ldt;
   double binv_in = 1.0;  // 1 / beta of the column the DOTS half works on (column jd-1)
-  T gi = gpre;           // g of that column (this thread's entry)
   // ================================ MID(jm) ================================
   if (jm) {
     const int j = jm;
     T* Hcol = Hd + (int64_t)(j - 1) * ldh;
-    if (tid <= j) a_s[tid] = ld_agent(red + tid);
-    __syncthreads();
+    const T* a_s = r_s;  // c_raw[0..j-1], ||w'||^2 at [j]
     T ci = zero_of(T{});
     if (tid < j) {  // c = T^H c_raw = V_true^H w'
-      if (tid < ntrue) {
-        ci = a_s[tid];
-      } else {
-#pragma unroll 4
-        for (int k = 0; k <= tid; ++k) ci = fma_(conj_(Tat(k, tid)), a_s[k], ci);
-      }
+      if (tid < ntrue) ci = a_s[tid];
+      else ci = dotc_contig(tb + (tid - ntrue) * tld, a_s, tid + 1);
     }
     const double wn2 = real_of(a_s[j]);
-    const double wnorm = sqrt(wn2), rnorm = st->rnorm;
+    const double wnorm = sqrt(wn2);
     // DGKS test, src/expansion.jl:91 -- against the larger of ||A v_true|| (the reference's rnorm) and ||y'|| / beta, the
     // norm of the vector the projection was really applied to.  The two differ only when the input column carries a
     // second-pass correction that is NOT small against it AND A v_true nearly cancels (a basis vector in the null space
     // of A right after a near-breakdown: test/partial_schur.jl:6-27); there the first projection loses as many digits as
     // y' - V g did, and the (implicit) second pass is what restores orthogonality.  Everywhere else the maximum is rnorm.
-    const bool reorth = wnorm < kEta * fmax(rnorm, st->rnorm2);
-    if (tid < 64) {
-      const double tot = wave_sum((reorth && tid < j) ? abs2_(ci) : 0.0);
-      if (tid == 0) scal_s[0] = tot;
-    }
-    __syncthreads();  // (also: every thread has read a_s before it is overwritten below)
+    const bool reorth = wnorm < kEta * fmax(rnorm, rnorm2);
+    const double c2 = wave_sum((reorth && tid < j) ? abs2_(ci) : 0.0);
     double beta, rnorm_p;
     if (reorth) {
-      const double b2 = wn2 - scal_s[0];  // ||w' - V c||^2 with V orthonormal
+      const double b2 = wn2 - c2;  // ||w' - V c||^2 with V orthonormal
       beta = sqrt(b2 > 0.0 ? b2 : 0.0);
-      rnorm_p = wnorm;                    // :92
+      rnorm_p = wnorm;             // :92
     } else {
       beta = wnorm;
       rnorm_p = rnorm;
@@ -1472,45 +1524,47 @@ __global__ void __launch_bounds__(kBlock)
         st->inv_norm = 0.0;
         if (reorth) st->n_reorth += 1;
       }
-      if (reorth && tid < j) Hcol[tid] = add_(h0, ci);  // h .+= correction happens before the test, :95
+      if (reorth) {  // h .+= correction happens before the test, :95
+        if (tid < j) Hcol[tid] = add_(h0, ci);
+      }
       return;
     }
     const double binv = 1.0 / beta;
     T hi = h0;
-    if (tid < j) {
-      if (reorth) {
-        hi = add_(hi, ci);  // :95
-        Hcol[tid] = hi;
-      }
-      a_s[tid] = ci;
+    if (tid < j && reorth) {
+      hi = add_(hi, ci);  // :95
+      Hcol[tid] = hi;
     }
+    if (tid < j) c_s[tid] = ci;
     __syncthreads();
     if (tid < j) {  // new column of T:  -(T c) / beta
       T a = zero_of(T{});
       if (reorth) {
         int k0 = tid;
         if (tid < ntrue) {
-          a = a_s[tid];
+          a = c_s[tid];
           k0 = ntrue;
         }
-#pragma unroll 4
-        for (int k = k0; k < j; ++k) a = fma_(Tat(tid, k), a_s[k], a);
+        a = add_(a, dot_strided(tb + tid - ntrue * tld, tld, c_s, k0, j));  // sum_{k >= k0} T[tid, k] c[k]
       }
       const T tv = scl(neg_(a), binv);
       Tm[tid + (int64_t)j * ldt] = tv;
       if (use_lds && jd) Tl[tid + (j - ntrue) * jt] = tv;
     }
-    if (tid <= j) {  // g for the next step: H[0:j+1, 0:j] c   (upper Hessenberg: H[i,k] = 0 for k < i-1)
+    {  // g for the next step: H[0:j+1, 0:j] c   (upper Hessenberg: H[i,k] = 0 for k < i-1); entries 0..j, lane 0 also does j = 64
       T g = zero_of(T{});
-      if (reorth) {
-#pragma unroll 8
-        for (int k = (tid > 0 ? tid - 1 : 0); k < j - 1; ++k)
-          g = fma_(h_lds ? Hl[tid + k * hr] : Hd[tid + (int64_t)k * ldh], a_s[k], g);
-        const T hlast = (tid < j) ? hi : from_real(beta, T{});  // column j-1 of H as this step leaves it
-        g = fma_(hlast, a_s[j - 1], g);
+      if (reorth && tid < j) {
+        const T* __restrict__ hb = h_lds ? Hl : Hd;
+        g = dot_strided(hb + tid, h_lds ? (int64_t)hr : (int64_t)ldh, c_s, tid > 0 ? tid - 1 : 0, j - 1);
+        g = fma_(hi, c_s[j - 1], g);  // column j-1 of H as this step leaves it
       }
-      gvec[tid] = g;
+      if (tid < j) gvec[tid] = g;
       gi = g;
+      if (tid == 0) {
+        const T glast = reorth ? scl(c_s[j - 1], beta) : zero_of(T{});  // H[j, j-1] c[j-1]
+        gvec[j] = glast;
+        c_s[kTMax - 1] = glast;
+      }
     }
     if (tid == 0) {
       Hcol[j] = from_real(beta, T{});  // :105
@@ -1524,50 +1578,51 @@ __global__ void __launch_bounds__(kBlock)
       if (reorth) st->n_reorth += 1;
     }
     binv_in = binv;
-    __syncthreads();  // the new column of T (LDS) and a_s are settled before the DOTS half reads / reuses them
+    __syncthreads();  // the new column of T (LDS), c_s[kTMax-1] are settled before the DOTS half reads them
+    if (jd && tid == j && j < 64) gi = c_s[kTMax - 1];  // lane j owns entry j of g in the DOTS half (jd = j+1 lanes)
+#ifdef KS_FIN_TIMING
+    tk3 = wall_clock64();
+#endif
   } else if (jd && (jd - 1) >= ntrue) {
-    binv_in = real_of(Tat(jd - 1, jd - 1));
+    binv_in = real_of(tb[(jd - 1) + (jd - 1 - ntrue) * tld]);
   }
   // ================================ DOTS(jd) ================================
   if (jd) {
     const int j = jd;
     T* Hcol = Hd + (int64_t)(j - 1) * ldh;
-    if (tid <= j) b_s[tid] = ld_agent(red + nm + tid);
-    __syncthreads();
+    const T* b_s = r_s + nm;  // s[0..j-1], |y'|^2 at [j]
     T ti = zero_of(T{});
     if (tid < j) {
-      if (tid < ntrue) {
-        ti = b_s[tid];
-      } else {  // t[i] = sum_{k <= i} conj(T[k,i]) s[k]
-#pragma unroll 4
-        for (int k = 0; k <= tid; ++k) ti = fma_(conj_(Tat(k, tid)), b_s[k], ti);
-      }
-      g_s[tid] = ti;
+      if (tid < ntrue) ti = b_s[tid];
+      else ti = dotc_contig(tb + (tid - ntrue) * tld, b_s, tid + 1);  // t[i] = sum_{k <= i} conj(T[k,i]) s[k]
+      t_s[tid] = ti;
       Hcol[tid] = scl(sub_(ti, gi), binv_in);  // h = V_true^H (A v_true)
     }
-    __syncthreads();
-    if (tid < 64) {  // ||A v_true||^2 = (|y'|^2 - 2 Re g^H t + |g|^2) / beta^2     (j <= 64: one wave holds every term)
-      const double term = (tid < j) ? fma(-2.0, redot_(gi, ti), abs2_(gi)) : 0.0;
-      const double tot = wave_sum(term);
-      if (tid == 0) {
-        const double rn2 = real_of(b_s[j]) + tot;
-        st->rnorm = sqrt(rn2 > 0.0 ? rn2 : 0.0) * binv_in;
-        st->rnorm2 = sqrt(real_of(b_s[j])) * binv_in;  // norm of what the projection kernel actually works on: y' / beta
-        st->invb = binv_in;
-      }
+    // ||A v_true||^2 = (|y'|^2 - 2 Re g^H t + |g|^2) / beta^2
+    const double tot = wave_sum((tid < j) ? fma(-2.0, redot_(gi, ti), abs2_(gi)) : 0.0);
+    if (tid == 0) {
+      const double rn2 = real_of(b_s[j]) + tot;
+      st->rnorm = sqrt(rn2 > 0.0 ? rn2 : 0.0) * binv_in;
+      st->rnorm2 = sqrt(real_of(b_s[j])) * binv_in;  // norm of what the projection kernel actually works on: y' / beta
+      st->invb = binv_in;
     }
+    __syncthreads();
     if (tid < j) {  // coefficients of the STORED columns: T t / beta
       T a = zero_of(T{});
       int k0 = tid;
       if (tid < ntrue) {
-        a = g_s[tid];
+        a = t_s[tid];
         k0 = ntrue;
       }
-#pragma unroll 4
-      for (int k = k0; k < j; ++k) a = fma_(Tat(tid, k), g_s[k], a);
+      a = add_(a, dot_strided(tb + tid - ntrue * tld, tld, t_s, k0, j));
       coef[tid] = scl(a, binv_in);
     }
   }
+#ifdef KS_FIN_TIMING
+  if (tid == 0 && jm == 35)
+    printf("[fin jm=%d jd=%d wg=%d] reduce %.2f us | election %.2f us | MID %.2f us | DOTS %.2f us\n", jm, jd, (int)blockIdx.x,
+           (tk1 - tk0) * 0.01, (tk2 - tk1) * 0.01, (tk3 - tk2) * 0.01, (wall_clock64() - tk3) * 0.01);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
