@@ -2667,7 +2667,26 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     w->n_global = n_global;
     w->row_begin = row_begin;
     w->maxdim = maxdim;
+    w->esz = dtype == KS_F64 ? 8 : 16;
     w->ld = std::max<int64_t>(round_up(n_local, 64), 64);
+    {
+      // COLUMN STRIDE.  A step streams 20-40 columns of V at the same row offset; how those streams fall onto the memory
+      // channels depends on the stride between columns modulo the interleave.  Measured (tools/stride_scan.sh,
+      // profiles/r02_column_stride.txt): with the stride at 0xEA00..0xFE00 modulo 128 KiB k_dots runs at 6.6-6.8 TB/s and
+      // k_axpy_dots_cs at 5.8-5.9, against 6.1-6.2 / 5.4-5.6 at the strides n happens to give (216^3, 215^3, 200^3,
+      // 232^3, 160^3: +3.5 ... +8 % iterations/s, every size).  A fixed rule, not a timing search: results stay
+      // reproducible.  Costs at most 128 KiB per column, applied from 4 MiB columns on.  KS_LD_PAD=<512-byte units>
+      // overrides (0 = none), KS_STRIDE_RULE=0 disables.
+      const int pad_env = env_int("KS_LD_PAD", -1);
+      const int64_t colb = w->ld * (int64_t)w->esz;
+      if (pad_env >= 0) {
+        w->ld += 64 * (int64_t)pad_env * (w->esz == 8 ? 1 : 1);
+      } else if (env_int("KS_STRIDE_RULE", 1) && colb >= ((int64_t)4 << 20)) {
+        const int64_t target = 0xF800, window = 0x20000;
+        const int64_t pad_bytes = ((target - colb % window) % window + window) % window;
+        w->ld += pad_bytes / (int64_t)w->esz;
+      }
+    }
     w->pstride = (int)round_up(maxdim + 2, 8);
     w->esz = dtype == KS_F64 ? 8 : 16;
     w->pnb = ctx->nblocks();
