@@ -498,3 +498,27 @@ def test_host_callback_sees_unit_norm_vectors(passes, monkeypatch):
     assert np.abs(np.array(norms) - 1.0).max() < 1e-10
     ref = np.sort(np.linalg.eigvalsh(A.toarray()))[::-1][:4]
     np.testing.assert_allclose(np.sort(dec.eigenvalues.real)[::-1], ref, rtol=1e-9)
+
+
+def test_column_stride_rule_is_deterministic_and_harmless(monkeypatch):
+    """The leading dimension of V is padded by a FIXED rule (stride = 0xF800 mod 128 KiB for columns >= 4 MiB,
+    profiles/r02_column_stride.txt) -- not by a timing search: two workspaces give bit-identical results, and the padded
+    layout agrees with the unpadded one to rounding (the row ranges of the workgroups, hence the summation order, differ)."""
+    m = 82                                        # 551 368 rows: 4.2 MiB columns, the rule applies
+    A = laplace3d(m, m, m)
+    n = A.shape[0]
+    v1 = _start(np.float64, n, seed=4)
+    out = []
+    for rule in ("1", "1", "0"):
+        monkeypatch.setenv("KS_STRIDE_RULE", rule)
+        op = pkg.csr_operator(A)
+        ws = pkg.ArnoldiWorkspace(n, 30, np.float64, ctx=op.ctx)
+        ws.reinitialize(0, v1)
+        ws.iterate_arnoldi(op, 1, 30)
+        H = np.array(ws.H)
+        res, orth = ws.arnoldi_relation(op, 30)
+        assert res < 1e-12 * np.linalg.norm(H) * 10 and orth < np.sqrt(EPS) / 100
+        out.append((H, ws.cols(0, 4)))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert np.linalg.norm(out[0][0] - out[2][0]) < 1e-12 * np.linalg.norm(out[2][0])
+    np.testing.assert_allclose(out[0][1], out[2][1], atol=1e-10)
