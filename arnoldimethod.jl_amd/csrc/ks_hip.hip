@@ -1284,25 +1284,56 @@ template <class D, int NCW, int U, int WB> int launch_axpy_dots_nc(ks_workspace*
                                                                        ws->st, defer, wdst, plain && ws->passes == 2);
   return nb;
 }
+// Write-back staging depth WB of the projection kernel.  The kernel writes ONE column next to the j+1 it reads, and that
+// write stream is what keeps it below k_dots: with its stores removed it runs at 7.0 TB/s, with 32 KiB bursts (WB = 8
+// at U = 4) at 5.9, with 64 KiB bursts at 6.6, with 96 KiB bursts at 6.7 (tools/fused_probe.hip,
+// profiles/r02_write_bursts.txt) -- every burst makes the memory channels turn around, so fewer and larger ones win even
+// at one workgroup per CU (the LDS of a gfx950 CU is 160 KiB: tbuf 32 KiB + 96 KiB of staged rows).  KS_FUSED_WB=8 / 24
+// forces one setting.
 template <class D> int launch_axpy_dots(ks_workspace* ws, int j, D* w, int defer, D* wdst = nullptr) {
   KS_REQUIRE(j >= 1 && j <= kFusedMaxJ, KS_ERR_INTERNAL, "fused projection kernel covers 1 <= j <= 64");
+  // (one workgroup per CU is too little parallelism while the basis is cache resident: 8 MiB columns lose 3 % with the deep
+  // staging, 80 MiB columns gain 11 % -- deep staging from KS_FUSED_WB_MIN_MB (24) MiB per column on)
+  static const int wb_env = env_int("KS_FUSED_WB", 0);
+  static const int wb_min_mb = env_int("KS_FUSED_WB_MIN_MB", 24);
+  const bool wb_small = wb_env ? wb_env <= 8 : (ws->ld * (int64_t)sizeof(D) < ((int64_t)wb_min_mb << 20));
+  if (wb_small) {
+    switch ((j + 3) / 4) {
+      case 1: return launch_axpy_dots_nc<D, 1, 4, 8>(ws, j, w, defer, wdst);
+      case 2: return launch_axpy_dots_nc<D, 2, 4, 8>(ws, j, w, defer, wdst);
+      case 3: return launch_axpy_dots_nc<D, 3, 4, 8>(ws, j, w, defer, wdst);
+      case 4: return launch_axpy_dots_nc<D, 4, 4, 8>(ws, j, w, defer, wdst);
+      case 5: return launch_axpy_dots_nc<D, 5, 4, 8>(ws, j, w, defer, wdst);
+      case 6: return launch_axpy_dots_nc<D, 6, 4, 8>(ws, j, w, defer, wdst);
+      case 7: return launch_axpy_dots_nc<D, 7, 4, 8>(ws, j, w, defer, wdst);
+      case 8: return launch_axpy_dots_nc<D, 8, 4, 8>(ws, j, w, defer, wdst);
+      case 9: return launch_axpy_dots_nc<D, 9, 4, 8>(ws, j, w, defer, wdst);
+      case 10: return launch_axpy_dots_nc<D, 10, 4, 8>(ws, j, w, defer, wdst);
+      case 11: return launch_axpy_dots_nc<D, 11, 2, 8>(ws, j, w, defer, wdst);
+      case 12: return launch_axpy_dots_nc<D, 12, 2, 8>(ws, j, w, defer, wdst);
+      case 13: return launch_axpy_dots_nc<D, 13, 2, 8>(ws, j, w, defer, wdst);
+      case 14: return launch_axpy_dots_nc<D, 14, 2, 8>(ws, j, w, defer, wdst);
+      case 15: return launch_axpy_dots_nc<D, 15, 2, 8>(ws, j, w, defer, wdst);
+      default: return launch_axpy_dots_nc<D, 16, 2, 8>(ws, j, w, defer, wdst);
+    }
+  }
   switch ((j + 3) / 4) {
-    case 1: return launch_axpy_dots_nc<D, 1, 4, 8>(ws, j, w, defer, wdst);
-    case 2: return launch_axpy_dots_nc<D, 2, 4, 8>(ws, j, w, defer, wdst);
-    case 3: return launch_axpy_dots_nc<D, 3, 4, 8>(ws, j, w, defer, wdst);
-    case 4: return launch_axpy_dots_nc<D, 4, 4, 8>(ws, j, w, defer, wdst);
-    case 5: return launch_axpy_dots_nc<D, 5, 4, 8>(ws, j, w, defer, wdst);
-    case 6: return launch_axpy_dots_nc<D, 6, 4, 8>(ws, j, w, defer, wdst);
-    case 7: return launch_axpy_dots_nc<D, 7, 4, 8>(ws, j, w, defer, wdst);
-    case 8: return launch_axpy_dots_nc<D, 8, 4, 8>(ws, j, w, defer, wdst);
-    case 9: return launch_axpy_dots_nc<D, 9, 4, 8>(ws, j, w, defer, wdst);
-    case 10: return launch_axpy_dots_nc<D, 10, 4, 8>(ws, j, w, defer, wdst);
-    case 11: return launch_axpy_dots_nc<D, 11, 2, 8>(ws, j, w, defer, wdst);
-    case 12: return launch_axpy_dots_nc<D, 12, 2, 8>(ws, j, w, defer, wdst);
-    case 13: return launch_axpy_dots_nc<D, 13, 2, 8>(ws, j, w, defer, wdst);
-    case 14: return launch_axpy_dots_nc<D, 14, 2, 8>(ws, j, w, defer, wdst);
-    case 15: return launch_axpy_dots_nc<D, 15, 2, 8>(ws, j, w, defer, wdst);
-    default: return launch_axpy_dots_nc<D, 16, 2, 8>(ws, j, w, defer, wdst);
+    case 1: return launch_axpy_dots_nc<D, 1, 4, 24>(ws, j, w, defer, wdst);
+    case 2: return launch_axpy_dots_nc<D, 2, 4, 24>(ws, j, w, defer, wdst);
+    case 3: return launch_axpy_dots_nc<D, 3, 4, 24>(ws, j, w, defer, wdst);
+    case 4: return launch_axpy_dots_nc<D, 4, 4, 24>(ws, j, w, defer, wdst);
+    case 5: return launch_axpy_dots_nc<D, 5, 4, 24>(ws, j, w, defer, wdst);
+    case 6: return launch_axpy_dots_nc<D, 6, 4, 24>(ws, j, w, defer, wdst);
+    case 7: return launch_axpy_dots_nc<D, 7, 4, 24>(ws, j, w, defer, wdst);
+    case 8: return launch_axpy_dots_nc<D, 8, 4, 24>(ws, j, w, defer, wdst);
+    case 9: return launch_axpy_dots_nc<D, 9, 4, 24>(ws, j, w, defer, wdst);
+    case 10: return launch_axpy_dots_nc<D, 10, 4, 24>(ws, j, w, defer, wdst);
+    case 11: return launch_axpy_dots_nc<D, 11, 2, 48>(ws, j, w, defer, wdst);
+    case 12: return launch_axpy_dots_nc<D, 12, 2, 48>(ws, j, w, defer, wdst);
+    case 13: return launch_axpy_dots_nc<D, 13, 2, 48>(ws, j, w, defer, wdst);
+    case 14: return launch_axpy_dots_nc<D, 14, 2, 48>(ws, j, w, defer, wdst);
+    case 15: return launch_axpy_dots_nc<D, 15, 2, 48>(ws, j, w, defer, wdst);
+    default: return launch_axpy_dots_nc<D, 16, 2, 48>(ws, j, w, defer, wdst);
   }
 }
 

@@ -1052,8 +1052,11 @@ __global__ void __launch_bounds__(kBlock)
         const int64_t fe = (base + 64 * U < pe) ? base + 64 * U : pe;
         // plain_store: the new column is the NEXT kernel's gather source (two-pass expansion: the operator is applied to it
         // right away) -- a cacheable store leaves it in the memory-side cache instead of streaming it past
-        if (plain_store) for (int64_t o = fb + threadIdx.x; o < fe; o += kBlock) st_pack(wdst + o * R, wout[o - fb]);
-        else for (int64_t o = fb + threadIdx.x; o < fe; o += kBlock) st_pack_nt(wdst + o * R, wout[o - fb]);
+        if (plain_store == 1) for (int64_t o = fb + threadIdx.x; o < fe; o += kBlock) st_pack(wdst + o * R, wout[o - fb]);
+        else if (plain_store == 0) for (int64_t o = fb + threadIdx.x; o < fe; o += kBlock) st_pack_nt(wdst + o * R, wout[o - fb]);
+        else if (plain_store == 3) for (int64_t o = fb + threadIdx.x; o < fe; o += kBlock) st_pack_nt(wdst + (o & 4095) * R, wout[o - fb]);
+        // (plain_store == 2: no store at all, 3: every store into one 64 KiB window -- tools/fused_probe.hip measures what
+        // the write stream costs and whether it is the memory or the issue path that pays)
       }
     }
   }
