@@ -1,0 +1,61 @@
+// Why does the stencil SpMV take 54 us inside the two-pass expansion and 44 us stand-alone?  216^3 7-point Laplacian; x cold.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/spmv_probe.hip -o /tmp/spmv_probe && /tmp/spmv_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../arnoldimethod.jl_amd/csrc/ks_kernels.hpp"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+using namespace ksd;
+__global__ void k_flush(const double* __restrict__ a, double* __restrict__ out, long n) {
+  double s = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += __builtin_nontemporal_load(a + i);
+  if (s == 1.2345) out[0] = s;
+}
+int main() {
+  const int m = 216;
+  const long n = (long)m * m * m;
+  long ld = (n + 63) / 64 * 64;
+  ld += ((((long)0xF800 - (ld * 8) % 0x20000) % 0x20000 + 0x20000) % 0x20000) / 8;
+  StencilDict<double> d{};
+  const long del[7] = {-(long)m * m, -m, -1, 0, 1, m, (long)m * m};
+  for (int k = 0; k < 7; ++k) { d.delta[k] = (int)del[k]; d.val[k] = k == 3 ? 6.0 : -1.0; }
+  std::vector<uint16_t> mask((n + 1) / 2);
+  for (long r = 0; r < n; ++r) {
+    const long xx = r % m, yy = (r / m) % m, zz = r / ((long)m * m);
+    unsigned b = 8;
+    if (zz > 0) b |= 1; if (yy > 0) b |= 2; if (xx > 0) b |= 4; if (xx < m - 1) b |= 16; if (yy < m - 1) b |= 32; if (zz < m - 1) b |= 64;
+    if (r & 1) mask[r >> 1] |= (uint16_t)(b << 8); else mask[r >> 1] = (uint16_t)b;
+  }
+  uint16_t* dm; double *V, *xs, *ys, *big, *out, *coef, *partial, *partial2;
+  CK(hipMalloc(&dm, mask.size() * 2)); CK(hipMemcpy(dm, mask.data(), mask.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMalloc(&V, ld * 43 * 8)); CK(hipMemset(V, 0, ld * 43 * 8));
+  CK(hipMalloc(&xs, n * 8)); CK(hipMalloc(&ys, n * 8)); CK(hipMalloc(&big, (1L << 28) * 8)); CK(hipMalloc(&out, 64));
+  CK(hipMalloc(&coef, 8 * 256)); CK(hipMalloc(&partial, 8 * 64 * 8192)); CK(hipMalloc(&partial2, 8 * 8192)); CK(hipMemset(coef, 0, 8 * 256));
+  std::vector<double> h(n);
+  for (auto& v : h) v = rand() / (double)RAND_MAX - 0.5;
+  CK(hipMemcpy(xs, h.data(), n * 8, hipMemcpyHostToDevice));
+  for (int c = 0; c < 43; ++c) CK(hipMemcpy(V + c * ld, h.data(), n * 8, hipMemcpyHostToDevice));
+  CK(hipMemset(big, 0, (1L << 28) * 8));
+  const int nt = (int)((n + 511) / 512);
+  const double MB = (2.0 * n + 16.0 * n) / 1e6;
+  auto run = [&](const char* name, auto pre, const double* x, double* y) {
+    float best = 1e9f;
+    for (int rep = 0; rep < 6; ++rep) {
+      pre();
+      hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+      CK(hipEventRecord(a)); k_spmv_stencil2<double, uint16_t><<<nt, 256>>>(dm, d, 7, x, y, n, nt, nullptr); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+      float ms; CK(hipEventElapsedTime(&ms, a, b)); if (rep) best = ms < best ? ms : best;
+    }
+    printf("%-86s %.1f us  %.0f GB/s\n", name, best * 1e3, MB / best);
+  };
+  auto flush = [&] { k_flush<<<2048, 256>>>(big, out, 1L << 28); };
+  auto fused = [&](int j) { return [&, j] { k_axpy_dots_cs<double, 10, 4, 24><<<256, 256>>>(V, ld, j, V + ld * 41, coef, partial, 8192, partial2, nullptr, 0, V + ld * j, 0); }; };
+  auto dots = [&](int j) { return [&, j] { k_dots<double, 10><<<768, 256>>>(V, ld, j, V + ld * 41, partial, 8192, j, 1, nullptr); }; };
+  run("x, y separate allocations, caches flushed", flush, xs, ys);
+  run("x = column 30 of V, y = column 41 of V, caches flushed", flush, V + 30 * ld, V + 41 * ld);
+  run("x = column 36 of V written by the projection kernel just before (as in the expansion), y = column 41", fused(36), V + 36 * ld, V + 41 * ld);
+  run("... and y separate", fused(36), V + 36 * ld, ys);
+  run("x = column 36 of V, k_dots just before (x read last)", dots(37), V + 36 * ld, V + 41 * ld);
+  return 0;
+}
