@@ -1614,11 +1614,12 @@ inline bool use_deferred(const ks_workspace* ws, int to) {
 
 // Start of a batch: fresh DevState and, when the host changed column factors since the last batch, the factors --
 // one asynchronous copy from the pinned control block, no synchronisation.
-inline void reset_state(ks_workspace* ws, bool upload_H = false) {
+inline void reset_state(ks_workspace* ws, bool upload_H = false, double sigma0 = 1.0) {
   // (no synchronisation: the state image is always the same bytes, and the factor image is only rewritten after a
   // host-side change, which follows the synchronising fetch of the previous batch)
   std::memset(ws->st_h, 0, sizeof(DevState));
   ws->st_h->breakdown = -1;
+  ws->st_h->sigma = sigma0;
   if (upload_H) {
     // implicit second pass: the device needs the CURRENT H (the restart rewrote its leading block on the host) for
     // g = H c -- the whole array travels with the state, still one copy
@@ -1983,7 +1984,13 @@ template <class T> struct HipBackend : ks::Backend<T> {
         materialize(ws);   // whatever is lazy (either kind) becomes ordinary: this batch starts a new T
         ws->ntrue = j0;
       }
-      reset_state(ws, tpath);
+      double sigma0 = 1.0;
+      if (tpath && ws->t_lazy && j0 - 1 >= ws->ntrue && j0 - 1 <= ws->t_hi) {
+        // the batch continues on a factored column (host callbacks: every batch): k_dots' scale factor from its 1 / beta
+        const double binv = reinterpret_cast<const double*>(static_cast<const char*>(ws->Th) + ((size_t)(j0 - 1) + (size_t)(j0 - 1) * ws->ldt) * ws->esz)[0];
+        if (binv > 0.0 && std::isfinite(binv)) sigma0 = std::ldexp(1.0, std::ilogb(binv));
+      }
+      reset_state(ws, tpath, sigma0);
       const bool mb = lazy && ws->use_mbox;          // the device publishes the results itself, the host spins
       const bool do_early = early && mb && !tpath && jend == to;  // (with two passes H is final only at the very end)
       const uint64_t seq = ++ws->mbox_seq;

@@ -46,6 +46,11 @@ struct DevState {
                        // 0: it is `wnorm` (already reduced) of the first pass
   double rnorm_p;      // reference norm of the pending breakdown test (src/expansion.jl:99)
   double invb;         // 1 / norm of the pending column (1 when none)
+  // two-pass expansion: power of two ~ 1 / ||A v|| of the previous step (an upper bound of the norm of the newest stored
+  // column).  k_dots multiplies y' = A * (stored column)
+  // by it before squaring / multiplying, so that the partial sums stay ~ ||A||^2 instead of ||A||^4 (the stored column is
+  // not normalised): the representable range of ||A|| is 1e+-150 as in the reference instead of 1e+-75.  Exact (power of 2).
+  double sigma;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -718,6 +723,7 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
   for (int c = 0; c < NC; ++c) acc[c] = zero_of(T{});
   double nrm = 0.0;
+  const double sig = st ? st->sigma : 1.0;  // power of two (1 outside the two-pass expansion): see DevState::sigma
 
   int64_t pb, pe;
   block_range(ldv / R, blockIdx.x, gridDim.x, pb, pe);
@@ -727,7 +733,7 @@ __global__ void __launch_bounds__(kBlock)
     P wv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      wv[u] = ld_pack(w + (p + (int64_t)u * kBlock) * R);
+      wv[u] = scale_pack(ld_pack(w + (p + (int64_t)u * kBlock) * R), sig);
       nrm += nrm2_pack(wv[u]);
     }
 #pragma unroll
@@ -746,7 +752,7 @@ __global__ void __launch_bounds__(kBlock)
   }
   for (; p < pe; p += kBlock) {  // remainder, one pack at a time
     const int64_t r = p * R;
-    const P wv = ld_pack(w + r);
+    const P wv = scale_pack(ld_pack(w + r), sig);
     nrm += nrm2_pack(wv);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -1441,6 +1447,7 @@ __global__ void __launch_bounds__(kBlock)
   T gi = zero_of(T{});
   if (!jm && jd && (jd - 1) >= ntrue && tid < jd) gi = gvec[tid];  // (only when a batch continues on factored columns)
   const double rnorm = st->rnorm, rnorm2 = st->rnorm2;
+  const double sig = st->sigma;  // what k_dots scaled y' by (set by the PREVIOUS launch of this kernel)
   // ---- reduction of this workgroup's column + election ----
   if (mode != 2) {
     const int c = blockIdx.x;
@@ -1593,21 +1600,29 @@ __global__ void __launch_bounds__(kBlock)
   if (jd) {
     const int j = jd;
     T* Hcol = Hd + (int64_t)(j - 1) * ldh;
-    const T* b_s = r_s + nm;  // s[0..j-1], |y'|^2 at [j]
+    // k_dots delivered the sums for sigma * y' (sigma a power of two): b_s = sigma s, sigma^2 |y'|^2; the algebra below runs on
+    // the scaled quantities (t'' = sigma t, g'' = sigma g) and divides the power of two out at the end -- exact
+    const T* b_s = r_s + nm;  // sigma s[0..j-1], sigma^2 |y'|^2 at [j]
+    const double isg = 1.0 / sig;
+    const T gs = scl(gi, sig);
     T ti = zero_of(T{});
     if (tid < j) {
       if (tid < ntrue) ti = b_s[tid];
-      else ti = dotc_contig(tb + (tid - ntrue) * tld, b_s, tid + 1);  // t[i] = sum_{k <= i} conj(T[k,i]) s[k]
+      else ti = dotc_contig(tb + (tid - ntrue) * tld, b_s, tid + 1);  // t''[i] = sum_{k <= i} conj(T[k,i]) s''[k]
       t_s[tid] = ti;
-      Hcol[tid] = scl(sub_(ti, gi), binv_in);  // h = V_true^H (A v_true)
+      Hcol[tid] = scl(scl(sub_(ti, gs), isg), binv_in);  // h = V_true^H (A v_true) = (t - g) / beta
     }
     // ||A v_true||^2 = (|y'|^2 - 2 Re g^H t + |g|^2) / beta^2
-    const double tot = wave_sum((tid < j) ? fma(-2.0, redot_(gi, ti), abs2_(gi)) : 0.0);
+    const double tot = wave_sum((tid < j) ? fma(-2.0, redot_(gs, ti), abs2_(gs)) : 0.0);
     if (tid == 0) {
       const double rn2 = real_of(b_s[j]) + tot;
-      st->rnorm = sqrt(rn2 > 0.0 ? rn2 : 0.0) * binv_in;
-      st->rnorm2 = sqrt(real_of(b_s[j])) * binv_in;  // norm of what the projection kernel actually works on: y' / beta
+      const double rn = sqrt(rn2 > 0.0 ? rn2 : 0.0) * isg * binv_in, rp = sqrt(real_of(b_s[j])) * isg * binv_in;
+      st->rnorm = rn;
+      st->rnorm2 = rp;  // norm of what the projection kernel actually works on: y' / beta
       st->invb = binv_in;
+      // scale for the NEXT step's k_dots: the column this step stores, w', has norm <= max(rn, rp) ~ ||A||
+      const double mag = fmax(rn, rp);
+      st->sigma = (mag > 0.0 && mag < 1.7e308) ? ldexp(1.0, -ilogb(mag)) : 1.0;
     }
     __syncthreads();
     if (tid < j) {  // coefficients of the STORED columns: T t / beta
@@ -1618,7 +1633,7 @@ __global__ void __launch_bounds__(kBlock)
         k0 = ntrue;
       }
       a = add_(a, dot_strided(tb + tid - ntrue * tld, tld, t_s, k0, j));
-      coef[tid] = scl(a, binv_in);
+      coef[tid] = scl(scl(a, isg), binv_in);
     }
   }
 #ifdef KS_FIN_TIMING

@@ -522,3 +522,18 @@ def test_column_stride_rule_is_deterministic_and_harmless(monkeypatch):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
     assert np.linalg.norm(out[0][0] - out[2][0]) < 1e-12 * np.linalg.norm(out[2][0])
     np.testing.assert_allclose(out[0][1], out[2][1], atol=1e-10)
+
+
+@pytest.mark.parametrize("scale", [1e100, 1e-100, 1e140, 1e-140])
+def test_operator_scaling_within_the_documented_range(scale):
+    """Norms on the device are square roots of sums of squares (no scaling pass as in BLAS nrm2), and the newest stored column
+    is not normalised: k_dots scales the product by a power of two so that every accumulated quantity stays of order ||A||^2
+    (DESIGN.md section 5).  Inside 1e-150 .. 1e150 the solver is scale-equivariant: eigenvalues of s A = s * eigenvalues of A,
+    same number of products."""
+    A, n = _operator(np.float64, (9, 10, 11))
+    v1 = _start(np.float64, n, seed=8)
+    kw = dict(nev=4, which="LM", tol=1e-10, mindim=8, maxdim=18, restarts=100)
+    d1, h1 = pkg.partialschur(A, v1=v1, **kw)
+    d2, h2 = pkg.partialschur(A * scale, v1=v1, **kw)
+    assert h1.converged and h2.converged and h1.mvproducts == h2.mvproducts
+    np.testing.assert_allclose(np.sort(d2.eigenvalues.real) / scale, np.sort(d1.eigenvalues.real), rtol=1e-9)
