@@ -1947,6 +1947,8 @@ template <class T> struct HipBackend : ks::Backend<T> {
   // second-pass update and the reduction of H[to, to-1] -- at n = 1e7 the update alone (0.4 ms) outlasts the whole early
   // part (0.13 ms), at n = 1e6 about 30 us of it are hidden (profiles/r02_restart_bubble.txt).
   // KS_EARLY_RESTART=0 keeps the strictly sequential order.  Same operations on the same numbers either way.
+  // Explicit-second-pass path (KS_PASSES=3) only: with the implicit second pass (default) H is final only when the batch
+  // ends -- there is no tail to hide behind -- and this returns false (the caller then runs the whole host step).
   bool iterate_arnoldi_early(int from, int to, const ks::Mat<T>& H, ks::ExpandStats& stats, const std::function<void()>& early) override {
     const char* e = std::getenv("KS_EARLY_RESTART");
     const bool on = !(e && e[0] == '0');
