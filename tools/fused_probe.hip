@@ -33,8 +33,11 @@ int main(int argc, char** argv) {
   const double GB = (double)n * 8 / 1e6;
   printf("ld = %ld (stride mod 128K = 0x%lx), j = %d\n", ld, (ld * 8) % window, j);
   for (int rep = 0; rep < 2; ++rep) {
-    float ms = timeit([&] { k_dots<double, 10><<<cu * 3, 256>>>(V, ld, j, y, partial, 8192, j, 1, nullptr); }, 5);
-    printf("k_dots<10> 3/CU                         %.3f ms  %.0f GB/s\n", ms, GB * (j + 1) / ms);
+    float ms = 0;
+    for (int g : {1, 2, 3, 4, 6}) {
+      ms = timeit([&] { k_dots<double, 10><<<cu * g, 256>>>(V, ld, j, y, partial, 8192, j, 1, nullptr); }, 5);
+      printf("k_dots<10> %d/CU                         %.3f ms  %.0f GB/s\n", g, ms, GB * (j + 1) / ms);
+    }
     for (int g : {2}) {
       for (int ps : {0, 1, 2, 3}) {
         ms = timeit([&] { k_axpy_dots_cs<double, 10, 4, 8><<<cu * g, 256>>>(V, ld, j, y, coef, partial, 8192, partial2, nullptr, 0, w, ps); }, 5);
@@ -53,6 +56,10 @@ int main(int argc, char** argv) {
     printf("cs<10,U=4,WB=16> 2/CU store=nt     %.3f ms  %.0f GB/s\n", ms, GB * (j + 2) / ms);
     ms = timeit([&] { k_axpy_dots_cs<double, 10, 4, 24><<<cu * 1, 256>>>(V, ld, j, y, coef, partial, 8192, partial2, nullptr, 0, w, 0); }, 5);
     printf("cs<10,U=4,WB=24> 1/CU store=nt     %.3f ms  %.0f GB/s\n", ms, GB * (j + 2) / ms);
+    ms = timeit([&] { k_axpy_dots_cs<double, 10, 4, 30><<<cu * 1, 256>>>(V, ld, j, y, coef, partial, 8192, partial2, nullptr, 0, w, 0); }, 5);
+    printf("cs<10,U=4,WB=30> 1/CU store=nt     %.3f ms  %.0f GB/s\n", ms, GB * (j + 2) / ms);
+    ms = timeit([&] { k_axpy_dots_cs<double, 10, 4, 24><<<cu * 1, 256>>>(V, ld, j, y, coef, partial, 8192, partial2, nullptr, 0, w, 2); }, 5);
+    printf("cs<10,U=4,WB=24> 1/CU store=none   %.3f ms  %.0f GB/s\n", ms, GB * (j + 2) / ms);
   }
   return 0;
 }
