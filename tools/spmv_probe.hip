@@ -57,5 +57,13 @@ int main() {
   run("x = column 36 of V written by the projection kernel just before (as in the expansion), y = column 41", fused(36), V + 36 * ld, V + 41 * ld);
   run("... and y separate", fused(36), V + 36 * ld, ys);
   run("x = column 36 of V, k_dots just before (x read last)", dots(37), V + 36 * ld, V + 41 * ld);
+  run("x = column 36 of V, k_dots over 4 columns just before", dots(4), V + 36 * ld, V + 41 * ld);
+  run("x = column 36 of V, single-stream read of the first 2 GB of V just before", [&] { k_flush<<<2048, 256>>>(V, out, 1L << 28); }, V + 36 * ld, V + 41 * ld);
+  run("x = column 36 of V, single-stream read of columns 10..35 of V just before", [&] { k_flush<<<2048, 256>>>(V + 10 * ld, out, 26 * ld); }, V + 36 * ld, V + 41 * ld);
+  run("x = column 36 of V, y SEPARATE, k_dots over 4 columns (w = column 41) just before", dots(4), V + 36 * ld, ys);
+  run("x = column 36 of V, y = column 42 of V, k_dots over 4 columns (w = column 41) just before", dots(4), V + 36 * ld, V + 42 * ld);
+  run("x = column 36 of V, y = column 42, projection kernel (reads column 41, writes column 36) just before", fused(36), V + 36 * ld, V + 42 * ld);
+  run("x, y separate allocations, k_dots over V just before", dots(37), xs, ys);
+  run("x, y separate allocations, projection kernel over V just before", fused(36), xs, ys);
   return 0;
 }
