@@ -677,6 +677,16 @@ def test_row_partitioned_solver_several_ranks_one_gpu(nproc, mode):
     assert r.stdout.count("-> OK") == nproc and "same: True" in r.stdout, r.stdout[-3000:]
 
 
+@pytest.mark.parametrize("nproc,mode,transport", [(2, "laplace", "p2p"), (3, "complex", "p2p"), (2, "laplace", "host"), (3, "hashed", "host")])
+def test_explicit_second_pass_path_with_real_ranks(nproc, mode, transport):
+    """KS_PASSES=3 (second projection applied to the vector; two exchanges per step, pending norm folded into the next
+    reduction) keeps its multi-rank modes covered now that the implicit second pass is the default: folded peer-to-peer
+    exchange and the reduce -> all-reduce -> post structure over the host-staged transport."""
+    r = _run_ranks(nproc, mode, extra_env={"KS_PASSES": "3", "KS_TRANSPORT": transport})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("-> OK") == nproc and "same: True" in r.stdout, r.stdout[-3000:]
+
+
 def test_reduce_allreduce_post_structure_with_real_ranks():
     """The RCCL transport's launch structure of the lazy path (reduce-only kernel -> all-reduce -> post kernel)
     with 3 real ranks: KS_P2P_NO_FOLD=1 runs exactly those kernel modes on the peer-to-peer all-reduce kernel."""
