@@ -212,6 +212,8 @@ def main():
                 spmv_b = fmt["bytes_per_nnz"] * nnz_global + 4.0 * (n + 1) + 16.0 * n
                 for j in range(k + 1, maxdim + 1):
                     state["moved"] += spmv_b + 8.0 * n * (j + 1) + 8.0 * n * (j + 2)
+                    # SURVEY 8d's compulsory B_step(j) as written there: plain CSR (12 B / non-zero), V twice, column once
+                    state["survey"] = state.get("survey", 0.0) + 12.0 * nnz_global + 4.0 * (n + 1) + 8.0 * n * (2 * j + 2)
                 if basis_passes == 3:
                     state["moved"] += st["reorth"] * 8.0 * n * ((k + 1 + maxdim) / 2.0 + 2)
                 state["t_expand"] += t1 - t0
@@ -424,7 +426,8 @@ def make_line(args, pkg, passes, order, world, rank, force_dist, wl, with_cpu_ba
     roof["fused_step"] = {
         "what": "SpMV + DGKS per Arnoldi step over the expansion wall time, per GPU.  moved_*: bytes the launched kernels must "
                 "move (" + ("two passes over V per step: the DGKS second projection is carried in a triangular factor, = SURVEY 8d's "
-                            "compulsory B_step(j) for the layout in use" if bp == 2 else
+                            "compulsory B_step(j) for the layout in use; survey_compulsory_frac prices the same time with SURVEY's own formula, "
+                            "12 B per non-zero of plain CSR, although the layout in use streams less" if bp == 2 else
                             "three passes over V when the second DGKS pass is taken") + ") -- the traffic-true figure, quote this one; "
                 "algorithmic_*: SURVEY 8d's formula for the UN-FUSED sequence with an explicit second pass (four passes over V) "
                 "divided by the same time -- a speed relative to the reference's op sequence, NOT a bandwidth (it rewards fusion "
@@ -433,6 +436,7 @@ def make_line(args, pkg, passes, order, world, rank, force_dist, wl, with_cpu_ba
         "moved_GBps": moved_gbs,
         "moved_frac": moved_gbs / HBM_PEAK_GBS,
         "moved_frac_of_measured_copy_ceiling": moved_gbs / 6290.0,
+        "survey_compulsory_frac": (state.get("survey", 0.0) / max(state["t_expand"], 1e-12) / 1e9 / world) / HBM_PEAK_GBS,
         "algorithmic_GBps": fused_gbs,
         "algorithmic_frac": fused_gbs / HBM_PEAK_GBS,
         "expand_seconds": state["t_expand"],
