@@ -61,5 +61,26 @@ int main(int argc, char** argv) {
     ms = timeit([&] { k_axpy_dots_cs<double, 10, 4, 24><<<cu * 1, 256>>>(V, ld, j, y, coef, partial, 8192, partial2, nullptr, 0, w, 2); }, 5);
     printf("cs<10,U=4,WB=24> 1/CU store=none   %.3f ms  %.0f GB/s\n", ms, GB * (j + 2) / ms);
   }
+  // the restart rotation (41 columns in, r out, in place): tile-bound or byte-bound?
+  {
+    double* Qd; CK(hipMalloc(&Qd, 8 * 44 * 48)); CK(hipMemset(Qd, 0, 8 * 44 * 48));
+    const int c = 41;
+    for (int r : {8, 16, 17, 21, 32}) {
+      const int ntile = (r + 15) / 16;
+      const size_t smem = (size_t)ntile * 16 * (4 * 11 + 1) * 8;
+      float ms = timeit([&] { k_rotate_mfma<11, 2><<<cu * 4, 256, smem>>>(V, ld, c, r, Qd, c, 0, -1); }, 5);
+      printf("k_rotate_mfma<11,2> 41 -> %2d columns  %.3f ms  %.0f GB/s (on %d columns)\n", r, ms, GB * (c + r) / ms, c + r);
+    }
+    {
+      const int r = 21, ntile = 2;
+      const size_t smem = (size_t)ntile * 16 * (4 * 11 + 1) * 8;
+      for (int g : {2, 3, 4}) {
+        float ms = timeit([&] { k_rotate_mfma<11, 4><<<cu * g, 256, smem>>>(V, ld, c, r, Qd, c, 0, -1); }, 5);
+        printf("k_rotate_mfma<11,RT=4> %d/CU 41 -> 21 columns  %.3f ms  %.0f GB/s\n", g, ms, GB * (c + r) / ms);
+        ms = timeit([&] { k_rotate_mfma<11, 1><<<cu * g * 2, 256, smem>>>(V, ld, c, r, Qd, c, 0, -1); }, 5);
+        printf("k_rotate_mfma<11,RT=1> %d/CU 41 -> 21 columns  %.3f ms  %.0f GB/s\n", g * 2, ms, GB * (c + r) / ms);
+      }
+    }
+  }
   return 0;
 }
