@@ -16,7 +16,7 @@ KS_OK, KS_ERR_ARGUMENT, KS_ERR_DIMENSION, KS_ERR_HIP, KS_ERR_RCCL, KS_ERR_QR, KS
 KS_F64, KS_C64 = 0, 1
 KS_I32, KS_I64 = 0, 1
 KS_CSR, KS_CSC = 0, 1
-LAYOUTS = {-1: "none", 0: "csr", 1: "csr-vi", 2: "csr-dvi", 3: "sell", 4: "sell-vi", 5: "stencil"}
+LAYOUTS = {-1: "none", 0: "csr", 1: "csr-vi", 2: "csr-dvi", 3: "sell", 4: "sell-vi", 5: "stencil", 6: "csr-cb"}
 WHICH = {"LM": 0, "LR": 1, "SR": 2, "LI": 3, "SI": 4}
 
 

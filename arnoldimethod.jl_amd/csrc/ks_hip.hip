@@ -342,6 +342,9 @@ template <class D> struct CsrOp : ks_operator {
   void* blkptr = nullptr;   // same integer type as rowptr
   int32_t* blkrow = nullptr;
   int nblk = 0;
+  // column-blocked layout: the matrix split into column blocks, each a CSR-row-block sub-operator of its own; apply() runs
+  // them in order, each continuing the row sums of the previous one (k_spmv_csr's yacc)
+  std::vector<std::unique_ptr<CsrOp<D>>> cblocks;
   int ni = 7;               // non-zeros per thread and block: a block holds at most ni * 256 entries in LDS
   int nlong = 0;            // rows longer than that: cut into chunk blocks, partial sums added by k_spmv_longfix
   int32_t* blkpart = nullptr;  // per block: -1, or the index of the chunk's partial sum
@@ -399,6 +402,29 @@ template <class D> struct CsrOp : ks_operator {
     (void)hipFree(sendbuf); (void)hipFree(send_idx); (void)hipFree(send_idx_all);
     (void)hipFree(codes); (void)hipFree(ddelta);
   }
+  // the CSR-row-block kernel of THIS operator's arrays on x -> y, continuing the row sums in `yacc` (column-blocked
+  // layout: plain CSR, single GPU, no long rows -- make_csr only builds column blocks under those conditions)
+  void launch_csr_blocks(const D* x, D* y, const DevState* st, const D* yacc, int plain_store) {
+    hipStream_t s = ctx->stream;
+    auto go = [&](auto ip_tag) {
+      using IP = decltype(ip_tag);
+      auto launch = [&](auto ni_tag) {
+        constexpr int NI = decltype(ni_tag)::value;
+        if constexpr ((size_t)NI * kBlock * sizeof(D) <= (size_t)ksd::kSpmvCapBytes)
+          ksd::k_spmv_csr<D, IP, false, NI><<<nblk, kBlock, 0, s>>>(static_cast<const IP*>(blkptr), blkrow, static_cast<const IP*>(rowptr), colidx, val, x,
+                                                                    nullptr, y, n_local, nblk, st, nullptr, 0, 0, nullptr, nullptr, yacc, plain_store);
+      };
+      switch (ni) {
+        case 4: launch(std::integral_constant<int, 4>{}); break;
+        case 7: launch(std::integral_constant<int, 7>{}); break;
+        case 8: launch(std::integral_constant<int, 8>{}); break;
+        case 12: launch(std::integral_constant<int, 12>{}); break;
+        default: launch(std::integral_constant<int, 16>{}); break;
+      }
+    };
+    if (ptr64) go(int64_t{});
+    else go(int32_t{});
+  }
   void apply(const void* xv, void* yv, const DevState* st) override {
     const D* x = static_cast<const D*>(xv);
     D* y = static_cast<D*>(yv);
@@ -449,6 +475,13 @@ template <class D> struct CsrOp : ks_operator {
       }
       KS_NCCL(ncclGroupEnd());
       }
+    }
+    if (n_local > 0 && !cblocks.empty()) {
+      // column-blocked CSR: one launch per column block; block b > 0 reads the partial row sums block b-1 left in y
+      ProfScope ps(ctx, KSP_SPMV, (double)nnz * bytes_per_nnz + aux_bytes + 2.0 * sizeof(D) * n_local);
+      for (size_t b = 0; b < cblocks.size(); ++b) cblocks[b]->launch_csr_blocks(x, y, st, b > 0 ? y : nullptr, b + 1 < cblocks.size() ? 1 : 0);
+      KS_HIP(hipGetLastError());
+      return;
     }
     if (n_local > 0) {
       // algorithmic bytes: 12 nnz + 4 (n+1) + 16 n   (8 -> 16 for complex); 4 nnz in the
@@ -684,7 +717,9 @@ inline void* upload_ptr(const std::vector<int64_t>& v, bool ptr64) {
 
 template <class D>
 CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<int64_t>& rp,
-                   const std::vector<int32_t>& ci, const std::vector<D>& vv) {
+                   const std::vector<int32_t>& ci, const std::vector<D>& vv, int cb_mode = 0) {
+  // cb_mode: 0 = column blocks not allowed (distributed operators: ghost columns), 1 = allowed (decided below),
+  //          2 = this IS a column block (plain CSR row blocks, nothing else is tried)
   auto op = std::make_unique<CsrOp<D>>();
   op->ctx = ctx;
   op->n_local = nrows;
@@ -695,7 +730,7 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
   // Delta-value-indexed layout (k_spmv_dvi): at most 256 distinct (column - row, value) pairs -> one byte per
   // non-zero.  KS_SPMV_FORMAT = csr | vi | dvi restricts the choice (default: the most compact that applies).
   {
-    const char* fmt = std::getenv("KS_SPMV_FORMAT");
+    const char* fmt = cb_mode == 2 ? "csr" : std::getenv("KS_SPMV_FORMAT");
     const bool try_dvi = nnz > 0 && (!fmt || std::string(fmt) == "dvi" || std::string(fmt) == "stencil");
     if (try_dvi) {
       struct Key {
@@ -839,7 +874,7 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
   std::vector<D> dict;
   std::vector<int32_t> packed;
   {
-    const char* fmt = std::getenv("KS_SPMV_FORMAT");
+    const char* fmt = cb_mode == 2 ? "csr" : std::getenv("KS_SPMV_FORMAT");
     bool try_vi = nnz > 0 && !(fmt && (std::string(fmt) == "csr" || std::string(fmt) == "dvi" || std::string(fmt) == "sell"));
     if (try_vi) {
       struct Key {
@@ -887,7 +922,7 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
   // KS_SPMV_FORMAT=sell / sellvi force it (KS_SELL_SIGMA = window for sorting rows by length, multiple of 64, default:
   // 1 = no permutation); csr / vi force the CSR blocks.
   {
-    const char* fmt = std::getenv("KS_SPMV_FORMAT");
+    const char* fmt = cb_mode == 2 ? "csr" : std::getenv("KS_SPMV_FORMAT");
     const std::string f = fmt ? fmt : "";
     const bool force_sell = f == "sell" || f == "sellvi";
     const bool allow_sell = force_sell || f.empty();
@@ -958,6 +993,58 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
         }
         return op.release();
       }
+    }
+  }
+  // COLUMN BLOCKS (KS_LAYOUT_CSR_CB).  A matrix with scattered columns whose x is larger than one XCD's L2 (4 MiB) runs at
+  // the device's random-gather rate (config 3: 59 us at n = 1e6, 5.1x its algorithmic traffic through the fabric).  Split
+  // into column blocks -- block b holds the entries with column in [b n/NB, (b+1) n/NB) -- each launch gathers from an
+  // x block that stays L2 resident, and because the entries of a row are sorted by column the row sums are simply
+  // continued from launch to launch (k_spmv_csr's yacc): same additions in the same order, bit-identical y.  Measured
+  // (tools/colblock_probe.py, n = 1e6): 59.5 us whole, 2 blocks 23 + 23 us, 4 blocks 4 x 13 us (launch floor), 8: 8 x 9.
+  // Auto: plain CSR row blocks would be used, single GPU, x between 6 and 160 MiB, rows sorted by column and short, and
+  // at least half of the entries further than n/16 from the diagonal -> blocks of ~4 MiB of x, at most 8.
+  // KS_SPMV_COLBLOCKS = 0 off / k >= 2 force.
+  if (cb_mode == 1 && op->ndict == 0 && nnz > 0) {
+    const int cb_env = env_int("KS_SPMV_COLBLOCKS", -1);  // (read per upload: tests switch it inside one process)
+    int nbk = 0;
+    if (cb_env != 0) {
+      bool sorted = true;
+      int64_t far = 0, maxrow = 0;
+      const int64_t fardist = std::max<int64_t>(1, nrows / 16);
+      for (int64_t r = 0; r < nrows && sorted; ++r) {
+        maxrow = std::max(maxrow, rp[r + 1] - rp[r]);
+        for (int64_t q = rp[r]; q < rp[r + 1]; ++q) {
+          if (q > rp[r] && ci[q] < ci[q - 1]) { sorted = false; break; }
+          far += std::llabs((int64_t)ci[q] - r) > fardist;
+        }
+      }
+      const double xmb = (double)nrows * sizeof(D) / (1 << 20);
+      if (sorted && maxrow <= 4 * kBlock) {
+        if (cb_env >= 2) nbk = cb_env;
+        // block width ~ 4 MiB of x (measured optimum at n = 1e6: 2 blocks, 2e6: 4 blocks); beyond 8 blocks the y that is
+        // written and read back between the launches (16 n bytes each) eats the gain (n = 1e7: 8 blocks -11 %, 16: +35 %)
+        else if (xmb >= 6.0 && xmb <= 160.0 && 2 * far >= nnz) nbk = std::min(8, std::max(2, (int)std::lround(xmb / 4.0)));
+      }
+    }
+    if (nbk >= 2) {
+      for (int b = 0; b < nbk; ++b) {
+        const int64_t lo = (int64_t)b * nrows / nbk, hi = (b + 1 == nbk) ? (int64_t)1 << 40 : (int64_t)(b + 1) * nrows / nbk;
+        std::vector<int64_t> rpb((size_t)nrows + 1, 0);
+        std::vector<int32_t> cib;
+        std::vector<D> vvb;
+        for (int64_t r = 0; r < nrows; ++r) {
+          for (int64_t q = rp[r]; q < rp[r + 1]; ++q)
+            if (ci[q] >= lo && ci[q] < hi) { cib.push_back(ci[q]); vvb.push_back(vv[q]); }
+          rpb[r + 1] = (int64_t)cib.size();
+        }
+        op->cblocks.emplace_back(make_csr<D>(ctx, nrows, (int64_t)cib.size(), rpb, cib, vvb, 2));
+      }
+      op->layout = KS_LAYOUT_CSR_CB;
+      op->bytes_per_nnz = 4.0 + sizeof(D);
+      op->aux_bytes = 0.0;
+      for (auto& cbk : op->cblocks) op->aux_bytes += cbk->aux_bytes;
+      op->aux_bytes += (double)(nbk - 1) * 2.0 * sizeof(D) * (double)nrows;  // y written and read back between the blocks
+      return op.release();
     }
   }
   // Row blocks of k_spmv_csr.  A block holds at most ni * 256 products in LDS (<= 32 KiB; KS_SPMV_NI overrides), so
@@ -2467,7 +2554,7 @@ int ks_operator_csr(ks_ctx* ctx, int64_t nrows_local, int64_t ncols, int64_t nnz
       using D = typename DevT<T>::type;
       std::vector<D> vv;
       build_csr_host<D>(nrows_local, ncols, nnz, ptr, idx, val, layout, index_base, index_type, rp, ci, vv);
-      *out = make_csr<D>(ctx, nrows_local, nnz, rp, ci, vv);
+      *out = make_csr<D>(ctx, nrows_local, nnz, rp, ci, vv, /*cb_mode=*/(ctx->nranks == 1 && nrows_local == ncols) ? 1 : 0);
     });
   });
 }

@@ -249,7 +249,9 @@ __global__ void __launch_bounds__(kBlock)
                const int32_t* __restrict__ colidx, const T* __restrict__ val, const T* __restrict__ x,
                const T* __restrict__ xg, T* __restrict__ y, int64_t n, int nblk, const DevState* __restrict__ st,
                const uint32_t* __restrict__ hseq, int64_t gstride, int ndict, const int32_t* __restrict__ blkpart,
-               T* __restrict__ lpart) {
+               T* __restrict__ lpart, const T* __restrict__ yacc = nullptr, int plain_store = 0) {
+  // yacc != nullptr: this launch handles ONE COLUMN BLOCK of the matrix (column-blocked layout) and continues the row sums
+  // an earlier launch left in yacc -- entries of a row are visited in CSR order across the launches, so y is bit-identical
   if (st && st->breakdown >= 0) return;
   // peer-to-peer halo (ks_p2p.hpp): the ghost vector is double-buffered, the parity of the halo sequence
   // number the push kernel just published selects the slot
@@ -301,9 +303,10 @@ __global__ void __launch_bounds__(kBlock)
     }
     __syncthreads();
     if (r0 + tid < r1) {
-      T s = zero_of(T{});
+      T s = yacc ? yacc[r0 + tid] : zero_of(T{});
       for (int32_t p = ra; p < rb; ++p) s = add_(s, prod[p]);
-      st_elem_nt(y + r0 + tid, s);
+      if (plain_store) y[r0 + tid] = s;  // (an intermediate column block: the next launch reads it back)
+      else st_elem_nt(y + r0 + tid, s);
     }
   } else {
     // one CHUNK (<= CAP entries) of a row too long for a block: the same coalesced loads, then every thread adds up

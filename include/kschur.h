@@ -151,6 +151,8 @@ int ks_operator_size(const ks_operator* op, int64_t* n_local, int64_t* nnz, int*
  *   KS_LAYOUT_DVI      one byte per non-zero into a <= 256-entry dictionary of (column - row, value) pairs (stencils)
  *   KS_LAYOUT_SELL     sliced ELLPACK, 64-row slices stored column-major (lane = row: coalesced loads and, for banded
  *                      matrices, coalesced gathers); taken when slicing pads the matrix by <= 15 % (uniform row lengths)
+ *   KS_LAYOUT_CSR_CB   column-blocked CSR row blocks: matrices with scattered columns whose x does not fit one XCD's L2 (config 3)
+ *                      are split into column blocks, one launch each, the row sums continued across the launches in CSR order
  *   KS_LAYOUT_CSR      row blocks of <= 256 rows / <= 4096 non-zeros streamed non-zero-parallel through LDS; a longer
  *                      row is a block of its own (ragged and skewed matrices)
  *   ..._VI             the same storage orders with ONE 32-bit word per non-zero (dictionary index << 24 | column):
@@ -160,7 +162,7 @@ int ks_operator_size(const ks_operator* op, int64_t* n_local, int64_t* nnz, int*
  * *bytes_per_nnz = what the SpMV streams per stored non-zero (padding included: 12 / 20 for plain CSR Float64 /
  * ComplexF64, 4 value-indexed, 1 delta-value-indexed), *ndict the dictionary size, *layout one of the codes below
  * (0 / 0 / -1 for dense and callback operators). */
-enum { KS_LAYOUT_CSR = 0, KS_LAYOUT_CSR_VI = 1, KS_LAYOUT_DVI = 2, KS_LAYOUT_SELL = 3, KS_LAYOUT_SELL_VI = 4, KS_LAYOUT_STENCIL = 5 };
+enum { KS_LAYOUT_CSR = 0, KS_LAYOUT_CSR_VI = 1, KS_LAYOUT_DVI = 2, KS_LAYOUT_SELL = 3, KS_LAYOUT_SELL_VI = 4, KS_LAYOUT_STENCIL = 5, KS_LAYOUT_CSR_CB = 6 };
 int ks_operator_format(const ks_operator* op, double* bytes_per_nnz, int* ndict, int* layout);
 /* y = A*x on raw device pointers (bench / tests; the solver uses ks_apply below). */
 int ks_operator_apply_raw(ks_operator* op, const void* x_dev, void* y_dev);

@@ -274,3 +274,62 @@ def test_malformed_pointer_arrays_are_rejected():
     p = np.array([0, 1, 2, 3, 4], dtype=np.int64)
     h = C.c_void_p()
     assert L.ks_operator_csr(ctx._h, 4, 4, 4, p.ctypes.data, bad_col.ctypes.data, val.ctypes.data, pkg._lib.KS_CSR, 0, pkg._lib.KS_I64, pkg._lib.KS_F64, C.byref(h)) == pkg._lib.KS_ERR_ARGUMENT
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_column_blocked_csr_is_bit_identical(dtype, monkeypatch):
+    """KS_LAYOUT_CSR_CB: the matrix split into column blocks, one launch each, the row sums continued from launch to launch
+    in CSR order -- y must equal the plain CSR row-block layout BIT for bit, for 2, 3 and 5 blocks, with empty rows, rows
+    confined to one block and rows that span all of them; the auto rule picks it for config 3's matrix (n = 1e6: x = 8 MB,
+    scattered columns) and leaves a banded matrix alone."""
+    rng = np.random.default_rng(11)
+    n = 30_000
+    A = sp.random(n, n, density=6.0 / n, random_state=rng, format="lil", dtype=np.float64)
+    A[100:140, :] = 0                                   # empty rows
+    for r in range(200, 260):                           # rows confined to the first / last column block
+        A[r, :] = 0
+        A[r, rng.choice(n // 8, 5, replace=False)] = rng.standard_normal(5)
+        A[r + 100, :] = 0
+        A[r + 100, n - 1 - rng.choice(n // 8, 5, replace=False)] = rng.standard_normal(5)
+    A = A.tocsr()
+    if np.dtype(dtype).kind == "c":
+        B = A.copy()
+        B.data = rng.standard_normal(B.nnz)
+        A = (A + 1j * B).tocsr()
+    A = A.astype(dtype)
+    A.sort_indices()
+    x = rnd(rng, dtype, n)
+    monkeypatch.setenv("KS_SPMV_FORMAT", "csr")
+    monkeypatch.setenv("KS_SPMV_COLBLOCKS", "0")
+    y0, f0, _ = _apply(A, x, dtype)
+    assert f0["layout"] == "csr"
+    for nb in ("2", "3", "5"):
+        monkeypatch.setenv("KS_SPMV_COLBLOCKS", nb)
+        y, f, _ = _apply(A, x, dtype)
+        assert f["layout"] == "csr-cb", f
+        assert np.array_equal(y, y0), nb
+    # unsorted rows: the order of the additions would change -> the layout must refuse
+    monkeypatch.setenv("KS_SPMV_COLBLOCKS", "2")
+    U = A.copy()
+    U.has_sorted_indices = False
+    r = 5000
+    a, b = U.indptr[r], U.indptr[r + 1]
+    if b - a >= 2:
+        U.indices[a:b] = U.indices[a:b][::-1].copy()
+        U.data[a:b] = U.data[a:b][::-1].copy()
+        yu, fu, _ = _apply(U, x, dtype)
+        assert fu["layout"] == "csr"
+    monkeypatch.delenv("KS_SPMV_FORMAT")
+    monkeypatch.delenv("KS_SPMV_COLBLOCKS")
+    if np.dtype(dtype).kind == "f":
+        H = pkg.matrices.hashed_nonsymmetric_csr(1_000_000, seed=7)
+        xh = rnd(rng, dtype, H.shape[0])
+        yh, fh, _ = _apply(H, xh, dtype)
+        assert fh["layout"] == "csr-cb", fh
+        monkeypatch.setenv("KS_SPMV_COLBLOCKS", "0")
+        yp, fp, _ = _apply(H, xh, dtype)
+        assert fp["layout"] == "csr" and np.array_equal(yh, yp)
+        monkeypatch.delenv("KS_SPMV_COLBLOCKS")
+        Bd = sp.diags([rng.standard_normal(1_000_000 - abs(k)) for k in (-3, -1, 0, 1, 3)], [-3, -1, 0, 1, 3], format="csr")
+        _, fb, _ = _apply(Bd, xh, dtype)
+        assert fb["layout"] != "csr-cb", fb
