@@ -50,13 +50,13 @@ class ks_params(C.Structure):
 class ks_history(C.Structure):
     _fields_ = [
         ("mvproducts", C.c_int32), ("nconverged", C.c_int32), ("converged", C.c_int32), ("nev", C.c_int32),
-        ("restarts", C.c_int32), ("reorth", C.c_int32), ("breakdowns", C.c_int32), ("reserved", C.c_int32),
+        ("restarts", C.c_int32), ("reorth", C.c_int32), ("breakdowns", C.c_int32), ("explicit_steps", C.c_int32),
         ("seconds_expand", C.c_double), ("seconds_host", C.c_double), ("seconds_rotate", C.c_double),
     ]
 
 
 class ks_expand_stats(C.Structure):
-    _fields_ = [("steps", C.c_int32), ("reorth", C.c_int32), ("breakdowns", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("steps", C.c_int32), ("reorth", C.c_int32), ("breakdowns", C.c_int32), ("explicit_steps", C.c_int32)]
 
 
 HOST_APPLY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
@@ -93,6 +93,9 @@ PROTOTYPES = {
     "ks_workspace_create": [vp, i64, i64, i64, i32, i32, P(vp)],
     "ks_workspace_placement": [vp, P(C.c_int), P(C.c_double), P(C.c_double), P(C.c_int)],
     "ks_workspace_passes": [vp, P(C.c_int)],
+    "ks_workspace_set_passes": [vp, i32, dbl],
+    "ks_workspace_assert_arnoldi": [vp, i32],
+    "ks_workspace_provenance": [vp, P(C.c_int)],
     "ks_workspace_check_guard": [vp, P(C.c_int)],
     "ks_workspace_destroy": [vp],
     "ks_workspace_dims": [vp, P(i64), P(C.c_int), P(C.c_int), P(i64)],

@@ -506,7 +506,7 @@ class ArnoldiWorkspace:
     def iterate_arnoldi(self, A: Operator, frm: int, to: int):
         st = _lib.ks_expand_stats()
         _check_op(_lib.load().ks_iterate_arnoldi(A._h, self._h, frm, to, C.byref(st)), A)
-        return dict(steps=st.steps, reorth=st.reorth, breakdowns=st.breakdowns)
+        return dict(steps=st.steps, reorth=st.reorth, breakdowns=st.breakdowns, explicit_steps=st.explicit_steps)
 
     def restart(self, active: int, nev: int, which="LM", tol=None, mindim=None, maxdim=None):
         """One Krylov-Schur restart (src/run.jl:278-365): host Schur / grouping / restore, then the
@@ -524,8 +524,9 @@ class ArnoldiWorkspace:
 
     def expand_restart(self, A: Operator, k: int, active: int, nev: int, which="LM", tol=None, mindim=None, maxdim=None):
         """One whole cycle of `_partialschur`'s loop (src/run.jl:272-365): iterate_arnoldi!(k+1 : maxdim) and the restart in
-        ONE library call, the early part of the restart's host work overlapped with the tail of the expansion (what
-        `partialschur` does internally; bit-identical to iterate_arnoldi + restart).  `k` = basis size the previous restart
+        ONE library call (what `partialschur` does internally; bit-identical to iterate_arnoldi + restart).  With the explicit
+        second pass (`passes == 3`) the early part of the restart's host work overlaps the tail of the expansion; with the
+        implicit second pass (default) H is final only when the batch ends.  `k` = basis size the previous restart
         left.  Returns restart()'s dict plus steps / reorth / breakdowns and seconds = (expansion, host, rotation enqueue)."""
         maxdim = self.maxdim if maxdim is None else maxdim
         mindim = min(max(10, nev), self.n_global) if mindim is None else mindim
@@ -538,7 +539,8 @@ class ArnoldiWorkspace:
         _check_op(_lib.load().ks_expand_restart(A._h, self._h, C.byref(p), active, k, C.byref(ko), C.byref(nlock), C.byref(purge),
                                                 lams.ctypes.data, rs.ctypes.data, groups.ctypes.data, C.byref(st), sec.ctypes.data), A)
         return dict(k=ko.value, nlock=nlock.value, purge=purge.value, eigenvalues=lams[0::2] + 1j * lams[1::2], residuals=rs,
-                    groups=groups, steps=st.steps, reorth=st.reorth, breakdowns=st.breakdowns, seconds=tuple(sec))
+                    groups=groups, steps=st.steps, reorth=st.reorth, breakdowns=st.breakdowns, explicit_steps=st.explicit_steps,
+                    seconds=tuple(sec))
 
     def residual_norms(self, A: Operator, ncols: int):
         r, o = C.c_double(), C.c_double()
@@ -555,6 +557,23 @@ class ArnoldiWorkspace:
         """Reads of the basis per fused expansion step: 2 (implicit second pass, default) or 3 (KS_PASSES=3)."""
         k = C.c_int()
         check(_lib.load().ks_workspace_passes(self._h, C.byref(k)))
+        return k.value
+
+    def set_passes(self, passes: int, max_ratio: float = float("nan")):
+        """Per-workspace switch: 2 = implicit second DGKS pass, 3 = explicit; `max_ratio` = largest ||c|| / beta the
+        implicit form carries before a step is redone explicitly (NaN keeps the current value, <= 0 removes the limit)."""
+        check(_lib.load().ks_workspace_set_passes(self._h, int(passes), float(max_ratio)))
+
+    def assert_arnoldi(self, k: int):
+        """The caller vouches that columns 0..k are orthonormal and satisfy, with the H now in `self.H`, the Arnoldi
+        relation of k steps (a restart the host language ran itself): re-enables the implicit second pass."""
+        check(_lib.load().ks_workspace_assert_arnoldi(self._h, int(k)))
+
+    @property
+    def provenance(self) -> int:
+        """Steps of the factorisation the library trusts as its own (-1: none) -- see ks_workspace_assert_arnoldi."""
+        k = C.c_int()
+        check(_lib.load().ks_workspace_provenance(self._h, C.byref(k)))
         return k.value
 
     @property
@@ -618,6 +637,7 @@ class History:
     restarts: int = 0
     reorth: int = 0
     breakdowns: int = 0
+    explicit_steps: int = 0  # steps the implicit second DGKS pass handed back to the explicit form
     seconds_expand: float = 0.0
     seconds_host: float = 0.0
     seconds_rotate: float = 0.0
@@ -639,7 +659,7 @@ def _run(op: Operator, ws: ArnoldiWorkspace, nev, which, tol, mindim, maxdim, re
         v1p = v1.ctypes.data
     _check_op(L.ks_partialschur(op._h, ws._h, C.byref(p), v1p, eig.ctypes.data, C.byref(h)), op)
     lam = (eig[0::2] + 1j * eig[1::2])[: h.nconverged].copy()
-    hist = History(h.mvproducts, h.nconverged, bool(h.converged), h.nev, h.restarts, h.reorth, h.breakdowns,
+    hist = History(h.mvproducts, h.nconverged, bool(h.converged), h.nev, h.restarts, h.reorth, h.breakdowns, h.explicit_steps,
                    h.seconds_expand, h.seconds_host, h.seconds_rotate)
     return PartialSchur(ws, h.nconverged, lam), hist
 

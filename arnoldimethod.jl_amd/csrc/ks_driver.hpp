@@ -23,6 +23,7 @@ namespace ks {
 
 struct ExpandStats {
   int steps = 0, reorth = 0, breakdowns = 0;
+  int explicit_steps = 0;  // steps a backend with an implicit second DGKS pass redid in the explicit form
 };
 
 // What the driver needs from whoever owns V.  Column/step numbering follows the reference with
@@ -62,7 +63,7 @@ struct Params {
 };
 
 struct History {
-  int mvproducts = 0, nconverged = 0, converged = 0, nev = 0, restarts = 0, reorth = 0, breakdowns = 0;
+  int mvproducts = 0, nconverged = 0, converged = 0, nev = 0, restarts = 0, reorth = 0, breakdowns = 0, explicit_steps = 0;
   double seconds_expand = 0, seconds_host = 0, seconds_rotate = 0;
 };
 
@@ -242,6 +243,7 @@ inline History partialschur_driver(Backend<T>& be, const Mat<T>& H, const Mat<T>
   hist.converged = nconverged >= nev;
   hist.reorth = st.reorth;
   hist.breakdowns = st.breakdowns;
+  hist.explicit_steps = st.explicit_steps;
   return hist;
 }
 

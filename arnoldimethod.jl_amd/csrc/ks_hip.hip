@@ -15,6 +15,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -126,6 +127,7 @@ struct ks_ctx {
     void* peer[ksd::kP2pMaxRanks] = {};
     uint32_t* seqc = nullptr;
     uint32_t* hstate = nullptr;
+    uint32_t hseq = 0;          // sequence number of the last halo exchange enqueued on this context (ks_p2p.hpp)
     int* err_h = nullptr;
     int cap = 0;
     ksd::P2pDev dev{};
@@ -387,6 +389,7 @@ template <class D> struct CsrOp : ks_operator {
   D* hrecv = nullptr;
   bool p2p_halo = false;
   int64_t ghost_stride = 0;         // elements between the two ghost slots
+  int64_t ghost_lo_end = 0, ghost_hi_begin = 0;  // only rows < ghost_lo_end or >= ghost_hi_begin reference ghost columns (fused exchange)
   size_t arena_lo = 0, arena_hi = 0;
   int32_t* send_idx_all = nullptr;  // every send entry (contiguous runs included), neighbour by neighbour
   ksd::HaloArgs hargs{};
@@ -413,6 +416,8 @@ template <class D> struct CsrOp : ks_operator {
         if constexpr ((size_t)NI * kBlock * sizeof(D) <= (size_t)ksd::kSpmvCapBytes)
           ksd::k_spmv_csr<D, IP, false, NI><<<nblk, kBlock, 0, s>>>(static_cast<const IP*>(blkptr), blkrow, static_cast<const IP*>(rowptr), colidx, val, x,
                                                                     nullptr, y, n_local, nblk, st, nullptr, 0, 0, nullptr, nullptr, yacc, plain_store);
+        else
+          throw KsError{KS_ERR_INTERNAL, "CSR row blocks of " + std::to_string(NI) + " x 256 entries exceed the LDS budget of this element type"};
       };
       switch (ni) {
         case 4: launch(std::integral_constant<int, 4>{}); break;
@@ -429,14 +434,35 @@ template <class D> struct CsrOp : ks_operator {
     const D* x = static_cast<const D*>(xv);
     D* y = static_cast<D*>(yv);
     hipStream_t s = ctx->stream;
-    if (p2p_halo) {
-      if (!neigh.empty()) {
-        const int64_t total = send_ptr.back();
+    // peer-to-peer mode: sequence number and ghost slot of this exchange (host counter, ks_p2p.hpp); the stencil and the
+    // CSR-row-block kernels do the exchange themselves, every other layout gets the push kernel in front
+    ksd::HaloFused hf{};
+    const D* xg = ghost;
+    if (p2p_halo && !neigh.empty()) {
+      uint32_t seq = ctx->p2p.hseq + 1u;
+      if (seq == 0u) seq = 1u;
+      ctx->p2p.hseq = seq;
+      xg = ghost + (int64_t)(seq & 1u) * ghost_stride;
+      static const int fuse_env = env_int("KS_HALO_FUSED", 1);
+      const bool fusable = fuse_env && n_local > 0 && cblocks.empty() && ndvi == 0 && nslices == 0;
+      const int64_t total = send_ptr.back();
+      if (fusable) {
+        hf.enabled = 1;
+        hf.seq = seq;
+        // pushers: ~8 entries per thread (two trips of four independent entries), at most 64 workgroups -- each pusher ends
+        // with a system-scope release fence (an L2 write-back), which is what an SpMV launch can afford only a few of
+        static const int npush_env = env_int("KS_HALO_NPUSH", 0);
+        hf.npush = npush_env > 0 ? npush_env : (int)std::max<int64_t>(1, std::min<int64_t>((total + 2047) / 2048, 64));
+        hf.send_idx = send_idx_all;
+        hf.counter = ctx->p2p.hstate + 1;
+        hf.ghost_lo_end = ghost_lo_end;
+        hf.ghost_hi_begin = ghost_hi_begin;
+      } else {
         const int gb = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 512));
-        ksd::k_halo_push<D><<<gb, 256, 0, s>>>(x, send_idx_all, hargs, ctx->p2p.dev, ctx->p2p.hstate,
+        ksd::k_halo_push<D><<<gb, 256, 0, s>>>(x, send_idx_all, hargs, ctx->p2p.dev, ctx->p2p.hstate, seq,
                                                  st ? &st->breakdown : nullptr);
       }
-    } else if (!neigh.empty()) {
+    } else if (!p2p_halo && !neigh.empty()) {
       // neighbours whose send list is one contiguous run of rows (grid planes of a slab partition) are sent
       // straight out of x; only genuinely scattered lists go through the pack kernel
       if (nscatter > 0) {
@@ -487,7 +513,7 @@ template <class D> struct CsrOp : ks_operator {
       // algorithmic bytes: 12 nnz + 4 (n+1) + 16 n   (8 -> 16 for complex); 4 nnz in the
       // value-indexed layout, 1 nnz in the delta-value-indexed one
       ProfScope ps(ctx, KSP_SPMV, (double)nnz * bytes_per_nnz + aux_bytes + 2.0 * sizeof(D) * n_local);
-      const uint32_t* hseq = (p2p_halo && !neigh.empty()) ? ctx->p2p.hstate : nullptr;
+      const uint32_t* hseq = nullptr;  // (the host picked the ghost slot: xg)
       auto with_ip = [&](auto f) {
         if (ptr64) f(int64_t{});
         else f(int32_t{});
@@ -508,8 +534,11 @@ template <class D> struct CsrOp : ks_operator {
           using MT = decltype(mt_tag);
           constexpr int RPT = decltype(rpt_tag)::value;
           const int nt = (int)((n_local + kBlock * RPT - 1) / (kBlock * RPT));
-          ksd::k_spmv_stencil<D, MT, RPT><<<nt, kBlock, 0, s>>>(static_cast<const MT*>(smask), sdict, nstencil, x, ghost, y, n_local,
-                                                                std::max<int64_t>(nghost, 0), nt, st, hseq, ghost_stride);
+          ksd::HaloFused h = hf;
+          h.npush = std::min(h.npush, nt);
+          h.tile_shift = (h.enabled && ghost_lo_end < n_local) ? (int)((ghost_lo_end + kBlock * RPT - 1) / (kBlock * RPT)) % std::max(nt, 1) : 0;
+          ksd::k_spmv_stencil<D, MT, RPT><<<nt, kBlock, 0, s>>>(static_cast<const MT*>(smask), sdict, nstencil, x, xg, y, n_local,
+                                                                std::max<int64_t>(nghost, 0), nt, st, h, hargs, ctx->p2p.dev);
         };
         auto by_rpt = [&](auto mt_tag) {
           if (rpt_env <= 1) go(mt_tag, std::integral_constant<int, 1>{});
@@ -528,7 +557,7 @@ template <class D> struct CsrOp : ks_operator {
           auto go = [&](auto un_tag, auto rpt_tag) {
             constexpr int UN = decltype(un_tag)::value, RPT = decltype(rpt_tag)::value;
             const int nt = (int)((n_local + kBlock * RPT - 1) / (kBlock * RPT));
-            ksd::k_spmv_dvi<D, IP, UN, RPT><<<nt, kBlock, 0, s>>>(rp, codes, ddelta, val, x, ghost, y, n_local, nt, ndvi, st, hseq, ghost_stride);
+            ksd::k_spmv_dvi<D, IP, UN, RPT><<<nt, kBlock, 0, s>>>(rp, codes, ddelta, val, x, xg, y, n_local, nt, ndvi, st, hseq, ghost_stride);
           };
           using I = std::integral_constant<int, 0>;
           (void)sizeof(I);
@@ -554,10 +583,10 @@ template <class D> struct CsrOp : ks_operator {
             constexpr int UN = decltype(un_tag)::value;
             static const int plain_loads = env_int("KS_SELL_PLAIN_LOADS", 0);  // experiment: default-policy loads of the matrix streams
             if (plain_loads)
-              ksd::k_spmv_sell<D, IP, VI, UN, false><<<ng, kBlock, 0, s>>>(static_cast<const IP*>(sliceptr), colidx, val, sperm, x, ghost, y,
+              ksd::k_spmv_sell<D, IP, VI, UN, false><<<ng, kBlock, 0, s>>>(static_cast<const IP*>(sliceptr), colidx, val, sperm, x, xg, y,
                                                                            n_local, nslices, ng, st, hseq, ghost_stride, ndict);
             else
-              ksd::k_spmv_sell<D, IP, VI, UN, true><<<ng, kBlock, 0, s>>>(static_cast<const IP*>(sliceptr), colidx, val, sperm, x, ghost, y,
+              ksd::k_spmv_sell<D, IP, VI, UN, true><<<ng, kBlock, 0, s>>>(static_cast<const IP*>(sliceptr), colidx, val, sperm, x, xg, y,
                                                                           n_local, nslices, ng, st, hseq, ghost_stride, ndict);
           };
           auto by_un = [&](auto vi_tag) {
@@ -576,8 +605,15 @@ template <class D> struct CsrOp : ks_operator {
           constexpr bool VI = decltype(vi_tag)::value;
           constexpr int NI = decltype(ni_tag)::value;
           if constexpr ((size_t)NI * kBlock * sizeof(D) <= (size_t)ksd::kSpmvCapBytes)
+          {
+            ksd::HaloFused h = hf;
+            h.npush = std::min(h.npush, nblk);
             ksd::k_spmv_csr<D, IP, VI, NI><<<nblk, kBlock, 0, s>>>(static_cast<const IP*>(blkptr), blkrow, static_cast<const IP*>(rowptr), colidx,
-                                                                   val, x, ghost, y, n_local, nblk, st, hseq, ghost_stride, ndict, blkpart, lpart);
+                                                                   val, x, xg, y, n_local, nblk, st, hseq, ghost_stride, ndict, blkpart, lpart,
+                                                                   nullptr, 0, h, hargs, ctx->p2p.dev);
+          }
+          else
+            throw KsError{KS_ERR_INTERNAL, "CSR row blocks of " + std::to_string(NI) + " x 256 entries exceed the LDS budget of this element type"};
         };
         auto by_ni = [&](auto vi_tag) {
           switch (ni) {
@@ -1185,7 +1221,18 @@ struct ks_workspace {
   bool use_mbox = true;         // KS_MAILBOX (read at creation); 0: hipMemcpyAsync + hipStreamSynchronize
   // IMPLICIT SECOND PASS (ks_kernels.hpp, k_fin_dots_t / k_fin_mid_t): V_true = S * T.  T and the vector g live in the
   // control block behind the column factors; columns < ntrue are ordinary, columns ntrue..t_hi are "T-lazy".
-  int passes = 2;               // KS_PASSES at creation: 2 = implicit second pass (default), 3 = second pass applied to the vector
+  int passes = 2;               // 2 = implicit second pass (default), 3 = second pass applied to the vector (KS_PASSES at
+                                // creation, ks_workspace_set_passes afterwards)
+  double max_ratio = 1e-3;      // largest ||c|| / beta an implicit second pass carries (DevState::max_ratio); a step beyond
+                                // it is redone in the explicit form.  KS_IMPLICIT_MAX_RATIO at creation, ks_workspace_set_passes
+  // PROVENANCE of the factorisation.  The implicit second pass reads EARLIER columns of H (g = H c) and
+  // relies on the Arnoldi relation A V[:, 0:k) = V[:, 0:k+1) H[0:k+1, 0:k) for them; the reference's iterate_arnoldi!
+  // never does.  prov_k >= 0: the library itself produced (or the caller asserted, ks_workspace_assert_arnoldi) steps
+  // 1..prov_k and nobody wrote to V since; Hshadow = the host H as the library last left it.  A batch starting at
+  // step `from` takes the implicit form only if prov_k >= from - 1 AND the caller's H[:, 0:from-1) still equals the
+  // shadow bit for bit; otherwise it runs the explicit three-pass form, which needs neither.  -1: unknown.
+  int prov_k = -1;
+  std::vector<char> Hshadow;
   size_t off_T = 0, off_g = 0, ctl_bytes = 0;
   int ldt = 0;
   void* Td = nullptr;           // device, ldt x ldt, inside the Hd allocation
@@ -1510,7 +1557,11 @@ inline void mbox_wait(ks_workspace* ws, int slot, uint64_t seq) {
   const uint64_t* f = ws->mbox + 8 * slot;
   unsigned spins = 0;
   while (__atomic_load_n(f, __ATOMIC_ACQUIRE) != seq) {
+#if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
     if ((++spins & 0xFFFu) == 0) {  // every ~50 us: is the stream still alive?
       const hipError_t q = hipStreamQuery(ws->ctx->stream);
       if (q == hipSuccess) {
@@ -1699,6 +1750,23 @@ inline bool use_deferred(const ks_workspace* ws, int to) {
   return to <= kFusedMaxJ && !no_fuse && !no_defer;
 }
 
+// Provenance (ks_workspace::prov_k): see the field's comment.
+inline size_t h_bytes(const ks_workspace* ws) { return (size_t)(ws->maxdim + 1) * ws->maxdim * ws->esz; }
+inline void prov_set(ks_workspace* ws, int k) {
+  ws->prov_k = k;
+  if (k < 0) return;
+  ws->Hshadow.resize(h_bytes(ws));
+  std::memcpy(ws->Hshadow.data(), ws->H, h_bytes(ws));
+}
+inline void prov_drop(ks_workspace* ws) { ws->prov_k = -1; }
+// may a batch that starts at step `from` lean on H[:, 0:from-1) and the relation of those steps?
+inline bool prov_ok(const ks_workspace* ws, int from) {
+  if (ws->prov_k < from - 1) return false;
+  const size_t bytes = (size_t)(ws->maxdim + 1) * (size_t)(from - 1) * ws->esz;
+  if (bytes == 0) return true;
+  return ws->Hshadow.size() >= bytes && std::memcmp(ws->H, ws->Hshadow.data(), bytes) == 0;
+}
+
 // Start of a batch: fresh DevState and, when the host changed column factors since the last batch, the factors --
 // one asynchronous copy from the pinned control block, no synchronisation.
 inline void reset_state(ks_workspace* ws, bool upload_H = false, double sigma0 = 1.0) {
@@ -1706,6 +1774,8 @@ inline void reset_state(ks_workspace* ws, bool upload_H = false, double sigma0 =
   // host-side change, which follows the synchronising fetch of the previous batch)
   std::memset(ws->st_h, 0, sizeof(DevState));
   ws->st_h->breakdown = -1;
+  ws->st_h->bail = -1;
+  ws->st_h->max_ratio = ws->max_ratio;
   ws->st_h->sigma = sigma0;
   if (upload_H) {
     // implicit second pass: the device needs the CURRENT H (the restart rewrote its leading block on the host) for
@@ -2054,6 +2124,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
       // (ks_reinitialize(ws, 0, ...) or ks_partialschur with initialize = 1) before using the workspace again.
       (void)hipStreamSynchronize(ws->ctx->stream);
       try { reset_lazy(ws); } catch (...) {}
+      prov_drop(ws);
       throw;
     }
   }
@@ -2063,12 +2134,18 @@ template <class T> struct HipBackend : ks::Backend<T> {
     ws->ctx->use();
     bool early_stands = false;
     int j0 = from;
+    int explicit_step = -1;  // a step the implicit form handed back (DevState::bail): redone with the explicit second pass
+    // Provenance: the implicit second pass reads earlier columns of the caller's H and assumes the Arnoldi relation for
+    // them.  Only a factorisation the library produced itself (or the caller vouched for) qualifies; anything else runs
+    // the explicit form, which -- like the reference's iterate_arnoldi! -- reads neither.
+    const bool trusted = prov_ok(ws, from);
     while (j0 <= to) {
       const double tb0 = ks::now_s();
       int jend = to;
       if (!op->async_capable) jend = j0;  // host operators: one step per batch
+      if (explicit_step >= 0) jend = j0;
       const bool lazy = use_deferred(ws, jend);
-      const bool tpath = lazy && ws->passes == 2;    // implicit second pass: two reads of the basis per step
+      const bool tpath = lazy && ws->passes == 2 && trusted && explicit_step < 0;  // implicit second pass: two reads of the basis per step
       if (tpath && !(ws->t_lazy && j0 == ws->t_hi + 1)) {
         materialize(ws);   // whatever is lazy (either kind) becomes ordinary: this batch starts a new T
         ws->ntrue = j0;
@@ -2097,6 +2174,12 @@ template <class T> struct HipBackend : ks::Backend<T> {
         }
       }
       bool early_ran = false;
+      // if anything throws after the early part of the restart step ran (transport time-out, operator error), the host H
+      // is put back as it was: a caller that catches the error must not find a half-restarted matrix
+      struct EarlyGuard {
+        ks_workspace* w; void* Hp; bool armed;
+        ~EarlyGuard() { if (armed && !w->Hbackup.empty()) std::memcpy(Hp, w->Hbackup.data(), w->Hbackup.size()); }
+      } early_guard{ws, H.p, false};
       static const int dbg = env_int("KS_EARLY_DEBUG", 0);
       double tq0 = dbg ? ks::now_s() : 0.0, tq1 = 0, tq2 = 0;
       if (mb) publish_control(ws, j0, ws->Hstage_dev, 1, seq, tpath);
@@ -2109,6 +2192,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
           const size_t hb = (size_t)H.ld * H.n * sizeof(T);
           ws->Hbackup.resize(hb);
           std::memcpy(ws->Hbackup.data(), H.p, hb);
+          early_guard.armed = true;
           fetch_H_columns<T>(ws, j0, jend, H, false, ws->Hstage_early);  // H[jend, jend-1] is not final yet, nobody reads it
           (*early)();
           early_ran = true;
@@ -2132,12 +2216,16 @@ template <class T> struct HipBackend : ks::Backend<T> {
         const double tq3 = ks::now_s();
         std::fprintf(stderr, "[early off] enqueue %.1f us | wait %.1f us | batch %.1f us\n", 1e6 * (tq0 - tb0), 1e6 * (tq3 - tq0), 1e6 * (tq3 - tb0));
       }
-      const int bd = ws->st_h->breakdown;
-      const int last_done = bd >= 0 ? bd : jend;
+      // bail: the implicit form refuses step `bail` (its second-pass correction is not small) -- steps before it stand,
+      // the step itself is redone below in the explicit form; not a breakdown
+      const int bail = tpath ? ws->st_h->bail : -1;
+      const int bd = bail >= 0 ? -1 : ws->st_h->breakdown;
+      const int last_done = bail >= 0 ? bail - 1 : (bd >= 0 ? bd : jend);
       if (early_ran && bd >= 0) {  // the last step broke down: withdraw (rare; the caller redoes the early part)
         std::memcpy(H.p, ws->Hbackup.data(), ws->Hbackup.size());
         early_ran = false;
       }
+      early_guard.armed = false;
       if (early_ran) {
         const T* hs = static_cast<const T*>(ws->Hstage);
         H(jend, jend - 1) = hs[(size_t)(jend - 1) * (ws->maxdim + 1) + jend];
@@ -2148,7 +2236,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
       }
       if (tpath) {
         // columns j0 .. (last completed step) are T-lazy now; a column that broke down is garbage until reinit_column
-        const int good = bd >= 0 ? bd - 1 : jend;
+        const int good = bail >= 0 ? bail - 1 : (bd >= 0 ? bd - 1 : jend);
         if (good >= ws->ntrue) {
           ws->t_lazy = true;
           ws->t_hi = good;
@@ -2156,6 +2244,11 @@ template <class T> struct HipBackend : ks::Backend<T> {
       }
       stats.steps += last_done - j0 + 1;
       stats.reorth += ws->st_h->n_reorth;
+      if (explicit_step >= 0) explicit_step = -1;  // the handed-back step is done
+      if (bail >= 0) {
+        explicit_step = bail;
+        stats.explicit_steps++;
+      }
       if (lazy && jend > j0) ws->oop_full = 10 * ws->st_h->n_reorth >= 9 * (last_done - j0 + 1);  // (batches of one step keep the setting)
       if (bd >= 0) {
         // orthogonalize! returned false at step bd: H[bd, bd-1] = 0 is already in place
@@ -2167,6 +2260,9 @@ template <class T> struct HipBackend : ks::Backend<T> {
       }
       j0 = last_done + 1;
     }
+    // the factorisation up to `to` is the library's own again (or stays unknown)
+    if (trusted) prov_set(ws, to);
+    else prov_drop(ws);
     return early_stands;
   }
 
@@ -2199,13 +2295,16 @@ template <class T> struct HipBackend : ks::Backend<T> {
   // the residual direction are one T-folded product S[:, 0:src+1) [ T Q | T[:, src] ] (the columns it does not write are
   // the ones the restart discards).
   void rotate_and_move(int c0, int c, int r, const ks::Mat<T>& Q, int dst, int src) override {
+    const bool own = ws->prov_k == src;  // the library's own factorisation of `src` steps is being truncated to `dst`
     if (ws->t_lazy) {
       rotate_tfold<T>(ws, c0, c, r, r > 0 ? &Q(c0, c0) : nullptr, Q.ld, c0, src, dst);
       reset_lazy(ws);
-      return;
+    } else {
+      rotate(c0, c, r, Q);
+      col_copy(dst, src);
     }
-    rotate(c0, c, r, Q);
-    col_copy(dst, src);
+    if (own) prov_set(ws, dst);  // (the host step rewrote H: new shadow)
+    else prov_drop(ws);
   }
 };
 
@@ -2585,6 +2684,25 @@ int ks_operator_csr_dist(ks_ctx* ctx, int64_t nrows_local, int64_t nghost, int64
       std::unique_ptr<CsrOp<D>> guard(op);
       op->nghost = nghost;
       op->p2p_halo = ctx->p2p.attached;
+      {
+        // rows that reference ghost columns: all of them lie outside ONE interval [ghost_lo_end, ghost_hi_begin) -- the
+        // largest gap between such rows (a slab of a structured grid: everything between its first and its last plane).
+        // Workgroups whose rows fall inside never wait for the exchange (fused halo, ks_p2p.hpp).
+        int64_t best_a = 0, best_b = nrows_local, prev = -1;
+        bool any = false;
+        int64_t gap_best = -1;
+        for (int64_t r = 0; r < nrows_local; ++r) {
+          bool touches = false;
+          for (int64_t q = rp[r]; q < rp[r + 1] && !touches; ++q) touches = ci[q] >= nrows_local;
+          if (!touches) continue;
+          any = true;
+          if (r - prev - 1 > gap_best) { gap_best = r - prev - 1; best_a = prev + 1; best_b = r; }
+          prev = r;
+        }
+        if (any && nrows_local - prev - 1 > gap_best) { best_a = prev + 1; best_b = nrows_local; }
+        op->ghost_lo_end = any ? best_a : 0;
+        op->ghost_hi_begin = any ? best_b : nrows_local;
+      }
       if (!op->p2p_halo) {
         KS_HIP(hipMalloc(&op->ghost, std::max<size_t>((size_t)nghost * sizeof(D), 16)));
         KS_HIP(hipMemset(op->ghost, 0, std::max<size_t>((size_t)nghost * sizeof(D), 16)));
@@ -2843,16 +2961,23 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     w->ctl_bytes = (size_t)round_up((int64_t)(w->off_g + (size_t)w->ldt * esz), 64);
     const size_t ctl_bytes = w->ctl_bytes;
     static_assert(sizeof(DevState) <= kCtlStateSlot, "DevState must fit its slot of the control block");
-    KS_HIP(hipHostMalloc(&w->Hstage, ctl_bytes));
+    // the images the device publishes into (k_publish) and the flag words the host spins on must be COHERENT pinned
+    // memory whatever the process default is (HIP_HOST_COHERENT=0 makes plain hipHostMalloc memory non-coherent: device
+    // stores would only become visible at a synchronisation and the spin would never see them)
+    const unsigned coh = hipHostMallocCoherent | hipHostMallocMapped;
+    KS_HIP(hipHostMalloc(&w->Hstage, ctl_bytes, coh));
     KS_HIP(hipHostMalloc(&w->Qstage, qxbytes));
-    KS_HIP(hipHostMalloc(&w->Hstage_early, ctl_bytes));
+    KS_HIP(hipHostMalloc(&w->Hstage_early, ctl_bytes, coh));
     std::memset(w->Hstage_early, 0, ctl_bytes);
-    KS_HIP(hipHostMalloc(reinterpret_cast<void**>(&w->mbox), 128));
+    KS_HIP(hipHostMalloc(reinterpret_cast<void**>(&w->mbox), 128, coh));
     std::memset(w->mbox, 0, 128);
-    KS_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&w->mbox_dev), w->mbox, 0));
-    KS_HIP(hipHostGetDevicePointer(&w->Hstage_dev, w->Hstage, 0));
-    KS_HIP(hipHostGetDevicePointer(&w->Hstage_early_dev, w->Hstage_early, 0));
     w->use_mbox = env_int("KS_MAILBOX", 1) != 0;
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&w->mbox_dev), w->mbox, 0) != hipSuccess ||
+        hipHostGetDevicePointer(&w->Hstage_dev, w->Hstage, 0) != hipSuccess ||
+        hipHostGetDevicePointer(&w->Hstage_early_dev, w->Hstage_early, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      w->use_mbox = false;  // no device view of the pinned images: copies + stream synchronisation instead
+    }
     std::memset(w->H, 0, hbytes);   // zeros(T, k+1, k), src/ArnoldiMethod.jl:66
     std::memset(w->Q, 0, qbytes);
     std::memset(w->Hstage, 0, ctl_bytes);
@@ -2868,6 +2993,7 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     KS_HIP(hipMalloc(reinterpret_cast<void**>(&w->ctr), 64));
     KS_HIP(hipMemsetAsync(w->ctr, 0, 64, ctx->stream));
     w->passes = env_int("KS_PASSES", 2) == 3 ? 3 : 2;
+    if (const char* mr = std::getenv("KS_IMPLICIT_MAX_RATIO")) w->max_ratio = std::atof(mr);
     KS_HIP(hipMalloc(&w->Hscratch, (size_t)(maxdim + 2) * esz));
     KS_HIP(hipMalloc(&w->partial, (size_t)w->pnb * w->pstride * esz));
     KS_HIP(hipMalloc(&w->partial_s, (size_t)w->pnb * w->pstride * esz));
@@ -2902,6 +3028,32 @@ int ks_workspace_passes(const ks_workspace* ws, int* passes) {
   return guarded([&] {
     KS_REQUIRE(ws && passes, KS_ERR_ARGUMENT, "null argument");
     *passes = ws->passes;
+  });
+}
+
+int ks_workspace_set_passes(ks_workspace* ws, int passes, double max_ratio) {
+  return guarded([&] {
+    KS_REQUIRE(ws, KS_ERR_ARGUMENT, "null workspace");
+    KS_REQUIRE(passes == 2 || passes == 3, KS_ERR_ARGUMENT, "passes must be 2 (implicit second pass) or 3 (explicit)");
+    ws->ctx->use();
+    materialize(ws);  // columns in the factored form of the other setting become ordinary first
+    ws->passes = passes;
+    if (!std::isnan(max_ratio)) ws->max_ratio = max_ratio;
+  });
+}
+
+int ks_workspace_assert_arnoldi(ks_workspace* ws, int k) {
+  return guarded([&] {
+    KS_REQUIRE(ws, KS_ERR_ARGUMENT, "null workspace");
+    KS_REQUIRE(k >= 0 && k <= ws->maxdim, KS_ERR_ARGUMENT, "k out of range");
+    prov_set(ws, k);
+  });
+}
+
+int ks_workspace_provenance(const ks_workspace* ws, int* k) {
+  return guarded([&] {
+    KS_REQUIRE(ws && k, KS_ERR_ARGUMENT, "null argument");
+    *k = ws->prov_k;
   });
 }
 
@@ -2973,6 +3125,7 @@ int ks_workspace_col_ptr(ks_workspace* ws, int j, void** dev_ptr) {
     KS_REQUIRE(dev_ptr, KS_ERR_ARGUMENT, "null argument");
     ws->ctx->use();
     materialize(ws);
+    prov_drop(ws);  // the caller may write through the pointer
     *dev_ptr = ws->col(j);
   });
 }
@@ -2991,6 +3144,7 @@ int ks_col_upload(ks_workspace* ws, int j, const void* host) {
     check_col(ws, j);
     KS_REQUIRE(host, KS_ERR_ARGUMENT, "null host pointer");
     ws->ctx->use();
+    prov_drop(ws);  // the caller writes to V: the factorisation is no longer the library's own
     materialize(ws);
     dispatch_dtype(ws->dtype, [&](auto tag) { col_upload<typename DevT<decltype(tag)>::type>(ws, j, host); });
   });
@@ -3028,6 +3182,7 @@ int ks_cols_upload(ks_workspace* ws, int j0, int ncols, const void* host, int64_
     KS_REQUIRE(ldhost >= ws->n, KS_ERR_ARGUMENT, "ldhost too small");
     if (ncols == 0 || ws->n == 0) return;
     ws->ctx->use();
+    prov_drop(ws);  // the caller writes to V: the factorisation is no longer the library's own
     materialize(ws);
     KS_HIP(hipMemcpy2DAsync(ws->col(j0), (size_t)ws->ld * ws->esz, host, (size_t)ldhost * ws->esz,
                             (size_t)ws->n * ws->esz, (size_t)ncols, hipMemcpyHostToDevice, ws->ctx->stream));
@@ -3039,6 +3194,7 @@ int ks_col_fill_uniform(ks_workspace* ws, int j, uint64_t seed) {
   return guarded([&] {
     check_col(ws, j);
     ws->ctx->use();
+    prov_drop(ws);  // the caller writes to V: the factorisation is no longer the library's own
     materialize(ws);
     const int gb = (int)std::min<int64_t>((ws->ld + kBlock - 1) / kBlock, 8192);
     dispatch_dtype(ws->dtype, [&](auto tag) {
@@ -3065,6 +3221,7 @@ int ks_col_div(ks_workspace* ws, int j, double s) {
   return guarded([&] {
     check_col(ws, j);
     ws->ctx->use();
+    prov_drop(ws);  // the caller writes to V: the factorisation is no longer the library's own
     materialize(ws);
     dispatch_dtype(ws->dtype, [&](auto tag) { col_scale<typename DevT<decltype(tag)>::type>(ws, j, 1.0 / s); });
     KS_HIP(hipStreamSynchronize(ws->ctx->stream));
@@ -3075,6 +3232,7 @@ int ks_col_copy(ks_workspace* ws, int dst, int src) {
   return guarded([&] {
     check_col(ws, dst);
     check_col(ws, src);
+    prov_drop(ws);
     // lazy-aware: a lazily normalised source is scaled on the way, nothing else is touched
     dispatch_dtype(ws->dtype, [&](auto tag) { col_copy_lazy<typename DevT<decltype(tag)>::type>(ws, dst, src); });
     KS_HIP(hipStreamSynchronize(ws->ctx->stream));
@@ -3089,6 +3247,7 @@ int ks_apply(ks_operator* A, ks_workspace* ws, int jsrc, int jdst) {
     KS_REQUIRE(jsrc != jdst, KS_ERR_ARGUMENT, "source and destination columns must differ");
     KS_REQUIRE(A->n_local == ws->n && A->dtype == ws->dtype, KS_ERR_DIMENSION, "operator / workspace mismatch");
     ws->ctx->use();
+    prov_drop(ws);  // the caller writes to V: the factorisation is no longer the library's own
     materialize(ws);
     A->in_scale = 1.0;
     A->apply(ws->col(jsrc), ws->col(jdst), nullptr);
@@ -3113,6 +3272,7 @@ int ks_gemv_n_sub(ks_workspace* ws, int j, int jv, const void* h_host) {
     KS_REQUIRE(j >= 1 && j <= ws->maxdim + 1 && h_host, KS_ERR_ARGUMENT, "bad arguments");
     KS_REQUIRE(jv >= j, KS_ERR_ARGUMENT, "the updated column must not be one of the projected-out columns");
     ws->ctx->use();
+    prov_drop(ws);  // the caller writes to V: the factorisation is no longer the library's own
     materialize(ws);
     dispatch_dtype(ws->dtype, [&](auto tag) { gemv_n_sub<typename DevT<decltype(tag)>::type>(ws, j, jv, h_host); });
   });
@@ -3124,6 +3284,7 @@ int ks_rotate(ks_workspace* ws, int c0, int c, int r, const void* Q_host, int ld
     KS_REQUIRE(c0 >= 0 && c >= 1 && r >= 1 && r <= c && c0 + c <= ws->maxdim + 1 && ldq >= c, KS_ERR_ARGUMENT,
                "bad rotation shape");
     KS_REQUIRE((size_t)c * r <= (size_t)ws->maxdim * ws->maxdim, KS_ERR_ARGUMENT, "rotation larger than the workspace Q");
+    prov_drop(ws);
     // lazily normalised columns inside the rotated range are absorbed into Q (no scaling passes), see rotate_lazy
     dispatch_dtype(ws->dtype, [&](auto tag) {
       using T = decltype(tag);
@@ -3170,6 +3331,7 @@ int ks_orthogonalize(ks_workspace* ws, int j, int* ok) {
     check_col(ws, j);
     KS_REQUIRE(j >= 1, KS_ERR_ARGUMENT, "orthogonalize needs j >= 1");
     ws->ctx->use();
+    prov_drop(ws);  // (a column the caller put there)
     reset_state(ws);
     dispatch_dtype(ws->dtype, [&](auto tag) {
       using T = decltype(tag);
@@ -3194,6 +3356,9 @@ int ks_reinitialize(ks_workspace* ws, int j, const void* v1_host, int* ok) {
     materialize(ws);
     bool good = true;
     dispatch_dtype(ws->dtype, [&](auto tag) { good = reinit_column<typename DevT<decltype(tag)>::type>(ws, j, v1_host); });
+    // column j is new: a factorisation of zero steps (j = 0) is the library's own; otherwise steps < j keep their status
+    if (j == 0 && good) prov_set(ws, 0);
+    else if (ws->prov_k > j - 1) ws->prov_k = j - 1;
     if (ok) *ok = good ? 1 : 0;
   });
 }
@@ -3215,7 +3380,7 @@ int ks_iterate_arnoldi(ks_operator* A, ks_workspace* ws, int from, int to, ks_ex
       stats->steps = st.steps;
       stats->reorth = st.reorth;
       stats->breakdowns = st.breakdowns;
-      stats->reserved = 0;
+      stats->explicit_steps = st.explicit_steps;
     }
   });
 }
@@ -3257,10 +3422,14 @@ int ks_partialschur(ks_operator* A, ks_workspace* ws, const ks_params* p, const 
       ks::Mat<T> Q(static_cast<T*>(ws->Q), prm.maxdim, prm.maxdim, ws->maxdim);
       HipBackend<T> be(A, ws);
       if (prm.initialize) be.reinitialize(prm.start_from - 1, prm.start_from == 1 ? static_cast<const T*>(v1_host) : nullptr);
+      // partialschur! trusts the workspace it is handed (src/run.jl:152-179: V[:, 1:start_from-1] and H hold a partial
+      // Schur decomposition, the start column is in place): so does the provenance from here on
+      prov_set(ws, prm.start_from - 1);
       std::vector<cplx> lams(prm.maxdim);
       ks::History h = ks::partialschur_driver<T>(be, H, Q, prm, prm.start_from - 1, lams.data());
       materialize(ws);
       KS_HIP(hipStreamSynchronize(ws->ctx->stream));
+      prov_drop(ws);  // (a partial Schur decomposition now, not an Arnoldi factorisation of maxdim steps)
       if (eigenvalues_c64)
         for (int i = 0; i < h.nconverged; ++i) {
           eigenvalues_c64[2 * i] = lams[i].real();
@@ -3274,7 +3443,7 @@ int ks_partialschur(ks_operator* A, ks_workspace* ws, const ks_params* p, const 
         history->restarts = h.restarts;
         history->reorth = h.reorth;
         history->breakdowns = h.breakdowns;
-        history->reserved = 0;
+        history->explicit_steps = h.explicit_steps;
         history->seconds_expand = h.seconds_expand;
         history->seconds_host = h.seconds_host;
         history->seconds_rotate = h.seconds_rotate;
@@ -3292,6 +3461,9 @@ int ks_restart(ks_workspace* ws, const ks_params* p, int active, int* k_out, int
     if (ks::check_params(ws->n_global, ws->maxdim + 1, prm, msg)) throw KsError{KS_ERR_ARGUMENT, msg};
     KS_REQUIRE(active >= 0 && active < prm.maxdim, KS_ERR_ARGUMENT, "active out of range");
     ws->ctx->use();
+    // the restart keeps the library's provenance only if it works on the factorisation the library left (all maxdim steps,
+    // H untouched since)
+    if (!(ws->prov_k == prm.maxdim && prov_ok(ws, prm.maxdim + 1))) prov_drop(ws);
     dispatch_dtype(ws->dtype, [&](auto tag) {
       using T = decltype(tag);
       ks::Mat<T> H(static_cast<T*>(ws->H), prm.maxdim + 1, prm.maxdim, ws->maxdim + 1);
@@ -3349,7 +3521,7 @@ int ks_expand_restart(ks_operator* A, ks_workspace* ws, const ks_params* p, int 
         if (rs) rs[i] = sc.rs[i];
         if (groups) groups[i] = sc.groups[i];
       }
-      if (stats) { stats->steps = st.steps; stats->reorth = st.reorth; stats->breakdowns = st.breakdowns; stats->reserved = 0; }
+      if (stats) { stats->steps = st.steps; stats->reorth = st.reorth; stats->breakdowns = st.breakdowns; stats->explicit_steps = st.explicit_steps; }
       if (seconds) { seconds[0] = t1 - t0; seconds[1] = t2 - t1; seconds[2] = t3 - t2; }
     });
   });

@@ -51,6 +51,13 @@ struct DevState {
   // by it before squaring / multiplying, so that the partial sums stay ~ ||A||^2 instead of ||A||^4 (the stored column is
   // not normalised): the representable range of ||A|| is 1e+-150 as in the reference instead of 1e+-75.  Exact (power of 2).
   double sigma;
+  // two-pass expansion: the largest ratio ||c|| / beta (second-pass correction against what is left of the vector) an
+  // implicit second pass may carry.  A step whose correction is larger is NOT settled by the triangular factor: the
+  // reduction kernel stops the batch there (bail = that step) and the host redoes the step with the correction applied
+  // to the vector (the explicit three-pass form).  <= 0: no limit.
+  double max_ratio;
+  int32_t bail;       // step handed back for the explicit second pass, else -1
+  int32_t pad_;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -249,7 +256,8 @@ __global__ void __launch_bounds__(kBlock)
                const int32_t* __restrict__ colidx, const T* __restrict__ val, const T* __restrict__ x,
                const T* __restrict__ xg, T* __restrict__ y, int64_t n, int nblk, const DevState* __restrict__ st,
                const uint32_t* __restrict__ hseq, int64_t gstride, int ndict, const int32_t* __restrict__ blkpart,
-               T* __restrict__ lpart, const T* __restrict__ yacc = nullptr, int plain_store = 0) {
+               T* __restrict__ lpart, const T* __restrict__ yacc = nullptr, int plain_store = 0, HaloFused hf = HaloFused{},
+               HaloArgs ha = HaloArgs{}, P2pDev pd = P2pDev{}) {
   // yacc != nullptr: this launch handles ONE COLUMN BLOCK of the matrix (column-blocked layout) and continues the row sums
   // an earlier launch left in yacc -- entries of a row are visited in CSR order across the launches, so y is bit-identical
   if (st && st->breakdown >= 0) return;
@@ -269,6 +277,8 @@ __global__ void __launch_bounds__(kBlock)
   const IP p0 = blkptr[b], p1 = blkptr[b + 1];
   const int32_t cnt = (int32_t)(p1 - p0);  // <= CAP by construction
   const int32_t part = blkpart ? blkpart[b] : -1;
+  // peer-to-peer mode: the ghost exchange is part of this launch (ks_p2p.hpp; xg is then the slot the host picked)
+  if (hf.enabled) halo_fused_prologue<T>(x, hf, ha, pd, (long long)r0, (long long)r1);
   if (part < 0) {
     // this thread's row bounds for phase 2: issued now, so their latency hides behind phase 1
     const int32_t rmine = (r0 + tid < r1) ? r0 + tid : r1 - 1;
@@ -294,7 +304,7 @@ __global__ void __launch_bounds__(kBlock)
         a[k] = dict[(uint32_t)c[k] >> 24];
         c[k] &= 0xffffff;
       }
-      xv[k] = (c[k] < n) ? x[c[k]] : xg[c[k] - n];
+      xv[k] = (c[k] < n) ? x[c[k]] : xg[c[k] - n];  // (ghost columns only occur in rows of boundary blocks, which waited)
     }
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
@@ -334,7 +344,7 @@ __global__ void __launch_bounds__(kBlock)
         a[k] = dict[(uint32_t)c[k] >> 24];
         c[k] &= 0xffffff;
       }
-      xv[k] = (c[k] < n) ? x[c[k]] : xg[c[k] - n];
+      xv[k] = (c[k] < n) ? x[c[k]] : xg[c[k] - n];  // (ghost columns only occur in rows of boundary blocks, which waited)
     }
     T s = zero_of(T{});
 #pragma unroll
@@ -541,11 +551,27 @@ template <class T, class MT, int RPT>
 __global__ void __launch_bounds__(kBlock)
     k_spmv_stencil(const MT* __restrict__ mask, const StencilDict<T> d, int nslots, const T* __restrict__ x,
                    const T* __restrict__ xg, T* __restrict__ y, int64_t n, int64_t nghost, int ntiles,
-                   const DevState* __restrict__ st, const uint32_t* __restrict__ hseq, int64_t gstride) {
+                   const DevState* __restrict__ st, HaloFused hf, HaloArgs ha, P2pDev pd) {
+  // (xg: the ghost vector of THIS exchange -- the host picks the slot of the double buffer, ks_p2p.hpp)
   if (st && st->breakdown >= 0) return;
-  if (hseq) xg += (int64_t)(*hseq & 1u) * gstride;
-  const int tile = xcd_remap(blockIdx.x, ntiles);
-  const int64_t cmax = n + nghost - 1;
+  int tile = xcd_remap(blockIdx.x, ntiles);
+  // peer-to-peer mode: the ghost exchange is part of this launch (ks_p2p.hpp).  The leading boundary rows (a slab's first
+  // plane) go to the END of the dispatch order, next to the trailing ones: by the time those workgroups start, the
+  // neighbours' entries have long arrived -- nobody sits on a CU spinning while the interior tiles want its slots.
+  if (hf.enabled && hf.tile_shift) { tile += hf.tile_shift; if (tile >= ntiles) tile -= ntiles; }
+  // Only a BOUNDARY tile (rows outside [ghost_lo_end, ghost_hi_begin)) may touch the ghost vector, and only after it waited
+  // for the exchange: every other tile folds ghost-range addresses (slots its rows do not have -- the loads below do not
+  // wait for the mask) back onto local rows.  So no tile can pull a ghost line into this CU's vector L1 before the data
+  // arrived, and nobody needs an acquire fence or cache-bypassing loads (both were tried: an acquire per waiting workgroup
+  // invalidates what the other tiles stream through the caches, 15 -> 35 us; bypassing loads break up the back-to-back
+  // issue of the gathers, 15 -> 22 us).
+  bool btile = true;
+  if (hf.enabled) {
+    const long long row_lo = (long long)tile * (kBlock * RPT), row_hi = row_lo + kBlock * RPT;
+    btile = row_lo < hf.ghost_lo_end || row_hi > hf.ghost_hi_begin;
+    halo_fused_prologue<T>(x, hf, ha, pd, row_lo, row_hi);
+  }
+  const int64_t cmax = btile ? n + nghost - 1 : n - 1;
   int64_t r[RPT];
   uint32_t m[RPT];
   T s[RPT];
@@ -564,9 +590,11 @@ __global__ void __launch_bounds__(kBlock)
       for (int q = 0; q < RPT; ++q)
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-          // clamped, mask-independent address (slots beyond nslots have delta 0)
+          // clamped, mask-independent address (slots beyond nslots have delta 0).  A column beyond the local-extended
+          // range is folded back onto the row itself, NOT onto the last ghost slot: in peer-to-peer mode ghost loads bypass
+          // the caches, and every interior row hitting the same uncached word serialised the whole launch on one channel
           int64_t c = r[q] + d.delta[k0 + u];
-          c = c < 0 ? 0 : (c > cmax ? cmax : c);
+          c = c < 0 ? 0 : (c > cmax ? (r[q] < n ? r[q] : n - 1) : c);
           xv[q][u] = (c < n) ? x[c] : xg[c - n];
         }
 #pragma unroll
@@ -1446,10 +1474,10 @@ __global__ void __launch_bounds__(kBlock)
     if (e < nH) hreg[u] = Hd[(e % hr) + (int64_t)(e / hr) * ldh];
   }
   T h0 = zero_of(T{});
-  if (jm && tid < jm) h0 = Hd[tid + (int64_t)(jm - 1) * ldh];  // h of step jm as its DOTS half left it
+  if (jm && (tid & 63) < jm) h0 = Hd[(tid & 63) + (int64_t)(jm - 1) * ldh];  // h of step jm as its DOTS half left it (one copy per wave)
   T gi = zero_of(T{});
-  if (!jm && jd && (jd - 1) >= ntrue && tid < jd) gi = gvec[tid];  // (only when a batch continues on factored columns)
-  const double rnorm = st->rnorm, rnorm2 = st->rnorm2;
+  if (!jm && jd && (jd - 1) >= ntrue && (tid & 63) < jd) gi = gvec[tid & 63];  // (only when a batch continues on factored columns)
+  const double rnorm = st->rnorm, rnorm2 = st->rnorm2, mr = st->max_ratio;
   const double sig = st->sigma;  // what k_dots scaled y' by (set by the PREVIOUS launch of this kernel)
   // ---- reduction of this workgroup's column + election ----
   if (mode != 2) {
@@ -1486,8 +1514,13 @@ __global__ void __launch_bounds__(kBlock)
     tk2 = wall_clock64();
 #endif
   }
-  // ---- the last workgroup: ONE round trip for every reduced value, the prefetched blocks go to LDS, then wave 0 alone
-  // does the algebra (<= 64 elements per vector: one lane each; barriers of a single live wave cost nothing) ----
+  // ---- the last workgroup: ONE round trip for every reduced value, the prefetched blocks go to LDS, then ALL FOUR waves do
+  // the algebra: every vector has <= 64 elements (lane li = tid & 63 owns element li in every wave) and every small
+  // matrix-vector product is split over the waves by SUMMATION RANGE (wave q sums the q-th quarter of the terms of
+  // element li, the four partial sums meet in LDS in fixed order -> deterministic).  One wave alone spent ~6 us at j = 36
+  // in four dependent products of up to j terms each (LDS round trips in a serial chain); a quarter of the terms per
+  // wave and two barriers per product is ~2 us.  Scalars (norms, the DGKS decisions) are formed redundantly and
+  // identically in every wave, so control flow stays uniform; only wave 0 writes results. ----
   if (tid < nm + nd) r_s[tid] = ld_agent(red + tid);
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
@@ -1496,20 +1529,52 @@ __global__ void __launch_bounds__(kBlock)
     if (e < nH) Hl[e] = hreg[u];
   }
   __syncthreads();
-  if (tid >= 64) return;
+  const int li = tid & 63;
+  const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __shared__ T ps[4][64];
+  auto combine = [&](T part) -> T {
+    ps[q][li] = part;
+    __syncthreads();
+    const T tot = add_(add_(ps[0][li], ps[1][li]), add_(ps[2][li], ps[3][li]));
+    __syncthreads();
+    return tot;
+  };
+  // this wave's quarter [a, b) of the summation range [k0, n) (multiples of four terms: dot_* batch their loads by four)
+  auto quarter = [&](int k0, int n, int& a, int& b) {
+    const int len = n > k0 ? n - k0 : 0;
+    const int per = ((len + 15) >> 4) << 2;
+    a = k0 + q * per;
+    b = a + per;
+    if (a > n) a = n;
+    if (b > n) b = n;
+  };
   // T as the algebra sees it: element (k, i), i >= ntrue, at tb[k + (i - ntrue) * tld]
   const T* tb = use_lds ? Tl : Tm + (int64_t)ntrue * ldt;
   const int64_t tld = use_lds ? jt : ldt;
+  // sum_{k in this wave's quarter of [0, i]} conj(T[k, i]) x[k]   (i >= ntrue)
+  auto tcol_dot = [&](const T* x, int i) -> T {
+    int a, b;
+    quarter(0, i + 1, a, b);
+    return dotc_contig(tb + (i - ntrue) * tld + a, x + a, b - a);
+  };
+  // sum_{k in this wave's quarter of [max(i, ntrue), n)} T[i, k] x[k]
+  auto trow_dot = [&](const T* x, int i, int n) -> T {
+    int a, b;
+    quarter(i > ntrue ? i : ntrue, n, a, b);
+    return dot_strided(tb + i - ntrue * tld, tld, x, a, b);
+  };
   double binv_in = 1.0;  // 1 / beta of the column the DOTS half works on (column jd-1)
   // ================================ MID(jm) ================================
   if (jm) {
     const int j = jm;
     T* Hcol = Hd + (int64_t)(j - 1) * ldh;
     const T* a_s = r_s;  // c_raw[0..j-1], ||w'||^2 at [j]
-    T ci = zero_of(T{});
-    if (tid < j) {  // c = T^H c_raw = V_true^H w'
-      if (tid < ntrue) ci = a_s[tid];
-      else ci = dotc_contig(tb + (tid - ntrue) * tld, a_s, tid + 1);
+    T ci;
+    {  // c = T^H c_raw = V_true^H w'
+      const T part = (li < j && li >= ntrue) ? tcol_dot(a_s, li) : zero_of(T{});
+      ci = combine(part);
+      if (li < j && li < ntrue) ci = a_s[li];
+      if (li >= j) ci = zero_of(T{});
     }
     const double wn2 = real_of(a_s[j]);
     const double wnorm = sqrt(wn2);
@@ -1518,8 +1583,9 @@ __global__ void __launch_bounds__(kBlock)
     // second-pass correction that is NOT small against it AND A v_true nearly cancels (a basis vector in the null space
     // of A right after a near-breakdown: test/partial_schur.jl:6-27); there the first projection loses as many digits as
     // y' - V g did, and the (implicit) second pass is what restores orthogonality.  Everywhere else the maximum is rnorm.
+    // (The maximum can only make the test fire MORE often than the reference's, never less.)
     const bool reorth = wnorm < kEta * fmax(rnorm, rnorm2);
-    const double c2 = wave_sum((reorth && tid < j) ? abs2_(ci) : 0.0);
+    const double c2 = wave_sum((reorth && li < j) ? abs2_(ci) : 0.0);
     double beta, rnorm_p;
     if (reorth) {
       const double b2 = wn2 - c2;  // ||w' - V c||^2 with V orthonormal
@@ -1530,6 +1596,19 @@ __global__ void __launch_bounds__(kBlock)
       rnorm_p = rnorm;
       ci = zero_of(T{});
     }
+    // A correction that is not small against what remains of the vector is not carried implicitly: g = H c leans on the
+    // Arnoldi relation of the earlier columns, which locked columns satisfy only to tol * |lambda| (src/run.jl:360), so
+    // its error is bounded by (residual of the relation) * ||c|| / beta.  Rounding-level corrections (every step of an
+    // operator with a dominant diagonal) stay implicit; a genuine one (near-breakdown) goes back to the host, which
+    // redoes this step with the second projection applied to the vector.  Checked before the breakdown test: the explicit
+    // form takes that decision itself.
+    if (reorth && mr > 0.0 && c2 > mr * mr * beta * beta) {
+      if (tid == 0) {
+        st->breakdown = j;  // every later kernel of the batch exits at once
+        st->bail = j;
+      }
+      return;
+    }
     if (beta <= kEta * rnorm_p) {  // src/expansion.jl:99-102
       if (tid == 0) {
         Hcol[j] = zero_of(T{});
@@ -1537,41 +1616,38 @@ __global__ void __launch_bounds__(kBlock)
         st->inv_norm = 0.0;
         if (reorth) st->n_reorth += 1;
       }
-      if (reorth) {  // h .+= correction happens before the test, :95
-        if (tid < j) Hcol[tid] = add_(h0, ci);
-      }
+      if (reorth && q == 0 && li < j) Hcol[li] = add_(h0, ci);  // h .+= correction happens before the test, :95
       return;
     }
     const double binv = 1.0 / beta;
     T hi = h0;
-    if (tid < j && reorth) {
+    if (li < j && reorth) {
       hi = add_(hi, ci);  // :95
-      Hcol[tid] = hi;
+      if (q == 0) Hcol[li] = hi;
     }
-    if (tid < j) c_s[tid] = ci;
+    if (q == 0 && li < j) c_s[li] = ci;
     __syncthreads();
-    if (tid < j) {  // new column of T:  -(T c) / beta
-      T a = zero_of(T{});
-      if (reorth) {
-        int k0 = tid;
-        if (tid < ntrue) {
-          a = c_s[tid];
-          k0 = ntrue;
-        }
-        a = add_(a, dot_strided(tb + tid - ntrue * tld, tld, c_s, k0, j));  // sum_{k >= k0} T[tid, k] c[k]
-      }
+    {  // new column of T:  -(T c) / beta
+      const T part = (reorth && li < j) ? trow_dot(c_s, li, j) : zero_of(T{});
+      T a = combine(part);
+      if (reorth && li < ntrue && li < j) a = add_(a, c_s[li]);
       const T tv = scl(neg_(a), binv);
-      Tm[tid + (int64_t)j * ldt] = tv;
-      if (use_lds && jd) Tl[tid + (j - ntrue) * jt] = tv;
-    }
-    {  // g for the next step: H[0:j+1, 0:j] c   (upper Hessenberg: H[i,k] = 0 for k < i-1); entries 0..j, lane 0 also does j = 64
-      T g = zero_of(T{});
-      if (reorth && tid < j) {
-        const T* __restrict__ hb = h_lds ? Hl : Hd;
-        g = dot_strided(hb + tid, h_lds ? (int64_t)hr : (int64_t)ldh, c_s, tid > 0 ? tid - 1 : 0, j - 1);
-        g = fma_(hi, c_s[j - 1], g);  // column j-1 of H as this step leaves it
+      if (q == 0 && li < j) {
+        Tm[li + (int64_t)j * ldt] = tv;
+        if (use_lds && jd) Tl[li + (j - ntrue) * jt] = tv;
       }
-      if (tid < j) gvec[tid] = g;
+    }
+    {  // g for the next step: H[0:j+1, 0:j] c   (upper Hessenberg: H[i,k] = 0 for k < i-1); entries 0..j-1 here, entry j below
+      T part = zero_of(T{});
+      if (reorth && li < j) {
+        const T* __restrict__ hb = h_lds ? Hl : Hd;
+        int a, b;
+        quarter(li > 0 ? li - 1 : 0, j - 1, a, b);
+        part = dot_strided(hb + li, h_lds ? (int64_t)hr : (int64_t)ldh, c_s, a, b);
+      }
+      T g = combine(part);
+      if (reorth && li < j) g = fma_(hi, c_s[j - 1], g);  // column j-1 of H as this step leaves it
+      if (q == 0 && li < j) gvec[li] = g;
       gi = g;
       if (tid == 0) {
         const T glast = reorth ? scl(c_s[j - 1], beta) : zero_of(T{});  // H[j, j-1] c[j-1]
@@ -1591,8 +1667,8 @@ __global__ void __launch_bounds__(kBlock)
       if (reorth) st->n_reorth += 1;
     }
     binv_in = binv;
-    __syncthreads();  // the new column of T (LDS), c_s[kTMax-1] are settled before the DOTS half reads them
-    if (jd && tid == j && j < 64) gi = c_s[kTMax - 1];  // lane j owns entry j of g in the DOTS half (jd = j+1 lanes)
+    __syncthreads();  // the new column of T (LDS or memory), c_s[kTMax-1] are settled before the DOTS half reads them
+    if (jd && li == j && j < 64) gi = c_s[kTMax - 1];  // lane j owns entry j of g in the DOTS half (jd = j+1 lanes)
 #ifdef KS_FIN_TIMING
     tk3 = wall_clock64();
 #endif
@@ -1608,15 +1684,19 @@ __global__ void __launch_bounds__(kBlock)
     const T* b_s = r_s + nm;  // sigma s[0..j-1], sigma^2 |y'|^2 at [j]
     const double isg = 1.0 / sig;
     const T gs = scl(gi, sig);
-    T ti = zero_of(T{});
-    if (tid < j) {
-      if (tid < ntrue) ti = b_s[tid];
-      else ti = dotc_contig(tb + (tid - ntrue) * tld, b_s, tid + 1);  // t''[i] = sum_{k <= i} conj(T[k,i]) s''[k]
-      t_s[tid] = ti;
-      Hcol[tid] = scl(scl(sub_(ti, gs), isg), binv_in);  // h = V_true^H (A v_true) = (t - g) / beta
+    T ti;
+    {  // t''[i] = sum_{k <= i} conj(T[k,i]) s''[k]
+      const T part = (li < j && li >= ntrue) ? tcol_dot(b_s, li) : zero_of(T{});
+      ti = combine(part);
+      if (li < j && li < ntrue) ti = b_s[li];
+      if (li >= j) ti = zero_of(T{});
+    }
+    if (q == 0 && li < j) {
+      t_s[li] = ti;
+      Hcol[li] = scl(scl(sub_(ti, gs), isg), binv_in);  // h = V_true^H (A v_true) = (t - g) / beta
     }
     // ||A v_true||^2 = (|y'|^2 - 2 Re g^H t + |g|^2) / beta^2
-    const double tot = wave_sum((tid < j) ? fma(-2.0, redot_(gs, ti), abs2_(gs)) : 0.0);
+    const double tot = wave_sum((li < j) ? fma(-2.0, redot_(gs, ti), abs2_(gs)) : 0.0);
     if (tid == 0) {
       const double rn2 = real_of(b_s[j]) + tot;
       const double rn = sqrt(rn2 > 0.0 ? rn2 : 0.0) * isg * binv_in, rp = sqrt(real_of(b_s[j])) * isg * binv_in;
@@ -1628,15 +1708,11 @@ __global__ void __launch_bounds__(kBlock)
       st->sigma = (mag > 0.0 && mag < 1.7e308) ? ldexp(1.0, -ilogb(mag)) : 1.0;
     }
     __syncthreads();
-    if (tid < j) {  // coefficients of the STORED columns: T t / beta
-      T a = zero_of(T{});
-      int k0 = tid;
-      if (tid < ntrue) {
-        a = t_s[tid];
-        k0 = ntrue;
-      }
-      a = add_(a, dot_strided(tb + tid - ntrue * tld, tld, t_s, k0, j));
-      coef[tid] = scl(scl(a, isg), binv_in);
+    {  // coefficients of the STORED columns: T t / beta
+      const T part = (li < j) ? trow_dot(t_s, li, j) : zero_of(T{});
+      T a = combine(part);
+      if (li < ntrue && li < j) a = add_(a, t_s[li]);
+      if (q == 0 && li < j) coef[li] = scl(scl(a, isg), binv_in);
     }
   }
 #ifdef KS_FIN_TIMING

@@ -144,46 +144,117 @@ struct HaloArgs {
   int recv_from[kP2pMaxNeigh];           // ranks whose flags I wait for
 };
 
-// hstate[0] = halo sequence number of this context, hstate[1] = finished-workgroup counter
+// SEQUENCE NUMBERS of the halo exchange are kept by the HOST (one counter per context, advanced at every enqueue of an
+// exchange) and travel in the kernel arguments; the slot of the double-buffered ghost vectors is seq & 1.  A kernel of a
+// batch that exits early after a Krylov breakdown skips its exchange on EVERY rank alike (the breakdown decision is
+// replicated), so numbers may be skipped -- flags are compared for equality, which does not care -- and the slot argument
+// survives a skip too: the breakdown was detected by a reduction kernel that every rank entered after its last executed
+// SpMV and left only with every peer's contribution, so no rank can push exchange e2 while a peer still reads the ghosts
+// of the last executed exchange e1 < e2, whatever their parities.  (Without skips it is the usual double-buffer argument:
+// push e+2 follows this rank's SpMV e+1, which waited for the peer's push e+1, which the peer issued after its SpMV e.)
+//
+// The work of one exchange, as device functions so that an SpMV kernel can do it ITSELF (k_spmv_stencil, k_spmv_csr with
+// `HaloFused::enabled`): workgroups 0 .. npush-1 of the launch -- the first to be dispatched -- store this rank's
+// boundary entries into the neighbours' ghost slots before they turn to their own tile, the last of them to finish raises
+// the neighbours' flags; a workgroup whose rows may read ghost entries waits for the flags of the ranks it receives from
+// before its loads, every other workgroup never waits.  One launch and ~9 us less per step than a push kernel in front
+// of the SpMV (its own launch, and the whole grid behind the slowest neighbour), and the wait overlaps the interior.
+// hstate[1] = finished-pusher counter (reset by the last pusher; the next exchange starts in a later launch).
+struct HaloFused {
+  int enabled;                     // 0: this launch has no exchange folded in
+  uint32_t seq;
+  int npush;                       // workgroups that push (<= gridDim.x)
+  const int32_t* send_idx;
+  uint32_t* counter;               // hstate + 1
+  long long ghost_lo_end, ghost_hi_begin;  // only rows < ghost_lo_end or >= ghost_hi_begin may read ghost entries
+  int tile_shift;                  // tiles are rotated by this many so that the leading boundary rows are dispatched LAST
+};
+
+// returns true in the workgroup that finished last (it raised the flags)
 template <class D>
-__global__ void __launch_bounds__(256)
-    k_halo_push(const D* __restrict__ x, const int32_t* __restrict__ send_idx, HaloArgs a, P2pDev p,
-                uint32_t* __restrict__ hstate, const int* __restrict__ breakdown) {
-  if (breakdown && *breakdown >= 0) return;
-  uint32_t seq = hstate[0] + 1u;
-  if (seq == 0u) seq = 1u;
+__device__ __forceinline__ bool halo_push_share(const D* __restrict__ x, const int32_t* __restrict__ send_idx, const HaloArgs& a,
+                                                const P2pDev& p, uint32_t seq, int wg, int nwg, uint32_t* __restrict__ counter) {
   const int slot = seq & 1u;
   const long long total = a.send_ptr[a.nneigh];
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    int pn = 0;
-    while (i >= a.send_ptr[pn + 1]) ++pn;
-    const D v = x[send_idx[i]];
-    D* d = static_cast<D*>(a.dst[pn]) + (long long)slot * a.dst_stride[pn] + (i - a.send_ptr[pn]);
-    *d = v;
+  // four entries per thread and trip: the push is a chain of two dependent loads and a remote store per entry, so the
+  // trips of a thread cost a memory round trip each -- few pushers with independent entries in flight, not many pushers
+  const long long stride = (long long)nwg * blockDim.x;
+  for (long long i0 = (long long)wg * blockDim.x + threadIdx.x; i0 < total; i0 += 4 * stride) {
+    int32_t si[4];
+    D v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) si[u] = (i0 + u * stride < total) ? send_idx[i0 + u * stride] : 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = x[si[u]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long i = i0 + u * stride;
+      if (i < total) {
+        int pn = 0;
+        while (i >= a.send_ptr[pn + 1]) ++pn;
+        D* d = static_cast<D*>(a.dst[pn]) + (long long)slot * a.dst_stride[pn] + (i - a.send_ptr[pn]);
+        *d = v[u];
+      }
+    }
   }
-  __threadfence_system();  // this workgroup's remote stores are visible at the neighbours
+  // A RELEASE fence at system scope: this workgroup's remote stores are performed at the neighbours before it reports in.
+  // Release only -- __threadfence_system() is release + ACQUIRE, and the acquire half invalidates this XCD's whole L2:
+  // inside an SpMV launch that threw away the x the other tiles re-read through L2 seven times (35 us per launch).
+  // (Waiting for the memory counter alone is NOT enough: the stores are acknowledged before they are performed at
+  // the destination, and a neighbour polling from another XCD read stale ghosts -- caught by tools/dist_overhead.py.)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   __syncthreads();
-  __shared__ int last;
-  if (threadIdx.x == 0) last = (atomicAdd(&hstate[1], 1u) == gridDim.x - 1) ? 1 : 0;
+  __shared__ int last_pusher;
+  if (threadIdx.x == 0) last_pusher = (atomicAdd(counter, 1u) == (unsigned)nwg - 1u) ? 1 : 0;
   __syncthreads();
-  if (!last) return;
+  if (!last_pusher) return false;
   const int t = threadIdx.x;
   if (t < a.nneigh && a.send_ptr[t + 1] > a.send_ptr[t])
     __hip_atomic_store(a.flag_dst[t] + (size_t)slot * p.nranks, (uint64_t)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (t == 0) *counter = 0u;
+  return true;
+}
+
+// all threads of the workgroup: returns once the ghost entries of exchange `seq` have arrived from every sender
+__device__ __forceinline__ void halo_wait(const HaloArgs& a, const P2pDev& p, uint32_t seq) {
+  const int slot = seq & 1u;
+  const int t = threadIdx.x;
   if (t < a.nrecv) {
     const uint64_t* f = p.region[p.rank] + p2p_ll_words(p.nranks, p.cap) + (size_t)slot * p.nranks + a.recv_from[t];
     const long long t0 = wall_clock64();
     long spins = 0;
-    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != (uint64_t)seq) {
+    // relaxed polls: flag and ghost entries live in uncached memory, there is nothing to invalidate -- an ACQUIRE load at
+    // system scope invalidates this XCD's whole L2 at every poll, under the feet of the tiles that are streaming x
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (uint64_t)seq) {
       if (p2p_expired(p, t0, spins++)) break;
-      __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_s_sleep(2);
     }
   }
+  // No acquire fence here (an acquire invalidates caches that every other tile is streaming x through).  What makes the
+  // plain ghost loads that follow safe: the arena is uncached fine-grained memory (nothing of it lives in an L2), the
+  // vector L1 is invalidated at every kernel launch, and inside a launch only workgroups that have passed this wait ever
+  // load from the ghost vector (the kernels fold every other ghost-range address back onto local rows).
+  asm volatile("" ::: "memory");
   __syncthreads();
-  if (t == 0) {
-    hstate[1] = 0u;
-    hstate[0] = seq;
-  }
+}
+
+// the prologue of an SpMV kernel with the exchange folded in; [row_lo, row_hi) = rows of this workgroup
+template <class D>
+__device__ __forceinline__ void halo_fused_prologue(const D* __restrict__ x, const HaloFused& h, const HaloArgs& a, const P2pDev& p,
+                                                    long long row_lo, long long row_hi) {
+  if ((int)blockIdx.x < h.npush) halo_push_share<D>(x, h.send_idx, a, p, h.seq, (int)blockIdx.x, h.npush, h.counter);
+  if (row_lo < h.ghost_lo_end || row_hi > h.ghost_hi_begin) halo_wait(a, p, h.seq);
+}
+
+// stand-alone exchange in front of an SpMV kernel that does not fold it in: push, raise, wait
+template <class D>
+__global__ void __launch_bounds__(256)
+    k_halo_push(const D* __restrict__ x, const int32_t* __restrict__ send_idx, HaloArgs a, P2pDev p,
+                uint32_t* __restrict__ hstate, uint32_t seq, const int* __restrict__ breakdown) {
+  if (breakdown && *breakdown >= 0) return;
+  // the last workgroup to finish raised the flags; it also waits for this rank's own ghosts, so that the SpMV launched
+  // behind this kernel finds them in place
+  if (halo_push_share<D>(x, send_idx, a, p, seq, (int)blockIdx.x, (int)gridDim.x, hstate + 1)) halo_wait(a, p, seq);
 }
 
 }  // namespace ksd

@@ -24,8 +24,12 @@
 #           P.Q * vecs                                   -> ks_basis_times                          eigvals.jl:94
 #   (2) FUSED EXPANSION: `ArnoldiMethod.iterate_arnoldi!(A::HipOperator, arnoldi{<:HipBasis}, range)` replaces the
 #       verb-by-verb loop of src/expansion.jl:116-133 by ONE call (ks_iterate_arnoldi: the whole range enqueued, DGKS
-#       decisions on the device, three passes over V per step, lazy normalisation).  Everything else of
-#       `_partialschur` still runs in Julia; the rotation verbs above absorb the lazy column factors.
+#       decisions on the device, TWO passes over V per step: the second DGKS projection is carried in a small triangular
+#       factor).  Everything else of `_partialschur` still runs in Julia; the rotation verbs above fold the factor in.
+#       The implicit second pass leans on the Arnoldi relation of the steps before `first(range)`; the reference only
+#       ever calls iterate_arnoldi! on such a decomposition (src/run.jl:267,272), so the method vouches for it
+#       (ks_workspace_assert_arnoldi) after handing the caller's H over -- without that the library would not trust a
+#       basis the reference's own restart code rotated through the verbs and would run its explicit three-pass form.
 #   (3) `ArnoldiMethod.partialschur(A::HipOperator; ...)`: builds the HipBasis workspace and calls the reference's
 #       `partialschur!`; `hip_partialschur` is the whole solver as one C call (ks_partialschur), for comparison.
 #
@@ -50,6 +54,8 @@ const KS_F64, KS_C64 = Cint(0), Cint(1)
 const KS_I32, KS_I64 = Cint(0), Cint(1)
 const KS_CSR, KS_CSC = Cint(0), Cint(1)
 const KS_ROW_MAJOR, KS_COL_MAJOR = Cint(0), Cint(1)
+# KS_LAYOUT_* of include/kschur.h, in code order (tests/test_julia_glue.py compares the count with the header's enum)
+const LAYOUTS = (:csr, :csr_vi, :csr_dvi, :sell, :sell_vi, :stencil, :csr_cb)
 const WHICH = Dict(:LM => Cint(0), :LR => Cint(1), :SR => Cint(2), :LI => Cint(3), :SI => Cint(4))
 const HipScalar = Union{Float64,ComplexF64}
 
@@ -161,7 +167,7 @@ end
 function operator_format(A::HipOperator)
     b = Ref{Cdouble}(0); d = Ref{Cint}(0); l = Ref{Cint}(0)
     check(ccall((:ks_operator_format, LIB), Cint, (Ptr{Cvoid}, Ref{Cdouble}, Ref{Cint}, Ref{Cint}), A.h, b, d, l))
-    (bytes_per_nnz = b[], ndict = Int(d[]), layout = (:csr, :csr_vi, :dvi, :sell, :sell_vi, :stencil)[l[] + 1])
+    (bytes_per_nnz = b[], ndict = Int(d[]), layout = LAYOUTS[l[] + 1])
 end
 
 # Opaque operators (LinearMaps etc., docs/src/index.md:246-249): the library calls back with two host pointers per
@@ -406,7 +412,7 @@ end
 
 # ---------------------------------------------------------------------------------------------- (2) fused expansion
 struct KsExpandStats
-    steps::Int32; reorth::Int32; breakdowns::Int32; reserved::Int32
+    steps::Int32; reorth::Int32; breakdowns::Int32; explicit_steps::Int32
 end
 
 """
@@ -423,6 +429,9 @@ function ArnoldiMethod.iterate_arnoldi!(A::HipOperator{T}, arnoldi::ArnoldiWorks
         # restart code rewrote the leading block of the caller's H on the host -> hand it over first
         @views copyto!(w.H[:, 1:first(range)-1], H[:, 1:first(range)-1])
     end
+    # V[:, 1:first(range)] and H[:, 1:first(range)-1] are an Arnoldi / Krylov-Schur decomposition of first(range)-1 steps
+    # whenever the reference calls this (src/run.jl:267,272): vouch for it, or the library runs its explicit form
+    check(ccall((:ks_workspace_assert_arnoldi, LIB), Cint, (Ptr{Cvoid}, Cint), w.h, first(range) - 1))
     check(ccall((:ks_iterate_arnoldi, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Ref{KsExpandStats}), A.h, w.h, first(range), last(range), st))
     if H !== w.H
         for j in range
@@ -459,7 +468,7 @@ struct KsParams
 end
 struct KsHistory
     mvproducts::Int32; nconverged::Int32; converged::Int32; nev::Int32
-    restarts::Int32; reorth::Int32; breakdowns::Int32; reserved::Int32
+    restarts::Int32; reorth::Int32; breakdowns::Int32; explicit_steps::Int32
     seconds_expand::Float64; seconds_host::Float64; seconds_rotate::Float64
 end
 

@@ -12,7 +12,12 @@
     (N > 1: launched by torch.distributed.run, one rank per GPU; rows of A and V are block-partitioned
      over the ranks -- total work fixed => "scaling": "strong", as north_star asks.  The per-step
      exchanges have two transports, RCCL and the library's peer-to-peer regions; both are measured
-     with the full W + K protocol and reported under "transports", `value` is the faster valid one.)
+     with the full W + K protocol -- RCCL FIRST and alone, each pass under a watchdog -- and reported
+     under "transports", `value` is the faster valid one.  With 8 ranks (or --config5) the line also
+     carries BASELINE config 5, the 464^3 Laplacian row-partitioned over the ranks, as "config5".)
+
+The line validates itself: after the timed cycles the reference's two invariants (test/expansion.jl:29-30) are
+evaluated ON THE BENCHED WORKSPACE (`validation`), and a run whose state violates them exits non-zero.
 
 Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel class (algorithmic bytes per
 launch / HIP-event duration on the library's own stream) and, as `fused_step`, the north-star quantity
@@ -96,6 +101,47 @@ def step_bytes(n, nnz, j, reorth, bpn=12.0):
     return b
 
 
+def plain_csr_spmv(pkg, ctx, A_host, n, reps=20):
+    """y = A x with the matrix uploaded as PLAIN CSR (rowptr / colidx int32 / val f64: 12 B per non-zero, SURVEY 8d's
+    formula; the row-block kernel k_spmv_csr: coalesced index/value reads, products through LDS, per-row sums), `reps`
+    launches on the library's stream between HIP events.  Returns GB/s on its algorithmic bytes 12 nnz + 4 (n+1) + 16 n."""
+    import torch
+
+    from arnoldimethod_jl_amd import _lib
+
+    old = os.environ.get("KS_SPMV_FORMAT")
+    os.environ["KS_SPMV_FORMAT"] = "csr"
+    try:
+        op = pkg.csr_operator(pkg.matrices.to_scipy(*A_host, n), ctx)
+    finally:
+        if old is None:
+            os.environ.pop("KS_SPMV_FORMAT", None)
+        else:
+            os.environ["KS_SPMV_FORMAT"] = old
+    try:
+        fmt = op.format
+        x = torch.from_numpy(pkg.matrices.start_vector(n)).cuda()
+        y = torch.empty_like(x)
+        torch.cuda.synchronize()
+        L = _lib.load()
+        for _ in range(3):
+            _lib.check(L.ks_operator_apply_raw(op._h, x.data_ptr(), y.data_ptr()))
+        ctx.synchronize()
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        for _ in range(reps):
+            _lib.check(L.ks_operator_apply_raw(op._h, x.data_ptr(), y.data_ptr()))
+        p = ctx.profile_get()["spmv"]
+        ctx.profile_enable(False)
+        ctx.profile_reset()
+        ms = p["ms"] / max(p["count"], 1)
+        gbs = p["bytes"] / max(p["count"], 1) / (ms * 1e-3) / 1e9
+        return {"layout": fmt["layout"], "bytes_per_nnz": fmt["bytes_per_nnz"], "launches": p["count"], "avg_launch_ms": ms,
+                "bytes_per_launch": p["bytes"] / max(p["count"], 1), "GBps": gbs, "frac": gbs / HBM_PEAK_GBS, "measured_in_run": True}
+    finally:
+        op.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,6 +151,9 @@ def main():
     ap.add_argument("--nev", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the second (HIP-event instrumented) pass")
+    ap.add_argument("--config5", action="store_true", help="also measure BASELINE config 5 (464^3 over the ranks) as a second record; "
+                                                           "default: only with 8 ranks")
+    ap.add_argument("--config5-grid", type=int, default=464)
     args = ap.parse_args()
 
     import torch
@@ -132,16 +181,22 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # CONTROL PLANE over gloo (rendezvous, the unique id / IPC handles, the MAX over ranks of the timing, pass/fail
+        # votes: a few CPU scalars); the DATA PATH's collectives are the library's own RCCL communicator
+        # (ks_ctx_create_dist: ncclAllReduce / ncclSend / ncclRecv) or its peer-to-peer regions.  One RCCL communicator
+        # in the process instead of two: torch's would be the first thing to meet a new fabric, outside every watchdog.
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         if world > 1 and same_device:
             dist.init_process_group("gloo")
             # RCCL cannot run here: measure the peer-to-peer transport and the host-staged one (which executes the RCCL
             # transport's launch structure with the exchanges staged through gloo)
             os.environ["KS_BENCH_TRANSPORTS"] = ",".join(
-                t for t in os.environ.get("KS_BENCH_TRANSPORTS", "p2p,host").split(",") if t in ("p2p", "host")) or "p2p"
+                t for t in os.environ.get("KS_BENCH_TRANSPORTS", "host,p2p").split(",") if t in ("p2p", "host")) or "p2p"
         elif world > 1:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("gloo")
         else:
             dist.init_process_group("gloo", rank=0, world_size=1)
+        red_dev = "cpu"
 
     def barrier():
         if dist is not None:
@@ -154,9 +209,11 @@ def main():
     which = "SR"
     tol = float(np.sqrt(np.finfo(np.float64).eps))
 
-    def measure(transport):
+    def measure(transport, m=m, n=n, steps=None, warmup=None, profile=True):
         """Build operand + workspace (rows block-partitioned over the ranks), run W untimed and K timed
         restart cycles, then the same K cycles once more with per-kernel HIP events."""
+        steps = args.steps if steps is None else steps
+        warmup = args.warmup if warmup is None else warmup
         if dist is None:
             ctx = pkg.Context(local_rank)
             ip, ix, dv = pkg.matrices.laplace3d_csr(m, m, m)
@@ -222,26 +279,44 @@ def main():
                 state["ritz"] = np.sort_complex(r["eigenvalues"][: r["k"]])
             state["k"], state["active"] = r["k"], r["nlock"]
 
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             cycle(False)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             cycle(True)
         barrier()
         elapsed = time.perf_counter() - t0
+        # SELF-VALIDATION on the benched state (outside the timed region): the reference's two invariants of an Arnoldi /
+        # Krylov-Schur decomposition, test/expansion.jl:29-30, evaluated on the device for the k columns the last restart
+        # left -- ||A V_k - V_{k+1} H_k||_F <= 1e-11 ||H||_F (tol-level instead once vectors are locked: the locked part of
+        # the relation holds to tol |lambda|, src/run.jl:206-208,360) and ||V'V - I||_F <= sqrt(eps) / 100
+        rel, orth = ws.arnoldi_relation(op, state["k"])
+        hnorm = float(np.linalg.norm(ws.H[: state["k"] + 1, : state["k"]]))
+        lim_rel = (1e-11 if state["active"] == 0 else 10.0 * tol) * hnorm
+        lim_orth = float(np.sqrt(np.finfo(np.float64).eps)) / 100.0
+        validation = {"arnoldi_rel": rel / hnorm, "orth": orth, "k": state["k"], "locked": state["active"], "H_fro": hnorm,
+                      "limit_rel": lim_rel / hnorm, "limit_orth": lim_orth, "ok": bool(rel <= lim_rel and orth <= lim_orth),
+                      "what": "||A V_k - V_{k+1} H_k||_F / ||H_k||_F and ||V'V - I||_F of the benched workspace after the timed "
+                              "cycles, evaluated on the device (test/expansion.jl:29-30)"}
         # Per-kernel HIP-event timing: the event pairs (recorded on the library's own stream around every
         # launch) cost ~4 % of throughput on this launch-dense path, so they are NOT left on while `value`
         # is measured; the same K cycles are repeated immediately afterwards with events on and the
         # per-kernel figures of `roofline` come from that second pass (same workload, same state machine).
         prof = None
-        if not args.no_profile:
+        if profile and not args.no_profile:
             ctx.profile_reset()
             ctx.profile_enable(True)
-            for _ in range(args.steps):
+            for _ in range(steps):
                 cycle(False)
             prof = ctx.profile_get()
             ctx.profile_enable(False)
+        # the SpMV BASELINE.json's metric names (north_star: "CSR SpMV with coalesced row-pointer/column reads and LDS
+        # per-row partial sums"), measured in this run next to the layout the solver picked: the same matrix uploaded
+        # as plain CSR (12 B per non-zero), 20 launches on the library's stream between HIP events
+        spmv_csr = None
+        if dist is None and profile and not args.no_profile:
+            spmv_csr = plain_csr_spmv(pkg, ctx, A_host, n)
         if dist is not None and world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -249,7 +324,8 @@ def main():
         ws.close()
         op.close()
         ctx.close()
-        return dict(elapsed=elapsed, state=state, prof=prof, nnz_global=nnz_global, A_host=A_host, fmt=fmt, placement=placement, basis_passes=basis_passes)
+        return dict(elapsed=elapsed, state=state, prof=prof, nnz_global=nnz_global, A_host=A_host, fmt=fmt, placement=placement, basis_passes=basis_passes,
+                    validation=validation, spmv_csr=spmv_csr, steps=steps, warmup=warmup)
 
     # N > 1: the row-partitioned solver has two transports for its per-step exchanges -- RCCL collectives
     # and the library's own peer-to-peer regions over xGMI (csrc/ks_p2p.hpp).  Both are measured with the
@@ -264,7 +340,9 @@ def main():
     if dist is None or (world == 1 and "KS_BENCH_TRANSPORTS" not in os.environ):
         order = ["single"]
     else:  # (KS_FORCE_DIST=1 KS_BENCH_TRANSPORTS=rccl,p2p exercises this selection logic on a single rank)
-        order = [t for t in os.environ.get("KS_BENCH_TRANSPORTS", "p2p,rccl").split(",") if t in ("rccl", "p2p", "host")] or ["rccl"]
+        # RCCL FIRST AND ALONE (the transport every fabric supports; nothing of the peer-to-peer machinery -- IPC handles,
+        # uncached regions, in-kernel spins -- has touched the devices when it runs), then the peer-to-peer regions
+        order = [t for t in os.environ.get("KS_BENCH_TRANSPORTS", "rccl,p2p").split(",") if t in ("rccl", "p2p", "host")] or ["rccl"]
     inject = os.environ.get("KS_BENCH_INJECT_FAIL", "")
     deadline_s = float(os.environ.get("KS_BENCH_PASS_DEADLINE_S", "300"))
 
@@ -274,19 +352,24 @@ def main():
         if rank == 0:
             print(json.dumps(out), flush=True)
 
-    def build_line(with_cpu_baseline=True):
-        return make_line(args, pkg, passes, order, world, rank, force_dist, dict(m=m, n=n, nev=nev, mindim=mindim, maxdim=maxdim, which=which),
-                         with_cpu_baseline)
+    extra = {}
 
-    for tr in order:
+    def build_line(with_cpu_baseline=True):  # (the records gathered so far ride along)
+        line = make_line(args, pkg, passes, order, world, rank, force_dist, dict(m=m, n=n, nev=nev, mindim=mindim, maxdim=maxdim, which=which),
+                         with_cpu_baseline)
+        line.update(extra)
+        return line
+
+    def run_pass(tr, store, key, fn):
+        """One measured pass under a watchdog; the outcome (result dict or {"error": ...}) lands in store[key]."""
         ok, res, err = 1, None, ""
         done = threading.Event()
 
-        def watchdog(tr=tr, done=done):
+        def watchdog():
             # a pass that hangs inside a collective cannot be interrupted from Python: report what we have and leave
             if done.wait(deadline_s):
                 return
-            passes[tr] = {"error": f"pass did not finish within {deadline_s:.0f} s (hung exchange?)"}
+            store[key] = {"error": f"pass did not finish within {deadline_s:.0f} s (hung exchange?)"}
             line = build_line(with_cpu_baseline=False)
             try:
                 emit(line)
@@ -300,7 +383,7 @@ def main():
                 if inject.endswith(":hang"):
                     time.sleep(10 * deadline_s)
                 raise RuntimeError(f"injected failure of the {tr} pass (KS_BENCH_INJECT_FAIL)")
-            res = measure(None if tr == "single" else tr)
+            res = fn()
         except Exception as e:  # noqa: BLE001
             if tr == "single":
                 raise
@@ -313,8 +396,35 @@ def main():
                     ok, err = 0, err or "failed on another rank"
             except Exception as e:  # noqa: BLE001 - the process group itself is broken
                 ok, err = 0, err or f"{type(e).__name__}: {e}"
-        passes[tr] = res if ok else {"error": err}
+        store[key] = res if ok else {"error": err}
         done.set()
+
+    for tr in order:
+        run_pass(tr, passes, tr, lambda tr=tr: measure(None if tr == "single" else tr))
+
+    # BASELINE config 5: the 464^3 Laplacian (n = 99 897 344, V = 32.8 GB in total) row-partitioned over the ranks, nev 20,
+    # 20/40 -- a second record in the same line, on the transport that won above, 1 untimed + 3 timed cycles
+    if args.config5 or world == 8 or os.environ.get("KS_BENCH_CONFIG5") == "1":
+        valid = [t for t in order if t in passes and "error" not in passes[t]]
+        if valid:
+            tr5 = min(valid, key=lambda t: passes[t]["elapsed"])
+            g5 = args.config5_grid
+            box = {}
+            run_pass(tr5, box, "r", lambda: measure(None if tr5 == "single" else tr5, m=g5, n=g5 ** 3, steps=3, warmup=1, profile=False))
+            r5 = box["r"]
+            if "error" in r5:
+                extra["config5"] = {"error": r5["error"], "transport": tr5}
+            else:
+                extra["config5"] = {
+                    "workload": f"laplace3d-7pt {g5}^3 (n={g5 ** 3}, nnz={r5['nnz_global']}), nev={nev}, which=SR, mindim={mindim}, maxdim={maxdim}, "
+                                f"rows/{world}; step = one Krylov-Schur restart cycle",
+                    "metric": "arnoldi_iters_per_sec", "value": r5["state"]["steps"] / r5["elapsed"], "unit": "iters/s", "n_gpus": world,
+                    "steps": r5["steps"], "warmup": r5["warmup"], "ms_per_step": 1e3 * r5["elapsed"] / max(r5["steps"], 1),
+                    "transport": tr5, "scaling": "weak (12.5e6 rows per GPU at 8 ranks)" if world > 1 else "single-gpu",
+                    "moved_GBps_per_gpu": r5["state"]["moved"] / max(r5["state"]["t_expand"], 1e-12) / 1e9 / world,
+                    "moved_frac": r5["state"]["moved"] / max(r5["state"]["t_expand"], 1e-12) / 1e9 / world / HBM_PEAK_GBS,
+                    "validation": r5["validation"],
+                }
     out = build_line()
     # Tear everything down first and flush the C stdio buffers (RCCL prints a version banner through printf,
     # which sits in the C buffer until exit when stdout is a pipe): the JSON line must be the LAST line on stdout.
@@ -327,6 +437,8 @@ def main():
     emit(out)
     if out["value"] is None:
         sys.exit(3)
+    if not out.get("validation", {}).get("ok", True) or not (out.get("config5") or {}).get("validation", {}).get("ok", True):
+        sys.exit(4)  # the benched state violates the Arnoldi relation / orthogonality: the number is not a valid measurement
 
 
 def make_line(args, pkg, passes, order, world, rank, force_dist, wl, with_cpu_baseline):
@@ -442,7 +554,16 @@ def make_line(args, pkg, passes, order, world, rank, force_dist, wl, with_cpu_ba
         "expand_seconds": state["t_expand"],
         "restart_seconds": state["t_restart"],
     }
+    sc = passes[chosen].get("spmv_csr")
+    if sc:
+        tr_csr = pmc_traffic("spmv_csr") if (m == 216 and world == 1 and not force_dist) else None
+        if tr_csr is not None:
+            tr_csr["measured_in_run"] = False
+        roof["spmv_plain_csr"] = dict(sc, what="the same matrix as plain CSR (12 B per non-zero) through k_spmv_csr: the SpMV "
+                                               "north_star describes, measured in this run beside the layout the solver picked", traffic=tr_csr)
     out["roofline"] = roof
+    if passes[chosen].get("validation") is not None:
+        out["validation"] = passes[chosen]["validation"]
 
     # ---- CPU baseline: the reference's op sequence on the host cores (rank 0, N = 1 only) ----
     if with_cpu_baseline and world == 1 and rank == 0 and not args.no_cpu_baseline and A_host is not None:

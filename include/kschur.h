@@ -186,6 +186,28 @@ int ks_workspace_placement(const ks_workspace* ws, int* candidates, double* best
  * the DGKS second projection, src/expansion.jl:93-94, is carried in a small triangular factor instead of being applied
  * to the n-vector), 3 = the second projection is applied to the vector as the reference does (KS_PASSES=3 at creation). */
 int ks_workspace_passes(const ks_workspace* ws, int* passes);
+/* Per-workspace switch for the above (instead of the KS_PASSES environment variable read at creation): passes = 2 or 3.
+ * `max_ratio`: the largest ||c|| / beta (second-pass correction against what is left of the vector,
+ * src/expansion.jl:93-96) the implicit form carries; a step whose correction is larger -- a genuine one, as opposed to
+ * the rounding-level corrections the DGKS test asks for at every step of a diagonally dominant operator -- is redone
+ * with the correction applied to the vector (counted in ks_expand_stats.explicit_steps / ks_history.explicit_steps).
+ * Default 1e-3 (KS_IMPLICIT_MAX_RATIO at creation); <= 0 removes the limit; NaN keeps the current value. */
+int ks_workspace_set_passes(ks_workspace* ws, int passes, double max_ratio);
+/* PROVENANCE.  The implicit second pass reads the columns < from of the host H and relies on the Arnoldi relation
+ * A V[:, 0:from-1) = V[:, 0:from) H[0:from, 0:from-1) holding for them -- the reference's iterate_arnoldi! reads
+ * neither.  The library therefore takes the implicit form only for a factorisation it produced itself: after
+ * ks_reinitialize(ws, 0, ...) and any sequence of ks_iterate_arnoldi / ks_restart / ks_expand_restart, inside
+ * ks_partialschur, and only while the host H still equals, bit for bit, what the library last left there.  Any verb
+ * that writes to V (ks_col_upload, ks_col_div, ks_gemv_n_sub, ks_rotate, ks_col_copy, ks_apply, ks_orthogonalize,
+ * ks_col_fill_uniform, handing out ks_workspace_col_ptr) or a changed / caller-built H makes ks_iterate_arnoldi run the
+ * explicit three-pass form instead (same results as the reference's op sequence, never wrong, about 1.5x slower).
+ * A host language that runs the restart itself (the reference's own `_partialschur` on a HipBasis: Schur step on its
+ * own H, then ks_rotate + ks_col_copy, src/run.jl:278-365) vouches for the result with
+ *     ks_workspace_assert_arnoldi(ws, k)   -- "columns 0..k are orthonormal and, with the H now in ks_workspace_H,
+ *                                              satisfy the Arnoldi relation of k steps"
+ * *k of ks_workspace_provenance: steps the library trusts (-1: none). */
+int ks_workspace_assert_arnoldi(ks_workspace* ws, int k);
+int ks_workspace_provenance(const ks_workspace* ws, int* k);
 /* Debugging aid: with KS_GUARD=1 in the environment a workspace puts 1 MiB canary zones on both sides of the
  * basis; *intact = 0 if any kernel wrote outside V (always 1 without KS_GUARD). */
 int ks_workspace_check_guard(ks_workspace* ws, int* intact);
@@ -194,7 +216,7 @@ int ks_workspace_dims(const ks_workspace* ws, int64_t* n_local, int* maxdim, int
 int ks_workspace_H(ks_workspace* ws, void** H, int* ldh);
 int ks_workspace_Q(ks_workspace* ws, void** Q, int* ldq);
 /* Device pointer of column j of V (for device-side consumers; PartialSchur.Q is a view of V,
- * src/run.jl:375,389). */
+ * src/run.jl:375,389).  The pointer may be written through: handing it out ends the library's provenance (above). */
 int ks_workspace_col_ptr(ks_workspace* ws, int j, void** dev_ptr);
 int ks_workspace_set_seed(ks_workspace* ws, uint64_t seed);
 
@@ -241,14 +263,17 @@ int ks_reinitialize(ks_workspace* ws, int j, const void* v1_host, int* ok);
 /* iterate_arnoldi!(A, arnoldi, from:to)   src/expansion.jl:116-133  (from/to as in the
  * reference: step j builds 0-based column j from column j-1).  The whole range is enqueued
  * asynchronously (operator apply + fused DGKS per step, decisions on-device) and the host
- * synchronises once at the end to fetch the new columns of H.  Columns < from of the workspace's host H (ks_workspace_H)
- * must hold the current Hessenberg matrix on entry: the default expansion (ks_workspace_passes == 2) reads it on the
- * device (g = H c of the implicit second DGKS pass). */
+ * synchronises once at the end to fetch the new columns of H.  Like the reference it needs nothing from columns < from
+ * of H: the implicit second pass (ks_workspace_passes == 2), which does read them, is only taken while the library's
+ * provenance of the factorisation is intact (see ks_workspace_assert_arnoldi); otherwise the explicit form runs.
+ * `reorth`: the DGKS test of the implicit form is taken against max(||A v||, ||y'|| / beta) (the norm of the vector the
+ * projection was really applied to; equal to the reference's rnorm, src/expansion.jl:81, unless the previous column
+ * carries a correction): it can ask for the second pass where the reference would not, never the other way round. */
 typedef struct ks_expand_stats {
-  int32_t steps;       /* operator applications performed                                    */
-  int32_t reorth;      /* steps whose DGKS test requested the second pass (src/expansion.jl:91) */
-  int32_t breakdowns;  /* steps that ended in reinitialize! (src/expansion.jl:127-129)        */
-  int32_t reserved;
+  int32_t steps;          /* operator applications performed                                    */
+  int32_t reorth;         /* steps whose DGKS test requested the second pass (src/expansion.jl:91) */
+  int32_t breakdowns;     /* steps that ended in reinitialize! (src/expansion.jl:127-129)        */
+  int32_t explicit_steps; /* steps the implicit second pass handed back to the explicit form (ks_workspace_set_passes) */
 } ks_expand_stats;
 int ks_iterate_arnoldi(ks_operator* A, ks_workspace* ws, int from, int to, ks_expand_stats* stats);
 
@@ -272,7 +297,7 @@ typedef struct ks_history { /* src/run.jl:217-222 (+ diagnostics) */
   int32_t restarts;   /* outer iterations performed */
   int32_t reorth;     /* DGKS second passes taken   */
   int32_t breakdowns;
-  int32_t reserved;
+  int32_t explicit_steps; /* steps redone with the explicit second pass (ks_workspace_set_passes) */
   double seconds_expand; /* wall time spent waiting for the device in iterate_arnoldi  */
   double seconds_host;   /* wall time in the host Schur / reorder / restore            */
   double seconds_rotate; /* wall time enqueueing+waiting for rotations (mostly async)  */
@@ -297,9 +322,11 @@ int ks_restart(ks_workspace* ws, const ks_params* p, int active, int* k, int* nl
                double* lams_c64, double* rs, int32_t* groups);
 
 /* One whole cycle of `_partialschur`'s loop (src/run.jl:272-365) in one call: the expansion k_in+1 .. maxdim followed by
- * the restart, with the part of the restart's host work that does not need H[maxdim+1, maxdim] (Schur form, Ritz values,
- * unit residuals, ordering: src/run.jl:278-289) running on the host WHILE the device finishes the last expansion step --
- * what ks_partialschur does internally.  Results are bit-identical to ks_iterate_arnoldi + ks_restart.  `k_in` is the
+ * the restart -- what ks_partialschur does internally.  With the explicit second pass (ks_workspace_passes == 3) the part
+ * of the restart's host work that does not need H[maxdim+1, maxdim] (Schur form, Ritz values, unit residuals, ordering:
+ * src/run.jl:278-289) runs on the host WHILE the device finishes the last expansion step; with the implicit second pass
+ * (default) H is final only when the batch ends and the host step follows it.  Results are bit-identical to
+ * ks_iterate_arnoldi + ks_restart either way.  `k_in` is the
  * basis size the previous restart left (mindim after the initial expansion).  seconds[3] (optional): wall time of the
  * expansion (including whatever of the early host part the device did not hide), of the remaining host part, of
  * enqueueing the rotation. */

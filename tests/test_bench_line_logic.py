@@ -25,7 +25,10 @@ def _pass(elapsed, ritz_shift=0.0, steps=200):
     state = dict(steps=steps, bytes=3.0e12, moved=2.4e12, t_expand=0.9 * elapsed, t_restart=0.1 * elapsed, reorth=steps,
                  trail=[(20, 0)] * 10, ritz=np.sort_complex(np.arange(20.0) + ritz_shift + 0j))
     return dict(elapsed=elapsed, state=state, prof=prof, nnz_global=70263936, A_host=None,
-                fmt=dict(bytes_per_nnz=0.1434, ndict=7, layout="stencil"), placement=dict(candidates=0))
+                fmt=dict(bytes_per_nnz=0.1434, ndict=7, layout="stencil"), placement=dict(candidates=0),
+                validation=dict(arnoldi_rel=3e-14, orth=9e-15, k=20, locked=0, ok=True),
+                spmv_csr=dict(layout="csr", bytes_per_nnz=12.0, launches=20, avg_launch_ms=0.2, bytes_per_launch=1.04e9, GBps=5200.0, frac=0.65,
+                              measured_in_run=True))
 
 
 def test_single_gpu_line_has_contract_fields_and_honest_roofline():
@@ -71,3 +74,20 @@ def test_deviating_peer_to_peer_pass_is_dropped_and_faster_valid_pass_wins():
 
 def test_cpu_budget_respects_cgroup_quota():
     assert 1 <= bench.CPU_BUDGET <= (os.cpu_count() or 1)
+
+
+def test_line_carries_validation_of_the_benched_state_and_the_plain_csr_spmv():
+    """the line validates itself (test/expansion.jl:29-30 on the benched workspace) and reports the
+    SpMV BASELINE.json's metric names -- plain CSR through k_spmv_csr -- measured in the run, next to the layout in use."""
+    out = bench.make_line(ARGS, None, {"single": _pass(0.3)}, ["single"], 1, 0, False, WL, False)
+    assert out["validation"]["ok"] is True and out["validation"]["arnoldi_rel"] < 1e-11 and out["validation"]["orth"] < 1.5e-10
+    pc = out["roofline"]["spmv_plain_csr"]
+    assert pc["layout"] == "csr" and pc["measured_in_run"] is True and pc["frac"] == 0.65 and "traffic" in pc
+    assert out["roofline"]["spmv"]["layout"] == "stencil"  # what the solver ran is still reported as such
+    json.dumps(out)
+
+
+def test_rccl_runs_first_and_alone_by_default():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'os.environ.get("KS_BENCH_TRANSPORTS", "rccl,p2p")' in src
+    assert 'init_process_group("nccl"' not in src  # control plane over gloo: the library's communicator is the only RCCL user

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def _bench(extra_env, nproc=2, grid=64, timeout=420):
+def _bench(extra_env, nproc=2, grid=64, timeout=420, extra_args=()):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -21,7 +21,7 @@ def _bench(extra_env, nproc=2, grid=64, timeout=420):
     env.update(extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1",
-           "--grid", str(grid)]
+           "--grid", str(grid), *extra_args]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
@@ -34,6 +34,34 @@ def test_both_transports_measured_and_agree():
     assert set(d["transports"]) == {"p2p", "host"} and all("value" in v for v in d["transports"].values()), d["transports"]
     assert d["value"] == max(v["value"] for v in d["transports"].values()) and d["n_gpus"] == 2
     assert d["roofline"]["fused_step"]["moved_frac"] > 0 and d["scaling"] == "strong"
+    # the collective-structured transport is measured FIRST (on an 8-GPU node: RCCL, alone, before any peer-to-peer set-up)
+    assert list(d["transports"])[0] == "host"
+    # the line validates the benched state (test/expansion.jl:29-30 on the device)
+    v = d["validation"]
+    assert v["ok"] and v["arnoldi_rel"] <= v["limit_rel"] and v["orth"] <= v["limit_orth"], v
+
+
+def test_config5_record_rides_in_the_same_line():
+    """BASELINE config 5 (464^3 over the ranks) as a second record of the N > 1 line -- here at 48^3 over 2 ranks on one GPU."""
+    r, d = _bench({}, extra_args=("--config5", "--config5-grid", "48"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    c5 = d["config5"]
+    assert c5["n_gpus"] == 2 and c5["value"] > 0 and c5["steps"] == 3 and "48^3" in c5["workload"]
+    assert c5["transport"] == d["config"]["transport"] and c5["validation"]["ok"], c5
+    assert d["value"] > 0 and "64^3" in d["config"]["workload"]
+
+
+def test_single_gpu_line_validates_itself_and_reports_the_plain_csr_spmv():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--grid", "96", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=420)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    v = d["validation"]
+    assert v["ok"] and v["arnoldi_rel"] < 1e-11 and v["orth"] < 1.5e-10, v
+    pc = d["roofline"]["spmv_plain_csr"]
+    assert pc["layout"] == "csr" and pc["bytes_per_nnz"] == 12.0 and pc["measured_in_run"] and pc["launches"] == 20 and pc["GBps"] > 0, pc
+    assert d["roofline"]["spmv"]["layout"] == "stencil"
 
 
 @pytest.mark.parametrize("victim,survivor", [("host", "p2p"), ("p2p", "host")])

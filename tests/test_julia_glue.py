@@ -220,3 +220,69 @@ def test_ctypes_prototype_table_matches_header_argument_by_argument():
     for cname, ct in (("ks_params", pkg._lib.ks_params), ("ks_history", pkg._lib.ks_history), ("ks_expand_stats", pkg._lib.ks_expand_stats)):
         got = [(n, cls(t)) for n, t in ct._fields_]
         assert got == hs[cname], (cname, got, hs[cname])
+
+
+# ------------------------------------------------------------------ enums: every code of the header has a name on both sides
+def header_enums():
+    """{first enumerator name: [(name, value), ...]} for every anonymous `enum { ... };` of the header."""
+    txt = re.sub(r"/\*.*?\*/", "", open(HDR).read(), flags=re.S)
+    out = {}
+    for m in re.finditer(r"enum\s*\{(.*?)\}\s*;", txt, flags=re.S):
+        items, nxt = [], 0
+        for it in m.group(1).split(","):
+            it = it.strip()
+            if not it:
+                continue
+            if "=" in it:
+                nm, v = (x.strip() for x in it.split("="))
+                nxt = int(v, 0)
+            else:
+                nm = it
+            items.append((nm, nxt))
+            nxt += 1
+        out[items[0][0]] = items
+    return out
+
+
+def _jl_tuple(name: str):
+    src = open(JL).read()
+    m = re.search(rf"^const\s+{name}\s*=\s*\((.*?)\)\s*$", src, flags=re.M)
+    assert m, f"const {name} = (...) not found in the Julia glue"
+    return [x.strip() for x in m.group(1).split(",") if x.strip()]
+
+
+def test_layout_codes_have_a_name_on_every_side():
+    """`operator_format` indexed a 6-tuple with 7 layout codes (BoundsError on config-3 matrices).  The
+    Julia tuple, the Python table and the header's enum must have the same cardinality, codes dense from 0."""
+    enums = header_enums()
+    lay = enums["KS_LAYOUT_CSR"]
+    assert [v for _, v in lay] == list(range(len(lay))), lay
+    jl = _jl_tuple("LAYOUTS")
+    assert len(jl) == len(lay), (jl, lay)
+    assert not re.search(r"\(:csr, :csr_vi[^)]*\)\[", open(JL).read()), "a literal layout tuple is indexed somewhere: use LAYOUTS"
+    py = pkg._lib.LAYOUTS
+    assert sorted(k for k in py if k >= 0) == [v for _, v in lay], (py, lay)
+    # the other small enums the glue mirrors as constants
+    src = open(JL).read()
+    for first, consts in (("KS_F64", ("KS_F64", "KS_C64")), ("KS_I32", ("KS_I32", "KS_I64")), ("KS_CSR", ("KS_CSR", "KS_CSC"))):
+        items = dict(enums[first])
+        assert len(items) == len(consts), (first, items)
+        m = re.search(rf"^const\s+{', '.join(consts)}\s*=\s*(.*)$", src, flags=re.M)
+        assert m, consts
+        vals = [int(x) for x in re.findall(r"Cint\((\d+)\)", m.group(1))]
+        assert vals == [items[c] for c in consts], (consts, vals, items)
+    which = dict(enums["KS_LM"])
+    jw = dict((k, int(v)) for k, v in re.findall(r":(\w+)\s*=>\s*Cint\((\d+)\)", re.search(r"^const WHICH = Dict\((.*)\)$", src, flags=re.M).group(1)))
+    assert {f"KS_{k}": v for k, v in jw.items()} == which, (jw, which)
+    assert {f"KS_{k}": v for k, v in pkg._lib.WHICH.items()} == which
+
+
+def test_glue_vouches_for_the_factorisation_before_the_fused_expansion():
+    """The implicit second pass is only taken on a factorisation the library trusts (include/kschur.h, PROVENANCE): the
+    level-2 method must hand H over and call ks_workspace_assert_arnoldi before ks_iterate_arnoldi."""
+    src = open(JL).read()
+    body = src[src.index("function ArnoldiMethod.iterate_arnoldi!"):]
+    body = body[: body.index("\nend\n")]
+    a, b = body.find(":ks_workspace_assert_arnoldi"), body.find(":ks_iterate_arnoldi")
+    assert 0 <= a < b, "assert_arnoldi must precede ks_iterate_arnoldi in iterate_arnoldi!"
+    assert "three passes over V per step" not in src
