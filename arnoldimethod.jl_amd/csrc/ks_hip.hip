@@ -348,6 +348,7 @@ template <class D> struct CsrOp : ks_operator {
   // them in order, each continuing the row sums of the previous one (k_spmv_csr's yacc)
   std::vector<std::unique_ptr<CsrOp<D>>> cblocks;
   int ni = 7;               // non-zeros per thread and block: a block holds at most ni * 256 entries in LDS
+  bool row_gather = false;  // k_spmv_csr: one thread per row gathers x itself (banded matrices) instead of the non-zero-parallel gathers
   int nlong = 0;            // rows longer than that: cut into chunk blocks, partial sums added by k_spmv_longfix
   int32_t* blkpart = nullptr;  // per block: -1, or the index of the chunk's partial sum
   D* lpart = nullptr;
@@ -415,7 +416,8 @@ template <class D> struct CsrOp : ks_operator {
         constexpr int NI = decltype(ni_tag)::value;
         if constexpr ((size_t)NI * kBlock * sizeof(D) <= (size_t)ksd::kSpmvCapBytes)
           ksd::k_spmv_csr<D, IP, false, NI><<<nblk, kBlock, 0, s>>>(static_cast<const IP*>(blkptr), blkrow, static_cast<const IP*>(rowptr), colidx, val, x,
-                                                                    nullptr, y, n_local, nblk, st, nullptr, 0, 0, nullptr, nullptr, yacc, plain_store);
+                                                                    nullptr, y, n_local, nblk, st, nullptr, 0, 0, nullptr, nullptr, yacc, plain_store,
+                                                                    ksd::HaloFused{}, ksd::HaloArgs{}, ksd::P2pDev{}, env_int("KS_SPMV_CSR_NT", 1) != 0, row_gather);
         else
           throw KsError{KS_ERR_INTERNAL, "CSR row blocks of " + std::to_string(NI) + " x 256 entries exceed the LDS budget of this element type"};
       };
@@ -606,11 +608,12 @@ template <class D> struct CsrOp : ks_operator {
           constexpr int NI = decltype(ni_tag)::value;
           if constexpr ((size_t)NI * kBlock * sizeof(D) <= (size_t)ksd::kSpmvCapBytes)
           {
+            static const int csr_nt = env_int("KS_SPMV_CSR_NT", 1);
             ksd::HaloFused h = hf;
             h.npush = std::min(h.npush, nblk);
             ksd::k_spmv_csr<D, IP, VI, NI><<<nblk, kBlock, 0, s>>>(static_cast<const IP*>(blkptr), blkrow, static_cast<const IP*>(rowptr), colidx,
                                                                    val, x, xg, y, n_local, nblk, st, hseq, ghost_stride, ndict, blkpart, lpart,
-                                                                   nullptr, 0, h, hargs, ctx->p2p.dev);
+                                                                   nullptr, 0, h, hargs, ctx->p2p.dev, csr_nt != 0, row_gather);
           }
           else
             throw KsError{KS_ERR_INTERNAL, "CSR row blocks of " + std::to_string(NI) + " x 256 entries exceed the LDS budget of this element type"};
@@ -1106,6 +1109,23 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
     if (ni != 4 && ni != 7 && ni != 8 && ni != 12 && ni != 16) ni = 16;
     ni = std::min(ni, nimax);
     op->ni = ni;
+    {
+      // ROW-GATHER or NON-ZERO-PARALLEL gathers (k_spmv_csr): with lane = row the gathers of one instruction are coalesced
+      // when neighbouring rows reference neighbouring columns (banded / stencil / FEM matrices: 212 -> 204 us on the 216^3
+      // Laplacian, 0.62 -> 0.64 of the HBM spec), and a chain of dependent LDS reads and scattered loads when they do not
+      // (hashed columns: 46.5 -> 49.5 us, heavy-tailed rows 109 -> 125 us).  Decided once from the matrix: the share of
+      // consecutive row pairs whose first stored columns are at most 16 apart.  KS_SPMV_CSR_ROWGATHER=0/1 forces.
+      int64_t pairs = 0, close = 0;
+      const int64_t stride = std::max<int64_t>(1, nrows / 65536);
+      for (int64_t r = 0; r + 1 < nrows; r += stride) {
+        if (rp[r + 1] == rp[r] || rp[r + 2] == rp[r + 1]) continue;
+        ++pairs;
+        const int64_t d = (int64_t)ci[rp[r + 1]] - (int64_t)ci[rp[r]];
+        if (d >= -16 && d <= 16) ++close;
+      }
+      const int rg_env = env_int("KS_SPMV_CSR_ROWGATHER", -1);
+      op->row_gather = rg_env >= 0 ? rg_env != 0 : (pairs > 0 && 2 * close >= pairs);
+    }
     const int64_t cap = (int64_t)ni * kBlock;
     std::vector<int64_t> bp{0};
     std::vector<int32_t> br{0}, part, lrow, lfirst{0};
@@ -1958,6 +1978,33 @@ template <class D> void rotate_device(ks_workspace* ws, int c0, int c, int r, in
   ProfScope ps(ctx, KSP_ROTATE, (double)ws->n * sizeof(D) * (c + r));  // in place: read c, write r columns
   const bool force_valu = env_int("KS_ROTATE_VALU", 0) != 0;
   if constexpr (sizeof(D) == 8) {
+    // KS_ROTATE = fma (default: vector-ALU kernel -- the FP64 matrix cores of gfx950 run at half the vector rate) |
+    // mfma (v_mfma_f64_16x16x4_f64 tiles)
+    const char* rot_env = std::getenv("KS_ROTATE");
+    const std::string rot = rot_env ? rot_env : "fma";
+    if (!force_valu && rot == "fma" && c <= 64) {
+      static const int bpc_env = env_int("KS_ROTATE_FMA_BPC", 2);
+      auto go = [&](auto ct_tag) {
+        constexpr int CT = decltype(ct_tag)::value;
+        const size_t smem = (size_t)r * CT * 8;
+        static int occ = -1;
+        if (occ < 0) {
+          KS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ksd::k_rotate_fma<CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+          int o = 0;
+          KS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, ksd::k_rotate_fma<CT>, kBlock, (size_t)48 * CT * 8));
+          occ = std::max(1, std::min(o, bpc_env));
+        }
+        const int nbr = cap_blocks(ws, ctx->num_cu * occ, kBlock);
+        ksd::k_rotate_fma<CT><<<nbr, kBlock, smem, s>>>(Vc, ws->ld, c, r, Qd, c, out0, extra_out);
+      };
+      KS_REQUIRE((size_t)r * 64 * 8 <= (size_t)64 * 1024, KS_ERR_INTERNAL, "rotation wider than the coefficient tile");
+      if (c <= 24) go(std::integral_constant<int, 24>{});
+      else if (c <= 32) go(std::integral_constant<int, 32>{});
+      else if (c <= 44) go(std::integral_constant<int, 44>{});
+      else go(std::integral_constant<int, 64>{});
+      KS_HIP(hipGetLastError());
+      return;
+    }
     if (!force_valu && c <= 64) {
       const int ntile = (r + 15) / 16;
       auto smem = [&](int KC) { return (size_t)ntile * 16 * (4 * KC + 1) * 8; };

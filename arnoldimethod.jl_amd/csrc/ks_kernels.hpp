@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(kBlock)
                const T* __restrict__ xg, T* __restrict__ y, int64_t n, int nblk, const DevState* __restrict__ st,
                const uint32_t* __restrict__ hseq, int64_t gstride, int ndict, const int32_t* __restrict__ blkpart,
                T* __restrict__ lpart, const T* __restrict__ yacc = nullptr, int plain_store = 0, HaloFused hf = HaloFused{},
-               HaloArgs ha = HaloArgs{}, P2pDev pd = P2pDev{}) {
+               HaloArgs ha = HaloArgs{}, P2pDev pd = P2pDev{}, bool nt_loads = true, bool row_gather = true) {
   // yacc != nullptr: this launch handles ONE COLUMN BLOCK of the matrix (column-blocked layout) and continues the row sums
   // an earlier launch left in yacc -- entries of a row are visited in CSR order across the launches, so y is bit-identical
   if (st && st->breakdown >= 0) return;
@@ -266,6 +266,7 @@ __global__ void __launch_bounds__(kBlock)
   if (hseq) xg += (int64_t)(*hseq & 1u) * gstride;
   constexpr int CAP = NI * kBlock;
   __shared__ T prod[CAP];
+  __shared__ int32_t lcol[CAP];
   // VI: the dictionary is staged in LDS (gathering it from global memory per non-zero measured 10 % slower);
   // the index loads are issued BEFORE the staging barrier so the two latencies overlap
   __shared__ T dict[VI ? 256 : 1];
@@ -290,12 +291,55 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
       const int32_t p = tid + k * kBlock;
-      c[k] = (p < cnt) ? ci[p] : 0;
-      if (!VI) a[k] = (p < cnt) ? va[p] : zero_of(T{});
+      // (the matrix is touched once per application: streaming loads keep it from evicting the x every row re-reads
+      // through L2 -- KS_SPMV_CSR_NT=0 restores plain loads)
+      c[k] = (p < cnt) ? ld_i32(ci + p, nt_loads) : 0;
+      if (!VI) a[k] = (p < cnt) ? ld_val(va + p, nt_loads) : zero_of(T{});
     }
     if (VI) {
       dict[tid] = dmine;
       __syncthreads();
+    }
+    if (row_gather) {
+      // ROW-GATHER form (default): the coalesced loads above only STAGE the block's (column, value) pairs in LDS; then one
+      // thread per row walks its segment and gathers x itself.  lane = row, so the gathers of one instruction read
+      // x[r + delta], x[r + 1 + delta], ... -- consecutive addresses for a banded matrix, a handful of cache lines per
+      // wave instruction -- where the non-zero-parallel gathers below touch one line per band per ~9 lanes; one barrier
+      // instead of two, no product round trip through LDS.  Same products, same order of additions: y is bit-identical.
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int32_t p = tid + k * kBlock;
+        if (VI) {
+          a[k] = dict[(uint32_t)c[k] >> 24];
+          c[k] &= 0xffffff;
+        }
+        if (p < cnt) {
+          prod[p] = a[k];
+          lcol[p] = c[k];
+        }
+      }
+      __syncthreads();
+      if (r0 + tid < r1) {
+        T s = yacc ? yacc[r0 + tid] : zero_of(T{});
+        for (int32_t p = ra; p < rb; p += 8) {
+          int32_t cc[8];
+          T aa[8], xx[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const bool ok = p + u < rb;
+            cc[u] = ok ? lcol[p + u] : 0;
+            aa[u] = ok ? prod[p + u] : zero_of(T{});
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) xx[u] = (cc[u] < n) ? x[cc[u]] : xg[cc[u] - n];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (p + u < rb) s = add_(s, mul_nc(aa[u], xx[u]));
+        }
+        if (plain_store) y[r0 + tid] = s;  // (an intermediate column block: the next launch reads it back)
+        else st_elem_nt(y + r0 + tid, s);
+      }
+      return;
     }
     T xv[NI];
 #pragma unroll
@@ -330,8 +374,10 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
       const int32_t p = tid + k * kBlock;
-      c[k] = (p < cnt) ? ci[p] : 0;
-      if (!VI) a[k] = (p < cnt) ? va[p] : zero_of(T{});
+      // (the matrix is touched once per application: streaming loads keep it from evicting the x every row re-reads
+      // through L2 -- KS_SPMV_CSR_NT=0 restores plain loads)
+      c[k] = (p < cnt) ? ld_i32(ci + p, nt_loads) : 0;
+      if (!VI) a[k] = (p < cnt) ? ld_val(va + p, nt_loads) : zero_of(T{});
     }
     if (VI) {
       dict[tid] = dmine;
@@ -1982,6 +2028,64 @@ __global__ void __launch_bounds__(kBlock)
           if (col < r) st_pack_nt(V + (int64_t)oc * ldv + row[t], make_double2(acc0[v], acc1[v]));
         }
       }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// VECTOR-ALU form of the Float64 rotation -- the DEFAULT on gfx950 for c <= 64.  On this part the FP64 matrix cores run
+// at HALF the rate of the FP64 vector ALUs (v_mfma_f64_16x16x4_f64 issues every ~128 cycles per SIMD: measured, the MFMA
+// kernels above read V at 4.8 TB/s with their stores removed and at 6.7 TB/s with the MFMAs removed as well), and the
+// 16-wide MFMA tiles pad r = 21 outputs to 32.  A plain FMA loop needs 2 c r flops per row and nothing else:
+//   lane = one 16-byte pack (two rows); all c <= CT input columns of the pack in registers (so the update is in place);
+//   per output column a dot product over the inputs against Q^T from LDS (broadcast 16-byte reads: two coefficients each),
+//   four independent accumulation chains; the result is stored at once -- 4 KiB contiguous per column and workgroup.
+// 2 c r / (8 (c + r)) ~ 3.5 flop/B at c = 41, r = 21: 0.22 ms of vector-ALU time at n = 1e7 against 0.8 ms of memory time
+// -- HBM-bound, which the MFMA forms are not on this part (0.72 ms of matrix-core time).  Measured at n = 1e7, c = 41,
+// r = 21 (profiles/r03_rotation.txt): 4.97 TB/s against 4.86 of k_rotate_mfma.  What does NOT lift it further, all tried:
+// staging the output in LDS and writing 6 KiB bursts per column (4.5-4.8), writing out of place (4.92), one to three
+// workgroups per CU (4.97-5.01).  With its stores removed the kernel reads at 6.7 TB/s: what is left is what this memory
+// system makes of 41 read streams next to 21 write streams (a third of the traffic is writes; the expansion kernels
+// write 3 %).
+// ------------------------------------------------------------------------------------------------
+template <int CT>
+__global__ void __launch_bounds__(kBlock)
+    k_rotate_fma(double* __restrict__ V, int64_t ldv, int c, int r, const double* __restrict__ Qd, int ldq, int out0, int extra_out) {
+  static_assert(CT % 4 == 0, "CT must be a multiple of four");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* qs = reinterpret_cast<double*>(smem_raw);  // [r][CT]: qs[n * CT + k] = Q[k, n], zero for k >= c
+  for (int i = threadIdx.x; i < r * CT; i += kBlock) {
+    const int k = i % CT, n = i / CT;
+    qs[i] = k < c ? Qd[k + (int64_t)n * ldq] : 0.0;
+  }
+  __syncthreads();
+  int64_t pb, pe;
+  block_range(ldv / 2, blockIdx.x, gridDim.x, pb, pe);
+  for (int64_t p = pb + threadIdx.x; p < pe; p += kBlock) {
+    const int64_t row = p * 2;
+    double2 in[CT];
+#pragma unroll
+    for (int k = 0; k < CT; ++k) {
+      const int k2 = k < c ? k : c - 1;  // (coefficient zero: value irrelevant, the load is an L1 / L2 hit)
+      in[k] = ld_pack_nt(V + (int64_t)k2 * ldv + row);
+    }
+    for (int n = 0; n < r; ++n) {
+      const double* qn = qs + n * CT;
+      double2 s0 = make_double2(0.0, 0.0), s1 = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int k = 0; k < CT; k += 4) {
+        const double2 qa = *reinterpret_cast<const double2*>(qn + k), qb = *reinterpret_cast<const double2*>(qn + k + 2);
+        s0.x = fma(in[k].x, qa.x, s0.x);
+        s0.y = fma(in[k].y, qa.x, s0.y);
+        s1.x = fma(in[k + 1].x, qa.y, s1.x);
+        s1.y = fma(in[k + 1].y, qa.y, s1.y);
+        s0.x = fma(in[k + 2].x, qb.x, s0.x);
+        s0.y = fma(in[k + 2].y, qb.x, s0.y);
+        s1.x = fma(in[k + 3].x, qb.y, s1.x);
+        s1.y = fma(in[k + 3].y, qb.y, s1.y);
+      }
+      const int oc = (extra_out >= 0 && n == r - 1) ? extra_out : out0 + n;
+      st_pack_nt(V + (int64_t)oc * ldv + row, make_double2(s0.x + s1.x, s0.y + s1.y));
     }
   }
 }
