@@ -347,6 +347,7 @@ template <class D> struct CsrOp : ks_operator {
   // column-blocked layout: the matrix split into column blocks, each a CSR-row-block sub-operator of its own; apply() runs
   // them in order, each continuing the row sums of the previous one (k_spmv_csr's yacc)
   std::vector<std::unique_ptr<CsrOp<D>>> cblocks;
+  int cb_rpt = 0, cb_ni = 0;  // single-launch form of the column-blocked layout (k_spmv_csr_cb): 256-row sub-tiles per workgroup, LDS depth; 0: one launch per block
   int ni = 7;               // non-zeros per thread and block: a block holds at most ni * 256 entries in LDS
   bool row_gather = false;  // k_spmv_csr: one thread per row gathers x itself (banded matrices) instead of the non-zero-parallel gathers
   int nlong = 0;            // rows longer than that: cut into chunk blocks, partial sums added by k_spmv_longfix
@@ -507,6 +508,37 @@ template <class D> struct CsrOp : ks_operator {
     if (n_local > 0 && !cblocks.empty()) {
       // column-blocked CSR: one launch per column block; block b > 0 reads the partial row sums block b-1 left in y
       ProfScope ps(ctx, KSP_SPMV, (double)nnz * bytes_per_nnz + aux_bytes + 2.0 * sizeof(D) * n_local);
+      if (cb_rpt) {
+        // ONE launch: a workgroup keeps the sums of its rows in registers while it walks the column blocks (k_spmv_csr_cb)
+        ksd::CbArgs<D> a{};
+        a.nb = (int)cblocks.size();
+        for (int b = 0; b < a.nb; ++b) {
+          a.rowptr[b] = static_cast<const int32_t*>(cblocks[b]->rowptr);
+          a.colidx[b] = cblocks[b]->colidx;
+          a.val[b] = cblocks[b]->val;
+        }
+        const int nt = (int)((n_local + (int64_t)kBlock * cb_rpt - 1) / ((int64_t)kBlock * cb_rpt));
+        auto go = [&](auto ni_tag, auto rpt_tag) {
+          constexpr int NI = decltype(ni_tag)::value, RPT = decltype(rpt_tag)::value;
+          if constexpr ((size_t)NI * kBlock * sizeof(D) <= (size_t)ksd::kSpmvCapBytes)
+            ksd::k_spmv_csr_cb<D, NI, RPT><<<nt, kBlock, 0, s>>>(a, x, y, n_local, nt, st);
+          else
+            throw KsError{KS_ERR_INTERNAL, "column-blocked CSR: LDS depth exceeds the budget of this element type"};
+        };
+        auto by_rpt = [&](auto ni_tag) {
+          switch (cb_rpt) {
+            case 1: go(ni_tag, std::integral_constant<int, 1>{}); break;
+            case 2: go(ni_tag, std::integral_constant<int, 2>{}); break;
+            case 4: go(ni_tag, std::integral_constant<int, 4>{}); break;
+            case 8: go(ni_tag, std::integral_constant<int, 8>{}); break;
+            default: go(ni_tag, std::integral_constant<int, 16>{}); break;
+          }
+        };
+        if (cb_ni == 8) by_rpt(std::integral_constant<int, 8>{});
+        else by_rpt(std::integral_constant<int, 16>{});
+        KS_HIP(hipGetLastError());
+        return;
+      }
       for (size_t b = 0; b < cblocks.size(); ++b) cblocks[b]->launch_csr_blocks(x, y, st, b > 0 ? y : nullptr, b + 1 < cblocks.size() ? 1 : 0);
       KS_HIP(hipGetLastError());
       return;
@@ -1066,6 +1098,12 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
       }
     }
     if (nbk >= 2) {
+      nbk = std::min(nbk, ksd::kCbMaxBlocks);
+      // single-launch form (k_spmv_csr_cb): largest segment (entries of a tile of 256 * RPT rows inside one column block)
+      // for every candidate RPT
+      constexpr int kRptCand[5] = {1, 2, 4, 8, 16};
+      int64_t maxseg[5] = {0, 0, 0, 0, 0};
+      bool small_ptrs = true;
       for (int b = 0; b < nbk; ++b) {
         const int64_t lo = (int64_t)b * nrows / nbk, hi = (b + 1 == nbk) ? (int64_t)1 << 40 : (int64_t)(b + 1) * nrows / nbk;
         std::vector<int64_t> rpb((size_t)nrows + 1, 0);
@@ -1076,13 +1114,42 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
             if (ci[q] >= lo && ci[q] < hi) { cib.push_back(ci[q]); vvb.push_back(vv[q]); }
           rpb[r + 1] = (int64_t)cib.size();
         }
+        for (int k = 0; k < 5; ++k) {
+          const int64_t tr = (int64_t)kBlock * kRptCand[k];
+          for (int64_t r0 = 0; r0 < nrows; r0 += tr) maxseg[k] = std::max(maxseg[k], rpb[std::min(nrows, r0 + tr)] - rpb[r0]);
+        }
         op->cblocks.emplace_back(make_csr<D>(ctx, nrows, (int64_t)cib.size(), rpb, cib, vvb, 2));
+        small_ptrs = small_ptrs && !op->cblocks.back()->ptr64;
+      }
+      // Measured (tools/cb_single_ab.py, profiles/r03_column_blocks.txt): the single launch wins where the y round trips of
+      // many blocks hurt (n = 1e7, 8 blocks: 858 -> 823 us) and loses a little where two to four launches were already close
+      // to what bounds this product -- the rate at which an XCD's L2 hands out randomly addressed lines, 5e6 of them for
+      // 1e6 rows: 46 us either way at n = 1e6, 100 vs 107 us at 2e6.  So: single launch from 5 blocks on
+      // (KS_SPMV_CB_SINGLE=0 never, KS_SPMV_CB_RPT=k forces it with k sub-tiles per workgroup).
+      const int rpt_force = env_int("KS_SPMV_CB_RPT", 0);
+      if (small_ptrs && env_int("KS_SPMV_CB_SINGLE", 1) && (nbk > 4 || rpt_force > 0)) {
+        // all tiles resident at once (one round of workgroups keeps them in step on the same column block): the smallest RPT
+        // whose tile count fits, among those whose segments fit the LDS depth (8 x 256 products, 16 x 256 for Float64)
+        const int nimax = (int)(ksd::kSpmvCapBytes / (kBlock * sizeof(D)));  // 16 (Float64) / 8 (ComplexF64)
+        const int rpt_env = env_int("KS_SPMV_CB_RPT", 0);
+        int best = -1;
+        for (int k = 0; k < 5; ++k) {
+          const int ni = maxseg[k] <= 8 * kBlock ? 8 : (maxseg[k] <= 16 * kBlock && nimax >= 16 ? 16 : 0);
+          if (!ni) break;  // (segments only grow with RPT)
+          best = k;
+          const int64_t ntiles = (nrows + (int64_t)kBlock * kRptCand[k] - 1) / ((int64_t)kBlock * kRptCand[k]);
+          if (rpt_env ? kRptCand[k] >= rpt_env : ntiles <= (int64_t)ctx->num_cu * (ni == 8 ? 8 : 4)) break;
+        }
+        if (best >= 0) {
+          op->cb_rpt = kRptCand[best];
+          op->cb_ni = maxseg[best] <= 8 * kBlock ? 8 : 16;
+        }
       }
       op->layout = KS_LAYOUT_CSR_CB;
       op->bytes_per_nnz = 4.0 + sizeof(D);
       op->aux_bytes = 0.0;
       for (auto& cbk : op->cblocks) op->aux_bytes += cbk->aux_bytes;
-      op->aux_bytes += (double)(nbk - 1) * 2.0 * sizeof(D) * (double)nrows;  // y written and read back between the blocks
+      if (!op->cb_rpt) op->aux_bytes += (double)(nbk - 1) * 2.0 * sizeof(D) * (double)nrows;  // y written and read back between the blocks
       return op.release();
     }
   }

@@ -308,6 +308,19 @@ def test_column_blocked_csr_is_bit_identical(dtype, monkeypatch):
         y, f, _ = _apply(A, x, dtype)
         assert f["layout"] == "csr-cb", f
         assert np.array_equal(y, y0), nb
+    # the SINGLE-LAUNCH form (k_spmv_csr_cb: a workgroup keeps its rows' sums in registers while it walks the column blocks;
+    # automatic from 5 blocks on): every rows-per-workgroup variant, 2 / 5 / 8 blocks, against one launch per block
+    for nb in ("2", "5", "8"):
+        monkeypatch.setenv("KS_SPMV_COLBLOCKS", nb)
+        for rpt in ("1", "2", "4", "8", "16"):
+            monkeypatch.setenv("KS_SPMV_CB_RPT", rpt)
+            y, f, _ = _apply(A, x, dtype)
+            assert f["layout"] == "csr-cb" and np.array_equal(y, y0), (nb, rpt)
+        monkeypatch.delenv("KS_SPMV_CB_RPT")
+        monkeypatch.setenv("KS_SPMV_CB_SINGLE", "0")
+        y, f, _ = _apply(A, x, dtype)
+        assert np.array_equal(y, y0), nb
+        monkeypatch.delenv("KS_SPMV_CB_SINGLE")
     # unsorted rows: the order of the additions would change -> the layout must refuse
     monkeypatch.setenv("KS_SPMV_COLBLOCKS", "2")
     U = A.copy()
