@@ -41,12 +41,18 @@ def test_uniform_hash_is_a_pure_function_and_uniform():
     v = np.empty(500)
     oa.rand_fill(v, oa.DEFAULT_SEED, row_offset=1000)
     assert (v == u[1000:1500]).all()
-    # golden values (also hard-coded in the HIP kernel test)
+    # LITERAL golden values, obtained independently of oracle/arnoldi.py (pure-Python integer arithmetic; VERDICT r2: the
+    # previous constant was computed from the function it checked):
+    #   * the published known answer of the splitmix64 generator (Vigna's splitmix64.c): state 1234567 -> first output
+    #     6457827717110365317 -- our finaliser is exactly one step of it, splitmix64(x) = mix(x + 0x9E3779B97F4A7C15);
+    #   * u[i] = (splitmix64(seed xor i) >> 11) * 2^-53 for seed 20240917, i = 0..3, as exact hexadecimal doubles.
+    assert int(oa.splitmix64(np.uint64(1234567))) == 6457827717110365317
     g = oa.uniform_hash(20240917, np.arange(4))
-    assert g.tolist() == pytest.approx(GOLDEN_HASH, abs=0)
+    assert [float(x).hex() for x in g] == GOLDEN_HASH_HEX
+    assert g.tolist() == [0.9248160014551147, 0.418340663264014, 0.11549796239421439, 0.27945786907302395]
 
 
-GOLDEN_HASH = [float(x) for x in oa.uniform_hash(20240917, np.arange(4))]
+GOLDEN_HASH_HEX = ["0x1.d9817ba22268dp-1", "0x1.ac617ead393aep-2", "0x1.d9146433cdfb8p-4", "0x1.1e2a34211d2bep-2"]
 
 
 # ------------------------------------------------------------------ test/expansion.jl

@@ -36,4 +36,25 @@ for cfg in cfg3 cfg4 cfg4big; do
     trim "$(find /tmp/pmc_${cfg}_$c -name '*counter_collection.csv' | head -1)" "$OUT/${cfg}_pmc_$(echo $c | tr A-Z a-z | sed s/_size//).csv"
   done
 done
+# round 3 additions
+# (a) the SpMV north_star names: plain CSR through k_spmv_csr on the 216^3 Laplacian, traffic next to it
+cd $REPO
+SPMV_TRIALS=2 python tools/spmv_bench.py lap216 lap100 lapvar216 hashed1e6 skew1e6 cplx5e5 > $OUT/spmv_layouts.txt 2>> $OUT/bench.err
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  KS_SPMV_FORMAT=csr SPMV_TRIALS=1 SPMV_REPS=20 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_spmv_$c -- python $REPO/tools/spmv_bench.py lap216 > /dev/null 2>> $OUT/bench.err
+  trim "$(find /tmp/pmc_spmv_$c -name '*counter_collection.csv' | head -1)" "$OUT/spmv_csr_pmc_$(echo $c | tr A-Z a-z | sed s/_size//).csv"
+done
+python $REPO/tools/pmc_generic.py $OUT/spmv_csr_pmc_fetch.csv $OUT/spmv_csr_pmc_write.csv > $OUT/spmv_csr_pmc_summary.txt 2>&1
+# (b) column-blocked CSR: one launch against one launch per block
+cd $REPO
+python tools/cb_single_ab.py 1000000 2000000 10000000 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostn\|^Librc" > $OUT/column_blocks.txt
+# (c) rotation kernels A/B on the headline
+for rot in fma mfma; do
+  echo "KS_ROTATE=$rot" >> $OUT/rotation.txt
+  KS_ROTATE=$rot python bench.py --no-cpu-baseline --steps 10 --warmup 2 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('  iterations/s', round(d['value'],1), ' rotate', d['roofline']['per_class']['rotate'])" >> $OUT/rotation.txt
+done
 ls -la $OUT
