@@ -1,0 +1,406 @@
+// the HIP backend of the Krylov-Schur driver (ks_driver.hpp), the on-device residual checks, the placement search
+// Part of the ONE translation unit of libkschur_hip.so: included by ks_hip.hip, in this order --
+//     ks_context.hpp -> ks_operators.hpp -> ks_workspace.hpp -> ks_backend.hpp -> (C ABI in ks_hip.hip)
+// -- and not meant to be included on its own (needs ks_workspace.hpp).
+#pragma once
+// ------------------------------------------------------------------------------------------------
+// the HIP backend of the driver
+// ------------------------------------------------------------------------------------------------
+template <class T> struct HipBackend : ks::Backend<T> {
+  using D = typename DevT<T>::type;
+  ks_operator* op;
+  ks_workspace* ws;
+  HipBackend(ks_operator* o, ks_workspace* w) : op(o), ws(w) {}
+
+  int64_t n_global() const override { return ws->n_global; }
+
+  void iterate_arnoldi(int from, int to, const ks::Mat<T>& H, ks::ExpandStats& stats) override {
+    guarded_expand([&] { iterate_arnoldi_impl(from, to, H, stats, nullptr); });
+  }
+
+  // The expansion a restart follows: H[0:to, :] is handed to `early` (restart_host_early: Schur form, Ritz values,
+  // unit residuals, ordering) as soon as the last step's k_fin_mid_def ran, while the device still runs that step's
+  // second-pass update and the reduction of H[to, to-1] -- at n = 1e7 the update alone (0.4 ms) outlasts the whole early
+  // part (0.13 ms), at n = 1e6 about 30 us of it are hidden (profiles/r02_restart_bubble.txt).
+  // KS_EARLY_RESTART=0 keeps the strictly sequential order.  Same operations on the same numbers either way.
+  // Explicit-second-pass path (KS_PASSES=3) only: with the implicit second pass (default) H is final only when the batch
+  // ends -- there is no tail to hide behind -- and this returns false (the caller then runs the whole host step).
+  bool iterate_arnoldi_early(int from, int to, const ks::Mat<T>& H, ks::ExpandStats& stats, const std::function<void()>& early) override {
+    const char* e = std::getenv("KS_EARLY_RESTART");
+    const bool on = !(e && e[0] == '0');
+    bool done = false;
+    guarded_expand([&] { done = iterate_arnoldi_impl(from, to, H, stats, on ? &early : nullptr); });
+    return done;
+  }
+
+  template <class F> void guarded_expand(F&& f) {
+    try {
+      f();
+    } catch (...) {
+      // an operator callback (or a HIP / transport error) aborted a batch midway: steps were enqueued whose H columns
+      // and lazy-normalisation factors were never fetched.  Drain the stream and return the bookkeeping to "every
+      // column is ordinary"; the factorisation itself is undefined from here on -- the caller must re-initialise
+      // (ks_reinitialize(ws, 0, ...) or ks_partialschur with initialize = 1) before using the workspace again.
+      (void)hipStreamSynchronize(ws->ctx->stream);
+      try { reset_lazy(ws); } catch (...) {}
+      prov_drop(ws);
+      throw;
+    }
+  }
+
+  // returns true iff *early ran and its effects on H stand
+  bool iterate_arnoldi_impl(int from, int to, const ks::Mat<T>& H, ks::ExpandStats& stats, const std::function<void()>* early) {
+    ws->ctx->use();
+    bool early_stands = false;
+    int j0 = from;
+    int explicit_step = -1;  // a step the implicit form handed back (DevState::bail): redone with the explicit second pass
+    // Provenance: the implicit second pass reads earlier columns of the caller's H and assumes the Arnoldi relation for
+    // them.  Only a factorisation the library produced itself (or the caller vouched for) qualifies; anything else runs
+    // the explicit form, which -- like the reference's iterate_arnoldi! -- reads neither.
+    const bool trusted = prov_ok(ws, from);
+    while (j0 <= to) {
+      const double tb0 = ks::now_s();
+      int jend = to;
+      if (!op->async_capable) jend = j0;  // host operators: one step per batch
+      if (explicit_step >= 0) jend = j0;
+      const bool lazy = use_deferred(ws, jend);
+      const bool tpath = lazy && ws->passes == 2 && trusted && explicit_step < 0;  // implicit second pass: two reads of the basis per step
+      if (tpath && !(ws->t_lazy && j0 == ws->t_hi + 1)) {
+        materialize(ws);   // whatever is lazy (either kind) becomes ordinary: this batch starts a new T
+        ws->ntrue = j0;
+      }
+      double sigma0 = 1.0;
+      if (tpath && ws->t_lazy && j0 - 1 >= ws->ntrue && j0 - 1 <= ws->t_hi) {
+        // the batch continues on a factored column (host callbacks: every batch): k_dots' scale factor from its 1 / beta
+        const double binv = reinterpret_cast<const double*>(static_cast<const char*>(ws->Th) + ((size_t)(j0 - 1) + (size_t)(j0 - 1) * ws->ldt) * ws->esz)[0];
+        if (binv > 0.0 && std::isfinite(binv)) sigma0 = std::ldexp(1.0, std::ilogb(binv));
+      }
+      reset_state(ws, tpath, sigma0);
+      const bool mb = lazy && ws->use_mbox;          // the device publishes the results itself, the host spins
+      const bool do_early = early && mb && !tpath && jend == to;  // (with two passes H is final only at the very end)
+      const uint64_t seq = ++ws->mbox_seq;
+      if (tpath) {
+        enqueue_steps_t<D>(ws, op, j0, jend);
+      } else if (lazy) {
+        if (ws->t_lazy) materialize(ws);
+        enqueue_steps_deferred<D>(ws, op, j0, jend, do_early ? seq : 0);
+      } else {
+        materialize(ws);  // the eager kernels expect ordinary columns
+        for (int j = j0; j <= jend; ++j) {
+          op->in_scale = 1.0;
+          op->apply(ws->col(j - 1), ws->col(j), ws->st);
+          enqueue_orthogonalize<D>(ws, j);
+        }
+      }
+      bool early_ran = false;
+      // if anything throws after the early part of the restart step ran (transport time-out, operator error), the host H
+      // is put back as it was: a caller that catches the error must not find a half-restarted matrix
+      struct EarlyGuard {
+        ks_workspace* w; void* Hp; bool armed;
+        ~EarlyGuard() { if (armed && !w->Hbackup.empty()) std::memcpy(Hp, w->Hbackup.data(), w->Hbackup.size()); }
+      } early_guard{ws, H.p, false};
+      static const int dbg = env_int("KS_EARLY_DEBUG", 0);
+      double tq0 = dbg ? ks::now_s() : 0.0, tq1 = 0, tq2 = 0;
+      if (mb) publish_control(ws, j0, ws->Hstage_dev, 1, seq, tpath);
+      else fetch_state_enqueue(ws, j0, tpath);
+      if (do_early) {
+        mbox_wait(ws, 0, seq);
+        if (dbg) tq1 = ks::now_s();
+        const DevState* se = reinterpret_cast<const DevState*>(static_cast<const char*>(ws->Hstage_early) + ws->hd_bytes);
+        if (se->breakdown < 0) {  // (a breakdown of the LAST step is only known after the final reduction: see below)
+          const size_t hb = (size_t)H.ld * H.n * sizeof(T);
+          ws->Hbackup.resize(hb);
+          std::memcpy(ws->Hbackup.data(), H.p, hb);
+          early_guard.armed = true;
+          fetch_H_columns<T>(ws, j0, jend, H, false, ws->Hstage_early);  // H[jend, jend-1] is not final yet, nobody reads it
+          (*early)();
+          early_ran = true;
+        }
+        if (dbg) tq2 = ks::now_s();
+      }
+      if (mb) {
+        mbox_wait(ws, 1, seq);
+        if (ws->ctx->profiling) {
+          KS_HIP(hipStreamSynchronize(ws->ctx->stream));
+          prof_collect(ws->ctx);
+        }
+        ws->ctx->check_comm();
+      } else {
+        fetch_state_wait(ws);
+      }
+      if (dbg && do_early) {
+        const double tq3 = ks::now_s();
+        std::fprintf(stderr, "[early] enqueue %.1f us | wait H %.1f us | early host part %.1f us | final wait %.1f us | batch %.1f us\n", 1e6 * (tq0 - tb0), 1e6 * (tq1 - tq0), 1e6 * (tq2 - tq1), 1e6 * (tq3 - tq2), 1e6 * (tq3 - tb0));
+      } else if (dbg) {
+        const double tq3 = ks::now_s();
+        std::fprintf(stderr, "[early off] enqueue %.1f us | wait %.1f us | batch %.1f us\n", 1e6 * (tq0 - tb0), 1e6 * (tq3 - tq0), 1e6 * (tq3 - tb0));
+      }
+      // bail: the implicit form refuses step `bail` (its second-pass correction is not small) -- steps before it stand,
+      // the step itself is redone below in the explicit form; not a breakdown
+      const int bail = tpath ? ws->st_h->bail : -1;
+      const int bd = bail >= 0 ? -1 : ws->st_h->breakdown;
+      const int last_done = bail >= 0 ? bail - 1 : (bd >= 0 ? bd : jend);
+      if (early_ran && bd >= 0) {  // the last step broke down: withdraw (rare; the caller redoes the early part)
+        std::memcpy(H.p, ws->Hbackup.data(), ws->Hbackup.size());
+        early_ran = false;
+      }
+      early_guard.armed = false;
+      if (early_ran) {
+        const T* hs = static_cast<const T*>(ws->Hstage);
+        H(jend, jend - 1) = hs[(size_t)(jend - 1) * (ws->maxdim + 1) + jend];
+        lazy_factors_from_stage<T>(ws, j0, jend, ws->Hstage);
+        early_stands = true;
+      } else {
+        fetch_H_columns<T>(ws, j0, last_done, H, lazy && !tpath);
+      }
+      if (tpath) {
+        // columns j0 .. (last completed step) are T-lazy now; a column that broke down is garbage until reinit_column
+        const int good = bail >= 0 ? bail - 1 : (bd >= 0 ? bd - 1 : jend);
+        if (good >= ws->ntrue) {
+          ws->t_lazy = true;
+          ws->t_hi = good;
+        }
+      }
+      stats.steps += last_done - j0 + 1;
+      stats.reorth += ws->st_h->n_reorth;
+      if (explicit_step >= 0) explicit_step = -1;  // the handed-back step is done
+      if (bail >= 0) {
+        explicit_step = bail;
+        stats.explicit_steps++;
+      }
+      if (lazy && jend > j0) ws->oop_full = 10 * ws->st_h->n_reorth >= 9 * (last_done - j0 + 1);  // (batches of one step keep the setting)
+      if (bd >= 0) {
+        // orthogonalize! returned false at step bd: H[bd, bd-1] = 0 is already in place
+        // (src/expansion.jl:99-102); draw a fresh vector unless bd == n (src/expansion.jl:127-129)
+        if ((int64_t)bd != ws->n_global) {
+          reinit_column<D>(ws, bd, nullptr);
+          stats.breakdowns++;
+        }
+      }
+      j0 = last_done + 1;
+    }
+    // the factorisation up to `to` is the library's own again (or stays unknown)
+    if (trusted) prov_set(ws, to);
+    else prov_drop(ws);
+    return early_stands;
+  }
+
+  bool reinitialize(int j, const T* v1_host) override {
+    ws->ctx->use();
+    return reinit_column<D>(ws, j, v1_host);
+  }
+
+  void rotate(int c0, int c, int r, const ks::Mat<T>& Q) override {
+    if (c <= 0 || r <= 0) return;
+    rotate_lazy<T>(ws, c0, c, r, &Q(c0, c0), Q.ld, /*update_device_factors=*/false);  // col_copy resets them right after
+  }
+
+  // V[:, dst] <- V[:, src]: the last act of a restart (src = maxdim holds the residual direction).  Every
+  // column that is still lazy afterwards is dead (it lies beyond the truncated basis) -> reset the factors.
+  void col_copy(int dst, int src) override {
+    if (ws->t_lazy) materialize(ws);
+    const double copy_factor = ws->hostscale[src];
+    if (dst != src || copy_factor != 1.0) {
+      if (dst == src)
+        ksd::k_scale<D><<<ws->nb, kBlock, 0, ws->ctx->stream>>>(static_cast<D*>(ws->col(src)), ws->ld, copy_factor, nullptr);
+      else
+        ksd::k_copy<D><<<ws->nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const D*>(ws->col(src)), static_cast<D*>(ws->col(dst)), ws->ld, copy_factor);
+      KS_HIP(hipGetLastError());
+    }
+    reset_lazy(ws);
+  }
+
+  // src/run.jl:363-365 as ONE operation.  With the implicit second pass the basis is S T: the rotation and the move of
+  // the residual direction are one T-folded product S[:, 0:src+1) [ T Q | T[:, src] ] (the columns it does not write are
+  // the ones the restart discards).
+  void rotate_and_move(int c0, int c, int r, const ks::Mat<T>& Q, int dst, int src) override {
+    const bool own = ws->prov_k == src;  // the library's own factorisation of `src` steps is being truncated to `dst`
+    if (ws->t_lazy) {
+      rotate_tfold<T>(ws, c0, c, r, r > 0 ? &Q(c0, c0) : nullptr, Q.ld, c0, src, dst);
+      reset_lazy(ws);
+    } else {
+      rotate(c0, c, r, Q);
+      col_copy(dst, src);
+    }
+    if (own) prov_set(ws, dst);  // (the host step rewrote H: new shadow)
+    else prov_drop(ws);
+  }
+};
+
+template <class F> void dispatch_dtype(int dtype, F&& f) {
+  if (dtype == KS_F64) f(double{});
+  else if (dtype == KS_C64) f(cplx{});
+  else throw KsError{KS_ERR_ARGUMENT, "unknown dtype"};
+}
+
+void check_col(const ks_workspace* ws, int j) {
+  KS_REQUIRE(ws != nullptr, KS_ERR_ARGUMENT, "null workspace");
+  KS_REQUIRE(j >= 0 && j <= ws->maxdim, KS_ERR_ARGUMENT, "column index out of range");
+}
+
+}  // namespace
+
+namespace {
+
+// Frobenius norm of (A X - Y C) where X = V[:, 0:nx), Y = V[:, 0:ny), C (ny x nx) host; and of (Y^H Y - I).
+template <class T>
+void relation_norms(ks_operator* A, ks_workspace* ws, int nx, int ny, const T* C, int ldc, double* resid, double* orth) {
+  using D = typename DevT<T>::type;
+  ks_ctx* c = ws->ctx;
+  hipStream_t s = c->stream;
+  D* y = static_cast<D*>(ws->ensure_tmp((size_t)ws->ld * sizeof(D)));
+  KS_HIP(hipMemsetAsync(y, 0, (size_t)ws->ld * sizeof(D), s));
+  const int nbk = c->num_cu * 4;
+  double r2 = 0.0;
+  for (int i = 0; i < nx; ++i) {
+    A->in_scale = 1.0;
+    A->apply(ws->col(i), y, nullptr);
+    std::memcpy(ws->coef_h, C + (size_t)i * ldc, (size_t)ny * sizeof(T));
+    KS_HIP(hipMemcpyAsync(ws->coef, ws->coef_h, (size_t)ny * sizeof(T), hipMemcpyHostToDevice, s));
+    ksd::k_sub_lincomb<D><<<nbk, kBlock, 0, s>>>(y, static_cast<const D*>(ws->V), ws->ld, ny, static_cast<const D*>(ws->coef), ws->n);
+    ksd::k_norm2<D><<<ws->nb, kBlock, 0, s>>>(y, ws->ld, ws->partial2);
+    ksd::k_sum<<<1, kBlock, 0, s>>>(ws->partial2, ws->nb, ws->scal);
+    c->allreduce(ws->scal, 1);
+    KS_HIP(hipMemcpyAsync(ws->scal_h, ws->scal, 8, hipMemcpyDeviceToHost, s));
+    KS_HIP(hipStreamSynchronize(s));
+    r2 += ws->scal_h[0];
+  }
+  *resid = std::sqrt(r2);
+  // Gram matrix in 8x8 tiles
+  const int gnb = std::min(ws->nb, c->num_cu * 2);
+  D* gp = static_cast<D*>(ws->ensure_tmp2((size_t)gnb * 64 * sizeof(D) + 64 * sizeof(D)));
+  D* gout = gp + (size_t)gnb * 64;
+  std::vector<T> tile(64);
+  double o2 = 0.0;
+  for (int i0 = 0; i0 < ny; i0 += 8)
+    for (int j0 = 0; j0 < ny; j0 += 8) {
+      const int na = std::min(8, ny - i0), nbc = std::min(8, ny - j0);
+      ksd::k_gram_tile<D><<<gnb, kBlock, 0, s>>>(static_cast<const D*>(ws->col(i0)), ws->ld, na, static_cast<const D*>(ws->col(j0)),
+                                                  ws->ld, nbc, ws->n, gp);
+      ksd::k_reduce_cols<D><<<1, kBlock, 0, s>>>(gp, gnb, 64, 64, gout);
+      c->allreduce(reinterpret_cast<double*>(gout), 64 * (int)(sizeof(D) / 8));
+      KS_HIP(hipMemcpyAsync(tile.data(), gout, 64 * sizeof(D), hipMemcpyDeviceToHost, s));
+      KS_HIP(hipStreamSynchronize(s));
+      for (int jj = 0; jj < nbc; ++jj)
+        for (int ii = 0; ii < na; ++ii) {
+          T g = tile[ii + 8 * jj];
+          if (i0 + ii == j0 + jj) g -= T(1);
+          o2 += ks::abs2_(g);
+        }
+    }
+  *orth = std::sqrt(o2);
+}
+
+}  // namespace
+
+namespace {
+// Placement tuning.  How fast the streaming kernels run on a basis of several GB depends on WHICH physical
+// pages back it: K simultaneous allocations of the same size in one process differ reproducibly by 6-8 %
+// (tools/placement_probe2.hip; the launches of three real steps take 5.31..5.67 ms on eight candidates at
+// n = 1e7) while offsets inside one allocation and the leading dimension make no difference
+// (tools/placement_probe.hip).  This is what made identical runs land on two plateaus 4 % apart.  So a large
+// workspace allocates a few candidates for V, times the launches of real steps at three basis sizes on each
+// (zeros in, zeros out) and keeps the fastest (search policy: tune_placement below); only for a basis of at
+// least KS_PLACE_MIN_MB (1024) MB; KS_PLACE_TRIALS=1 disables.
+template <class D> double placement_trio_ms(ks_workspace* w, hipEvent_t a, hipEvent_t b) {
+  ks_ctx* c = w->ctx;
+  const int jmax = std::min(w->maxdim, 40);
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {  // rep 0 warms up
+    KS_HIP(hipEventRecord(a, c->stream));
+    for (int j = jmax; j >= 1 && j > jmax - 20; j -= 6) {  // the launches of real steps at a few basis sizes
+      D* col = static_cast<D*>(w->col(j));
+      launch_dots<D>(w, j, col, 1, nullptr);
+      launch_axpy_dots<D>(w, std::min(j, kFusedMaxJ), col, 0);
+      const int64_t ppb = (w->ld / 2) / std::max(1, w->nb);
+      if (sizeof(D) == 8 && ppb >= 3072)
+        ksd::k_axpy<D, 8><<<w->nb, kBlock, 0, c->stream>>>(static_cast<const D*>(w->V), w->ld, j, col, static_cast<const D*>(w->coef), w->partial2, 1, nullptr);
+      else
+        ksd::k_axpy<D, 4><<<w->nb, kBlock, 0, c->stream>>>(static_cast<const D*>(w->V), w->ld, j, col, static_cast<const D*>(w->coef), w->partial2, 1, nullptr);
+    }
+    KS_HIP(hipEventRecord(b, c->stream));
+    KS_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    KS_HIP(hipEventElapsedTime(&ms, a, b));
+    if (rep > 0) best = std::min(best, ms);
+  }
+  return best;
+}
+
+// Search policy (round 2: opt-in, bounded and exception-safe).  KS_PLACE_TRIALS=N (N >= 2) times N candidate
+// allocations of V and keeps the fastest; it HOLDS its candidates while it runs (a freed block would simply be handed
+// out again), at most KS_PLACE_MAX_X (default 2) times the basis size and only while half of the free memory stays
+// untouched, within KS_PLACE_BUDGET_MS.  Default KS_PLACE_TRIALS=1: no search.  Candidates live in an RAII holder:
+// whatever happens, every loser is freed and w->V / w->Vbase name the kept allocation.
+struct PlacementCandidates {
+  ks_workspace* w;
+  std::vector<void*> cand;
+  size_t keep = 0;
+  int failed = 0;  // allocations that were refused (reported through ks_workspace_placement)
+  explicit PlacementCandidates(ks_workspace* ws) : w(ws), cand{ws->V} {}
+  ~PlacementCandidates() {
+    for (size_t k = 0; k < cand.size(); ++k)
+      if (k != keep) (void)hipFree(cand[k]);
+    w->V = cand[keep];
+    w->Vbase = w->V;
+  }
+};
+
+template <class D> void tune_placement(ks_workspace* w, size_t vbytes) {
+  // OFF by default (round 2).  The gain of round 1 (+3 % on the streaming kernels) came from ONE kind of candidate, a
+  // physically contiguous allocation (hipDeviceMallocContiguous, now behind KS_PLACE_CONTIGUOUS=1) -- and in such memory
+  // the SpMV, which re-reads every x element seven times and lives on L2 hits, runs 2.3x SLOWER (42 -> 96 us): the
+  // solver as a whole loses (669 vs 677 iterations/s, profiles/r02_placement_ab.txt).  Plain candidates are
+  // indistinguishable from each other on the boxes measured.  KS_PLACE_TRIALS >= 2 opts in.
+  static const int trials = env_int("KS_PLACE_TRIALS", 1);
+  // measured: +3 % at 3.3 GB, +1.5 % at 1.6 GB, nothing at 0.8 GB, -2 % at 0.4 GB (there the calibration, which
+  // revisits the same columns, sees the memory-side cache more than the placement)
+  static const int min_mb = env_int("KS_PLACE_MIN_MB", 1024);
+  static const int budget_ms = env_int("KS_PLACE_BUDGET_MS", 1500);
+  static const int max_x = std::max(2, env_int("KS_PLACE_MAX_X", 2));  // total footprint of held candidates / basis size
+  static const int debug = env_int("KS_PLACE_DEBUG", 0);
+  if (trials <= 1 || vbytes < ((size_t)min_mb << 20) || w->guard) return;
+  ks_ctx* c = w->ctx;
+  struct Events {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  } ev;
+  KS_HIP(hipEventCreate(&ev.a));
+  KS_HIP(hipEventCreate(&ev.b));
+  PlacementCandidates pc(w);
+  double best_ms = 1e30, worst_ms = 0.0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (size_t k = 0;; ++k) {
+    w->V = pc.cand[k];
+    const double ms = placement_trio_ms<D>(w, ev.a, ev.b);
+    if (debug) std::fprintf(stderr, "[ks] placement candidate %zu @%p: %.3f ms\n", k, pc.cand[k], ms);
+    if (ms < best_ms) { best_ms = ms; pc.keep = k; }
+    worst_ms = std::max(worst_ms, ms);
+    const double spent = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if ((int)pc.cand.size() >= trials || spent > budget_ms) break;
+    if ((int)pc.cand.size() + 1 > max_x) break;                      // footprint cap: held candidates <= max_x * V
+    if (pc.cand.size() >= 4 && best_ms <= 0.955 * worst_ms) break;   // a candidate from the fast cluster was found
+    size_t free_b = 0, total_b = 0;
+    KS_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (free_b / 2 < vbytes) { pc.failed++; break; }                 // never take more than half of what is left
+    void* p = nullptr;
+    static const int try_contig = env_int("KS_PLACE_CONTIGUOUS", 0);
+    if (try_contig && pc.cand.size() == 1 && hipExtMallocWithFlags(&p, vbytes, hipDeviceMallocContiguous) != hipSuccess) {
+      (void)hipGetLastError();
+      pc.failed++;
+      p = nullptr;
+    }
+    if (!p && hipMalloc(&p, vbytes) != hipSuccess) { (void)hipGetLastError(); pc.failed++; break; }
+    pc.cand.push_back(p);  // owned by the holder from here on
+    KS_HIP(hipMemsetAsync(p, 0, vbytes, c->stream));
+  }
+  w->place_candidates = (int)pc.cand.size();
+  w->place_failed = pc.failed;
+  w->place_best_ms = best_ms;
+  w->place_worst_ms = worst_ms;
+  if (debug) std::fprintf(stderr, "[ks] placement: kept candidate %zu of %zu (%.3f ms, slowest %.3f ms, %d refused)\n", pc.keep, pc.cand.size(), best_ms, worst_ms, pc.failed);
+  // ~PlacementCandidates frees the losers and points w->V at the kept one; the calibration wrote (zeros) into the
+  // scratch of the reductions only, V is still all zero
+}
+}  // namespace
+
