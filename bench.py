@@ -240,7 +240,8 @@ def main():
         def cycle(timed):
             k = state["k"]
             # one cycle of _partialschur's loop (src/run.jl:272-365) the way ks_partialschur runs it: expansion + restart
-            # in one library call, the restart's Schur factorisation overlapped with the tail of the expansion
+            # in one library call (with the explicit second pass, KS_PASSES=3, the restart's Schur factorisation overlaps the
+            # tail of the expansion; with the default two-pass expansion H is final only when the batch ends)
             # (KS_BENCH_SPLIT_CYCLE=1: the two calls ks_iterate_arnoldi + ks_restart of rounds 1-2, bit-identical results)
             t0 = time.perf_counter()
             if split_cycle:

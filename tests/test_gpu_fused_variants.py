@@ -307,14 +307,18 @@ def test_out_of_place_update_mode_is_bit_identical(dtype, monkeypatch):
     assert res["1"][0]["reorth"] < 6
 
 
+@pytest.mark.parametrize("passes", ["3", "2"])
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("kind", ["csr", "host_callback"])
-def test_early_restart_handover_is_bit_identical(dtype, kind, monkeypatch):
+def test_early_restart_handover_is_bit_identical(dtype, kind, passes, monkeypatch):
     """the part of the restart's host step that does not need H[maxdim+1, maxdim] (Schur form, Ritz values, unit
     residuals, ordering: src/run.jl:278-289) runs while the device finishes the last expansion step (KS_EARLY_RESTART=1,
     default).  It performs the same operations on the same numbers as the sequential order: every output of a whole solve
     -- eigenvalues, Q, R, restart count, products -- must be BIT-identical, with device operators (one batch per
     expansion) and with host callbacks (one batch per step)."""
+    # (ADVICE r2: the early hand-over exists on the explicit-second-pass path only -- passes = 3 is where this test is not
+    # vacuous; with the default two-pass expansion the switches must simply change nothing)
+    monkeypatch.setenv("KS_PASSES", passes)
     A, n = _operator(dtype, (12, 13, 14))
     v1 = _start(dtype, n, seed=33)
     which = "LM" if np.dtype(dtype).kind == "c" else "SR"
@@ -335,9 +339,12 @@ def test_early_restart_handover_is_bit_identical(dtype, kind, monkeypatch):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
 
 
-def test_early_restart_handover_with_breakdown_in_last_step(monkeypatch):
+@pytest.mark.parametrize("passes", ["3", "2"])
+def test_early_restart_handover_with_breakdown_in_last_step(passes, monkeypatch):
     """An operator whose Krylov space is exhausted exactly at maxdim: the LAST step of the expansion breaks down (known only
-    after the final reduction), the early part of the restart has already run on H and must be withdrawn."""
+    after the final reduction), the early part of the restart has already run on H and must be withdrawn (passes = 3: the
+    path that hands H over early; passes = 2: nothing to withdraw, same results)."""
+    monkeypatch.setenv("KS_PASSES", passes)
     n, m = 4000, 12
     # block-diagonal operator: an m x m block acting on the first m coordinates, identity elsewhere; start vector
     # supported on the first m coordinates -> invariant subspace of dimension m
