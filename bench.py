@@ -176,6 +176,20 @@ def main():
     red_dev = "cpu" if same_device else "cuda"
     dist = None
     force_dist = os.environ.get("KS_FORCE_DIST") == "1"  # run the sharded code path on a single rank (debugging)
+    if world > 1:
+        # last line of defence for N > 1: whatever hangs OUTSIDE the per-pass watchdogs (the rendezvous itself, a vote, the
+        # teardown), rank 0 still prints a line -- value null, the reason -- and every rank leaves
+        def _global_watchdog():
+            limit = float(os.environ.get("KS_BENCH_GLOBAL_DEADLINE_S", "1500"))
+            time.sleep(limit)
+            if rank == 0:
+                print(json.dumps({"metric": "arnoldi_iters_per_sec", "value": None, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
+                                  "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                                  "dtype": "f64", "data": "synthetic", "config": {"workload": f"laplace3d-7pt {args.grid}^3"},
+                                  "error": f"bench.py did not finish within {limit:.0f} s (hung rendezvous or teardown?)"}), flush=True)
+            os._exit(3)
+
+        threading.Thread(target=_global_watchdog, daemon=True).start()
     if world > 1 or force_dist:
         import torch.distributed as dist
 
@@ -185,7 +199,8 @@ def main():
         # votes: a few CPU scalars); the DATA PATH's collectives are the library's own RCCL communicator
         # (ks_ctx_create_dist: ncclAllReduce / ncclSend / ncclRecv) or its peer-to-peer regions.  One RCCL communicator
         # in the process instead of two: torch's would be the first thing to meet a new fabric, outside every watchdog.
-        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        if os.path.isdir("/sys/class/net/lo"):  # one node: rendezvous over loopback (the container's hostname may not resolve)
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         if world > 1 and same_device:
             dist.init_process_group("gloo")
             # RCCL cannot run here: measure the peer-to-peer transport and the host-staged one (which executes the RCCL
