@@ -436,7 +436,7 @@ def main():
                                 f"rows/{world}; step = one Krylov-Schur restart cycle",
                     "metric": "arnoldi_iters_per_sec", "value": r5["state"]["steps"] / r5["elapsed"], "unit": "iters/s", "n_gpus": world,
                     "steps": r5["steps"], "warmup": r5["warmup"], "ms_per_step": 1e3 * r5["elapsed"] / max(r5["steps"], 1),
-                    "transport": tr5, "scaling": "weak (12.5e6 rows per GPU at 8 ranks)" if world > 1 else "single-gpu",
+                    "transport": tr5, "rows_per_gpu": g5 ** 3 // world,
                     "moved_GBps_per_gpu": r5["state"]["moved"] / max(r5["state"]["t_expand"], 1e-12) / 1e9 / world,
                     "moved_frac": r5["state"]["moved"] / max(r5["state"]["t_expand"], 1e-12) / 1e9 / world / HBM_PEAK_GBS,
                     "validation": r5["validation"],
