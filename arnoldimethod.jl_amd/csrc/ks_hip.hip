@@ -487,6 +487,12 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     const size_t esz = w->esz;
     const size_t vbytes = (size_t)w->ld * (maxdim + 1) * esz;
     w->vbytes = vbytes;
+    {
+      // basis small enough for the 256 MiB memory-side cache: cacheable loads keep it there between kernels (ld_v,
+      // ks_kernels.hpp: +2...4 % on BASELINE configs 2-4); KS_V_NT=0/1 forces, KS_V_NT_MB moves the threshold
+      const int nt_env = env_int("KS_V_NT", -1);
+      w->v_nt = nt_env >= 0 ? nt_env != 0 : vbytes > ((size_t)env_int("KS_V_NT_MB", 352) << 20);
+    }
     if (env_int("KS_GUARD", 0)) {  // debugging: 1 MiB of 0xA5 on both sides of V, verified by ks_workspace_check_guard
       w->guard = (size_t)1 << 20;
       KS_HIP(hipMalloc(&w->Vbase, vbytes + 2 * w->guard));

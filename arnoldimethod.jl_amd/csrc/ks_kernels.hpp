@@ -94,6 +94,16 @@ __device__ __forceinline__ cd ld_pack_nt(const cd* p) {
   const double* q = reinterpret_cast<const double*>(p);
   return cd{__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1)};
 }
+// Loads of the basis V.  NT = true (default): streaming -- the basis does not fit any cache, every line is used once per
+// kernel (+5 % on pure reads, tools/streambench.hip).  NT = false: the basis FITS the 256 MiB memory-side cache (BASELINE
+// configs 2-4: 168-328 MB), cacheable loads let it stay there from kernel to kernel: k_dots 34.3 -> 31.9 us, projection
+// 29.0 -> 26.8, rotation 57 -> 49 at n = 1e6 (config 3 +3.8 %, config 2 +2.2 %); at 413 MB it is a wash and beyond that
+// a loss (n = 2.7e6: -9 %, headline -10 %).  Chosen per workspace from its size (ks_workspace::v_nt).
+template <bool NT, class T> __device__ __forceinline__ typename Pack<T>::type ld_v(const T* p) {
+  if constexpr (NT) return ld_pack_nt(p);
+  else return ld_pack(p);
+}
+
 __device__ __forceinline__ void st_pack_nt(double* p, double2 v) {
   __builtin_nontemporal_store(v.x, p);
   __builtin_nontemporal_store(v.y, p + 1);
@@ -864,7 +874,7 @@ __global__ void __launch_bounds__(kBlock)
 // re-reads column j-1 (an L1/L2 hit) instead of branching so all loads of a pack issue back to back.
 // `pass` 1: first projection; 2: DGKS correction (skipped unless st->reorth).
 // ------------------------------------------------------------------------------------------------
-template <class T, int NC4, int U = 1>
+template <class T, int NC4, int U = 1, bool NT = true>
 __global__ void __launch_bounds__(kBlock)
     k_dots(const T* __restrict__ V, int64_t ldv, int j, const T* __restrict__ w, T* __restrict__ partial,
            int pnb, int norm_slot, int pass, const DevState* __restrict__ st) {
@@ -900,7 +910,7 @@ __global__ void __launch_bounds__(kBlock)
       if (c < NC - 3 || c < j) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const P v = ld_pack_nt(V + (int64_t)c * ldv + (p + (int64_t)u * kBlock) * R);
+          const P v = ld_v<NT>(V + (int64_t)c * ldv + (p + (int64_t)u * kBlock) * R);
           dot_acc(acc[c], v, wv[u]);
         }
       }
@@ -913,7 +923,7 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       if (c < NC - 3 || c < j) {
-        const P v = ld_pack_nt(V + (int64_t)c * ldv + r);
+        const P v = ld_v<NT>(V + (int64_t)c * ldv + r);
         dot_acc(acc[c], v, wv);
       }
     }
@@ -1130,7 +1140,7 @@ __device__ __forceinline__ cd scl(cd a, double s) { return cd{a.x * s, a.y * s};
 __device__ __forceinline__ double from_real(double v, double) { return v; }
 __device__ __forceinline__ cd from_real(double v, cd) { return cd{v, 0.0}; }
 
-template <class T, int NCW, int U, int WB>
+template <class T, int NCW, int U, int WB, bool NT = true>
 __global__ void __launch_bounds__(kBlock)
     k_axpy_dots_cs(const T* __restrict__ V, int64_t ldv, int j, T* __restrict__ w, const T* __restrict__ coef,
                    T* __restrict__ partial, int pnb, double* __restrict__ partial2, const DevState* __restrict__ st,
@@ -1176,7 +1186,7 @@ __global__ void __launch_bounds__(kBlock)
     for (int i = 0; i < NCW; ++i) {
       if (i < NCW - 1 || last_valid) {  // wave-uniform: only this wave's last column can be absent
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[i][u] = ld_pack_nt(colp[i] + r[u]);
+        for (int u = 0; u < U; ++u) v[i][u] = ld_v<NT>(colp[i] + r[u]);
       } else {
 #pragma unroll
         for (int u = 0; u < U; ++u) v[i][u] = zero_pack(T{});
@@ -2127,7 +2137,7 @@ __global__ void __launch_bounds__(kBlock)
 // system makes of 41 read streams next to 21 write streams (a third of the traffic is writes; the expansion kernels
 // write 3 %).
 // ------------------------------------------------------------------------------------------------
-template <int CT>
+template <int CT, bool NT = true>
 __global__ void __launch_bounds__(kBlock)
     k_rotate_fma(double* __restrict__ V, int64_t ldv, int c, int r, const double* __restrict__ Qd, int ldq, int out0, int extra_out) {
   static_assert(CT % 4 == 0, "CT must be a multiple of four");
@@ -2146,7 +2156,7 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
     for (int k = 0; k < CT; ++k) {
       const int k2 = k < c ? k : c - 1;  // (coefficient zero: value irrelevant, the load is an L1 / L2 hit)
-      in[k] = ld_pack_nt(V + (int64_t)k2 * ldv + row);
+      in[k] = ld_v<NT>(V + (int64_t)k2 * ldv + row);
     }
     for (int n = 0; n < r; ++n) {
       const double* qn = qs + n * CT;

@@ -17,6 +17,7 @@ struct ks_workspace {
   void* V = nullptr;        // device, ld x (maxdim+1)
   void* Vbase = nullptr;    // what hipFree gets: == V, or V - guard when KS_GUARD=1 put canary zones around the basis
   size_t guard = 0, vbytes = 0;
+  bool v_nt = true;             // streaming (non-temporal) loads of V; false when the basis fits the memory-side cache (ld_v, ks_kernels.hpp)
   int place_failed = 0;         // candidate allocations the search was refused
   int place_candidates = 0;     // placement search of ks_workspace_create: candidates timed, fastest / slowest calibration time
   double place_best_ms = 0.0, place_worst_ms = 0.0;
@@ -160,7 +161,7 @@ template <class K> int resident_blocks(ks_ctx* ctx, K kernel, size_t smem, int& 
 // register file; the update kernels on the other hand gain 8 % from 8 packs per lane.)
 template <class D, int NC4> int dots_blocks(ks_workspace* ws) {
   static int cache = -1;
-  return resident_blocks(ws->ctx, ksd::k_dots<D, NC4, 1>, 0, cache);
+  return resident_blocks(ws->ctx, ksd::k_dots<D, NC4, 1, true>, 0, cache);
 }
 
 template <class D> int dots_blocks_for(ks_workspace* ws, int nc4) {
@@ -181,7 +182,8 @@ template <class D> int dots_blocks_for(ks_workspace* ws, int nc4) {
 template <class D, int NC4>
 void launch_dots_nc(ks_workspace* ws, int nb, const D* V, int jc, const D* w, D* partial, int norm_slot, int pass,
                     const DevState* st) {
-  ksd::k_dots<D, NC4, 1><<<nb, kBlock, 0, ws->ctx->stream>>>(V, ws->ld, jc, w, partial, ws->pnb, norm_slot, pass, st);
+  if (ws->v_nt) ksd::k_dots<D, NC4, 1, true><<<nb, kBlock, 0, ws->ctx->stream>>>(V, ws->ld, jc, w, partial, ws->pnb, norm_slot, pass, st);
+  else ksd::k_dots<D, NC4, 1, false><<<nb, kBlock, 0, ws->ctx->stream>>>(V, ws->ld, jc, w, partial, ws->pnb, norm_slot, pass, st);
 }
 
 // partial[b][0..j) = V[:,0:j)^H w (block-local), partial[b][j] = |w|^2 (block-local); returns the
@@ -246,11 +248,21 @@ constexpr int kFusedMaxJ = 64;
 template <class D, int NCW, int U, int WB> int launch_axpy_dots_nc(ks_workspace* ws, int j, D* w, int defer, D* wdst = nullptr) {
   static int cache = -1;
   static const int plain = env_int("KS_FUSED_PLAIN_STORE", 0);
-  const int nb = cap_blocks(ws, resident_blocks(ws->ctx, ksd::k_axpy_dots_cs<D, NCW, U, WB>, 0, cache), 64 * U);
-  ksd::k_axpy_dots_cs<D, NCW, U, WB><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const D*>(ws->V), ws->ld, j, w,
-                                                                       static_cast<const D*>(ws->coef),
-                                                                       static_cast<D*>(ws->partial), ws->pnb, ws->partial2,
-                                                                       ws->st, defer, wdst, plain && ws->passes == 2);
+  const int nb = cap_blocks(ws, resident_blocks(ws->ctx, ksd::k_axpy_dots_cs<D, NCW, U, WB, true>, 0, cache), 64 * U);
+  // (cacheable loads of V only exist for the shallow-staging family: a basis that fits the memory-side cache has small columns)
+  if constexpr (WB <= 8) {
+    if (!ws->v_nt) {
+      ksd::k_axpy_dots_cs<D, NCW, U, WB, false><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const D*>(ws->V), ws->ld, j, w,
+                                                                                  static_cast<const D*>(ws->coef),
+                                                                                  static_cast<D*>(ws->partial), ws->pnb, ws->partial2,
+                                                                                  ws->st, defer, wdst, plain && ws->passes == 2);
+      return nb;
+    }
+  }
+  ksd::k_axpy_dots_cs<D, NCW, U, WB, true><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const D*>(ws->V), ws->ld, j, w,
+                                                                             static_cast<const D*>(ws->coef),
+                                                                             static_cast<D*>(ws->partial), ws->pnb, ws->partial2,
+                                                                             ws->st, defer, wdst, plain && ws->passes == 2);
   return nb;
 }
 // Write-back staging depth WB of the projection kernel.  The kernel writes ONE column next to the j+1 it reads, and that
@@ -804,13 +816,15 @@ template <class D> void rotate_device(ks_workspace* ws, int c0, int c, int r, in
         const size_t smem = (size_t)r * CT * 8;
         static int occ = -1;
         if (occ < 0) {
-          KS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ksd::k_rotate_fma<CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+          KS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ksd::k_rotate_fma<CT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+          KS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ksd::k_rotate_fma<CT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
           int o = 0;
-          KS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, ksd::k_rotate_fma<CT>, kBlock, (size_t)48 * CT * 8));
+          KS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, ksd::k_rotate_fma<CT, true>, kBlock, (size_t)48 * CT * 8));
           occ = std::max(1, std::min(o, bpc_env));
         }
         const int nbr = cap_blocks(ws, ctx->num_cu * occ, kBlock);
-        ksd::k_rotate_fma<CT><<<nbr, kBlock, smem, s>>>(Vc, ws->ld, c, r, Qd, c, out0, extra_out);
+        if (ws->v_nt) ksd::k_rotate_fma<CT, true><<<nbr, kBlock, smem, s>>>(Vc, ws->ld, c, r, Qd, c, out0, extra_out);
+        else ksd::k_rotate_fma<CT, false><<<nbr, kBlock, smem, s>>>(Vc, ws->ld, c, r, Qd, c, out0, extra_out);
       };
       KS_REQUIRE((size_t)r * 64 * 8 <= (size_t)64 * 1024, KS_ERR_INTERNAL, "rotation wider than the coefficient tile");
       if (c <= 24) go(std::integral_constant<int, 24>{});
