@@ -686,6 +686,20 @@ def test_row_partitioned_solver_several_ranks_one_gpu(nproc, mode):
     assert r.stdout.count("-> OK") == nproc and "same: True" in r.stdout, r.stdout[-3000:]
 
 
+@pytest.mark.parametrize("nproc,mode,transport,fused", [(2, "halo", "p2p", "1"), (4, "halo", "p2p", "1"), (3, "halohashed", "p2p", "1"),
+                                                        (4, "halohashed", "p2p", "1"), (3, "halo", "p2p", "0"), (2, "halohashed", "host", "1")])
+def test_ghost_exchange_stress_with_real_ranks(nproc, mode, transport, fused):
+    """The ghost exchange alone, 200 rounds of chains of 1-4 back-to-back products with fresh vectors, every result against
+    the whole matrix on the host (tools/dist_gpu_check.py halo / halohashed).  Round 3 folded the exchange into the SpMV
+    launch (stencil and CSR kernels; KS_HALO_FUSED=0: push kernel in front): the first workgroups push, only boundary
+    workgroups wait, ghosts are read without an acquire fence -- a stale or early-read entry would be an O(1) error (one was
+    caught this way during development).  Slab Laplacian (contiguous planes, stencil layout) and hashed matrix (every rank
+    neighbours every other, CSR layout)."""
+    r = _run_ranks(nproc, mode, m=20, extra_env={"KS_TRANSPORT": transport, "KS_HALO_FUSED": fused})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("-> OK") == nproc and "bad rounds 0" in r.stdout, r.stdout[-3000:]
+
+
 @pytest.mark.parametrize("nproc,mode,transport", [(2, "laplace", "p2p"), (3, "complex", "p2p"), (2, "laplace", "host"), (3, "hashed", "host")])
 def test_explicit_second_pass_path_with_real_ranks(nproc, mode, transport):
     """KS_PASSES=3 (second projection applied to the vector; two exchanges per step, pending norm folded into the next

@@ -23,6 +23,11 @@ MODE
            run of the whole problem, Arnoldi relation and orthogonality evaluated on the device for both.
   timeout  rank 1 never joins; rank 0 must get CommTimeout (KS_ERR_COMM) after KS_P2P_TIMEOUT_S
            seconds instead of hanging.
+  halo / halohashed
+           stress of the ghost exchange alone (round 3: folded into the SpMV launch in peer-to-peer mode): 200 rounds of
+           CHAINS of 1-4 back-to-back products y = A^c x on the slab Laplacian / the hashed matrix, fresh x every round, no
+           host synchronisation inside a chain (consecutive exchanges alternate the ghost slots), every result compared
+           with the same chain on the whole matrix on the host.  A stale or early-read ghost entry is an O(1) error.
 """
 import os
 import sys
@@ -132,6 +137,43 @@ def main():
 
     if mode == "shard5":
         sys.exit(shard5(rank, world, ctx, m))
+
+    if mode in ("halo", "halohashed"):
+        if mode == "halo":
+            mx, my, mz = m, m + 1, m + 2 * world
+            n = mx * my * mz
+            offs = ksd.partition_rows(n, world, granule=mx * my)
+            A = sp.csr_matrix(ks.matrices.laplace3d_csr(mx, my, mz, 0, n, index_dtype=np.int64)[::-1], shape=(n, n))
+        else:
+            n = m * m * m
+            A = (ks.matrices.hashed_nonsymmetric_csr(n, seed=11) + sp.diags(np.linspace(1.0, 40.0, n))).tocsr()
+            A.sort_indices()
+            offs = ksd.partition_rows(n, world)
+        r0, r1 = int(offs[rank]), int(offs[rank + 1])
+        B = A[r0:r1]
+        plan = ksd.build_halo_plan(B.indices.astype(np.int64), offs, rank, dist)
+        op = ksd.dist_operator(api, ctx, B.indptr.astype(np.int64), B.data, plan, n)
+        ws = api.ArnoldiWorkspace(r1 - r0, 5, np.float64, ctx=ctx, n_global=n, row_begin=r0)
+        worst, bad = 0.0, 0
+        for it in range(200):
+            x = ks.matrices.uniform_hash(1000 + it, np.arange(n)) - 0.5
+            chain = 1 + it % 4
+            ws.set_col(0, x[r0:r1])
+            for c in range(chain):  # columns 0 -> 1 -> 2 -> ...: no host synchronisation in between
+                _lib.check(_lib.load().ks_apply(op._h, ws._h, c, c + 1))
+            y = x
+            for c in range(chain):
+                y = A @ y
+            got = ws.col(chain)
+            err = float(np.abs(got - y[r0:r1]).max() / max(1e-300, np.abs(y).max()))
+            worst = max(worst, err)
+            bad += err > 1e-12
+        ok = bad == 0
+        print(f"[rank {rank}] {mode}: 200 chains of 1-4 products, rows {r0}:{r1}, neighbours={len(plan.neigh)}, layout={op.format['layout']}, "
+              f"worst relative error {worst:.1e}, bad rounds {bad} -> {'OK' if ok else 'FAIL'}", flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(0 if ok else 1)
 
     if mode == "laplace":
         mx, my, mz = m, m + 1, m + 2 * world
