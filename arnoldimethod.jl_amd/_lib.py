@@ -132,6 +132,7 @@ PROTOTYPES = {
     "ks_host_restart_step": [i32, vp, i32, vp, i32, i32, i32, i32, i32, dbl, i32, P(C.c_int), P(C.c_int), P(C.c_int), vp, vp, vp],
     "ks_host_sortschur": [i32, vp, i32, i32, i32, vp, i32, i32, i32, i32],
     "ks_host_givens": [i32, vp, vp, P(dbl), vp, vp],
+    "ks_last_words": [C.c_char_p, i32],
 }
 
 _lib = None

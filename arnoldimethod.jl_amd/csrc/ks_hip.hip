@@ -7,6 +7,9 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <signal.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -1184,6 +1187,47 @@ int ks_host_sortschur(int dtype, void* H, int m, int n, int ldh, void* Q, int nq
       ks::Mat<T> Hm(static_cast<T*>(H), m, n, ldh), Qm(static_cast<T*>(Q), nq, nq, ldq);
       ks::sortschur(Hm, Qm, nconv, ks::Ordering{which});
     });
+  });
+}
+
+// ---- last words (include/kschur.h, diagnostics) -----------------------------------------------------------------------
+namespace {
+char* g_last_words = nullptr;           // owned; replaced, never freed while a handler may run
+volatile size_t g_last_words_len = 0;
+volatile int g_last_words_exit = 0;
+void last_words_handler(int) {
+  // async-signal-safe only: write(2) and _exit(2)
+  if (g_last_words && g_last_words_len) {
+    ssize_t r = ::write(1, "\n", 1);
+    r = ::write(1, g_last_words, g_last_words_len);
+    r = ::write(1, "\n", 1);
+    (void)r;
+  }
+  ::_exit(g_last_words_exit);
+}
+}  // namespace
+
+int ks_last_words(const char* line, int exit_code) {
+  return guarded([&] {
+    static const int sigs[] = {SIGSEGV, SIGBUS, SIGABRT, SIGFPE, SIGILL, SIGTERM};
+    if (!line) {
+      for (int sg : sigs) ::signal(sg, SIG_DFL);
+      g_last_words_len = 0;
+      return;
+    }
+    const size_t n = std::strlen(line);
+    char* copy = static_cast<char*>(std::malloc(n + 1));
+    KS_REQUIRE(copy != nullptr, KS_ERR_INTERNAL, "out of memory");
+    std::memcpy(copy, line, n + 1);
+    g_last_words_len = 0;       // (a signal between these stores prints nothing rather than a torn line)
+    g_last_words = copy;        // the previous copy is leaked on purpose: a handler may be reading it
+    g_last_words_exit = exit_code;
+    g_last_words_len = n;
+    struct sigaction sa;
+    std::memset(&sa, 0, sizeof sa);
+    sa.sa_handler = last_words_handler;
+    sigemptyset(&sa.sa_mask);
+    for (int sg : sigs) ::sigaction(sg, &sa, nullptr);
   });
 }
 

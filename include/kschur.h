@@ -365,6 +365,14 @@ int ks_host_sortschur(int dtype, void* H, int m, int n, int ldh, void* Q, int nq
 /* givensAlgorithm (Julia stdlib LinearAlgebra = LAPACK dlartg/zlartg); out: c, s(re,im), r(re,im) */
 int ks_host_givens(int dtype, const double* f, const double* g, double* c, double* s, double* r);
 
+/* ---- diagnostics ---------------------------------------------------------------------------- */
+/* Last words.  A measuring harness (bench.py with N > 1: a transport meets a new fabric for the first time) hands over the
+ * text it wants on standard output should the process die under it -- SIGSEGV / SIGBUS / SIGABRT / SIGFPE / SIGILL (a
+ * memory fault reported by the GPU runtime aborts the process) or SIGTERM (the launcher tearing the ranks down after a peer
+ * died): the handler writes "\n<line>\n" to file descriptor 1 with write(2) and leaves with _exit(exit_code); nothing else
+ * runs.  line == NULL uninstalls.  The text is copied.  No reference equivalent. */
+int ks_last_words(const char* line, int exit_code);
+
 #ifdef __cplusplus
 }
 #endif

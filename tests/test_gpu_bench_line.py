@@ -81,3 +81,12 @@ def test_line_survives_a_hung_transport():
 def test_line_appears_even_when_nothing_survives():
     r, d = _bench({"KS_BENCH_TRANSPORTS": "p2p", "KS_BENCH_INJECT_FAIL": "p2p"})
     assert r.returncode != 0 and d["value"] is None and "error" in d["transports"]["p2p"]
+
+
+def test_line_survives_a_rank_that_dies_the_hard_way():
+    """First contact of a transport with a new fabric can end in a memory fault, and the GPU runtime then ABORTS the process:
+    no exception, no watchdog.  Rank 1 aborts inside the second pass; the launcher tears rank 0 down with SIGTERM; the line
+    built from the pass that had completed is what the library writes on rank 0's way out (ks_last_words)."""
+    r, d = _bench({"KS_BENCH_TRANSPORTS": "host,p2p", "KS_BENCH_INJECT_FAIL": "p2p:crash"})
+    assert d["died_during"] == "p2p" and "value" in d["transports"]["host"], d
+    assert d["value"] == d["transports"]["host"]["value"] and d["value"] > 0 and d["config"]["transport"] == "host"
