@@ -86,6 +86,8 @@ PROTOTYPES = {
     "ks_operator_dense": [vp, i64, vp, i64, i32, i32, P(vp)],
     "ks_operator_host_callback": [vp, i64, i32, HOST_APPLY_FN, vp, P(vp)],
     "ks_operator_device_callback": [vp, i64, i32, DEVICE_APPLY_FN, vp, P(vp)],
+    "ks_operator_lu": [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, P(vp)],
+    "ks_operator_lu_info": [vp, P(i64), P(i64), P(i64), P(i64)],
     "ks_operator_destroy": [vp],
     "ks_operator_size": [vp, P(i64), P(i64), P(C.c_int)],
     "ks_operator_format": [vp, P(C.c_double), P(C.c_int), P(C.c_int)],

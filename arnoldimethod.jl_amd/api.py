@@ -274,6 +274,54 @@ def csr_operator(A, ctx: Context | None = None) -> Operator:
     return Operator(ctx, h, tuple(shp), dt)
 
 
+def lu_operator(L, U, perm_in=None, perm_out=None, scale=None, ctx: Context | None = None) -> Operator:
+    """y = P_out U^-1 L^-1 P_in (scale o x) with both sparse triangular solves on the device (`ks_operator_lu`): the
+    `ldiv!(y, F, x)` of the LinearMap a user of the reference wraps around a host factorisation
+    (docs/src/index.md:246-249).  `L`, `U`: scipy.sparse triangular factors (any format; converted to CSR here),
+    `perm_in[i]` = the entry of x that becomes row i of the triangular system, `perm_out[i]` = the entry of y that
+    receives solution entry i.  See `splu_operator` for the SuperLU convention."""
+    import scipy.sparse as sp
+
+    ctx = ctx or default_context()
+    lib = _lib.load()
+    n = L.shape[0]
+    if L.shape != (n, n) or U.shape != (n, n):
+        raise DimensionMismatch(f"factors are not square of one size: {L.shape}, {U.shape}")
+    dt = np.dtype(np.complex128 if (L.dtype.kind == "c" or U.dtype.kind == "c") else np.float64)
+    arrs = []
+    for M in (L, U):
+        M = sp.csr_matrix(M)
+        M.sort_indices()
+        arrs += [np.ascontiguousarray(M.indptr, dtype=np.int64), np.ascontiguousarray(M.indices, dtype=np.int32),
+                 np.ascontiguousarray(M.data, dtype=dt)]
+    pin = None if perm_in is None else np.ascontiguousarray(perm_in, dtype=np.int32)
+    pout = None if perm_out is None else np.ascontiguousarray(perm_out, dtype=np.int32)
+    sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float64)
+    for a, name in ((pin, "perm_in"), (pout, "perm_out"), (sc, "scale")):
+        if a is not None and a.shape != (n,):
+            raise DimensionMismatch(f"{name} must have {n} entries")
+    ptr = lambda a: None if a is None or a.size == 0 else a.ctypes.data  # noqa: E731
+    h = C.c_void_p()
+    check(lib.ks_operator_lu(ctx._h, n, _dtype_code(dt), arrs[0].ctypes.data, ptr(arrs[1]), ptr(arrs[2]), arrs[3].ctypes.data,
+                             ptr(arrs[4]), ptr(arrs[5]), ptr(pin), ptr(pout), ptr(sc), C.byref(h)))
+    op = Operator(ctx, h, (n, n), dt)
+    v = [C.c_int64() for _ in range(4)]
+    check(lib.ks_operator_lu_info(h, *[C.byref(x) for x in v]))
+    op.lu_info = dict(nnz_l=v[0].value, nnz_u=v[1].value, levels_l=v[2].value, levels_u=v[3].value)
+    return op
+
+
+def splu_operator(lu, ctx: Context | None = None) -> Operator:
+    """The device operator x -> A^-1 x from a `scipy.sparse.linalg.splu` factorisation (`Pr A Pc = L U`:
+    z[perm_r] = x, L U w = z, y = w[perm_c])."""
+    n = lu.shape[0]
+    inv_r = np.empty(n, dtype=np.int32)
+    inv_r[lu.perm_r] = np.arange(n, dtype=np.int32)
+    inv_c = np.empty(n, dtype=np.int32)
+    inv_c[lu.perm_c] = np.arange(n, dtype=np.int32)
+    return lu_operator(lu.L, lu.U, perm_in=inv_r, perm_out=inv_c, ctx=ctx)
+
+
 def host_operator(fn, n: int, dtype=np.float64, ctx: Context | None = None) -> Operator:
     """Opaque host operator: `fn(y, x)` fills y = A*x on numpy views (a LinearMap wrapping ldiv!,
     docs/src/index.md:246-249).  Columns are staged over PCIe by the library."""

@@ -7,7 +7,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "ks_hip.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("ks_kernels.hpp", "ks_p2p.hpp", "ks_driver.hpp", "ks_smalldense.hpp", "ks_context.hpp", "ks_operators.hpp", "ks_workspace.hpp", "ks_backend.hpp")] + [
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("ks_kernels.hpp", "ks_p2p.hpp", "ks_driver.hpp", "ks_smalldense.hpp", "ks_context.hpp", "ks_operators.hpp", "ks_sptrsv.hpp", "ks_workspace.hpp", "ks_backend.hpp")] + [
     os.path.join(HERE, "..", "include", "kschur.h")
 ]
 OUT = os.path.join(HERE, "libkschur_hip.so")

@@ -121,6 +121,17 @@ struct ks_ctx {
     double* stage = nullptr;  // pinned
     size_t stage_doubles = 0;
   } hc;
+  // device-reported failure of an operator kernel (ks_sptrsv.hpp: a bounded spin gave up); pinned + mapped, made on demand
+  int* operr_h = nullptr;
+  int* operr_dev() {
+    if (!operr_h) {
+      KS_HIP(hipHostMalloc(&operr_h, sizeof(int), hipHostMallocMapped));
+      *operr_h = 0;
+    }
+    int* d = nullptr;
+    KS_HIP(hipHostGetDevicePointer((void**)&d, operr_h, 0));
+    return d;
+  }
   int num_cu = 256;
   int bpc = 6;  // streaming workgroups per CU (KS_BPC; 6 measured best on MI355X, tools/streambench.hip)
   int nblocks() const { return num_cu * bpc; }
@@ -151,6 +162,8 @@ struct ks_ctx {
   }
   // a bounded spin of the peer-to-peer kernels gave up: report instead of computing on garbage
   void check_comm() const {
+    if (operr_h && *operr_h != 0)
+      throw KsError{KS_ERR_OPERATOR, "sparse triangular solve gave up waiting for a solution entry (KS_LU_TIMEOUT_S): malformed factor or a stalled device"};
     if (p2p.err_h && *p2p.err_h != 0)
       throw KsError{KS_ERR_COMM, "peer-to-peer exchange timed out waiting for a peer (first reported by rank " +
                                      std::to_string(*p2p.err_h - 1) + ")"};

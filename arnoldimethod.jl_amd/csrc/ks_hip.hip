@@ -33,6 +33,7 @@ using ksd::kBlock;
 
 #include "ks_context.hpp"    // errors, ks_ctx, transports
 #include "ks_operators.hpp"  // ks_operator and its layouts
+#include "ks_sptrsv.hpp"     // shift-invert operator from triangular factors (sparse triangular solves)
 #include "ks_workspace.hpp"  // ks_workspace, launch helpers, expansion, rotations
 #include "ks_backend.hpp"    // HipBackend, residual checks, placement search
 
@@ -155,6 +156,7 @@ int ks_ctx_destroy(ks_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
     if (ctx->hc.stage) (void)hipHostFree(ctx->hc.stage);
+    if (ctx->operr_h) (void)hipHostFree(ctx->operr_h);
     p2p_release(ctx);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -401,6 +403,36 @@ int ks_operator_device_callback(ks_ctx* ctx, int64_t n_local, int dtype, ks_devi
     auto op = std::make_unique<DeviceCallbackOp>();
     op->ctx = ctx; op->n_local = n_local; op->dtype = dtype; op->fn = apply; op->user = user;
     *out = op.release();
+  });
+}
+
+int ks_operator_lu(ks_ctx* ctx, int64_t n, int dtype, const int64_t* l_rowptr, const int32_t* l_colind, const void* l_val,
+                   const int64_t* u_rowptr, const int32_t* u_colind, const void* u_val, const int32_t* perm_in,
+                   const int32_t* perm_out, const double* scale, ks_operator** out) {
+  return guarded([&] {
+    KS_REQUIRE(ctx && out && l_rowptr && u_rowptr, KS_ERR_ARGUMENT, "null argument");
+    KS_REQUIRE(dtype == KS_F64 || dtype == KS_C64, KS_ERR_ARGUMENT, "unknown dtype");
+    KS_REQUIRE(n >= 1 && n < (int64_t)2147483647, KS_ERR_ARGUMENT, "ks_operator_lu: n must be in [1, 2^31)");
+    KS_REQUIRE(!ctx->distributed(), KS_ERR_ARGUMENT, "ks_operator_lu: single-GPU contexts only (a triangular solve does not shard by rows)");
+    KS_REQUIRE((l_rowptr[n] == 0 || (l_colind && l_val)) && u_colind && u_val, KS_ERR_ARGUMENT, "null factor arrays");
+    ctx->use();
+    *out = dtype == KS_F64 ? make_lu<double>(ctx, n, l_rowptr, l_colind, l_val, u_rowptr, u_colind, u_val, perm_in, perm_out, scale)
+                           : make_lu<cd>(ctx, n, l_rowptr, l_colind, l_val, u_rowptr, u_colind, u_val, perm_in, perm_out, scale);
+  });
+}
+
+int ks_operator_lu_info(const ks_operator* op, int64_t* nnz_l, int64_t* nnz_u, int64_t* levels_l, int64_t* levels_u) {
+  return guarded([&] {
+    KS_REQUIRE(op, KS_ERR_ARGUMENT, "null operator");
+    auto fill = [&](auto* lu) {
+      if (nnz_l) *nnz_l = lu->L.nnz;
+      if (nnz_u) *nnz_u = lu->U.nnz;
+      if (levels_l) *levels_l = lu->L.levels;
+      if (levels_u) *levels_u = lu->U.levels;
+    };
+    if (auto* a = dynamic_cast<const LuOp<double>*>(op)) fill(a);
+    else if (auto* b = dynamic_cast<const LuOp<cd>*>(op)) fill(b);
+    else throw KsError{KS_ERR_ARGUMENT, "ks_operator_lu_info: not an operator made by ks_operator_lu"};
   });
 }
 

@@ -1,0 +1,558 @@
+// Shift-invert operator from caller-supplied triangular factors:  y = P_out U^-1 L^-1 P_in (s o x)  with both sparse
+// triangular solves on the device.  This is what a user of the reference wraps as
+//     LinearMap{ComplexF64}((y, x) -> ldiv!(y, F, x), n; ismutating = true),   F = lu(A - sigma I)      docs/src/index.md:246-249
+// and hands to partialschur as the operator `A` of mul!(y, A, x) (src/expansion.jl:121).  The factorisation stays the
+// caller's (SuiteSparse / SuperLU on the host, exactly as in the reference); only its APPLICATION is on the hot path
+// (once per Arnoldi step), and here it never leaves HBM.
+// Part of the ONE translation unit of libkschur_hip.so (included by ks_hip.hip after ks_operators.hpp).
+//
+// Algorithm: synchronisation-free sparse triangular solve in CSR row form.  One wavefront per row; the lanes hold the
+// row's off-diagonal entries and wait for the solution entries they need to appear, then the wave reduces and publishes
+// the row's entry.  No launch per dependency level: ONE launch per triangular factor.
+//   * Rows are RENUMBERED on the host by dependency level (stable: ties keep the elimination order).  Any topological
+//     order keeps a triangular factor triangular; this one puts everything that can run concurrently next to each other
+//     (the window of rows in flight is then full of independent rows -- in elimination order the backward solve walks
+//     the elimination tree depth-first and the window holds one dependent path: measured 5x slower than the forward
+//     solve) and it puts a chain of single-row levels -- the dense triangle of a separator -- on consecutive rows.
+//     Both factors become LOWER triangular in their own numbering; the permutations between the caller's x, the two
+//     numberings and the caller's y are folded into three index arrays.
+//   * Solution entries are published as "LL" words -- 32 bits of payload + the 32-bit sequence number of this solve in
+//     one 8-byte atomic store -- so a reader that sees the sequence number has the data (no flag + fence pair, nothing
+//     to reset between solves).  Float64: 2 words per entry, ComplexF64: 4.
+//   * Rows are handed out through a ticket counter in that order (one workgroup = 16 consecutive rows, one per wave),
+//     so every row a resident wave waits for belongs to a workgroup that already runs or has finished: forward progress
+//     does not depend on the dispatch order of workgroups.
+//   * Every wait is bounded by a wall-clock budget (KS_LU_TIMEOUT_S, default 20 s): reports KS_ERR_OPERATOR at the next
+//     synchronisation point of the context instead of hanging the device (the host rejects malformed factors up front;
+//     this guards what it cannot see, e.g. a device that is shared with a process that starves the producers).
+// The product is bound by the LENGTH OF THE DEPENDENCY CHAIN (levels x hand-over latency), not by bytes;
+// ks_operator_lu_info reports it so a caller can judge an ordering (fill-reducing with a short elimination tree).
+#pragma once
+
+namespace ksd {
+
+struct TrsvArgs {
+  int64_t row0, n;         // this launch solves rows [row0, n) (everything before is complete: earlier launch)
+  const int64_t* rowptr;   // strictly lower triangular part in the factor's own (level) numbering, CSR, columns ascending
+  const int32_t* colind;
+  const void* val;
+  const void* diag;        // n INVERSE diagonal entries; nullptr: unit diagonal
+  uint64_t* sol;           // LL words of this factor's solution (W per row)
+  const void* rhs;         // first solve: x;  second solve: nullptr
+  const uint64_t* rhs_ll;  // second solve: the first solve's LL words (complete: previous launch)
+  const int32_t* src;      // row i takes rhs[src[i]] (first) / rhs_ll[src[i]] (second)
+  const double* scale;     // first solve: ... times scale[i] (already in row order; nullptr: none)
+  void* out;               // second solve: y[dst[i]] = entry i
+  const int32_t* dst;
+  int* ticket;             // this launch's control words: [0] row counter, [2] owning XCD + 1 (zeroed by the host side before the product)
+  int* err;                // pinned host word
+  long long timeout_ticks;
+  uint32_t seq;
+  int backoff;             // nap between two polls of the awaited entry, in units of 128 clocks
+  int nap_lds;             // nap between two polls of an LDS flag, in units of 64 clocks
+  unsigned long long* stats;  // KS_LU_STATS=1: [0] ticks in ticket + barriers [1] rows [2] ticks of rows [3] ticks at the gate [4] ticks on LDS only
+                              // [5] gate polls [6] attempts [7] cached hits [8] cached misses [9] coherent tries (per lane)
+};
+
+template <class D> struct LLWords { static constexpr int W = (int)(sizeof(D) / 4); };
+
+// LOCAL (3, 4): every producer and consumer of the launch runs on ONE XCD (see k_sptrsv).  Measured, 216x250 grid / 500x1000
+// grid, ms per product: all XCDs 2.7 / 13.5 (and 15-40 once more than ~64 workgroups wait: every poll crosses the fabric);
+// one XCD 3.1 / -- with device-scope stores (4); 2.2 / 13.9 with stores that stop at that XCD's L2 (3, the default: the
+// workgroup-scope bits, sc0) and device-scope loads.  Loads with the workgroup-scope bits never see another CU's store
+// (they are served by the CU's own cache, which neither snoops nor is dropped by `buffer_inv sc0`): the solve stalls until
+// its time budget ends.  Whatever a load returns, a word carrying the current sequence number is valid data.
+template <int LOCAL> __device__ __forceinline__ uint64_t ll_word(const uint64_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class D, int LOCAL> __device__ __forceinline__ void ll_put(uint64_t* p, D v, uint32_t seq) {
+  constexpr int W = LLWords<D>::W;
+  uint32_t w[W];
+  __builtin_memcpy(w, &v, sizeof(D));
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    const uint64_t word = ((uint64_t)seq << 32) | w[k];
+    if (LOCAL == 3) __hip_atomic_store(p + k, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(p + k, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// CACHED: an ordinary load that may be served by this CU's / this XCD's caches.  A word that carries the current
+// sequence number is valid wherever it was found (payload and number are one 8-byte store); a stale line just reads as
+// "not there yet" and the caller asks again with the coherent form.
+template <class D, int LOCAL, bool CACHED = false> __device__ __forceinline__ bool ll_get(const uint64_t* p, D& v, uint32_t seq) {
+  constexpr int W = LLWords<D>::W;
+  uint64_t u[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) u[k] = CACHED ? __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : ll_word<LOCAL>(p + k);
+  bool ok = true;
+  uint32_t w[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    ok = ok && (uint32_t)(u[k] >> 32) == seq;
+    w[k] = (uint32_t)u[k];
+  }
+  if (ok) __builtin_memcpy(&v, w, sizeof(D));
+  return ok;
+}
+// payload of words known to be complete (written by an earlier launch)
+template <class D> __device__ __forceinline__ D ll_payload(const uint64_t* p) {
+  constexpr int W = LLWords<D>::W;
+  uint32_t w[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) w[k] = (uint32_t)p[k];
+  D v;
+  __builtin_memcpy(&v, w, sizeof(D));
+  return v;
+}
+
+__device__ __forceinline__ bool trsv_expired(int* err, long long t0, long long budget, long spins) {
+  if ((spins & 255) != 255) return false;
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return true;
+  if (wall_clock64() - t0 > budget) {
+    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return true;
+  }
+  return false;
+}
+
+// Forward substitution on a factor in level numbering.  A workgroup of C waves takes C consecutive rows per ticket, ONE
+// ROW PER WAVE: every row in flight has fetched its entries and consumed every solution entry that already exists, and
+// sits waiting for the first missing one -- so the time along a dependency chain is hand-over latency only, not the
+// row's start-up (offsets -> columns -> solution words are three dependent memory round trips).
+//   * entries produced by the SAME workgroup travel through LDS (value + flag: ~0.2 us per hand-over): consecutive
+//     single-row levels (the dense triangle of a separator) are where a factor's chain is longest;
+//   * entries of earlier chunks come from the LL words in memory: first through the caches (entries finished long ago
+//     -- nearly all of a long row), then coherently.  A waiting wave polls ONE entry -- the latest missing dependency
+//     of its current batch -- with W lanes, and only when that has arrived do its lanes fetch theirs again: thousands
+//     of waiting waves cost a few loads per microsecond each instead of 64 x W (which saturates the fabric and slows
+//     the producers: measured 25 us per level).
+constexpr int kTrsvWaves = 16, kTrsvUnroll = 4;
+
+// LOCAL: the launch is 8x oversubscribed and only the workgroups that landed on ONE XCD work -- the XCD of whichever
+// workgroup asks first (an election, not "XCD 0": in a partitioned device there is one XCD and it need not be number 0);
+// the others leave at once.  Tickets make it irrelevant which workgroups those are.
+__device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf); }  // HW_REG_XCC_ID[3:0]
+
+// wave64 sum without LDS traffic: four DPP steps inside each row of 16 lanes, then the four row sums through scalar
+// registers (the butterfly of ks_kernels.hpp's wave_sum is 12 ds_bpermute per double: ~0.5 us, too slow for a chain)
+template <int CTRL> __device__ __forceinline__ double dpp_perm(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_value(double v, int l) {  // l uniform
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ cd lane_value(cd v, int l) { return cd{lane_value(v.x, l), lane_value(v.y, l)}; }
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_perm<0xB1>(v);   // quad_perm(1,0,3,2)
+  v += dpp_perm<0x4E>(v);   // quad_perm(2,3,0,1)
+  v += dpp_perm<0x141>(v);  // row_half_mirror
+  v += dpp_perm<0x140>(v);  // row_mirror
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+__device__ __forceinline__ cd wave_sum_dpp(cd v) { return cd{wave_sum_dpp(v.x), wave_sum_dpp(v.y)}; }
+
+template <class D, int LOCAL>
+__global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
+  constexpr int W = LLWords<D>::W, C = kTrsvWaves, U = kTrsvUnroll;
+  __shared__ D xs[C];
+  __shared__ int ready[C];
+  __shared__ int s_ticket;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const D* __restrict__ val = static_cast<const D*>(a.val);
+  const D* __restrict__ dinv = static_cast<const D*>(a.diag);
+  if (LOCAL) {
+    if (threadIdx.x == 0) {
+      const int mine = xcc_id() + 1;
+      const int seen = atomicCAS(a.ticket + 2, 0, mine);  // [2]: owner of this launch (0: none yet)
+      s_ticket = (seen == 0 || seen == mine) ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_ticket == 0) return;
+  }
+  unsigned long long st_ticket = 0, st_rows = 0, st_row = 0, st_gate = 0, st_near = 0, st_polls = 0, st_att = 0, st_hit = 0, st_miss = 0, st_coh = 0;
+  for (;;) {
+    const long long tk0 = a.stats ? wall_clock64() : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = atomicAdd(a.ticket, 1);
+    if (threadIdx.x < C) ready[threadIdx.x] = 0;
+    __syncthreads();
+    const long long tk1 = a.stats ? wall_clock64() : 0;
+    st_ticket += (unsigned long long)(tk1 - tk0);
+    const int64_t base = a.row0 + (int64_t)s_ticket * C;
+    if (base >= a.n) break;
+    const int64_t r = base + wave;
+    if (r >= a.n) continue;
+    const int64_t p0 = a.rowptr[r], p1 = a.rowptr[r + 1];
+    // Entries produced by THIS workgroup: the last m of the row (columns ascend).  Lane l < 16 looks at entry p1-1-l;
+    // they are consumed one by one at the end, in column order, by the whole wave in step (no reduction on the chain).
+    int li_reg = -1;
+    D av_reg = zero_of(D{});
+    if (lane < C && p1 - 1 - lane >= p0) {
+      const int32_t c = a.colind[p1 - 1 - lane];
+      if (c >= base) { li_reg = (int)(c - base); av_reg = val[p1 - 1 - lane]; }
+    }
+    const int m = __popcll(__ballot(li_reg >= 0));
+    const int64_t pf = p1 - m;  // entries of earlier chunks: [p0, pf)
+    // right-hand side and inverse pivot: fetched now, needed last (same address in every lane: one transaction)
+    D b;
+    {
+      const int64_t s = a.src[r];
+      if (a.rhs) {
+        b = static_cast<const D*>(a.rhs)[s];
+        if (a.scale) b = scl(b, a.scale[r]);
+      } else {
+        b = ll_payload<D>(a.rhs_ll + (size_t)s * W);
+      }
+    }
+    const D piv = dinv ? dinv[r] : zero_of(D{});
+    D acc = zero_of(D{});
+    const long long t0 = wall_clock64();
+    long spins = 0;
+    bool dead = false;
+    for (int64_t q0 = p0; q0 < pf && !dead; q0 += 64 * U) {
+      int32_t c[U];
+      D av[U], xv[U];
+      bool need[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t p = q0 + u * 64 + lane;
+        need[u] = p < pf;
+        c[u] = need[u] ? a.colind[p] : 0;
+        av[u] = need[u] ? val[p] : zero_of(D{});
+        xv[u] = zero_of(D{});
+      }
+      // first attempt: through the caches
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (need[u]) {
+          if (ll_get<D, LOCAL, true>(a.sol + (size_t)c[u] * W, xv[u], a.seq)) { need[u] = false; ++st_hit; }
+          else ++st_miss;
+        }
+      for (;;) {
+        // one coherent attempt at everything still missing; `far` = this lane's latest missing entry
+        int far = -1;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (!need[u]) continue;
+          if (++st_coh, ll_get<D, LOCAL>(a.sol + (size_t)c[u] * W, xv[u], a.seq)) need[u] = false;
+          else far = c[u] > far ? c[u] : far;
+        }
+        int gate = far;  // latest missing entry of the wave
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(gate, off, 64); gate = o > gate ? o : gate; }
+        ++st_att;
+        if (gate < 0) break;  // batch complete
+        const long long tg0 = a.stats ? wall_clock64() : 0;
+        const uint64_t* g = a.sol + (size_t)gate * W;
+        for (;;) {
+          bool ok = true;
+            if (lane < W) ok = (uint32_t)(ll_word<LOCAL>(g + lane) >> 32) == a.seq;
+          ++st_polls;
+          if (__all(ok)) break;
+          for (int q = 0; q < a.backoff; ++q) __builtin_amdgcn_s_sleep(2);
+          if (trsv_expired(a.err, t0, a.timeout_ticks, spins++)) { dead = true; break; }
+        }
+        st_gate += a.stats ? (unsigned long long)(wall_clock64() - tg0) : 0;
+        if (dead) break;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc = fma_(av[u], xv[u], acc);
+    }
+    acc = wave_sum_dpp(acc);
+    // the chain: entries of this chunk, oldest first, every lane in step
+    const long long tn0 = a.stats ? wall_clock64() : 0;
+    for (int k = m - 1; k >= 0 && !dead; --k) {
+      const int li = __builtin_amdgcn_readlane(li_reg, k);
+      const D av = lane_value(av_reg, k);
+      while (__hip_atomic_load(&ready[li], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+        for (int q = 0; q < a.nap_lds; ++q) __builtin_amdgcn_s_sleep(1);  // the producer shares this CU's issue slots
+        if (trsv_expired(a.err, t0, a.timeout_ticks, spins++)) { dead = true; break; }
+      }
+      acc = fma_(av, xs[li], acc);
+    }
+    st_near += a.stats ? (unsigned long long)(wall_clock64() - tn0) : 0;
+    D x = sub_(b, acc);
+    if (dinv) x = mul_(x, piv);
+    if (lane == 0) {
+      xs[wave] = x;
+      __hip_atomic_store(&ready[wave], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      ll_put<D, LOCAL>(a.sol + (size_t)r * W, x, a.seq);
+      if (a.out) static_cast<D*>(a.out)[a.dst[r]] = x;
+    }
+    if (a.stats) { ++st_rows; st_row += (unsigned long long)(wall_clock64() - tk1); }
+  }
+  if (a.stats) {
+    unsigned long long v[3] = {st_hit, st_miss, st_coh};  // per-lane counters -> wave totals
+    for (int k = 0; k < 3; ++k)
+      for (int off = 32; off >= 1; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+    if (lane == 0) {
+      const unsigned long long w[10] = {st_ticket, st_rows, st_row, st_gate, st_near, st_polls, st_att, v[0], v[1], v[2]};
+      for (int k = 0; k < 10; ++k) atomicAdd(a.stats + k, w[k]);
+      if (wave == 0) { atomicOr(a.stats + 10, 1ull << xcc_id()); atomicAdd(a.stats + 11, 1ull); }
+    }
+  }
+}
+
+}  // namespace ksd
+
+namespace {
+
+inline double from_real_host(double v, double) { return v; }
+inline ksd::cd from_real_host(double v, ksd::cd) { return ksd::cd{v, 0.0}; }
+inline double inverse_host(double v) { return 1.0 / v; }
+inline ksd::cd inverse_host(ksd::cd v) {
+  const std::complex<double> r = 1.0 / std::complex<double>(v.x, v.y);
+  return ksd::cd{r.real(), r.imag()};
+}
+inline bool is_zero_host(double v) { return v == 0.0; }
+inline bool is_zero_host(ksd::cd v) { return v.x == 0.0 && v.y == 0.0; }
+
+template <class D> struct TriFactor {
+  int64_t nnz = 0;       // strictly triangular entries
+  int64_t levels = 0;    // length of the longest dependency chain
+  std::vector<int32_t> order, pos;  // host: level numbering -> caller's row, and back
+  int64_t* rowptr = nullptr;
+  int32_t* colind = nullptr;
+  D* val = nullptr;
+  D* diag = nullptr;     // inverse diagonal entries; nullptr: unit diagonal
+  uint64_t* sol = nullptr;
+  void release() {
+    (void)hipFree(rowptr); (void)hipFree(colind); (void)hipFree(val); (void)hipFree(diag); (void)hipFree(sol);
+  }
+};
+
+// Split a triangular CSR factor into its strict part and its diagonal (checking the triangle), renumber rows and columns
+// by dependency level, upload.
+template <class D>
+void upload_factor(TriFactor<D>& f, int64_t n, const int64_t* rp, const int32_t* ci, const D* vv, bool lower, const char* name) {
+  std::vector<int64_t> srp((size_t)n + 1, 0);
+  std::vector<int32_t> sci;
+  std::vector<D> sv, dg((size_t)n, D{});
+  std::vector<char> has((size_t)n, 0);
+  sci.reserve((size_t)rp[n]);
+  sv.reserve((size_t)rp[n]);
+  bool any_diag = false;
+  for (int64_t r = 0; r < n; ++r) {
+    KS_REQUIRE(rp[r + 1] >= rp[r], KS_ERR_ARGUMENT, std::string(name) + ": row offsets must not decrease");
+    for (int64_t p = rp[r]; p < rp[r + 1]; ++p) {
+      const int64_t c = ci[p];
+      KS_REQUIRE(c >= 0 && c < n, KS_ERR_ARGUMENT, std::string(name) + ": column index out of range");
+      if (c == r) {
+        KS_REQUIRE(!has[r], KS_ERR_ARGUMENT, std::string(name) + ": duplicate diagonal entry");
+        has[r] = 1;
+        dg[r] = vv[p];
+        any_diag = true;
+        continue;
+      }
+      KS_REQUIRE(lower ? c < r : c > r, KS_ERR_ARGUMENT, std::string(name) + (lower ? ": entry above the diagonal of the lower factor" : ": entry below the diagonal of the upper factor"));
+      sci.push_back((int32_t)c);
+      sv.push_back(vv[p]);
+    }
+    srp[r + 1] = (int64_t)sci.size();
+  }
+  const bool with_diag = any_diag || !lower;
+  if (with_diag) {
+    for (int64_t r = 0; r < n; ++r) {
+      if (!has[r]) {
+        KS_REQUIRE(lower, KS_ERR_ARGUMENT, std::string(name) + ": the upper factor needs every diagonal entry");
+        dg[r] = from_real_host(1.0, D{});
+      }
+      KS_REQUIRE(!is_zero_host(dg[r]), KS_ERR_ARGUMENT, std::string(name) + ": zero on the diagonal (singular factor)");
+    }
+  }
+  // dependency levels in elimination order (ascending rows for L, descending for U), then a stable counting sort
+  std::vector<int32_t> lev((size_t)n, 0);
+  int64_t top = 0;
+  for (int64_t t = 0; t < n; ++t) {
+    const int64_t r = lower ? t : n - 1 - t;
+    int32_t l = 0;
+    for (int64_t p = srp[r]; p < srp[r + 1]; ++p) l = std::max(l, lev[sci[p]] + 1);
+    lev[r] = l;
+    top = std::max<int64_t>(top, l + 1);
+  }
+  f.levels = n > 0 ? top : 0;
+  std::vector<int64_t> start((size_t)top + 1, 0);
+  for (int64_t r = 0; r < n; ++r) start[lev[r] + 1]++;
+  for (int64_t l = 0; l < top; ++l) start[l + 1] += start[l];
+  f.order.assign((size_t)n, 0);
+  f.pos.assign((size_t)n, 0);
+  for (int64_t t = 0; t < n; ++t) {
+    const int64_t r = lower ? t : n - 1 - t;
+    const int64_t i = start[lev[r]]++;
+    f.order[i] = (int32_t)r;
+    f.pos[r] = (int32_t)i;
+  }
+  // the factor in its own numbering: row i = caller's row order[i], columns pos[c], ascending
+  std::vector<int64_t> nrp((size_t)n + 1, 0);
+  std::vector<int32_t> nci(sci.size());
+  std::vector<D> nv(sv.size()), ndg;
+  std::vector<std::pair<int32_t, int64_t>> tmp;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t r = f.order[i];
+    tmp.clear();
+    for (int64_t p = srp[r]; p < srp[r + 1]; ++p) tmp.emplace_back(f.pos[sci[p]], p);
+    std::sort(tmp.begin(), tmp.end());
+    int64_t q = nrp[i];
+    for (auto& e : tmp) {
+      nci[q] = e.first;
+      nv[q] = sv[e.second];
+      ++q;
+    }
+    nrp[i + 1] = q;
+  }
+  if (with_diag) {
+    ndg.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) ndg[i] = inverse_host(dg[f.order[i]]);  // the chain multiplies (a division is ~100 cycles per hand-over)
+  }
+  f.nnz = (int64_t)nci.size();
+  KS_HIP(hipMalloc(&f.rowptr, ((size_t)n + 1) * 8));
+  KS_HIP(hipMalloc(&f.colind, std::max<size_t>(nci.size(), 1) * 4));
+  KS_HIP(hipMalloc(&f.val, std::max<size_t>(nv.size(), 1) * sizeof(D)));
+  KS_HIP(hipMemcpy(f.rowptr, nrp.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice));
+  if (!nci.empty()) {
+    KS_HIP(hipMemcpy(f.colind, nci.data(), nci.size() * 4, hipMemcpyHostToDevice));
+    KS_HIP(hipMemcpy(f.val, nv.data(), nv.size() * sizeof(D), hipMemcpyHostToDevice));
+  }
+  if (with_diag) {
+    KS_HIP(hipMalloc(&f.diag, (size_t)n * sizeof(D)));
+    KS_HIP(hipMemcpy(f.diag, ndg.data(), (size_t)n * sizeof(D), hipMemcpyHostToDevice));
+  }
+  const size_t words = (size_t)n * ksd::LLWords<D>::W;
+  KS_HIP(hipMalloc(&f.sol, std::max<size_t>(words, 1) * 8));
+  KS_HIP(hipMemset(f.sol, 0, std::max<size_t>(words, 1) * 8));  // sequence number 0 is never used by a solve
+}
+
+template <class D> struct LuOp : ks_operator {
+  TriFactor<D> L, U;
+  int32_t* src_l = nullptr;  // row i of L's numbering takes x[src_l[i]]
+  double* scale_l = nullptr; //   ... times scale_l[i]
+  int32_t* src_u = nullptr;  // row i of U's numbering takes entry src_u[i] of L's solution
+  int32_t* dst_u = nullptr;  //   ... and its result goes to y[dst_u[i]]
+  int* tickets = nullptr;    // 4 control words per launch, 4 launches
+  int local = 3;             // form of the tail launch (KS_LU_XCD): 3 = one XCD, stores to its L2; 4 = one XCD, stores through; 0 = all XCDs
+  int* err_d = nullptr;      // the context's pinned error word (checked at every synchronisation point of the context)
+  uint32_t seq = 0;
+  int grid = 0, backoff = 2, nap_lds = 1;
+  long long timeout_ticks = 0;
+  unsigned long long* stats = nullptr;  // KS_LU_STATS=1
+  ~LuOp() override {
+    L.release(); U.release();
+    (void)hipFree(src_l); (void)hipFree(scale_l); (void)hipFree(src_u); (void)hipFree(dst_u); (void)hipFree(tickets);
+    (void)hipFree(stats);
+  }
+  // One launch per factor.  (Two were tried -- the wide levels on every XCD, the narrow tail on one: the all-XCD part
+  // collapses as soon as more than ~64 workgroups wait on entries through the fabric, 15-65 ms instead of 2.2 / 14.)
+  void solve(ksd::TrsvArgs a, int* words) {
+    a.row0 = 0; a.n = n_local; a.ticket = words;
+    const int g = (int)std::max<int64_t>(1, std::min<int64_t>((n_local + ksd::kTrsvWaves - 1) / ksd::kTrsvWaves, grid));
+    switch (local) {
+      case 3: ksd::k_sptrsv<D, 3><<<g * 8, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a); break;
+      case 4: ksd::k_sptrsv<D, 4><<<g * 8, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a); break;
+      default: ksd::k_sptrsv<D, 0><<<g, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a);
+    }
+    KS_HIP(hipGetLastError());
+  }
+  void apply(const void* x, void* y, const DevState*) override {
+    ctx->check_comm();  // (of earlier products: the word is written by the device)
+    ProfScope ps(ctx, KSP_SPMV, (double)(L.nnz + U.nnz) * (sizeof(D) + 4.0 + 8.0 * ksd::LLWords<D>::W) + (double)n_local * (4.0 * sizeof(D) + 2.0 * 8.0 + 3.0 * 4.0 + 3.0 * 8.0 * ksd::LLWords<D>::W));
+    const size_t sol_bytes = (size_t)n_local * ksd::LLWords<D>::W * 8;
+    if (++seq == 0) {  // 2^32 solves: start the sequence numbers over
+      KS_HIP(hipMemsetAsync(L.sol, 0, sol_bytes, ctx->stream));
+      KS_HIP(hipMemsetAsync(U.sol, 0, sol_bytes, ctx->stream));
+      seq = 1;
+    }
+    ksd::TrsvArgs a{};
+    a.n = n_local;
+    a.err = err_d;
+    a.timeout_ticks = timeout_ticks;
+    a.seq = seq;
+    a.backoff = backoff;
+    a.nap_lds = nap_lds;
+    a.stats = stats;
+    if (stats) KS_HIP(hipMemsetAsync(stats, 0, 24 * 8, ctx->stream));
+    // L z = P_in (s o x)
+    a.rowptr = L.rowptr; a.colind = L.colind; a.val = L.val; a.diag = L.diag; a.sol = L.sol;
+    a.rhs = x; a.src = src_l; a.scale = scale_l;
+    KS_HIP(hipMemsetAsync(tickets, 0, 16 * sizeof(int), ctx->stream));
+    solve(a, tickets);
+    // U w = z;  y[perm_out] = w
+    a.rowptr = U.rowptr; a.colind = U.colind; a.val = U.val; a.diag = U.diag; a.sol = U.sol;
+    a.rhs = nullptr; a.rhs_ll = L.sol; a.src = src_u; a.scale = nullptr;
+    a.out = y; a.dst = dst_u;
+    if (stats) a.stats = stats + 12;
+    solve(a, tickets + 8);
+    if (stats) {
+      unsigned long long h[24];
+      KS_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+      KS_HIP(hipStreamSynchronize(ctx->stream));
+      for (int f = 0; f < 2; ++f) {
+        const unsigned long long* q = h + 12 * f;
+        const double rows = (double)std::max<unsigned long long>(q[1], 1);
+        std::fprintf(stderr, "[lu %s] per row: ticket %.2f us, row %.2f us (gate %.2f, lds-only %.2f); gate polls %.1f, attempts %.1f; entries per row: cached hit %.1f miss %.1f, coherent tries %.1f; %llu workgroups on XCDs 0x%llx\n",
+                     f == 0 ? "L" : "U", 0.01 * q[0] / rows, 0.01 * q[2] / rows, 0.01 * q[3] / rows, 0.01 * q[4] / rows, q[5] / rows, q[6] / rows, q[7] / rows, q[8] / rows, q[9] / rows, q[11], q[10]);
+      }
+    }
+  }
+};
+
+template <class D>
+ks_operator* make_lu(ks_ctx* ctx, int64_t n, const int64_t* lrp, const int32_t* lci, const void* lv, const int64_t* urp,
+                     const int32_t* uci, const void* uv, const int32_t* pin, const int32_t* pout, const double* sc) {
+  auto op = std::make_unique<LuOp<D>>();
+  op->ctx = ctx;
+  op->n_local = n;
+  op->dtype = sizeof(D) == 8 ? KS_F64 : KS_C64;
+  for (const int32_t* p : {pin, pout}) {
+    if (!p) continue;
+    std::vector<char> seen((size_t)n, 0);
+    for (int64_t i = 0; i < n; ++i) {
+      KS_REQUIRE(p[i] >= 0 && p[i] < n && !seen[p[i]], KS_ERR_ARGUMENT, std::string("ks_operator_lu: ") + (p == pin ? "perm_in" : "perm_out") + " is not a permutation of 0..n-1");
+      seen[p[i]] = 1;
+    }
+  }
+  upload_factor<D>(op->L, n, lrp, lci, static_cast<const D*>(lv), true, "ks_operator_lu: L");
+  upload_factor<D>(op->U, n, urp, uci, static_cast<const D*>(uv), false, "ks_operator_lu: U");
+  op->nnz = op->L.nnz + op->U.nnz + n;
+  // index arrays between the caller's vectors and the two level numberings
+  std::vector<int32_t> sl((size_t)n), su((size_t)n), du((size_t)n);
+  std::vector<double> scl;
+  if (sc) scl.resize((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    const int32_t rl = op->L.order[i];  // row of the triangular system
+    sl[i] = pin ? pin[rl] : rl;
+    if (sc) scl[i] = sc[sl[i]];
+    const int32_t ru = op->U.order[i];
+    su[i] = op->L.pos[ru];
+    du[i] = pout ? pout[ru] : ru;
+  }
+  auto up = [&](const void* h, size_t bytes, void** d) {
+    KS_HIP(hipMalloc(d, std::max<size_t>(bytes, 8)));
+    KS_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+  };
+  up(sl.data(), (size_t)n * 4, (void**)&op->src_l);
+  up(su.data(), (size_t)n * 4, (void**)&op->src_u);
+  up(du.data(), (size_t)n * 4, (void**)&op->dst_u);
+  if (sc) up(scl.data(), (size_t)n * 8, (void**)&op->scale_l);
+  std::vector<int32_t>().swap(op->L.order); std::vector<int32_t>().swap(op->L.pos);
+  std::vector<int32_t>().swap(op->U.order); std::vector<int32_t>().swap(op->U.pos);
+  KS_HIP(hipMalloc(&op->tickets, 16 * sizeof(int)));
+  KS_HIP(hipMemset(op->tickets, 0, 16 * sizeof(int)));
+  op->err_d = ctx->operr_dev();
+  // two 1024-thread workgroups per CU of one XCD (launched 8x over, KS_LU_XCD=3/4) or 64 workgroups anywhere (=0: fewer
+  // waiting waves are faster there, each polls through the fabric)
+  op->local = env_int("KS_LU_XCD", 3);
+  op->grid = std::max(1, env_int("KS_LU_GRID", op->local ? std::max(1, ctx->num_cu / 8) * 2 : 64));
+  op->backoff = std::max(0, env_int("KS_LU_BACKOFF", 2));  // nap between two polls of a missing entry, x 128 clocks
+  op->nap_lds = std::max(0, env_int("KS_LU_NAP_LDS", 1));
+  op->timeout_ticks = (long long)env_int("KS_LU_TIMEOUT_S", 20) * 100000000LL;
+  if (env_int("KS_LU_STATS", 0)) {
+    KS_HIP(hipMalloc(&op->stats, 24 * 8));
+    KS_HIP(hipMemset(op->stats, 0, 24 * 8));
+  }
+  return op.release();
+}
+
+}  // namespace

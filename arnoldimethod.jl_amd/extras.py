@@ -7,6 +7,10 @@ vector resident in HBM instead of crossing PCIe twice per product.
     TridiagonalShiftInvert(dl, d, du, sigma)   y = (T - sigma I)^{-1} x  with rocSPARSE's pivoting tridiagonal solver
                                                (rocsparse_[dz]gtsv), on the library's stream.  torch is only plumbing
                                                (device buffers for the three diagonals and the solver's work space).
+    sparse_shift_invert(A, sigma)              y = (A - sigma I)^{-1} x for a general sparse A: SuperLU factorisation on
+                                               the host (scipy), both triangular solves of every product on the device
+                                               through the LIBRARY's own operator `ks_operator_lu` (hand-written
+                                               synchronisation-free solve, csrc/ks_sptrsv.hpp) -- no vendor call, no torch.
 """
 from __future__ import annotations
 
@@ -83,3 +87,26 @@ class TridiagonalShiftInvert:
             self.close()
         except Exception:
             pass
+
+
+def sparse_shift_invert(A, sigma=0.0, ctx: api.Context | None = None, symmetric_pattern: bool | None = None, **splu_kw) -> api.Operator:
+    """`api.Operator` for y = (A - sigma I)^{-1} x, A scipy.sparse.  The factorisation runs once on the host
+    (`scipy.sparse.linalg.splu`, i.e. SuperLU -- the role SuiteSparse plays behind `factorize` in
+    docs/src/index.md:246-249); its triangular factors live in HBM and are applied on the device.  The cost of a product
+    is the length of the factors' dependency chains (`operator.lu_info`), so the ordering matters: for matrices with a
+    symmetric non-zero pattern (`symmetric_pattern`, detected if None) minimum degree on A + A' with diagonal pivots gives
+    far shorter chains and less fill than SuperLU's default column ordering."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    n = A.shape[0]
+    cplx = A.dtype.kind == "c" or isinstance(sigma, complex)
+    M = (sp.csc_matrix(A, dtype=np.complex128 if cplx else np.float64) - sigma * sp.identity(n, format="csc")).tocsc()
+    if symmetric_pattern is None:
+        P = M.copy()
+        P.data[:] = 1.0
+        symmetric_pattern = (P != P.T).nnz == 0
+    if symmetric_pattern and not splu_kw:
+        splu_kw = dict(permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    lu = spla.splu(M, **splu_kw)
+    return api.splu_operator(lu, ctx)

@@ -163,6 +163,38 @@ function HipOperator(ctx::HipContext, A::Matrix{T}) where {T<:HipScalar}
     _finish_operator(T, r[], n, ctx, nothing)
 end
 
+# Shift-invert: mul!(y, A, x) with A = LinearMap((y, x) -> ldiv!(y, F, x)) around F = lu(M), M = A0 - sigma*I
+# (docs/src/index.md:246-249).  The factorisation stays SuiteSparse's, on the host; its factors go to HBM once and every
+# product is two sparse triangular solves ON THE DEVICE (ks_operator_lu) instead of a host ldiv! plus two PCIe copies.
+# UMFPACK: (F.Rs .* M)[F.p, F.q] == F.L * F.U  ->  perm_in = p-1, scale = Rs, perm_out = q-1.  The library wants CSR
+# factors: the CSC arrays of the TRANSPOSED factors are exactly that.
+function HipOperator(ctx::HipContext, F::SparseArrays.UMFPACK.UmfpackLU{Tv}) where {Tv}
+    T = Tv <: Complex ? ComplexF64 : Float64
+    Lt = SparseMatrixCSC{T,Int64}(sparse(transpose(F.L)))   # CSC of L^T == CSR of L (columns ascending)
+    Ut = SparseMatrixCSC{T,Int64}(sparse(transpose(F.U)))
+    n = size(Lt, 1)
+    lptr = Lt.colptr .- 1; lidx = Int32.(Lt.rowval .- 1)
+    uptr = Ut.colptr .- 1; uidx = Int32.(Ut.rowval .- 1)
+    pin = Int32.(F.p .- 1); pout = Int32.(F.q .- 1)
+    rs = Vector{Float64}(F.Rs)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve Lt Ut lptr lidx uptr uidx pin pout rs begin
+        check(ccall((:ks_operator_lu, LIB), Cint,
+                    (Ptr{Cvoid}, Int64, Cint, Ptr{Int64}, Ptr{Int32}, Ptr{Cvoid}, Ptr{Int64}, Ptr{Int32}, Ptr{Cvoid},
+                     Ptr{Int32}, Ptr{Int32}, Ptr{Cdouble}, Ref{Ptr{Cvoid}}),
+                    ctx.h, n, dtype_code(T), pointer(lptr), pointer(lidx), pointer(Lt.nzval), pointer(uptr), pointer(uidx),
+                    pointer(Ut.nzval), pointer(pin), pointer(pout), pointer(rs), r))
+    end
+    _finish_operator(T, r[], n, ctx, nothing)
+end
+
+"Stored entries and dependency-chain lengths of the two triangular factors of a shift-invert operator."
+function lu_info(A::HipOperator)
+    v = [Ref{Int64}(0) for _ in 1:4]
+    check(ccall((:ks_operator_lu_info, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Int64}, Ref{Int64}), A.h, v[1], v[2], v[3], v[4]))
+    (nnz_l = v[1][], nnz_u = v[2][], levels_l = v[3][], levels_u = v[4][])
+end
+
 "Device layout the library chose for a stored matrix: (bytes streamed per non-zero, dictionary size, layout code)."
 function operator_format(A::HipOperator)
     b = Ref{Cdouble}(0); d = Ref{Cint}(0); l = Ref{Cint}(0)

@@ -142,6 +142,26 @@ int ks_operator_host_callback(ks_ctx* ctx, int64_t n_local, int dtype, ks_host_a
 typedef int (*ks_device_apply_fn)(void* user, const void* x_dev, void* y_dev, void* hip_stream);
 int ks_operator_device_callback(ks_ctx* ctx, int64_t n_local, int dtype, ks_device_apply_fn apply,
                                 void* user, ks_operator** out);
+/* (iv) shift-invert from the caller's triangular factors:  y = P_out U^-1 L^-1 P_in (s o x), both sparse triangular
+ * solves on the device, every vector resident in HBM.  Replaces the host `ldiv!(y, F, x)` inside the LinearMap a user of
+ * the reference wraps around F = lu(A - sigma I) / factorize(A)  (docs/src/index.md:246-249, 273-287); the
+ * factorisation itself stays the caller's, on the host, as there.
+ *   L, U       n x n CSR, int64 row offsets, int32 0-based columns, values of `dtype`; L lower triangular (diagonal
+ *              entries optional: unit where absent), U upper triangular with every diagonal entry, both non-singular
+ *   perm_in    row i of the triangular system takes x[perm_in[i]]      (NULL: identity)
+ *   scale      ... multiplied by the real scale[perm_in[i]]            (NULL: none; UMFPACK's row scaling `Rs`)
+ *   perm_out   y[perm_out[i]] = entry i of U^-1 L^-1 (...)             (NULL: identity)
+ * SuiteSparse UMFPACK (Julia `F = lu(A)`: (Rs .* A)[p, q] = L U): perm_in = p-1, scale = Rs, perm_out = q-1, factors
+ * transposed from CSC.  SuperLU (scipy `splu`: Pr A Pc = L U): perm_in = inverse(perm_r), perm_out = inverse(perm_c).
+ * One launch per factor (synchronisation-free solve: a row's wavefront waits for the entries it needs); the cost is the
+ * length of the longest dependency chain, which ks_operator_lu_info reports next to the stored entries -- choose a
+ * fill-reducing ordering with a short elimination tree.  A wait that exceeds KS_LU_TIMEOUT_S (20) surfaces as
+ * KS_ERR_OPERATOR at the next synchronisation point of the context.  Single-GPU contexts only. */
+int ks_operator_lu(ks_ctx* ctx, int64_t n, int dtype, const int64_t* l_rowptr, const int32_t* l_colind, const void* l_val,
+                   const int64_t* u_rowptr, const int32_t* u_colind, const void* u_val, const int32_t* perm_in,
+                   const int32_t* perm_out, const double* scale, ks_operator** out);
+/* strictly triangular stored entries and dependency-chain lengths ("levels") of the two factors */
+int ks_operator_lu_info(const ks_operator* op, int64_t* nnz_l, int64_t* nnz_u, int64_t* levels_l, int64_t* levels_u);
 int ks_operator_destroy(ks_operator* op);
 int ks_operator_size(const ks_operator* op, int64_t* n_local, int64_t* nnz, int* dtype);
 /* Device layout chosen for a stored matrix at upload (mul!(y, A, x), src/expansion.jl:121; all layouts give bit-identical y):

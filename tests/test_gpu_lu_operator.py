@@ -1,0 +1,163 @@
+"""`-m gpu`: shift-invert from caller-supplied triangular factors (`ks_operator_lu`, SURVEY section 8 f4 "on-device
+shift-invert").  The reference side of this operator is the LinearMap of docs/src/index.md:246-249 --
+`(y, x) -> ldiv!(y, factorize(A - sigma I), x)` -- whose `ldiv!` runs in SuiteSparse on the host.  Here the factorisation
+still comes from the host (scipy's SuperLU stands in for SuiteSparse), the two sparse triangular solves of every product run
+on the device.  Checked against the host solve of the SAME factorisation (`lu.solve`), which is the reference's arithmetic
+up to the order of the row sums; tolerance 1e-11 relative to max|x| (well-conditioned test matrices, observed 1e-14)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from __graft_entry__ import import_package
+
+pytestmark = pytest.mark.gpu
+pkg = import_package()
+TOL = 1e-11
+
+
+def _lap2d(nx, ny):
+    ex = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(nx, nx))
+    ey = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(ny, ny))
+    return (sp.kron(sp.identity(ny), ex) + sp.kron(ey, sp.identity(nx))).tocsc()
+
+
+def _random_matrix(n, cplx, seed):
+    A = sp.random(n, n, density=min(1.0, 6.0 / n), random_state=seed, format="csc") + 4.0 * sp.identity(n)
+    if cplx:
+        A = A + 1j * sp.random(n, n, density=min(1.0, 3.0 / n), random_state=seed + 1, format="csc")
+    return A.tocsc()
+
+
+def _apply(op, b, ctx):
+    n = b.shape[0]
+    ws = pkg.ArnoldiWorkspace(n, min(4, n - 1) if n > 1 else 1, op.dtype, ctx=ctx)
+    ws.set_col(0, b.astype(op.dtype))
+    ws.apply(op, 0, 1)
+    return ws.col(1), ws
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("n", [2, 5, 63, 64, 65, 300, 5000])
+def test_product_matches_the_host_solve_of_the_same_factorisation(n, cplx):
+    """Sizes around the 64-row chunk of the kernel; column-pivoting orderings with real row interchanges (perm_r != id)."""
+    ctx = pkg.Context(0)
+    A = _random_matrix(n, cplx, seed=n)
+    lu = spla.splu(A)
+    op = pkg.splu_operator(lu, ctx)
+    rng = np.random.default_rng(n)
+    b = rng.random(n) + (1j * rng.random(n) if cplx else 0.0)
+    y, ws = _apply(op, b, ctx)
+    x = lu.solve(b.astype(op.dtype))
+    assert np.abs(y - x).max() <= TOL * np.abs(x).max()
+    info = op.lu_info
+    assert info["nnz_l"] == lu.L.nnz - n and info["nnz_u"] == lu.U.nnz - n  # strictly triangular parts
+    assert 1 <= info["levels_l"] <= n and 1 <= info["levels_u"] <= n
+    # the solves are deterministic (fixed lane -> entry assignment, fixed reduction tree): bit-identical when repeated,
+    # whatever the order in which the rows happened to complete
+    for _ in range(3):
+        ws.apply(op, 0, 1)
+        assert np.array_equal(ws.col(1), y)
+
+
+def test_chain_of_n_dependent_rows():
+    """A bidiagonal factor pair: every row waits for its predecessor (levels = n): the worst case of the dependency
+    chain, across many chunks and workgroups.  Also: L without stored diagonal (unit), identity permutations."""
+    n = 20000
+    ctx = pkg.Context(0)
+    rng = np.random.default_rng(5)
+    L = sp.diags([0.5 * rng.random(n - 1) + 0.1], [-1], shape=(n, n), format="csr")        # strictly lower: unit diagonal implied
+    U = sp.diags([1.0 + rng.random(n), 0.3 * rng.random(n - 1)], [0, 1], shape=(n, n), format="csr")
+    op = pkg.lu_operator(L, U, ctx=ctx)
+    assert op.lu_info["levels_l"] == n and op.lu_info["levels_u"] == n
+    b = rng.random(n)
+    y, _ = _apply(op, b, ctx)
+    Lfull = (L + sp.identity(n)).tocsr()
+    x = spla.spsolve_triangular(U, spla.spsolve_triangular(Lfull, b, lower=True), lower=False)
+    assert np.abs(y - x).max() <= TOL * np.abs(x).max()
+
+
+def test_umfpack_convention_row_scaling_and_permutations():
+    """Julia's `F = lu(A)` (UMFPACK): (Rs .* A)[p, q] = L U  ->  perm_in = p - 1, scale = Rs, perm_out = q - 1
+    (include/kschur.h).  Emulated: scale the rows, permute rows and columns, factor WITHOUT further pivoting."""
+    n = 400
+    ctx = pkg.Context(0)
+    rng = np.random.default_rng(11)
+    A = _random_matrix(n, True, seed=3)
+    Rs = 0.5 + rng.random(n)
+    p, q = rng.permutation(n), rng.permutation(n)
+    B = (sp.diags(Rs) @ A).tocsr()[p][:, q].tocsc()
+    B = B + 50.0 * sp.identity(n)  # keep the un-pivoted factorisation stable
+    A_eff = sp.diags(1.0 / Rs) @ _unpermute(B, p, q)
+    lu = spla.splu(B, permc_spec="NATURAL", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    assert np.array_equal(lu.perm_r, np.arange(n)) and np.array_equal(lu.perm_c, np.arange(n))
+    op = pkg.lu_operator(lu.L, lu.U, perm_in=p, perm_out=q, scale=Rs, ctx=ctx)
+    b = rng.random(n) + 1j * rng.random(n)
+    y, _ = _apply(op, b, ctx)
+    x = spla.spsolve(A_eff.tocsc(), b)
+    assert np.abs(y - x).max() <= 1e-10 * np.abs(x).max()
+
+
+def _unpermute(B, p, q):
+    n = B.shape[0]
+    ip, iq = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64)
+    ip[p], iq[q] = np.arange(n), np.arange(n)
+    return B.tocsr()[ip][:, iq]
+
+
+def test_malformed_factors_are_refused_on_the_host():
+    ctx = pkg.Context(0)
+    n = 6
+    I = sp.identity(n, format="csr")
+    up = sp.csr_matrix(([1.0], ([1], [4])), shape=(n, n))
+    lo = sp.csr_matrix(([1.0], ([4], [1])), shape=(n, n))
+    with pytest.raises(pkg.ArgumentError, match="above the diagonal"):
+        pkg.lu_operator(I + up, I, ctx=ctx)
+    with pytest.raises(pkg.ArgumentError, match="below the diagonal"):
+        pkg.lu_operator(I, I + lo, ctx=ctx)
+    with pytest.raises(pkg.ArgumentError, match="every diagonal entry|singular"):
+        pkg.lu_operator(I, up, ctx=ctx)
+    with pytest.raises(pkg.ArgumentError, match="not a permutation"):
+        pkg.lu_operator(I, I, perm_in=np.zeros(n, dtype=np.int32), ctx=ctx)
+    with pytest.raises(pkg.DimensionMismatch):
+        pkg.lu_operator(I, sp.identity(n + 1, format="csr"), ctx=ctx)
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+def test_shift_invert_solve_matches_the_host_callback(cplx):
+    """BASELINE config 4 in the flavour SURVEY section 8c names (2-D Laplacian + i*diag, sigma interior, nev 6, :LM): the
+    device operator and the host callback around the SAME factorisation give the same trail and eigenvalues, and the
+    eigenvalues sigma + 1/theta are eigenvalues of A (residual against A itself)."""
+    nx, ny = 60, 70
+    n = nx * ny
+    ctx = pkg.Context(0)
+    rng = np.random.default_rng(3)
+    A = _lap2d(nx, ny)
+    if cplx:
+        A = (A.astype(np.complex128) + 1j * sp.diags(0.3 * rng.random(n))).tocsc()
+        sigma = 1.7 + 0.1j
+    else:
+        sigma = 1.7003
+    lu = spla.splu((A - sigma * sp.identity(n)).tocsc(), permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    op = pkg.splu_operator(lu, ctx)
+    dt = op.dtype
+
+    def cb(y, x):
+        y[:] = lu.solve(x)
+
+    hop = pkg.host_operator(cb, n, dt, ctx)
+    v1 = rng.random(n).astype(dt)
+    kw = dict(nev=6, which="LM", tol=1e-10, mindim=10, maxdim=20, v1=v1)
+    dec, hist = pkg.partialschur(op, **kw)
+    dec2, hist2 = pkg.partialschur(hop, **kw)
+    assert hist.converged and hist2.converged
+    assert (hist.mvproducts, hist.nconverged) == (hist2.mvproducts, hist2.nconverged)
+    th = np.sort_complex(np.asarray(dec.eigenvalues))
+    th2 = np.sort_complex(np.asarray(dec2.eigenvalues))
+    assert np.abs(th - th2).max() <= 1e-9 * np.abs(th2).max()
+    # eigenpairs of A itself
+    vals, vecs = pkg.partialeigen(dec)
+    lam = sigma + 1.0 / np.asarray(vals)
+    X = np.asarray(vecs)
+    R = A @ X - X * lam[None, :]
+    assert np.linalg.norm(R, axis=0).max() <= 1e-7 * np.abs(lam).max()
