@@ -50,6 +50,7 @@ struct TrsvArgs {
   uint32_t seq;
   int backoff;             // nap between two polls of the awaited entry, in units of 128 clocks
   int nap_lds;             // nap between two polls of an LDS flag, in units of 64 clocks
+  unsigned long long* timeline;  // KS_LU_TIMELINE=<prefix>: per row, wall clock (10 ns ticks): ticket obtained, far part summed, published; entries from its own chunk
   unsigned long long* stats;  // KS_LU_STATS=1: [0] ticks in ticket + barriers [1] rows [2] ticks of rows [3] ticks at the gate [4] ticks on LDS only
                               // [5] gate polls [6] attempts [7] cached hits [8] cached misses [9] coherent tries (per lane)
 };
@@ -82,8 +83,19 @@ template <class D, int LOCAL> __device__ __forceinline__ void ll_put(uint64_t* p
 template <class D, int LOCAL, bool CACHED = false> __device__ __forceinline__ bool ll_get(const uint64_t* p, D& v, uint32_t seq) {
   constexpr int W = LLWords<D>::W;
   uint64_t u[W];
+  if (CACHED) {
+    // 16 bytes per request: the cache's request rate, not its bandwidth, is what a dense triangle's gathers run into
+    // (every 8-byte word is still consistent in itself: payload and number never straddle a naturally aligned dword pair)
 #pragma unroll
-  for (int k = 0; k < W; ++k) u[k] = CACHED ? __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : ll_word<LOCAL>(p + k);
+    for (int k = 0; k < W; k += 2) {
+      const ulonglong2 q = *reinterpret_cast<const ulonglong2*>(p + k);
+      u[k] = q.x;
+      u[k + 1] = q.y;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < W; ++k) u[k] = ll_word<LOCAL>(p + k);
+  }
   bool ok = true;
   uint32_t w[W];
 #pragma unroll
@@ -179,7 +191,7 @@ __global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
     if (threadIdx.x == 0) s_ticket = atomicAdd(a.ticket, 1);
     if (threadIdx.x < C) ready[threadIdx.x] = 0;
     __syncthreads();
-    const long long tk1 = a.stats ? wall_clock64() : 0;
+    const long long tk1 = (a.stats || a.timeline) ? wall_clock64() : 0;
     st_ticket += (unsigned long long)(tk1 - tk0);
     const int64_t base = a.row0 + (int64_t)s_ticket * C;
     if (base >= a.n) break;
@@ -200,7 +212,9 @@ __global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
     D b;
     {
       const int64_t s = a.src[r];
-      if (a.rhs) {
+      if (s < 0) {
+        b = zero_of(D{});  // solution row of a dense run: x = T^-1 s, no right-hand side of its own
+      } else if (a.rhs) {
         b = static_cast<const D*>(a.rhs)[s];
         if (a.scale) b = scl(b, a.scale[r]);
       } else {
@@ -212,14 +226,19 @@ __global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
     const long long t0 = wall_clock64();
     long spins = 0;
     bool dead = false;
-    for (int64_t q0 = p0; q0 < pf && !dead; q0 += 64 * U) {
+    // Batches of 64 x U entries, the SHORT one first: the last batch then holds the 64 x U latest dependencies, and a row
+    // of a dense triangle reaches it while the front is still hundreds of rows away.  (Short batch last: its gate opens
+    // a few rows before the row's turn, and fetching that batch -- columns, values, solution words: three round trips --
+    // then stalls the chain; with 16 rows per chunk some row nearly always hit it: 8 us per chunk instead of 2.)
+    const int64_t first = (pf - p0) % (64 * U) == 0 ? 64 * U : (pf - p0) % (64 * U);
+    for (int64_t q0 = p0, qe = p0 + first; q0 < pf && !dead; q0 = qe, qe += 64 * U) {
       int32_t c[U];
       D av[U], xv[U];
       bool need[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int64_t p = q0 + u * 64 + lane;
-        need[u] = p < pf;
+        need[u] = p < qe;
         c[u] = need[u] ? a.colind[p] : 0;
         av[u] = need[u] ? val[p] : zero_of(D{});
         xv[u] = zero_of(D{});
@@ -262,6 +281,7 @@ __global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
       for (int u = 0; u < U; ++u) acc = fma_(av[u], xv[u], acc);
     }
     acc = wave_sum_dpp(acc);
+    const unsigned long long tl_far = a.timeline ? (unsigned long long)wall_clock64() : 0;
     // the chain: entries of this chunk, oldest first, every lane in step
     const long long tn0 = a.stats ? wall_clock64() : 0;
     for (int k = m - 1; k >= 0 && !dead; --k) {
@@ -280,7 +300,14 @@ __global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
       xs[wave] = x;
       __hip_atomic_store(&ready[wave], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       ll_put<D, LOCAL>(a.sol + (size_t)r * W, x, a.seq);
-      if (a.out) static_cast<D*>(a.out)[a.dst[r]] = x;
+      if (a.out) {
+        const int64_t d = a.dst[r];
+        if (d >= 0) static_cast<D*>(a.out)[d] = x;
+      }
+      if (a.timeline) {
+        unsigned long long* tl = a.timeline + 4 * (size_t)r;
+        tl[0] = (unsigned long long)tk1; tl[1] = tl_far; tl[2] = (unsigned long long)wall_clock64(); tl[3] = (unsigned long long)m;
+      }
     }
     if (a.stats) { ++st_rows; st_row += (unsigned long long)(wall_clock64() - tk1); }
   }
@@ -307,13 +334,21 @@ inline ksd::cd inverse_host(ksd::cd v) {
   const std::complex<double> r = 1.0 / std::complex<double>(v.x, v.y);
   return ksd::cd{r.real(), r.imag()};
 }
+inline std::complex<double> to_complex_host(double v) { return {v, 0.0}; }
+inline std::complex<double> to_complex_host(ksd::cd v) { return {v.x, v.y}; }
+inline double from_complex_host(std::complex<double> v, double) { return v.real(); }
+inline ksd::cd from_complex_host(std::complex<double> v, ksd::cd) { return ksd::cd{v.real(), v.imag()}; }
 inline bool is_zero_host(double v) { return v == 0.0; }
 inline bool is_zero_host(ksd::cd v) { return v.x == 0.0 && v.y == 0.0; }
 
 template <class D> struct TriFactor {
   int64_t nnz = 0;       // strictly triangular entries
   int64_t levels = 0;    // length of the longest dependency chain
-  std::vector<int32_t> order, pos;  // host: level numbering -> caller's row, and back
+  int64_t rows = 0;      // rows of the system the kernel solves (n + the rows of the dense runs)
+  int64_t run_rows = 0;  // rows that belong to inverted dense runs
+  int64_t stored = 0;    // entries stored for the kernel
+  std::vector<int32_t> order, pos;  // host: kernel's row -> caller's row;  caller's row -> kernel's row that holds its solution entry
+  std::vector<char> kind;           // host: 0 ordinary row, 1 right-hand-side row of a run, 2 solution row of a run
   int64_t* rowptr = nullptr;
   int32_t* colind = nullptr;
   D* val = nullptr;
@@ -388,7 +423,7 @@ void upload_factor(TriFactor<D>& f, int64_t n, const int64_t* rp, const int32_t*
   // the factor in its own numbering: row i = caller's row order[i], columns pos[c], ascending
   std::vector<int64_t> nrp((size_t)n + 1, 0);
   std::vector<int32_t> nci(sci.size());
-  std::vector<D> nv(sv.size()), ndg;
+  std::vector<D> nv(sv.size());
   std::vector<std::pair<int32_t, int64_t>> tmp;
   for (int64_t i = 0; i < n; ++i) {
     const int64_t r = f.order[i];
@@ -403,24 +438,154 @@ void upload_factor(TriFactor<D>& f, int64_t n, const int64_t* rp, const int32_t*
     }
     nrp[i + 1] = q;
   }
-  if (with_diag) {
-    ndg.resize((size_t)n);
-    for (int64_t i = 0; i < n; ++i) ndg[i] = inverse_host(dg[f.order[i]]);  // the chain multiplies (a division is ~100 cycles per hand-over)
+  // ---- dense runs -------------------------------------------------------------------------------------------------
+  // Where the levels are narrow (the dense triangles of the top separators: one or two rows per level, every row depending
+  // on all rows before it) substitution is a chain: measured 0.36 us per row through LDS plus 2.3 us per 16-row chunk
+  // through memory, i.e. 0.48 us per row, and nearly half of a product.  There the rows are cut into runs of up to R
+  // consecutive rows and the triangle T of each run (its diagonal and the entries between its rows) is INVERTED here, once:
+  //     x_run = T^-1 s_run,     s_run = b_run - (entries outside the run) x
+  // which is again a sparse triangular system, in twice the unknowns of the run: the rows of s depend on earlier x only,
+  // the rows of x on the s of their run only (entries -T^-1).  The kernel solves the augmented system as it stands: the
+  // chain through a run of R rows is two hand-overs through memory instead of R.  (Inverted diagonal blocks are what
+  // dense triangular solves do on GPUs; the factors of a pivoted LU keep the inverse of such a block tame.)
+  const int64_t R = std::max(0, env_int("KS_LU_RUN", 256));
+  const int64_t narrow = std::max(1, env_int("KS_LU_NARROW", 16));
+  std::vector<char> in_run((size_t)n, 0);       // level-numbered row is part of a run
+  std::vector<int64_t> run_begin;               // first row of each run (level numbering), and a final sentinel
+  if (R >= 2) {
+    // start[l] now holds the END of level l (the counting sort advanced it): level l = rows [end[l-1], end[l])
+    int64_t i = 0;
+    while (i < n) {
+      // a stretch of narrow levels starting at row i (i is the first row of its level)
+      int64_t j = i;
+      int64_t l = lev[f.order[i]];
+      while (j < n) {
+        const int64_t lb = l == 0 ? 0 : start[l - 1], le = start[l];
+        if (le - lb > narrow) break;
+        j = le;
+        ++l;
+      }
+      if (j - i >= 32) {
+        for (int64_t a = i; a < j; a += R) run_begin.push_back(a);
+        for (int64_t q = i; q < j; ++q) in_run[q] = 1;
+        run_begin.push_back(-j);  // (negative: the stretch ends here)
+        i = j;
+      } else {
+        // skip to the first row of the next level
+        const int64_t le = start[lev[f.order[i]]];
+        i = j > i ? j : le;
+      }
+    }
   }
+  // augmented numbering: a row outside the runs keeps one unknown; a run of r rows becomes r rows of s, then r rows of x
+  std::vector<int32_t> xidx((size_t)n, 0);      // level-numbered row -> augmented index of its x
+  std::vector<int32_t> aug_owner;               // augmented row -> level-numbered row
+  std::vector<char> aug_kind;                   // 0: ordinary row, 1: s row, 2: x row
+  {
+    size_t rb = 0;
+    int64_t i = 0;
+    while (i < n) {
+      if (!in_run[i]) {
+        xidx[i] = (int32_t)aug_owner.size();
+        aug_owner.push_back((int32_t)i);
+        aug_kind.push_back(0);
+        ++i;
+        continue;
+      }
+      while (rb < run_begin.size() && (run_begin[rb] < 0 || run_begin[rb] < i)) ++rb;
+      const int64_t a = run_begin[rb];
+      const int64_t nxt = run_begin[rb + 1];
+      const int64_t b = nxt < 0 ? -nxt : nxt;
+      for (int64_t q = a; q < b; ++q) { aug_owner.push_back((int32_t)q); aug_kind.push_back(1); }
+      for (int64_t q = a; q < b; ++q) { xidx[q] = (int32_t)aug_owner.size(); aug_owner.push_back((int32_t)q); aug_kind.push_back(2); }
+      i = b;
+      ++rb;
+    }
+  }
+  const int64_t N = (int64_t)aug_owner.size();
+  KS_REQUIRE(N < (int64_t)2147483647, KS_ERR_ARGUMENT, std::string(name) + ": too many rows");
+  std::vector<int64_t> arp((size_t)N + 1, 0);
+  std::vector<int32_t> aci;
+  std::vector<D> av, adg((size_t)N, from_real_host(1.0, D{}));
+  aci.reserve(nci.size() + (size_t)(N - n) * 8);
+  av.reserve(nci.size() + (size_t)(N - n) * 8);
+  using cplx_t = std::complex<double>;
+  auto to_c = [](const D& v) { return to_complex_host(v); };
+  std::vector<cplx_t> T, Ti;
+  int64_t run_a = -1, run_b = -1;  // the run whose inverse is in Ti
+  for (int64_t k = 0; k < N; ++k) {
+    const int64_t i = aug_owner[k];
+    if (aug_kind[k] == 0) {
+      for (int64_t p = nrp[i]; p < nrp[i + 1]; ++p) { aci.push_back(xidx[nci[p]]); av.push_back(nv[p]); }
+      if (with_diag) adg[k] = inverse_host(dg[f.order[i]]);
+    } else if (aug_kind[k] == 1) {
+      if (run_a < 0 || i < run_a || i >= run_b) {
+        // first s row of a run: its extent is the block of s rows that starts here
+        run_a = i;
+        int64_t e = k;
+        while (e < N && aug_kind[e] == 1) ++e;
+        run_b = run_a + (e - k);
+        const int64_t r = run_b - run_a;
+        T.assign((size_t)(r * r), cplx_t(0.0, 0.0));
+        for (int64_t q = run_a; q < run_b; ++q) {
+          T[(size_t)((q - run_a) * r + (q - run_a))] = with_diag ? to_c(dg[f.order[q]]) : cplx_t(1.0, 0.0);
+          for (int64_t p = nrp[q]; p < nrp[q + 1]; ++p)
+            if (nci[p] >= run_a) T[(size_t)((q - run_a) * r + (nci[p] - run_a))] = to_c(nv[p]);
+        }
+        // Ti = T^-1, column by column (forward substitution on the identity)
+        Ti.assign((size_t)(r * r), cplx_t(0.0, 0.0));
+        for (int64_t c = 0; c < r; ++c) {
+          Ti[(size_t)(c * r + c)] = cplx_t(1.0, 0.0) / T[(size_t)(c * r + c)];
+          for (int64_t q = c + 1; q < r; ++q) {
+            cplx_t acc(0.0, 0.0);
+            const cplx_t* trow = &T[(size_t)(q * r)];
+            for (int64_t t = c; t < q; ++t)
+              if (trow[t] != cplx_t(0.0, 0.0)) acc += trow[t] * Ti[(size_t)(t * r + c)];
+            Ti[(size_t)(q * r + c)] = -acc / trow[q];
+          }
+        }
+      }
+      // s row: the entries outside the run, unit pivot
+      for (int64_t p = nrp[i]; p < nrp[i + 1]; ++p)
+        if (nci[p] < run_a) { aci.push_back(xidx[nci[p]]); av.push_back(nv[p]); }
+    } else {
+      // x row: x_i = sum_j Ti[i][j] s_j  ->  entries -Ti on the s rows of the run (they sit r rows before the x rows)
+      const int64_t r = run_b - run_a, q = i - run_a;
+      const int32_t s0 = xidx[run_a] - (int32_t)r;
+      for (int64_t t = 0; t <= q; ++t) {
+        const cplx_t w = Ti[(size_t)(q * r + t)];
+        if (w != cplx_t(0.0, 0.0)) { aci.push_back(s0 + (int32_t)t); av.push_back(from_complex_host(-w, D{})); }
+      }
+    }
+    arp[k + 1] = (int64_t)aci.size();
+  }
+  // order/pos now describe the augmented numbering: order[k] = caller's row, kind[k], pos[caller's row] = index of its x
+  {
+    std::vector<int32_t> o2((size_t)N), p2((size_t)n);
+    for (int64_t k = 0; k < N; ++k) o2[k] = f.order[aug_owner[k]];
+    for (int64_t i = 0; i < n; ++i) p2[f.order[i]] = xidx[i];
+    f.order.swap(o2);
+    f.pos.swap(p2);
+    f.kind.assign(aug_kind.begin(), aug_kind.end());
+  }
+  f.rows = N;
+  f.run_rows = N - n;
   f.nnz = (int64_t)nci.size();
-  KS_HIP(hipMalloc(&f.rowptr, ((size_t)n + 1) * 8));
-  KS_HIP(hipMalloc(&f.colind, std::max<size_t>(nci.size(), 1) * 4));
-  KS_HIP(hipMalloc(&f.val, std::max<size_t>(nv.size(), 1) * sizeof(D)));
-  KS_HIP(hipMemcpy(f.rowptr, nrp.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice));
-  if (!nci.empty()) {
-    KS_HIP(hipMemcpy(f.colind, nci.data(), nci.size() * 4, hipMemcpyHostToDevice));
-    KS_HIP(hipMemcpy(f.val, nv.data(), nv.size() * sizeof(D), hipMemcpyHostToDevice));
+  const bool any_pivot = with_diag || N > n;
+  KS_HIP(hipMalloc(&f.rowptr, ((size_t)N + 1) * 8));
+  KS_HIP(hipMalloc(&f.colind, std::max<size_t>(aci.size(), 1) * 4));
+  KS_HIP(hipMalloc(&f.val, std::max<size_t>(av.size(), 1) * sizeof(D)));
+  KS_HIP(hipMemcpy(f.rowptr, arp.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice));
+  if (!aci.empty()) {
+    KS_HIP(hipMemcpy(f.colind, aci.data(), aci.size() * 4, hipMemcpyHostToDevice));
+    KS_HIP(hipMemcpy(f.val, av.data(), av.size() * sizeof(D), hipMemcpyHostToDevice));
   }
-  if (with_diag) {
-    KS_HIP(hipMalloc(&f.diag, (size_t)n * sizeof(D)));
-    KS_HIP(hipMemcpy(f.diag, ndg.data(), (size_t)n * sizeof(D), hipMemcpyHostToDevice));
+  f.stored = (int64_t)aci.size();
+  if (any_pivot) {
+    KS_HIP(hipMalloc(&f.diag, (size_t)N * sizeof(D)));
+    KS_HIP(hipMemcpy(f.diag, adg.data(), (size_t)N * sizeof(D), hipMemcpyHostToDevice));
   }
-  const size_t words = (size_t)n * ksd::LLWords<D>::W;
+  const size_t words = (size_t)N * ksd::LLWords<D>::W;
   KS_HIP(hipMalloc(&f.sol, std::max<size_t>(words, 1) * 8));
   KS_HIP(hipMemset(f.sol, 0, std::max<size_t>(words, 1) * 8));  // sequence number 0 is never used by a solve
 }
@@ -438,16 +603,19 @@ template <class D> struct LuOp : ks_operator {
   int grid = 0, backoff = 2, nap_lds = 1;
   long long timeout_ticks = 0;
   unsigned long long* stats = nullptr;  // KS_LU_STATS=1
+  unsigned long long* timeline = nullptr;  // KS_LU_TIMELINE=<file prefix>: 2 x 4 x tl_rows
+  int64_t tl_rows = 0;
   ~LuOp() override {
     L.release(); U.release();
     (void)hipFree(src_l); (void)hipFree(scale_l); (void)hipFree(src_u); (void)hipFree(dst_u); (void)hipFree(tickets);
     (void)hipFree(stats);
+    (void)hipFree(timeline);
   }
   // One launch per factor.  (Two were tried -- the wide levels on every XCD, the narrow tail on one: the all-XCD part
   // collapses as soon as more than ~64 workgroups wait on entries through the fabric, 15-65 ms instead of 2.2 / 14.)
-  void solve(ksd::TrsvArgs a, int* words) {
-    a.row0 = 0; a.n = n_local; a.ticket = words;
-    const int g = (int)std::max<int64_t>(1, std::min<int64_t>((n_local + ksd::kTrsvWaves - 1) / ksd::kTrsvWaves, grid));
+  void solve(ksd::TrsvArgs a, int64_t rows, int* words) {
+    a.row0 = 0; a.n = rows; a.ticket = words;
+    const int g = (int)std::max<int64_t>(1, std::min<int64_t>((rows + ksd::kTrsvWaves - 1) / ksd::kTrsvWaves, grid));
     switch (local) {
       case 3: ksd::k_sptrsv<D, 3><<<g * 8, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a); break;
       case 4: ksd::k_sptrsv<D, 4><<<g * 8, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a); break;
@@ -457,11 +625,10 @@ template <class D> struct LuOp : ks_operator {
   }
   void apply(const void* x, void* y, const DevState*) override {
     ctx->check_comm();  // (of earlier products: the word is written by the device)
-    ProfScope ps(ctx, KSP_SPMV, (double)(L.nnz + U.nnz) * (sizeof(D) + 4.0 + 8.0 * ksd::LLWords<D>::W) + (double)n_local * (4.0 * sizeof(D) + 2.0 * 8.0 + 3.0 * 4.0 + 3.0 * 8.0 * ksd::LLWords<D>::W));
-    const size_t sol_bytes = (size_t)n_local * ksd::LLWords<D>::W * 8;
+    ProfScope ps(ctx, KSP_SPMV, (double)(L.stored + U.stored) * (sizeof(D) + 4.0 + 8.0 * ksd::LLWords<D>::W) + (double)n_local * (4.0 * sizeof(D) + 2.0 * 8.0 + 3.0 * 4.0 + 3.0 * 8.0 * ksd::LLWords<D>::W));
     if (++seq == 0) {  // 2^32 solves: start the sequence numbers over
-      KS_HIP(hipMemsetAsync(L.sol, 0, sol_bytes, ctx->stream));
-      KS_HIP(hipMemsetAsync(U.sol, 0, sol_bytes, ctx->stream));
+      KS_HIP(hipMemsetAsync(L.sol, 0, (size_t)L.rows * ksd::LLWords<D>::W * 8, ctx->stream));
+      KS_HIP(hipMemsetAsync(U.sol, 0, (size_t)U.rows * ksd::LLWords<D>::W * 8, ctx->stream));
       seq = 1;
     }
     ksd::TrsvArgs a{};
@@ -477,13 +644,23 @@ template <class D> struct LuOp : ks_operator {
     a.rowptr = L.rowptr; a.colind = L.colind; a.val = L.val; a.diag = L.diag; a.sol = L.sol;
     a.rhs = x; a.src = src_l; a.scale = scale_l;
     KS_HIP(hipMemsetAsync(tickets, 0, 16 * sizeof(int), ctx->stream));
-    solve(a, tickets);
+    a.timeline = timeline;
+    solve(a, L.rows, tickets);
     // U w = z;  y[perm_out] = w
     a.rowptr = U.rowptr; a.colind = U.colind; a.val = U.val; a.diag = U.diag; a.sol = U.sol;
     a.rhs = nullptr; a.rhs_ll = L.sol; a.src = src_u; a.scale = nullptr;
     a.out = y; a.dst = dst_u;
     if (stats) a.stats = stats + 12;
-    solve(a, tickets + 8);
+    const size_t nchunks = 4 * (size_t)tl_rows;
+    if (timeline) a.timeline = timeline + nchunks;
+    solve(a, U.rows, tickets + 8);
+    if (timeline) {
+      std::vector<unsigned long long> h(2 * nchunks);
+      KS_HIP(hipMemcpyAsync(h.data(), timeline, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+      KS_HIP(hipStreamSynchronize(ctx->stream));
+      const std::string path = std::string(std::getenv("KS_LU_TIMELINE")) + ".u64";
+      if (FILE* fp = std::fopen(path.c_str(), "wb")) { std::fwrite(h.data(), 8, h.size(), fp); std::fclose(fp); }
+    }
     if (stats) {
       unsigned long long h[24];
       KS_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -516,28 +693,33 @@ ks_operator* make_lu(ks_ctx* ctx, int64_t n, const int64_t* lrp, const int32_t* 
   upload_factor<D>(op->L, n, lrp, lci, static_cast<const D*>(lv), true, "ks_operator_lu: L");
   upload_factor<D>(op->U, n, urp, uci, static_cast<const D*>(uv), false, "ks_operator_lu: U");
   op->nnz = op->L.nnz + op->U.nnz + n;
-  // index arrays between the caller's vectors and the two level numberings
-  std::vector<int32_t> sl((size_t)n), su((size_t)n), du((size_t)n);
+  // index arrays between the caller's vectors and the rows of the two systems the kernel solves
+  const int64_t nl = op->L.rows, nu = op->U.rows;
+  std::vector<int32_t> sl((size_t)nl), su((size_t)nu), du((size_t)nu);
   std::vector<double> scl;
-  if (sc) scl.resize((size_t)n);
-  for (int64_t i = 0; i < n; ++i) {
+  if (sc) scl.assign((size_t)nl, 1.0);
+  for (int64_t i = 0; i < nl; ++i) {
     const int32_t rl = op->L.order[i];  // row of the triangular system
+    if (op->L.kind[i] == 2) { sl[i] = -1; continue; }
     sl[i] = pin ? pin[rl] : rl;
     if (sc) scl[i] = sc[sl[i]];
+  }
+  for (int64_t i = 0; i < nu; ++i) {
     const int32_t ru = op->U.order[i];
-    su[i] = op->L.pos[ru];
-    du[i] = pout ? pout[ru] : ru;
+    su[i] = op->U.kind[i] == 2 ? -1 : op->L.pos[ru];
+    du[i] = op->U.kind[i] == 1 ? -1 : (pout ? pout[ru] : ru);
   }
   auto up = [&](const void* h, size_t bytes, void** d) {
     KS_HIP(hipMalloc(d, std::max<size_t>(bytes, 8)));
     KS_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
   };
-  up(sl.data(), (size_t)n * 4, (void**)&op->src_l);
-  up(su.data(), (size_t)n * 4, (void**)&op->src_u);
-  up(du.data(), (size_t)n * 4, (void**)&op->dst_u);
-  if (sc) up(scl.data(), (size_t)n * 8, (void**)&op->scale_l);
+  up(sl.data(), (size_t)nl * 4, (void**)&op->src_l);
+  up(su.data(), (size_t)nu * 4, (void**)&op->src_u);
+  up(du.data(), (size_t)nu * 4, (void**)&op->dst_u);
+  if (sc) up(scl.data(), (size_t)nl * 8, (void**)&op->scale_l);
   std::vector<int32_t>().swap(op->L.order); std::vector<int32_t>().swap(op->L.pos);
   std::vector<int32_t>().swap(op->U.order); std::vector<int32_t>().swap(op->U.pos);
+  std::vector<char>().swap(op->L.kind); std::vector<char>().swap(op->U.kind);
   KS_HIP(hipMalloc(&op->tickets, 16 * sizeof(int)));
   KS_HIP(hipMemset(op->tickets, 0, 16 * sizeof(int)));
   op->err_d = ctx->operr_dev();
@@ -548,6 +730,12 @@ ks_operator* make_lu(ks_ctx* ctx, int64_t n, const int64_t* lrp, const int32_t* 
   op->backoff = std::max(0, env_int("KS_LU_BACKOFF", 2));  // nap between two polls of a missing entry, x 128 clocks
   op->nap_lds = std::max(0, env_int("KS_LU_NAP_LDS", 1));
   op->timeout_ticks = (long long)env_int("KS_LU_TIMEOUT_S", 20) * 100000000LL;
+  if (std::getenv("KS_LU_TIMELINE")) {
+    op->tl_rows = std::max(op->L.rows, op->U.rows);
+    const size_t nchunks = 4 * (size_t)op->tl_rows;
+    KS_HIP(hipMalloc(&op->timeline, 2 * nchunks * 8));
+    KS_HIP(hipMemset(op->timeline, 0, 2 * nchunks * 8));
+  }
   if (env_int("KS_LU_STATS", 0)) {
     KS_HIP(hipMalloc(&op->stats, 24 * 8));
     KS_HIP(hipMemset(op->stats, 0, 24 * 8));
