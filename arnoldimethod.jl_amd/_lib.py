@@ -88,6 +88,7 @@ PROTOTYPES = {
     "ks_operator_device_callback": [vp, i64, i32, DEVICE_APPLY_FN, vp, P(vp)],
     "ks_operator_lu": [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, P(vp)],
     "ks_operator_lu_info": [vp, P(i64), P(i64), P(i64), P(i64)],
+    "ks_operator_lu_layout": [vp, i32, P(i64), P(i64), P(i64), P(C.c_int)],
     "ks_operator_destroy": [vp],
     "ks_operator_size": [vp, P(i64), P(i64), P(C.c_int)],
     "ks_operator_format": [vp, P(C.c_double), P(C.c_int), P(C.c_int)],

@@ -308,6 +308,11 @@ def lu_operator(L, U, perm_in=None, perm_out=None, scale=None, ctx: Context | No
     v = [C.c_int64() for _ in range(4)]
     check(lib.ks_operator_lu_info(h, *[C.byref(x) for x in v]))
     op.lu_info = dict(nnz_l=v[0].value, nnz_u=v[1].value, levels_l=v[2].value, levels_u=v[3].value)
+    for upper, tag in ((0, "l"), (1, "u")):
+        w = [C.c_int64() for _ in range(3)]
+        g = C.c_int()
+        check(lib.ks_operator_lu_layout(h, upper, C.byref(w[0]), C.byref(w[1]), C.byref(w[2]), C.byref(g)))
+        op.lu_info.update({f"rows_{tag}": w[0].value, f"run_rows_{tag}": w[1].value, f"top_rows_{tag}": w[2].value, f"groups_{tag}": g.value})
     return op
 
 

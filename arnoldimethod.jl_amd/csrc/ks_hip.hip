@@ -436,6 +436,22 @@ int ks_operator_lu_info(const ks_operator* op, int64_t* nnz_l, int64_t* nnz_u, i
   });
 }
 
+int ks_operator_lu_layout(const ks_operator* op, int upper, int64_t* rows, int64_t* run_rows, int64_t* top_rows, int* ngroups) {
+  return guarded([&] {
+    KS_REQUIRE(op, KS_ERR_ARGUMENT, "null operator");
+    auto fill = [&](auto* lu) {
+      const auto& f = upper ? lu->U : lu->L;
+      if (rows) *rows = f.rows;
+      if (run_rows) *run_rows = f.run_rows;
+      if (top_rows) *top_rows = f.top_end - f.top_begin;
+      if (ngroups) *ngroups = f.ngroups;
+    };
+    if (auto* a = dynamic_cast<const LuOp<double>*>(op)) fill(a);
+    else if (auto* b = dynamic_cast<const LuOp<cd>*>(op)) fill(b);
+    else throw KsError{KS_ERR_ARGUMENT, "ks_operator_lu_layout: not an operator made by ks_operator_lu"};
+  });
+}
+
 int ks_operator_destroy(ks_operator* op) {
   return guarded([&] {
     if (!op) return;

@@ -44,7 +44,10 @@ struct TrsvArgs {
   const double* scale;     // first solve: ... times scale[i] (already in row order; nullptr: none)
   void* out;               // second solve: y[dst[i]] = entry i
   const int32_t* dst;
-  int* ticket;             // this launch's control words: [0] row counter, [2] owning XCD + 1 (zeroed by the host side before the product)
+  int* ticket;             // this launch's control words: [0] row counter, [2] owning XCD + 1 (zeroed by the host side before the product);
+                           // grouped launch: four words per group
+  int64_t gbeg[8], gend[8];  // grouped launch (LOCAL = 5): rows of group g; a group belongs to ONE XCD
+  signed char xcc_group[16]; //   XCC id -> group (-1: none)
   int* err;                // pinned host word
   long long timeout_ticks;
   uint32_t seq;
@@ -73,7 +76,7 @@ template <class D, int LOCAL> __device__ __forceinline__ void ll_put(uint64_t* p
 #pragma unroll
   for (int k = 0; k < W; ++k) {
     const uint64_t word = ((uint64_t)seq << 32) | w[k];
-    if (LOCAL == 3) __hip_atomic_store(p + k, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (LOCAL == 3 || LOCAL == 5) __hip_atomic_store(p + k, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else __hip_atomic_store(p + k, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -175,7 +178,14 @@ __global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const D* __restrict__ val = static_cast<const D*>(a.val);
   const D* __restrict__ dinv = static_cast<const D*>(a.diag);
-  if (LOCAL) {
+  int64_t row0 = a.row0, nend = a.n;
+  int* ticket = a.ticket;
+  if (LOCAL == 5) {
+    // independent parts of the factor, one per XCD: every hand-over stays inside that XCD's L2
+    const int g = a.xcc_group[xcc_id()];
+    if (g < 0) return;
+    row0 = a.gbeg[g]; nend = a.gend[g]; ticket = a.ticket + 4 * g;
+  } else if (LOCAL) {
     if (threadIdx.x == 0) {
       const int mine = xcc_id() + 1;
       const int seen = atomicCAS(a.ticket + 2, 0, mine);  // [2]: owner of this launch (0: none yet)
@@ -188,15 +198,15 @@ __global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
   for (;;) {
     const long long tk0 = a.stats ? wall_clock64() : 0;
     __syncthreads();
-    if (threadIdx.x == 0) s_ticket = atomicAdd(a.ticket, 1);
+    if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1);
     if (threadIdx.x < C) ready[threadIdx.x] = 0;
     __syncthreads();
     const long long tk1 = (a.stats || a.timeline) ? wall_clock64() : 0;
     st_ticket += (unsigned long long)(tk1 - tk0);
-    const int64_t base = a.row0 + (int64_t)s_ticket * C;
-    if (base >= a.n) break;
+    const int64_t base = row0 + (int64_t)s_ticket * C;
+    if (base >= nend) break;
     const int64_t r = base + wave;
-    if (r >= a.n) continue;
+    if (r >= nend) continue;
     const int64_t p0 = a.rowptr[r], p1 = a.rowptr[r + 1];
     // Entries produced by THIS workgroup: the last m of the row (columns ascend).  Lane l < 16 looks at entry p1-1-l;
     // they are consumed one by one at the end, in column order, by the whole wave in step (no reduction on the chain).
@@ -323,6 +333,18 @@ __global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
   }
 }
 
+// which XCC ids exist on this device (bit mask)
+__global__ void k_xcc_probe(unsigned* mask) {
+  if (threadIdx.x == 0) atomicOr(mask, 1u << xcc_id());
+}
+// after a grouped launch: every group's tickets must have been handed out (a group whose XCD got no workgroup -- a device
+// shared with something that occupies a whole XCD -- would otherwise go unnoticed)
+__global__ void k_trsv_check(const int* words, const int* needed, int ngroups, int* err) {
+  if (threadIdx.x == 0)
+    for (int g = 0; g < ngroups; ++g)
+      if (words[4 * g] < needed[g]) __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace ksd
 
 namespace {
@@ -349,20 +371,29 @@ template <class D> struct TriFactor {
   int64_t stored = 0;    // entries stored for the kernel
   std::vector<int32_t> order, pos;  // host: kernel's row -> caller's row;  caller's row -> kernel's row that holds its solution entry
   std::vector<char> kind;           // host: 0 ordinary row, 1 right-hand-side row of a run, 2 solution row of a run
+  // Launch structure.  The rows next to the root of the elimination tree ("top": narrow levels, dense runs) are one
+  // launch on one XCD; what is left falls apart into independent parts (connected components of the dependency graph),
+  // packed into `ngroups` groups of similar work, one XCD each, ONE launch for all of them.  Lower factor: groups, then
+  // top; upper factor (solved from the root): top, then groups.
+  int ngroups = 0;                  // 0: everything is "top" (one launch)
+  bool top_first = false;
+  int64_t top_begin = 0, top_end = 0;   // rows of the top launch (kernel numbering)
+  int64_t gbeg[8] = {}, gend[8] = {};
+  int* needed_d = nullptr;          // tickets each group has to hand out (k_trsv_check)
   int64_t* rowptr = nullptr;
   int32_t* colind = nullptr;
   D* val = nullptr;
   D* diag = nullptr;     // inverse diagonal entries; nullptr: unit diagonal
   uint64_t* sol = nullptr;
   void release() {
-    (void)hipFree(rowptr); (void)hipFree(colind); (void)hipFree(val); (void)hipFree(diag); (void)hipFree(sol);
+    (void)hipFree(rowptr); (void)hipFree(colind); (void)hipFree(val); (void)hipFree(diag); (void)hipFree(sol); (void)hipFree(needed_d);
   }
 };
 
 // Split a triangular CSR factor into its strict part and its diagonal (checking the triangle), renumber rows and columns
 // by dependency level, upload.
 template <class D>
-void upload_factor(TriFactor<D>& f, int64_t n, const int64_t* rp, const int32_t* ci, const D* vv, bool lower, const char* name) {
+void upload_factor(TriFactor<D>& f, int64_t n, const int64_t* rp, const int32_t* ci, const D* vv, bool lower, const char* name, int want_groups) {
   std::vector<int64_t> srp((size_t)n + 1, 0);
   std::vector<int32_t> sci;
   std::vector<D> sv, dg((size_t)n, D{});
@@ -409,17 +440,78 @@ void upload_factor(TriFactor<D>& f, int64_t n, const int64_t* rp, const int32_t*
     top = std::max<int64_t>(top, l + 1);
   }
   f.levels = n > 0 ? top : 0;
-  std::vector<int64_t> start((size_t)top + 1, 0);
-  for (int64_t r = 0; r < n; ++r) start[lev[r] + 1]++;
-  for (int64_t l = 0; l < top; ++l) start[l + 1] += start[l];
+  // "top": the LAST K pivots (the separators next to the root of the elimination tree; the same rows in both factors).
+  // Without them the rest of the factor falls apart into independent parts -- connected components of its dependency
+  // graph -- which are packed by work into groups, one XCD each.  K: the smallest of 128, 256, 512, ... for which the
+  // heaviest group stays under 1.75 / groups of the work (found by adding rows to a union-find from the largest K down).
+  std::vector<int32_t> seg((size_t)n, 0);  // 0 .. G-1: group; G: top   (lower)  /  0: top; 1 .. G: group  (upper)
+  int G = 0;
+  if (want_groups > 1 && n >= 4096) {
+    // edges keyed by their LARGER endpoint: the rows of the lower factor as they are, the columns of the upper one
+    std::vector<int64_t> ep;
+    std::vector<int32_t> ei;
+    if (lower) { ep = srp; ei = sci; }
+    else {
+      ep.assign((size_t)n + 1, 0);
+      for (int32_t c : sci) ep[(size_t)c + 1]++;
+      for (int64_t r = 0; r < n; ++r) ep[r + 1] += ep[r];
+      ei.resize(sci.size());
+      std::vector<int64_t> fill(ep.begin(), ep.end() - 1);
+      for (int64_t r = 0; r < n; ++r)
+        for (int64_t p = srp[r]; p < srp[r + 1]; ++p) ei[fill[sci[p]]++] = (int32_t)r;
+    }
+    std::vector<int32_t> parent((size_t)n);
+    for (int64_t r = 0; r < n; ++r) parent[r] = (int32_t)r;
+    auto find = [&](int32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+    std::vector<int64_t> cand;
+    for (int64_t K = 128; K <= n / 2; K *= 2) cand.push_back(K);
+    std::vector<double> work((size_t)n), load;
+    std::vector<int32_t> comps, bin_of((size_t)n, 0), best_bin;
+    int64_t added = 0, best_K = -1;  // rows [0, added) are in the union-find
+    int best_bins = 0;
+    for (size_t k = cand.size(); k-- > 0;) {
+      const int64_t K = cand[k], nb = n - K;
+      for (int64_t r = added; r < nb; ++r)
+        for (int64_t p = ep[r]; p < ep[r + 1]; ++p) { const int32_t a = find((int32_t)r), b = find(ei[p]); if (a != b) parent[a] = b; }
+      added = nb;
+      std::fill(work.begin(), work.begin() + nb, 0.0);
+      double total = 0.0;
+      for (int64_t r = 0; r < nb; ++r) { const double w = (double)(srp[r + 1] - srp[r]) + 8.0; work[find((int32_t)r)] += w; total += w; }
+      comps.clear();
+      for (int64_t r = 0; r < nb; ++r) if (parent[r] == r) comps.push_back((int32_t)r);
+      std::sort(comps.begin(), comps.end(), [&](int32_t a, int32_t b) { return work[a] != work[b] ? work[a] > work[b] : a < b; });
+      const int bins = std::min<int>(want_groups, (int)comps.size());
+      load.assign((size_t)bins, 0.0);
+      for (int32_t c : comps) {
+        int best = 0;
+        for (int b = 1; b < bins; ++b) if (load[b] < load[best]) best = b;
+        bin_of[c] = best;
+        load[best] += work[c];
+      }
+      const double worst = *std::max_element(load.begin(), load.end());
+      if (bins < 2 || worst > 1.75 / want_groups * total) break;  // (smaller K only merges parts)
+      best_K = K;
+      best_bins = bins;
+      best_bin.assign((size_t)n, -1);
+      for (int64_t r = 0; r < nb; ++r) best_bin[r] = bin_of[find((int32_t)r)];
+    }
+    if (best_K > 0) {
+      G = best_bins;
+      for (int64_t r = 0; r < n; ++r) seg[r] = r >= n - best_K ? (lower ? G : 0) : (lower ? best_bin[r] : 1 + best_bin[r]);
+    }
+  }
+  if (G == 0) std::fill(seg.begin(), seg.end(), 0);  // one segment: everything is "top"
+  // numbering: by segment, inside a segment by level, ties in elimination order (stable sort of the elimination order)
   f.order.assign((size_t)n, 0);
   f.pos.assign((size_t)n, 0);
-  for (int64_t t = 0; t < n; ++t) {
-    const int64_t r = lower ? t : n - 1 - t;
-    const int64_t i = start[lev[r]]++;
-    f.order[i] = (int32_t)r;
-    f.pos[r] = (int32_t)i;
-  }
+  for (int64_t t = 0; t < n; ++t) f.order[t] = (int32_t)(lower ? t : n - 1 - t);
+  std::stable_sort(f.order.begin(), f.order.end(), [&](int32_t a, int32_t b) { return seg[a] != seg[b] ? seg[a] < seg[b] : lev[a] < lev[b]; });
+  for (int64_t i = 0; i < n; ++i) f.pos[f.order[i]] = (int32_t)i;
+  const int nseg = G == 0 ? 1 : G + 1;
+  const int top_seg = G == 0 ? 0 : (lower ? G : 0);
+  std::vector<int64_t> segb((size_t)nseg + 1, 0);  // segment boundaries in this numbering
+  for (int64_t r = 0; r < n; ++r) segb[seg[r] + 1]++;
+  for (int k = 0; k < nseg; ++k) segb[k + 1] += segb[k];
   // the factor in its own numbering: row i = caller's row order[i], columns pos[c], ascending
   std::vector<int64_t> nrp((size_t)n + 1, 0);
   std::vector<int32_t> nci(sci.size());
@@ -453,27 +545,26 @@ void upload_factor(TriFactor<D>& f, int64_t n, const int64_t* rp, const int32_t*
   std::vector<char> in_run((size_t)n, 0);       // level-numbered row is part of a run
   std::vector<int64_t> run_begin;               // first row of each run (level numbering), and a final sentinel
   if (R >= 2) {
-    // start[l] now holds the END of level l (the counting sort advanced it): level l = rows [end[l-1], end[l])
-    int64_t i = 0;
-    while (i < n) {
-      // a stretch of narrow levels starting at row i (i is the first row of its level)
-      int64_t j = i;
-      int64_t l = lev[f.order[i]];
-      while (j < n) {
-        const int64_t lb = l == 0 ? 0 : start[l - 1], le = start[l];
-        if (le - lb > narrow) break;
-        j = le;
-        ++l;
-      }
-      if (j - i >= 32) {
-        for (int64_t a = i; a < j; a += R) run_begin.push_back(a);
-        for (int64_t q = i; q < j; ++q) in_run[q] = 1;
-        run_begin.push_back(-j);  // (negative: the stretch ends here)
-        i = j;
-      } else {
-        // skip to the first row of the next level
-        const int64_t le = start[lev[f.order[i]]];
-        i = j > i ? j : le;
+    // in every segment (the top part and each group has its own narrow end: its sub-separators)
+    for (int sg = 0; sg < nseg; ++sg) {
+      const int64_t ta = segb[sg], tb = segb[sg + 1];
+      auto level_end = [&](int64_t i) { int64_t e = i; const int32_t l = lev[f.order[i]]; while (e < tb && lev[f.order[e]] == l) ++e; return e; };
+      int64_t i = ta;
+      while (i < tb) {
+        int64_t j = i;  // a stretch of narrow levels starting at row i (the first row of its level)
+        while (j < tb) {
+          const int64_t e = level_end(j);
+          if (e - j > narrow) break;
+          j = e;
+        }
+        if (j - i >= 32) {
+          for (int64_t a = i; a < j; a += R) run_begin.push_back(a);
+          for (int64_t q = i; q < j; ++q) in_run[q] = 1;
+          run_begin.push_back(-j);  // (negative: the stretch ends here)
+          i = j;
+        } else {
+          i = j > i ? j : level_end(i);
+        }
       }
     }
   }
@@ -481,10 +572,13 @@ void upload_factor(TriFactor<D>& f, int64_t n, const int64_t* rp, const int32_t*
   std::vector<int32_t> xidx((size_t)n, 0);      // level-numbered row -> augmented index of its x
   std::vector<int32_t> aug_owner;               // augmented row -> level-numbered row
   std::vector<char> aug_kind;                   // 0: ordinary row, 1: s row, 2: x row
+  std::vector<int64_t> seg_aug((size_t)nseg + 1, 0);  // segment boundaries in the augmented numbering
   {
     size_t rb = 0;
     int64_t i = 0;
+    int sgi = 0;
     while (i < n) {
+      while (sgi <= nseg && segb[sgi] <= i) seg_aug[sgi++] = (int64_t)aug_owner.size();
       if (!in_run[i]) {
         xidx[i] = (int32_t)aug_owner.size();
         aug_owner.push_back((int32_t)i);
@@ -501,6 +595,7 @@ void upload_factor(TriFactor<D>& f, int64_t n, const int64_t* rp, const int32_t*
       i = b;
       ++rb;
     }
+    while (sgi <= nseg) seg_aug[sgi++] = (int64_t)aug_owner.size();
   }
   const int64_t N = (int64_t)aug_owner.size();
   KS_REQUIRE(N < (int64_t)2147483647, KS_ERR_ARGUMENT, std::string(name) + ": too many rows");
@@ -570,6 +665,21 @@ void upload_factor(TriFactor<D>& f, int64_t n, const int64_t* rp, const int32_t*
   }
   f.rows = N;
   f.run_rows = N - n;
+  f.ngroups = G;
+  f.top_first = !lower;
+  f.top_begin = seg_aug[top_seg];
+  f.top_end = seg_aug[top_seg + 1];
+  if (G > 0) {
+    std::vector<int> needed((size_t)G);
+    for (int g = 0; g < G; ++g) {
+      const int sgi = lower ? g : 1 + g;
+      f.gbeg[g] = seg_aug[sgi];
+      f.gend[g] = seg_aug[sgi + 1];
+      needed[g] = (int)((f.gend[g] - f.gbeg[g] + ksd::kTrsvWaves - 1) / ksd::kTrsvWaves);
+    }
+    KS_HIP(hipMalloc(&f.needed_d, (size_t)G * sizeof(int)));
+    KS_HIP(hipMemcpy(f.needed_d, needed.data(), (size_t)G * sizeof(int), hipMemcpyHostToDevice));
+  }
   f.nnz = (int64_t)nci.size();
   const bool any_pivot = with_diag || N > n;
   KS_HIP(hipMalloc(&f.rowptr, ((size_t)N + 1) * 8));
@@ -596,7 +706,9 @@ template <class D> struct LuOp : ks_operator {
   double* scale_l = nullptr; //   ... times scale_l[i]
   int32_t* src_u = nullptr;  // row i of U's numbering takes entry src_u[i] of L's solution
   int32_t* dst_u = nullptr;  //   ... and its result goes to y[dst_u[i]]
-  int* tickets = nullptr;    // 4 control words per launch, 4 launches
+  int* tickets = nullptr;    // per factor: 4 control words of the top launch + 4 per group
+  int xcc_group[16];         // XCC id -> group (probed once; 127: no such XCC)
+  int nxcc = 1;
   int local = 3;             // form of the tail launch (KS_LU_XCD): 3 = one XCD, stores to its L2; 4 = one XCD, stores through; 0 = all XCDs
   int* err_d = nullptr;      // the context's pinned error word (checked at every synchronisation point of the context)
   uint32_t seq = 0;
@@ -611,17 +723,34 @@ template <class D> struct LuOp : ks_operator {
     (void)hipFree(stats);
     (void)hipFree(timeline);
   }
-  // One launch per factor.  (Two were tried -- the wide levels on every XCD, the narrow tail on one: the all-XCD part
-  // collapses as soon as more than ~64 workgroups wait on entries through the fabric, 15-65 ms instead of 2.2 / 14.)
-  void solve(ksd::TrsvArgs a, int64_t rows, int* words) {
-    a.row0 = 0; a.n = rows; a.ticket = words;
-    const int g = (int)std::max<int64_t>(1, std::min<int64_t>((rows + ksd::kTrsvWaves - 1) / ksd::kTrsvWaves, grid));
+  // Top part: one launch on one XCD (or, KS_LU_XCD=0, on 64 workgroups anywhere: fewer waiting waves are faster there,
+  // each polls through the fabric -- with more than ~64 workgroups the all-XCD form collapses to 15-65 ms per product).
+  void launch_rows(ksd::TrsvArgs a, int64_t row0, int64_t row1, int* words) {
+    if (row1 <= row0) return;
+    a.row0 = row0; a.n = row1; a.ticket = words;
+    const int g = (int)std::max<int64_t>(1, std::min<int64_t>((row1 - row0 + ksd::kTrsvWaves - 1) / ksd::kTrsvWaves, grid));
     switch (local) {
       case 3: ksd::k_sptrsv<D, 3><<<g * 8, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a); break;
       case 4: ksd::k_sptrsv<D, 4><<<g * 8, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a); break;
       default: ksd::k_sptrsv<D, 0><<<g, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a);
     }
     KS_HIP(hipGetLastError());
+  }
+  // The independent parts: ONE launch, every XCD works on its own group (two 1024-thread workgroups per CU).
+  void launch_groups(ksd::TrsvArgs a, const TriFactor<D>& f, int* words) {
+    for (int g = 0; g < 8; ++g) { a.gbeg[g] = g < f.ngroups ? f.gbeg[g] : 0; a.gend[g] = g < f.ngroups ? f.gend[g] : 0; }
+    for (int k = 0; k < 16; ++k) a.xcc_group[k] = (signed char)(xcc_group[k] < f.ngroups ? xcc_group[k] : -1);
+    a.ticket = words;
+    ksd::k_sptrsv<D, 5><<<ctx->num_cu * 2, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a);
+    KS_HIP(hipGetLastError());
+    ksd::k_trsv_check<<<1, 64, 0, ctx->stream>>>(words, f.needed_d, f.ngroups, err_d);
+    KS_HIP(hipGetLastError());
+  }
+  void solve(const ksd::TrsvArgs& a, const TriFactor<D>& f, int* words) {
+    if (f.ngroups == 0) { launch_rows(a, 0, f.rows, words); return; }
+    if (f.top_first) launch_rows(a, f.top_begin, f.top_end, words);
+    launch_groups(a, f, words + 4);
+    if (!f.top_first) launch_rows(a, f.top_begin, f.top_end, words);
   }
   void apply(const void* x, void* y, const DevState*) override {
     ctx->check_comm();  // (of earlier products: the word is written by the device)
@@ -643,9 +772,9 @@ template <class D> struct LuOp : ks_operator {
     // L z = P_in (s o x)
     a.rowptr = L.rowptr; a.colind = L.colind; a.val = L.val; a.diag = L.diag; a.sol = L.sol;
     a.rhs = x; a.src = src_l; a.scale = scale_l;
-    KS_HIP(hipMemsetAsync(tickets, 0, 16 * sizeof(int), ctx->stream));
+    KS_HIP(hipMemsetAsync(tickets, 0, 80 * sizeof(int), ctx->stream));
     a.timeline = timeline;
-    solve(a, L.rows, tickets);
+    solve(a, L, tickets);
     // U w = z;  y[perm_out] = w
     a.rowptr = U.rowptr; a.colind = U.colind; a.val = U.val; a.diag = U.diag; a.sol = U.sol;
     a.rhs = nullptr; a.rhs_ll = L.sol; a.src = src_u; a.scale = nullptr;
@@ -653,7 +782,7 @@ template <class D> struct LuOp : ks_operator {
     if (stats) a.stats = stats + 12;
     const size_t nchunks = 4 * (size_t)tl_rows;
     if (timeline) a.timeline = timeline + nchunks;
-    solve(a, U.rows, tickets + 8);
+    solve(a, U, tickets + 40);
     if (timeline) {
       std::vector<unsigned long long> h(2 * nchunks);
       KS_HIP(hipMemcpyAsync(h.data(), timeline, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -690,8 +819,23 @@ ks_operator* make_lu(ks_ctx* ctx, int64_t n, const int64_t* lrp, const int32_t* 
       seen[p[i]] = 1;
     }
   }
-  upload_factor<D>(op->L, n, lrp, lci, static_cast<const D*>(lv), true, "ks_operator_lu: L");
-  upload_factor<D>(op->U, n, urp, uci, static_cast<const D*>(uv), false, "ks_operator_lu: U");
+  {
+    // which XCDs does this device have?  (8 on an unpartitioned MI355X; the groups are dealt to the ids that answer)
+    unsigned* mask_d = nullptr;
+    unsigned mask = 0;
+    KS_HIP(hipMalloc(&mask_d, sizeof(unsigned)));
+    KS_HIP(hipMemsetAsync(mask_d, 0, sizeof(unsigned), ctx->stream));
+    ksd::k_xcc_probe<<<ctx->num_cu * 8, 64, 0, ctx->stream>>>(mask_d);
+    KS_HIP(hipGetLastError());
+    KS_HIP(hipMemcpyAsync(&mask, mask_d, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    KS_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(mask_d);
+    op->nxcc = 0;
+    for (int k = 0; k < 16; ++k) op->xcc_group[k] = (mask >> k & 1u) && op->nxcc < 8 ? op->nxcc++ : 127;
+  }
+  const int want_groups = std::min(op->nxcc, std::max(1, env_int("KS_LU_GROUPS", 8)));
+  upload_factor<D>(op->L, n, lrp, lci, static_cast<const D*>(lv), true, "ks_operator_lu: L", want_groups);
+  upload_factor<D>(op->U, n, urp, uci, static_cast<const D*>(uv), false, "ks_operator_lu: U", want_groups);
   op->nnz = op->L.nnz + op->U.nnz + n;
   // index arrays between the caller's vectors and the rows of the two systems the kernel solves
   const int64_t nl = op->L.rows, nu = op->U.rows;
@@ -720,8 +864,8 @@ ks_operator* make_lu(ks_ctx* ctx, int64_t n, const int64_t* lrp, const int32_t* 
   std::vector<int32_t>().swap(op->L.order); std::vector<int32_t>().swap(op->L.pos);
   std::vector<int32_t>().swap(op->U.order); std::vector<int32_t>().swap(op->U.pos);
   std::vector<char>().swap(op->L.kind); std::vector<char>().swap(op->U.kind);
-  KS_HIP(hipMalloc(&op->tickets, 16 * sizeof(int)));
-  KS_HIP(hipMemset(op->tickets, 0, 16 * sizeof(int)));
+  KS_HIP(hipMalloc(&op->tickets, 80 * sizeof(int)));
+  KS_HIP(hipMemset(op->tickets, 0, 80 * sizeof(int)));
   op->err_d = ctx->operr_dev();
   // two 1024-thread workgroups per CU of one XCD (launched 8x over, KS_LU_XCD=3/4) or 64 workgroups anywhere (=0: fewer
   // waiting waves are faster there, each polls through the fabric)

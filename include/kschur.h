@@ -162,6 +162,10 @@ int ks_operator_lu(ks_ctx* ctx, int64_t n, int dtype, const int64_t* l_rowptr, c
                    const int32_t* perm_out, const double* scale, ks_operator** out);
 /* strictly triangular stored entries and dependency-chain lengths ("levels") of the two factors */
 int ks_operator_lu_info(const ks_operator* op, int64_t* nnz_l, int64_t* nnz_u, int64_t* levels_l, int64_t* levels_u);
+/* how one factor (upper = 0 / 1) is laid out for the device: rows of the system the kernel solves (n + 2 per row of an
+ * inverted dense run - 1), rows in such runs, rows of the part next to the root of the elimination tree that runs on one
+ * XCD, and the number of independent groups the rest was split into (0: one launch for everything) */
+int ks_operator_lu_layout(const ks_operator* op, int upper, int64_t* rows, int64_t* run_rows, int64_t* top_rows, int* ngroups);
 int ks_operator_destroy(ks_operator* op);
 int ks_operator_size(const ks_operator* op, int64_t* n_local, int64_t* nnz, int* dtype);
 /* Device layout chosen for a stored matrix at upload (mul!(y, A, x), src/expansion.jl:121; all layouts give bit-identical y):

@@ -7,11 +7,16 @@ import numpy as np
 
 raw = np.fromfile(sys.argv[1], dtype=np.uint64).astype(np.float64).reshape(2, -1, 4)
 for name, a in (("first factor", raw[0]), ("second factor", raw[1])):
+    a = a[a[:, 2] > 0]  # (rows of the other factor's padding)
     n = a.shape[0]
     t0 = a[:, 0].min()
     tick, far, pub, m = (a[:, 0] - t0) * 0.01, (a[:, 1] - t0) * 0.01, (a[:, 2] - t0) * 0.01, a[:, 3]
     front = np.maximum.accumulate(pub)
     print(f"{name}: {n} rows, {front[-1]:.0f} us")
+    # rows published per 100 us
+    edges = np.arange(0.0, pub.max() + 100.0, 100.0)
+    hist, _ = np.histogram(pub, bins=edges)
+    print("   rows published per 100 us:", " ".join(str(int(h)) for h in hist))
     for frac in (0.5, 0.9, 0.98, 0.99, 0.995, 1.0):
         k = min(n - 1, int(frac * n) - 1)
         print(f"   {100 * frac:5.1f} % of the rows published after {front[k]:9.1f} us")
