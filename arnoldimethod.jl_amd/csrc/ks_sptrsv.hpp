@@ -8,25 +8,33 @@
 //
 // Algorithm: synchronisation-free sparse triangular solve in CSR row form.  One wavefront per row; the lanes hold the
 // row's off-diagonal entries and wait for the solution entries they need to appear, then the wave reduces and publishes
-// the row's entry.  No launch per dependency level: ONE launch per triangular factor.
-//   * Rows are RENUMBERED on the host by dependency level (stable: ties keep the elimination order).  Any topological
-//     order keeps a triangular factor triangular; this one puts everything that can run concurrently next to each other
-//     (the window of rows in flight is then full of independent rows -- in elimination order the backward solve walks
-//     the elimination tree depth-first and the window holds one dependent path: measured 5x slower than the forward
-//     solve) and it puts a chain of single-row levels -- the dense triangle of a separator -- on consecutive rows.
-//     Both factors become LOWER triangular in their own numbering; the permutations between the caller's x, the two
-//     numberings and the caller's y are folded into three index arrays.
+// the row's entry.  No launch per dependency level: one or two launches per triangular factor.
+// Host side, once (upload_factor):
+//   * The LAST K pivots (the separators next to the root of the elimination tree) are the "top" part.  Without them the
+//     factor falls apart into independent parts (connected components of its dependency graph), which are packed by work
+//     into up to 8 groups: ONE launch runs all groups, each on its own XCD (every hand-over inside that XCD's L2), a
+//     second launch runs the top part on one XCD -- after the groups for the lower factor, before them for the upper one.
+//   * Inside each of these segments the rows are RENUMBERED by dependency level (stable: ties keep the elimination
+//     order).  Any topological order keeps a triangular factor triangular; this one puts what can run concurrently next to
+//     each other (in elimination order the backward solve walks the elimination tree depth-first and the window of rows
+//     in flight holds one dependent path: measured 5x slower than the forward solve).  Both factors become LOWER
+//     triangular in their own numbering; the permutations between the caller's x, the two numberings and the caller's y
+//     are folded into three index arrays.
+//   * Where the levels are narrow -- the dense triangles of the separators: a chain -- runs of up to 256 consecutive rows
+//     are INVERTED (x_run = T^-1 s_run), which turns 256 dependent hand-overs into two (see "dense runs" below).
+// Device side (k_sptrsv):
 //   * Solution entries are published as "LL" words -- 32 bits of payload + the 32-bit sequence number of this solve in
 //     one 8-byte atomic store -- so a reader that sees the sequence number has the data (no flag + fence pair, nothing
 //     to reset between solves).  Float64: 2 words per entry, ComplexF64: 4.
-//   * Rows are handed out through a ticket counter in that order (one workgroup = 16 consecutive rows, one per wave),
+//   * Rows are handed out through a ticket counter in numbering order (one workgroup = 16 consecutive rows, one per wave),
 //     so every row a resident wave waits for belongs to a workgroup that already runs or has finished: forward progress
 //     does not depend on the dispatch order of workgroups.
 //   * Every wait is bounded by a wall-clock budget (KS_LU_TIMEOUT_S, default 20 s): reports KS_ERR_OPERATOR at the next
 //     synchronisation point of the context instead of hanging the device (the host rejects malformed factors up front;
-//     this guards what it cannot see, e.g. a device that is shared with a process that starves the producers).
-// The product is bound by the LENGTH OF THE DEPENDENCY CHAIN (levels x hand-over latency), not by bytes;
-// ks_operator_lu_info reports it so a caller can judge an ordering (fill-reducing with a short elimination tree).
+//     this guards what it cannot see, e.g. a device shared with a process that starves the producers).
+// The product is bound by dependency chains and memory round trips, not by bytes (profiles/r03_shift_invert.txt has the
+// path from 605 ms to 2.9 ms per product at n = 5e5); ks_operator_lu_info / _layout report levels, fill, groups and runs so
+// a caller can judge an ordering (fill-reducing with a short, bushy elimination tree).
 #pragma once
 
 namespace ksd {

@@ -105,6 +105,36 @@ def _unpermute(B, p, q):
     return B.tocsr()[ip][:, iq]
 
 
+def test_layout_variants_agree(monkeypatch):
+    """The device layout of a factor -- independent parts on separate XCDs (KS_LU_GROUPS), dense runs of narrow levels
+    inverted on the host (KS_LU_RUN), one XCD or all of them for the part next to the root (KS_LU_XCD) -- changes the
+    order of the sums, not the result: every variant within 1e-11 of the host solve, and the default layout of a 2-D
+    problem really uses groups and runs (otherwise this test would compare a variant with itself)."""
+    nx, ny = 120, 130
+    n = nx * ny
+    rng = np.random.default_rng(9)
+    A = (_lap2d(nx, ny).astype(np.complex128) + 1j * sp.diags(0.3 * rng.random(n))).tocsc()
+    lu = spla.splu((A - (1.7 + 0.1j) * sp.identity(n)).tocsc(), permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    b = rng.random(n) + 1j * rng.random(n)
+    x = lu.solve(b)
+    seen = {}
+    for name, env in (("default", {}), ("one launch", {"KS_LU_GROUPS": "1"}), ("substitution only", {"KS_LU_RUN": "0"}),
+                      ("short runs", {"KS_LU_RUN": "64"}), ("all XCDs", {"KS_LU_XCD": "0", "KS_LU_GROUPS": "1"}), ("stores through", {"KS_LU_XCD": "4"})):
+        for k in ("KS_LU_GROUPS", "KS_LU_RUN", "KS_LU_XCD"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = pkg.Context(0)
+        op = pkg.splu_operator(lu, ctx)
+        y, _ = _apply(op, b, ctx)
+        assert np.abs(y - x).max() <= TOL * np.abs(x).max(), name
+        seen[name] = op.lu_info
+    d = seen["default"]
+    assert d["groups_l"] >= 2 and d["groups_u"] >= 2 and d["run_rows_l"] > 0 and d["run_rows_u"] > 0, d
+    assert d["rows_l"] == n + d["run_rows_l"] and d["top_rows_l"] < n // 2, d
+    assert seen["one launch"]["groups_l"] == 0 and seen["substitution only"]["run_rows_l"] == 0
+
+
 def test_malformed_factors_are_refused_on_the_host():
     ctx = pkg.Context(0)
     n = 6

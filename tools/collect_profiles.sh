@@ -58,3 +58,9 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('  iterations/s', round(d['value'],1), ' rotate', d['roofline']['per_class']['rotate'])" >> $OUT/rotation.txt
 done
 ls -la $OUT
+# (shift-invert, ks_operator_lu) the two sparse triangular solves of a product on tools/lu_bench.py's 2-D problems
+python $REPO/tools/lu_bench.py 200 250 --reps 20 --solve > $OUT/lu_n5e4.txt 2>&1
+LU_RESTARTS=6 python $REPO/tools/lu_bench.py 500 1000 --reps 10 --solve > $OUT/lu_n5e5.txt 2>&1
+KS_LU_STATS=1 python $REPO/tools/lu_bench.py 500 1000 --reps 1 2>&1 | grep "lu L\|lu U" | tail -2 >> $OUT/lu_n5e5.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_lu -- python $REPO/tools/lu_bench.py 500 1000 --reps 20 > /dev/null 2>> $OUT/bench.err
+cp "$(find /tmp/kt_lu -name '*kernel_stats.csv' | head -1)" $OUT/lu_kernel_stats.csv

@@ -68,7 +68,7 @@ def main():
     t = time.time()
     x = lu.solve(b)
     th = time.time() - t
-    print(f"  error vs lu.solve: {np.abs(y - x).max() / np.abs(x).max():.2e}; residual {np.abs(M @ y - b).max():.2e}; host solve {1e3 * th:.1f} ms", flush=True)
+    print(f"  error vs lu.solve: {np.abs(y - x).max() / np.abs(x).max():.2e}; residual {np.abs(M @ y - b).max():.2e} (host solve: {np.abs(M @ x - b).max():.2e}); host solve {1e3 * th:.1f} ms", flush=True)
     ctx.synchronize()
     t = time.time()
     for _ in range(reps):
