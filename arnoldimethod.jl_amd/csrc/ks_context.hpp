@@ -162,8 +162,10 @@ struct ks_ctx {
   }
   // a bounded spin of the peer-to-peer kernels gave up: report instead of computing on garbage
   void check_comm() const {
-    if (operr_h && *operr_h != 0)
+    if (operr_h && *operr_h != 0) {
+      *operr_h = 0;  // reported once: the operator's next product starts clean (its vectors of THIS product are garbage)
       throw KsError{KS_ERR_OPERATOR, "sparse triangular solve gave up waiting for a solution entry (KS_LU_TIMEOUT_S): malformed factor or a stalled device"};
+    }
     if (p2p.err_h && *p2p.err_h != 0)
       throw KsError{KS_ERR_COMM, "peer-to-peer exchange timed out waiting for a peer (first reported by rank " +
                                      std::to_string(*p2p.err_h - 1) + ")"};

@@ -61,6 +61,7 @@ struct TrsvArgs {
   uint32_t seq;
   int backoff;             // nap between two polls of the awaited entry, in units of 128 clocks
   int nap_lds;             // nap between two polls of an LDS flag, in units of 64 clocks
+  int64_t stall_row;       // fault injection (KS_LU_INJECT_STALL=<row>): this row is never published; -1: none
   unsigned long long* timeline;  // KS_LU_TIMELINE=<prefix>: per row, wall clock (10 ns ticks): ticket obtained, far part summed, published; entries from its own chunk
   unsigned long long* stats;  // KS_LU_STATS=1: [0] ticks in ticket + barriers [1] rows [2] ticks of rows [3] ticks at the gate [4] ticks on LDS only
                               // [5] gate polls [6] attempts [7] cached hits [8] cached misses [9] coherent tries (per lane)
@@ -314,7 +315,7 @@ __global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
     st_near += a.stats ? (unsigned long long)(wall_clock64() - tn0) : 0;
     D x = sub_(b, acc);
     if (dinv) x = mul_(x, piv);
-    if (lane == 0) {
+    if (lane == 0 && r != a.stall_row) {
       xs[wave] = x;
       __hip_atomic_store(&ready[wave], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       ll_put<D, LOCAL>(a.sol + (size_t)r * W, x, a.seq);
@@ -721,6 +722,7 @@ template <class D> struct LuOp : ks_operator {
   int* err_d = nullptr;      // the context's pinned error word (checked at every synchronisation point of the context)
   uint32_t seq = 0;
   int grid = 0, backoff = 2, nap_lds = 1;
+  int64_t stall_row = -1;
   long long timeout_ticks = 0;
   unsigned long long* stats = nullptr;  // KS_LU_STATS=1
   unsigned long long* timeline = nullptr;  // KS_LU_TIMELINE=<file prefix>: 2 x 4 x tl_rows
@@ -775,6 +777,7 @@ template <class D> struct LuOp : ks_operator {
     a.seq = seq;
     a.backoff = backoff;
     a.nap_lds = nap_lds;
+    a.stall_row = stall_row;
     a.stats = stats;
     if (stats) KS_HIP(hipMemsetAsync(stats, 0, 24 * 8, ctx->stream));
     // L z = P_in (s o x)
@@ -881,6 +884,7 @@ ks_operator* make_lu(ks_ctx* ctx, int64_t n, const int64_t* lrp, const int32_t* 
   op->grid = std::max(1, env_int("KS_LU_GRID", op->local ? std::max(1, ctx->num_cu / 8) * 2 : 64));
   op->backoff = std::max(0, env_int("KS_LU_BACKOFF", 2));  // nap between two polls of a missing entry, x 128 clocks
   op->nap_lds = std::max(0, env_int("KS_LU_NAP_LDS", 1));
+  op->stall_row = env_int("KS_LU_INJECT_STALL", -1);  // tests: the bounded waits must end in KS_ERR_OPERATOR, not in a hung device
   op->timeout_ticks = (long long)env_int("KS_LU_TIMEOUT_S", 20) * 100000000LL;
   if (std::getenv("KS_LU_TIMELINE")) {
     op->tl_rows = std::max(op->L.rows, op->U.rows);

@@ -135,6 +135,61 @@ def test_layout_variants_agree(monkeypatch):
     assert seen["one launch"]["groups_l"] == 0 and seen["substitution only"]["run_rows_l"] == 0
 
 
+def test_a_row_that_never_arrives_ends_in_an_error_not_in_a_hung_device(monkeypatch):
+    """Every wait of the solve kernel has a wall-clock budget (KS_LU_TIMEOUT_S).  Fault injection: one row is never
+    published; everything that depends on it gives up after the budget, the kernel ENDS, and the failure surfaces as
+    KS_ERR_OPERATOR at the next synchronisation point.  The flag is reported once: the same context then runs an intact
+    operator correctly."""
+    import time
+
+    n = 3000
+    ctx = pkg.Context(0)
+    rng = np.random.default_rng(0)
+    # bidiagonal factors: every row has a dependent, whatever the device numbering makes of row 7
+    L = sp.diags([0.5 * rng.random(n - 1) + 0.1], [-1], shape=(n, n), format="csr")
+    U = sp.diags([1.0 + rng.random(n), 0.3 * rng.random(n - 1)], [0, 1], shape=(n, n), format="csr")
+    b = rng.random(n)
+    monkeypatch.setenv("KS_LU_TIMEOUT_S", "1")
+    monkeypatch.setenv("KS_LU_INJECT_STALL", "7")
+    bad = pkg.lu_operator(L, U, ctx=ctx)
+    monkeypatch.delenv("KS_LU_INJECT_STALL")
+    good = pkg.lu_operator(L, U, ctx=ctx)
+    ws = pkg.ArnoldiWorkspace(n, 4, np.float64, ctx=ctx)
+    ws.set_col(0, b)
+    t = time.time()
+    with pytest.raises(pkg.HipError, match="gave up waiting"):
+        ws.apply(bad, 0, 1)
+        ctx.synchronize()
+    assert time.time() - t < 30.0
+    ws.apply(good, 0, 1)
+    ctx.synchronize()
+    x = spla.spsolve_triangular(U, spla.spsolve_triangular((L + sp.identity(n)).tocsr(), b, lower=True), lower=False)
+    assert np.abs(ws.col(1) - x).max() <= TOL * np.abs(x).max()
+
+
+def test_sparse_shift_invert_helper():
+    """`extras.sparse_shift_invert(A, sigma)`: factorisation on the host, operator on the device."""
+    import importlib
+
+    extras = importlib.import_module(pkg.__name__ + ".extras")
+    n = 2500
+    ctx = pkg.Context(0)
+    rng = np.random.default_rng(4)
+    A = _lap2d(50, 50)
+    sigma = 0.913
+    op = extras.sparse_shift_invert(A, sigma, ctx)
+    b = rng.random(n)
+    y, _ = _apply(op, b, ctx)
+    x = spla.spsolve((A - sigma * sp.identity(n)).tocsc(), b)
+    assert np.abs(y - x).max() <= 1e-9 * np.abs(x).max()
+    dec, hist = pkg.partialschur(op, nev=4, which="LM", tol=1e-10)
+    assert hist.converged
+    lam = np.sort(sigma + 1.0 / np.real(np.asarray(dec.eigenvalues)))
+    exact = np.sort(np.linalg.eigvalsh(A.toarray()))
+    near = exact[np.argsort(np.abs(exact - sigma))[:4]]
+    assert np.abs(lam - np.sort(near)).max() <= 1e-8
+
+
 def test_malformed_factors_are_refused_on_the_host():
     ctx = pkg.Context(0)
     n = 6
