@@ -549,10 +549,61 @@ void upload_factor(TriFactor<D>& f, int64_t n, const int64_t* rp, const int32_t*
   // the rows of x on the s of their run only (entries -T^-1).  The kernel solves the augmented system as it stands: the
   // chain through a run of R rows is two hand-overs through memory instead of R.  (Inverted diagonal blocks are what
   // dense triangular solves do on GPUs; the factors of a pivoted LU keep the inverse of such a block tame.)
+  // A run is only taken if its inverse is tame: kappa = max|T^-1| * max|T| <= KS_LU_RUN_COND (default 1e4).  The factors
+  // of an UNPIVOTED factorisation of an indefinite matrix (shift-invert with diagonal pivots) can have triangles whose
+  // inverses grow; multiplying by such an inverse costs digits that substitution keeps (measured on a real, nearly
+  // singular 2-D problem: residual 9e-9 without runs, 6e-7 with runs of 256, the host solve 7e-8).  A run that fails is
+  // halved, and halved again; what is left under 16 rows stays a chain.
   const int64_t R = std::max(0, env_int("KS_LU_RUN", 256));
   const int64_t narrow = std::max(1, env_int("KS_LU_NARROW", 16));
+  const double kappa_max = (double)std::max(1, env_int("KS_LU_RUN_COND", 10000));
+  using cplx_t = std::complex<double>;
+  auto to_c = [](const D& v) { return to_complex_host(v); };
+  struct Run { int64_t a, b; std::vector<cplx_t> Ti; };
+  std::vector<Run> runs;                        // in increasing row order
   std::vector<char> in_run((size_t)n, 0);       // level-numbered row is part of a run
-  std::vector<int64_t> run_begin;               // first row of each run (level numbering), and a final sentinel
+  double kappa_seen = 0.0;
+  int64_t rejected = 0;
+  auto invert = [&](int64_t a, int64_t b, std::vector<cplx_t>& Ti) {
+    const int64_t r = b - a;
+    std::vector<cplx_t> T((size_t)(r * r), cplx_t(0.0, 0.0));
+    double tmax = 0.0, imax = 0.0;
+    for (int64_t q = a; q < b; ++q) {
+      T[(size_t)((q - a) * r + (q - a))] = with_diag ? to_c(dg[f.order[q]]) : cplx_t(1.0, 0.0);
+      for (int64_t p = nrp[q]; p < nrp[q + 1]; ++p)
+        if (nci[p] >= a) T[(size_t)((q - a) * r + (nci[p] - a))] = to_c(nv[p]);
+    }
+    for (const cplx_t& v : T) tmax = std::max(tmax, std::abs(v));
+    // Ti = T^-1, column by column (forward substitution on the identity)
+    Ti.assign((size_t)(r * r), cplx_t(0.0, 0.0));
+    for (int64_t c = 0; c < r; ++c) {
+      Ti[(size_t)(c * r + c)] = cplx_t(1.0, 0.0) / T[(size_t)(c * r + c)];
+      for (int64_t q = c + 1; q < r; ++q) {
+        cplx_t acc(0.0, 0.0);
+        const cplx_t* trow = &T[(size_t)(q * r)];
+        for (int64_t t = c; t < q; ++t)
+          if (trow[t] != cplx_t(0.0, 0.0)) acc += trow[t] * Ti[(size_t)(t * r + c)];
+        Ti[(size_t)(q * r + c)] = -acc / trow[q];
+      }
+    }
+    for (const cplx_t& v : Ti) imax = std::max(imax, std::abs(v));
+    return tmax * imax;
+  };
+  std::function<void(int64_t, int64_t)> take = [&](int64_t a, int64_t b) {
+    if (b - a < 16) return;
+    std::vector<cplx_t> Ti;
+    const double kappa = invert(a, b, Ti);
+    if (kappa <= kappa_max) {
+      kappa_seen = std::max(kappa_seen, kappa);
+      for (int64_t q = a; q < b; ++q) in_run[q] = 1;
+      runs.push_back(Run{a, b, std::move(Ti)});
+      return;
+    }
+    ++rejected;
+    const int64_t mid = (a + b) / 2;
+    take(a, mid);
+    take(mid, b);
+  };
   if (R >= 2) {
     // in every segment (the top part and each group has its own narrow end: its sub-separators)
     for (int sg = 0; sg < nseg; ++sg) {
@@ -567,9 +618,7 @@ void upload_factor(TriFactor<D>& f, int64_t n, const int64_t* rp, const int32_t*
           j = e;
         }
         if (j - i >= 32) {
-          for (int64_t a = i; a < j; a += R) run_begin.push_back(a);
-          for (int64_t q = i; q < j; ++q) in_run[q] = 1;
-          run_begin.push_back(-j);  // (negative: the stretch ends here)
+          for (int64_t a = i; a < j; a += R) take(a, std::min(a + R, j));
           i = j;
         } else {
           i = j > i ? j : level_end(i);
@@ -577,10 +626,13 @@ void upload_factor(TriFactor<D>& f, int64_t n, const int64_t* rp, const int32_t*
       }
     }
   }
+  if (env_int("KS_LU_STATS", 0))
+    std::fprintf(stderr, "[lu %s] %zu dense runs inverted (largest max|T^-1| max|T| = %.3g), %lld pieces refused and halved (limit %.3g)\n", lower ? "L" : "U", runs.size(), kappa_seen, (long long)rejected, kappa_max);
   // augmented numbering: a row outside the runs keeps one unknown; a run of r rows becomes r rows of s, then r rows of x
   std::vector<int32_t> xidx((size_t)n, 0);      // level-numbered row -> augmented index of its x
   std::vector<int32_t> aug_owner;               // augmented row -> level-numbered row
   std::vector<char> aug_kind;                   // 0: ordinary row, 1: s row, 2: x row
+  std::vector<int32_t> aug_run;                 // augmented row -> index of its run (-1: none)
   std::vector<int64_t> seg_aug((size_t)nseg + 1, 0);  // segment boundaries in the augmented numbering
   {
     size_t rb = 0;
@@ -592,15 +644,14 @@ void upload_factor(TriFactor<D>& f, int64_t n, const int64_t* rp, const int32_t*
         xidx[i] = (int32_t)aug_owner.size();
         aug_owner.push_back((int32_t)i);
         aug_kind.push_back(0);
+        aug_run.push_back(-1);
         ++i;
         continue;
       }
-      while (rb < run_begin.size() && (run_begin[rb] < 0 || run_begin[rb] < i)) ++rb;
-      const int64_t a = run_begin[rb];
-      const int64_t nxt = run_begin[rb + 1];
-      const int64_t b = nxt < 0 ? -nxt : nxt;
-      for (int64_t q = a; q < b; ++q) { aug_owner.push_back((int32_t)q); aug_kind.push_back(1); }
-      for (int64_t q = a; q < b; ++q) { xidx[q] = (int32_t)aug_owner.size(); aug_owner.push_back((int32_t)q); aug_kind.push_back(2); }
+      while (runs[rb].a < i) ++rb;
+      const int64_t a = runs[rb].a, b = runs[rb].b;
+      for (int64_t q = a; q < b; ++q) { aug_owner.push_back((int32_t)q); aug_kind.push_back(1); aug_run.push_back((int32_t)rb); }
+      for (int64_t q = a; q < b; ++q) { xidx[q] = (int32_t)aug_owner.size(); aug_owner.push_back((int32_t)q); aug_kind.push_back(2); aug_run.push_back((int32_t)rb); }
       i = b;
       ++rb;
     }
@@ -613,51 +664,23 @@ void upload_factor(TriFactor<D>& f, int64_t n, const int64_t* rp, const int32_t*
   std::vector<D> av, adg((size_t)N, from_real_host(1.0, D{}));
   aci.reserve(nci.size() + (size_t)(N - n) * 8);
   av.reserve(nci.size() + (size_t)(N - n) * 8);
-  using cplx_t = std::complex<double>;
-  auto to_c = [](const D& v) { return to_complex_host(v); };
-  std::vector<cplx_t> T, Ti;
-  int64_t run_a = -1, run_b = -1;  // the run whose inverse is in Ti
   for (int64_t k = 0; k < N; ++k) {
     const int64_t i = aug_owner[k];
     if (aug_kind[k] == 0) {
       for (int64_t p = nrp[i]; p < nrp[i + 1]; ++p) { aci.push_back(xidx[nci[p]]); av.push_back(nv[p]); }
       if (with_diag) adg[k] = inverse_host(dg[f.order[i]]);
     } else if (aug_kind[k] == 1) {
-      if (run_a < 0 || i < run_a || i >= run_b) {
-        // first s row of a run: its extent is the block of s rows that starts here
-        run_a = i;
-        int64_t e = k;
-        while (e < N && aug_kind[e] == 1) ++e;
-        run_b = run_a + (e - k);
-        const int64_t r = run_b - run_a;
-        T.assign((size_t)(r * r), cplx_t(0.0, 0.0));
-        for (int64_t q = run_a; q < run_b; ++q) {
-          T[(size_t)((q - run_a) * r + (q - run_a))] = with_diag ? to_c(dg[f.order[q]]) : cplx_t(1.0, 0.0);
-          for (int64_t p = nrp[q]; p < nrp[q + 1]; ++p)
-            if (nci[p] >= run_a) T[(size_t)((q - run_a) * r + (nci[p] - run_a))] = to_c(nv[p]);
-        }
-        // Ti = T^-1, column by column (forward substitution on the identity)
-        Ti.assign((size_t)(r * r), cplx_t(0.0, 0.0));
-        for (int64_t c = 0; c < r; ++c) {
-          Ti[(size_t)(c * r + c)] = cplx_t(1.0, 0.0) / T[(size_t)(c * r + c)];
-          for (int64_t q = c + 1; q < r; ++q) {
-            cplx_t acc(0.0, 0.0);
-            const cplx_t* trow = &T[(size_t)(q * r)];
-            for (int64_t t = c; t < q; ++t)
-              if (trow[t] != cplx_t(0.0, 0.0)) acc += trow[t] * Ti[(size_t)(t * r + c)];
-            Ti[(size_t)(q * r + c)] = -acc / trow[q];
-          }
-        }
-      }
       // s row: the entries outside the run, unit pivot
+      const int64_t run_a = runs[aug_run[k]].a;
       for (int64_t p = nrp[i]; p < nrp[i + 1]; ++p)
         if (nci[p] < run_a) { aci.push_back(xidx[nci[p]]); av.push_back(nv[p]); }
     } else {
       // x row: x_i = sum_j Ti[i][j] s_j  ->  entries -Ti on the s rows of the run (they sit r rows before the x rows)
-      const int64_t r = run_b - run_a, q = i - run_a;
-      const int32_t s0 = xidx[run_a] - (int32_t)r;
+      const Run& rn = runs[aug_run[k]];
+      const int64_t r = rn.b - rn.a, q = i - rn.a;
+      const int32_t s0 = xidx[rn.a] - (int32_t)r;
       for (int64_t t = 0; t <= q; ++t) {
-        const cplx_t w = Ti[(size_t)(q * r + t)];
+        const cplx_t w = rn.Ti[(size_t)(q * r + t)];
         if (w != cplx_t(0.0, 0.0)) { aci.push_back(s0 + (int32_t)t); av.push_back(from_complex_host(-w, D{})); }
       }
     }

@@ -190,6 +190,33 @@ def test_sparse_shift_invert_helper():
     assert np.abs(lam - np.sort(near)).max() <= 1e-8
 
 
+def test_unpivoted_indefinite_factors_keep_the_accuracy_of_substitution(monkeypatch):
+    """Real shift inside the spectrum, factorisation with diagonal pivots only: a nearly singular, badly scaled pair of
+    factors whose dense triangles have inverses that GROW.  Inverted runs are only taken while max|T^-1| max|T| stays under
+    KS_LU_RUN_COND, so the product keeps the residual of plain substitution (and of the host solve of the same factors);
+    with the limit lifted the residual is visibly worse -- which is what the limit is for."""
+    nx, ny = 150, 160
+    n = nx * ny
+    A = _lap2d(nx, ny)
+    M = (A - 1.7 * sp.identity(n)).tocsc()
+    lu = spla.splu(M, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    b = np.random.default_rng(3).random(n)
+    x = lu.solve(b)
+    host = np.abs(M @ x - b).max()
+    res = {}
+    for name, env in (("default", {}), ("no runs", {"KS_LU_RUN": "0"}), ("no limit", {"KS_LU_RUN_COND": "2000000000"})):
+        for k in ("KS_LU_RUN", "KS_LU_RUN_COND"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = pkg.Context(0)
+        op = pkg.splu_operator(lu, ctx)
+        y, _ = _apply(op, b, ctx)
+        res[name] = np.abs(M @ y - b).max()
+    assert res["default"] <= 4.0 * max(host, res["no runs"]), (res, host)
+    assert res["default"] <= res["no limit"] * 1.0001 + 1e-300, (res, host)
+
+
 def test_malformed_factors_are_refused_on_the_host():
     ctx = pkg.Context(0)
     n = 6
