@@ -153,17 +153,20 @@ int ks_operator_device_callback(ks_ctx* ctx, int64_t n_local, int dtype, ks_devi
  *   perm_out   y[perm_out[i]] = entry i of U^-1 L^-1 (...)             (NULL: identity)
  * SuiteSparse UMFPACK (Julia `F = lu(A)`: (Rs .* A)[p, q] = L U): perm_in = p-1, scale = Rs, perm_out = q-1, factors
  * transposed from CSC.  SuperLU (scipy `splu`: Pr A Pc = L U): perm_in = inverse(perm_r), perm_out = inverse(perm_c).
- * One launch per factor (synchronisation-free solve: a row's wavefront waits for the entries it needs); the cost is the
- * length of the longest dependency chain, which ks_operator_lu_info reports next to the stored entries -- choose a
- * fill-reducing ordering with a short elimination tree.  A wait that exceeds KS_LU_TIMEOUT_S (20) surfaces as
- * KS_ERR_OPERATOR at the next synchronisation point of the context.  Single-GPU contexts only. */
+ * One or two launches per factor (synchronisation-free solves: a row's wavefront waits for the entries it needs; independent
+ * parts of the factor run on separate XCDs, dense triangles of narrow dependency levels are inverted at upload while their
+ * inverses stay tame -- KS_LU_RUN_COND).  The cost is dependency chains and memory round trips, not bytes:
+ * ks_operator_lu_info / ks_operator_lu_layout report levels, fill and the device layout -- choose a fill-reducing ordering
+ * with a short, bushy elimination tree.  Products are deterministic (bit-identical when repeated).  A wait that exceeds
+ * KS_LU_TIMEOUT_S (20) ends the kernel and surfaces ONCE as KS_ERR_OPERATOR at the next synchronisation point of the
+ * context (the vectors of that product are garbage).  Single-GPU contexts only. */
 int ks_operator_lu(ks_ctx* ctx, int64_t n, int dtype, const int64_t* l_rowptr, const int32_t* l_colind, const void* l_val,
                    const int64_t* u_rowptr, const int32_t* u_colind, const void* u_val, const int32_t* perm_in,
                    const int32_t* perm_out, const double* scale, ks_operator** out);
 /* strictly triangular stored entries and dependency-chain lengths ("levels") of the two factors */
 int ks_operator_lu_info(const ks_operator* op, int64_t* nnz_l, int64_t* nnz_u, int64_t* levels_l, int64_t* levels_u);
-/* how one factor (upper = 0 / 1) is laid out for the device: rows of the system the kernel solves (n + 2 per row of an
- * inverted dense run - 1), rows in such runs, rows of the part next to the root of the elimination tree that runs on one
+/* how one factor (upper = 0 / 1) is laid out for the device: rows of the system the kernel solves (n + one more per row
+ * of an inverted dense run), rows in such runs, rows of the part next to the root of the elimination tree that runs on one
  * XCD, and the number of independent groups the rest was split into (0: one launch for everything) */
 int ks_operator_lu_layout(const ks_operator* op, int upper, int64_t* rows, int64_t* run_rows, int64_t* top_rows, int* ngroups);
 int ks_operator_destroy(ks_operator* op);
