@@ -150,6 +150,8 @@ __device__ __forceinline__ bool trsv_expired(int* err, long long t0, long long b
 //     of its current batch -- with W lanes, and only when that has arrived do its lanes fetch theirs again: thousands
 //     of waiting waves cost a few loads per microsecond each instead of 64 x W (which saturates the fabric and slows
 //     the producers: measured 25 us per level).
+// (one 1024-thread workgroup per CU: with registers for two -- 64 VGPRs, unroll 2 -- a product takes 4.7 instead of 2.9 ms:
+// twice the waiting waves poll twice as much, and what a chain needs is a quick hand-over, not occupancy)
 constexpr int kTrsvWaves = 16, kTrsvUnroll = 4;
 
 // LOCAL: the launch is 8x oversubscribed and only the workgroups that landed on ONE XCD work -- the XCD of whichever
@@ -178,8 +180,11 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
 }
 __device__ __forceinline__ cd wave_sum_dpp(cd v) { return cd{wave_sum_dpp(v.x), wave_sum_dpp(v.y)}; }
 
-template <class D, int LOCAL>
+template <class D, int LOCAL, bool PROBE>
 __global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
+  // (the probes -- ten per-lane counters, clock reads -- cost a third of the register budget: compiled out unless asked for)
+  unsigned long long* const stats_ = PROBE ? a.stats : nullptr;
+  unsigned long long* const timeline_ = PROBE ? a.timeline : nullptr;
   constexpr int W = LLWords<D>::W, C = kTrsvWaves, U = kTrsvUnroll;
   __shared__ D xs[C];
   __shared__ int ready[C];
@@ -205,12 +210,12 @@ __global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
   }
   unsigned long long st_ticket = 0, st_rows = 0, st_row = 0, st_gate = 0, st_near = 0, st_polls = 0, st_att = 0, st_hit = 0, st_miss = 0, st_coh = 0;
   for (;;) {
-    const long long tk0 = a.stats ? wall_clock64() : 0;
+    const long long tk0 = stats_ ? wall_clock64() : 0;
     __syncthreads();
     if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1);
     if (threadIdx.x < C) ready[threadIdx.x] = 0;
     __syncthreads();
-    const long long tk1 = (a.stats || a.timeline) ? wall_clock64() : 0;
+    const long long tk1 = (stats_ || timeline_) ? wall_clock64() : 0;
     st_ticket += (unsigned long long)(tk1 - tk0);
     const int64_t base = row0 + (int64_t)s_ticket * C;
     if (base >= nend) break;
@@ -283,7 +288,7 @@ __global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
         for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(gate, off, 64); gate = o > gate ? o : gate; }
         ++st_att;
         if (gate < 0) break;  // batch complete
-        const long long tg0 = a.stats ? wall_clock64() : 0;
+        const long long tg0 = stats_ ? wall_clock64() : 0;
         const uint64_t* g = a.sol + (size_t)gate * W;
         for (;;) {
           bool ok = true;
@@ -293,16 +298,16 @@ __global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
           for (int q = 0; q < a.backoff; ++q) __builtin_amdgcn_s_sleep(2);
           if (trsv_expired(a.err, t0, a.timeout_ticks, spins++)) { dead = true; break; }
         }
-        st_gate += a.stats ? (unsigned long long)(wall_clock64() - tg0) : 0;
+        st_gate += stats_ ? (unsigned long long)(wall_clock64() - tg0) : 0;
         if (dead) break;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) acc = fma_(av[u], xv[u], acc);
     }
     acc = wave_sum_dpp(acc);
-    const unsigned long long tl_far = a.timeline ? (unsigned long long)wall_clock64() : 0;
+    const unsigned long long tl_far = timeline_ ? (unsigned long long)wall_clock64() : 0;
     // the chain: entries of this chunk, oldest first, every lane in step
-    const long long tn0 = a.stats ? wall_clock64() : 0;
+    const long long tn0 = stats_ ? wall_clock64() : 0;
     for (int k = m - 1; k >= 0 && !dead; --k) {
       const int li = __builtin_amdgcn_readlane(li_reg, k);
       const D av = lane_value(av_reg, k);
@@ -312,7 +317,7 @@ __global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
       }
       acc = fma_(av, xs[li], acc);
     }
-    st_near += a.stats ? (unsigned long long)(wall_clock64() - tn0) : 0;
+    st_near += stats_ ? (unsigned long long)(wall_clock64() - tn0) : 0;
     D x = sub_(b, acc);
     if (dinv) x = mul_(x, piv);
     if (lane == 0 && r != a.stall_row) {
@@ -323,21 +328,21 @@ __global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
         const int64_t d = a.dst[r];
         if (d >= 0) static_cast<D*>(a.out)[d] = x;
       }
-      if (a.timeline) {
-        unsigned long long* tl = a.timeline + 4 * (size_t)r;
+      if (timeline_) {
+        unsigned long long* tl = timeline_ + 4 * (size_t)r;
         tl[0] = (unsigned long long)tk1; tl[1] = tl_far; tl[2] = (unsigned long long)wall_clock64(); tl[3] = (unsigned long long)m;
       }
     }
-    if (a.stats) { ++st_rows; st_row += (unsigned long long)(wall_clock64() - tk1); }
+    if (stats_) { ++st_rows; st_row += (unsigned long long)(wall_clock64() - tk1); }
   }
-  if (a.stats) {
+  if (stats_) {
     unsigned long long v[3] = {st_hit, st_miss, st_coh};  // per-lane counters -> wave totals
     for (int k = 0; k < 3; ++k)
       for (int off = 32; off >= 1; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
     if (lane == 0) {
       const unsigned long long w[10] = {st_ticket, st_rows, st_row, st_gate, st_near, st_polls, st_att, v[0], v[1], v[2]};
-      for (int k = 0; k < 10; ++k) atomicAdd(a.stats + k, w[k]);
-      if (wave == 0) { atomicOr(a.stats + 10, 1ull << xcc_id()); atomicAdd(a.stats + 11, 1ull); }
+      for (int k = 0; k < 10; ++k) atomicAdd(stats_ + k, w[k]);
+      if (wave == 0) { atomicOr(stats_ + 10, 1ull << xcc_id()); atomicAdd(stats_ + 11, 1ull); }
     }
   }
 }
@@ -744,7 +749,7 @@ template <class D> struct LuOp : ks_operator {
   int local = 3;             // form of the tail launch (KS_LU_XCD): 3 = one XCD, stores to its L2; 4 = one XCD, stores through; 0 = all XCDs
   int* err_d = nullptr;      // the context's pinned error word (checked at every synchronisation point of the context)
   uint32_t seq = 0;
-  int grid = 0, backoff = 2, nap_lds = 1;
+  int grid = 0, grid_groups = 256, backoff = 2, nap_lds = 1;
   int64_t stall_row = -1;
   long long timeout_ticks = 0;
   unsigned long long* stats = nullptr;  // KS_LU_STATS=1
@@ -762,10 +767,14 @@ template <class D> struct LuOp : ks_operator {
     if (row1 <= row0) return;
     a.row0 = row0; a.n = row1; a.ticket = words;
     const int g = (int)std::max<int64_t>(1, std::min<int64_t>((row1 - row0 + ksd::kTrsvWaves - 1) / ksd::kTrsvWaves, grid));
+    const bool probe = a.stats || a.timeline;
     switch (local) {
-      case 3: ksd::k_sptrsv<D, 3><<<g * 8, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a); break;
-      case 4: ksd::k_sptrsv<D, 4><<<g * 8, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a); break;
-      default: ksd::k_sptrsv<D, 0><<<g, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a);
+      case 3:
+        if (probe) ksd::k_sptrsv<D, 3, true><<<g * 8, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a);
+        else ksd::k_sptrsv<D, 3, false><<<g * 8, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a);
+        break;
+      case 4: ksd::k_sptrsv<D, 4, false><<<g * 8, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a); break;
+      default: ksd::k_sptrsv<D, 0, false><<<g, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a);
     }
     KS_HIP(hipGetLastError());
   }
@@ -774,7 +783,8 @@ template <class D> struct LuOp : ks_operator {
     for (int g = 0; g < 8; ++g) { a.gbeg[g] = g < f.ngroups ? f.gbeg[g] : 0; a.gend[g] = g < f.ngroups ? f.gend[g] : 0; }
     for (int k = 0; k < 16; ++k) a.xcc_group[k] = (signed char)(xcc_group[k] < f.ngroups ? xcc_group[k] : -1);
     a.ticket = words;
-    ksd::k_sptrsv<D, 5><<<ctx->num_cu * 2, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a);
+    if (a.stats || a.timeline) ksd::k_sptrsv<D, 5, true><<<grid_groups, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a);
+    else ksd::k_sptrsv<D, 5, false><<<grid_groups, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a);
     KS_HIP(hipGetLastError());
     ksd::k_trsv_check<<<1, 64, 0, ctx->stream>>>(words, f.needed_d, f.ngroups, err_d);
     KS_HIP(hipGetLastError());
@@ -905,6 +915,7 @@ ks_operator* make_lu(ks_ctx* ctx, int64_t n, const int64_t* lrp, const int32_t* 
   // waiting waves are faster there, each polls through the fabric)
   op->local = env_int("KS_LU_XCD", 3);
   op->grid = std::max(1, env_int("KS_LU_GRID", op->local ? std::max(1, ctx->num_cu / 8) * 2 : 64));
+  op->grid_groups = std::max(8, env_int("KS_LU_GRID_GROUPS", ctx->num_cu));  // one workgroup per CU
   op->backoff = std::max(0, env_int("KS_LU_BACKOFF", 2));  // nap between two polls of a missing entry, x 128 clocks
   op->nap_lds = std::max(0, env_int("KS_LU_NAP_LDS", 1));
   op->stall_row = env_int("KS_LU_INJECT_STALL", -1);  // tests: the bounded waits must end in KS_ERR_OPERATOR, not in a hung device
