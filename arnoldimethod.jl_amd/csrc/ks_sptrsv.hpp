@@ -42,6 +42,8 @@ namespace ksd {
 struct TrsvArgs {
   int64_t row0, n;         // this launch solves rows [row0, n) (everything before is complete: earlier launch)
   const int64_t* rowptr;   // strictly lower triangular part in the factor's own (level) numbering, CSR, columns ascending
+  const int64_t* rowbegin; // first entry of row r this launch has to sum itself (== rowptr, or past the entries a pre-pass summed)
+  const void* pre;         // pre-summed part of every row (nullptr: none)
   const int32_t* colind;
   const void* val;
   const void* diag;        // n INVERSE diagonal entries; nullptr: unit diagonal
@@ -221,7 +223,7 @@ __global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
     if (base >= nend) break;
     const int64_t r = base + wave;
     if (r >= nend) continue;
-    const int64_t p0 = a.rowptr[r], p1 = a.rowptr[r + 1];
+    const int64_t p0 = a.rowbegin[r], p1 = a.rowptr[r + 1];
     // Entries produced by THIS workgroup: the last m of the row (columns ascend).  Lane l < 16 looks at entry p1-1-l;
     // they are consumed one by one at the end, in column order, by the whole wave in step (no reduction on the chain).
     int li_reg = -1;
@@ -244,6 +246,7 @@ __global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
       } else {
         b = ll_payload<D>(a.rhs_ll + (size_t)s * W);
       }
+      if (a.pre) b = sub_(b, static_cast<const D*>(a.pre)[r]);
     }
     const D piv = dinv ? dinv[r] : zero_of(D{});
     D acc = zero_of(D{});
@@ -347,6 +350,23 @@ __global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
   }
 }
 
+// Pre-pass of a factor's SECOND launch: the entries of its rows that refer to rows of the first launch need no waiting
+// (that launch is complete) and no particular XCD -- one wave per row over the whole device, plain cached loads.  What is
+// left for the solve kernel of the part next to the root (one XCD: bandwidth of one XCD) is the part that really is a chain.
+template <class D>
+__global__ void __launch_bounds__(256) k_trsv_pre(int64_t row0, int64_t row1, const int64_t* __restrict__ rowptr, const int64_t* __restrict__ rowmid,
+                                                  const int32_t* __restrict__ colind, const D* __restrict__ val, const uint64_t* __restrict__ sol, D* __restrict__ pre) {
+  constexpr int W = LLWords<D>::W;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t r = row0 + wave; r < row1; r += nwaves) {
+    D acc = zero_of(D{});
+    for (int64_t p = rowptr[r] + lane; p < rowmid[r]; p += 64) acc = fma_(val[p], ll_payload<D>(sol + (size_t)colind[p] * W), acc);
+    acc = wave_sum_dpp(acc);
+    if (lane == 0) pre[r] = acc;
+  }
+}
+
 // which XCC ids exist on this device (bit mask)
 __global__ void k_xcc_probe(unsigned* mask) {
   if (threadIdx.x == 0) atomicOr(mask, 1u << xcc_id());
@@ -394,13 +414,16 @@ template <class D> struct TriFactor {
   int64_t top_begin = 0, top_end = 0;   // rows of the top launch (kernel numbering)
   int64_t gbeg[8] = {}, gend[8] = {};
   int* needed_d = nullptr;          // tickets each group has to hand out (k_trsv_check)
+  int64_t* rowmid = nullptr;        // second launch: first entry of a row that refers to a row of the SAME launch (before it: pre-pass)
+  D* pre = nullptr;                 // pre-pass sums (rows of the second launch)
+  int64_t second_begin = 0, second_end = 0;
   int64_t* rowptr = nullptr;
   int32_t* colind = nullptr;
   D* val = nullptr;
   D* diag = nullptr;     // inverse diagonal entries; nullptr: unit diagonal
   uint64_t* sol = nullptr;
   void release() {
-    (void)hipFree(rowptr); (void)hipFree(colind); (void)hipFree(val); (void)hipFree(diag); (void)hipFree(sol); (void)hipFree(needed_d);
+    (void)hipFree(rowptr); (void)hipFree(colind); (void)hipFree(val); (void)hipFree(diag); (void)hipFree(sol); (void)hipFree(needed_d); (void)hipFree(rowmid); (void)hipFree(pre);
   }
 };
 
@@ -716,6 +739,18 @@ void upload_factor(TriFactor<D>& f, int64_t n, const int64_t* rp, const int32_t*
     }
     KS_HIP(hipMalloc(&f.needed_d, (size_t)G * sizeof(int)));
     KS_HIP(hipMemcpy(f.needed_d, needed.data(), (size_t)G * sizeof(int), hipMemcpyHostToDevice));
+    if (env_int("KS_LU_PREPASS", 1)) {
+      // rows of the second launch: lower factor = the top part (after the groups), upper factor = the groups (after the top part)
+      f.second_begin = lower ? f.top_begin : f.top_end;
+      f.second_end = lower ? f.top_end : N;
+      std::vector<int64_t> mid(arp.begin(), arp.end());
+      for (int64_t r = f.second_begin; r < f.second_end; ++r)
+        mid[r] = std::lower_bound(aci.begin() + arp[r], aci.begin() + arp[r + 1], (int32_t)f.second_begin) - aci.begin();
+      KS_HIP(hipMalloc(&f.rowmid, ((size_t)N + 1) * 8));
+      KS_HIP(hipMemcpy(f.rowmid, mid.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice));
+      KS_HIP(hipMalloc(&f.pre, (size_t)N * sizeof(D)));
+      KS_HIP(hipMemset(f.pre, 0, (size_t)N * sizeof(D)));
+    }
   }
   f.nnz = (int64_t)nci.size();
   const bool any_pivot = with_diag || N > n;
@@ -789,11 +824,27 @@ template <class D> struct LuOp : ks_operator {
     ksd::k_trsv_check<<<1, 64, 0, ctx->stream>>>(words, f.needed_d, f.ngroups, err_d);
     KS_HIP(hipGetLastError());
   }
-  void solve(const ksd::TrsvArgs& a, const TriFactor<D>& f, int* words) {
+  void prepass(const TriFactor<D>& f) {
+    const int64_t rows = f.second_end - f.second_begin;
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((rows + 3) / 4, (int64_t)ctx->num_cu * 8));
+    ksd::k_trsv_pre<D><<<nb, 256, 0, ctx->stream>>>(f.second_begin, f.second_end, f.rowptr, f.rowmid, f.colind, f.val, f.sol, f.pre);
+    KS_HIP(hipGetLastError());
+  }
+  void solve(ksd::TrsvArgs a, const TriFactor<D>& f, int* words) {
+    a.rowbegin = f.rowptr;
+    a.pre = nullptr;
     if (f.ngroups == 0) { launch_rows(a, 0, f.rows, words); return; }
-    if (f.top_first) launch_rows(a, f.top_begin, f.top_end, words);
-    launch_groups(a, f, words + 4);
-    if (!f.top_first) launch_rows(a, f.top_begin, f.top_end, words);
+    ksd::TrsvArgs a2 = a;  // the second launch sums only what the pre-pass left
+    if (f.rowmid) { a2.rowbegin = f.rowmid; a2.pre = f.pre; }
+    if (f.top_first) {
+      launch_rows(a, f.top_begin, f.top_end, words);
+      if (f.rowmid) prepass(f);
+      launch_groups(a2, f, words + 4);
+    } else {
+      launch_groups(a, f, words + 4);
+      if (f.rowmid) prepass(f);
+      launch_rows(a2, f.top_begin, f.top_end, words);
+    }
   }
   void apply(const void* x, void* y, const DevState*) override {
     ctx->check_comm();  // (of earlier products: the word is written by the device)

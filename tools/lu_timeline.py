@@ -20,6 +20,9 @@ for name, a in (("first factor", raw[0]), ("second factor", raw[1])):
     for frac in (0.5, 0.9, 0.98, 0.99, 0.995, 1.0):
         k = min(n - 1, int(frac * n) - 1)
         print(f"   {100 * frac:5.1f} % of the rows published after {front[k]:9.1f} us")
+    # by position in the numbering (the groups are contiguous ranges): when did each sixteenth of the rows start / finish?
+    parts = np.array_split(np.arange(n), 16)
+    print("   sixteenths of the numbering, first ticket .. last row published (us): " + "  ".join(f"{tick[q].min():.0f}..{pub[q].max():.0f}" for q in parts))
     # the slowest stretch: 1024 consecutive rows with the largest time span
     w = 1024
     span = front[w:] - front[:-w]
