@@ -33,7 +33,7 @@
 //     synchronisation point of the context instead of hanging the device (the host rejects malformed factors up front;
 //     this guards what it cannot see, e.g. a device shared with a process that starves the producers).
 // The product is bound by dependency chains and memory round trips, not by bytes (profiles/r03_shift_invert.txt has the
-// path from 605 ms to 2.9 ms per product at n = 5e5); ks_operator_lu_info / _layout report levels, fill, groups and runs so
+// path from 605 ms to 2.3 ms per product at n = 5e5); ks_operator_lu_info / _layout report levels, fill, groups and runs so
 // a caller can judge an ordering (fill-reducing with a short, bushy elimination tree).
 #pragma once
 
@@ -583,7 +583,7 @@ void upload_factor(TriFactor<D>& f, int64_t n, const int64_t* rp, const int32_t*
   // singular 2-D problem: residual 9e-9 without runs, 6e-7 with runs of 256, the host solve 7e-8).  A run that fails is
   // halved, and halved again; what is left under 16 rows stays a chain.
   const int64_t R = std::max(0, env_int("KS_LU_RUN", 256));
-  const int64_t narrow = std::max(1, env_int("KS_LU_NARROW", 16));
+  const int64_t narrow = std::max(1, env_int("KS_LU_NARROW", 64));
   const double kappa_max = (double)std::max(1, env_int("KS_LU_RUN_COND", 10000));
   using cplx_t = std::complex<double>;
   auto to_c = [](const D& v) { return to_complex_host(v); };
