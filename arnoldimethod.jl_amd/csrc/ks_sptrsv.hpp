@@ -33,7 +33,7 @@
 //     synchronisation point of the context instead of hanging the device (the host rejects malformed factors up front;
 //     this guards what it cannot see, e.g. a device shared with a process that starves the producers).
 // The product is bound by dependency chains and memory round trips, not by bytes (profiles/r03_shift_invert.txt has the
-// path from 605 ms to 2.3 ms per product at n = 5e5); ks_operator_lu_info / _layout report levels, fill, groups and runs so
+// path from 605 ms to 2.0 ms per product at n = 5e5); ks_operator_lu_info / _layout report levels, fill, groups and runs so
 // a caller can judge an ordering (fill-reducing with a short, bushy elimination tree).
 #pragma once
 
@@ -409,21 +409,26 @@ template <class D> struct TriFactor {
   // launch on one XCD; what is left falls apart into independent parts (connected components of the dependency graph),
   // packed into `ngroups` groups of similar work, one XCD each, ONE launch for all of them.  Lower factor: groups, then
   // top; upper factor (solved from the root): top, then groups.
-  int ngroups = 0;                  // 0: everything is "top" (one launch)
+  struct Layer {                    // one launch of independent groups
+    int ngroups = 0;
+    int64_t gbeg[8] = {}, gend[8] = {};   // rows of the groups (kernel numbering)
+    int64_t begin = 0, end = 0;           // all of them
+    int* needed_d = nullptr;              // tickets each group has to hand out (k_trsv_check)
+  };
+  std::vector<Layer> layers;        // in LAUNCH order; empty: everything is "top" (one launch)
+  int ngroups = 0;                  // groups of the outermost layer (reported)
   bool top_first = false;
   int64_t top_begin = 0, top_end = 0;   // rows of the top launch (kernel numbering)
-  int64_t gbeg[8] = {}, gend[8] = {};
-  int* needed_d = nullptr;          // tickets each group has to hand out (k_trsv_check)
-  int64_t* rowmid = nullptr;        // second launch: first entry of a row that refers to a row of the SAME launch (before it: pre-pass)
-  D* pre = nullptr;                 // pre-pass sums (rows of the second launch)
-  int64_t second_begin = 0, second_end = 0;
+  int64_t* rowmid = nullptr;        // per row: first entry that refers to a row of the SAME launch (before it: pre-pass)
+  D* pre = nullptr;                 // pre-pass sums
   int64_t* rowptr = nullptr;
   int32_t* colind = nullptr;
   D* val = nullptr;
   D* diag = nullptr;     // inverse diagonal entries; nullptr: unit diagonal
   uint64_t* sol = nullptr;
   void release() {
-    (void)hipFree(rowptr); (void)hipFree(colind); (void)hipFree(val); (void)hipFree(diag); (void)hipFree(sol); (void)hipFree(needed_d); (void)hipFree(rowmid); (void)hipFree(pre);
+    (void)hipFree(rowptr); (void)hipFree(colind); (void)hipFree(val); (void)hipFree(diag); (void)hipFree(sol); (void)hipFree(rowmid); (void)hipFree(pre);
+    for (auto& l : layers) (void)hipFree(l.needed_d);
   }
 };
 
@@ -481,8 +486,10 @@ void upload_factor(TriFactor<D>& f, int64_t n, const int64_t* rp, const int32_t*
   // Without them the rest of the factor falls apart into independent parts -- connected components of its dependency
   // graph -- which are packed by work into groups, one XCD each.  K: the smallest of 128, 256, 512, ... for which the
   // heaviest group stays under 1.75 / groups of the work (found by adding rows to a union-find from the largest K down).
-  std::vector<int32_t> seg((size_t)n, 0);  // 0 .. G-1: group; G: top   (lower)  /  0: top; 1 .. G: group  (upper)
-  int G = 0;
+  // The same is then done to the top part itself (its own last K' pivots stay, the rest falls apart again), up to four
+  // layers: what is finally left for ONE XCD is the root separator and its nearest descendants.
+  struct LayerPlan { int64_t lo, cut; int bins; std::vector<int32_t> bin; };  // pivots [lo, cut) in `bins` groups
+  std::vector<LayerPlan> plan;
   if (want_groups > 1 && n >= 4096) {
     // edges keyed by their LARGER endpoint: the rows of the lower factor as they are, the columns of the upper one
     std::vector<int64_t> ep;
@@ -498,54 +505,80 @@ void upload_factor(TriFactor<D>& f, int64_t n, const int64_t* rp, const int32_t*
         for (int64_t p = srp[r]; p < srp[r + 1]; ++p) ei[fill[sci[p]]++] = (int32_t)r;
     }
     std::vector<int32_t> parent((size_t)n);
-    for (int64_t r = 0; r < n; ++r) parent[r] = (int32_t)r;
     auto find = [&](int32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
-    std::vector<int64_t> cand;
-    for (int64_t K = 128; K <= n / 2; K *= 2) cand.push_back(K);
     std::vector<double> work((size_t)n), load;
-    std::vector<int32_t> comps, bin_of((size_t)n, 0), best_bin;
-    int64_t added = 0, best_K = -1;  // rows [0, added) are in the union-find
-    int best_bins = 0;
-    for (size_t k = cand.size(); k-- > 0;) {
-      const int64_t K = cand[k], nb = n - K;
-      for (int64_t r = added; r < nb; ++r)
-        for (int64_t p = ep[r]; p < ep[r + 1]; ++p) { const int32_t a = find((int32_t)r), b = find(ei[p]); if (a != b) parent[a] = b; }
-      added = nb;
-      std::fill(work.begin(), work.begin() + nb, 0.0);
-      double total = 0.0;
-      for (int64_t r = 0; r < nb; ++r) { const double w = (double)(srp[r + 1] - srp[r]) + 8.0; work[find((int32_t)r)] += w; total += w; }
-      comps.clear();
-      for (int64_t r = 0; r < nb; ++r) if (parent[r] == r) comps.push_back((int32_t)r);
-      std::sort(comps.begin(), comps.end(), [&](int32_t a, int32_t b) { return work[a] != work[b] ? work[a] > work[b] : a < b; });
-      const int bins = std::min<int>(want_groups, (int)comps.size());
-      load.assign((size_t)bins, 0.0);
-      for (int32_t c : comps) {
-        int best = 0;
-        for (int b = 1; b < bins; ++b) if (load[b] < load[best]) best = b;
-        bin_of[c] = best;
-        load[best] += work[c];
+    std::vector<int32_t> comps, bin_of((size_t)n, 0);
+    const int max_layers = std::max(1, env_int("KS_LU_LAYERS", 4));
+    int64_t lo = 0;
+    for (int depth = 0; depth < max_layers && n - lo >= (depth == 0 ? 4096 : 1024); ++depth) {
+      for (int64_t r = lo; r < n; ++r) parent[r] = (int32_t)r;
+      std::vector<int64_t> cand;
+      for (int64_t K = depth == 0 ? 128 : 64; K <= (n - lo) / 2; K *= 2) cand.push_back(K);
+      int64_t added = lo, best_K = -1;  // rows [lo, added) are in the union-find
+      int best_bins = 0;
+      std::vector<int32_t> best_bin;
+      for (size_t k = cand.size(); k-- > 0;) {
+        const int64_t K = cand[k], nb = n - K;
+        for (int64_t r = added; r < nb; ++r)
+          for (int64_t p = ep[r]; p < ep[r + 1]; ++p)
+            if (ei[p] >= lo) { const int32_t a = find((int32_t)r), b = find(ei[p]); if (a != b) parent[a] = b; }
+        added = nb;
+        std::fill(work.begin() + lo, work.begin() + nb, 0.0);
+        double total = 0.0;
+        for (int64_t r = lo; r < nb; ++r) { const double w = (double)(srp[r + 1] - srp[r]) + 8.0; work[find((int32_t)r)] += w; total += w; }
+        comps.clear();
+        for (int64_t r = lo; r < nb; ++r) if (parent[r] == r) comps.push_back((int32_t)r);
+        std::sort(comps.begin(), comps.end(), [&](int32_t a, int32_t b) { return work[a] != work[b] ? work[a] > work[b] : a < b; });
+        const int bins = std::min<int>(want_groups, (int)comps.size());
+        load.assign((size_t)bins, 0.0);
+        for (int32_t c : comps) {
+          int best = 0;
+          for (int b = 1; b < bins; ++b) if (load[b] < load[best]) best = b;
+          bin_of[c] = best;
+          load[best] += work[c];
+        }
+        const double worst = *std::max_element(load.begin(), load.end());
+        // the outermost layer must fill the device; further in, the tree next to the root is binary: two parts are a gain
+        const double limit = depth == 0 ? 1.75 / want_groups : std::max(1.75 / want_groups, 0.6);
+        if (bins < 2 || worst > limit * total) break;  // (smaller K only merges parts)
+        best_K = K;
+        best_bins = bins;
+        best_bin.assign((size_t)(nb - lo), 0);
+        for (int64_t r = lo; r < nb; ++r) best_bin[r - lo] = bin_of[find((int32_t)r)];
       }
-      const double worst = *std::max_element(load.begin(), load.end());
-      if (bins < 2 || worst > 1.75 / want_groups * total) break;  // (smaller K only merges parts)
-      best_K = K;
-      best_bins = bins;
-      best_bin.assign((size_t)n, -1);
-      for (int64_t r = 0; r < nb; ++r) best_bin[r] = bin_of[find((int32_t)r)];
-    }
-    if (best_K > 0) {
-      G = best_bins;
-      for (int64_t r = 0; r < n; ++r) seg[r] = r >= n - best_K ? (lower ? G : 0) : (lower ? best_bin[r] : 1 + best_bin[r]);
+      if (best_K <= 0) break;
+      plan.push_back(LayerPlan{lo, n - best_K, best_bins, std::move(best_bin)});
+      lo = n - best_K;
     }
   }
-  if (G == 0) std::fill(seg.begin(), seg.end(), 0);  // one segment: everything is "top"
+  // segments in LAUNCH order: lower factor = layers outside in, then the top; upper factor = the top, then layers inside out
+  std::vector<int32_t> seg((size_t)n, 0);
+  int nseg = 1, top_seg = 0;
+  std::vector<int> layer_first_seg(plan.size(), 0);  // per plan entry: id of its group 0
+  if (!plan.empty()) {
+    int total_groups = 0;
+    for (auto& l : plan) total_groups += l.bins;
+    nseg = total_groups + 1;
+    if (lower) {
+      int base = 0;
+      for (size_t d = 0; d < plan.size(); ++d) { layer_first_seg[d] = base; base += plan[d].bins; }
+      top_seg = total_groups;
+    } else {
+      int base = 1;
+      for (size_t d = plan.size(); d-- > 0;) { layer_first_seg[d] = base; base += plan[d].bins; }
+      top_seg = 0;
+    }
+    const int64_t top_lo = plan.back().cut;
+    for (int64_t r = top_lo; r < n; ++r) seg[r] = top_seg;
+    for (size_t d = 0; d < plan.size(); ++d)
+      for (int64_t r = plan[d].lo; r < plan[d].cut; ++r) seg[r] = layer_first_seg[d] + plan[d].bin[r - plan[d].lo];
+  }
   // numbering: by segment, inside a segment by level, ties in elimination order (stable sort of the elimination order)
   f.order.assign((size_t)n, 0);
   f.pos.assign((size_t)n, 0);
   for (int64_t t = 0; t < n; ++t) f.order[t] = (int32_t)(lower ? t : n - 1 - t);
   std::stable_sort(f.order.begin(), f.order.end(), [&](int32_t a, int32_t b) { return seg[a] != seg[b] ? seg[a] < seg[b] : lev[a] < lev[b]; });
   for (int64_t i = 0; i < n; ++i) f.pos[f.order[i]] = (int32_t)i;
-  const int nseg = G == 0 ? 1 : G + 1;
-  const int top_seg = G == 0 ? 0 : (lower ? G : 0);
   std::vector<int64_t> segb((size_t)nseg + 1, 0);  // segment boundaries in this numbering
   for (int64_t r = 0; r < n; ++r) segb[seg[r] + 1]++;
   for (int k = 0; k < nseg; ++k) segb[k + 1] += segb[k];
@@ -725,27 +758,40 @@ void upload_factor(TriFactor<D>& f, int64_t n, const int64_t* rp, const int32_t*
   }
   f.rows = N;
   f.run_rows = N - n;
-  f.ngroups = G;
+  f.ngroups = plan.empty() ? 0 : plan.front().bins;
   f.top_first = !lower;
   f.top_begin = seg_aug[top_seg];
   f.top_end = seg_aug[top_seg + 1];
-  if (G > 0) {
-    std::vector<int> needed((size_t)G);
-    for (int g = 0; g < G; ++g) {
-      const int sgi = lower ? g : 1 + g;
-      f.gbeg[g] = seg_aug[sgi];
-      f.gend[g] = seg_aug[sgi + 1];
-      needed[g] = (int)((f.gend[g] - f.gbeg[g] + ksd::kTrsvWaves - 1) / ksd::kTrsvWaves);
+  if (!plan.empty()) {
+    // layers in launch order
+    std::vector<size_t> order_d;
+    if (lower) for (size_t d = 0; d < plan.size(); ++d) order_d.push_back(d);
+    else for (size_t d = plan.size(); d-- > 0;) order_d.push_back(d);
+    for (size_t d : order_d) {
+      typename TriFactor<D>::Layer L;
+      L.ngroups = plan[d].bins;
+      std::vector<int> needed((size_t)L.ngroups);
+      for (int g = 0; g < L.ngroups; ++g) {
+        const int sgi = layer_first_seg[d] + g;
+        L.gbeg[g] = seg_aug[sgi];
+        L.gend[g] = seg_aug[sgi + 1];
+        needed[g] = (int)((L.gend[g] - L.gbeg[g] + ksd::kTrsvWaves - 1) / ksd::kTrsvWaves);
+      }
+      L.begin = L.gbeg[0];
+      L.end = L.gend[L.ngroups - 1];
+      KS_HIP(hipMalloc(&L.needed_d, (size_t)L.ngroups * sizeof(int)));
+      KS_HIP(hipMemcpy(L.needed_d, needed.data(), (size_t)L.ngroups * sizeof(int), hipMemcpyHostToDevice));
+      f.layers.push_back(L);
     }
-    KS_HIP(hipMalloc(&f.needed_d, (size_t)G * sizeof(int)));
-    KS_HIP(hipMemcpy(f.needed_d, needed.data(), (size_t)G * sizeof(int), hipMemcpyHostToDevice));
     if (env_int("KS_LU_PREPASS", 1)) {
-      // rows of the second launch: lower factor = the top part (after the groups), upper factor = the groups (after the top part)
-      f.second_begin = lower ? f.top_begin : f.top_end;
-      f.second_end = lower ? f.top_end : N;
+      // every launch but the first: the entries that refer to rows of EARLIER launches (complete by then) are summed by a
+      // pre-pass; rowmid[r] = the first entry of row r that refers to its own launch
       std::vector<int64_t> mid(arp.begin(), arp.end());
-      for (int64_t r = f.second_begin; r < f.second_end; ++r)
-        mid[r] = std::lower_bound(aci.begin() + arp[r], aci.begin() + arp[r + 1], (int32_t)f.second_begin) - aci.begin();
+      auto mark = [&](int64_t b, int64_t e) {
+        for (int64_t r = b; r < e; ++r) mid[r] = std::lower_bound(aci.begin() + arp[r], aci.begin() + arp[r + 1], (int32_t)b) - aci.begin();
+      };
+      for (auto& L : f.layers) mark(L.begin, L.end);
+      mark(f.top_begin, f.top_end);
       KS_HIP(hipMalloc(&f.rowmid, ((size_t)N + 1) * 8));
       KS_HIP(hipMemcpy(f.rowmid, mid.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice));
       KS_HIP(hipMalloc(&f.pre, (size_t)N * sizeof(D)));
@@ -778,7 +824,8 @@ template <class D> struct LuOp : ks_operator {
   double* scale_l = nullptr; //   ... times scale_l[i]
   int32_t* src_u = nullptr;  // row i of U's numbering takes entry src_u[i] of L's solution
   int32_t* dst_u = nullptr;  //   ... and its result goes to y[dst_u[i]]
-  int* tickets = nullptr;    // per factor: 4 control words of the top launch + 4 per group
+  static constexpr int kWords = 4 + 4 * 32;  // control words per factor: 4 of the top launch + 4 per group, up to 4 layers of 8
+  int* tickets = nullptr;
   int xcc_group[16];         // XCC id -> group (probed once; 127: no such XCC)
   int nxcc = 1;
   int local = 3;             // form of the tail launch (KS_LU_XCD): 3 = one XCD, stores to its L2; 4 = one XCD, stores through; 0 = all XCDs
@@ -813,38 +860,43 @@ template <class D> struct LuOp : ks_operator {
     }
     KS_HIP(hipGetLastError());
   }
-  // The independent parts: ONE launch, every XCD works on its own group (two 1024-thread workgroups per CU).
-  void launch_groups(ksd::TrsvArgs a, const TriFactor<D>& f, int* words) {
-    for (int g = 0; g < 8; ++g) { a.gbeg[g] = g < f.ngroups ? f.gbeg[g] : 0; a.gend[g] = g < f.ngroups ? f.gend[g] : 0; }
-    for (int k = 0; k < 16; ++k) a.xcc_group[k] = (signed char)(xcc_group[k] < f.ngroups ? xcc_group[k] : -1);
+  // Independent parts: ONE launch per layer, every XCD works on its own group (one 1024-thread workgroup per CU).
+  void launch_groups(ksd::TrsvArgs a, const typename TriFactor<D>::Layer& L, int* words) {
+    for (int g = 0; g < 8; ++g) { a.gbeg[g] = g < L.ngroups ? L.gbeg[g] : 0; a.gend[g] = g < L.ngroups ? L.gend[g] : 0; }
+    for (int k = 0; k < 16; ++k) a.xcc_group[k] = (signed char)(xcc_group[k] < L.ngroups ? xcc_group[k] : -1);
     a.ticket = words;
     if (a.stats || a.timeline) ksd::k_sptrsv<D, 5, true><<<grid_groups, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a);
     else ksd::k_sptrsv<D, 5, false><<<grid_groups, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a);
     KS_HIP(hipGetLastError());
-    ksd::k_trsv_check<<<1, 64, 0, ctx->stream>>>(words, f.needed_d, f.ngroups, err_d);
+    ksd::k_trsv_check<<<1, 64, 0, ctx->stream>>>(words, L.needed_d, L.ngroups, err_d);
     KS_HIP(hipGetLastError());
   }
-  void prepass(const TriFactor<D>& f) {
-    const int64_t rows = f.second_end - f.second_begin;
-    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((rows + 3) / 4, (int64_t)ctx->num_cu * 8));
-    ksd::k_trsv_pre<D><<<nb, 256, 0, ctx->stream>>>(f.second_begin, f.second_end, f.rowptr, f.rowmid, f.colind, f.val, f.sol, f.pre);
+  void prepass(const TriFactor<D>& f, int64_t b, int64_t e) {
+    if (e <= b) return;
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((e - b + 3) / 4, (int64_t)ctx->num_cu * 8));
+    ksd::k_trsv_pre<D><<<nb, 256, 0, ctx->stream>>>(b, e, f.rowptr, f.rowmid, f.colind, f.val, f.sol, f.pre);
     KS_HIP(hipGetLastError());
   }
+  // words: 4 control words for the top launch, then 32 per layer
   void solve(ksd::TrsvArgs a, const TriFactor<D>& f, int* words) {
     a.rowbegin = f.rowptr;
     a.pre = nullptr;
-    if (f.ngroups == 0) { launch_rows(a, 0, f.rows, words); return; }
-    ksd::TrsvArgs a2 = a;  // the second launch sums only what the pre-pass left
+    if (f.layers.empty()) { launch_rows(a, 0, f.rows, words); return; }
+    ksd::TrsvArgs a2 = a;  // every launch but the first sums only what its pre-pass left
     if (f.rowmid) { a2.rowbegin = f.rowmid; a2.pre = f.pre; }
-    if (f.top_first) {
-      launch_rows(a, f.top_begin, f.top_end, words);
-      if (f.rowmid) prepass(f);
-      launch_groups(a2, f, words + 4);
-    } else {
-      launch_groups(a, f, words + 4);
-      if (f.rowmid) prepass(f);
-      launch_rows(a2, f.top_begin, f.top_end, words);
+    bool first = true;
+    auto top = [&] {
+      if (!first && f.rowmid) prepass(f, f.top_begin, f.top_end);
+      launch_rows(first ? a : a2, f.top_begin, f.top_end, words);
+      first = false;
+    };
+    if (f.top_first) top();
+    for (size_t k = 0; k < f.layers.size(); ++k) {
+      if (!first && f.rowmid) prepass(f, f.layers[k].begin, f.layers[k].end);
+      launch_groups(first ? a : a2, f.layers[k], words + 4 + 32 * (int)k);
+      first = false;
     }
+    if (!f.top_first) top();
   }
   void apply(const void* x, void* y, const DevState*) override {
     ctx->check_comm();  // (of earlier products: the word is written by the device)
@@ -867,7 +919,7 @@ template <class D> struct LuOp : ks_operator {
     // L z = P_in (s o x)
     a.rowptr = L.rowptr; a.colind = L.colind; a.val = L.val; a.diag = L.diag; a.sol = L.sol;
     a.rhs = x; a.src = src_l; a.scale = scale_l;
-    KS_HIP(hipMemsetAsync(tickets, 0, 80 * sizeof(int), ctx->stream));
+    KS_HIP(hipMemsetAsync(tickets, 0, 2 * kWords * sizeof(int), ctx->stream));
     a.timeline = timeline;
     solve(a, L, tickets);
     // U w = z;  y[perm_out] = w
@@ -877,7 +929,7 @@ template <class D> struct LuOp : ks_operator {
     if (stats) a.stats = stats + 12;
     const size_t nchunks = 4 * (size_t)tl_rows;
     if (timeline) a.timeline = timeline + nchunks;
-    solve(a, U, tickets + 40);
+    solve(a, U, tickets + kWords);
     if (timeline) {
       std::vector<unsigned long long> h(2 * nchunks);
       KS_HIP(hipMemcpyAsync(h.data(), timeline, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -959,8 +1011,8 @@ ks_operator* make_lu(ks_ctx* ctx, int64_t n, const int64_t* lrp, const int32_t* 
   std::vector<int32_t>().swap(op->L.order); std::vector<int32_t>().swap(op->L.pos);
   std::vector<int32_t>().swap(op->U.order); std::vector<int32_t>().swap(op->U.pos);
   std::vector<char>().swap(op->L.kind); std::vector<char>().swap(op->U.kind);
-  KS_HIP(hipMalloc(&op->tickets, 80 * sizeof(int)));
-  KS_HIP(hipMemset(op->tickets, 0, 80 * sizeof(int)));
+  KS_HIP(hipMalloc(&op->tickets, 2 * LuOp<D>::kWords * sizeof(int)));
+  KS_HIP(hipMemset(op->tickets, 0, 2 * LuOp<D>::kWords * sizeof(int)));
   op->err_d = ctx->operr_dev();
   // two 1024-thread workgroups per CU of one XCD (launched 8x over, KS_LU_XCD=3/4) or 64 workgroups anywhere (=0: fewer
   // waiting waves are faster there, each polls through the fabric)
