@@ -118,9 +118,10 @@ def test_layout_variants_agree(monkeypatch):
     b = rng.random(n) + 1j * rng.random(n)
     x = lu.solve(b)
     seen = {}
-    for name, env in (("default", {}), ("one launch", {"KS_LU_GROUPS": "1"}), ("substitution only", {"KS_LU_RUN": "0"}),
+    for name, env in (("default", {}), ("one launch", {"KS_LU_GROUPS": "1"}), ("one layer", {"KS_LU_LAYERS": "1"}), ("no pre-pass", {"KS_LU_PREPASS": "0"}),
+                      ("substitution only", {"KS_LU_RUN": "0"}),
                       ("short runs", {"KS_LU_RUN": "64"}), ("all XCDs", {"KS_LU_XCD": "0", "KS_LU_GROUPS": "1"}), ("stores through", {"KS_LU_XCD": "4"})):
-        for k in ("KS_LU_GROUPS", "KS_LU_RUN", "KS_LU_XCD"):
+        for k in ("KS_LU_GROUPS", "KS_LU_RUN", "KS_LU_XCD", "KS_LU_LAYERS", "KS_LU_PREPASS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -133,6 +134,7 @@ def test_layout_variants_agree(monkeypatch):
     assert d["groups_l"] >= 2 and d["groups_u"] >= 2 and d["run_rows_l"] > 0 and d["run_rows_u"] > 0, d
     assert d["rows_l"] == n + d["run_rows_l"] and d["top_rows_l"] < n // 2, d
     assert seen["one launch"]["groups_l"] == 0 and seen["substitution only"]["run_rows_l"] == 0
+    assert seen["one layer"]["top_rows_l"] >= d["top_rows_l"]
 
 
 def test_a_row_that_never_arrives_ends_in_an_error_not_in_a_hung_device(monkeypatch):
