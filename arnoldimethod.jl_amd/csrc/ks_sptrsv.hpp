@@ -65,7 +65,6 @@ struct TrsvArgs {
   uint32_t seq;
   int backoff;             // nap between two polls of the awaited entry, in units of 128 clocks
   int nap_lds;             // nap between two polls of an LDS flag, in units of 64 clocks
-  int direct;              // up to this many lanes with missing entries poll them themselves instead of the gate
   int64_t stall_row;       // fault injection (KS_LU_INJECT_STALL=<row>): this row is never published; -1: none
   unsigned long long* timeline;  // KS_LU_TIMELINE=<prefix>: per row, wall clock (10 ns ticks): ticket obtained, far part summed, published; entries from its own chunk
   unsigned long long* stats;  // KS_LU_STATS=1: [0] ticks in ticket + barriers [1] rows [2] ticks of rows [3] ticks at the gate [4] ticks on LDS only
@@ -294,18 +293,6 @@ __global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
         for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(gate, off, 64); gate = o > gate ? o : gate; }
         ++st_att;
         if (gate < 0) break;  // batch complete
-        // A handful of missing entries: their lanes ask again themselves (one round trip less per hand-over than
-        // waiting at the gate and then fetching); many: one polled entry per wave, as the fabric / the L2 can take.
-        if (a.direct > 0) {
-          bool missing = false;
-#pragma unroll
-          for (int u = 0; u < U; ++u) missing = missing || need[u];
-          if (__popcll(__ballot(missing)) <= a.direct) {
-            for (int q = 0; q < a.backoff; ++q) __builtin_amdgcn_s_sleep(2);
-            if (trsv_expired(a.err, t0, a.timeout_ticks, spins++)) { dead = true; break; }
-            continue;
-          }
-        }
         const long long tg0 = stats_ ? wall_clock64() : 0;
         const uint64_t* g = a.sol + (size_t)gate * W;
         for (;;) {
@@ -846,7 +833,7 @@ template <class D> struct LuOp : ks_operator {
   int local = 3;             // form of the tail launch (KS_LU_XCD): 3 = one XCD, stores to its L2; 4 = one XCD, stores through; 0 = all XCDs
   int* err_d = nullptr;      // the context's pinned error word (checked at every synchronisation point of the context)
   uint32_t seq = 0;
-  int grid = 0, grid_groups = 256, backoff = 2, nap_lds = 1, direct = 0;
+  int grid = 0, grid_groups = 256, backoff = 2, nap_lds = 1;
   int64_t stall_row = -1;
   long long timeout_ticks = 0;
   unsigned long long* stats = nullptr;  // KS_LU_STATS=1
@@ -928,7 +915,6 @@ template <class D> struct LuOp : ks_operator {
     a.seq = seq;
     a.backoff = backoff;
     a.nap_lds = nap_lds;
-    a.direct = direct;
     a.stall_row = stall_row;
     a.stats = stats;
     if (stats) KS_HIP(hipMemsetAsync(stats, 0, 24 * 8, ctx->stream));
@@ -1037,7 +1023,6 @@ ks_operator* make_lu(ks_ctx* ctx, int64_t n, const int64_t* lrp, const int32_t* 
   op->grid_groups = std::max(8, env_int("KS_LU_GRID_GROUPS", ctx->num_cu));  // one workgroup per CU
   op->backoff = std::max(0, env_int("KS_LU_BACKOFF", 2));  // nap between two polls of a missing entry, x 128 clocks
   op->nap_lds = std::max(0, env_int("KS_LU_NAP_LDS", 1));
-  op->direct = std::max(0, env_int("KS_LU_DIRECT", 0));
   op->stall_row = env_int("KS_LU_INJECT_STALL", -1);  // tests: the bounded waits must end in KS_ERR_OPERATOR, not in a hung device
   op->timeout_ticks = (long long)env_int("KS_LU_TIMEOUT_S", 20) * 100000000LL;
   if (std::getenv("KS_LU_TIMELINE")) {
