@@ -73,12 +73,13 @@ struct TrsvArgs {
 
 template <class D> struct LLWords { static constexpr int W = (int)(sizeof(D) / 4); };
 
-// LOCAL (3, 4): every producer and consumer of the launch runs on ONE XCD (see k_sptrsv).  Measured, 216x250 grid / 500x1000
-// grid, ms per product: all XCDs 2.7 / 13.5 (and 15-40 once more than ~64 workgroups wait: every poll crosses the fabric);
-// one XCD 3.1 / -- with device-scope stores (4); 2.2 / 13.9 with stores that stop at that XCD's L2 (3, the default: the
-// workgroup-scope bits, sc0) and device-scope loads.  Loads with the workgroup-scope bits never see another CU's store
-// (they are served by the CU's own cache, which neither snoops nor is dropped by `buffer_inv sc0`): the solve stalls until
-// its time budget ends.  Whatever a load returns, a word carrying the current sequence number is valid data.
+// LOCAL (3, 4, 5): every producer and consumer of a launch (of a group, 5) runs on ONE XCD (see k_sptrsv).  Measured before
+// the factor was cut into groups and runs, 200 x 250 / 500 x 1000 grid, ms per product: all XCDs 2.7 / 13.5 (and 15-65 once
+// more than ~64 workgroups wait: every poll crosses the fabric); one XCD 3.1 / -- with device-scope stores (4); 2.2 / 13.9
+// with stores that stop at that XCD's L2 (3 and 5: the workgroup-scope bits, sc0) and device-scope loads, which that L2
+// serves.  Loads with the workgroup-scope bits never see another CU's store (they are served by the CU's own cache, which
+// neither snoops nor is dropped by `buffer_inv sc0`): the solve stalls until its time budget ends.  Whatever a load
+// returns, a word carrying the current sequence number is valid data.
 template <int LOCAL> __device__ __forceinline__ uint64_t ll_word(const uint64_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -297,7 +298,7 @@ __global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
         const uint64_t* g = a.sol + (size_t)gate * W;
         for (;;) {
           bool ok = true;
-            if (lane < W) ok = (uint32_t)(ll_word<LOCAL>(g + lane) >> 32) == a.seq;
+          if (lane < W) ok = (uint32_t)(ll_word<LOCAL>(g + lane) >> 32) == a.seq;
           ++st_polls;
           if (__all(ok)) break;
           for (int q = 0; q < a.backoff; ++q) __builtin_amdgcn_s_sleep(2);
