@@ -419,6 +419,8 @@ def as_operator(A, ctx: Context | None = None) -> Operator:
         return csr_operator(A, ctx)
     if sp.issparse(A):
         return csr_operator(A, ctx)
+    if all(hasattr(A, k) for k in ("L", "U", "perm_r", "perm_c", "solve")):
+        return splu_operator(A, ctx)  # a scipy SuperLU factorisation: the operator is x -> A^-1 x, applied on the device
     shp = getattr(A, "shape", None)
     if shp is None or len(shp) != 2 or shp[0] != shp[1]:
         raise DimensionMismatch(f"matrix is not square: dimensions are {shp}")

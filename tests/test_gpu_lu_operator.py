@@ -253,7 +253,8 @@ def test_shift_invert_solve_matches_the_host_callback(cplx):
     else:
         sigma = 1.7003
     lu = spla.splu((A - sigma * sp.identity(n)).tocsc(), permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
-    op = pkg.splu_operator(lu, ctx)
+    op = pkg.as_operator(lu, ctx)  # (a SuperLU object is recognised: same as pkg.splu_operator)
+    assert "levels_l" in op.lu_info
     dt = op.dtype
 
     def cb(y, x):
