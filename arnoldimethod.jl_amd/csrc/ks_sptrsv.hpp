@@ -155,8 +155,9 @@ __device__ __forceinline__ bool trsv_expired(int* err, long long t0, long long b
 //     of its current batch -- with W lanes, and only when that has arrived do its lanes fetch theirs again: thousands
 //     of waiting waves cost a few loads per microsecond each instead of 64 x W (which saturates the fabric and slows
 //     the producers: measured 25 us per level).
-// (one 1024-thread workgroup per CU: with registers for two -- 64 VGPRs, unroll 2 -- a product takes 4.7 instead of 2.9 ms:
-// twice the waiting waves poll twice as much, and what a chain needs is a quick hand-over, not occupancy)
+// (one 1024-thread workgroup per CU: with registers for two -- 64 VGPRs at unroll 2 with spills, or unroll 1 without -- a
+// product is slower, 4.7 against 2.9 ms at the time and 2.2-2.3 against 2.0 in the final form: more rows in flight do not
+// pay, shorter batches cost; what a chain needs is a quick hand-over, not occupancy)
 constexpr int kTrsvWaves = 16, kTrsvUnroll = 4;
 
 // LOCAL: the launch is 8x oversubscribed and only the workgroups that landed on ONE XCD work -- the XCD of whichever
