@@ -219,6 +219,46 @@ def test_unpivoted_indefinite_factors_keep_the_accuracy_of_substitution(monkeypa
     assert res["default"] <= res["no limit"] * 1.0001 + 1e-300, (res, host)
 
 
+def test_trivial_factors_and_mixed_element_types():
+    """n = 1; a lower factor with no stored entries at all; a pure permutation (identity factors); real L with complex U
+    (promoted to ComplexF64 as `vtype` would)."""
+    ctx = pkg.Context(0)
+    # n = 1
+    op = pkg.lu_operator(sp.csr_matrix((1, 1)), sp.csr_matrix([[4.0]]), ctx=ctx)
+    ws = pkg.ArnoldiWorkspace(1, 1, np.float64, ctx=ctx)
+    ws.set_col(0, np.array([2.0]))
+    ws.apply(op, 0, 1)
+    assert ws.col(1)[0] == 0.5
+    # empty L, diagonal U, both permutations
+    n = 100
+    rng = np.random.default_rng(1)
+    d = 1.0 + rng.random(n)
+    p, q = rng.permutation(n), rng.permutation(n)
+    op = pkg.lu_operator(sp.csr_matrix((n, n)), sp.diags(d).tocsr(), perm_in=p, perm_out=q, ctx=ctx)
+    b = rng.random(n)
+    y, _ = _apply(op, b, ctx)
+    x = np.empty(n)
+    x[q] = b[p] / d
+    assert np.abs(y - x).max() <= 1e-15 * np.abs(x).max()
+    # real L, complex U
+    L = sp.diags([0.3 * rng.random(n - 1)], [-1], shape=(n, n), format="csr")
+    U = sp.diags([1.0 + rng.random(n) + 0.2j, 0.1j * rng.random(n - 1)], [0, 1], shape=(n, n), format="csr")
+    op = pkg.lu_operator(L, U, ctx=ctx)
+    assert op.dtype == np.complex128
+    bc = rng.random(n) + 1j * rng.random(n)
+    y, _ = _apply(op, bc, ctx)
+    x = spla.spsolve_triangular(U, spla.spsolve_triangular((L + sp.identity(n)).tocsr().astype(np.complex128), bc, lower=True), lower=False)
+    assert np.abs(y - x).max() <= TOL * np.abs(x).max()
+
+
+def test_refused_on_a_distributed_context():
+    """A triangular solve does not shard by rows: the operator exists for single-GPU contexts only."""
+    ctx = pkg.Context(0, rank=0, nranks=1, hostcomm=(lambda buf: None, lambda peers, send, recv: None))
+    I = sp.identity(8, format="csr")
+    with pytest.raises(pkg.ArgumentError, match="single-GPU"):
+        pkg.lu_operator(I, I, ctx=ctx)
+
+
 def test_malformed_factors_are_refused_on_the_host():
     ctx = pkg.Context(0)
     n = 6
