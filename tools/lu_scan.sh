@@ -1,9 +1,21 @@
 #!/bin/bash
-# the knobs of the sparse triangular solves (csrc/ks_sptrsv.hpp) on tools/lu_bench.py's 2-D shift-invert problems
-export KS_LU_TIMEOUT_S=${KS_LU_TIMEOUT_S:-3}
-for g in 64 128 256 512; do
-  echo "all XCDs grid $g: $(KS_LU_XCD=0 KS_LU_GRID=$g timeout 100 python tools/lu_bench.py 500 1000 --reps 5 2>&1 | grep 'device product')"
-done
-for r in 0 64 128 256 512; do
-  echo "one XCD, runs of $r: $(KS_LU_RUN=$r timeout 100 python tools/lu_bench.py 500 1000 --reps 5 2>&1 | grep 'device product\|error vs' | tr '\n' ' ')"
-done
+# the launch / layout knobs of the sparse triangular solves (csrc/ks_sptrsv.hpp) on tools/lu_bench.py's 2-D shift-invert problem
+# (n = 500 x 1000 by default; the factorisation runs on the host every time: ~15 s per line)
+export KS_LU_TIMEOUT_S=${KS_LU_TIMEOUT_S:-5}
+DIMS=${DIMS:-"500 1000"}
+run() { echo "$1: $(env $1 timeout 300 python tools/lu_bench.py $DIMS --reps 10 2>&1 | grep 'device product' | cut -c1-60)"; }
+run "KS_LU_XCD=3"
+run "KS_LU_XCD=4"
+run "KS_LU_XCD=0 KS_LU_GROUPS=1"
+run "KS_LU_GROUPS=1"
+run "KS_LU_LAYERS=1"
+run "KS_LU_PREPASS=0"
+run "KS_LU_RUN=0"
+run "KS_LU_RUN=128"
+run "KS_LU_RUN=512"
+run "KS_LU_NARROW=16"
+run "KS_LU_NARROW=128"
+run "KS_LU_RUN_COND=100"
+run "KS_LU_BACKOFF=0"
+run "KS_LU_BACKOFF=8"
+run "KS_LU_GRID_GROUPS=128"
