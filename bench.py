@@ -142,6 +142,54 @@ def plain_csr_spmv(pkg, ctx, A_host, n, reps=20):
         op.close()
 
 
+def shift_invert_record(pkg, nx=200, ny=250, reps=20):
+    """BASELINE config 4's operator in its general form, measured in the run (rank 0, one GPU): a 2-D Laplacian + i*diag,
+    sigma interior, ComplexF64; SuperLU factorisation on the host (as the reference's users factor on the host), the two
+    sparse triangular solves of every product on the device (ks_operator_lu).  Reports ms per product next to the host solve
+    of the same factorisation and the difference between the two results.  A side record: never part of `value`."""
+    import time
+
+    import numpy as np
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    n = nx * ny
+    rng = np.random.default_rng(3)
+    ex = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(nx, nx))
+    ey = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(ny, ny))
+    A = (sp.kron(sp.identity(ny), ex) + sp.kron(ey, sp.identity(nx))).astype(np.complex128) + 1j * sp.diags(0.3 * rng.random(n))
+    sigma = 1.7 + 0.1j
+    M = (A - sigma * sp.identity(n)).tocsc()
+    t = time.perf_counter()
+    lu = spla.splu(M, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    t_factor = time.perf_counter() - t
+    ctx = pkg.Context(0)
+    op = pkg.splu_operator(lu, ctx)
+    try:
+        ws = pkg.ArnoldiWorkspace(n, 4, np.complex128, ctx=ctx)
+        b = rng.random(n) + 1j * rng.random(n)
+        ws.set_col(0, b)
+        ws.apply(op, 0, 1)
+        y = ws.col(1)
+        t = time.perf_counter()
+        x = lu.solve(b)
+        t_host = time.perf_counter() - t
+        ctx.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            ws.apply(op, 0, 1)
+        ctx.synchronize()
+        t_dev = (time.perf_counter() - t) / reps
+        info = op.lu_info
+        return {"workload": f"(A - sigma I)^-1 x, A = laplace2d {nx}x{ny} + i*diag, sigma = 1.7+0.1i, ComplexF64, SuperLU factors applied by ks_operator_lu",
+                "n": n, "stored_entries": info["nnz_l"] + info["nnz_u"], "dependency_levels": info["levels_l"] + info["levels_u"],
+                "ms_per_product": 1e3 * t_dev, "host_solve_ms": 1e3 * t_host, "host_factorisation_s": t_factor, "products_timed": reps,
+                "max_rel_diff_vs_host_solve": float(np.abs(y - x).max() / np.abs(x).max()),
+                "repeatable": bool(np.array_equal(ws.col(1), y)), "measured_in_run": True}
+    finally:
+        op.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,6 +198,7 @@ def main():
     ap.add_argument("--grid", type=int, default=216, help="grid points per dimension (216^3 ~ 1e7 rows)")
     ap.add_argument("--nev", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shift-invert", action="store_true", help="skip the side record of the sparse shift-invert operator (N = 1 only)")
     ap.add_argument("--no-profile", action="store_true", help="skip the second (HIP-event instrumented) pass")
     ap.add_argument("--config5", action="store_true", help="also measure BASELINE config 5 (464^3 over the ranks) as a second record; "
                                                            "default: only with 8 ranks")
@@ -461,6 +510,11 @@ def main():
                     "moved_frac": r5["state"]["moved"] / max(r5["state"]["t_expand"], 1e-12) / 1e9 / world / HBM_PEAK_GBS,
                     "validation": r5["validation"],
                 }
+    if world == 1 and not args.no_shift_invert:
+        try:
+            extra["shift_invert"] = shift_invert_record(pkg)
+        except Exception as e:  # noqa: BLE001 - a side record must never cost the headline line
+            extra["shift_invert"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     leave_last_words("cpu baseline / teardown")
     out = build_line()
     # Tear everything down first and flush the C stdio buffers (RCCL prints a version banner through printf,

@@ -62,6 +62,9 @@ def test_single_gpu_line_validates_itself_and_reports_the_plain_csr_spmv():
     pc = d["roofline"]["spmv_plain_csr"]
     assert pc["layout"] == "csr" and pc["bytes_per_nnz"] == 12.0 and pc["measured_in_run"] and pc["launches"] == 20 and pc["GBps"] > 0, pc
     assert d["roofline"]["spmv"]["layout"] == "stencil"
+    # the side record of the sparse shift-invert operator (BASELINE config 4 in its general form), measured in the run
+    si = d["shift_invert"]
+    assert si["measured_in_run"] and si["repeatable"] and si["max_rel_diff_vs_host_solve"] < 1e-11 and 0.0 < si["ms_per_product"] < si["host_solve_ms"], si
 
 
 @pytest.mark.parametrize("victim,survivor", [("host", "p2p"), ("p2p", "host")])
