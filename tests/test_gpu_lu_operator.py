@@ -219,6 +219,40 @@ def test_unpivoted_indefinite_factors_keep_the_accuracy_of_substitution(monkeypa
     assert res["default"] <= res["no limit"] * 1.0001 + 1e-300, (res, host)
 
 
+def test_full_size_config4_sparse_shift_invert_5e5():
+    """BASELINE config 4 at its size (ComplexF64, n = 5 * 10^5, nev 6, 10/20) with a matrix that needs a GENERAL sparse
+    factorisation (2-D Laplacian + i*diag, sigma interior): factors from the host, every product on the device.  The product
+    against the host solve at full size, the expansion invariants of 20 steps evaluated on the device THROUGH this operator,
+    deterministic restarts, and the layout the factors got (groups on separate XCDs, inverted runs, layers)."""
+    nx, ny = 500, 1000
+    n = nx * ny
+    EPS = np.finfo(np.float64).eps
+    rng = np.random.default_rng(3)
+    A = (_lap2d(nx, ny).astype(np.complex128) + 1j * sp.diags(0.3 * rng.random(n))).tocsc()
+    lu = spla.splu((A - (1.7 + 0.1j) * sp.identity(n)).tocsc(), permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    ctx = pkg.Context(0)
+    op = pkg.splu_operator(lu, ctx)
+    info = op.lu_info
+    assert info["groups_l"] >= 2 and info["groups_u"] >= 2 and info["run_rows_l"] > 0 and info["top_rows_l"] < n // 10, info
+    v1 = (pkg.matrices.uniform_hash(1, np.arange(n)) + 1j * pkg.matrices.uniform_hash(2, np.arange(n))).astype(np.complex128)
+    ws = pkg.ArnoldiWorkspace(n, 20, np.complex128, ctx=ctx)
+    ws.set_col(0, v1)
+    ws.apply(op, 0, 1)
+    x = lu.solve(v1)
+    assert np.abs(ws.col(1) - x).max() <= TOL * np.abs(x).max()
+    ws.reinitialize(0, v1)
+    st = ws.iterate_arnoldi(op, 1, 20)
+    assert st["steps"] == 20 and st["breakdowns"] == 0
+    res, orth = ws.arnoldi_relation(op, 20)
+    hn = np.linalg.norm(ws.H)
+    assert res <= 1e-12 * hn and orth <= np.sqrt(EPS) / 100, (res / hn, orth)
+    Hs = []
+    for _ in range(2):
+        F, hist = pkg.partialschur_(op, pkg.ArnoldiWorkspace(v1, 20, ctx=ctx), nev=6, which="LM", restarts=3)
+        Hs.append(np.array(F.workspace.H))
+    assert (Hs[0] == Hs[1]).all() and hist.restarts == 3
+
+
 def test_trivial_factors_and_mixed_element_types():
     """n = 1; a lower factor with no stored entries at all; a pure permutation (identity factors); real L with complex U
     (promoted to ComplexF64 as `vtype` would)."""
