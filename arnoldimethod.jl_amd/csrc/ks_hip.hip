@@ -650,8 +650,9 @@ int ks_workspace_set_passes(ks_workspace* ws, int passes, double max_ratio) {
 int ks_workspace_assert_arnoldi(ks_workspace* ws, int k) {
   return guarded([&] {
     KS_REQUIRE(ws, KS_ERR_ARGUMENT, "null workspace");
-    KS_REQUIRE(k >= 0 && k <= ws->maxdim, KS_ERR_ARGUMENT, "k out of range");
-    prov_set(ws, k);
+    KS_REQUIRE(k >= -1 && k <= ws->maxdim, KS_ERR_ARGUMENT, "k out of range");
+    if (k < 0) prov_drop(ws);  // the caller withdraws: the next expansion runs the explicit form
+    else prov_set(ws, k);
   });
 }
 

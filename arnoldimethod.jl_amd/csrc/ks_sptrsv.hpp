@@ -41,7 +41,11 @@
 
 namespace ksd {
 
+constexpr int kLuMaxLayers = 4;  // layers per factor the control words (LuOp::kWords) provide for
+
 struct TrsvArgs {
+  const DevState* st;      // expansion batch state (nullptr outside a batch): after a breakdown / bail of the batch every
+                           // remaining product is skipped, like every other operator kernel does
   int64_t row0, n;         // this launch solves rows [row0, n) (everything before is complete: earlier launch)
   const int64_t* rowptr;   // strictly lower triangular part in the factor's own (level) numbering, CSR, columns ascending
   const int64_t* rowbegin; // first entry of row r this launch has to sum itself (== rowptr, or past the entries a pre-pass summed)
@@ -188,6 +192,7 @@ __device__ __forceinline__ cd wave_sum_dpp(cd v) { return cd{wave_sum_dpp(v.x), 
 
 template <class D, int LOCAL, bool PROBE>
 __global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
+  if (a.st && a.st->breakdown >= 0) return;
   // (the probes -- ten per-lane counters, clock reads -- cost a third of the register budget: compiled out unless asked for)
   unsigned long long* const stats_ = PROBE ? a.stats : nullptr;
   unsigned long long* const timeline_ = PROBE ? a.timeline : nullptr;
@@ -359,7 +364,9 @@ __global__ void __launch_bounds__(kTrsvWaves * 64) k_sptrsv(const TrsvArgs a) {
 // left for the solve kernel of the part next to the root (one XCD: bandwidth of one XCD) is the part that really is a chain.
 template <class D>
 __global__ void __launch_bounds__(256) k_trsv_pre(int64_t row0, int64_t row1, const int64_t* __restrict__ rowptr, const int64_t* __restrict__ rowmid,
-                                                  const int32_t* __restrict__ colind, const D* __restrict__ val, const uint64_t* __restrict__ sol, D* __restrict__ pre) {
+                                                  const int32_t* __restrict__ colind, const D* __restrict__ val, const uint64_t* __restrict__ sol, D* __restrict__ pre,
+                                                  const DevState* __restrict__ st) {
+  if (st && st->breakdown >= 0) return;
   constexpr int W = LLWords<D>::W;
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -377,7 +384,8 @@ __global__ void k_xcc_probe(unsigned* mask) {
 }
 // after a grouped launch: every group's tickets must have been handed out (a group whose XCD got no workgroup -- a device
 // shared with something that occupies a whole XCD -- would otherwise go unnoticed)
-__global__ void k_trsv_check(const int* words, const int* needed, int ngroups, int* err) {
+__global__ void k_trsv_check(const int* words, const int* needed, int ngroups, int* err, const DevState* st) {
+  if (st && st->breakdown >= 0) return;  // (the solve kernels skipped themselves: nothing was handed out)
   if (threadIdx.x == 0)
     for (int g = 0; g < ngroups; ++g)
       if (words[4 * g] < needed[g]) __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -512,7 +520,8 @@ void upload_factor(TriFactor<D>& f, int64_t n, const int64_t* rp, const int32_t*
     auto find = [&](int32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
     std::vector<double> work((size_t)n), load;
     std::vector<int32_t> comps, bin_of((size_t)n, 0);
-    const int max_layers = std::max(1, env_int("KS_LU_LAYERS", 4));
+    // (LuOp::kWords reserves ticket words for at most kLuMaxLayers layers per factor: ADVICE r3)
+    const int max_layers = std::min(ksd::kLuMaxLayers, std::max(1, env_int("KS_LU_LAYERS", ksd::kLuMaxLayers)));
     int64_t lo = 0;
     for (int depth = 0; depth < max_layers && n - lo >= (depth == 0 ? 4096 : 1024); ++depth) {
       for (int64_t r = lo; r < n; ++r) parent[r] = (int32_t)r;
@@ -828,7 +837,7 @@ template <class D> struct LuOp : ks_operator {
   double* scale_l = nullptr; //   ... times scale_l[i]
   int32_t* src_u = nullptr;  // row i of U's numbering takes entry src_u[i] of L's solution
   int32_t* dst_u = nullptr;  //   ... and its result goes to y[dst_u[i]]
-  static constexpr int kWords = 4 + 4 * 32;  // control words per factor: 4 of the top launch + 4 per group, up to 4 layers of 8
+  static constexpr int kWords = 4 + ksd::kLuMaxLayers * 32;  // control words per factor: 4 of the top launch + 4 per group, up to 4 layers of 8
   int* tickets = nullptr;
   int xcc_group[16];         // XCC id -> group (probed once; 127: no such XCC)
   int nxcc = 1;
@@ -872,13 +881,13 @@ template <class D> struct LuOp : ks_operator {
     if (a.stats || a.timeline) ksd::k_sptrsv<D, 5, true><<<grid_groups, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a);
     else ksd::k_sptrsv<D, 5, false><<<grid_groups, ksd::kTrsvWaves * 64, 0, ctx->stream>>>(a);
     KS_HIP(hipGetLastError());
-    ksd::k_trsv_check<<<1, 64, 0, ctx->stream>>>(words, L.needed_d, L.ngroups, err_d);
+    ksd::k_trsv_check<<<1, 64, 0, ctx->stream>>>(words, L.needed_d, L.ngroups, err_d, a.st);
     KS_HIP(hipGetLastError());
   }
-  void prepass(const TriFactor<D>& f, int64_t b, int64_t e) {
+  void prepass(const TriFactor<D>& f, int64_t b, int64_t e, const ksd::DevState* st) {
     if (e <= b) return;
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((e - b + 3) / 4, (int64_t)ctx->num_cu * 8));
-    ksd::k_trsv_pre<D><<<nb, 256, 0, ctx->stream>>>(b, e, f.rowptr, f.rowmid, f.colind, f.val, f.sol, f.pre);
+    ksd::k_trsv_pre<D><<<nb, 256, 0, ctx->stream>>>(b, e, f.rowptr, f.rowmid, f.colind, f.val, f.sol, f.pre, st);
     KS_HIP(hipGetLastError());
   }
   // words: 4 control words for the top launch, then 32 per layer
@@ -886,23 +895,24 @@ template <class D> struct LuOp : ks_operator {
     a.rowbegin = f.rowptr;
     a.pre = nullptr;
     if (f.layers.empty()) { launch_rows(a, 0, f.rows, words); return; }
+    KS_REQUIRE((int)f.layers.size() <= ksd::kLuMaxLayers, KS_ERR_INTERNAL, "more layers than the control words of a factor provide for");
     ksd::TrsvArgs a2 = a;  // every launch but the first sums only what its pre-pass left
     if (f.rowmid) { a2.rowbegin = f.rowmid; a2.pre = f.pre; }
     bool first = true;
     auto top = [&] {
-      if (!first && f.rowmid) prepass(f, f.top_begin, f.top_end);
+      if (!first && f.rowmid) prepass(f, f.top_begin, f.top_end, a.st);
       launch_rows(first ? a : a2, f.top_begin, f.top_end, words);
       first = false;
     };
     if (f.top_first) top();
     for (size_t k = 0; k < f.layers.size(); ++k) {
-      if (!first && f.rowmid) prepass(f, f.layers[k].begin, f.layers[k].end);
+      if (!first && f.rowmid) prepass(f, f.layers[k].begin, f.layers[k].end, a.st);
       launch_groups(first ? a : a2, f.layers[k], words + 4 + 32 * (int)k);
       first = false;
     }
     if (!f.top_first) top();
   }
-  void apply(const void* x, void* y, const DevState*) override {
+  void apply(const void* x, void* y, const DevState* st) override {
     ctx->check_comm();  // (of earlier products: the word is written by the device)
     ProfScope ps(ctx, KSP_SPMV, (double)(L.stored + U.stored) * (sizeof(D) + 4.0 + 8.0 * ksd::LLWords<D>::W) + (double)n_local * (4.0 * sizeof(D) + 2.0 * 8.0 + 3.0 * 4.0 + 3.0 * 8.0 * ksd::LLWords<D>::W));
     if (++seq == 0) {  // 2^32 solves: start the sequence numbers over
@@ -911,6 +921,7 @@ template <class D> struct LuOp : ks_operator {
       seq = 1;
     }
     ksd::TrsvArgs a{};
+    a.st = st;
     a.n = n_local;
     a.err = err_d;
     a.timeout_ticks = timeout_ticks;

@@ -130,6 +130,9 @@ def make_context(api, dist, local_rank: int, transport: str | None = None):
 
     rank, world = dist.get_rank(), dist.get_world_size()
     transport = transport or os.environ.get("KS_TRANSPORT", "rccl")
+    # the host driver only supports dmabuf IPC: without this RCCL and the peer-to-peer regions fail with
+    # `hipIpcGetMemHandle: invalid argument` (read when the HSA runtime starts, i.e. at the first device call)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if transport == "p2p":
         ctx = api.Context(local_rank, rank, world, p2p=True)
         if world > 1:
@@ -143,6 +146,16 @@ def make_context(api, dist, local_rank: int, transport: str | None = None):
     box = [api.Context.unique_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
     return api.Context(local_rank, rank, world, box[0])
+
+
+def ready_barrier(dist):
+    """Control-plane rendezvous between SET-UP and the first exchange.  Every wait inside the library is bounded by wall
+    clock (KS_P2P_TIMEOUT_S, 30 s; RCCL has its own watchdog) and the clock starts when the first exchange kernel of the
+    FASTEST rank starts -- while a slower rank may still be assembling its row block on the host (8 processes on a 16-CPU
+    quota: tens of seconds at 464^3 / 8; round 3's committed config-5 evidence died exactly there with CommTimeout).
+    Call after the operator and the workspace exist on every rank and before the first verb that exchanges."""
+    if dist.get_world_size() > 1:
+        dist.barrier()
 
 
 def host_transport(dist):
@@ -183,6 +196,7 @@ def setup_laplace3d(pkg, dist, m: int, maxdim: int, local_rank: int, transport: 
     ws = api.ArnoldiWorkspace(r1 - r0, maxdim, np.float64, ctx=ctx, n_global=n, row_begin=r0)
     v1 = pkg.matrices.start_vector(r1 - r0, row_begin=r0)
     nnz = 7 * n - 6 * m * m  # 7-point stencil with Dirichlet faces
+    ready_barrier(dist)  # nobody starts exchanging before the slowest rank finished its set-up
     return ctx, op, ws, v1, nnz
 
 

@@ -245,6 +245,22 @@ mutable struct HipWorkspace{T}
     H::Matrix{T}      # (maxdim+1) x maxdim, wraps library memory (do not resize)
     Q::Matrix{T}      # maxdim x maxdim
     ctx::HipContext
+    # What the GLUE ITSELF knows about the factorisation (ADVICE r3): columns 1..relation_k+1 of V and columns
+    # 1..relation_k of the caller's H form an Arnoldi / Krylov-Schur decomposition because this glue watched it being
+    # built -- a start vector written into column 1, fused expansions, the reference's restart pair (src/run.jl:363-365).
+    # Any other write to a column (upload, rand!, ./=, mul! into it, a Gram-Schmidt update) cuts it back.  Only then does
+    # iterate_arnoldi! vouch for the decomposition (ks_workspace_assert_arnoldi); otherwise the library runs its
+    # explicit three-pass expansion, which -- like the reference's iterate_arnoldi! -- reads no earlier column of H.
+    # -1: nothing known.
+    relation_k::Int
+    pending_rot::Tuple{Int,Int}   # (m, k) of a rotation V[:, purge:k] <- V[:, purge:m] Q that still waits for its copyto!; (-1, -1): none
+end
+
+# column j (0-based) was written by something other than the expansion / restart pair
+function _touched!(w::HipWorkspace, j::Integer)
+    w.pending_rot = (-1, -1)
+    w.relation_k = j == 0 ? 0 : min(w.relation_k, j - 1)   # (a lone first column is a 0-step decomposition)
+    nothing
 end
 
 function HipWorkspace(ctx::HipContext, ::Type{T}, n::Integer, maxdim::Integer) where {T<:HipScalar}
@@ -257,7 +273,7 @@ function HipWorkspace(ctx::HipContext, ::Type{T}, n::Integer, maxdim::Integer) w
     H = unsafe_wrap(Array, Ptr{T}(hp[]), (maxdim + 1, maxdim))
     check(ccall((:ks_workspace_Q, LIB), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ref{Cint}), r[], hp, ld))
     Q = unsafe_wrap(Array, Ptr{T}(hp[]), (maxdim, maxdim))
-    w = HipWorkspace{T}(r[], n, maxdim, H, Q, ctx)
+    w = HipWorkspace{T}(r[], n, maxdim, H, Q, ctx, -1, (-1, -1))
     _adopt(ctx)
     finalizer(w) do x
         if x.h != C_NULL
@@ -331,6 +347,7 @@ Base.collect(V::Union{HipColumn,HipColumns,HipBasis}) = Array(V)
 # populate!(v): rand!(v) (src/expansion.jl:15,21) and copyto!(v, v1) (src/run.jl:126)
 function Random.rand!(rng::Random.AbstractRNG, v::HipColumn)
     check(ccall((:ks_col_fill_uniform, LIB), Cint, (Ptr{Cvoid}, Cint, UInt64), v.ws.h, v.j, rand(rng, UInt64)))
+    _touched!(v.ws, v.j)
     v
 end
 Random.rand!(v::HipColumn) = Random.rand!(Random.default_rng(), v)
@@ -338,12 +355,22 @@ function Base.copyto!(v::HipColumn{T}, src::AbstractVector) where {T}
     length(src) == v.ws.n || throw(DimensionMismatch("source has length $(length(src)), the column has $(v.ws.n)"))
     buf = convert(Vector{T}, src)
     GC.@preserve buf check(ccall((:ks_col_upload, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}), v.ws.h, v.j, pointer(buf)))
+    _touched!(v.ws, v.j)
     v
 end
 # copyto!(view(V, :, k+1), view(V, :, maxdim+1))   src/run.jl:365
 function Base.copyto!(dst::HipColumn{T}, src::HipColumn{T}) where {T}
     dst.ws === src.ws || return copyto!(dst, Array(src))
     check(ccall((:ks_col_copy, LIB), Cint, (Ptr{Cvoid}, Cint, Cint), dst.ws.h, dst.j, src.j))
+    w = dst.ws
+    if w.pending_rot == (src.j, dst.j)
+        # second half of the reference's restart (src/run.jl:365): the residual direction moves next to the truncated
+        # basis -- a Krylov-Schur decomposition of dst.j steps (the caller's host code transformed H alongside)
+        w.pending_rot = (-1, -1)
+        w.relation_k = dst.j
+    else
+        _touched!(w, dst.j)
+    end
     dst
 end
 # copyto!(view(V, :, a:b), view(V_tmp, :, a:b))   src/run.jl:364,383: the rotation already happened in place
@@ -371,6 +398,7 @@ function Base.Broadcast.materialize!(dest::HipColumn{T}, bc::Base.Broadcast.Broa
     src, s = bc.args
     (src.ws === dest.ws && src.j == dest.j) || throw(ArgumentError("only the in-place form v ./= s is supported on device columns"))
     check(ccall((:ks_col_div, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble), dest.ws.h, dest.j, Float64(real(s))))
+    _touched!(dest.ws, dest.j)
     dest
 end
 
@@ -378,6 +406,7 @@ end
 function LinearAlgebra.mul!(y::HipColumn{T}, A::HipOperator{T}, x::HipColumn{T}) where {T}
     y.ws === x.ws || throw(ArgumentError("source and destination columns must belong to the same basis"))
     check(ccall((:ks_apply, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint), A.h, y.ws.h, x.j, y.j))
+    _touched!(y.ws, y.j)
     y
 end
 # any other operator with a host mul!: one column over PCIe each way (what the reference does for LinearMaps, but
@@ -413,6 +442,7 @@ function LinearAlgebra.mul!(v::HipColumn{T}, Vp::HipColumns{T}, h::AbstractVecto
     Vp.ncols == 0 && return v
     hb = convert(Vector{T}, h)
     GC.@preserve hb check(ccall((:ks_gemv_n_sub, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}), v.ws.h, Vp.ncols, v.j, pointer(hb)))
+    _touched!(v.ws, v.j)
     v
 end
 
@@ -426,6 +456,21 @@ function LinearAlgebra.mul!(dst::HipColumns{T}, src::HipColumns{T}, Qb::Abstract
     (c == 0 || r == 0) && return dst
     Qh = Matrix{T}(Qb)                     # small host copy, column-major, leading dimension c
     GC.@preserve Qh check(ccall((:ks_rotate, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cvoid}, Cint), src.ws.h, src.j0, c, r, pointer(Qh), c))
+    w = src.ws
+    m, k = src.j0 + c, src.j0 + r
+    if w.relation_k == m && r < c
+        # first half of the reference's restart (src/run.jl:363-364) on a decomposition of m steps this glue saw being
+        # built: it becomes one of k steps once column m moves to column k (copyto! above)
+        w.pending_rot = (m, k)
+        w.relation_k = src.j0 > 0 ? src.j0 - 1 : -1
+    elseif w.relation_k >= m && r == c
+        # the final rotation of the converged block (src/run.jl:382-383, Q unitary, r == c): what lies beyond it is gone
+        w.pending_rot = (-1, -1)
+        w.relation_k = src.j0 > 0 ? src.j0 - 1 : -1
+    else
+        w.pending_rot = (-1, -1)
+        w.relation_k = min(w.relation_k, src.j0 - 1)
+    end
     dst
 end
 
@@ -462,9 +507,15 @@ function ArnoldiMethod.iterate_arnoldi!(A::HipOperator{T}, arnoldi::ArnoldiWorks
         @views copyto!(w.H[:, 1:first(range)-1], H[:, 1:first(range)-1])
     end
     # V[:, 1:first(range)] and H[:, 1:first(range)-1] are an Arnoldi / Krylov-Schur decomposition of first(range)-1 steps
-    # whenever the reference calls this (src/run.jl:267,272): vouch for it, or the library runs its explicit form
-    check(ccall((:ks_workspace_assert_arnoldi, LIB), Cint, (Ptr{Cvoid}, Cint), w.h, first(range) - 1))
+    # whenever the REFERENCE calls this (src/run.jl:267,272).  Vouch for it only when this glue saw that decomposition
+    # being built (relation_k, above): a caller who wrote V by hand and expands from j > 1 -- legal with the reference,
+    # whose iterate_arnoldi! reads no earlier column of H -- gets the library's explicit form instead of g = H c computed
+    # from a relation that does not hold (ADVICE r3).
+    vouched = w.relation_k >= first(range) - 1
+    check(ccall((:ks_workspace_assert_arnoldi, LIB), Cint, (Ptr{Cvoid}, Cint), w.h, vouched ? first(range) - 1 : -1))
     check(ccall((:ks_iterate_arnoldi, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Ref{KsExpandStats}), A.h, w.h, first(range), last(range), st))
+    w.pending_rot = (-1, -1)
+    w.relation_k = vouched ? last(range) : min(w.relation_k, first(range) - 1)
     if H !== w.H
         for j in range
             @views copyto!(H[1:j+1, j], w.H[1:j+1, j])

@@ -232,7 +232,8 @@ int ks_workspace_set_passes(ks_workspace* ws, int passes, double max_ratio);
  * own H, then ks_rotate + ks_col_copy, src/run.jl:278-365) vouches for the result with
  *     ks_workspace_assert_arnoldi(ws, k)   -- "columns 0..k are orthonormal and, with the H now in ks_workspace_H,
  *                                              satisfy the Arnoldi relation of k steps"
- * *k of ks_workspace_provenance: steps the library trusts (-1: none). */
+ * k = -1 WITHDRAWS whatever the library trusted (a binding that saw the caller write into V through a path the library
+ * does not watch).  *k of ks_workspace_provenance: steps the library trusts (-1: none). */
 int ks_workspace_assert_arnoldi(ks_workspace* ws, int k);
 int ks_workspace_provenance(const ks_workspace* ws, int* k);
 /* Debugging aid: with KS_GUARD=1 in the environment a workspace puts 1 MiB canary zones on both sides of the

@@ -192,6 +192,33 @@ def test_sparse_shift_invert_helper():
     assert np.abs(lam - np.sort(near)).max() <= 1e-8
 
 
+def test_sparse_shift_invert_refuses_a_bad_unpivoted_factorisation():
+    """symmetric pattern => diagonal pivots only, which is not backward stable.  A matrix with a (nearly) zero
+    diagonal makes that factorisation useless (relative residual 0.2); the helper must notice (one host solve), warn, fall
+    back to partial pivoting and report the residual of the factors it actually uses."""
+    import importlib
+
+    extras = importlib.import_module(pkg.__name__ + ".extras")
+    n = 200
+    rng = np.random.default_rng(0)
+    A = sp.diags([np.ones(n - 1), 1e-14 * np.ones(n), np.ones(n - 1)], [-1, 0, 1], format="csc") + sp.random(n, n, 0.02, random_state=rng, format="csc")
+    A = (A + A.T).tocsc()
+    ctx = pkg.Context(0)
+    with pytest.warns(RuntimeWarning, match="refactorising with partial pivoting"):
+        op = extras.sparse_shift_invert(A, 0.0, ctx)
+    assert op.factor_residual <= 1e-12
+    b = rng.random(n)
+    y, _ = _apply(op, b, ctx)
+    assert np.abs(A @ y - b).max() <= 1e-9 * np.abs(y).max()
+    # a well-conditioned symmetric-pattern problem keeps the cheap ordering, silently
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        op2 = extras.sparse_shift_invert(_lap2d(30, 30), 0.913, ctx)
+    assert op2.factor_residual <= 1e-10
+
+
 def test_unpivoted_indefinite_factors_keep_the_accuracy_of_substitution(monkeypatch):
     """Real shift inside the spectrum, factorisation with diagonal pivots only: a nearly singular, badly scaled pair of
     factors whose dense triangles have inverses that GROW.  Inverted runs are only taken while max|T^-1| max|T| stays under

@@ -710,6 +710,16 @@ def test_explicit_second_pass_path_with_real_ranks(nproc, mode, transport):
     assert r.stdout.count("-> OK") == nproc and "same: True" in r.stdout, r.stdout[-3000:]
 
 
+def test_setup_skew_longer_than_the_exchange_timeout_is_absorbed():
+    """Round 3's committed config-5 evidence ended in `CommTimeout` on 7 of 8 ranks: the wall-clock budget of the first
+    exchange kernel started while slower ranks were still assembling their row blocks on the host.  `dist.ready_barrier`
+    (control plane, after operator + workspace exist everywhere) now sits between set-up and the first exchange: a rank
+    that dawdles 12 s during set-up with a 5 s exchange budget must NOT make anybody time out."""
+    r = _run_ranks(3, "laplace", extra_env={"KS_P2P_TIMEOUT_S": "5", "KS_TEST_SETUP_SKEW_S": "1:12"})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("-> OK") == 3 and "same: True" in r.stdout and "CommTimeout" not in r.stdout + r.stderr, r.stdout[-3000:]
+
+
 def test_reduce_allreduce_post_structure_with_real_ranks():
     """The RCCL transport's launch structure of the lazy path (reduce-only kernel -> all-reduce -> post kernel)
     with 3 real ranks: KS_P2P_NO_FOLD=1 runs exactly those kernel modes on the peer-to-peer all-reduce kernel."""

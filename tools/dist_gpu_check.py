@@ -45,6 +45,20 @@ ks = import_package()
 from arnoldimethod_jl_amd import _lib, api, dist as ksd  # noqa: E402
 
 
+def setup_skew(rank):
+    """KS_TEST_SETUP_SKEW_S="<rank>:<seconds>": that rank dawdles during set-up (stands for a slow host-side assembly: 8
+    processes on a 16-CPU quota).  With the control-plane barrier between set-up and the first exchange
+    (dist.ready_barrier) the others simply wait for it; without it their exchange kernels would give up after
+    KS_P2P_TIMEOUT_S."""
+    spec = os.environ.get("KS_TEST_SETUP_SKEW_S", "")
+    if spec:
+        import time
+
+        r, sec = spec.split(":")
+        if int(r) == rank:
+            time.sleep(float(sec))
+
+
 def run_cycles(op, ws, v1, cycles, nev=20, mindim=20, maxdim=40):
     """bench.py's state machine (src/run.jl:267-368): initial expansion, then `cycles` restart cycles.  Returns the
     restart trail [(k, nlock)], the Ritz values entering the last restart and the device-side invariants."""
@@ -80,6 +94,8 @@ def shard5(rank, world, ctx, m, cycles=2):
     op = ksd.dist_operator(api, ctx, ip, dv, plan, n)
     del ip, ix, dv
     ws = api.ArnoldiWorkspace(r1 - r0, 40, np.float64, ctx=ctx, n_global=n, row_begin=r0)
+    setup_skew(rank)
+    ksd.ready_barrier(dist)  # the spin budget of the first exchange must not pay for the slowest rank's assembly
     d = run_cycles(op, ws, ks.matrices.start_vector(r1 - r0, row_begin=r0), cycles)
     t1 = time.time()
     ok = d["rel"] <= 1e-12 * d["hnorm"] * 10 and d["orth"] <= np.sqrt(np.finfo(np.float64).eps) / 100
@@ -154,6 +170,7 @@ def main():
         plan = ksd.build_halo_plan(B.indices.astype(np.int64), offs, rank, dist)
         op = ksd.dist_operator(api, ctx, B.indptr.astype(np.int64), B.data, plan, n)
         ws = api.ArnoldiWorkspace(r1 - r0, 5, np.float64, ctx=ctx, n_global=n, row_begin=r0)
+        ksd.ready_barrier(dist)
         worst, bad = 0.0, 0
         for it in range(200):
             x = ks.matrices.uniform_hash(1000 + it, np.arange(n)) - 0.5
@@ -204,6 +221,8 @@ def main():
     op = ksd.dist_operator(api, ctx, ip, dv, plan, n)
     ws = api.ArnoldiWorkspace(r1 - r0, kw["maxdim"], dtype, ctx=ctx, n_global=n, row_begin=r0)
     ws._v1 = ks.matrices.start_vector(r1 - r0, row_begin=r0).astype(dtype)
+    setup_skew(rank)
+    ksd.ready_barrier(dist)
     F, hist = ks.partialschur_(op, ws, **kw)
     res, orth = ws.residual_norms(op, F.nconverged)
     # ||A Q - Q R||_F over nconverged columns; the solver's criterion is per vector, tol * |lambda| (src/run.jl:330)
