@@ -619,6 +619,21 @@ class ArnoldiWorkspace:
         implicit form carries before a step is redone explicitly (NaN keeps the current value, <= 0 removes the limit)."""
         check(_lib.load().ks_workspace_set_passes(self._h, int(passes), float(max_ratio)))
 
+    def set_sstep(self, s: int, pivot_min: float = float("nan")):
+        """s-step (block) expansion: s >= 2 takes the steps of an expansion in blocks of up to s (two reads of the basis per
+        BLOCK instead of per step; include/kschur.h, ks_workspace_set_sstep); 0 switches it off.  `pivot_min`: smallest
+        Cholesky pivot ratio a block may have before it is abandoned and redone step by step (NaN keeps the value)."""
+        check(_lib.load().ks_workspace_set_sstep(self._h, int(s), float(pivot_min)))
+
+    @property
+    def sstep_info(self) -> dict:
+        """Block size in force, blocks completed / abandoned since creation, and of the last batch: smallest pivot ratios of
+        the two Gram-Schmidt stages and the largest entry of |Gram matrix of the written block - I|."""
+        s, b, a = C.c_int(), C.c_int(), C.c_int()
+        d = (C.c_double * 3)()
+        check(_lib.load().ks_workspace_sstep_info(self._h, C.byref(s), C.byref(b), C.byref(a), d))
+        return dict(s=s.value, blocks=b.value, abandoned=a.value, pivot_stage1=d[0], pivot_stage2=d[1], gram_dev=d[2])
+
     def assert_arnoldi(self, k: int):
         """The caller vouches that columns 0..k are orthonormal and satisfy, with the H now in `self.H`, the Arnoldi
         relation of k steps (a restart the host language ran itself): re-enables the implicit second pass."""

@@ -58,6 +58,8 @@ template <class T> struct HipBackend : ks::Backend<T> {
     // them.  Only a factorisation the library produced itself (or the caller vouched for) qualifies; anything else runs
     // the explicit form, which -- like the reference's iterate_arnoldi! -- reads neither.
     const bool trusted = prov_ok(ws, from);
+    bool no_block = false;  // a block of this call was abandoned: the rest of the range runs step by step
+    blk_shifts_from_saved_H();
     while (j0 <= to) {
       const double tb0 = ks::now_s();
       int jend = to;
@@ -65,7 +67,16 @@ template <class T> struct HipBackend : ks::Backend<T> {
       if (explicit_step >= 0) jend = j0;
       const bool lazy = use_deferred(ws, jend);
       const bool tpath = lazy && ws->passes == 2 && trusted && explicit_step < 0;  // implicit second pass: two reads of the basis per step
-      if (tpath && !(ws->t_lazy && j0 == ws->t_hi + 1)) {
+      // S-STEP form of the same path (ks_block.hpp): blocks of up to ws->sstep steps, two reads of the basis per BLOCK.
+      // Needs Newton shifts (Ritz values of a previous restart: not before the first one), a device-resident operator
+      // and a single GPU; a range of one step gains nothing.
+      std::vector<int> blk_sizes;
+      ksd::BlkShifts<D> blk_sh{};
+      if (tpath && !no_block && ws->sstep >= 2 && op->async_capable && !ws->ctx->distributed() && jend - j0 + 1 >= 2 &&
+          blk_make_shifts<D>(ws, std::min(ws->sstep, ksd::kBlkSMax), blk_sh))
+        blk_sizes = blk_partition(ws->dtype, j0, jend - j0 + 1, std::min(ws->sstep, ksd::kBlkSMax));
+      const bool bpath = !blk_sizes.empty();
+      if (tpath && (bpath || ws->blk_tail || !(ws->t_lazy && j0 == ws->t_hi + 1))) {
         materialize(ws);   // whatever is lazy (either kind) becomes ordinary: this batch starts a new T
         ws->ntrue = j0;
       }
@@ -79,7 +90,10 @@ template <class T> struct HipBackend : ks::Backend<T> {
       const bool mb = lazy && ws->use_mbox;          // the device publishes the results itself, the host spins
       const bool do_early = early && mb && !tpath && jend == to;  // (with two passes H is final only at the very end)
       const uint64_t seq = ++ws->mbox_seq;
-      if (tpath) {
+      if (bpath) {
+        blk_ensure_buffers(ws);
+        enqueue_steps_blk<D>(ws, op, j0, blk_sizes, blk_sh);
+      } else if (tpath) {
         enqueue_steps_t<D>(ws, op, j0, jend);
       } else if (lazy) {
         if (ws->t_lazy) materialize(ws);
@@ -137,9 +151,21 @@ template <class T> struct HipBackend : ks::Backend<T> {
       }
       // bail: the implicit form refuses step `bail` (its second-pass correction is not small) -- steps before it stand,
       // the step itself is redone below in the explicit form; not a breakdown
-      const int bail = tpath ? ws->st_h->bail : -1;
-      const int bd = bail >= 0 ? -1 : ws->st_h->breakdown;
-      const int last_done = bail >= 0 ? bail - 1 : (bd >= 0 ? bd : jend);
+      // blk_bail: a block was abandoned before anything of it was committed (rank-deficient Gram matrix: breakdown, or a
+      // Newton basis too ill-conditioned to trust) -- the blocks before it stand, the rest of the range runs step by step
+      const int blk_bail = bpath ? ws->st_h->blk_bail : -1;
+      const int bail = (tpath && !bpath) ? ws->st_h->bail : -1;
+      const int bd = (bail >= 0 || blk_bail >= 0) ? -1 : ws->st_h->breakdown;
+      const int last_done = blk_bail >= 0 ? blk_bail - 1 : (bail >= 0 ? bail - 1 : (bd >= 0 ? bd : jend));
+      if (bpath) {
+        ws->blk_diag[0] = ws->st_h->blk_piv1;
+        ws->blk_diag[1] = ws->st_h->blk_piv2;
+        ws->blk_diag[2] = ws->st_h->blk_gdev;
+        int done = 0;
+        for (int sz : blk_sizes) { if (j0 + done + sz - 1 <= last_done) { done += sz; ws->blk_count++; } }
+        if (blk_bail >= 0) { ws->blk_bails++; stats.blk_bails++; no_block = true; }
+        stats.blocks += (int)blk_sizes.size() - (blk_bail >= 0 ? 1 : 0);
+      }
       if (early_ran && bd >= 0) {  // the last step broke down: withdraw (rare; the caller redoes the early part)
         std::memcpy(H.p, ws->Hbackup.data(), ws->Hbackup.size());
         early_ran = false;
@@ -155,10 +181,11 @@ template <class T> struct HipBackend : ks::Backend<T> {
       }
       if (tpath) {
         // columns j0 .. (last completed step) are T-lazy now; a column that broke down is garbage until reinit_column
-        const int good = bail >= 0 ? bail - 1 : (bd >= 0 ? bd - 1 : jend);
+        const int good = blk_bail >= 0 ? blk_bail - 1 : (bail >= 0 ? bail - 1 : (bd >= 0 ? bd - 1 : jend));
         if (good >= ws->ntrue) {
           ws->t_lazy = true;
           ws->t_hi = good;
+          ws->blk_tail = bpath;
         }
       }
       stats.steps += last_done - j0 + 1;
@@ -182,7 +209,43 @@ template <class T> struct HipBackend : ks::Backend<T> {
     // the factorisation up to `to` is the library's own again (or stays unknown)
     if (trusted) prov_set(ws, to);
     else prov_drop(ws);
+    if (ws->sstep >= 2 && to == ws->maxdim && !early_stands) {
+      // a caller that runs the restart itself (the reference's own _partialschur on a device basis) never tells the library
+      // its Ritz values: keep the full Hessenberg matrix, the next expansion takes its shifts from it (blk_shifts_from_saved_H)
+      ws->Hfull.assign(static_cast<const char*>(ws->H), static_cast<const char*>(ws->H) + h_bytes(ws));
+      ws->hfull_valid = true;
+      ws->ritz_valid = false;   // (note_ritz of a driver that does know them follows and takes precedence)
+    }
     return early_stands;
+  }
+
+  // Ritz values of the restart that just happened (Newton shifts of the next expansion's blocks)
+  void note_ritz(const cplx* lams, int m) override {
+    if (ws->sstep < 2) return;
+    ws->ritz.assign(lams, lams + m);
+    ws->ritz_valid = true;
+    ws->hfull_valid = false;
+  }
+  // ... or, when nobody told us, the eigenvalues of the Hessenberg matrix the last full expansion left (one Schur
+  // factorisation of a copy on the host, ~0.1 ms: only on the path of callers that run their own restart)
+  void blk_shifts_from_saved_H() {
+    using TT = T;
+    if (ws->sstep < 2 || ws->ritz_valid || !ws->hfull_valid) return;
+    const int m = ws->maxdim;
+    std::vector<TT> Hc((size_t)(m + 1) * m), Qc((size_t)m * m, TT(0));
+    std::memcpy(Hc.data(), ws->Hfull.data(), Hc.size() * sizeof(TT));
+    for (int i = 0; i < m; ++i) Qc[i + (size_t)i * m] = TT(1);
+    ks::Mat<TT> Hm(Hc.data(), m + 1, m, m + 1), Qm(Qc.data(), m, m, m);
+    try {
+      ks::local_schurfact(Hm.top(m), 0, m - 1, Qm);
+      std::vector<cplx> lams(m);
+      ks::copy_eigenvalues(lams.data(), Hm, 0, m - 1);
+      ws->ritz = lams;
+      ws->ritz_valid = true;
+    } catch (...) {
+      ws->ritz_valid = false;   // (QR did not converge on the copy: the expansion simply runs step by step)
+    }
+    ws->hfull_valid = false;
   }
 
   bool reinitialize(int j, const T* v1_host) override {

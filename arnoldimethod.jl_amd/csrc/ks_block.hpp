@@ -1,0 +1,196 @@
+// host side of the S-STEP (block) Arnoldi expansion (kernels: ks_block_kernels.hpp; model: tests/sstep_model.py).
+// Part of the ONE translation unit of libkschur_hip.so: included by ks_hip.hip after ks_workspace.hpp.
+//
+// iterate_arnoldi!(A, arnoldi, from:to) (src/expansion.jl:116-133) in blocks of s steps: per block s operator products
+// (Newton basis, shifts = Leja-ordered Ritz values of the previous restart), TWO passes over the basis and two reductions --
+// instead of two passes and one reduction per STEP of the default (implicit second pass) expansion, four passes per step of
+// the reference.  Same Krylov space, hence the same H up to rounding (implicit-Q); blocks whose Gram matrix is numerically
+// rank deficient (breakdown, ill-conditioned basis) are abandoned before anything is committed and redone step by step.
+#pragma once
+
+// (kernels: ks_block_kernels.hpp, included at the top of ks_hip.hip; this file sits inside the anonymous namespace that
+// ks_workspace.hpp opens and ks_backend.hpp closes)
+
+
+// ---- block sizes ------------------------------------------------------------------------------------------------------------
+// instantiated block sizes (ks_block_kernels.hpp templates): Float64 1..5, 8, 10; ComplexF64 1..5
+inline bool blk_size_ok(int dtype, int s) {
+  if (s >= 1 && s <= 5) return true;
+  return dtype == KS_F64 && (s == 8 || s == 10);
+}
+// can the block kernels take k existing columns with block size s?  (column-split width NCW = 4, 8, 12, 16 per wave)
+inline bool blk_shape_ok(int dtype, int k, int s) {
+  if (!blk_size_ok(dtype, s) || k < 1 || k + s > ksd::kBlkKMax) return false;
+  if (dtype == KS_C64) return k <= 32;          // ComplexF64: NCW 4 / 8 only
+  if (k > 48) return s <= 5;                    // NCW = 16: register budget
+  return true;
+}
+// split `count` steps starting with k0 existing columns into block sizes <= smax
+inline std::vector<int> blk_partition(int dtype, int k0, int count, int smax) {
+  std::vector<int> out;
+  int k = k0;
+  while (count > 0) {
+    int s = std::min(count, smax);
+    while (s > 1 && !blk_shape_ok(dtype, k, s)) --s;
+    if (!blk_shape_ok(dtype, k, s)) return {};
+    out.push_back(s);
+    k += s;
+    count -= s;
+  }
+  return out;
+}
+
+// ---- Newton shifts ------------------------------------------------------------------------------------------------------------
+// Leja ordering of the Ritz values of the previous restart (tests/sstep_model.py: leja_order / newton_shifts).  Real element
+// type: real parts only, a conjugate pair contributes once.
+inline std::vector<std::complex<double>> leja_shifts(const std::vector<std::complex<double>>& ritz, int s, bool real) {
+  std::vector<std::complex<double>> pts;
+  for (auto z : ritz) {
+    if (real) z = std::complex<double>(z.real(), 0.0);
+    if (!std::isfinite(z.real()) || !std::isfinite(z.imag())) continue;
+    bool dup = false;
+    for (auto& q : pts) dup = dup || std::abs(q - z) <= 1e-14 * std::max(1.0, std::abs(z));
+    if (!dup) pts.push_back(z);
+  }
+  std::vector<std::complex<double>> out;
+  if (pts.empty()) { out.assign(s, 0.0); return out; }
+  std::vector<double> logprod(pts.size(), 0.0);
+  std::vector<bool> used(pts.size(), false);
+  size_t cur = 0;
+  for (size_t i = 1; i < pts.size(); ++i) if (std::abs(pts[i]) > std::abs(pts[cur])) cur = i;
+  while (out.size() < pts.size() && (int)out.size() < s) {
+    used[cur] = true;
+    out.push_back(pts[cur]);
+    size_t best = pts.size();
+    for (size_t i = 0; i < pts.size(); ++i) {
+      if (used[i]) continue;
+      logprod[i] += std::log(std::max(std::abs(pts[i] - pts[cur]), 1e-300));
+      if (best == pts.size() || logprod[i] > logprod[best]) best = i;
+    }
+    if (best == pts.size()) break;
+    cur = best;
+  }
+  const size_t have = out.size();
+  while ((int)out.size() < s) out.push_back(out[out.size() % have]);
+  return out;
+}
+
+inline void blk_ensure_buffers(ks_workspace* ws) {
+  if (ws->bpart) return;
+  const size_t entries = (size_t)ksd::kBlkKMax * ksd::kBlkSMax + ksd::kBlkGram;
+  KS_HIP(hipMalloc(&ws->bpart, entries * (size_t)ws->pnb * ws->esz));
+  KS_HIP(hipMalloc(&ws->bred, entries * ws->esz));
+  const size_t sb = ws->dtype == KS_F64 ? sizeof(ksd::BlkScratch<double>) : sizeof(ksd::BlkScratch<cd>);
+  KS_HIP(hipMalloc(&ws->bscr, sb));
+  KS_HIP(hipMemset(ws->bscr, 0, sb));
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------------------------------
+template <class D, int NCW, int S> int launch_bdots_t(ks_workspace* ws, int k) {
+  constexpr int U = S <= 5 ? 2 : 1;
+  static int cache = -1;
+  const int nb = cap_blocks(ws, resident_blocks(ws->ctx, ksd::k_bdots<D, NCW, S, U, true>, 0, cache), 64 * U);
+  if (ws->v_nt) ksd::k_bdots<D, NCW, S, U, true><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const D*>(ws->V), ws->ld, k, static_cast<D*>(ws->bpart), ws->pnb, ws->st);
+  else ksd::k_bdots<D, NCW, S, U, false><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const D*>(ws->V), ws->ld, k, static_cast<D*>(ws->bpart), ws->pnb, ws->st);
+  return nb;
+}
+template <class D, int NCW, int S> int launch_bupdate_t(ks_workspace* ws, int k) {
+  constexpr int U = S <= 5 ? 2 : 1;
+  static int cache = -1;
+  const int nb = cap_blocks(ws, resident_blocks(ws->ctx, ksd::k_bupdate<D, NCW, S, U, true>, 0, cache), 64 * U);
+  auto* bs = static_cast<ksd::BlkScratch<D>*>(ws->bscr);
+  if (ws->v_nt) ksd::k_bupdate<D, NCW, S, U, true><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<D*>(ws->V), ws->ld, k, bs->coefp, k, bs->r1inv, static_cast<D*>(ws->bpart), ws->pnb, ws->st);
+  else ksd::k_bupdate<D, NCW, S, U, false><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<D*>(ws->V), ws->ld, k, bs->coefp, k, bs->r1inv, static_cast<D*>(ws->bpart), ws->pnb, ws->st);
+  return nb;
+}
+// (which, k, s) -> instantiation
+template <class D, int NCW> int launch_blk_s(ks_workspace* ws, int which, int k, int s) {
+#define KS_BLK_CASE(SS) case SS: return which == 0 ? launch_bdots_t<D, NCW, SS>(ws, k) : launch_bupdate_t<D, NCW, SS>(ws, k);
+  switch (s) {
+    KS_BLK_CASE(1) KS_BLK_CASE(2) KS_BLK_CASE(3) KS_BLK_CASE(4) KS_BLK_CASE(5)
+    default: break;
+  }
+  if constexpr (sizeof(D) == 8 && NCW <= 12) {
+    switch (s) {
+      KS_BLK_CASE(8) KS_BLK_CASE(10)
+      default: break;
+    }
+  }
+#undef KS_BLK_CASE
+  throw KsError{KS_ERR_INTERNAL, "block size without a kernel instantiation"};
+}
+template <class D> int launch_blk(ks_workspace* ws, int which, int k, int s) {
+  if (k <= 16) return launch_blk_s<D, 4>(ws, which, k, s);
+  if (k <= 32) return launch_blk_s<D, 8>(ws, which, k, s);
+  if constexpr (sizeof(D) == 8) {
+    if (k <= 48) return launch_blk_s<D, 12>(ws, which, k, s);
+    return launch_blk_s<D, 16>(ws, which, k, s);
+  }
+  throw KsError{KS_ERR_INTERNAL, "block kernels: too many columns for this element type"};
+}
+
+// Steps from..to as blocks of the given sizes.  Every column is an ordinary one on entry (the caller materialised): T = I
+// below `from`, ws->ntrue == from.
+template <class D>
+void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::vector<int>& sizes, const ksd::BlkShifts<D>& sh) {
+  ks_ctx* cx = ws->ctx;
+  hipStream_t s_ = cx->stream;
+  const int ldh = ws->maxdim + 1;
+  const double nb8 = (double)ws->n * sizeof(D);
+  D* Hd = static_cast<D*>(ws->Hd);
+  D* Tm = static_cast<D*>(ws->Td);
+  auto* bs = static_cast<ksd::BlkScratch<D>*>(ws->bscr);
+  int k = from;   // existing columns == index of the block's first step
+  int first = 1;
+  for (int s : sizes) {
+    for (int i = 0; i < s; ++i) {
+      double tre, tim;
+      if constexpr (sizeof(D) == 8) { tre = sh.theta[i]; tim = 0.0; }
+      else { tre = sh.theta[i].x; tim = sh.theta[i].y; }
+      op->in_scale = 1.0;
+      op->apply_shifted(ws->col(k - 1 + i), ws->col(k + i), tre, tim, sh.sigma[i], ws->ld, ws->st);
+    }
+    const int ne = k * s + s * (s + 1) / 2;
+    int nb1, nb2;
+    {
+      ProfScope ps(cx, KSP_DOTS, nb8 * (k + s));               // reads S[:, 0:k) and Z
+      nb1 = launch_blk<D>(ws, 0, k, s);
+    }
+    {
+      ProfScope ps(cx, KSP_FIN, 0.0);
+      ksd::k_fin_blk<D><<<ne, kBlock, 0, s_>>>(1, static_cast<const D*>(ws->bpart), nb1, ws->pnb, k, s, static_cast<D*>(ws->bred), Hd, ldh, Tm,
+                                               ws->ldt, ws->ntrue, bs, sh, first, ws->blk_pivmin, ws->st, ws->ctr);
+    }
+    {
+      ProfScope ps(cx, KSP_FUSED, nb8 * (k + 2 * s));          // reads S[:, 0:k) and Z, writes the block
+      nb2 = launch_blk<D>(ws, 1, k, s);
+    }
+    {
+      ProfScope ps(cx, KSP_FIN, 0.0);
+      ksd::k_fin_blk<D><<<ne, kBlock, 0, s_>>>(2, static_cast<const D*>(ws->bpart), nb2, ws->pnb, k, s, static_cast<D*>(ws->bred), Hd, ldh, Tm,
+                                               ws->ldt, ws->ntrue, bs, sh, first, ws->blk_pivmin, ws->st, ws->ctr);
+    }
+    k += s;
+    first = 0;
+  }
+  KS_HIP(hipGetLastError());
+}
+
+// shifts of a batch from the workspace's Ritz values; false: nothing to take them from (first expansion of a run)
+template <class D> bool blk_make_shifts(ks_workspace* ws, int smax, ksd::BlkShifts<D>& sh) {
+  if (!ws->ritz_valid || ws->ritz.empty()) return false;
+  const bool real = sizeof(D) == 8;
+  const auto th = leja_shifts(ws->ritz, smax, real);
+  double rho = 0.0;
+  for (auto z : ws->ritz)
+    if (std::isfinite(std::abs(z))) rho = std::max(rho, std::abs(z));
+  if (!(rho > 0.0) || !std::isfinite(rho)) return false;
+  const double sigma = std::ldexp(1.0, -(int)std::lround(std::log2(rho)));   // power of two ~ 1 / ||A||: range only, exact
+  for (int i = 0; i < ksd::kBlkSMax; ++i) {
+    const auto z = th[i < (int)th.size() ? i : 0];
+    if constexpr (sizeof(D) == 8) sh.theta[i] = z.real();
+    else sh.theta[i] = cd{z.real(), z.imag()};
+    sh.sigma[i] = sigma;
+  }
+  return true;
+}

@@ -24,6 +24,7 @@ namespace ks {
 struct ExpandStats {
   int steps = 0, reorth = 0, breakdowns = 0;
   int explicit_steps = 0;  // steps a backend with an implicit second DGKS pass redid in the explicit form
+  int blocks = 0, blk_bails = 0;  // s-step expansion: blocks completed / abandoned (their steps redone one by one)
 };
 
 // What the driver needs from whoever owns V.  Column/step numbering follows the reference with
@@ -54,6 +55,9 @@ template <class T> struct Backend {
     rotate(c0, c, r, Q);
     col_copy(dst, src);
   }
+  // the Ritz values (all maxdim eigenvalues of the active Hessenberg matrix) of the restart in progress: a backend with an
+  // s-step expansion takes the Newton shifts of its next blocks from them
+  virtual void note_ritz(const cplx* lams, int m) { (void)lams; (void)m; }
 };
 
 struct Params {
@@ -215,6 +219,7 @@ inline History partialschur_driver(Backend<T>& be, const Mat<T>& H, const Mat<T>
     t0 = now_s();
     if (!early_done) restart_host_early(H, Q, maxdim, ordering, active, scratch);
     const RestartResult r = restart_host_late(H, Q, maxdim, mindim, nev, p.tol, active, scratch);
+    be.note_ritz(scratch.lams.data(), maxdim);
     hist.seconds_host += now_s() - t0;
     k = r.k;
 

@@ -25,6 +25,7 @@
 #include "../../include/kschur.h"
 #include "ks_driver.hpp"
 #include "ks_kernels.hpp"
+#include "ks_block_kernels.hpp"  // kernels of the s-step (block) expansion
 
 using ks::cplx;
 using ksd::cd;
@@ -35,6 +36,7 @@ using ksd::kBlock;
 #include "ks_operators.hpp"  // ks_operator and its layouts
 #include "ks_sptrsv.hpp"     // shift-invert operator from triangular factors (sparse triangular solves)
 #include "ks_workspace.hpp"  // ks_workspace, launch helpers, expansion, rotations
+#include "ks_block.hpp"      // s-step (block) expansion: launchers, shifts, block sizes
 #include "ks_backend.hpp"    // HipBackend, residual checks, placement search
 
 // ================================================================================================
@@ -598,6 +600,7 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     KS_HIP(hipMalloc(reinterpret_cast<void**>(&w->ctr), 64));
     KS_HIP(hipMemsetAsync(w->ctr, 0, 64, ctx->stream));
     w->passes = env_int("KS_PASSES", 2) == 3 ? 3 : 2;
+    w->sstep = std::max(0, std::min(env_int("KS_SSTEP", 0), ksd::kBlkSMax));
     if (const char* mr = std::getenv("KS_IMPLICIT_MAX_RATIO")) w->max_ratio = std::atof(mr);
     KS_HIP(hipMalloc(&w->Hscratch, (size_t)(maxdim + 2) * esz));
     KS_HIP(hipMalloc(&w->partial, (size_t)w->pnb * w->pstride * esz));
@@ -644,6 +647,27 @@ int ks_workspace_set_passes(ks_workspace* ws, int passes, double max_ratio) {
     materialize(ws);  // columns in the factored form of the other setting become ordinary first
     ws->passes = passes;
     if (!std::isnan(max_ratio)) ws->max_ratio = max_ratio;
+  });
+}
+
+int ks_workspace_set_sstep(ks_workspace* ws, int s, double pivot_min) {
+  return guarded([&] {
+    KS_REQUIRE(ws, KS_ERR_ARGUMENT, "null workspace");
+    KS_REQUIRE(s >= 0 && s <= ksd::kBlkSMax, KS_ERR_ARGUMENT, "block size must be 0 (off) .. 10");
+    ws->ctx->use();
+    materialize(ws);
+    ws->sstep = s;
+    if (!std::isnan(pivot_min)) ws->blk_pivmin = pivot_min;
+  });
+}
+
+int ks_workspace_sstep_info(const ks_workspace* ws, int* s, int* blocks, int* abandoned, double* diag3) {
+  return guarded([&] {
+    KS_REQUIRE(ws, KS_ERR_ARGUMENT, "null workspace");
+    if (s) *s = ws->sstep;
+    if (blocks) *blocks = ws->blk_count;
+    if (abandoned) *abandoned = ws->blk_bails;
+    if (diag3) { diag3[0] = ws->blk_diag[0]; diag3[1] = ws->blk_diag[1]; diag3[2] = ws->blk_diag[2]; }
   });
 }
 
@@ -1078,6 +1102,7 @@ int ks_restart(ks_workspace* ws, const ks_params* p, int active, int* k_out, int
       const ks::RestartResult r =
           ks::restart_host_step(H, Q, prm.maxdim, prm.mindim, prm.nev, ks::Ordering{prm.which}, prm.tol, active, sc);
       HipBackend<T> be(nullptr, ws);
+      be.note_ritz(sc.lams.data(), prm.maxdim);
       be.rotate_and_move(r.purge, prm.maxdim - r.purge, r.k - r.purge, Q, r.k, prm.maxdim);  // src/run.jl:363-365
       if (k_out) *k_out = r.k;
       if (nlock_out) *nlock_out = r.nlock;
@@ -1116,6 +1141,7 @@ int ks_expand_restart(ks_operator* A, ks_workspace* ws, const ks_params* p, int 
       double t1 = ks::now_s();
       if (!early_done) ks::restart_host_early(H, Q, prm.maxdim, ordering, active, sc);
       const ks::RestartResult r = ks::restart_host_late(H, Q, prm.maxdim, prm.mindim, prm.nev, prm.tol, active, sc);
+      be.note_ritz(sc.lams.data(), prm.maxdim);
       double t2 = ks::now_s();
       be.rotate_and_move(r.purge, prm.maxdim - r.purge, r.k - r.purge, Q, r.k, prm.maxdim);  // src/run.jl:363-365
       double t3 = ks::now_s();

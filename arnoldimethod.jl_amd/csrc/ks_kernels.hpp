@@ -57,8 +57,12 @@ struct DevState {
   // to the vector (the explicit three-pass form).  <= 0: no limit.
   double max_ratio;
   int32_t bail;       // step handed back for the explicit second pass, else -1
-  int32_t pad_;
+  int32_t blk_bail;   // s-step expansion (ks_block_kernels.hpp): first step of a block that was abandoned (rank-deficient Gram
+                      // matrix: breakdown or an ill-conditioned Newton basis), else -1; the host redoes it step by step
+  double blk_piv1, blk_piv2;  // ... smallest Cholesky pivot ratio of the batch so far, stage 1 / stage 2 (1 = orthogonal block)
+  double blk_gdev;            // ... largest entry of |G_t - I|: how far the written blocks were from orthonormal
 };
+static_assert(sizeof(DevState) <= 128, "DevState must fit its slot in the control block (kCtlStateSlot)");
 
 // ------------------------------------------------------------------------------------------------
 // element helpers
@@ -673,6 +677,10 @@ __global__ void __launch_bounds__(kBlock)
 // coalesced.  Slots are visited in the common order (= CSR order of every row), products rounded separately, absent
 // slots skipped (never multiplied): y is bit-identical to the other layouts.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double sub_s(double a, double b) { return a - b; }
+__device__ __forceinline__ cd sub_s(cd a, cd b) { return cd{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ double scl(double a, double s);
+__device__ __forceinline__ cd scl(cd a, double s);
 constexpr int kStencilSlots = 32;
 template <class T> struct StencilDict {
   int32_t delta[kStencilSlots];
@@ -766,7 +774,8 @@ __device__ __forceinline__ void ld_pair_u(const cd* p, cd& a, cd& b) {  // compl
 template <class T, class MT2>
 __global__ void __launch_bounds__(kBlock)
     k_spmv_stencil2(const MT2* __restrict__ mask2, const StencilDict<T> d, int nslots, const T* __restrict__ x,
-                    T* __restrict__ y, int64_t n, int ntiles, const DevState* __restrict__ st) {
+                    T* __restrict__ y, int64_t n, int ntiles, const DevState* __restrict__ st, int shifted = 0,
+                    T theta = T{}, double sigma = 1.0) {
   if (st && st->breakdown >= 0) return;
   const int tile = xcd_remap(blockIdx.x, ntiles);
   const int64_t r = 2 * ((int64_t)tile * kBlock + threadIdx.x);  // rows r, r + 1
@@ -802,6 +811,16 @@ __global__ void __launch_bounds__(kBlock)
         s1 = ((m1 >> (k0 + u)) & 1u) ? add_(s1, p1) : s1;
       }
     }
+  }
+  if (shifted) {
+    // Newton-basis step of the s-step expansion (ks_block_kernels.hpp): y = sigma (A x - theta x), fused -- the rows' own x
+    // entries are one more (cached) pair load instead of a 24 n-byte pass of their own.  shifted == 0: the plain product,
+    // bit-identical to every other layout.
+    T x0, x1;
+    if (two) ld_pair_u(x + r, x0, x1);
+    else { x0 = x[r]; x1 = x0; }
+    s0 = scl(sub_s(s0, mul_(theta, x0)), sigma);
+    s1 = scl(sub_s(s1, mul_(theta, x1)), sigma);
   }
   if (two) {
     if constexpr (sizeof(T) == 8) st_pack_nt(y + r, make_double2(s0, s1));

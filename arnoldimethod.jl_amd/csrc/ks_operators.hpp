@@ -22,6 +22,9 @@ struct ks_operator {
   // y = A x on device pointers, enqueued on ctx->stream; `st` lets the kernels of a batch skip work
   // after a breakdown.
   virtual void apply(const void* x, void* y, const DevState* st) = 0;
+  // y = sigma (A x - theta x): one step of the Newton basis of the s-step expansion (ks_block.hpp).  Default: the product
+  // followed by a streaming pass (24 n bytes); layouts with a fused form override it.  theta = (re, im).
+  virtual void apply_shifted(const void* x, void* y, double theta_re, double theta_im, double sigma, int64_t ld, const DevState* st);
 };
 
 namespace {
@@ -123,6 +126,20 @@ template <class D> struct CsrOp : ks_operator {
     };
     if (ptr64) go(int64_t{});
     else go(int32_t{});
+  }
+  // fused Newton-basis step (s-step expansion): the paired stencil kernel applies y = sigma (A x - theta x) itself
+  bool shift_on = false;
+  D shift_theta{};
+  double shift_sigma = 1.0;
+  void apply_shifted(const void* xv, void* yv, double tre, double tim, double sigma, int64_t ld, const DevState* st) override {
+    static const int fuse = env_int("KS_SHIFT_FUSED", 1);
+    const bool fused = fuse && nstencil > 0 && nghost == 0 && smask2 && n_local >= 2 && cblocks.empty() && env_int("KS_STENCIL_PAIRS", 1);
+    if (!fused) { ks_operator::apply_shifted(xv, yv, tre, tim, sigma, ld, st); return; }
+    shift_on = true;
+    if constexpr (sizeof(D) == 8) shift_theta = tre; else shift_theta = D{tre, tim};
+    shift_sigma = sigma;
+    try { apply(xv, yv, st); } catch (...) { shift_on = false; throw; }
+    shift_on = false;
   }
   void apply(const void* xv, void* yv, const DevState* st) override {
     const D* x = static_cast<const D*>(xv);
@@ -247,9 +264,9 @@ template <class D> struct CsrOp : ks_operator {
         // two rows per lane, 16-byte gathers (no ghost columns: single GPU)
         const int nt = (int)(((n_local + 1) / 2 + kBlock - 1) / kBlock);
         if (stencil_mask_bytes == 1)
-          ksd::k_spmv_stencil2<D, uint16_t><<<nt, kBlock, 0, s>>>(static_cast<const uint16_t*>(smask2), sdict, nstencil, x, y, n_local, nt, st);
+          ksd::k_spmv_stencil2<D, uint16_t><<<nt, kBlock, 0, s>>>(static_cast<const uint16_t*>(smask2), sdict, nstencil, x, y, n_local, nt, st, shift_on ? 1 : 0, shift_theta, shift_sigma);
         else
-          ksd::k_spmv_stencil2<D, uint64_t><<<nt, kBlock, 0, s>>>(static_cast<const uint64_t*>(smask2), sdict, nstencil, x, y, n_local, nt, st);
+          ksd::k_spmv_stencil2<D, uint64_t><<<nt, kBlock, 0, s>>>(static_cast<const uint64_t*>(smask2), sdict, nstencil, x, y, n_local, nt, st, shift_on ? 1 : 0, shift_theta, shift_sigma);
         KS_HIP(hipGetLastError());
         return;
       }
@@ -946,3 +963,15 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
 
 }  // namespace
 
+// default of ks_operator::apply_shifted: product + one streaming pass
+inline void ks_operator::apply_shifted(const void* x, void* y, double theta_re, double theta_im, double sigma, int64_t ld, const DevState* st) {
+  apply(x, y, st);
+  ProfScope ps(ctx, KSP_SCALE, 3.0 * (double)n_local * (dtype == KS_F64 ? 8.0 : 16.0));
+  const int nbk = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->num_cu * 8, ld / (2 * kBlock) + 1));
+  if (dtype == KS_F64) {
+    ksd::k_shift_scale<double><<<nbk, kBlock, 0, ctx->stream>>>(static_cast<double*>(y), static_cast<const double*>(x), theta_re, sigma, ld, st);
+  } else {
+    ksd::k_shift_scale<cd><<<nbk, kBlock, 0, ctx->stream>>>(static_cast<cd*>(y), static_cast<const cd*>(x), cd{theta_re, theta_im}, sigma, ld, st);
+  }
+  KS_HIP(hipGetLastError());
+}

@@ -94,6 +94,19 @@ struct ks_workspace {
   std::vector<double> ones;
   int lazy_lo = 1 << 30, lazy_hi = -1;
   bool has_lazy() const { return lazy_hi >= lazy_lo || t_lazy; }
+  // S-STEP (block) expansion (ks_block.hpp): s steps per block, two passes over the basis per BLOCK.  0 / 1: off.
+  int sstep = 0;                // KS_SSTEP at creation, ks_workspace_set_sstep afterwards
+  double blk_pivmin = 1e-6;     // smallest Cholesky pivot ratio d_i / G_ii a block may have (below: abandoned, steps redone one by one)
+  std::vector<std::complex<double>> ritz;  // Ritz values of the last restart (Newton shifts of the next expansion)
+  bool ritz_valid = false;
+  std::vector<char> Hfull;      // host H as the last full expansion left it (shifts for callers that run their own restart)
+  bool hfull_valid = false;
+  void* bpart = nullptr;        // device: partial sums of the block kernels, [entry][workgroup]
+  void* bred = nullptr;         // device: reduced entries
+  void* bscr = nullptr;         // device: ksd::BlkScratch
+  bool blk_tail = false;        // the T-lazy columns were produced by blocks (a batch continuing on them starts a new T)
+  double blk_diag[3] = {1.0, 1.0, 0.0};  // of the last batch: worst pivot ratio of stage 1 / stage 2, largest |G_t - I| entry
+  int blk_count = 0, blk_bails = 0;      // blocks completed / abandoned since creation
   int nb = 0;               // streaming workgroups (capped for small problems)
   int pnb = 0;              // column stride of `partial` (>= every producer's grid)
   uint64_t seed = 20240917ull;
@@ -124,6 +137,7 @@ struct ks_workspace {
     (void)hipFree(scal); (void)hipHostFree(scal_h); (void)hipHostFree(coef_h);
     (void)hipFree(Qd); (void)hipHostFree(Qstage); (void)hipFree(tmp); (void)hipFree(tmp2); (void)hipFree(oop);
     (void)hipHostFree(Hstage_early); (void)hipHostFree(mbox); (void)hipFree(ctr);
+    (void)hipFree(bpart); (void)hipFree(bred); (void)hipFree(bscr);
   }
 };
 
@@ -361,6 +375,7 @@ template <class D> void enqueue_orthogonalize(ks_workspace* ws, int j) {
 inline void reset_lazy(ks_workspace* ws) {
   ws->t_lazy = false;
   ws->t_hi = -1;
+  ws->blk_tail = false;
   if (!(ws->lazy_hi >= ws->lazy_lo)) return;
   for (int c = ws->lazy_lo; c <= ws->lazy_hi; ++c) ws->hostscale[c] = 1.0;
   ws->colscale_dirty = true;  // the device copy is only read inside expansion batches: uploaded with the next one's state
@@ -622,6 +637,8 @@ inline void reset_state(ks_workspace* ws, bool upload_H = false, double sigma0 =
   std::memset(ws->st_h, 0, sizeof(DevState));
   ws->st_h->breakdown = -1;
   ws->st_h->bail = -1;
+  ws->st_h->blk_bail = -1;
+  ws->st_h->blk_piv1 = ws->st_h->blk_piv2 = 1.0;
   ws->st_h->max_ratio = ws->max_ratio;
   ws->st_h->sigma = sigma0;
   if (upload_H) {
@@ -923,6 +940,7 @@ template <class T> void rotate_tfold(ks_workspace* ws, int c0, int c, int r, con
   rotate_device<D>(ws, 0, cin, rr, out0, extra_elsewhere ? dst : -1);
   ws->t_lazy = false;
   ws->t_hi = -1;
+  ws->blk_tail = false;
 }
 
 // all T-lazy columns -> ordinary columns, in place (verbs outside the expansion / restart pair are about to read V)

@@ -220,6 +220,24 @@ int ks_workspace_passes(const ks_workspace* ws, int* passes);
  * with the correction applied to the vector (counted in ks_expand_stats.explicit_steps / ks_history.explicit_steps).
  * Default 1e-3 (KS_IMPLICIT_MAX_RATIO at creation); <= 0 removes the limit; NaN keeps the current value. */
 int ks_workspace_set_passes(ks_workspace* ws, int passes, double max_ratio);
+/* S-STEP (block) EXPANSION -- a faster form of iterate_arnoldi!(A, arnoldi, from:to), src/expansion.jl:116-133, for
+ * device-resident operators on one GPU.  s >= 2: the steps of a range are taken in blocks of up to s (instantiated sizes:
+ * 1-5, 8, 10 for Float64, 1-5 for ComplexF64): s operator products build a Newton basis (shifts = Leja-ordered Ritz values
+ * of the previous restart, so the first expansion of a run still goes step by step), then TWO passes over the basis
+ * orthogonalise the whole block (block classical Gram-Schmidt with Pythagorean inner products, applied twice, both times
+ * carried in the triangular factor of the implicit second pass) and the s Hessenberg columns follow from the basis
+ * recurrence -- per block what the default expansion does per step.  Same Krylov space, hence the same H, V and Ritz values
+ * up to rounding (H to ~1e-12 relative on the reference's test matrices, tests/test_sstep_model.py); the DGKS decisions of
+ * src/expansion.jl:91 are not taken (the second projection is always applied).  A block whose Gram matrix has a Cholesky
+ * pivot below pivot_min times its diagonal entry (breakdown, src/expansion.jl:99-102, or an ill-conditioned basis) is
+ * abandoned before anything is committed and its steps are redone one at a time, which takes the reference's decisions.
+ * Like the implicit second pass it needs the library's provenance of the factorisation; otherwise, for host-callback
+ * operators, distributed contexts and maxdim > 64 the expansion runs as before.  s = 0 / 1: off (default; KS_SSTEP at
+ * creation).  pivot_min: NaN keeps the current value (default 1e-6).
+ * ks_workspace_sstep_info: blocks completed / abandoned since creation; diag3 = of the last batch { smallest pivot ratio
+ * of the first stage, of the second stage, largest |entry| of (Gram matrix of the written block - I) }. */
+int ks_workspace_set_sstep(ks_workspace* ws, int s, double pivot_min);
+int ks_workspace_sstep_info(const ks_workspace* ws, int* s, int* blocks, int* abandoned, double* diag3);
 /* PROVENANCE.  The implicit second pass reads the columns < from of the host H and relies on the Arnoldi relation
  * A V[:, 0:from-1) = V[:, 0:from) H[0:from, 0:from-1) holding for them -- the reference's iterate_arnoldi! reads
  * neither.  The library therefore takes the implicit form only for a factorisation it produced itself: after
