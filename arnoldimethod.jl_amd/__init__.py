@@ -7,7 +7,7 @@ API call dlopens `libkschur_hip.so` and fails loudly if it (or a gfx950 device) 
 from ._lib import ArgumentError, CommTimeout, DimensionMismatch, HipError, QRDidNotConverge  # noqa: F401
 from .api import (  # noqa: F401
     LI, LM, LR, SI, SR, ArnoldiWorkspace, Context, History, Operator, PartialSchur, Target, as_operator,
-    csr_operator, default_context, dense_operator, device_operator, host_operator, lu_operator, splu_operator, partialeigen, partialschur, partialschur_, vtype,
+    csr_operator, default_context, dense_operator, device_operator, host_operator, lu_operator, splu_operator, partialeigen, partialschur, partialschur_, sstep_partition, vtype,
 )
 from . import matrices  # noqa: F401
 # `extras` (ready-made device operators on the callback seam; needs torch + rocSPARSE) is imported on demand:
@@ -16,5 +16,5 @@ from . import matrices  # noqa: F401
 __all__ = [
     "partialschur", "partialschur_", "partialeigen", "ArnoldiWorkspace", "PartialSchur", "History",
     "LM", "LR", "SR", "LI", "SI", "Context", "Operator", "csr_operator", "dense_operator", "host_operator", "device_operator", "lu_operator", "splu_operator", "as_operator",
-    "ArgumentError", "DimensionMismatch", "CommTimeout", "matrices",
+    "ArgumentError", "DimensionMismatch", "CommTimeout", "matrices", "sstep_partition",
 ]

@@ -619,11 +619,12 @@ class ArnoldiWorkspace:
         implicit form carries before a step is redone explicitly (NaN keeps the current value, <= 0 removes the limit)."""
         check(_lib.load().ks_workspace_set_passes(self._h, int(passes), float(max_ratio)))
 
-    def set_sstep(self, s: int, pivot_min: float = float("nan")):
+    def set_sstep(self, s: int, pivot_min: float = float("nan"), gram_dev_max: float = float("nan")):
         """s-step (block) expansion: s >= 2 takes the steps of an expansion in blocks of up to s (two reads of the basis per
         BLOCK instead of per step; include/kschur.h, ks_workspace_set_sstep); 0 switches it off.  `pivot_min`: smallest
-        Cholesky pivot ratio a block may have before it is abandoned and redone step by step (NaN keeps the value)."""
-        check(_lib.load().ks_workspace_set_sstep(self._h, int(s), float(pivot_min)))
+        Cholesky pivot ratio, `gram_dev_max`: largest deviation of the written block's Gram matrix from I a block may have
+        before it is abandoned and redone step by step (NaN keeps the value)."""
+        check(_lib.load().ks_workspace_set_sstep(self._h, int(s), float(pivot_min), float(gram_dev_max)))
 
     @property
     def sstep_info(self) -> dict:
@@ -669,6 +670,33 @@ class ArnoldiWorkspace:
             self.close()
         except Exception:
             pass
+
+
+def sstep_partition(dtype, k0: int, count: int, smax: int) -> list:
+    """Block sizes the s-step expansion uses for `count` steps on top of `k0` existing columns (mirror of blk_partition,
+    csrc/ks_block.hpp: instantiated sizes 1-5, 8, 10 for Float64, 1-5 for ComplexF64; [] = not block-capable).  For byte
+    accounting in benchmarks: a block of s steps on k columns reads 8 n (k + s) + 8 n (k + s) and writes 8 n s bytes
+    (x2 for ComplexF64) next to its s operator products."""
+    cplx = np.dtype(dtype).kind == "c"
+
+    def ok(k, s):
+        if not (1 <= s <= 5 or (not cplx and s in (8, 10))) or k < 1 or k + s > 65:
+            return False
+        if cplx:
+            return k <= 32
+        return s <= 5 if k > 48 else True
+
+    out, k = [], k0
+    while count > 0:
+        s = min(count, smax)
+        while s > 1 and not ok(k, s):
+            s -= 1
+        if not ok(k, s):
+            return []
+        out.append(s)
+        k += s
+        count -= s
+    return out
 
 
 # ------------------------------------------------------------------ results

@@ -72,9 +72,9 @@ template <class T> struct HipBackend : ks::Backend<T> {
       // and a single GPU; a range of one step gains nothing.
       std::vector<int> blk_sizes;
       ksd::BlkShifts<D> blk_sh{};
-      if (tpath && !no_block && ws->sstep >= 2 && op->async_capable && !ws->ctx->distributed() && jend - j0 + 1 >= 2 &&
-          blk_make_shifts<D>(ws, std::min(ws->sstep, ksd::kBlkSMax), blk_sh))
-        blk_sizes = blk_partition(ws->dtype, j0, jend - j0 + 1, std::min(ws->sstep, ksd::kBlkSMax));
+      if (tpath && !no_block && ws->sstep_eff >= 2 && op->async_capable && !ws->ctx->distributed() && jend - j0 + 1 >= 2 &&
+          blk_make_shifts<D>(ws, std::min(ws->sstep_eff, ksd::kBlkSMax), blk_sh))
+        blk_sizes = blk_partition(ws->dtype, j0, jend - j0 + 1, std::min(ws->sstep_eff, ksd::kBlkSMax));
       const bool bpath = !blk_sizes.empty();
       if (tpath && (bpath || ws->blk_tail || !(ws->t_lazy && j0 == ws->t_hi + 1))) {
         materialize(ws);   // whatever is lazy (either kind) becomes ordinary: this batch starts a new T
@@ -163,7 +163,16 @@ template <class T> struct HipBackend : ks::Backend<T> {
         ws->blk_diag[2] = ws->st_h->blk_gdev;
         int done = 0;
         for (int sz : blk_sizes) { if (j0 + done + sz - 1 <= last_done) { done += sz; ws->blk_count++; } }
-        if (blk_bail >= 0) { ws->blk_bails++; stats.blk_bails++; no_block = true; }
+        if (blk_bail >= 0) {
+          // abandoned: the rest of this range goes step by step; and since what fails is usually the conditioning of the
+          // Newton basis (a spectrum the real / few shifts do not cover), later batches use smaller blocks -- 5 -> 2 -> off
+          ws->blk_bails++; stats.blk_bails++; no_block = true;
+          ws->sstep_eff = ws->sstep_eff >= 4 ? ws->sstep_eff / 2 : (ws->sstep_eff > 2 ? 2 : 1);
+          ws->blk_clean = 0;
+        } else if (++ws->blk_clean >= 16 && ws->sstep_eff < ws->sstep) {
+          ws->sstep_eff = std::min(ws->sstep, std::max(2, ws->sstep_eff + 1));   // (probe a larger block again)
+          ws->blk_clean = 0;
+        }
         stats.blocks += (int)blk_sizes.size() - (blk_bail >= 0 ? 1 : 0);
       }
       if (early_ran && bd >= 0) {  // the last step broke down: withdraw (rare; the caller redoes the early part)
@@ -209,7 +218,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
     // the factorisation up to `to` is the library's own again (or stays unknown)
     if (trusted) prov_set(ws, to);
     else prov_drop(ws);
-    if (ws->sstep >= 2 && to == ws->maxdim && !early_stands) {
+    if (ws->sstep_eff >= 2 && to == ws->maxdim && !early_stands) {
       // a caller that runs the restart itself (the reference's own _partialschur on a device basis) never tells the library
       // its Ritz values: keep the full Hessenberg matrix, the next expansion takes its shifts from it (blk_shifts_from_saved_H)
       ws->Hfull.assign(static_cast<const char*>(ws->H), static_cast<const char*>(ws->H) + h_bytes(ws));
@@ -230,7 +239,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
   // factorisation of a copy on the host, ~0.1 ms: only on the path of callers that run their own restart)
   void blk_shifts_from_saved_H() {
     using TT = T;
-    if (ws->sstep < 2 || ws->ritz_valid || !ws->hfull_valid) return;
+    if (ws->sstep_eff < 2 || ws->ritz_valid || !ws->hfull_valid) return;
     const int m = ws->maxdim;
     std::vector<TT> Hc((size_t)(m + 1) * m), Qc((size_t)m * m, TT(0));
     std::memcpy(Hc.data(), ws->Hfull.data(), Hc.size() * sizeof(TT));

@@ -94,14 +94,22 @@ template <class D, int NCW, int S> int launch_bdots_t(ks_workspace* ws, int k) {
   else ksd::k_bdots<D, NCW, S, U, false><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const D*>(ws->V), ws->ld, k, static_cast<D*>(ws->bpart), ws->pnb, ws->st);
   return nb;
 }
-template <class D, int NCW, int S> int launch_bupdate_t(ks_workspace* ws, int k) {
+inline int& blk_dbg() { static int v = env_int("KS_BLK_DBG", 0); return v; }
+inline int& blk_wb() { static int v = env_int("KS_BLK_WB", 8); return v; }
+template <class D, int NCW, int S, int WB> int launch_bupdate_w(ks_workspace* ws, int k) {
   constexpr int U = S <= 5 ? 2 : 1;
   static int cache = -1;
-  const int nb = cap_blocks(ws, resident_blocks(ws->ctx, ksd::k_bupdate<D, NCW, S, U, true>, 0, cache), 64 * U);
+  const int nb = cap_blocks(ws, resident_blocks(ws->ctx, ksd::k_bupdate<D, NCW, S, U, true, WB>, 0, cache), 64 * U);
   auto* bs = static_cast<ksd::BlkScratch<D>*>(ws->bscr);
-  if (ws->v_nt) ksd::k_bupdate<D, NCW, S, U, true><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<D*>(ws->V), ws->ld, k, bs->coefp, k, bs->r1inv, static_cast<D*>(ws->bpart), ws->pnb, ws->st);
-  else ksd::k_bupdate<D, NCW, S, U, false><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<D*>(ws->V), ws->ld, k, bs->coefp, k, bs->r1inv, static_cast<D*>(ws->bpart), ws->pnb, ws->st);
+  if (ws->v_nt) ksd::k_bupdate<D, NCW, S, U, true, WB><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<D*>(ws->V), ws->ld, k, bs->coefp, k, bs->r1inv, static_cast<D*>(ws->bpart), ws->pnb, ws->st, blk_dbg());
+  else ksd::k_bupdate<D, NCW, S, U, false, WB><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<D*>(ws->V), ws->ld, k, bs->coefp, k, bs->r1inv, static_cast<D*>(ws->bpart), ws->pnb, ws->st, blk_dbg());
   return nb;
+}
+template <class D, int NCW, int S> int launch_bupdate_t(ks_workspace* ws, int k) {
+  if constexpr (sizeof(D) == 8) {
+    if (blk_wb() > 0 && !(blk_dbg() & 2)) return launch_bupdate_w<D, NCW, S, 8>(ws, k);   // (dbg & 2: the direct-store form)
+  }
+  return launch_bupdate_w<D, NCW, S, 0>(ws, k);
 }
 // (which, k, s) -> instantiation
 template <class D, int NCW> int launch_blk_s(ks_workspace* ws, int which, int k, int s) {
@@ -159,7 +167,7 @@ void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::v
     {
       ProfScope ps(cx, KSP_FIN, 0.0);
       ksd::k_fin_blk<D><<<ne, kBlock, 0, s_>>>(1, static_cast<const D*>(ws->bpart), nb1, ws->pnb, k, s, static_cast<D*>(ws->bred), Hd, ldh, Tm,
-                                               ws->ldt, ws->ntrue, bs, sh, first, ws->blk_pivmin, ws->st, ws->ctr);
+                                               ws->ldt, ws->ntrue, bs, sh, first, ws->blk_pivmin, ws->blk_gdevmax, ws->st, ws->ctr);
     }
     {
       ProfScope ps(cx, KSP_FUSED, nb8 * (k + 2 * s));          // reads S[:, 0:k) and Z, writes the block
@@ -168,7 +176,7 @@ void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::v
     {
       ProfScope ps(cx, KSP_FIN, 0.0);
       ksd::k_fin_blk<D><<<ne, kBlock, 0, s_>>>(2, static_cast<const D*>(ws->bpart), nb2, ws->pnb, k, s, static_cast<D*>(ws->bred), Hd, ldh, Tm,
-                                               ws->ldt, ws->ntrue, bs, sh, first, ws->blk_pivmin, ws->st, ws->ctr);
+                                               ws->ldt, ws->ntrue, bs, sh, first, ws->blk_pivmin, ws->blk_gdevmax, ws->st, ws->ctr);
     }
     k += s;
     first = 0;

@@ -206,15 +206,21 @@ __global__ void __launch_bounds__(kBlock)
 // the four meet in LDS (double buffered, one barrier per iteration),  Qt[r,i] = -(t_0 + t_1 + t_2 + t_3)[i].
 // Wave w stores the columns i = w mod 4.
 // ---------------------------------------------------------------------------------------------------------------------------
-template <class T, int NCW, int S, int U, bool NT>
+// WB > 0: the written block is staged in LDS and goes out in bursts of WB iterations (WB x U KiB contiguous per column, all
+// four waves writing) -- every switch between reading and writing costs the memory channels a turn-around, and this kernel
+// writes s of the k + 2 s streams it touches (k_axpy_dots_cs: profiles/r02_write_bursts.txt); the exchange buffer is then
+// single (a second barrier per iteration) so that both fit the CU's 160 KiB.  WB = 0: direct 1 KiB stores, double buffer.
+template <class T, int NCW, int S, int U, bool NT, int WB = 0>
 __global__ void __launch_bounds__(kBlock)
     k_bupdate(T* __restrict__ V, int64_t ldv, int k, const T* __restrict__ coefp, int ldc, const T* __restrict__ r1inv,
-              T* __restrict__ partial, int pnb, const DevState* __restrict__ st) {
+              T* __restrict__ partial, int pnb, const DevState* __restrict__ st, int dbg = 0) {
   if (st && st->breakdown >= 0) return;
   using P = typename Pack<T>::type;
   constexpr int R = Pack<T>::R;
   constexpr int NG = S * (S + 1) / 2, NGW = (NG + 3) / 4;
-  __shared__ P tbuf[2][4][U][S][64];
+  constexpr int NB = WB > 0 ? 1 : 2;
+  __shared__ P tbuf[NB][4][U][S][64];
+  __shared__ P wout[WB > 0 ? S : 1][WB > 0 ? WB * U * 64 : 1];
   __shared__ T cf[4 * NCW][S];   // coefp rows (columns of the basis) as the waves index them: cf[c][i]
   __shared__ T ri[S][S];         // r1inv[l][i], l <= i
   const int lane = threadIdx.x & 63;
@@ -297,19 +303,22 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int i = 0; i < S; ++i) tbuf[it & 1][wave][u][i][lane] = t[u][i];
+      for (int i = 0; i < S; ++i) tbuf[it & (NB - 1)][wave][u][i][lane] = t[u][i];
     __syncthreads();
     P q[U][S];
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int i = 0; i < S; ++i) {
-        const P t0 = tbuf[it & 1][0][u][i][lane], t1 = tbuf[it & 1][1][u][i][lane];
-        const P t2 = tbuf[it & 1][2][u][i][lane], t3 = tbuf[it & 1][3][u][i][lane];
+        const P t0 = tbuf[it & (NB - 1)][0][u][i][lane], t1 = tbuf[it & (NB - 1)][1][u][i][lane];
+        const P t2 = tbuf[it & (NB - 1)][2][u][i][lane], t3 = tbuf[it & (NB - 1)][3][u][i][lane];
         P qq = sub_pack(zero_pack(T{}), addp(addp(t0, t1), addp(t2, t3)));
         if (!ok[u]) qq = zero_pack(T{});
         q[u][i] = qq;
-        if ((i & 3) == wave && ok[u]) st_pack_nt(Z + (int64_t)i * ldv + r[u], qq);
+        if ((i & 3) == wave && ok[u] && !(dbg & 1)) {  // (dbg & 1: timing probe without the write stream)
+          if constexpr (WB > 0) wout[i][((it % WB) * U + u) * 64 + lane] = qq;
+          else st_pack_nt(Z + (int64_t)i * ldv + r[u], qq);
+        }
       }
 #pragma unroll
     for (int ii = 0; ii < NCW; ++ii)
@@ -327,6 +336,20 @@ __global__ void __launch_bounds__(kBlock)
           for (int u = 0; u < U; ++u) dotp(gacc[g >> 2], q[u][i], q[u][i2]);
         }
       }
+    if constexpr (WB > 0) {
+      const bool lastt = base + 64 * U >= pe;
+      if ((it % WB) == WB - 1 || lastt) {  // workgroup-uniform
+        __syncthreads();
+        const int64_t fb = base - (int64_t)(it % WB) * 64 * U;  // first pack staged
+        const int64_t fe = (base + 64 * U < pe) ? base + 64 * U : pe;
+        if (!(dbg & 1)) {
+#pragma unroll
+          for (int i = 0; i < S; ++i)
+            for (int64_t o = fb + threadIdx.x; o < fe; o += kBlock) st_pack_nt(Z + (int64_t)i * ldv + o * R, wout[i][o - fb]);
+        }
+      }
+      __syncthreads();  // single exchange buffer (and the staging area) may be overwritten from here on
+    }
   }
   constexpr int D = Dpe<T>::value;
   constexpr int NE = NCW * S + NGW;
@@ -448,7 +471,7 @@ template <class T>
 __global__ void __launch_bounds__(kBlock)
     k_fin_blk(int stage, const T* __restrict__ partial, int nb, int pnb, int k, int s, T* __restrict__ red, T* __restrict__ Hd,
               int ldh, T* __restrict__ Tm, int ldt, int ntrue, BlkScratch<T>* __restrict__ bs, BlkShifts<T> sh, int first,
-              double pivmin, DevState* __restrict__ st, unsigned* __restrict__ counter) {
+              double pivmin, double gdevmax, DevState* __restrict__ st, unsigned* __restrict__ counter) {
   if (st->breakdown >= 0) return;
   __shared__ T sm[kBlock];
   __shared__ int last_wg;
@@ -489,16 +512,27 @@ __global__ void __launch_bounds__(kBlock)
     Gm[i + i2 * s] = a;
   }
   __syncthreads();
+  // How far the block that stage 1 wrote is from orthonormal: G_t = I + delta, delta ~ eps cond(R_1)^2 (the cancellation in
+  // G_Z - P^H P amplified by the conditioning of the Newton basis).  The recovered Hessenberg columns carry errors of order
+  // eps cond(R_1), so a block is only accepted while delta <= gdevmax (default 1e-8: cond <= ~1e4, H at the per-step path's
+  // accuracy; tests/test_sstep_model.py); beyond that it is abandoned like a rank-deficient one and the host lowers s.
   double gdev = 0.0;
-  if (stage == 2 && tid == 0) {  // how far the written block is from orthonormal (diagnostic)
-    for (int i2 = 0; i2 < s; ++i2)
-      for (int i = 0; i <= i2; ++i) {
-        const T g = Gin[gram_idx(i, i2)];
-        gdev = fmax(gdev, sqrt(abs2_(sub_(g, from_real(i == i2 ? 1.0 : 0.0, T{})))));
-      }
+  if (stage == 2) {
+    if (tid == 0) {
+      for (int i2 = 0; i2 < s; ++i2)
+        for (int i = 0; i <= i2; ++i) {
+          const T g = Gin[gram_idx(i, i2)];
+          gdev = fmax(gdev, sqrt(abs2_(sub_(g, from_real(i == i2 ? 1.0 : 0.0, T{})))));
+        }
+      sh_ratio = gdev;
+    }
+    __syncthreads();
+    gdev = sh_ratio;
+    __syncthreads();
   }
-  const double worst = chol_upper_lds(Gm, s, stage == 1 ? pivmin : 0.25, &sh_ratio);
-  if (!(worst > (stage == 1 ? pivmin : 0.25))) {
+  const bool too_far = stage == 2 && !(gdev <= gdevmax);
+  const double worst = too_far ? 0.0 : chol_upper_lds(Gm, s, stage == 1 ? pivmin : 0.25, &sh_ratio);
+  if (too_far || !(worst > (stage == 1 ? pivmin : 0.25))) {
     // the block is (numerically) rank deficient: a breakdown, or a Newton basis too ill-conditioned to trust.  Nothing of
     // this block has been committed to T / H; the host redoes its steps one at a time (the per-step path takes the
     // reference's breakdown decisions, src/expansion.jl:99-102)
@@ -506,7 +540,7 @@ __global__ void __launch_bounds__(kBlock)
       st->breakdown = k;   // step index of the block's first step == number of existing columns
       st->blk_bail = k;
       if (stage == 1) st->blk_piv1 = fmin(st->blk_piv1, worst);
-      else st->blk_piv2 = fmin(st->blk_piv2, worst);
+      else { st->blk_piv2 = fmin(st->blk_piv2, worst); st->blk_gdev = fmax(st->blk_gdev, gdev); }
     }
     return;
   }

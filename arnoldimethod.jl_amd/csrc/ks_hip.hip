@@ -601,6 +601,9 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     KS_HIP(hipMemsetAsync(w->ctr, 0, 64, ctx->stream));
     w->passes = env_int("KS_PASSES", 2) == 3 ? 3 : 2;
     w->sstep = std::max(0, std::min(env_int("KS_SSTEP", 0), ksd::kBlkSMax));
+    w->sstep_eff = w->sstep;
+    if (const char* e = std::getenv("KS_SSTEP_GDEV_MAX")) w->blk_gdevmax = std::atof(e);
+    if (const char* e = std::getenv("KS_SSTEP_PIVOT_MIN")) w->blk_pivmin = std::atof(e);
     if (const char* mr = std::getenv("KS_IMPLICIT_MAX_RATIO")) w->max_ratio = std::atof(mr);
     KS_HIP(hipMalloc(&w->Hscratch, (size_t)(maxdim + 2) * esz));
     KS_HIP(hipMalloc(&w->partial, (size_t)w->pnb * w->pstride * esz));
@@ -650,24 +653,66 @@ int ks_workspace_set_passes(ks_workspace* ws, int passes, double max_ratio) {
   });
 }
 
-int ks_workspace_set_sstep(ks_workspace* ws, int s, double pivot_min) {
+int ks_workspace_set_sstep(ks_workspace* ws, int s, double pivot_min, double gram_dev_max) {
   return guarded([&] {
     KS_REQUIRE(ws, KS_ERR_ARGUMENT, "null workspace");
     KS_REQUIRE(s >= 0 && s <= ksd::kBlkSMax, KS_ERR_ARGUMENT, "block size must be 0 (off) .. 10");
     ws->ctx->use();
     materialize(ws);
     ws->sstep = s;
+    ws->sstep_eff = s;
+    ws->blk_clean = 0;
     if (!std::isnan(pivot_min)) ws->blk_pivmin = pivot_min;
+    if (!std::isnan(gram_dev_max)) ws->blk_gdevmax = gram_dev_max;
   });
 }
 
 int ks_workspace_sstep_info(const ks_workspace* ws, int* s, int* blocks, int* abandoned, double* diag3) {
   return guarded([&] {
     KS_REQUIRE(ws, KS_ERR_ARGUMENT, "null workspace");
-    if (s) *s = ws->sstep;
+    if (s) *s = ws->sstep_eff;
     if (blocks) *blocks = ws->blk_count;
     if (abandoned) *abandoned = ws->blk_bails;
     if (diag3) { diag3[0] = ws->blk_diag[0]; diag3[1] = ws->blk_diag[1]; diag3[2] = ws->blk_diag[2]; }
+  });
+}
+
+// diagnostics: average duration of `reps` launches of one block kernel on the workspace's basis (contents irrelevant: the
+// kernels have no data-dependent control flow); which = 0 k_bdots, 1 k_bupdate.  Leaves columns k..k+s-1 overwritten.
+int ks_debug_blk_time(ks_workspace* ws, int k, int s, int which, int reps, int dbg, double* ms_per_launch, int* grid) {
+  return guarded([&] {
+    KS_REQUIRE(ws && ms_per_launch, KS_ERR_ARGUMENT, "null argument");
+    KS_REQUIRE(blk_shape_ok(ws->dtype, k, s) && k + s <= ws->maxdim + 1, KS_ERR_ARGUMENT, "no block kernel for this shape");
+    KS_REQUIRE(reps >= 1 && (which == 0 || which == 1), KS_ERR_ARGUMENT, "bad reps / which");
+    ws->ctx->use();
+    materialize(ws);
+    prov_drop(ws);
+    blk_ensure_buffers(ws);
+    reset_state(ws);
+    const int saved = blk_dbg();
+    blk_dbg() = dbg;
+    hipEvent_t a, b;
+    KS_HIP(hipEventCreate(&a));
+    KS_HIP(hipEventCreate(&b));
+    int nb = 0;
+    auto run = [&](int n) {
+      for (int i = 0; i < n; ++i) {
+        if (ws->dtype == KS_F64) nb = launch_blk<double>(ws, which, k, s);
+        else nb = launch_blk<cd>(ws, which, k, s);
+      }
+    };
+    run(2);  // warm-up
+    KS_HIP(hipEventRecord(a, ws->ctx->stream));
+    run(reps);
+    KS_HIP(hipEventRecord(b, ws->ctx->stream));
+    KS_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    KS_HIP(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    blk_dbg() = saved;
+    *ms_per_launch = (double)ms / reps;
+    if (grid) *grid = nb;
   });
 }
 

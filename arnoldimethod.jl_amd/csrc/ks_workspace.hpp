@@ -97,6 +97,9 @@ struct ks_workspace {
   // S-STEP (block) expansion (ks_block.hpp): s steps per block, two passes over the basis per BLOCK.  0 / 1: off.
   int sstep = 0;                // KS_SSTEP at creation, ks_workspace_set_sstep afterwards
   double blk_pivmin = 1e-6;     // smallest Cholesky pivot ratio d_i / G_ii a block may have (below: abandoned, steps redone one by one)
+  double blk_gdevmax = 1e-8;    // largest entry of |Gram matrix of the written block - I| a block may have (~ eps cond(R_1)^2)
+  int sstep_eff = 0;            // block size in force: lowered when blocks are abandoned (ill-conditioned Newton basis), raised
+  int blk_clean = 0;            //   again after blk_clean consecutive clean batches
   std::vector<std::complex<double>> ritz;  // Ritz values of the last restart (Newton shifts of the next expansion)
   bool ritz_valid = false;
   std::vector<char> Hfull;      // host H as the last full expansion left it (shifts for callers that run their own restart)

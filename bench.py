@@ -77,6 +77,12 @@ KERNEL_NAMES = {
 }
 
 
+BLOCK_KERNEL_NAMES = {
+    "dots": "k_bdots (s-step pass 1: P = S'Z and Z'Z for a block of s vectors, basis read once per block)",
+    "fused": "k_bupdate (s-step pass 2: block = (Z - S coef) R1^-1 written in place, C = S'block and its Gram matrix; basis read once per block)",
+}
+
+
 def pmc_traffic(kernel_class):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE collected separately, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_summary.py)."""
@@ -200,6 +206,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shift-invert", action="store_true", help="skip the side record of the sparse shift-invert operator (N = 1 only)")
     ap.add_argument("--no-profile", action="store_true", help="skip the second (HIP-event instrumented) pass")
+    ap.add_argument("--sstep", type=int, default=int(os.environ.get("KS_BENCH_SSTEP", "5")),
+                    help="s-step (block) expansion: steps per block (ks_workspace_set_sstep; 0 = the per-step expansion of rounds 2-3)")
     ap.add_argument("--config5", action="store_true", help="also measure BASELINE config 5 (464^3 over the ranks) as a second record; "
                                                            "default: only with 8 ranks")
     ap.add_argument("--config5-grid", type=int, default=464)
@@ -294,6 +302,10 @@ def main():
         fmt = op.format
         placement = ws.placement
         basis_passes = ws.passes
+        # s-step (block) expansion (include/kschur.h: ks_workspace_set_sstep): single GPU, device-resident operator
+        sstep = args.sstep if (dist is None and args.sstep >= 2) else 0
+        if sstep:
+            ws.set_sstep(sstep)
         ws.reinitialize(0, v1)
         ws.iterate_arnoldi(op, 1, mindim)  # initial expansion, src/run.jl:267 (untimed)
 
@@ -307,6 +319,7 @@ def main():
             # in one library call (with the explicit second pass, KS_PASSES=3, the restart's Schur factorisation overlaps the
             # tail of the expansion; with the default two-pass expansion H is final only when the batch ends)
             # (KS_BENCH_SPLIT_CYCLE=1: the two calls ks_iterate_arnoldi + ks_restart of rounds 1-2, bit-identical results)
+            blocks0 = ws.sstep_info["blocks"] if (sstep and timed) else 0
             t0 = time.perf_counter()
             if split_cycle:
                 st = ws.iterate_arnoldi(op, k + 1, maxdim)
@@ -332,11 +345,31 @@ def main():
                 # passes over V per step (k_dots, k_axpy_dots_cs) whether or not the DGKS test asks for the second
                 # projection = SURVEY 8d's compulsory B_step(j); KS_PASSES=3: a third one (k_axpy) when it does
                 spmv_b = fmt["bytes_per_nnz"] * nnz_global + 4.0 * (n + 1) + 16.0 * n
+                blk = []
+                if sstep:
+                    info = ws.sstep_info
+                    blk = pkg.sstep_partition(np.float64, k + 1, nst, sstep)
+                    if info["blocks"] - blocks0 != len(blk):   # a block was abandoned (or no shifts yet): not a block cycle
+                        state["blk_irregular"] = state.get("blk_irregular", 0) + 1
+                        blk = []
+                    state["blk_cycles"] = state.get("blk_cycles", 0) + (1 if blk else 0)
+                    state["blk_blocks"] = state.get("blk_blocks", 0) + len(blk)
+                    state["blk_pivot_min"] = min(state.get("blk_pivot_min", 1.0), info["pivot_stage1"], info["pivot_stage2"])
+                    state["blk_gram_dev"] = max(state.get("blk_gram_dev", 0.0), info["gram_dev"])
+                if blk:
+                    # s-step cycle: per block of s steps on kk columns  s products (the Newton shift is fused into the stencil
+                    # kernel; other layouts pay a 24 n-byte pass per product) + k_bdots 8 n (kk + s) + k_bupdate 8 n (kk + 2 s)
+                    shift_b = 0.0 if fmt["layout"] == "stencil" else 24.0 * n
+                    kk = k + 1
+                    for sb in blk:
+                        state["moved"] += sb * (spmv_b + shift_b) + 8.0 * n * (kk + sb) + 8.0 * n * (kk + 2 * sb)
+                        kk += sb
                 for j in range(k + 1, maxdim + 1):
-                    state["moved"] += spmv_b + 8.0 * n * (j + 1) + 8.0 * n * (j + 2)
+                    if not blk:
+                        state["moved"] += spmv_b + 8.0 * n * (j + 1) + 8.0 * n * (j + 2)
                     # SURVEY 8d's compulsory B_step(j) as written there: plain CSR (12 B / non-zero), V twice, column once
                     state["survey"] = state.get("survey", 0.0) + 12.0 * nnz_global + 4.0 * (n + 1) + 8.0 * n * (2 * j + 2)
-                if basis_passes == 3:
+                if basis_passes == 3 and not blk:
                     state["moved"] += st["reorth"] * 8.0 * n * ((k + 1 + maxdim) / 2.0 + 2)
                 state["t_expand"] += t1 - t0
                 state["t_restart"] += t2 - t1
@@ -389,7 +422,7 @@ def main():
         ws.close()
         op.close()
         ctx.close()
-        return dict(elapsed=elapsed, state=state, prof=prof, nnz_global=nnz_global, A_host=A_host, fmt=fmt, placement=placement, basis_passes=basis_passes,
+        return dict(elapsed=elapsed, state=state, prof=prof, nnz_global=nnz_global, A_host=A_host, fmt=fmt, placement=placement, basis_passes=basis_passes, sstep=sstep,
                     validation=validation, spmv_csr=spmv_csr, steps=steps, warmup=warmup)
 
     # N > 1: the row-partitioned solver has two transports for its per-step exchanges -- RCCL collectives
@@ -576,6 +609,7 @@ def make_line(args, pkg, passes, order, world, rank, force_dist, wl, with_cpu_ba
     elapsed, state, prof = passes[chosen]["elapsed"], passes[chosen]["state"], passes[chosen]["prof"]
     nnz_global, A_host, fmt = passes[chosen]["nnz_global"], passes[chosen]["A_host"], passes[chosen]["fmt"]
     bp = passes[chosen].get("basis_passes", 3)
+    sst = passes[chosen].get("sstep", 0)
     out["value"] = state["steps"] / elapsed
     out["ms_per_step"] = 1e3 * elapsed / max(args.steps, 1)
     layout = fmt["layout"]
@@ -586,6 +620,10 @@ def make_line(args, pkg, passes, order, world, rank, force_dist, wl, with_cpu_ba
         "arnoldi_iterations_timed": state["steps"],
         "dgks_second_passes": state["reorth"],
         "basis_passes_per_step": bp,  # 2: the DGKS second projection is carried in a triangular factor (implicit), 3: applied to the vector
+        # s-step (block) expansion: steps per block; with it the basis is read twice per BLOCK (not per step)
+        "sstep": {"s": sst, "block_cycles": state.get("blk_cycles", 0), "blocks": state.get("blk_blocks", 0),
+                  "cycles_not_in_blocks": state.get("blk_irregular", 0), "smallest_pivot_ratio": state.get("blk_pivot_min"),
+                  "largest_gram_deviation": state.get("blk_gram_dev")} if sst else None,
         "spmv_layout": {"csr-dvi": "csr-dvi: %d-entry (column-row, value) dictionary, 1 B per non-zero (bit-identical products)",
                         "csr-vi": "csr-vi: %d-entry value dictionary, 4 B per non-zero (bit-identical products)",
                         "stencil": "stencil-mask: %d-slot (column-row, value) dictionary in the kernel arguments, 1 bit per slot and row (bit-identical products)",
@@ -610,11 +648,11 @@ def make_line(args, pkg, passes, order, world, rank, force_dist, wl, with_cpu_ba
         dom = max(classes, key=lambda k: classes[k]["ms"])
         d = classes[dom]
         ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-        traffic = pmc_traffic(dom) if (m == 216 and world == 1 and not force_dist) else None
+        traffic = pmc_traffic(("blk_" + dom) if (sst and state.get("blk_cycles", 0) and dom in BLOCK_KERNEL_NAMES) else dom) if (m == 216 and world == 1 and not force_dist) else None
         if traffic is not None:
             traffic["measured_in_run"] = False  # read from the committed PMC passes (profiles/), not collected by this run
         roof.update({
-            "kernel": KERNEL_NAMES[dom],
+            "kernel": (BLOCK_KERNEL_NAMES if sst and state.get("blk_cycles", 0) else KERNEL_NAMES).get(dom, KERNEL_NAMES[dom]),
             "achieved": ach,
             "frac": ach / HBM_PEAK_GBS,
             "launches": d["count"],
@@ -637,7 +675,12 @@ def make_line(args, pkg, passes, order, world, rank, force_dist, wl, with_cpu_ba
     else:
         roof.update({"kernel": "fused step (no per-kernel events)", "achieved": moved_gbs, "frac": moved_gbs / HBM_PEAK_GBS})
     roof["fused_step"] = {
-        "what": "SpMV + DGKS per Arnoldi step over the expansion wall time, per GPU.  moved_*: bytes the launched kernels must "
+        "what": ("S-STEP EXPANSION: per block of s steps, s operator products + two passes over the basis (k_bdots reads 8 n (k + s), "
+                 "k_bupdate reads 8 n (k + s) and writes 8 n s); moved_* prices exactly those launches.  survey_compulsory_frac and "
+                 "algorithmic_* price the same wall time with the PER-STEP byte counts of SURVEY 8d (two / four passes over V per step): "
+                 "speeds relative to those op sequences, NOT bandwidths -- they exceed the HBM peak because the block form does not move "
+                 "those bytes.  " if sst and state.get("blk_cycles", 0) else "") +
+                "SpMV + DGKS per Arnoldi step over the expansion wall time, per GPU.  moved_*: bytes the launched kernels must "
                 "move (" + ("two passes over V per step: the DGKS second projection is carried in a triangular factor, = SURVEY 8d's "
                             "compulsory B_step(j) for the layout in use; survey_compulsory_frac prices the same time with SURVEY's own formula, "
                             "12 B per non-zero of plain CSR, although the layout in use streams less" if bp == 2 else

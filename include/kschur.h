@@ -233,11 +233,22 @@ int ks_workspace_set_passes(ks_workspace* ws, int passes, double max_ratio);
  * abandoned before anything is committed and its steps are redone one at a time, which takes the reference's decisions.
  * Like the implicit second pass it needs the library's provenance of the factorisation; otherwise, for host-callback
  * operators, distributed contexts and maxdim > 64 the expansion runs as before.  s = 0 / 1: off (default; KS_SSTEP at
- * creation).  pivot_min: NaN keeps the current value (default 1e-6).
- * ks_workspace_sstep_info: blocks completed / abandoned since creation; diag3 = of the last batch { smallest pivot ratio
- * of the first stage, of the second stage, largest |entry| of (Gram matrix of the written block - I) }. */
-int ks_workspace_set_sstep(ks_workspace* ws, int s, double pivot_min);
+ * creation).  A block is also abandoned when the Gram matrix of what its first stage wrote differs from I by more than
+ * gram_dev_max in any entry (~ eps cond^2 of the Newton basis; the recovered H carries errors ~ eps cond): default 1e-8
+ * keeps H at the per-step path's accuracy.  After an abandoned block the library lowers the block size for the following
+ * expansions (s -> s/2 -> 2 -> off) and probes a larger one again after 16 clean batches: spectra the shifts cover badly
+ * (a complex disc, with real shifts) simply run with small blocks.  pivot_min / gram_dev_max: NaN keeps the current value
+ * (defaults 1e-6 / 1e-8; KS_SSTEP_PIVOT_MIN / KS_SSTEP_GDEV_MAX at creation).
+ * ks_workspace_sstep_info: *s = block size in force; blocks completed / abandoned since creation; diag3 = of the last
+ * batch { smallest pivot ratio of the first stage, of the second stage, largest |entry| of (Gram matrix of the written
+ * block - I) }. */
+int ks_workspace_set_sstep(ks_workspace* ws, int s, double pivot_min, double gram_dev_max);
 int ks_workspace_sstep_info(const ks_workspace* ws, int* s, int* blocks, int* abandoned, double* diag3);
+/* Diagnostics (tools/blk_bench.py): average duration of `reps` back-to-back launches of one streaming kernel of the s-step
+ * expansion at basis size k and block size s (which = 0: first pass, 1: second pass), timed with HIP events on the
+ * library's stream; *grid = workgroups launched.  dbg: probe flags of the kernels (1: second pass without its stores).
+ * Overwrites columns k .. k+s-1 and drops the provenance of the factorisation. */
+int ks_debug_blk_time(ks_workspace* ws, int k, int s, int which, int reps, int dbg, double* ms_per_launch, int* grid);
 /* PROVENANCE.  The implicit second pass reads the columns < from of the host H and relies on the Arnoldi relation
  * A V[:, 0:from-1) = V[:, 0:from) H[0:from, 0:from-1) holding for them -- the reference's iterate_arnoldi! reads
  * neither.  The library therefore takes the implicit form only for a factorisation it produced itself: after

@@ -218,7 +218,7 @@ def expand_block(A, st, frm, to, shifts, s_max, stats, pivot_min=1e-6, gram="dou
         blk += 1
 
 
-def expand_block2(A, st, frm, to, shifts, s_max, stats, pivot_min=1e-6, scale=None, **_):
+def expand_block2(A, st, frm, to, shifts, s_max, stats, pivot_min=1e-6, scale=None, gdev_max=1e-8, **_):
     """TWO-STAGE block step (what the device runs): the first pass also delivers G_Z = Z^H Z, so the block's triangular
     factor is known BEFORE the second pass, which then writes the block already (nearly) orthonormal:
 
@@ -258,6 +258,11 @@ def expand_block2(A, st, frm, to, shifts, s_max, stats, pivot_min=1e-6, scale=No
         Craw = S[:, :k].conj().T @ Qt
         Gt = Qt.conj().T @ Qt
         C = T[:k, :k].conj().T @ Craw
+        # G_t = I + delta with delta ~ eps cond(R_1)^2; the recovered H carries errors ~ eps cond(R_1): a block is accepted
+        # only while delta <= gdev_max (1e-8: cond <= ~1e4, H as accurate as the per-step path's)
+        gdev = float(np.abs(Gt - np.eye(s)).max())
+        if not (gdev <= gdev_max):
+            raise BlockBail(j, f"written block too far from orthonormal: {gdev:.1e} (k = {k})")
         R2, piv2 = chol_upper(Gt - C.conj().T @ C, 0.25, k, j)     # G_t ~ I: anything else means stage 1 failed
         R2inv = tri_inv(R2)
         S[:, k:k + s] = Qt
@@ -331,6 +336,7 @@ def expand_steps(A, st, frm, to, stats):
 
 def expand(A, st, frm, to, stats, ritz, s, real, **kw):
     """What the backend does: blocks when shifts exist, single steps otherwise or after a bail."""
+    s = min(s, stats.get("s_eff", s))          # lowered after abandoned blocks (what the backend does: s -> s/2 -> 2 -> off)
     if s <= 1 or ritz is None:
         st.materialize(frm)
         expand_steps(A, st, frm, to, stats)
@@ -346,6 +352,7 @@ def expand(A, st, frm, to, stats, ritz, s, real, **kw):
         (expand_block2 if variant == "twostage" else expand_block)(A, st, frm, to, shifts, s, stats, scale=scale, **kw)
     except BlockBail as b:
         stats["bails"] = stats.get("bails", 0) + 1
+        stats["s_eff"] = s // 2 if s >= 4 else (2 if s > 2 else 1)
         st.materialize(b.step)                 # the completed blocks stand (b.step = first step of the abandoned block)
         expand_steps(A, st, b.step, to, stats)
 
