@@ -13,18 +13,8 @@
 
 
 // ---- block sizes ------------------------------------------------------------------------------------------------------------
-// instantiated block sizes (ks_block_kernels.hpp templates): Float64 1..5, 8, 10; ComplexF64 1..5
-inline bool blk_size_ok(int dtype, int s) {
-  if (s >= 1 && s <= 5) return true;
-  return dtype == KS_F64 && (s == 8 || s == 10);
-}
-// can the block kernels take k existing columns with block size s?  (column-split width NCW = 4, 8, 12, 16 per wave)
-inline bool blk_shape_ok(int dtype, int k, int s) {
-  if (!blk_size_ok(dtype, s) || k < 1 || k + s > ksd::kBlkKMax) return false;
-  if (dtype == KS_C64) return k <= 32;          // ComplexF64: NCW 4 / 8 only
-  if (k > 48) return s <= 5;                    // NCW = 16: register budget
-  return true;
-}
+// instantiated shapes: ks_blk_shape_ok (ks_block_launch.hpp)
+inline bool blk_shape_ok(int dtype, int k, int s) { return ks_blk_shape_ok(dtype == KS_F64 ? 0 : 1, k, s); }
 // split `count` steps starting with k0 existing columns into block sizes <= smax
 inline std::vector<int> blk_partition(int dtype, int k0, int count, int smax) {
   std::vector<int> out;
@@ -86,55 +76,19 @@ inline void blk_ensure_buffers(ks_workspace* ws) {
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------------------------------
-template <class D, int NCW, int S> int launch_bdots_t(ks_workspace* ws, int k) {
-  constexpr int U = S <= 5 ? 2 : 1;
-  static int cache = -1;
-  const int nb = cap_blocks(ws, resident_blocks(ws->ctx, ksd::k_bdots<D, NCW, S, U, true>, 0, cache), 64 * U);
-  if (ws->v_nt) ksd::k_bdots<D, NCW, S, U, true><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const D*>(ws->V), ws->ld, k, static_cast<D*>(ws->bpart), ws->pnb, ws->st);
-  else ksd::k_bdots<D, NCW, S, U, false><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<const D*>(ws->V), ws->ld, k, static_cast<D*>(ws->bpart), ws->pnb, ws->st);
-  return nb;
-}
+// (the ~200 instantiations of the two streaming kernels live in translation units of their own: ks_block_inst.hip)
 inline int& blk_dbg() { static int v = env_int("KS_BLK_DBG", 0); return v; }
-inline int& blk_wb() { static int v = env_int("KS_BLK_WB", 8); return v; }
-template <class D, int NCW, int S, int WB> int launch_bupdate_w(ks_workspace* ws, int k) {
-  constexpr int U = S <= 5 ? 2 : 1;
-  static int cache = -1;
-  const int nb = cap_blocks(ws, resident_blocks(ws->ctx, ksd::k_bupdate<D, NCW, S, U, true, WB>, 0, cache), 64 * U);
-  auto* bs = static_cast<ksd::BlkScratch<D>*>(ws->bscr);
-  if (ws->v_nt) ksd::k_bupdate<D, NCW, S, U, true, WB><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<D*>(ws->V), ws->ld, k, bs->coefp, k, bs->r1inv, static_cast<D*>(ws->bpart), ws->pnb, ws->st, blk_dbg());
-  else ksd::k_bupdate<D, NCW, S, U, false, WB><<<nb, kBlock, 0, ws->ctx->stream>>>(static_cast<D*>(ws->V), ws->ld, k, bs->coefp, k, bs->r1inv, static_cast<D*>(ws->bpart), ws->pnb, ws->st, blk_dbg());
-  return nb;
-}
-template <class D, int NCW, int S> int launch_bupdate_t(ks_workspace* ws, int k) {
-  if constexpr (sizeof(D) == 8) {
-    if (blk_wb() > 0 && !(blk_dbg() & 2)) return launch_bupdate_w<D, NCW, S, 8>(ws, k);   // (dbg & 2: the direct-store form)
-  }
-  return launch_bupdate_w<D, NCW, S, 0>(ws, k);
-}
-// (which, k, s) -> instantiation
-template <class D, int NCW> int launch_blk_s(ks_workspace* ws, int which, int k, int s) {
-#define KS_BLK_CASE(SS) case SS: return which == 0 ? launch_bdots_t<D, NCW, SS>(ws, k) : launch_bupdate_t<D, NCW, SS>(ws, k);
-  switch (s) {
-    KS_BLK_CASE(1) KS_BLK_CASE(2) KS_BLK_CASE(3) KS_BLK_CASE(4) KS_BLK_CASE(5)
-    default: break;
-  }
-  if constexpr (sizeof(D) == 8 && NCW <= 12) {
-    switch (s) {
-      KS_BLK_CASE(8) KS_BLK_CASE(10)
-      default: break;
-    }
-  }
-#undef KS_BLK_CASE
-  throw KsError{KS_ERR_INTERNAL, "block size without a kernel instantiation"};
-}
 template <class D> int launch_blk(ks_workspace* ws, int which, int k, int s) {
-  if (k <= 16) return launch_blk_s<D, 4>(ws, which, k, s);
-  if (k <= 32) return launch_blk_s<D, 8>(ws, which, k, s);
-  if constexpr (sizeof(D) == 8) {
-    if (k <= 48) return launch_blk_s<D, 12>(ws, which, k, s);
-    return launch_blk_s<D, 16>(ws, which, k, s);
+  auto* bs = static_cast<ksd::BlkScratch<D>*>(ws->bscr);
+  BlkLaunchArgs a{};
+  a.V = ws->V; a.ld = ws->ld; a.dtype = sizeof(D) == 8 ? 0 : 1; a.k = k; a.s = s;
+  a.partial = ws->bpart; a.pnb = ws->pnb; a.coefp = bs->coefp; a.r1inv = bs->r1inv; a.st = ws->st;
+  a.dbg = blk_dbg(); a.nt = ws->v_nt ? 1 : 0; a.num_cu = ws->ctx->num_cu; a.bpc = ws->ctx->bpc; a.stream = ws->ctx->stream;
+  try {
+    return ks_blk_launch(which, a);
+  } catch (const std::runtime_error& e) {
+    throw KsError{KS_ERR_INTERNAL, e.what()};
   }
-  throw KsError{KS_ERR_INTERNAL, "block kernels: too many columns for this element type"};
 }
 
 // Steps from..to as blocks of the given sizes.  Every column is an ordinary one on entry (the caller materialised): T = I

@@ -1,0 +1,111 @@
+// Instantiations + launch dispatch of the s-step streaming kernels (see ks_block_launch.hpp).  Compiled in PARTS
+// (-DKS_BLK_PART=0: Float64 block sizes 1-4, 1: Float64 5 / 8 / 10, 2: ComplexF64) so that build.py can run them in parallel.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <stdexcept>
+#include <string>
+
+#include "ks_block_kernels.hpp"
+#include "ks_block_launch.hpp"
+
+#ifndef KS_BLK_PART
+#error "compile with -DKS_BLK_PART=0|1|2"
+#endif
+
+namespace {
+using ksd::cd;
+using ksd::kBlock;
+
+inline void hipcheck(hipError_t e, const char* what) {
+  if (e != hipSuccess) throw std::runtime_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+}
+// streaming kernels partition the rows into one contiguous range per workgroup: all workgroups must be co-resident
+template <class K> int resident(const BlkLaunchArgs& a, K kernel, int& cache) {
+  if (cache < 0) {
+    int occ = 0;
+    hipcheck(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kBlock, 0), "occupancy query");
+    cache = std::max(1, std::min(occ, a.bpc));
+  }
+  return a.num_cu * cache;
+}
+inline int cap(const BlkLaunchArgs& a, int nb, int packs_per_iter, size_t esz) {
+  const int64_t npacks = a.ld * (int64_t)esz / 16;
+  const int64_t want = std::max<int64_t>(1, npacks / (2 * (int64_t)packs_per_iter));
+  return (int)std::min<int64_t>(nb, want);
+}
+
+template <class D, int NCW, int S> int go(int which, const BlkLaunchArgs& a) {
+  constexpr int U = ksd::blk_u<D, NCW, S>();
+  const ksd::DevState* st = static_cast<const ksd::DevState*>(a.st);
+  D* V = static_cast<D*>(a.V);
+  D* part = static_cast<D*>(a.partial);
+  if (which == 0) {
+    static int cache = -1;
+    const int nb = cap(a, resident(a, ksd::k_bdots<D, NCW, S, U, true>, cache), 64 * U, sizeof(D));
+    if (a.nt) ksd::k_bdots<D, NCW, S, U, true><<<nb, kBlock, 0, a.stream>>>(V, a.ld, a.k, part, a.pnb, st);
+    else ksd::k_bdots<D, NCW, S, U, false><<<nb, kBlock, 0, a.stream>>>(V, a.ld, a.k, part, a.pnb, st);
+    return nb;
+  }
+  static int cache = -1;
+  const int nb = cap(a, resident(a, ksd::k_bupdate<D, NCW, S, U, true>, cache), 64 * U, sizeof(D));
+  const D* cp = static_cast<const D*>(a.coefp);
+  const D* ri = static_cast<const D*>(a.r1inv);
+  if (a.nt) ksd::k_bupdate<D, NCW, S, U, true><<<nb, kBlock, 0, a.stream>>>(V, a.ld, a.k, cp, a.k, ri, part, a.pnb, st, a.dbg);
+  else ksd::k_bupdate<D, NCW, S, U, false><<<nb, kBlock, 0, a.stream>>>(V, a.ld, a.k, cp, a.k, ri, part, a.pnb, st, a.dbg);
+  return nb;
+}
+
+// columns per wave: ceil(k / 4), rounded up to an instantiated width
+template <class D, int S> int by_ncw(int which, const BlkLaunchArgs& a) {
+  const int need = (a.k + 3) / 4;
+  if constexpr (sizeof(D) == 8) {
+    if (need <= 4) return go<D, 4, S>(which, a);
+    if (need <= 5) return go<D, 5, S>(which, a);
+    if (need <= 6) return go<D, 6, S>(which, a);
+    if (need <= 7) return go<D, 7, S>(which, a);
+    if (need <= 8) return go<D, 8, S>(which, a);
+    if (need <= 9) return go<D, 9, S>(which, a);
+    if (need <= 10) return go<D, 10, S>(which, a);
+    if (need <= 12) return go<D, 12, S>(which, a);
+    if constexpr (S <= 5) return go<D, 16, S>(which, a);
+  } else {
+    if (need <= 4) return go<D, 4, S>(which, a);
+    if (need <= 6) return go<D, 6, S>(which, a);
+    if (need <= 8) return go<D, 8, S>(which, a);
+  }
+  throw std::runtime_error("block kernels: no instantiation for this many columns");
+}
+}  // namespace
+
+#if KS_BLK_PART == 0
+int ks_blk_launch_part0(int which, const BlkLaunchArgs& a) {
+  switch (a.s) {
+    case 1: return by_ncw<double, 1>(which, a);
+    case 2: return by_ncw<double, 2>(which, a);
+    case 3: return by_ncw<double, 3>(which, a);
+    case 4: return by_ncw<double, 4>(which, a);
+    default: throw std::runtime_error("block kernels: block size not in this part");
+  }
+}
+#elif KS_BLK_PART == 1
+int ks_blk_launch_part1(int which, const BlkLaunchArgs& a) {
+  switch (a.s) {
+    case 5: return by_ncw<double, 5>(which, a);
+    case 8: return by_ncw<double, 8>(which, a);
+    case 10: return by_ncw<double, 10>(which, a);
+    default: throw std::runtime_error("block kernels: block size not in this part");
+  }
+}
+#else
+int ks_blk_launch_part2(int which, const BlkLaunchArgs& a) {
+  switch (a.s) {
+    case 1: return by_ncw<cd, 1>(which, a);
+    case 2: return by_ncw<cd, 2>(which, a);
+    case 3: return by_ncw<cd, 3>(which, a);
+    case 4: return by_ncw<cd, 4>(which, a);
+    case 5: return by_ncw<cd, 5>(which, a);
+    default: throw std::runtime_error("block kernels: block size not instantiated for ComplexF64");
+  }
+}
+#endif

@@ -53,6 +53,17 @@ template <class T> struct Dpe { static constexpr int value = (int)(sizeof(T) / 8
 __device__ __forceinline__ void put_acc(double* f, int idx, double v) { f[idx] = v; }
 __device__ __forceinline__ void put_acc(double* f, int idx, cd v) { f[2 * idx] = v.x; f[2 * idx + 1] = v.y; }
 
+// packs per lane and iteration, and the occupancy the kernels are compiled for: a lane keeps NCW x S accumulators, NCW x U
+// basis packs and 2 S U block packs; while that fits 256 registers TWO workgroups share a CU (measured on the 216^3 basis:
+// pass 1 6.2-6.5 TB/s with two resident workgroups, 3.0-5.0 with one; pass 2 5.0 against 3.8) -- what counts is the number
+// of bytes in flight per CU.
+template <class T, int NCW, int S> constexpr int blk_u() { return S <= 5 ? 2 : 1; }
+template <class T, int NCW, int S, int U> constexpr int blk_regs() {
+  constexpr int D = (int)(sizeof(T) / 8);
+  return 2 * (D * NCW * S + 2 * NCW * U + 2 * S * U + D * ((S * (S + 1) / 2 + 3) / 4)) + 44;
+}
+template <class T, int NCW, int S, int U> constexpr int blk_wpe() { return blk_regs<T, NCW, S, U>() <= 256 ? 2 : 1; }
+
 // upper-triangle index of Gram entry (i, i2), i <= i2
 __host__ __device__ __forceinline__ constexpr int gram_idx(int i, int i2) { return i2 * (i2 + 1) / 2 + i; }
 
@@ -112,7 +123,7 @@ __global__ void __launch_bounds__(kBlock)
 // S = V[:, 0:k), Z = V[:, k:k+S).
 // ---------------------------------------------------------------------------------------------------------------------------
 template <class T, int NCW, int S, int U, bool NT>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, (blk_wpe<T, NCW, S, U>()))
     k_bdots(const T* __restrict__ V, int64_t ldv, int k, T* __restrict__ partial, int pnb, const DevState* __restrict__ st) {
   if (st && st->breakdown >= 0) return;
   using P = typename Pack<T>::type;
@@ -206,21 +217,21 @@ __global__ void __launch_bounds__(kBlock)
 // the four meet in LDS (double buffered, one barrier per iteration),  Qt[r,i] = -(t_0 + t_1 + t_2 + t_3)[i].
 // Wave w stores the columns i = w mod 4.
 // ---------------------------------------------------------------------------------------------------------------------------
-// WB > 0: the written block is staged in LDS and goes out in bursts of WB iterations (WB x U KiB contiguous per column, all
-// four waves writing) -- every switch between reading and writing costs the memory channels a turn-around, and this kernel
-// writes s of the k + 2 s streams it touches (k_axpy_dots_cs: profiles/r02_write_bursts.txt); the exchange buffer is then
-// single (a second barrier per iteration) so that both fit the CU's 160 KiB.  WB = 0: direct 1 KiB stores, double buffer.
-template <class T, int NCW, int S, int U, bool NT, int WB = 0>
-__global__ void __launch_bounds__(kBlock)
+// Exchange buffer: double (one barrier per iteration) while one workgroup has the CU to itself; SINGLE (a second barrier per
+// iteration) in the instantiations compiled for two resident workgroups, so that both fit the CU's 160 KiB of LDS.
+// (Staging the written block in LDS and writing 16 KiB bursts per column -- what pays in k_axpy_dots_cs, which writes ONE
+// column in 96 KiB bursts -- was measured here and is slower: 710 against 651 us at k = 21, s = 5; five columns leave no room
+// for bursts of that size.)
+template <class T, int NCW, int S, int U, bool NT>
+__global__ void __launch_bounds__(kBlock, (blk_wpe<T, NCW, S, U>()))
     k_bupdate(T* __restrict__ V, int64_t ldv, int k, const T* __restrict__ coefp, int ldc, const T* __restrict__ r1inv,
               T* __restrict__ partial, int pnb, const DevState* __restrict__ st, int dbg = 0) {
   if (st && st->breakdown >= 0) return;
   using P = typename Pack<T>::type;
   constexpr int R = Pack<T>::R;
   constexpr int NG = S * (S + 1) / 2, NGW = (NG + 3) / 4;
-  constexpr int NB = WB > 0 ? 1 : 2;
+  constexpr int NB = blk_wpe<T, NCW, S, U>() == 2 ? 1 : 2;
   __shared__ P tbuf[NB][4][U][S][64];
-  __shared__ P wout[WB > 0 ? S : 1][WB > 0 ? WB * U * 64 : 1];
   __shared__ T cf[4 * NCW][S];   // coefp rows (columns of the basis) as the waves index them: cf[c][i]
   __shared__ T ri[S][S];         // r1inv[l][i], l <= i
   const int lane = threadIdx.x & 63;
@@ -315,8 +326,8 @@ __global__ void __launch_bounds__(kBlock)
         P qq = sub_pack(zero_pack(T{}), addp(addp(t0, t1), addp(t2, t3)));
         if (!ok[u]) qq = zero_pack(T{});
         q[u][i] = qq;
-        if ((i & 3) == wave && ok[u] && !(dbg & 1)) {  // (dbg & 1: timing probe without the write stream)
-          if constexpr (WB > 0) wout[i][((it % WB) * U + u) * 64 + lane] = qq;
+        if ((i & 3) == wave && ok[u] && !(dbg & 1)) {  // (dbg & 1: timing probe without the write stream, & 4: cacheable stores)
+          if (dbg & 4) st_pack(Z + (int64_t)i * ldv + r[u], qq);
           else st_pack_nt(Z + (int64_t)i * ldv + r[u], qq);
         }
       }
@@ -336,20 +347,7 @@ __global__ void __launch_bounds__(kBlock)
           for (int u = 0; u < U; ++u) dotp(gacc[g >> 2], q[u][i], q[u][i2]);
         }
       }
-    if constexpr (WB > 0) {
-      const bool lastt = base + 64 * U >= pe;
-      if ((it % WB) == WB - 1 || lastt) {  // workgroup-uniform
-        __syncthreads();
-        const int64_t fb = base - (int64_t)(it % WB) * 64 * U;  // first pack staged
-        const int64_t fe = (base + 64 * U < pe) ? base + 64 * U : pe;
-        if (!(dbg & 1)) {
-#pragma unroll
-          for (int i = 0; i < S; ++i)
-            for (int64_t o = fb + threadIdx.x; o < fe; o += kBlock) st_pack_nt(Z + (int64_t)i * ldv + o * R, wout[i][o - fb]);
-        }
-      }
-      __syncthreads();  // single exchange buffer (and the staging area) may be overwritten from here on
-    }
+    if constexpr (NB == 1) __syncthreads();  // the single exchange buffer may be overwritten from here on
   }
   constexpr int D = Dpe<T>::value;
   constexpr int NE = NCW * S + NGW;

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -25,7 +26,8 @@
 #include "../../include/kschur.h"
 #include "ks_driver.hpp"
 #include "ks_kernels.hpp"
-#include "ks_block_kernels.hpp"  // kernels of the s-step (block) expansion
+#include "ks_block_kernels.hpp"  // kernels of the s-step (block) expansion (the streaming ones are instantiated in ks_block_inst.hip)
+#include "ks_block_launch.hpp"
 
 using ks::cplx;
 using ksd::cd;

@@ -821,6 +821,11 @@ __global__ void __launch_bounds__(kBlock)
     else { x0 = x[r]; x1 = x0; }
     s0 = scl(sub_s(s0, mul_(theta, x0)), sigma);
     s1 = scl(sub_s(s1, mul_(theta, x1)), sigma);
+    if (shifted & 2) {  // cacheable stores: the next launch is the next product of the chain and gathers exactly this vector
+      if (two) { if constexpr (sizeof(T) == 8) st_pack(y + r, make_double2(s0, s1)); else { y[r] = s0; y[r + 1] = s1; } }
+      else y[r] = s0;
+      return;
+    }
   }
   if (two) {
     if constexpr (sizeof(T) == 8) st_pack_nt(y + r, make_double2(s0, s1));
@@ -1969,7 +1974,7 @@ __global__ void __launch_bounds__(kBlock) k_norm2(const T* __restrict__ v, int64
 }
 
 // out[0] = sum_b partial2[b]   (plain reduction used by the synchronous verbs)
-__global__ void __launch_bounds__(kBlock) k_sum(const double* __restrict__ partial2, int nb, double* __restrict__ out) {
+static __global__ void __launch_bounds__(kBlock) k_sum(const double* __restrict__ partial2, int nb, double* __restrict__ out) {
   __shared__ double sm[kBlock];
   const int tid = threadIdx.x;
   double s = 0.0;
@@ -2268,7 +2273,7 @@ __global__ void __launch_bounds__(kBlock)
 // spins on.  A hipMemcpyAsync in its place costs the host ~100 us of enqueue time and stalls the stream's submission;
 // a kernel is 3 us in line.  No early exit: the host must always be woken (the state it reads says what happened).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_publish(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst_host, int nwords,
+static __global__ void __launch_bounds__(kBlock) k_publish(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst_host, int nwords,
                                                     uint64_t* flag_host, uint64_t seq) {
   for (int i = threadIdx.x; i < nwords; i += kBlock) dst_host[i] = src[i];
   __threadfence_system();

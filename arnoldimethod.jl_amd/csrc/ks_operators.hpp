@@ -264,9 +264,9 @@ template <class D> struct CsrOp : ks_operator {
         // two rows per lane, 16-byte gathers (no ghost columns: single GPU)
         const int nt = (int)(((n_local + 1) / 2 + kBlock - 1) / kBlock);
         if (stencil_mask_bytes == 1)
-          ksd::k_spmv_stencil2<D, uint16_t><<<nt, kBlock, 0, s>>>(static_cast<const uint16_t*>(smask2), sdict, nstencil, x, y, n_local, nt, st, shift_on ? 1 : 0, shift_theta, shift_sigma);
+          ksd::k_spmv_stencil2<D, uint16_t><<<nt, kBlock, 0, s>>>(static_cast<const uint16_t*>(smask2), sdict, nstencil, x, y, n_local, nt, st, shift_on ? (1 | (env_int("KS_SHIFT_PLAIN", 0) ? 2 : 0)) : 0, shift_theta, shift_sigma);
         else
-          ksd::k_spmv_stencil2<D, uint64_t><<<nt, kBlock, 0, s>>>(static_cast<const uint64_t*>(smask2), sdict, nstencil, x, y, n_local, nt, st, shift_on ? 1 : 0, shift_theta, shift_sigma);
+          ksd::k_spmv_stencil2<D, uint64_t><<<nt, kBlock, 0, s>>>(static_cast<const uint64_t*>(smask2), sdict, nstencil, x, y, n_local, nt, st, shift_on ? (1 | (env_int("KS_SHIFT_PLAIN", 0) ? 2 : 0)) : 0, shift_theta, shift_sigma);
         KS_HIP(hipGetLastError());
         return;
       }

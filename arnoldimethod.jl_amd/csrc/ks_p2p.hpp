@@ -117,7 +117,7 @@ __device__ __forceinline__ void p2p_sum_wave(const P2pDev& p, int elem0, const d
 
 // Stand-alone in-place sum over ranks of `count` doubles (the generic verbs; the lazy expansion path
 // folds the exchange into its reduction kernels instead).  One wave per 4 elements.
-__global__ void __launch_bounds__(256) k_p2p_allreduce(double* __restrict__ v, int count, P2pDev p) {
+static __global__ void __launch_bounds__(256) k_p2p_allreduce(double* __restrict__ v, int count, P2pDev p) {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int e0 = wave * 4;
   if (e0 >= count) return;

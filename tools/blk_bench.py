@@ -1,6 +1,6 @@
 """Times the two streaming kernels of the s-step expansion (k_bdots / k_bupdate) stand-alone at the headline shape.
    python tools/blk_bench.py [grid=216] [maxdim=40]
-BLK_DBGS: probe flags of the second-pass kernel (1: no stores, 2: direct 1 KiB stores instead of LDS-staged bursts).
+BLK_DBGS: probe flags of the second-pass kernel (1: no stores, 4: cacheable instead of non-temporal stores).
 Prints ms per launch and GB/s on the bytes the launch must move: 8 n (k + s) (pass 1), 8 n (k + 2 s) (pass 2)."""
 import ctypes as C
 import os
@@ -24,7 +24,7 @@ def main():
     L = _lib.load()
     shapes = [(21, 5), (26, 5), (31, 5), (36, 5), (21, 10), (31, 10), (25, 8), (33, 8), (21, 4), (37, 4), (21, 2), (39, 2)]
     shapes = [(k, s) for k, s in shapes if k + s <= maxdim + 1]
-    dbgs = [int(x) for x in os.environ.get("BLK_DBGS", "0,1,2,3").split(",")]
+    dbgs = [int(x) for x in os.environ.get("BLK_DBGS", "0,1,4").split(",")]
     for k, s in shapes:
         for which, name in ((0, "bdots"), (1, "bupdate")):
             for dbg in (dbgs if which == 1 else [0]):
