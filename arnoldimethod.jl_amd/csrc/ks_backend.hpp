@@ -68,11 +68,11 @@ template <class T> struct HipBackend : ks::Backend<T> {
       const bool lazy = use_deferred(ws, jend);
       const bool tpath = lazy && ws->passes == 2 && trusted && explicit_step < 0;  // implicit second pass: two reads of the basis per step
       // S-STEP form of the same path (ks_block.hpp): blocks of up to ws->sstep steps, two reads of the basis per BLOCK.
-      // Needs Newton shifts (Ritz values of a previous restart: not before the first one), a device-resident operator
-      // and a single GPU; a range of one step gains nothing.
+      // Needs Newton shifts (Ritz values of a previous restart: not before the first one) and a device-resident operator;
+      // a range of one step gains nothing.  Several ranks: two all-reduces per block (ks_block.hpp).
       std::vector<int> blk_sizes;
       ksd::BlkShifts<D> blk_sh{};
-      if (tpath && !no_block && ws->sstep_eff >= 2 && op->async_capable && !ws->ctx->distributed() && jend - j0 + 1 >= 2 &&
+      if (tpath && !no_block && ws->sstep_eff >= 2 && op->async_capable && jend - j0 + 1 >= 2 &&
           blk_make_shifts<D>(ws, std::min(ws->sstep_eff, ksd::kBlkSMax), blk_sh))
         blk_sizes = blk_partition(ws->dtype, j0, jend - j0 + 1, std::min(ws->sstep_eff, ksd::kBlkSMax));
       const bool bpath = !blk_sizes.empty();

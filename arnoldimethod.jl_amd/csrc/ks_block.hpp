@@ -114,24 +114,34 @@ void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::v
     }
     const int ne = k * s + s * (s + 1) / 2;
     int nb1, nb2;
+    // reduction + small algebra of one stage.  Several ranks: reduce -> ONE all-reduce of k s + s (s + 1) / 2 elements over
+    // the context's transport -> algebra (every rank the same sums, the same decisions); per BLOCK what the per-step paths
+    // do per step (src/expansion.jl:84,88,93,96 are the reductions that become collectives)
+    auto fin = [&](int stage, int nbp) {
+      ProfScope ps(cx, KSP_FIN, 0.0);
+      const D* part = static_cast<const D*>(ws->bpart);
+      D* red = static_cast<D*>(ws->bred);
+      if (!cx->distributed()) {
+        ksd::k_fin_blk<D><<<ne, kBlock, 0, s_>>>(stage, 0, part, nbp, ws->pnb, k, s, red, Hd, ldh, Tm, ws->ldt, ws->ntrue, bs, sh, first, ws->blk_pivmin,
+                                                 ws->blk_gdevmax, ws->st, ws->ctr);
+      } else {
+        ksd::k_fin_blk<D><<<ne, kBlock, 0, s_>>>(stage, 1, part, nbp, ws->pnb, k, s, red, Hd, ldh, Tm, ws->ldt, ws->ntrue, bs, sh, first, ws->blk_pivmin,
+                                                 ws->blk_gdevmax, ws->st, ws->ctr);
+        cx->allreduce(reinterpret_cast<double*>(red), ne * (int)(sizeof(D) / 8));
+        ksd::k_fin_blk<D><<<1, kBlock, 0, s_>>>(stage, 2, part, nbp, ws->pnb, k, s, red, Hd, ldh, Tm, ws->ldt, ws->ntrue, bs, sh, first, ws->blk_pivmin,
+                                                ws->blk_gdevmax, ws->st, ws->ctr);
+      }
+    };
     {
       ProfScope ps(cx, KSP_DOTS, nb8 * (k + s));               // reads S[:, 0:k) and Z
       nb1 = launch_blk<D>(ws, 0, k, s);
     }
-    {
-      ProfScope ps(cx, KSP_FIN, 0.0);
-      ksd::k_fin_blk<D><<<ne, kBlock, 0, s_>>>(1, static_cast<const D*>(ws->bpart), nb1, ws->pnb, k, s, static_cast<D*>(ws->bred), Hd, ldh, Tm,
-                                               ws->ldt, ws->ntrue, bs, sh, first, ws->blk_pivmin, ws->blk_gdevmax, ws->st, ws->ctr);
-    }
+    fin(1, nb1);
     {
       ProfScope ps(cx, KSP_FUSED, nb8 * (k + 2 * s));          // reads S[:, 0:k) and Z, writes the block
       nb2 = launch_blk<D>(ws, 1, k, s);
     }
-    {
-      ProfScope ps(cx, KSP_FIN, 0.0);
-      ksd::k_fin_blk<D><<<ne, kBlock, 0, s_>>>(2, static_cast<const D*>(ws->bpart), nb2, ws->pnb, k, s, static_cast<D*>(ws->bred), Hd, ldh, Tm,
-                                               ws->ldt, ws->ntrue, bs, sh, first, ws->blk_pivmin, ws->blk_gdevmax, ws->st, ws->ctr);
-    }
+    fin(2, nb2);
     k += s;
     first = 0;
   }

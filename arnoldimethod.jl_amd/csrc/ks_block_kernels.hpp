@@ -23,6 +23,7 @@ namespace ksd {
 
 constexpr int kBlkSMax = 10;                                   // largest block (steps per block)
 constexpr int kBlkGram = kBlkSMax * (kBlkSMax + 1) / 2;        // upper triangle of an s x s Gram matrix
+constexpr int kBlkTLds = 2048;                                 // elements of T the block algebra stages in LDS (16 / 32 KiB)
 constexpr int kBlkKMax = kTMax;                                // columns the factored path covers (maxdim <= 64 -> 65 columns)
 
 // ---- per-lane accumulators -> per-wave totals by halving exchanges ---------------------------------------------------------
@@ -434,17 +435,27 @@ template <class T> __device__ void tri_inv_lds(const T* Rm, T* X, int s) {
   __syncthreads();
 }
 
+// The non-trivial columns ntrue..k-1 of T as the algebra reads them: element (l, c) at tb[l + (c - ntrue) * tld] -- staged in
+// LDS (coalesced cooperative load) when they fit, else straight from memory (tld = ldt).  A thread of th_times walks DOWN a
+// column of T: from memory that is a chain of dependent, uncoalesced L2 round trips (~30 us at k = 37).
 // X[c, i] = sum_l conj(T[l, c]) Y[l, i]   (true coordinates from stored-column inner products); k x s, column stride k
 template <class T>
-__device__ void th_times(const T* __restrict__ Tm, int ldt, int ntrue, int k, int s, const T* Y, T* X) {
+__device__ void th_times(const T* __restrict__ tb, int64_t tld, int ntrue, int k, int s, const T* Y, T* X) {
   for (int e = threadIdx.x; e < k * s; e += kBlock) {
     const int c = e % k, i = e / k;
     T a;
     if (c < ntrue) a = Y[i * k + c];
     else {
-      a = zero_of(T{});
-      const T* tc = Tm + (int64_t)c * ldt;
-      for (int l = 0; l <= c; ++l) a = fma_(conj_(tc[l]), Y[i * k + l], a);
+      T a0 = zero_of(T{}), a1 = zero_of(T{});
+      const T* tc = tb + (int64_t)(c - ntrue) * tld;
+      const T* y = Y + i * k;
+      int l = 0;
+      for (; l + 1 <= c; l += 2) {
+        a0 = fma_(conj_(tc[l]), y[l], a0);
+        a1 = fma_(conj_(tc[l + 1]), y[l + 1], a1);
+      }
+      if (l <= c) a0 = fma_(conj_(tc[l]), y[l], a0);
+      a = add_(a0, a1);
     }
     X[e] = a;
   }
@@ -452,22 +463,30 @@ __device__ void th_times(const T* __restrict__ Tm, int ldt, int ntrue, int k, in
 }
 // X[r, i] = sum_c T[r, c] Y[c, i]        (coefficients of the stored columns from true coordinates)
 template <class T>
-__device__ void t_times(const T* __restrict__ Tm, int ldt, int ntrue, int k, int s, const T* Y, T* X) {
+__device__ void t_times(const T* __restrict__ tb, int64_t tld, int ntrue, int k, int s, const T* Y, T* X) {
   for (int e = threadIdx.x; e < k * s; e += kBlock) {
     const int r = e % k, i = e / k;
-    T a = r < ntrue ? Y[i * k + r] : zero_of(T{});
+    T a0 = r < ntrue ? Y[i * k + r] : zero_of(T{}), a1 = zero_of(T{});
     const int c0 = r > ntrue ? r : ntrue;
-    for (int c = c0; c < k; ++c) a = fma_(Tm[r + (int64_t)c * ldt], Y[i * k + c], a);
-    X[e] = a;
+    int c = c0;
+    for (; c + 1 < k; c += 2) {
+      a0 = fma_(tb[r + (int64_t)(c - ntrue) * tld], Y[i * k + c], a0);
+      a1 = fma_(tb[r + (int64_t)(c + 1 - ntrue) * tld], Y[i * k + c + 1], a1);
+    }
+    if (c < k) a0 = fma_(tb[r + (int64_t)(c - ntrue) * tld], Y[i * k + c], a0);
+    X[e] = add_(a0, a1);
   }
   __syncthreads();
 }
 
 // stage 1 (after k_bdots) / stage 2 (after k_bupdate).  `first`: first block of the batch (the last stored column is an
 // ordinary one: u = e_{k-1}).
+// mode 0: single GPU (reduce, elect, algebra);  mode 1: reduce only -> red[] (then the context's all-reduce over the ranks:
+// RCCL / peer-to-peer / host-staged);  mode 2: algebra only from red[], ONE workgroup -- every rank holds the same sums and
+// takes the same decisions (row-partitioned basis, replicated H / T: SURVEY 8e).
 template <class T>
 __global__ void __launch_bounds__(kBlock)
-    k_fin_blk(int stage, const T* __restrict__ partial, int nb, int pnb, int k, int s, T* __restrict__ red, T* __restrict__ Hd,
+    k_fin_blk(int stage, int mode, const T* __restrict__ partial, int nb, int pnb, int k, int s, T* __restrict__ red, T* __restrict__ Hd,
               int ldh, T* __restrict__ Tm, int ldt, int ntrue, BlkScratch<T>* __restrict__ bs, BlkShifts<T> sh, int first,
               double pivmin, double gdevmax, DevState* __restrict__ st, unsigned* __restrict__ counter) {
   if (st->breakdown >= 0) return;
@@ -479,26 +498,40 @@ __global__ void __launch_bounds__(kBlock)
   __shared__ T A2[kBlkKMax * kBlkSMax];      // stage 1: T P;   stage 2: T C, then PC
   __shared__ T Gm[kBlkSMax * kBlkSMax], Xi[kBlkSMax * kBlkSMax], Rf[kBlkSMax * kBlkSMax];
   __shared__ T zu[kBlkKMax + kBlkSMax], hk[kBlkKMax + kBlkSMax];
+  __shared__ T Tl[kBlkTLds];
   const int tid = threadIdx.x;
   const int ng = s * (s + 1) / 2, ne = k * s + ng;
-  {
+  if (mode != 2) {
     const int c = blockIdx.x;
     const T v = block_sum(partial + (int64_t)c * pnb, nb, sm);
     if (tid == 0) {
       red[c] = v;
-      __threadfence();
-      last_wg = (atomicAdd(counter, 1u) == gridDim.x - 1) ? 1 : 0;
+      if (mode == 0) {
+        __threadfence();
+        last_wg = (atomicAdd(counter, 1u) == gridDim.x - 1) ? 1 : 0;
+      }
     }
+    if (mode == 1) return;
     __syncthreads();
     if (!last_wg) return;
     if (tid == 0) *counter = 0u;
     __threadfence();
   }
   for (int e = tid; e < ne; e += kBlock) rs[e] = ld_agent(red + e);
+  // columns ntrue..k-1 of T -> LDS (rows 0..k-1; entries below the diagonal are never read)
+  const int nlz = k - ntrue;
+  const bool t_lds = nlz > 0 && nlz * k <= kBlkTLds;
+  if (t_lds)
+    for (int e = tid; e < nlz * k; e += kBlock) {
+      const int l = e % k, c = ntrue + e / k;
+      Tl[e] = l <= c ? Tm[l + (int64_t)c * ldt] : zero_of(T{});
+    }
+  const T* tb = t_lds ? Tl : Tm + (int64_t)ntrue * ldt;
+  const int64_t tld = t_lds ? k : ldt;
   __syncthreads();
   const T* Gin = rs + k * s;
   // A1 = T^H (raw inner products)
-  th_times(Tm, ldt, ntrue, k, s, rs, A1);
+  th_times(tb, tld, ntrue, k, s, rs, A1);
   // Gm = Gin - A1^H A1   (upper triangle)
   for (int g = tid; g < ng; g += kBlock) {
     int i2 = 0;
@@ -544,7 +577,7 @@ __global__ void __launch_bounds__(kBlock)
   }
   tri_inv_lds(Gm, Xi, s);
   if (stage == 1) {
-    t_times(Tm, ldt, ntrue, k, s, A1, A2);   // T P
+    t_times(tb, tld, ntrue, k, s, A1, A2);   // T P
     for (int e = tid; e < k * s; e += kBlock) {
       const int r = e % k, i = e / k;
       T a = zero_of(T{});
@@ -561,7 +594,7 @@ __global__ void __launch_bounds__(kBlock)
     return;
   }
   // ---------------- stage 2: A1 = C, Gm = R2, Xi = R2^-1 ----------------
-  t_times(Tm, ldt, ntrue, k, s, A1, A2);     // T C
+  t_times(tb, tld, ntrue, k, s, A1, A2);     // T C
   // new columns of T
   for (int e = tid; e < (k + s) * s; e += kBlock) {
     const int r = e % (k + s), i = e / (k + s);

@@ -46,7 +46,7 @@ using LinearAlgebra, SparseArrays, Random
 import ArnoldiMethod
 import ArnoldiMethod: ArnoldiWorkspace, PartialSchur
 
-export HipContext, HipOperator, HipWorkspace, HipBasis, HipColumn, HipColumns, hip_partialschur, hip_partialschur!, hip_partialeigen
+export HipContext, HipOperator, HipWorkspace, HipBasis, HipColumn, HipColumns, hip_partialschur, hip_partialschur!, hip_partialeigen, set_sstep!
 
 const LIB = get(ENV, "KSCHUR_LIB", joinpath(@__DIR__, "..", "libkschur_hip.so"))
 
@@ -282,6 +282,18 @@ function HipWorkspace(ctx::HipContext, ::Type{T}, n::Integer, maxdim::Integer) w
             _release(x.ctx)
         end
     end
+    w
+end
+
+"""
+    set_sstep!(w, s; pivot_min = NaN, gram_dev_max = NaN)
+
+s-step (block) expansion for the fused `iterate_arnoldi!` / `partialschur` paths (include/kschur.h, ks_workspace_set_sstep):
+`s >= 2` takes the steps of an expansion in blocks of up to `s` -- two passes over the basis per block instead of per step.
+`0` switches it off (default).
+"""
+function set_sstep!(w::HipWorkspace, s::Integer; pivot_min::Float64 = NaN, gram_dev_max::Float64 = NaN)
+    check(ccall((:ks_workspace_set_sstep, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cdouble), w.h, s, pivot_min, gram_dev_max))
     w
 end
 

@@ -302,8 +302,9 @@ def main():
         fmt = op.format
         placement = ws.placement
         basis_passes = ws.passes
-        # s-step (block) expansion (include/kschur.h: ks_workspace_set_sstep): single GPU, device-resident operator
-        sstep = args.sstep if (dist is None and args.sstep >= 2) else 0
+        # s-step (block) expansion (include/kschur.h: ks_workspace_set_sstep): device-resident operator; with several ranks
+        # the two reductions of a block are the only collectives of its s steps
+        sstep = args.sstep if args.sstep >= 2 else 0
         if sstep:
             ws.set_sstep(sstep)
         ws.reinitialize(0, v1)

@@ -98,6 +98,26 @@ def check_matrix(A, offs, rank, world, tag):
     assert nre == st.get("reorth", 0), (tag, nre, st)
     np.testing.assert_allclose(H, ows.H, atol=1e-12)
     np.testing.assert_allclose(V, ows.V[r0:r1], atol=1e-10)
+    # 3. the S-STEP (block) expansion, sharded: steps 5..12 in blocks of 4 on top of the first four columns.  The n-sized
+    # work is row-local; per block TWO all-reduces ([S Z]^H Z, then [S Qt]^H Qt) and a halo exchange per product; the small
+    # algebra (tests/sstep_model.py = csrc/ks_block_kernels.hpp: k_fin_blk) runs replicated on every rank from identical sums.
+    import sstep_model as sm
+
+    def inner(X, Y):
+        loc = X.conj().T @ Y
+        return allsum(loc.ravel()).reshape(loc.shape)
+
+    stf = sm.Factored(r1 - r0, m, np.float64)
+    stf.S[:, :5] = V[:, :5]
+    stf.H[:, :4] = H[:, :4]
+    shifts = sm.newton_shifts(np.linalg.eigvals(ows.H[:m, :m]), 4, True)
+    sm.expand_block2(A, stf, 5, m, shifts, 4, {}, scale=1.0 / 8.0, inner=inner, apply=lambda x: dist_spmv(plan, ip, dv, x, rank))
+    Vt = stf.true_basis(m + 1)
+    np.testing.assert_allclose(stf.H, ows.H, atol=1e-11)
+    np.testing.assert_allclose(Vt, ows.V[r0:r1], atol=1e-9)
+    allH = [None] * world
+    dist.all_gather_object(allH, stf.H.tobytes())
+    assert all(h == allH[0] for h in allH), (tag, "ranks disagree on H: the replicated algebra must see identical sums")
     return True
 
 

@@ -218,7 +218,7 @@ def expand_block(A, st, frm, to, shifts, s_max, stats, pivot_min=1e-6, gram="dou
         blk += 1
 
 
-def expand_block2(A, st, frm, to, shifts, s_max, stats, pivot_min=1e-6, scale=None, gdev_max=1e-8, **_):
+def expand_block2(A, st, frm, to, shifts, s_max, stats, pivot_min=1e-6, scale=None, gdev_max=1e-8, inner=None, apply=None, **_):
     """TWO-STAGE block step (what the device runs): the first pass also delivers G_Z = Z^H Z, so the block's triangular
     factor is known BEFORE the second pass, which then writes the block already (nearly) orthonormal:
 
@@ -233,6 +233,11 @@ def expand_block2(A, st, frm, to, shifts, s_max, stats, pivot_min=1e-6, scale=No
     level as long as delta << 1.  The last stored column is q_s up to R_2 ~ I: no combine pass."""
     S, T, H = st.S, st.T, st.H
     dtype = H.dtype
+    # `inner(X, Y)` = X^H Y and `apply(x)` = A x: the only places where the n-sized data is touched -- a row-partitioned run
+    # passes an all-reduced inner product and a product with a halo exchange (tests/dist_worker.py), everything else is the
+    # replicated small algebra
+    inner = inner or (lambda X, Y: X.conj().T @ Y)
+    apply = apply or (lambda x: A @ x)
     j = frm
     blk = 0
     while j <= to:
@@ -244,19 +249,19 @@ def expand_block2(A, st, frm, to, shifts, s_max, stats, pivot_min=1e-6, scale=No
         Z = np.zeros((S.shape[0], s), dtype=dtype, order="F")
         prev = S[:, k - 1]
         for i in range(s):
-            Z[:, i] = (A @ prev - th[i] * prev) * sig[i]
+            Z[:, i] = (apply(prev) - th[i] * prev) * sig[i]
             prev = Z[:, i]
         # ---- pass 1 ----
-        Praw = S[:, :k].conj().T @ Z
-        GZ = Z.conj().T @ Z
+        both = inner(np.hstack([S[:, :k], Z]), Z)      # ONE reduction: S^H Z and Z^H Z
+        Praw, GZ = both[:k], both[k:]
         P = T[:k, :k].conj().T @ Praw
         R1, piv1 = chol_upper(GZ - P.conj().T @ P, pivot_min, k, j)
         R1inv = tri_inv(R1)
         coef = T[:k, :k] @ P
         # ---- pass 2 ----
         Qt = (Z - S[:, :k] @ coef) @ R1inv
-        Craw = S[:, :k].conj().T @ Qt
-        Gt = Qt.conj().T @ Qt
+        both = inner(np.hstack([S[:, :k], Qt]), Qt)    # ONE reduction: S^H Qt and Qt^H Qt
+        Craw, Gt = both[:k], both[k:]
         C = T[:k, :k].conj().T @ Craw
         # G_t = I + delta with delta ~ eps cond(R_1)^2; the recovered H carries errors ~ eps cond(R_1): a block is accepted
         # only while delta <= gdev_max (1e-8: cond <= ~1e4, H as accurate as the per-step path's)

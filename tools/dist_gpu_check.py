@@ -228,6 +228,9 @@ def main():
     # ||A Q - Q R||_F over nconverged columns; the solver's criterion is per vector, tol * |lambda| (src/run.jl:330)
     ok = bool(hist.converged and res < 10 * kw["tol"] * np.abs(F.eigenvalues).max() * max(1, F.nconverged) and orth < 1e-12)
     msg = f"{hist} resid={res:.2e} orth={orth:.2e} neighbours={len(plan.neigh)} rows {r0}:{r1}"
+    if os.environ.get("KS_CHECK_BLOCKS") == "1":  # the s-step expansion must really have run in blocks on every rank
+        info = ws.sstep_info
+        msg += f" sstep={info['s']} blocks{'>0' if info['blocks'] > 0 else '=0'} ({info['blocks']}, abandoned {info['abandoned']})"
     if mode == "laplace":
         exact = ks.matrices.laplace3d_eigs(mx, my, mz, 6)
         err = np.abs(np.sort(F.eigenvalues.real)[:6] - exact).max() if F.nconverged >= 6 else float("nan")
