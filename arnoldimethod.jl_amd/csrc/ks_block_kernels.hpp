@@ -23,6 +23,7 @@ namespace ksd {
 
 constexpr int kBlkSMax = 10;                                   // largest block (steps per block)
 constexpr int kBlkGram = kBlkSMax * (kBlkSMax + 1) / 2;        // upper triangle of an s x s Gram matrix
+constexpr int kBlkHLds = 2048;                                 // ... and of H[0:k, 0:k-1)
 constexpr int kBlkTLds = 2048;                                 // elements of T the block algebra stages in LDS (16 / 32 KiB)
 constexpr int kBlkKMax = kTMax;                                // columns the factored path covers (maxdim <= 64 -> 65 columns)
 
@@ -391,34 +392,55 @@ __device__ __forceinline__ cd inv_(cd a) {
   return cd{a.x * d, -a.y * d};
 }
 
+__device__ __forceinline__ double bcast_(double v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ cd bcast_(cd v, int src) { return cd{__shfl(v.x, src, 64), __shfl(v.y, src, 64)}; }
+
 // Cholesky R^H R = G of an s x s Hermitian matrix given by its upper triangle in LDS (column stride s), in place: on exit
 // the upper triangle holds R.  All threads of the workgroup call it; returns the smallest pivot ratio d_i / G_ii (<= 0 when
-// the matrix is not positive definite).  pivmin: the factorisation stops (and the caller bails) at the first ratio <= pivmin.
+// the matrix is not positive definite); the factorisation stops (and the caller bails) at the first ratio <= pivmin.
+// Done by WAVE 0 in registers: lane l owns column l, column i of R travels by lane broadcasts -- no barrier and no LDS round
+// trip inside the s dependent steps (the first version, thread 0 + two barriers per step, cost 10 us of a 28 us kernel).
 template <class T> __device__ double chol_upper_lds(T* G, int s, double pivmin, double* sh_ratio) {
   const int tid = threadIdx.x;
-  double worst = 1.0;
-  for (int i = 0; i < s; ++i) {
-    if (tid == 0) {
-      const double gii = real_of(G[i + i * s]);
-      double d = gii;
-      for (int p = 0; p < i; ++p) d -= abs2_(G[p + i * s]);
-      const double ratio = gii > 0.0 ? d / gii : 0.0;
-      *sh_ratio = ratio;
-      if (ratio > pivmin) G[i + i * s] = from_real(sqrt(d), T{});
+  if (tid < 64) {
+    const int lane = tid;
+    T r[kBlkSMax];
+#pragma unroll
+    for (int i = 0; i < kBlkSMax; ++i) r[i] = (lane < s && i <= lane && i < s) ? G[i + lane * s] : zero_of(T{});
+    double worst = 1.0;
+    bool okay = true;
+#pragma unroll
+    for (int i = 0; i < kBlkSMax; ++i) {
+      if (i < s && okay) {  // (uniform)
+        double d = real_of(r[i]);
+        const double gii = d;
+#pragma unroll
+        for (int p = 0; p < i; ++p) d -= abs2_(r[p]);
+        const double di = __shfl(d, i, 64), gi = __shfl(gii, i, 64);
+        const double ratio = gi > 0.0 ? di / gi : 0.0;
+        worst = fmin(worst, ratio);
+        if (!(ratio > pivmin)) {
+          okay = false;
+        } else {
+          const double rii = sqrt(di), rinv = 1.0 / rii;
+          T a = r[i];
+#pragma unroll
+          for (int p = 0; p < i; ++p) a = sub_(a, mul_(conj_(bcast_(r[p], i)), r[p]));
+          r[i] = lane == i ? from_real(rii, T{}) : scl(a, rinv);
+        }
+      }
     }
-    __syncthreads();
-    const double ratio = *sh_ratio;
-    worst = fmin(worst, ratio);
-    if (!(ratio > pivmin)) return worst;
-    const int l = i + 1 + tid;
-    if (l < s) {
-      T a = G[i + l * s];
-      for (int p = 0; p < i; ++p) a = sub_(a, mul_(conj_(G[p + i * s]), G[p + l * s]));
-      G[i + l * s] = scl(a, 1.0 / real_of(G[i + i * s]));
+    if (okay && lane < s) {
+#pragma unroll
+      for (int i = 0; i < kBlkSMax; ++i)
+        if (i <= lane && i < s) G[i + lane * s] = r[i];
     }
-    __syncthreads();
+    if (lane == 0) *sh_ratio = worst;
   }
-  return worst;
+  __syncthreads();
+  const double w = *sh_ratio;
+  __syncthreads();
+  return w;
 }
 // X = R^-1 (upper triangular, column stride s): thread c < s computes column c by back substitution
 template <class T> __device__ void tri_inv_lds(const T* Rm, T* X, int s) {
@@ -499,8 +521,16 @@ __global__ void __launch_bounds__(kBlock)
   __shared__ T Gm[kBlkSMax * kBlkSMax], Xi[kBlkSMax * kBlkSMax], Rf[kBlkSMax * kBlkSMax];
   __shared__ T zu[kBlkKMax + kBlkSMax], hk[kBlkKMax + kBlkSMax];
   __shared__ T Tl[kBlkTLds];
+  __shared__ T Hl[kBlkHLds];
+  __shared__ T rhs[(kBlkKMax + kBlkSMax) * (kBlkSMax - 1)];
   const int tid = threadIdx.x;
   const int ng = s * (s + 1) / 2, ne = k * s + ng;
+#ifdef KS_FIN_TIMING
+  long long tq[8] = {wall_clock64(), 0, 0, 0, 0, 0, 0, 0};
+#define KS_TQ(i) tq[i] = wall_clock64()
+#else
+#define KS_TQ(i) ((void)0)
+#endif
   if (mode != 2) {
     const int c = blockIdx.x;
     const T v = block_sum(partial + (int64_t)c * pnb, nb, sm);
@@ -517,6 +547,7 @@ __global__ void __launch_bounds__(kBlock)
     if (tid == 0) *counter = 0u;
     __threadfence();
   }
+  KS_TQ(1);
   for (int e = tid; e < ne; e += kBlock) rs[e] = ld_agent(red + e);
   // columns ntrue..k-1 of T -> LDS (rows 0..k-1; entries below the diagonal are never read)
   const int nlz = k - ntrue;
@@ -530,8 +561,10 @@ __global__ void __launch_bounds__(kBlock)
   const int64_t tld = t_lds ? k : ldt;
   __syncthreads();
   const T* Gin = rs + k * s;
+  KS_TQ(2);
   // A1 = T^H (raw inner products)
   th_times(tb, tld, ntrue, k, s, rs, A1);
+  KS_TQ(3);
   // Gm = Gin - A1^H A1   (upper triangle)
   for (int g = tid; g < ng; g += kBlock) {
     int i2 = 0;
@@ -549,13 +582,17 @@ __global__ void __launch_bounds__(kBlock)
   // accuracy; tests/test_sstep_model.py); beyond that it is abandoned like a rank-deficient one and the host lowers s.
   double gdev = 0.0;
   if (stage == 2) {
-    if (tid == 0) {
-      for (int i2 = 0; i2 < s; ++i2)
-        for (int i = 0; i <= i2; ++i) {
-          const T g = Gin[gram_idx(i, i2)];
-          gdev = fmax(gdev, sqrt(abs2_(sub_(g, from_real(i == i2 ? 1.0 : 0.0, T{})))));
-        }
-      sh_ratio = gdev;
+    if (tid < 64) {  // ng <= 55 entries: one wave, |entry - delta|^2, wave maximum
+      double dv = 0.0;
+      if (tid < ng) {
+        int i2 = 0;
+        while ((i2 + 1) * (i2 + 2) / 2 <= tid) ++i2;
+        const int i = tid - i2 * (i2 + 1) / 2;
+        dv = abs2_(sub_(Gin[tid], from_real(i == i2 ? 1.0 : 0.0, T{})));
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) dv = fmax(dv, __shfl_xor(dv, off, 64));
+      if (tid == 0) sh_ratio = sqrt(dv);
     }
     __syncthreads();
     gdev = sh_ratio;
@@ -576,6 +613,7 @@ __global__ void __launch_bounds__(kBlock)
     return;
   }
   tri_inv_lds(Gm, Xi, s);
+  KS_TQ(4);
   if (stage == 1) {
     t_times(tb, tld, ntrue, k, s, A1, A2);   // T P
     for (int e = tid; e < k * s; e += kBlock) {
@@ -591,6 +629,10 @@ __global__ void __launch_bounds__(kBlock)
       bs->r1inv[e] = l <= i ? Xi[e] : zero_of(T{});
     }
     if (tid == 0) st->blk_piv1 = fmin(st->blk_piv1, worst);
+#ifdef KS_FIN_TIMING
+    if (tid == 0 && k == 29) printf("[fin_blk stage 1 k=%d s=%d] reduce+elect %.2f | fetch %.2f | T^H %.2f | gram+chol+inv %.2f | rest %.2f us\n", k, s,
+                                    (tq[1] - tq[0]) * 0.01, (tq[2] - tq[1]) * 0.01, (tq[3] - tq[2]) * 0.01, (tq[4] - tq[3]) * 0.01, (wall_clock64() - tq[4]) * 0.01);
+#endif
     return;
   }
   // ---------------- stage 2: A1 = C, Gm = R2, Xi = R2^-1 ----------------
@@ -627,32 +669,56 @@ __global__ void __launch_bounds__(kBlock)
   // zeta_i[r] for i >= 1:  r < k: A2[(i-1) k + r],  r = k + a: Rf[a + (i-1) s]
   auto zeta = [&](int i, int r) -> T { return r < k ? A2[(i - 1) * k + r] : Rf[(r - k) + (i - 1) * s]; };
   const int m = k + s;
+  KS_TQ(5);
+  // H[0:k, 0:k-1) -> LDS (coalesced; a thread below walks ALONG a row of H: from memory that is a chain of L2 round trips)
+  const bool h_lds = k * (k - 1) <= kBlkHLds;
+  if (h_lds)
+    for (int e = tid; e < k * (k - 1); e += kBlock) Hl[e] = Hd[(e % k) + (int64_t)(e / k) * ldh];
+  const T* hb = h_lds ? Hl : Hd;
+  const int64_t hld = h_lds ? k : ldh;
+  __syncthreads();
   // H column k-1:  (zeta_1 / sigma_1 + theta_1 zeta_0 - H[:, 0:k-1) u[0:k-1)) / u[k-1]
   for (int r = tid; r < m; r += kBlock) {
     T a = scl(zeta(1, r), 1.0 / sh.sigma[0]);
     if (r < k) {
       a = fma_(sh.theta[0], zu[r], a);
-      T hu = zero_of(T{});
-      for (int c = (r > 0 ? r - 1 : 0); c < k - 1; ++c) hu = fma_(Hd[r + (int64_t)c * ldh], zu[c], hu);  // upper Hessenberg
-      a = sub_(a, hu);
+      T h0 = zero_of(T{}), h1 = zero_of(T{});
+      int c = r > 0 ? r - 1 : 0;  // upper Hessenberg
+      for (; c + 1 < k - 1; c += 2) {
+        h0 = fma_(hb[r + c * hld], zu[c], h0);
+        h1 = fma_(hb[r + (c + 1) * hld], zu[c + 1], h1);
+      }
+      if (c < k - 1) h0 = fma_(hb[r + c * hld], zu[c], h0);
+      a = sub_(a, add_(h0, h1));
     }
     hk[r] = mul_(a, inv_(zu[k - 1]));
   }
   __syncthreads();
   for (int r = tid; r < ldh; r += kBlock) Hd[r + (int64_t)(k - 1) * ldh] = r < m ? hk[r] : zero_of(T{});
-  // H columns k .. k+s-2: row-parallel forward substitution with R
+  // H columns k .. k+s-2:  M R_{s-1} = rhs,  rhs[:, i-1] = zeta_{i+1} / sigma_{i+1} + theta_{i+1} zeta_i - Hext PC[:, i-1]
+  // (Hext = [ H[:, 0:k-1) | hk ]);  all (row, column) pairs of rhs in parallel, then a row-parallel forward substitution
   if (s > 1) {
+    for (int e = tid; e < m * (s - 1); e += kBlock) {
+      const int r = e % m, i = 1 + e / m;
+      T a = fma_(sh.theta[i], zeta(i, r), scl(zeta(i + 1, r), 1.0 / sh.sigma[i]));
+      T h0 = zero_of(T{}), h1 = zero_of(T{});
+      const T* pc = A2 + (i - 1) * k;
+      if (r < k) {
+        int c = r > 0 ? r - 1 : 0;
+        for (; c + 1 < k - 1; c += 2) {
+          h0 = fma_(hb[r + c * hld], pc[c], h0);
+          h1 = fma_(hb[r + (c + 1) * hld], pc[c + 1], h1);
+        }
+        if (c < k - 1) h0 = fma_(hb[r + c * hld], pc[c], h0);
+      }
+      h0 = fma_(hk[r], pc[k - 1], h0);
+      rhs[e] = sub_(a, add_(h0, h1));
+    }
+    __syncthreads();
     for (int r = tid; r < m; r += kBlock) {
       T Mrow[kBlkSMax];
       for (int i = 1; i < s; ++i) {
-        // rhs = zeta_{i+1} / sigma_{i+1} + theta_{i+1} zeta_i - Hext PC[:, i-1]
-        T a = fma_(sh.theta[i], zeta(i, r), scl(zeta(i + 1, r), 1.0 / sh.sigma[i]));
-        T hx = zero_of(T{});
-        if (r < k) {
-          for (int c = (r > 0 ? r - 1 : 0); c < k - 1; ++c) hx = fma_(Hd[r + (int64_t)c * ldh], A2[(i - 1) * k + c], hx);
-        }
-        hx = fma_(hk[r], A2[(i - 1) * k + (k - 1)], hx);
-        a = sub_(a, hx);
+        T a = rhs[r + (i - 1) * m];
         for (int l = 0; l < i - 1; ++l) a = sub_(a, mul_(Mrow[l], Rf[l + (i - 1) * s]));
         Mrow[i - 1] = mul_(a, inv_(Rf[(i - 1) + (i - 1) * s]));
       }
@@ -672,6 +738,10 @@ __global__ void __launch_bounds__(kBlock)
     st->blk_piv2 = fmin(st->blk_piv2, worst);
     st->blk_gdev = fmax(st->blk_gdev, gdev);
   }
+#ifdef KS_FIN_TIMING
+  if (tid == 0 && k == 29) printf("[fin_blk stage 2 k=%d s=%d] reduce+elect %.2f | fetch %.2f | T^H %.2f | gram+chol+inv %.2f | T cols, R, PC %.2f | H %.2f us\n", k, s,
+                                  (tq[1] - tq[0]) * 0.01, (tq[2] - tq[1]) * 0.01, (tq[3] - tq[2]) * 0.01, (tq[4] - tq[3]) * 0.01, (tq[5] - tq[4]) * 0.01, (wall_clock64() - tq[5]) * 0.01);
+#endif
 }
 
 }  // namespace ksd

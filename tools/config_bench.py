@@ -74,6 +74,8 @@ def main():
     ap.add_argument("config")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--sstep", type=int, default=int(os.environ.get("KS_BENCH_SSTEP", "0")),
+                    help="s-step (block) expansion: steps per block (ks_workspace_set_sstep); 0 = per-step expansion")
     args = ap.parse_args()
     if args.config == "cfg4d":
         import torch  # noqa: F401 - before the first HIP call of the library
@@ -86,6 +88,8 @@ def main():
     v1 = M.start_vector(n).astype(dtype)
     if esz == 16:
         v1 = v1 + 1j * M.start_vector(n, seed=5)
+    if args.sstep >= 2:
+        ws.set_sstep(args.sstep)
     ws.reinitialize(0, v1)
     ws.iterate_arnoldi(op, 1, mindim)
     fmt = op.format
@@ -107,11 +111,25 @@ def main():
         if timed:
             state["steps"] += maxdim - k
             state["reorth"] += st["reorth"]
+            info = ws.sstep_info
+            blk = ks.sstep_partition(dtype, k + 1, maxdim - k, info["s"]) if (args.sstep >= 2 and info["s"] >= 2) else []
+            if blk and info["blocks"] - state.get("blocks_seen", 0) != len(blk):
+                blk = []                                   # (a block was abandoned, or no shifts yet: not a block cycle)
+            state["blocks_seen"] = info["blocks"]
+            state["abandoned"] = info["abandoned"]
+            state["blk_cycles"] = state.get("blk_cycles", 0) + (1 if blk else 0)
+            if blk:  # per block of s steps on kk columns: s products (+ 3 esz n for the shift unless fused) + two passes
+                shift_b = 0.0 if fmt["layout"] == "stencil" else 3.0 * esz * n
+                kk = k + 1
+                for sb in blk:
+                    state["moved"] += sb * (spmv_b + shift_b) + esz * n * (kk + sb) + esz * n * (kk + 2 * sb)
+                    kk += sb
             for j in range(k + 1, maxdim + 1):
-                state["moved"] += spmv_b + esz * n * (j + 1) + esz * n * (j + 2)
+                if not blk:
+                    state["moved"] += spmv_b + esz * n * (j + 1) + esz * n * (j + 2)
             # (a third pass over V exists only on the explicit-second-pass path, KS_PASSES=3: the default expansion carries
             # the second projection in the triangular factor -- booking it unconditionally gave moved_frac 1.07 in round 3)
-            if ws.passes == 3:
+            if ws.passes == 3 and not blk:
                 state["moved"] += st["reorth"] * esz * n * ((k + 1 + maxdim) / 2.0 + 2)
             state["t_expand"] += t1 - t0
             state["t_restart"] += t2 - t1
@@ -145,6 +163,7 @@ def main():
         "config": args.config, "workload": f"{what}, nev={nev}, which={which}, mindim={mindim}, maxdim={maxdim}, dtype={'c128' if esz == 16 else 'f64'}",
         "iters_per_s": state["steps"] / elapsed, "ms_per_cycle": 1e3 * elapsed / args.steps, "iterations": state["steps"],
         "dgks_second_passes": state["reorth"], "spmv_layout": fmt, "per_class": per,
+        "sstep": {"requested": args.sstep, "in_force": ws.sstep_info["s"], "block_cycles": state.get("blk_cycles", 0), "abandoned": state.get("abandoned", 0)} if args.sstep >= 2 else None,
         "expansion": {"moved_GBps": moved, "moved_frac": moved / PEAK, "expand_seconds": state["t_expand"], "restart_seconds": state["t_restart"]},
     }
     print(json.dumps(out), flush=True)

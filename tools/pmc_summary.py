@@ -2,7 +2,8 @@
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (collected in SEPARATE runs, each with only
 --kernel-trace next to --pmc) per kernel, and write profiles/pmc_traffic.json for bench.py.
 
-usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <n> <nnz> [out.json] [bytes_per_nnz] [index_bytes_per_row] [rotation_columns]
+usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <n> <nnz> [out.json] [bytes_per_nnz] [index_bytes_per_row] [rotation_columns] [kstart]
+(out.json is MERGED: classes of an earlier pass that this one does not exercise are kept)
 (bytes_per_nnz: what the SpMV layout in use streams per stored entry -- 12 plain CSR, 4 value-indexed, 1
 delta-value-indexed; `bench.py` prints it as config.spmv_layout)
 
@@ -30,6 +31,10 @@ def load(path):
 
 
 def klass(name):
+    if name.startswith("k_bdots"):
+        return "blk_dots"
+    if name.startswith("k_bupdate"):
+        return "blk_fused"
     if name.startswith("k_dots"):
         return "dots"
     if name.startswith("k_axpy_dots"):
@@ -51,6 +56,7 @@ def main():
     bpn = float(sys.argv[6]) if len(sys.argv) > 6 else 12.0
     aux = float(sys.argv[7]) if len(sys.argv) > 7 else 4.0  # index bytes per row next to the non-zeros (4: rowptr; 0: stencil-mask layout)
     rot_cols = float(sys.argv[8]) if len(sys.argv) > 8 else 60.0  # columns the restart rotation reads + writes (T-folded: 41 + 21)
+    kstart = int(sys.argv[9]) if len(sys.argv) > 9 else 21       # s-step expansion: columns in place when a batch starts (k + 1 of the restart)
     def after_calibration(rows):
         # the launches before the first SpMV are the placement search of ks_workspace_create; their number
         # differs from process to process
@@ -66,6 +72,7 @@ def main():
     # the dots template parameter and the order inside one expansion (j increases by one per step).
     per = defaultdict(lambda: dict(launches=0, fetch=0.0, write=0.0, alg=0.0))
     j = None
+    blk_k = None
     last_nc4 = None
     started = False  # the launches before the first SpMV are the placement calibration of ks_workspace_create
     for (_, name, f), (_, _, w) in zip(F, W):
@@ -78,6 +85,17 @@ def main():
             continue
         if k == "spmv":
             alg = bpn * nnz + aux * (n + 1) + 2 * col
+        elif k in ("blk_dots", "blk_fused"):
+            # s-step kernels: k_bdots<double, NCW, S, ...> reads the kb existing columns and the S new ones, k_bupdate reads the
+            # same and writes the S; kb starts at `kstart` after every rotation and grows by S per block
+            S = int(re.search(r"k_b(?:dots|update)<double, \d+, (\d+)", name).group(1))
+            if k == "blk_dots":
+                kb = kstart if (blk_k is None) else blk_k
+                blk_k = kb
+                alg = col * (kb + S)
+            else:
+                alg = col * (blk_k + 2 * S)
+                blk_k += S
         elif k == "dots":
             nc4 = int(re.search(r"k_dots<double, (\d+)", name).group(1))
             # first step of an expansion: smallest j of the granule is unknown -> track by sequence
@@ -93,6 +111,7 @@ def main():
         elif k == "scale":
             alg = 2 * col
         elif k == "rotate":
+            blk_k = None
             alg = col * rot_cols  # the restart of the bench workload reads 40 columns and writes 20 (T-folded form: 41 and 21)
         else:
             alg = None
@@ -112,6 +131,12 @@ def main():
                              "calibrated": k != "spmv"}
         print(f"{k:8s} {e['launches']:8d} {hbm/1e9:22.4f} {(alg or 0)/1e9:22.4f} {(hbm/alg if alg else 0):6.3f}")
     if out:
+        try:  # keep the classes of an earlier pass that this one did not exercise (per-step kernels next to the block kernels)
+            old = json.load(open(out))
+            for kk, vv in old.get("classes", {}).items():
+                res["classes"].setdefault(kk, vv)
+        except Exception:
+            pass
         json.dump(res, open(out, "w"), indent=1)
         print("wrote", out)
 
