@@ -694,7 +694,8 @@ template <class T, class MT, int RPT>
 __global__ void __launch_bounds__(kBlock)
     k_spmv_stencil(const MT* __restrict__ mask, const StencilDict<T> d, int nslots, const T* __restrict__ x,
                    const T* __restrict__ xg, T* __restrict__ y, int64_t n, int64_t nghost, int ntiles,
-                   const DevState* __restrict__ st, HaloFused hf, HaloArgs ha, P2pDev pd) {
+                   const DevState* __restrict__ st, HaloFused hf, HaloArgs ha, P2pDev pd, int shifted = 0, T theta = T{},
+                   double sigma = 1.0) {
   // (xg: the ghost vector of THIS exchange -- the host picks the slot of the double buffer, ks_p2p.hpp)
   if (st && st->breakdown >= 0) return;
   int tile = xcd_remap(blockIdx.x, ntiles);
@@ -752,7 +753,11 @@ __global__ void __launch_bounds__(kBlock)
   }
 #pragma unroll
   for (int q = 0; q < RPT; ++q)
-    if (r[q] < n) st_elem_nt(y + r[q], s[q]);
+    if (r[q] < n) {
+      // shifted: Newton-basis step of the s-step expansion, y = sigma (A x - theta x) (as in k_spmv_stencil2)
+      if (shifted) s[q] = scl(sub_s(s[q], mul_(theta, x[r[q]])), sigma);
+      st_elem_nt(y + r[q], s[q]);
+    }
 }
 
 // Paired form (single GPU, no ghost columns): a lane owns the two consecutive rows 2t, 2t+1 and fetches x[r + delta_k],

@@ -133,7 +133,8 @@ template <class D> struct CsrOp : ks_operator {
   double shift_sigma = 1.0;
   void apply_shifted(const void* xv, void* yv, double tre, double tim, double sigma, int64_t ld, const DevState* st) override {
     static const int fuse = env_int("KS_SHIFT_FUSED", 1);
-    const bool fused = fuse && nstencil > 0 && nghost == 0 && smask2 && n_local >= 2 && cblocks.empty() && env_int("KS_STENCIL_PAIRS", 1);
+    // (both stencil kernels: the paired one on a single GPU, the one with ghost columns on a row block of several ranks)
+    const bool fused = fuse && nstencil > 0 && n_local > 0 && cblocks.empty();
     if (!fused) { ks_operator::apply_shifted(xv, yv, tre, tim, sigma, ld, st); return; }
     shift_on = true;
     if constexpr (sizeof(D) == 8) shift_theta = tre; else shift_theta = D{tre, tim};
@@ -280,7 +281,8 @@ template <class D> struct CsrOp : ks_operator {
           h.npush = std::min(h.npush, nt);
           h.tile_shift = (h.enabled && ghost_lo_end < n_local) ? (int)((ghost_lo_end + kBlock * RPT - 1) / (kBlock * RPT)) % std::max(nt, 1) : 0;
           ksd::k_spmv_stencil<D, MT, RPT><<<nt, kBlock, 0, s>>>(static_cast<const MT*>(smask), sdict, nstencil, x, xg, y, n_local,
-                                                                std::max<int64_t>(nghost, 0), nt, st, h, hargs, ctx->p2p.dev);
+                                                                std::max<int64_t>(nghost, 0), nt, st, h, hargs, ctx->p2p.dev, shift_on ? 1 : 0,
+                                                                shift_theta, shift_sigma);
         };
         auto by_rpt = [&](auto mt_tag) {
           if (rpt_env <= 1) go(mt_tag, std::integral_constant<int, 1>{});

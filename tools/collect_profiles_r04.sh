@@ -40,7 +40,7 @@ for mode in 0 8; do   # per-step kernels first, then the block kernels: the summ
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_${mode}_$c -- python $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-shift-invert --no-profile --sstep $mode > /dev/null 2>> $OUT/bench.err
     trim "$(find /tmp/pmc_${mode}_$c -name '*counter_collection.csv' | head -1)" "$OUT/pmc_sstep${mode}_$(echo $c | tr A-Z a-z | sed s/_size//).csv"
   done
-  python $REPO/tools/pmc_summary.py $OUT/pmc_sstep${mode}_fetch.csv $OUT/pmc_sstep${mode}_write.csv $N $NNZ $OUT/pmc_traffic.json 0.125 0 62 21 > $OUT/pmc_summary_sstep${mode}.txt 2>&1
+  python $REPO/tools/pmc_summary.py $OUT/pmc_sstep${mode}_fetch.csv $OUT/pmc_sstep${mode}_write.csv $N $NNZ $OUT/pmc_traffic.json 0.1434 0 62 21 > $OUT/pmc_summary_sstep${mode}.txt 2>&1
 done
 for cfg in cfg2 cfg3 cfg4; do
   for s in 0 8; do
