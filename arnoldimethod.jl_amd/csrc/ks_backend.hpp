@@ -41,6 +41,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
       // and lazy-normalisation factors were never fetched.  Drain the stream and return the bookkeeping to "every
       // column is ordinary"; the factorisation itself is undefined from here on -- the caller must re-initialise
       // (ks_reinitialize(ws, 0, ...) or ks_partialschur with initialize = 1) before using the workspace again.
+      gate_cancel(ws);
       (void)hipStreamSynchronize(ws->ctx->stream);
       try { reset_lazy(ws); } catch (...) {}
       prov_drop(ws);
@@ -117,6 +118,9 @@ template <class T> struct HipBackend : ks::Backend<T> {
       double tq0 = dbg ? ks::now_s() : 0.0, tq1 = 0, tq2 = 0;
       if (mb) publish_control(ws, j0, ws->Hstage_dev, 1, seq, tpath);
       else fetch_state_enqueue(ws, j0, tpath);
+      // reverse mailbox: the restart that follows this (last) batch will rotate the factored basis -- put that rotation into
+      // the stream NOW, behind a gate the host releases when it has Q (ks_workspace.hpp: gate_arm / rotate_tfold)
+      if (early && tpath && mb && jend == to) gate_arm(ws);
       if (do_early) {
         mbox_wait(ws, 0, seq);
         if (dbg) tq1 = ks::now_s();
@@ -153,6 +157,8 @@ template <class T> struct HipBackend : ks::Backend<T> {
       // the step itself is redone below in the explicit form; not a breakdown
       // blk_bail: a block was abandoned before anything of it was committed (rank-deficient Gram matrix: breakdown, or a
       // Newton basis too ill-conditioned to trust) -- the blocks before it stand, the rest of the range runs step by step
+      if (ws->gate_armed && (ws->st_h->breakdown >= 0 || ws->st_h->bail >= 0 || ws->st_h->blk_bail >= 0))
+        gate_cancel(ws);  // the batch did not run to its end: more batches (or a re-initialisation) follow, no restart yet
       const int blk_bail = bpath ? ws->st_h->blk_bail : -1;
       const int bail = (tpath && !bpath) ? ws->st_h->bail : -1;
       const int bd = (bail >= 0 || blk_bail >= 0) ? -1 : ws->st_h->breakdown;
@@ -296,6 +302,17 @@ template <class T> struct HipBackend : ks::Backend<T> {
     }
     if (own) prov_set(ws, dst);  // (the host step rewrote H: new shadow)
     else prov_drop(ws);
+  }
+};
+
+// While alive, expansions that announce a restart (iterate_arnoldi_early) may pre-enqueue its rotation behind the gate; on
+// exit -- normal or by exception (QR failure in the host step, operator error) -- a gate still waiting is cancelled.
+struct GateScope {
+  ks_workspace* ws;
+  explicit GateScope(ks_workspace* w) : ws(w) { ws->gate_allowed = true; }
+  ~GateScope() {
+    ws->gate_allowed = false;
+    gate_cancel(ws);
   }
 };
 

@@ -575,11 +575,26 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     // stores would only become visible at a synchronisation and the spin would never see them)
     const unsigned coh = hipHostMallocCoherent | hipHostMallocMapped;
     KS_HIP(hipHostMalloc(&w->Hstage, ctl_bytes, coh));
-    KS_HIP(hipHostMalloc(&w->Qstage, qxbytes));
+    KS_HIP(hipHostMalloc(&w->Qstage, qxbytes, coh));   // (coherent + mapped: the rotation gate reads it from the device)
     KS_HIP(hipHostMalloc(&w->Hstage_early, ctl_bytes, coh));
     std::memset(w->Hstage_early, 0, ctl_bytes);
     KS_HIP(hipHostMalloc(reinterpret_cast<void**>(&w->mbox), 128, coh));
     std::memset(w->mbox, 0, 128);
+    // reverse mailbox (k_rot_gate): pinned parameter block the gate polls, its device copy, device view of the Q stage
+    if (hipHostMalloc(reinterpret_cast<void**>(&w->gate_h), sizeof(ksd::RotGate), coh) == hipSuccess) {
+      std::memset(w->gate_h, 0, sizeof(ksd::RotGate));
+      if (hipHostGetDevicePointer(reinterpret_cast<void**>(&w->gate_hd), w->gate_h, 0) != hipSuccess ||
+          hipHostGetDevicePointer(&w->Qstage_dev, w->Qstage, 0) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&w->gate_d), sizeof(ksd::RotGate)) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipHostFree(w->gate_h);
+        w->gate_h = nullptr;
+      } else {
+        KS_HIP(hipMemset(w->gate_d, 0, sizeof(ksd::RotGate)));
+      }
+    } else {
+      (void)hipGetLastError();
+      w->gate_h = nullptr;
+    }
     w->use_mbox = env_int("KS_MAILBOX", 1) != 0;
     if (hipHostGetDevicePointer(reinterpret_cast<void**>(&w->mbox_dev), w->mbox, 0) != hipSuccess ||
         hipHostGetDevicePointer(&w->Hstage_dev, w->Hstage, 0) != hipSuccess ||
@@ -1098,6 +1113,7 @@ int ks_partialschur(ks_operator* A, ks_workspace* ws, const ks_params* p, const 
       ks::Mat<T> H(Hh, prm.maxdim + 1, prm.maxdim, ldh);
       ks::Mat<T> Q(static_cast<T*>(ws->Q), prm.maxdim, prm.maxdim, ws->maxdim);
       HipBackend<T> be(A, ws);
+      GateScope gate_scope(ws);  // every expansion of the driver's loop is followed by the restart: its rotation may be pre-enqueued
       if (prm.initialize) be.reinitialize(prm.start_from - 1, prm.start_from == 1 ? static_cast<const T*>(v1_host) : nullptr);
       // partialschur! trusts the workspace it is handed (src/run.jl:152-179: V[:, 1:start_from-1] and H hold a partial
       // Schur decomposition, the start column is in place): so does the provenance from here on
@@ -1181,6 +1197,7 @@ int ks_expand_restart(ks_operator* A, ks_workspace* ws, const ks_params* p, int 
       ks::RestartScratch<T> sc(prm.maxdim);
       const ks::Ordering ordering{prm.which};
       HipBackend<T> be(A, ws);
+      GateScope gate_scope(ws);
       ks::ExpandStats st;
       double t0 = ks::now_s();
       const bool early_done = be.iterate_arnoldi_early(k_in + 1, prm.maxdim, H, st,

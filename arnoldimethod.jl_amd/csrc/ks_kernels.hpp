@@ -2166,10 +2166,57 @@ __global__ void __launch_bounds__(kBlock)
 // system makes of 41 read streams next to 21 write streams (a third of the traffic is writes; the expansion kernels
 // write 3 %).
 // ------------------------------------------------------------------------------------------------
+// REVERSE MAILBOX.  The restart's rotation is enqueued BEFORE the host's Schur step, behind a one-workgroup
+// gate that waits for a word in pinned host memory: when the host has Q it writes the product T Q and the shape of the
+// rotation into pinned memory and releases the word -- the gate copies both into device memory and the rotation, already
+// queued behind it, starts at once.  What leaves the critical path: a stream synchronisation, a hipMemcpyAsync of Q and a
+// kernel launch issued only after the host step (20-30 us per restart cycle).  The wait is bounded by wall clock; a gate
+// that is cancelled (breakdown in the last batch, an exception in the host step) or times out marks the parameters
+// cancelled and the rotation behind it returns immediately.
+struct RotGate {
+  uint64_t flag;          // host -> device: sequence number of the release (pinned, polled by the gate)
+  int32_t c, r, out0, extra_out, ldq, cancel, nq, pad_;
+  uint64_t timed_out;     // device -> host: the gate gave up waiting (sequence number)
+};
+static __global__ void __launch_bounds__(kBlock) k_rot_gate(RotGate* __restrict__ host, uint64_t seq, RotGate* __restrict__ dev,
+                                                            const double* __restrict__ q_host, double* __restrict__ q_dev,
+                                                            long long timeout_ticks) {
+  __shared__ int state;   // 1: released, 2: gave up
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();
+    int st = 0;
+    while (st == 0) {
+      if (__hip_atomic_load(&host->flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == seq) st = 1;
+      else if (wall_clock64() - t0 > timeout_ticks) st = 2;
+      else __builtin_amdgcn_s_sleep(8);
+    }
+    state = st;
+  }
+  __syncthreads();
+  if (state == 2) {
+    if (threadIdx.x == 0) {
+      dev->cancel = 1;
+      __hip_atomic_store(&host->timed_out, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
+  const int nq = host->nq;
+  for (int i = threadIdx.x; i < nq; i += kBlock) q_dev[i] = q_host[i];
+  if (threadIdx.x == 0) {
+    dev->c = host->c; dev->r = host->r; dev->out0 = host->out0; dev->extra_out = host->extra_out; dev->ldq = host->ldq;
+    dev->cancel = host->cancel;
+  }
+}
+
 template <int CT, bool NT = true>
 __global__ void __launch_bounds__(kBlock)
-    k_rotate_fma(double* __restrict__ V, int64_t ldv, int c, int r, const double* __restrict__ Qd, int ldq, int out0, int extra_out) {
+    k_rotate_fma(double* __restrict__ V, int64_t ldv, int c, int r, const double* __restrict__ Qd, int ldq, int out0, int extra_out,
+                 const RotGate* __restrict__ gate = nullptr) {
   static_assert(CT % 4 == 0, "CT must be a multiple of four");
+  if (gate) {  // shape from the gate in front of this launch (reverse mailbox)
+    if (gate->cancel) return;
+    c = gate->c; r = gate->r; ldq = gate->ldq; out0 = gate->out0; extra_out = gate->extra_out;
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* qs = reinterpret_cast<double*>(smem_raw);  // [r][CT]: qs[n * CT + k] = Q[k, n], zero for k >= c
   for (int i = threadIdx.x; i < r * CT; i += kBlock) {

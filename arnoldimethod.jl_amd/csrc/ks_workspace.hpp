@@ -110,6 +110,15 @@ struct ks_workspace {
   bool blk_tail = false;        // the T-lazy columns were produced by blocks (a batch continuing on them starts a new T)
   double blk_diag[3] = {1.0, 1.0, 0.0};  // of the last batch: worst pivot ratio of stage 1 / stage 2, largest |G_t - I| entry
   int blk_count = 0, blk_bails = 0;      // blocks completed / abandoned since creation
+  // REVERSE MAILBOX (k_rot_gate, ks_kernels.hpp): the restart rotation pre-enqueued behind a gate the host releases
+  ksd::RotGate* gate_h = nullptr;      // pinned host (coherent)
+  ksd::RotGate* gate_hd = nullptr;     // the same memory through its device pointer
+  ksd::RotGate* gate_d = nullptr;      // device copy the gated rotation reads
+  void* Qstage_dev = nullptr;          // device pointer of the pinned Qstage
+  bool gate_allowed = false;           // a driver entry point that always follows the expansion by the restart is running
+  bool gate_armed = false;
+  uint64_t gate_seq = 0;
+  int gate_cin = 0, gate_rmax = 0;     // shape the armed rotation was launched for
   int nb = 0;               // streaming workgroups (capped for small problems)
   int pnb = 0;              // column stride of `partial` (>= every producer's grid)
   uint64_t seed = 20240917ull;
@@ -141,10 +150,18 @@ struct ks_workspace {
     (void)hipFree(Qd); (void)hipHostFree(Qstage); (void)hipFree(tmp); (void)hipFree(tmp2); (void)hipFree(oop);
     (void)hipHostFree(Hstage_early); (void)hipHostFree(mbox); (void)hipFree(ctr);
     (void)hipFree(bpart); (void)hipFree(bred); (void)hipFree(bscr);
+    if (gate_armed && gate_h) {  // never leave a gate waiting: cancel, let the stream drain
+      gate_h->cancel = 1;
+      __atomic_store_n(&gate_h->flag, gate_seq, __ATOMIC_RELEASE);
+      (void)hipStreamSynchronize(ctx->stream);
+    }
+    (void)hipHostFree(gate_h); (void)hipFree(gate_d);
   }
 };
 
 namespace {
+
+inline void gate_cancel(ks_workspace* ws);  // (reverse mailbox, below: nothing may synchronise the stream behind an armed gate)
 
 inline int cap_blocks(const ks_workspace* ws, int nb, int packs_per_iter) {
   const int64_t npacks = ws->ld * (int64_t)ws->esz / 16;
@@ -387,6 +404,7 @@ inline void reset_lazy(ks_workspace* ws) {
 }
 template <class D> void materialize_t(ks_workspace* ws);
 inline void materialize(ks_workspace* ws) {
+  gate_cancel(ws);
   if (ws->t_lazy) {  // implicit second pass: V_true = S T, one in-place triangular product over the T-lazy columns
     if (ws->dtype == KS_F64) materialize_t<double>(ws);
     else materialize_t<cd>(ws);
@@ -817,7 +835,14 @@ void gemm_tall_chunked(ks_workspace* ws, const TV* V, int c, int r, const TY* Yd
 // V[:, c0+out0 : c0+out0+r) <- V[:, c0:c0+c) Q  with Q already on the device (column-major, ld = c); in place.  out0 = 0 is
 // the plain rotation; extra_out >= 0 sends the LAST output to column c0 + extra_out instead (T-folded restart: the
 // residual direction lands next to the truncated basis).
-template <class D> void rotate_device(ks_workspace* ws, int c0, int c, int r, int out0 = 0, int extra_out = -1) {
+// cancel a pre-enqueued rotation (its gate is released with the cancel mark: the rotation behind it returns at once)
+inline void gate_cancel(ks_workspace* ws) {
+  if (!ws->gate_armed) return;
+  ws->gate_h->cancel = 1;
+  __atomic_store_n(&ws->gate_h->flag, ws->gate_seq, __ATOMIC_RELEASE);
+  ws->gate_armed = false;
+}
+template <class D> void rotate_device(ks_workspace* ws, int c0, int c, int r, int out0 = 0, int extra_out = -1, bool gated = false) {
   ks_ctx* ctx = ws->ctx;
   hipStream_t s = ctx->stream;
   D* Vc = static_cast<D*>(ws->col(c0));
@@ -843,8 +868,9 @@ template <class D> void rotate_device(ks_workspace* ws, int c0, int c, int r, in
           occ = std::max(1, std::min(o, bpc_env));
         }
         const int nbr = cap_blocks(ws, ctx->num_cu * occ, kBlock);
-        if (ws->v_nt) ksd::k_rotate_fma<CT, true><<<nbr, kBlock, smem, s>>>(Vc, ws->ld, c, r, Qd, c, out0, extra_out);
-        else ksd::k_rotate_fma<CT, false><<<nbr, kBlock, smem, s>>>(Vc, ws->ld, c, r, Qd, c, out0, extra_out);
+        const ksd::RotGate* g = gated ? ws->gate_d : nullptr;
+        if (ws->v_nt) ksd::k_rotate_fma<CT, true><<<nbr, kBlock, smem, s>>>(Vc, ws->ld, c, r, Qd, c, out0, extra_out, g);
+        else ksd::k_rotate_fma<CT, false><<<nbr, kBlock, smem, s>>>(Vc, ws->ld, c, r, Qd, c, out0, extra_out, g);
       };
       KS_REQUIRE((size_t)r * 64 * 8 <= (size_t)64 * 1024, KS_ERR_INTERNAL, "rotation wider than the coefficient tile");
       if (c <= 24) go(std::integral_constant<int, 24>{});
@@ -901,10 +927,35 @@ template <class T> inline T t_entry(const ks_workspace* ws, int k, int i) {
 //   V[:, dst]           <- V_true[:, src]                         (src < 0: none)
 // computed as S[:, 0:cin) (T Q) with cin = max(c0 + c, src + 1).  Afterwards NO column is T-lazy: every T-lazy column that
 // is not among the outputs is dead (the caller guarantees it: restart, or materialisation of all of them).
+// Pre-enqueue the T-folded restart rotation of a Float64 workspace behind its gate (after the expansion batch and its
+// publishing kernel are in the stream, before the host starts the Schur step).  The rotation of a restart always reads
+// columns 0..maxdim (cin = maxdim + 1) and writes at most maxdim + 1 of them.
+inline bool gate_arm(ks_workspace* ws) {
+  static const int on = env_int("KS_ROT_GATE", 1);
+  static const long long timeout_ticks = (long long)env_int("KS_ROT_GATE_TIMEOUT_S", 60) * 100000000LL;  // wall_clock64: 100 MHz
+  const char* rot_env = std::getenv("KS_ROTATE");
+  if (!on || !ws->gate_allowed || ws->gate_armed || !ws->gate_h || ws->dtype != KS_F64 || ws->maxdim + 1 > 64 || ws->ctx->profiling ||
+      !ws->use_mbox || (rot_env && std::string(rot_env) != "fma") || env_int("KS_ROTATE_VALU", 0))
+    return false;
+  const int cin = ws->maxdim + 1;
+  ws->gate_h->cancel = 0;
+  ws->gate_seq += 1;
+  ksd::k_rot_gate<<<1, kBlock, 0, ws->ctx->stream>>>(ws->gate_hd, ws->gate_seq, ws->gate_d, static_cast<const double*>(ws->Qstage_dev),
+                                                     static_cast<double*>(ws->Qd), timeout_ticks);
+  ws->gate_cin = cin;
+  ws->gate_rmax = cin;
+  // (launched with the largest coefficient tile: r <= cin outputs)
+  rotate_device<double>(ws, 0, cin, cin, 0, -1, /*gated=*/true);
+  KS_HIP(hipGetLastError());
+  ws->gate_armed = true;
+  return true;
+}
+
 template <class T> void rotate_tfold(ks_workspace* ws, int c0, int c, int r, const T* Qh, int ldq, int out0, int src, int dst) {
   using D = typename DevT<T>::type;
   ws->ctx->use();
-  KS_HIP(hipStreamSynchronize(ws->ctx->stream));  // Qstage may still be in flight from a previous rotation
+  const bool gated = ws->gate_armed;
+  if (!gated) KS_HIP(hipStreamSynchronize(ws->ctx->stream));  // Qstage may still be in flight from a previous rotation
   const int rr = r + (src >= 0 ? 1 : 0);
   const int cin = std::max(c0 + c, src + 1);
   KS_REQUIRE(cin <= ws->maxdim + 1 && rr <= ws->maxdim + 1, KS_ERR_INTERNAL, "T-folded rotation out of range");
@@ -938,8 +989,25 @@ template <class T> void rotate_tfold(ks_workspace* ws, int c0, int c, int r, con
       out[src] = T(1);
     }
   }
-  KS_HIP(hipMemcpyAsync(ws->Qd, qs, (size_t)cin * rr * sizeof(T), hipMemcpyHostToDevice, ws->ctx->stream));
   const bool extra_elsewhere = src >= 0 && dst != out0 + r;
+  if (gated) {
+    if constexpr (sizeof(T) == 8) {
+      if (cin == ws->gate_cin && rr <= ws->gate_rmax && __atomic_load_n(&ws->gate_h->timed_out, __ATOMIC_ACQUIRE) != ws->gate_seq) {
+        // reverse mailbox: T Q is in the pinned stage, the gate copies it and the queued rotation runs
+        ksd::RotGate* g = ws->gate_h;
+        g->c = cin; g->r = rr; g->out0 = out0; g->extra_out = extra_elsewhere ? dst : -1; g->ldq = cin; g->nq = cin * rr; g->cancel = 0;
+        __atomic_store_n(&g->flag, ws->gate_seq, __ATOMIC_RELEASE);
+        ws->gate_armed = false;
+        ws->t_lazy = false;
+        ws->t_hi = -1;
+        ws->blk_tail = false;
+        return;
+      }
+    }
+    gate_cancel(ws);  // (shape does not fit what was enqueued, or the gate gave up: the ordinary sequence)
+    KS_HIP(hipStreamSynchronize(ws->ctx->stream));
+  }
+  KS_HIP(hipMemcpyAsync(ws->Qd, qs, (size_t)cin * rr * sizeof(T), hipMemcpyHostToDevice, ws->ctx->stream));
   rotate_device<D>(ws, 0, cin, rr, out0, extra_elsewhere ? dst : -1);
   ws->t_lazy = false;
   ws->t_hi = -1;
@@ -966,6 +1034,7 @@ template <class T> void rotate_lazy(ks_workspace* ws, int c0, int c, int r, cons
   using D = typename DevT<T>::type;
   if (c <= 0 || r <= 0) return;
   ws->ctx->use();
+  gate_cancel(ws);
   if (ws->t_lazy) materialize(ws);  // (T-lazy columns outside the rotated range would lose the columns they refer to)
   KS_HIP(hipStreamSynchronize(ws->ctx->stream));  // Qstage may still be in flight from a previous rotation
   if (ws->has_lazy() && ws->lazy_lo < c0) materialize(ws);

@@ -31,7 +31,9 @@ def bubbles(rows):
         if not name.startswith("k_rotate"):
             continue
         j = i - 1
-        while j >= 0 and rows[j][2].startswith("__amd"):
+        # (blit kernels and the rotation gate -- a one-workgroup kernel that only WAITS for the host, reverse mailbox -- are
+        # not work: the bubble runs from the last expansion kernel to the start of the rotation)
+        while j >= 0 and (rows[j][2].startswith("__amd") or rows[j][2] == "k_rot_gate"):
             j -= 1
         A.append((s - rows[j][1]) / 1e3)
         j, end = i + 1, e
