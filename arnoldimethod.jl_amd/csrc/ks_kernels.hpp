@@ -221,6 +221,23 @@ __global__ void __launch_bounds__(kBlock) k_fill_uniform(T* __restrict__ v, int6
 // Distributed mode: column indices >= n_local address the ghost buffer `xg` (filled by the halo
 // exchange: RCCL send/recv, or remote stores of the neighbours in peer-to-peer mode) instead of the local column.
 // ------------------------------------------------------------------------------------------------
+// Newton-basis step of the s-step expansion (ks_block_kernels.hpp) fused into a product's store: y = sigma (A x - theta x).
+// on == 0: the plain product, bit-identical to what the kernels have always stored.
+template <class T> struct ShiftArg {
+  int on = 0;
+  T theta{};
+  double sigma = 1.0;
+};
+__device__ __forceinline__ double shift_apply(const ShiftArg<double>& sh, double s, const double* __restrict__ x, int64_t row) {
+  return sh.on ? (s - sh.theta * x[row]) * sh.sigma : s;
+}
+__device__ __forceinline__ cd shift_apply(const ShiftArg<cd>& sh, cd s, const cd* __restrict__ x, int64_t row) {
+  if (!sh.on) return s;
+  const cd xv = x[row];
+  const cd tx = cd{sh.theta.x * xv.x - sh.theta.y * xv.y, sh.theta.x * xv.y + sh.theta.y * xv.x};
+  return cd{(s.x - tx.x) * sh.sigma, (s.y - tx.y) * sh.sigma};
+}
+
 constexpr int kSpmvRows = 256;       // rows per block at most
 constexpr int kSpmvCapBytes = 32768;  // LDS for the products of a block: NI * 256 * sizeof(T) <= 32 KiB
 
@@ -271,7 +288,8 @@ __global__ void __launch_bounds__(kBlock)
                const T* __restrict__ xg, T* __restrict__ y, int64_t n, int nblk, const DevState* __restrict__ st,
                const uint32_t* __restrict__ hseq, int64_t gstride, int ndict, const int32_t* __restrict__ blkpart,
                T* __restrict__ lpart, const T* __restrict__ yacc = nullptr, int plain_store = 0, HaloFused hf = HaloFused{},
-               HaloArgs ha = HaloArgs{}, P2pDev pd = P2pDev{}, bool nt_loads = true, bool row_gather = true) {
+               HaloArgs ha = HaloArgs{}, P2pDev pd = P2pDev{}, bool nt_loads = true, bool row_gather = true,
+               ShiftArg<T> sh = ShiftArg<T>{}) {
   // yacc != nullptr: this launch handles ONE COLUMN BLOCK of the matrix (column-blocked layout) and continues the row sums
   // an earlier launch left in yacc -- entries of a row are visited in CSR order across the launches, so y is bit-identical
   if (st && st->breakdown >= 0) return;
@@ -351,7 +369,7 @@ __global__ void __launch_bounds__(kBlock)
             if (p + u < rb) s = add_(s, mul_nc(aa[u], xx[u]));
         }
         if (plain_store) y[r0 + tid] = s;  // (an intermediate column block: the next launch reads it back)
-        else st_elem_nt(y + r0 + tid, s);
+        else st_elem_nt(y + r0 + tid, shift_apply(sh, s, x, r0 + tid));
       }
       return;
     }
@@ -374,7 +392,7 @@ __global__ void __launch_bounds__(kBlock)
       T s = yacc ? yacc[r0 + tid] : zero_of(T{});
       for (int32_t p = ra; p < rb; ++p) s = add_(s, prod[p]);
       if (plain_store) y[r0 + tid] = s;  // (an intermediate column block: the next launch reads it back)
-      else st_elem_nt(y + r0 + tid, s);
+      else st_elem_nt(y + r0 + tid, shift_apply(sh, s, x, r0 + tid));
     }
   } else {
     // one CHUNK (<= CAP entries) of a row too long for a block: the same coalesced loads, then every thread adds up
@@ -443,7 +461,7 @@ template <class T> struct CbArgs {
 template <class T, int NI, int RPT>
 __global__ void __launch_bounds__(kBlock)
     k_spmv_csr_cb(const CbArgs<T> A, const T* __restrict__ x, T* __restrict__ y, int64_t n, int ntiles,
-                  const DevState* __restrict__ st) {
+                  const DevState* __restrict__ st, ShiftArg<T> sh = ShiftArg<T>{}) {
   if (st && st->breakdown >= 0) return;
   constexpr int CAP = NI * kBlock;
   __shared__ T prod[CAP];
@@ -495,7 +513,7 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
     const int64_t r = row0 + (int64_t)q * kBlock + tid;
-    if (r < rowe) st_elem_nt(y + r, s[q]);
+    if (r < rowe) st_elem_nt(y + r, shift_apply(sh, s[q], x, r));
   }
 }
 
@@ -529,7 +547,7 @@ __global__ void __launch_bounds__(kBlock)
     k_spmv_sell(const IP* __restrict__ sliceptr, const int32_t* __restrict__ scol, const T* __restrict__ sval,
                 const int32_t* __restrict__ perm, const T* __restrict__ x, const T* __restrict__ xg, T* __restrict__ y,
                 int64_t n, int nslices, int ngroups, const DevState* __restrict__ st, const uint32_t* __restrict__ hseq,
-                int64_t gstride, int ndict) {
+                int64_t gstride, int ndict, ShiftArg<T> sh = ShiftArg<T>{}) {
   if (st && st->breakdown >= 0) return;
   if (hseq) xg += (int64_t)(*hseq & 1u) * gstride;
   __shared__ T dict[VI ? 256 : 1];
@@ -571,7 +589,10 @@ __global__ void __launch_bounds__(kBlock)
     for (int u = 0; u < UN; ++u)
       if (c[u] >= 0) s = add_(s, mul_nc(a[u], xv[u]));
   }
-  if (pos < n) st_elem_nt(y + (perm ? perm[pos] : pos), s);
+  if (pos < n) {
+    const int64_t row = perm ? perm[pos] : pos;
+    st_elem_nt(y + row, shift_apply(sh, s, x, row));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -596,7 +617,7 @@ __global__ void __launch_bounds__(kBlock)
     k_spmv_dvi(const IP* __restrict__ rowptr, const uint8_t* __restrict__ codes, const int32_t* __restrict__ ddelta,
                const T* __restrict__ dval, const T* __restrict__ x, const T* __restrict__ xg, T* __restrict__ y,
                int64_t n, int ntiles, int ndict, const DevState* __restrict__ st, const uint32_t* __restrict__ hseq,
-               int64_t gstride) {
+               int64_t gstride, ShiftArg<T> sh = ShiftArg<T>{}) {
   if (st && st->breakdown >= 0) return;
   if (hseq) xg += (int64_t)(*hseq & 1u) * gstride;
   __shared__ int32_t sd[256];
@@ -662,7 +683,7 @@ __global__ void __launch_bounds__(kBlock)
   }
 #pragma unroll
   for (int k = 0; k < RPT; ++k)
-    if (r[k] < n) st_elem_nt(y + r[k], s[k]);
+    if (r[k] < n) st_elem_nt(y + r[k], shift_apply(sh, s[k], x, r[k]));
 }
 
 // ------------------------------------------------------------------------------------------------

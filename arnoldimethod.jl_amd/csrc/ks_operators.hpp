@@ -103,7 +103,7 @@ template <class D> struct CsrOp : ks_operator {
   }
   // the CSR-row-block kernel of THIS operator's arrays on x -> y, continuing the row sums in `yacc` (column-blocked
   // layout: plain CSR, single GPU, no long rows -- make_csr only builds column blocks under those conditions)
-  void launch_csr_blocks(const D* x, D* y, const DevState* st, const D* yacc, int plain_store) {
+  void launch_csr_blocks(const D* x, D* y, const DevState* st, const D* yacc, int plain_store, ksd::ShiftArg<D> shift = ksd::ShiftArg<D>{}) {
     hipStream_t s = ctx->stream;
     auto go = [&](auto ip_tag) {
       using IP = decltype(ip_tag);
@@ -112,7 +112,8 @@ template <class D> struct CsrOp : ks_operator {
         if constexpr ((size_t)NI * kBlock * sizeof(D) <= (size_t)ksd::kSpmvCapBytes)
           ksd::k_spmv_csr<D, IP, false, NI><<<nblk, kBlock, 0, s>>>(static_cast<const IP*>(blkptr), blkrow, static_cast<const IP*>(rowptr), colidx, val, x,
                                                                     nullptr, y, n_local, nblk, st, nullptr, 0, 0, nullptr, nullptr, yacc, plain_store,
-                                                                    ksd::HaloFused{}, ksd::HaloArgs{}, ksd::P2pDev{}, env_int("KS_SPMV_CSR_NT", 1) != 0, row_gather);
+                                                                    ksd::HaloFused{}, ksd::HaloArgs{}, ksd::P2pDev{}, env_int("KS_SPMV_CSR_NT", 1) != 0, row_gather,
+                                                                    plain_store ? ksd::ShiftArg<D>{} : shift);
         else
           throw KsError{KS_ERR_INTERNAL, "CSR row blocks of " + std::to_string(NI) + " x 256 entries exceed the LDS budget of this element type"};
       };
@@ -131,10 +132,18 @@ template <class D> struct CsrOp : ks_operator {
   bool shift_on = false;
   D shift_theta{};
   double shift_sigma = 1.0;
+  ksd::ShiftArg<D> shift_arg() const {
+    ksd::ShiftArg<D> a;
+    a.on = shift_on ? 1 : 0;
+    a.theta = shift_theta;
+    a.sigma = shift_sigma;
+    return a;
+  }
   void apply_shifted(const void* xv, void* yv, double tre, double tim, double sigma, int64_t ld, const DevState* st) override {
     static const int fuse = env_int("KS_SHIFT_FUSED", 1);
-    // (both stencil kernels: the paired one on a single GPU, the one with ghost columns on a row block of several ranks)
-    const bool fused = fuse && nstencil > 0 && n_local > 0 && cblocks.empty();
+    // (every stored-matrix layout stores y = sigma (A x - theta x) itself -- the row's own x entry is one more cached load
+    // -- except rows cut into chunks, whose sums are finished by a second kernel)
+    const bool fused = fuse && n_local > 0 && nlong == 0;
     if (!fused) { ks_operator::apply_shifted(xv, yv, tre, tim, sigma, ld, st); return; }
     shift_on = true;
     if constexpr (sizeof(D) == 8) shift_theta = tre; else shift_theta = D{tre, tim};
@@ -230,7 +239,7 @@ template <class D> struct CsrOp : ks_operator {
         auto go = [&](auto ni_tag, auto rpt_tag) {
           constexpr int NI = decltype(ni_tag)::value, RPT = decltype(rpt_tag)::value;
           if constexpr ((size_t)NI * kBlock * sizeof(D) <= (size_t)ksd::kSpmvCapBytes)
-            ksd::k_spmv_csr_cb<D, NI, RPT><<<nt, kBlock, 0, s>>>(a, x, y, n_local, nt, st);
+            ksd::k_spmv_csr_cb<D, NI, RPT><<<nt, kBlock, 0, s>>>(a, x, y, n_local, nt, st, shift_arg());
           else
             throw KsError{KS_ERR_INTERNAL, "column-blocked CSR: LDS depth exceeds the budget of this element type"};
         };
@@ -248,7 +257,7 @@ template <class D> struct CsrOp : ks_operator {
         KS_HIP(hipGetLastError());
         return;
       }
-      for (size_t b = 0; b < cblocks.size(); ++b) cblocks[b]->launch_csr_blocks(x, y, st, b > 0 ? y : nullptr, b + 1 < cblocks.size() ? 1 : 0);
+      for (size_t b = 0; b < cblocks.size(); ++b) cblocks[b]->launch_csr_blocks(x, y, st, b > 0 ? y : nullptr, b + 1 < cblocks.size() ? 1 : 0, shift_arg());
       KS_HIP(hipGetLastError());
       return;
     }
@@ -301,7 +310,7 @@ template <class D> struct CsrOp : ks_operator {
           auto go = [&](auto un_tag, auto rpt_tag) {
             constexpr int UN = decltype(un_tag)::value, RPT = decltype(rpt_tag)::value;
             const int nt = (int)((n_local + kBlock * RPT - 1) / (kBlock * RPT));
-            ksd::k_spmv_dvi<D, IP, UN, RPT><<<nt, kBlock, 0, s>>>(rp, codes, ddelta, val, x, xg, y, n_local, nt, ndvi, st, hseq, ghost_stride);
+            ksd::k_spmv_dvi<D, IP, UN, RPT><<<nt, kBlock, 0, s>>>(rp, codes, ddelta, val, x, xg, y, n_local, nt, ndvi, st, hseq, ghost_stride, shift_arg());
           };
           using I = std::integral_constant<int, 0>;
           (void)sizeof(I);
@@ -328,10 +337,10 @@ template <class D> struct CsrOp : ks_operator {
             static const int plain_loads = env_int("KS_SELL_PLAIN_LOADS", 0);  // experiment: default-policy loads of the matrix streams
             if (plain_loads)
               ksd::k_spmv_sell<D, IP, VI, UN, false><<<ng, kBlock, 0, s>>>(static_cast<const IP*>(sliceptr), colidx, val, sperm, x, xg, y,
-                                                                           n_local, nslices, ng, st, hseq, ghost_stride, ndict);
+                                                                           n_local, nslices, ng, st, hseq, ghost_stride, ndict, shift_arg());
             else
               ksd::k_spmv_sell<D, IP, VI, UN, true><<<ng, kBlock, 0, s>>>(static_cast<const IP*>(sliceptr), colidx, val, sperm, x, xg, y,
-                                                                          n_local, nslices, ng, st, hseq, ghost_stride, ndict);
+                                                                          n_local, nslices, ng, st, hseq, ghost_stride, ndict, shift_arg());
           };
           auto by_un = [&](auto vi_tag) {
             if (sell_un <= 4) go(vi_tag, std::integral_constant<int, 4>{});
@@ -355,7 +364,7 @@ template <class D> struct CsrOp : ks_operator {
             h.npush = std::min(h.npush, nblk);
             ksd::k_spmv_csr<D, IP, VI, NI><<<nblk, kBlock, 0, s>>>(static_cast<const IP*>(blkptr), blkrow, static_cast<const IP*>(rowptr), colidx,
                                                                    val, x, xg, y, n_local, nblk, st, hseq, ghost_stride, ndict, blkpart, lpart,
-                                                                   nullptr, 0, h, hargs, ctx->p2p.dev, csr_nt != 0, row_gather);
+                                                                   nullptr, 0, h, hargs, ctx->p2p.dev, csr_nt != 0, row_gather, shift_arg());
           }
           else
             throw KsError{KS_ERR_INTERNAL, "CSR row blocks of " + std::to_string(NI) + " x 256 entries exceed the LDS budget of this element type"};

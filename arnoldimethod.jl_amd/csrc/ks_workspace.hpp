@@ -770,6 +770,12 @@ template <class D> bool reinit_column(ks_workspace* ws, int j, const void* v1_ho
   }
   double rnorm = col_norm<D>(ws, j);                      // :24
   if (j == 0) {                                           // :27-30
+    // a NEW factorisation starts here: Ritz values of whatever this workspace solved before say nothing about it (they
+    // would only be used as Newton shifts -- valid, but possibly ill-conditioned), and the block size starts afresh
+    ws->ritz_valid = false;
+    ws->hfull_valid = false;
+    ws->sstep_eff = ws->sstep;
+    ws->blk_clean = 0;
     col_scale<D>(ws, j, 1.0 / rnorm);
     return true;
   }

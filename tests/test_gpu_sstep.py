@@ -203,11 +203,12 @@ def test_ill_conditioned_newton_basis_is_abandoned_and_the_block_size_lowered():
 
 
 def test_every_layout_takes_the_newton_step(monkeypatch):
-    """The stencil layout fuses y = sigma (A x - theta x) into the SpMV launch, every other layout applies it with one
-    streaming pass: same H (1e-12) through both, and through the un-fused stencil form (KS_SHIFT_FUSED=0)."""
+    """Every stored-matrix layout fuses y = sigma (A x - theta x) into the SpMV launch (KS_SHIFT_FUSED=0: the product followed
+    by one streaming pass, which is also what dense and callback operators get): same H (1e-12) through all of them."""
     A = laplace3d(20, 21, 22)
     Hs = {}
-    for name, env in (("stencil-fused", {}), ("stencil-unfused", {"KS_SHIFT_FUSED": "0"}), ("csr", {"KS_SPMV_FORMAT": "csr"}), ("sell", {"KS_SPMV_FORMAT": "sell"})):
+    for name, env in (("stencil-fused", {}), ("stencil-unfused", {"KS_SHIFT_FUSED": "0"}), ("csr", {"KS_SPMV_FORMAT": "csr"}), ("sell", {"KS_SPMV_FORMAT": "sell"}),
+                      ("dvi", {"KS_SPMV_FORMAT": "dvi"}), ("vi", {"KS_SPMV_FORMAT": "vi"}), ("csr-unfused", {"KS_SPMV_FORMAT": "csr", "KS_SHIFT_FUSED": "0"})):
         for k_ in ("KS_SHIFT_FUSED", "KS_SPMV_FORMAT"):
             monkeypatch.delenv(k_, raising=False)
         for k_, v_ in env.items():
@@ -216,7 +217,7 @@ def test_every_layout_takes_the_newton_step(monkeypatch):
             if cyc == 1:
                 assert info["blocks"] == 4 and info["abandoned"] == 0
                 Hs[name] = Hb
-    assert len(Hs) == 4
+    assert len(Hs) == 7
     for name, H in Hs.items():
         assert np.abs(H - Hs["stencil-fused"]).max() <= 1e-12 * np.abs(H).max(), name
 

@@ -143,6 +143,9 @@ def main():
         cycle(True)
     ctx.synchronize()
     elapsed = time.perf_counter() - t0
+    # the reference's two invariants on the benched workspace (test/expansion.jl:29-30), as bench.py's `validation`
+    rel, orth = ws.arnoldi_relation(op, state["k"]) if nnz else (float("nan"), float("nan"))
+    hnorm = float(np.linalg.norm(np.array(ws.H)[: state["k"] + 1, : state["k"]]))
     ctx.profile_reset()
     ctx.profile_enable(True)
     for _ in range(args.steps):
@@ -164,6 +167,7 @@ def main():
         "iters_per_s": state["steps"] / elapsed, "ms_per_cycle": 1e3 * elapsed / args.steps, "iterations": state["steps"],
         "dgks_second_passes": state["reorth"], "spmv_layout": fmt, "per_class": per,
         "sstep": {"requested": args.sstep, "in_force": ws.sstep_info["s"], "block_cycles": state.get("blk_cycles", 0), "abandoned": state.get("abandoned", 0)} if args.sstep >= 2 else None,
+        "validation": {"arnoldi_rel": rel / hnorm if hnorm else None, "orth": orth, "k": state["k"], "locked": state["active"]},
         "expansion": {"moved_GBps": moved, "moved_frac": moved / PEAK, "expand_seconds": state["t_expand"], "restart_seconds": state["t_restart"]},
     }
     print(json.dumps(out), flush=True)
