@@ -133,6 +133,20 @@ def make_context(api, dist, local_rank: int, transport: str | None = None):
     # the host driver only supports dmabuf IPC: without this RCCL and the peer-to-peer regions fail with
     # `hipIpcGetMemHandle: invalid argument` (read when the HSA runtime starts, i.e. at the first device call)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if transport == "p2p" and world > 1:
+        # Ranks that SHARE a device (several processes on one GPU: how the multi-rank path is tested on a one-GPU box) must
+        # not use the exchange folded into the SpMV launch: there the workgroups of a slab's boundary planes WAIT inside the
+        # kernel for the neighbours' entries (1 700 workgroups per rank at 464^2 rows per plane), and on a shared device they
+        # hold the very CU slots the neighbours' pushing workgroups need -- a deadlock that only the wall-clock budget ends
+        # (CommTimeout; seen with >= 4 ranks from 232^3 on, never with one rank per GPU, where a rank's own pushers are
+        # dispatched first and its waiters only ever wait for ANOTHER device).  The push kernel in front of the SpMV
+        # (KS_HALO_FUSED=0) has no such coupling.  An explicit KS_HALO_FUSED wins.
+        import socket
+
+        where = [None] * world
+        dist.all_gather_object(where, (socket.gethostname(), int(local_rank)))
+        if len(set(where)) < world:
+            os.environ.setdefault("KS_HALO_FUSED", "0")
     if transport == "p2p":
         ctx = api.Context(local_rank, rank, world, p2p=True)
         if world > 1:
@@ -154,7 +168,9 @@ def ready_barrier(dist):
     FASTEST rank starts -- while a slower rank may still be assembling its row block on the host (8 processes on a 16-CPU
     quota: tens of seconds at 464^3 / 8; round 3's committed config-5 evidence died exactly there with CommTimeout).
     Call after the operator and the workspace exist on every rank and before the first verb that exchanges."""
-    if dist.get_world_size() > 1:
+    import os
+
+    if dist.get_world_size() > 1 and os.environ.get("KS_NO_READY_BARRIER") != "1":   # (the switch exists for A/B experiments only)
         dist.barrier()
 
 

@@ -62,6 +62,12 @@ def test_random_case_against_the_oracle(seed):
     # where the comparison of TRAILS is meaningful: the Ritz values are not rounding noise (rank-deficient operators) and the
     # run is not a 60-restart non-convergent one (there the trail is a chaotic function of the last bits)
     well_posed = kind != "lowrank"
+    # ... and the reference's OWN answer is a Schur pair to start with: degenerate parameter sets (mindim = nev = 1 across a
+    # conjugate pair) make it "converge" to a pair with an O(1) residual -- a function of the last bits of every rounding, which
+    # a differently-rounded but equally valid expansion (the s-step form, on by default) cannot and need not reproduce
+    if rh.nconverged:
+        res_ref0 = np.linalg.norm(A @ ref.Q - ref.Q @ ref.R)
+        well_posed = well_posed and res_ref0 <= 1e-4 * max(1.0, sp.linalg.norm(A))
     settled = rh.converged and rh.restarts <= 40
     if well_posed and settled:
         assert h.converged and h.nconverged == rh.nconverged and h.mvproducts == rh.mvproducts, tag

@@ -176,6 +176,11 @@ def test_level2_takes_the_implicit_form_only_because_the_glue_vouches():
         _check(name, A, kw, dec, hist, v1)
         prof = ctx.profile_get()
         if vouch:
-            assert prof["axpy"]["count"] == 0 and prof["fused"]["count"] == hist.mvproducts, prof
+            # (no explicit second-pass kernel; after the first restart the steps go in BLOCKS -- the s-step expansion, whose
+            # Newton shifts the library takes from the Hessenberg matrix it handed back, since this caller runs the restart
+            # itself and never tells it the Ritz values -- so there are fewer projection launches than products)
+            info = ws.sstep_info
+            assert prof["axpy"]["count"] == 0 and 0 < prof["fused"]["count"] <= hist.mvproducts, prof
+            assert info["blocks"] > 0, info
         else:
             assert prof["axpy"]["count"] == hist.mvproducts, prof

@@ -222,13 +222,18 @@ def test_every_layout_takes_the_newton_step(monkeypatch):
         assert np.abs(H - Hs["stencil-fused"]).max() <= 1e-12 * np.abs(H).max(), name
 
 
-def test_switch_off_is_the_default_path_bit_for_bit_and_callbacks_ignore_it():
+def test_switch_off_is_the_per_step_path_bit_for_bit_and_callbacks_ignore_it(monkeypatch):
     A = laplace3d(9, 10, 11)
     n = A.shape[0]
     v1 = _start(np.float64, n)
     kw = dict(nev=6, which="SR", tol=1e-10, mindim=10, maxdim=24, restarts=100)
-    base, bh = pkg.partialschur(A, v1=v1, **kw)
-    ws = pkg.ArnoldiWorkspace(n, 24, np.float64)
+    monkeypatch.setenv("KS_SSTEP", "0")          # a workspace that never knew the switch ...
+    ws0 = pkg.ArnoldiWorkspace(n, 24, np.float64)
+    monkeypatch.delenv("KS_SSTEP")
+    ws0._v1 = v1
+    base, bh = pkg.partialschur_(pkg.csr_operator(A), ws0, **kw)
+    ws = pkg.ArnoldiWorkspace(n, 24, np.float64)  # ... and one created with the default (on), switched to 5, then off
+    assert ws.sstep_info["s"] == 8
     ws.set_sstep(5)
     ws.set_sstep(0)
     ws._v1 = v1
@@ -241,6 +246,9 @@ def test_switch_off_is_the_default_path_bit_for_bit_and_callbacks_ignore_it():
     F2, h2 = pkg.partialschur_(pkg.host_operator(lambda y, x: np.copyto(y, A @ x), n, np.float64), ws2, **kw)
     assert h2.mvproducts == bh.mvproducts and ws2.sstep_info["blocks"] == 0
     assert np.abs(np.sort(F2.eigenvalues.real) - np.sort(base.eigenvalues.real)).max() <= 1e-10
+    # and the default really is the block form
+    dec, hd = pkg.partialschur(A, v1=v1, **kw)
+    assert hd.mvproducts == bh.mvproducts and dec.workspace.sstep_info["blocks"] > 0
 
 
 def test_full_size_config2_in_blocks():

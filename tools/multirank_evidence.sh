@@ -32,8 +32,12 @@ for cfg in "2 laplace 20" "3 hashed 18" "2 complex 16" "3 eager 16"; do
   KS_TRANSPORT=host leg timeout 300 python -m torch.distributed.run --nproc-per-node $1 --master-addr 127.0.0.1 --master-port $port tools/dist_gpu_check.py $2 $3
 done
 echo "# BASELINE config 5 at true per-rank size: 8 ranks x (464 x 464 x 58 rows) on device 0 vs the single-process 464^3 run"
+echo "## host-staged transport (RCCL launch structure), 8 ranks"
 port=$((port+1))
-leg timeout 900 python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 --master-port $port tools/dist_gpu_check.py shard5 464
+KS_TRANSPORT=host leg timeout 900 python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 --master-port $port tools/dist_gpu_check.py shard5 464
+echo "## peer-to-peer transport, 6 ranks (8 peer-to-peer processes on ONE device exceed what it schedules concurrently: DESIGN.md section 7)"
+port=$((port+1))
+leg timeout 900 python -m torch.distributed.run --nproc-per-node 6 --master-addr 127.0.0.1 --master-port $port tools/dist_gpu_check.py shard5 464
 echo "## set-up skew: rank 1 dawdles 12 s with KS_P2P_TIMEOUT_S=5 (the barrier between set-up and the first exchange absorbs it)"
 port=$((port+1))
 KS_P2P_TIMEOUT_S=5 KS_TEST_SETUP_SKEW_S=1:12 leg timeout 300 python -m torch.distributed.run --nproc-per-node 3 --master-addr 127.0.0.1 --master-port $port tools/dist_gpu_check.py laplace 20
