@@ -36,18 +36,17 @@ inline int cap(const BlkLaunchArgs& a, int nb, int packs_per_iter, size_t esz) {
 }
 
 template <class D, int NCW, int S> int go(int which, const BlkLaunchArgs& a) {
+  constexpr int U = ksd::blk_u<D, NCW, S>();
   const ksd::DevState* st = static_cast<const ksd::DevState*>(a.st);
   D* V = static_cast<D*>(a.V);
   D* part = static_cast<D*>(a.partial);
   if (which == 0) {
-    constexpr int U = ksd::blk_u<D, NCW, S, 0>();
     static int cache = -1;
     const int nb = cap(a, resident(a, ksd::k_bdots<D, NCW, S, U, true>, cache), 64 * U, sizeof(D));
     if (a.nt) ksd::k_bdots<D, NCW, S, U, true><<<nb, kBlock, 0, a.stream>>>(V, a.ld, a.k, part, a.pnb, st);
     else ksd::k_bdots<D, NCW, S, U, false><<<nb, kBlock, 0, a.stream>>>(V, a.ld, a.k, part, a.pnb, st);
     return nb;
   }
-  constexpr int U = ksd::blk_u<D, NCW, S, 1>();
   static int cache = -1;
   const int nb = cap(a, resident(a, ksd::k_bupdate<D, NCW, S, U, true>, cache), 64 * U, sizeof(D));
   const D* cp = static_cast<const D*>(a.coefp);

@@ -59,20 +59,12 @@ __device__ __forceinline__ void put_acc(double* f, int idx, cd v) { f[2 * idx] =
 // basis packs and 2 S U block packs; while that fits 256 registers TWO workgroups share a CU (measured on the 216^3 basis:
 // pass 1 6.2-6.5 TB/s with two resident workgroups, 3.0-5.0 with one; pass 2 5.0 against 3.8) -- what counts is the number
 // of bytes in flight per CU.
-// which = 0: k_bdots (keeps the S U packs of the new block next to the N U basis packs), 1: k_bupdate (one pack of the block at a
-// time, see its loop)
-template <class T, int NCW, int S, int U, int WHICH> constexpr int blk_regs() {
+template <class T, int NCW, int S> constexpr int blk_u() { return S <= 5 ? 2 : 1; }
+template <class T, int NCW, int S, int U> constexpr int blk_regs() {
   constexpr int D = (int)(sizeof(T) / 8);
-  return 2 * (D * NCW * S + 2 * NCW * U + 2 * S * (WHICH == 0 ? U : 1) + D * ((S * (S + 1) / 2 + 3) / 4)) + 44;
+  return 2 * (D * NCW * S + 2 * NCW * U + 2 * S * U + D * ((S * (S + 1) / 2 + 3) / 4)) + 44;
 }
-// two packs per lane whenever that still fits two workgroups per CU, or the block is small; else one pack if THAT fits two
-// workgroups; else two packs at one workgroup per CU (bytes in flight are what counts)
-template <class T, int NCW, int S, int WHICH> constexpr int blk_u() {
-  if (S <= 5 || blk_regs<T, NCW, S, 2, WHICH>() <= 256) return 2;
-  if (blk_regs<T, NCW, S, 1, WHICH>() <= 256) return 1;
-  return WHICH == 1 && sizeof(T) == 8 && S <= 8 ? 2 : 1;
-}
-template <class T, int NCW, int S, int U, int WHICH> constexpr int blk_wpe() { return blk_regs<T, NCW, S, U, WHICH>() <= 256 ? 2 : 1; }
+template <class T, int NCW, int S, int U> constexpr int blk_wpe() { return blk_regs<T, NCW, S, U>() <= 256 ? 2 : 1; }
 
 // upper-triangle index of Gram entry (i, i2), i <= i2
 __host__ __device__ __forceinline__ constexpr int gram_idx(int i, int i2) { return i2 * (i2 + 1) / 2 + i; }
@@ -133,7 +125,7 @@ __global__ void __launch_bounds__(kBlock)
 // S = V[:, 0:k), Z = V[:, k:k+S).
 // ---------------------------------------------------------------------------------------------------------------------------
 template <class T, int NCW, int S, int U, bool NT>
-__global__ void __launch_bounds__(kBlock, (blk_wpe<T, NCW, S, U, 0>()))
+__global__ void __launch_bounds__(kBlock, (blk_wpe<T, NCW, S, U>()))
     k_bdots(const T* __restrict__ V, int64_t ldv, int k, T* __restrict__ partial, int pnb, const DevState* __restrict__ st) {
   if (st && st->breakdown >= 0) return;
   using P = typename Pack<T>::type;
@@ -233,14 +225,14 @@ __global__ void __launch_bounds__(kBlock, (blk_wpe<T, NCW, S, U, 0>()))
 // column in 96 KiB bursts -- was measured here and is slower: 710 against 651 us at k = 21, s = 5; five columns leave no room
 // for bursts of that size.)
 template <class T, int NCW, int S, int U, bool NT>
-__global__ void __launch_bounds__(kBlock, (blk_wpe<T, NCW, S, U, 1>()))
+__global__ void __launch_bounds__(kBlock, (blk_wpe<T, NCW, S, U>()))
     k_bupdate(T* __restrict__ V, int64_t ldv, int k, const T* __restrict__ coefp, int ldc, const T* __restrict__ r1inv,
               T* __restrict__ partial, int pnb, const DevState* __restrict__ st, int dbg = 0) {
   if (st && st->breakdown >= 0) return;
   using P = typename Pack<T>::type;
   constexpr int R = Pack<T>::R;
   constexpr int NG = S * (S + 1) / 2, NGW = (NG + 3) / 4;
-  constexpr int NB = blk_wpe<T, NCW, S, U, 1>() == 2 ? 1 : 2;
+  constexpr int NB = blk_wpe<T, NCW, S, U>() == 2 ? 1 : 2;
   __shared__ P tbuf[NB][4][U][S][64];
   __shared__ T cf[4 * NCW][S];   // coefp rows (columns of the basis) as the waves index them: cf[c][i]
   __shared__ T ri[S][S];         // r1inv[l][i], l <= i
@@ -293,60 +285,70 @@ __global__ void __launch_bounds__(kBlock, (blk_wpe<T, NCW, S, U, 1>()))
         for (int u = 0; u < U; ++u) v[ii][u] = zero_pack(T{});
       }
     }
-    // (one pack at a time through both halves: next to the accumulators and the basis packs only S block packs are live,
-    // which is what lets s = 8 run two packs per lane at two workgroups per CU for k <= 24)
+    P t[U][S];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      P t[S];
+    for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int i = 0; i < S; ++i) t[i] = zero_pack(T{});
-      // own Z columns (l = wave mod 4): t[i] -= Z_l r1inv[l, i], i >= l
+      for (int i = 0; i < S; ++i) t[u][i] = zero_pack(T{});
+    // own Z columns (l = wave mod 4): t[i] -= Z_l r1inv[l, i], i >= l
 #pragma unroll
-      for (int l = 0; l < S; ++l) {
-        if ((l & 3) == wave) {
+    for (int l = 0; l < S; ++l) {
+      if ((l & 3) == wave) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
           const P zl = ld_pack(Z + (int64_t)l * ldv + r[u]);
 #pragma unroll
-          for (int i = l; i < S; ++i) axpy_acc(t[i], zl, neg_(ri[l][i]));
+          for (int i = l; i < S; ++i) axpy_acc(t[u][i], zl, neg_(ri[l][i]));
         }
       }
-#pragma unroll
-      for (int ii = 0; ii < NCW; ++ii) {
-        if (valid[ii]) {
-#pragma unroll
-          for (int i = 0; i < S; ++i) axpy_acc(t[i], v[ii][u], cf[wave + 4 * ii][i]);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < S; ++i) tbuf[it & (NB - 1)][wave][u][i][lane] = t[i];
     }
-    __syncthreads();
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      P q[S];
+    for (int ii = 0; ii < NCW; ++ii) {
+      if (valid[ii]) {
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+          const T g = cf[wave + 4 * ii][i];
+#pragma unroll
+          for (int u = 0; u < U; ++u) axpy_acc(t[u][i], v[ii][u], g);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int i = 0; i < S; ++i) tbuf[it & (NB - 1)][wave][u][i][lane] = t[u][i];
+    __syncthreads();
+    P q[U][S];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int i = 0; i < S; ++i) {
         const P t0 = tbuf[it & (NB - 1)][0][u][i][lane], t1 = tbuf[it & (NB - 1)][1][u][i][lane];
         const P t2 = tbuf[it & (NB - 1)][2][u][i][lane], t3 = tbuf[it & (NB - 1)][3][u][i][lane];
         P qq = sub_pack(zero_pack(T{}), addp(addp(t0, t1), addp(t2, t3)));
         if (!ok[u]) qq = zero_pack(T{});
-        q[i] = qq;
+        q[u][i] = qq;
         if ((i & 3) == wave && ok[u] && !(dbg & 1)) {  // (dbg & 1: timing probe without the write stream, & 4: cacheable stores)
           if (dbg & 4) st_pack(Z + (int64_t)i * ldv + r[u], qq);
           else st_pack_nt(Z + (int64_t)i * ldv + r[u], qq);
         }
       }
 #pragma unroll
-      for (int ii = 0; ii < NCW; ++ii)
+    for (int ii = 0; ii < NCW; ++ii)
 #pragma unroll
-        for (int i = 0; i < S; ++i) dotp(acc[ii][i], v[ii][u], q[i]);
+      for (int i = 0; i < S; ++i)
 #pragma unroll
-      for (int i2 = 0; i2 < S; ++i2)
+        for (int u = 0; u < U; ++u) dotp(acc[ii][i], v[ii][u], q[u][i]);
 #pragma unroll
-        for (int i = 0; i <= i2; ++i) {
-          const int g = gram_idx(i, i2);
-          if ((g & 3) == wave) dotp(gacc[g >> 2], q[i], q[i2]);
+    for (int i2 = 0; i2 < S; ++i2)
+#pragma unroll
+      for (int i = 0; i <= i2; ++i) {
+        const int g = gram_idx(i, i2);
+        if ((g & 3) == wave) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) dotp(gacc[g >> 2], q[u][i], q[u][i2]);
         }
-    }
+      }
     if constexpr (NB == 1) __syncthreads();  // the single exchange buffer may be overwritten from here on
   }
   constexpr int D = Dpe<T>::value;
