@@ -237,7 +237,19 @@ int ks_operator_csr_dist(ks_ctx* ctx, int64_t nrows_local, int64_t nghost, int64
       using T = decltype(tag);
       using D = typename DevT<T>::type;
       std::vector<D> vv(static_cast<const D*>(val), static_cast<const D*>(val) + nnz);
-      CsrOp<D>* op = make_csr<D>(ctx, nrows_local, nnz, rp, ci, vv);
+      // ghost slots owned by lower ranks (they precede the local columns in the global order: column blocks keep the
+      // single-GPU summation order); -1: the neighbour list is not ascending by rank with consecutive slots -> no column blocks
+      int64_t nlow = 0;
+      {
+        bool above = false, ok = true;
+        for (int p = 0; p < nneigh; ++p) {
+          KS_REQUIRE(recv_cnt[p] >= 0, KS_ERR_ARGUMENT, "negative receive count");
+          if (neigh[p] < ctx->rank) { if (above) ok = false; nlow += recv_cnt[p]; }
+          else above = true;
+        }
+        if (!ok) nlow = -1;
+      }
+      CsrOp<D>* op = make_csr<D>(ctx, nrows_local, nnz, rp, ci, vv, nlow >= 0 ? 3 : 0, nghost, std::max<int64_t>(nlow, 0));
       std::unique_ptr<CsrOp<D>> guard(op);
       op->nghost = nghost;
       op->p2p_halo = ctx->p2p.attached;

@@ -456,6 +456,7 @@ template <class T> struct CbArgs {
   const int32_t* rowptr[kCbMaxBlocks];
   const int32_t* colidx[kCbMaxBlocks];
   const T* val[kCbMaxBlocks];
+  const T* xb[kCbMaxBlocks];  // gather base of the block; null: x (distributed operators: the ghost vector for ghost-column blocks)
 };
 
 template <class T, int NI, int RPT>
@@ -487,6 +488,7 @@ __global__ void __launch_bounds__(kBlock)
     }
     const int32_t* ci = A.colidx[b] + p0;
     const T* va = A.val[b] + p0;
+    const T* __restrict__ xs = A.xb[b] ? A.xb[b] : x;
     int32_t c[NI];
     T a[NI], xv[NI];
 #pragma unroll
@@ -496,7 +498,7 @@ __global__ void __launch_bounds__(kBlock)
       a[k] = (p < cnt) ? ld_val(va + p, true) : zero_of(T{});
     }
 #pragma unroll
-    for (int k = 0; k < NI; ++k) xv[k] = x[c[k]];
+    for (int k = 0; k < NI; ++k) xv[k] = xs[c[k]];
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
       const int32_t p = tid + k * kBlock;

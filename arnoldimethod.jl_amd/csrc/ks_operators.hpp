@@ -41,6 +41,7 @@ template <class D> struct CsrOp : ks_operator {
   // column-blocked layout: the matrix split into column blocks, each a CSR-row-block sub-operator of its own; apply() runs
   // them in order, each continuing the row sums of the previous one (k_spmv_csr's yacc)
   std::vector<std::unique_ptr<CsrOp<D>>> cblocks;
+  std::vector<char> cb_from_ghost;  // per column block: gathers from the ghost vector (row block of a distributed operator)
   int cb_rpt = 0, cb_ni = 0;  // single-launch form of the column-blocked layout (k_spmv_csr_cb): 256-row sub-tiles per workgroup, LDS depth; 0: one launch per block
   int ni = 7;               // non-zeros per thread and block: a block holds at most ni * 256 entries in LDS
   bool row_gather = false;  // k_spmv_csr: one thread per row gathers x itself (banded matrices) instead of the non-zero-parallel gathers
@@ -234,6 +235,7 @@ template <class D> struct CsrOp : ks_operator {
           a.rowptr[b] = static_cast<const int32_t*>(cblocks[b]->rowptr);
           a.colidx[b] = cblocks[b]->colidx;
           a.val[b] = cblocks[b]->val;
+          a.xb[b] = (!cb_from_ghost.empty() && cb_from_ghost[b]) ? xg : nullptr;
         }
         const int nt = (int)((n_local + (int64_t)kBlock * cb_rpt - 1) / ((int64_t)kBlock * cb_rpt));
         auto go = [&](auto ni_tag, auto rpt_tag) {
@@ -507,9 +509,10 @@ inline void* upload_ptr(const std::vector<int64_t>& v, bool ptr64) {
 
 template <class D>
 CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<int64_t>& rp,
-                   const std::vector<int32_t>& ci, const std::vector<D>& vv, int cb_mode = 0) {
-  // cb_mode: 0 = column blocks not allowed (distributed operators: ghost columns), 1 = allowed (decided below),
-  //          2 = this IS a column block (plain CSR row blocks, nothing else is tried)
+                   const std::vector<int32_t>& ci, const std::vector<D>& vv, int cb_mode = 0, int64_t nghost = 0, int64_t nlow = 0) {
+  // cb_mode: 0 = column blocks not allowed, 1 = allowed (decided below), 2 = this IS a column block (plain CSR row blocks,
+  //          nothing else is tried), 3 = allowed, row block of a distributed operator: columns >= nrows are ghost slots
+  //          (nghost of them, the first nlow owned by lower ranks -- they precede the local columns in the global order)
   auto op = std::make_unique<CsrOp<D>>();
   op->ctx = ctx;
   op->n_local = nrows;
@@ -794,21 +797,28 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
   // Auto: plain CSR row blocks would be used, single GPU, x between 6 and 160 MiB, rows sorted by column and short, and
   // at least half of the entries further than n/16 from the diagonal -> blocks of ~4 MiB of x, at most 8.
   // KS_SPMV_COLBLOCKS = 0 off / k >= 2 force.
-  if (cb_mode == 1 && op->ndict == 0 && nnz > 0) {
+  if ((cb_mode == 1 || cb_mode == 3) && op->ndict == 0 && nnz > 0) {
     const int cb_env = env_int("KS_SPMV_COLBLOCKS", -1);  // (read per upload: tests switch it inside one process)
+    // Distributed operators (cb_mode 3): the referenced columns in GLOBAL order are [ghosts of lower ranks | local columns |
+    // ghosts of higher ranks]; key(c) is the position of local-extended column c in that order.  Blocks are ranges of keys
+    // that do not straddle a segment, so every block gathers either from x or from the ghost vector, and a row stored in
+    // global column order (what a row block of a sorted CSR matrix is) is summed in the same order as on one GPU.
+    const int64_t next = nrows + nghost;
+    auto key = [&](int64_t c) { return c < nrows ? nlow + c : (c - nrows < nlow ? c - nrows : c); };
+    const int64_t seg_lo[3] = {0, nlow, nlow + nrows}, seg_hi[3] = {nlow, nlow + nrows, next};
     int nbk = 0;
     if (cb_env != 0) {
       bool sorted = true;
       int64_t far = 0, maxrow = 0;
-      const int64_t fardist = std::max<int64_t>(1, nrows / 16);
+      const int64_t fardist = std::max<int64_t>(1, next / 16);
       for (int64_t r = 0; r < nrows && sorted; ++r) {
         maxrow = std::max(maxrow, rp[r + 1] - rp[r]);
         for (int64_t q = rp[r]; q < rp[r + 1]; ++q) {
-          if (q > rp[r] && ci[q] < ci[q - 1]) { sorted = false; break; }
-          far += std::llabs((int64_t)ci[q] - r) > fardist;
+          if (q > rp[r] && key(ci[q]) < key(ci[q - 1])) { sorted = false; break; }
+          far += std::llabs(key(ci[q]) - (nlow + r)) > fardist;
         }
       }
-      const double xmb = (double)nrows * sizeof(D) / (1 << 20);
+      const double xmb = (double)next * sizeof(D) / (1 << 20);
       if (sorted && maxrow <= 4 * kBlock) {
         if (cb_env >= 2) nbk = cb_env;
         // block width ~ 4 MiB of x (measured optimum at n = 1e6: 2 blocks, 2e6: 4 blocks); beyond 8 blocks the y that is
@@ -818,19 +828,54 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
     }
     if (nbk >= 2) {
       nbk = std::min(nbk, ksd::kCbMaxBlocks);
+      // block boundaries in key space: nbk blocks shared out over the non-empty segments in proportion to their width
+      // (one segment -- a single GPU --: b n / nbk, as before)
+      std::vector<int64_t> bounds{0};
+      std::vector<int> bseg;
+      {
+        int nseg = 0;
+        for (int g = 0; g < 3; ++g) nseg += seg_hi[g] > seg_lo[g];
+        nbk = std::max(nbk, nseg);
+        int cnt[3] = {0, 0, 0}, used = 0;
+        for (int g = 0; g < 3; ++g)
+          if (seg_hi[g] > seg_lo[g]) { cnt[g] = std::max(1, (int)((double)nbk * (double)(seg_hi[g] - seg_lo[g]) / (double)next)); used += cnt[g]; }
+        while (used > std::min(nbk, ksd::kCbMaxBlocks)) {  // (rounding up the narrow segments): take from the segment with the most blocks
+          int g = 0;
+          for (int h = 1; h < 3; ++h) if (cnt[h] > cnt[g]) g = h;
+          if (cnt[g] <= 1) break;
+          --cnt[g]; --used;
+        }
+        while (used < nbk) {  // give the rest to the segment with the widest blocks
+          int g = -1;
+          for (int h = 0; h < 3; ++h)
+            if (cnt[h] > 0 && (g < 0 || (double)(seg_hi[h] - seg_lo[h]) / cnt[h] > (double)(seg_hi[g] - seg_lo[g]) / cnt[g])) g = h;
+          ++cnt[g]; ++used;
+        }
+        KS_REQUIRE(used <= ksd::kCbMaxBlocks, KS_ERR_INTERNAL, "column blocks: more segments than blocks");
+        for (int g = 0; g < 3; ++g)
+          for (int b = 0; b < cnt[g]; ++b) {
+            const int64_t w = seg_hi[g] - seg_lo[g];
+            bounds.push_back(b + 1 == cnt[g] ? seg_hi[g] : seg_lo[g] + (int64_t)(b + 1) * w / cnt[g]);
+            bseg.push_back(g);
+          }
+        nbk = used;
+      }
       // single-launch form (k_spmv_csr_cb): largest segment (entries of a tile of 256 * RPT rows inside one column block)
       // for every candidate RPT
       constexpr int kRptCand[5] = {1, 2, 4, 8, 16};
       int64_t maxseg[5] = {0, 0, 0, 0, 0};
       bool small_ptrs = true;
       for (int b = 0; b < nbk; ++b) {
-        const int64_t lo = (int64_t)b * nrows / nbk, hi = (b + 1 == nbk) ? (int64_t)1 << 40 : (int64_t)(b + 1) * nrows / nbk;
+        const int64_t lo = bounds[b], hi = (b + 1 == nbk) ? (int64_t)1 << 40 : bounds[b + 1];
+        const bool from_ghost = bseg[b] != 1;
         std::vector<int64_t> rpb((size_t)nrows + 1, 0);
         std::vector<int32_t> cib;
         std::vector<D> vvb;
         for (int64_t r = 0; r < nrows; ++r) {
-          for (int64_t q = rp[r]; q < rp[r + 1]; ++q)
-            if (ci[q] >= lo && ci[q] < hi) { cib.push_back(ci[q]); vvb.push_back(vv[q]); }
+          for (int64_t q = rp[r]; q < rp[r + 1]; ++q) {
+            const int64_t kq = key(ci[q]);
+            if (kq >= lo && kq < hi) { cib.push_back(from_ghost ? (int32_t)(ci[q] - nrows) : ci[q]); vvb.push_back(vv[q]); }
+          }
           rpb[r + 1] = (int64_t)cib.size();
         }
         for (int k = 0; k < 5; ++k) {
@@ -838,15 +883,17 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
           for (int64_t r0 = 0; r0 < nrows; r0 += tr) maxseg[k] = std::max(maxseg[k], rpb[std::min(nrows, r0 + tr)] - rpb[r0]);
         }
         op->cblocks.emplace_back(make_csr<D>(ctx, nrows, (int64_t)cib.size(), rpb, cib, vvb, 2));
+        op->cb_from_ghost.push_back(from_ghost ? 1 : 0);
         small_ptrs = small_ptrs && !op->cblocks.back()->ptr64;
       }
       // Measured (tools/cb_single_ab.py, profiles/r03_column_blocks.txt): the single launch wins where the y round trips of
       // many blocks hurt (n = 1e7, 8 blocks: 858 -> 823 us) and loses a little where two to four launches were already close
       // to what bounds this product -- the rate at which an XCD's L2 hands out randomly addressed lines, 5e6 of them for
       // 1e6 rows: 46 us either way at n = 1e6, 100 vs 107 us at 2e6.  So: single launch from 5 blocks on
-      // (KS_SPMV_CB_SINGLE=0 never, KS_SPMV_CB_RPT=k forces it with k sub-tiles per workgroup).
+      // (KS_SPMV_CB_SINGLE=0 never, KS_SPMV_CB_RPT=k forces it with k sub-tiles per workgroup).  A distributed operator
+      // always takes the single launch (the per-block launches have one x; the kernel takes a base per block).
       const int rpt_force = env_int("KS_SPMV_CB_RPT", 0);
-      if (small_ptrs && env_int("KS_SPMV_CB_SINGLE", 1) && (nbk > 4 || rpt_force > 0)) {
+      if (small_ptrs && (cb_mode == 3 || (env_int("KS_SPMV_CB_SINGLE", 1) && (nbk > 4 || rpt_force > 0)))) {
         // all tiles resident at once (one round of workgroups keeps them in step on the same column block): the smallest RPT
         // whose tile count fits, among those whose segments fit the LDS depth (8 x 256 products, 16 x 256 for Float64)
         const int nimax = (int)(ksd::kSpmvCapBytes / (kBlock * sizeof(D)));  // 16 (Float64) / 8 (ComplexF64)
@@ -864,12 +911,18 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
           op->cb_ni = maxseg[best] <= 8 * kBlock ? 8 : 16;
         }
       }
-      op->layout = KS_LAYOUT_CSR_CB;
-      op->bytes_per_nnz = 4.0 + sizeof(D);
-      op->aux_bytes = 0.0;
-      for (auto& cbk : op->cblocks) op->aux_bytes += cbk->aux_bytes;
-      if (!op->cb_rpt) op->aux_bytes += (double)(nbk - 1) * 2.0 * sizeof(D) * (double)nrows;  // y written and read back between the blocks
-      return op.release();
+      if (cb_mode == 3 && !op->cb_rpt) {
+        // (no single-launch shape fits: row blocks of plain CSR below)
+        op->cblocks.clear();
+        op->cb_from_ghost.clear();
+      } else {
+        op->layout = KS_LAYOUT_CSR_CB;
+        op->bytes_per_nnz = 4.0 + sizeof(D);
+        op->aux_bytes = 0.0;
+        for (auto& cbk : op->cblocks) op->aux_bytes += cbk->aux_bytes;
+        if (!op->cb_rpt) op->aux_bytes += (double)(nbk - 1) * 2.0 * sizeof(D) * (double)nrows;  // y written and read back between the blocks
+        return op.release();
+      }
     }
   }
   // Row blocks of k_spmv_csr.  A block holds at most ni * 256 products in LDS (<= 32 KiB; KS_SPMV_NI overrides), so

@@ -686,6 +686,27 @@ def test_row_partitioned_solver_several_ranks_one_gpu(nproc, mode):
     assert r.stdout.count("-> OK") == nproc and "same: True" in r.stdout, r.stdout[-3000:]
 
 
+@pytest.mark.parametrize("nproc,m,extra", [(2, 110, {}), (4, 110, {}), (3, 20, {"KS_SPMV_COLBLOCKS": "5"}),
+                                           (2, 110, {"KS_TRANSPORT": "host"})])
+def test_distributed_operator_column_blocks(nproc, m, extra):
+    """the row block of a distributed operator gets the column-blocked layout -- local columns and the
+    ghost slots of lower / higher ranks are column blocks of their own, walked in global column order by ONE launch
+    (k_spmv_csr_cb with a gather base per block).  Every rank must report layout csr-cb and products that equal the
+    single-GPU product of the whole matrix bit for bit (tools/dist_gpu_check.py cbprod; n = 1e6 takes the layout by
+    itself -- every rank references more than 6 MiB of x --, the small case forces it)."""
+    r = _run_ranks(nproc, "cbprod", m=m, extra_env=extra)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("-> OK") == nproc and r.stdout.count("layout=csr-cb") == nproc, r.stdout[-3000:]
+
+
+def test_row_partitioned_solver_with_column_blocked_rank_operators():
+    """Whole solves over 3 ranks whose operators are column blocked (forced: the test matrix is small): same mvproducts and
+    Ritz values as the single-GPU run."""
+    r = _run_ranks(3, "hashed", extra_env={"KS_SPMV_COLBLOCKS": "4"})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("-> OK") == 3 and "same: True" in r.stdout, r.stdout[-3000:]
+
+
 @pytest.mark.parametrize("nproc,mode,transport,fused", [(2, "halo", "p2p", "1"), (4, "halo", "p2p", "1"), (3, "halohashed", "p2p", "1"),
                                                         (4, "halohashed", "p2p", "1"), (3, "halo", "p2p", "0"), (2, "halohashed", "host", "1")])
 def test_ghost_exchange_stress_with_real_ranks(nproc, mode, transport, fused):

@@ -31,6 +31,15 @@ for cfg in "2 laplace 20" "3 hashed 18" "2 complex 16" "3 eager 16"; do
   echo "## $1 ranks, mode $2, m=$3, KS_TRANSPORT=host"
   KS_TRANSPORT=host leg timeout 300 python -m torch.distributed.run --nproc-per-node $1 --master-addr 127.0.0.1 --master-port $port tools/dist_gpu_check.py $2 $3
 done
+echo "# distributed operator in the column-blocked layout (config-3-like hashed matrix, n = 110^3): per-rank product bit-identical to the single-GPU product; KS_SPMV_COLBLOCKS=0 = plain CSR row blocks beside it"
+for np_ in 2 4; do
+  port=$((port+1))
+  echo "## $np_ ranks, cbprod 110 (automatic layout)"
+  leg timeout 600 python -m torch.distributed.run --nproc-per-node $np_ --master-addr 127.0.0.1 --master-port $port tools/dist_gpu_check.py cbprod 110
+  port=$((port+1))
+  echo "## $np_ ranks, cbprod 110, KS_SPMV_COLBLOCKS=0"
+  KS_SPMV_COLBLOCKS=0 KS_EXPECT_LAYOUT=csr leg timeout 600 python -m torch.distributed.run --nproc-per-node $np_ --master-addr 127.0.0.1 --master-port $port tools/dist_gpu_check.py cbprod 110
+done
 echo "# BASELINE config 5 at true per-rank size: 8 ranks x (464 x 464 x 58 rows) on device 0 vs the single-process 464^3 run"
 echo "## host-staged transport (RCCL launch structure), 8 ranks"
 port=$((port+1))
