@@ -674,7 +674,7 @@ class ArnoldiWorkspace:
 
 def sstep_partition(dtype, k0: int, count: int, smax: int) -> list:
     """Block sizes the s-step expansion uses for `count` steps on top of `k0` existing columns (mirror of blk_partition,
-    csrc/ks_block.hpp: instantiated sizes 1-5, 8, 10 for Float64, 1-5 for ComplexF64; [] = not block-capable).  For byte
+    csrc/ks_block.hpp: instantiated sizes 1-5, 8 (up to 48 columns), 10 (up to 32) for Float64, 1-5 for ComplexF64; [] = not block-capable).  For byte
     accounting in benchmarks: a block of s steps on k columns reads 8 n (k + s) + 8 n (k + s) and writes 8 n s bytes
     (x2 for ComplexF64) next to its s operator products."""
     cplx = np.dtype(dtype).kind == "c"
@@ -683,6 +683,8 @@ def sstep_partition(dtype, k0: int, count: int, smax: int) -> list:
         if not (1 <= s <= 5 or (not cplx and s in (8, 10))) or k < 1 or k + s > 65:
             return False
         if cplx:
+            return k <= 32
+        if s == 10:
             return k <= 32
         return s <= 5 if k > 48 else True
 

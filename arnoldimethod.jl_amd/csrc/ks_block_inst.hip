@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -21,10 +22,10 @@ inline void hipcheck(hipError_t e, const char* what) {
   if (e != hipSuccess) throw std::runtime_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
 }
 // streaming kernels partition the rows into one contiguous range per workgroup: all workgroups must be co-resident
-template <class K> int resident(const BlkLaunchArgs& a, K kernel, int& cache) {
+template <class K> int resident(const BlkLaunchArgs& a, K kernel, int& cache, int threads = kBlock) {
   if (cache < 0) {
     int occ = 0;
-    hipcheck(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kBlock, 0), "occupancy query");
+    hipcheck(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, 0), "occupancy query");
     cache = std::max(1, std::min(occ, a.bpc));
   }
   return a.num_cu * cache;
@@ -35,31 +36,86 @@ inline int cap(const BlkLaunchArgs& a, int nb, int packs_per_iter, size_t esz) {
   return (int)std::min<int64_t>(nb, want);
 }
 
-template <class D, int NCW, int S> int go(int which, const BlkLaunchArgs& a) {
-  constexpr int U = ksd::blk_u<D, NCW, S>();
+// ring form of pass 1 (Float64 wide instantiations; KS_BLK_RING=0: the register form)
+inline int ring_env() { static const int v = [] { const char* e = std::getenv("KS_BLK_RING"); return e ? std::atoi(e) : 3; }(); return v; }
+template <int NCW, int S, int NW, int WB> int go_ring0(const BlkLaunchArgs& a) {
+  const int ncol = a.k + S;
+  int stages = std::min(4, (150 * 1024) / (ncol * 1024));
+  static const int st_env = [] { const char* e = std::getenv("KS_BLK_RING_STAGES"); return e ? std::atoi(e) : 0; }();
+  if (st_env >= 2) stages = std::min(st_env, (158 * 1024) / (ncol * 1024));
+  if (stages < 2) throw std::runtime_error("block kernels: ring does not fit the LDS");
+  const size_t smem = (size_t)stages * ncol * 1024;
+  auto kern = ksd::k_bdots_ring<NCW, S, NW, WB>;
+  static bool attr = false;
+  if (!attr) {
+    hipcheck(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "dynamic LDS size");
+    attr = true;
+  }
+  const int nb = cap(a, a.num_cu, 64, sizeof(double));   // one workgroup per CU
+  kern<<<nb, 64 * NW, smem, a.stream>>>(static_cast<const double*>(a.V), a.ld, a.k, stages, static_cast<double*>(a.partial), a.pnb,
+                                        static_cast<const ksd::DevState*>(a.st), a.dbg | (a.nt ? 64 : 0));
+  return nb;
+}
+
+template <int NCW, int S, int NW, int WB> int go_ring1(const BlkLaunchArgs& a) {
+  constexpr int WA = NW / WB, SP = ((S + WB - 1) / WB) * WB;
+  const int ncol = a.k + S;
+  const size_t fixed = (size_t)(WA * S + S) * 1024 + (size_t)(WA * NCW * SP + S * SP) * 8;
+  int stages = (int)std::min<size_t>(3, (158 * 1024 - fixed) / ((size_t)ncol * 1024));
+  static const int st_env = [] { const char* e = std::getenv("KS_BLK_RING_STAGES"); return e ? std::atoi(e) : 0; }();
+  if (st_env >= 2) stages = (int)std::min<size_t>(st_env, (158 * 1024 - fixed) / ((size_t)ncol * 1024));
+  if (stages < 2) throw std::runtime_error("block kernels: ring does not fit the LDS");
+  const size_t smem = (size_t)stages * ncol * 1024 + fixed;
+  auto kern = ksd::k_bupdate_ring<NCW, S, NW, WB>;
+  static bool attr = false;
+  if (!attr) {
+    hipcheck(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "dynamic LDS size");
+    attr = true;
+  }
+  const int nb = cap(a, a.num_cu, 64, sizeof(double));
+  kern<<<nb, 64 * NW, smem, a.stream>>>(static_cast<double*>(a.V), a.ld, a.k, stages, static_cast<const double*>(a.coefp), a.k,
+                                        static_cast<const double*>(a.r1inv), static_cast<double*>(a.partial), a.pnb,
+                                        static_cast<const ksd::DevState*>(a.st), a.dbg | (a.nt ? 64 : 0));
+  return nb;
+}
+
+template <class D, int NCW, int S, int NW = 4, int WB = 1> int go(int which, const BlkLaunchArgs& a) {
+  if constexpr (sizeof(D) == 8 && NW == 8) {
+    if (which == 0 && (ring_env() & 1)) return go_ring0<NCW, S, NW, WB>(a);
+    if (which == 1 && (ring_env() & 2)) return go_ring1<NCW, S, NW, WB>(a);
+  }
+  constexpr int U = ksd::blk_u<D, NCW, S, NW>();
+  constexpr int NT_ = 64 * NW;  // threads per workgroup
   const ksd::DevState* st = static_cast<const ksd::DevState*>(a.st);
   D* V = static_cast<D*>(a.V);
   D* part = static_cast<D*>(a.partial);
   if (which == 0) {
     static int cache = -1;
-    const int nb = cap(a, resident(a, ksd::k_bdots<D, NCW, S, U, true>, cache), 64 * U, sizeof(D));
-    if (a.nt) ksd::k_bdots<D, NCW, S, U, true><<<nb, kBlock, 0, a.stream>>>(V, a.ld, a.k, part, a.pnb, st);
-    else ksd::k_bdots<D, NCW, S, U, false><<<nb, kBlock, 0, a.stream>>>(V, a.ld, a.k, part, a.pnb, st);
+    const int nb = cap(a, resident(a, ksd::k_bdots<D, NCW, S, U, true, NW, WB>, cache, NT_), 64 * U, sizeof(D));
+    if (a.nt) ksd::k_bdots<D, NCW, S, U, true, NW, WB><<<nb, NT_, 0, a.stream>>>(V, a.ld, a.k, part, a.pnb, st);
+    else ksd::k_bdots<D, NCW, S, U, false, NW, WB><<<nb, NT_, 0, a.stream>>>(V, a.ld, a.k, part, a.pnb, st);
     return nb;
   }
   static int cache = -1;
-  const int nb = cap(a, resident(a, ksd::k_bupdate<D, NCW, S, U, true>, cache), 64 * U, sizeof(D));
+  const int nb = cap(a, resident(a, ksd::k_bupdate<D, NCW, S, U, true, NW, WB>, cache, NT_), 64 * U, sizeof(D));
   const D* cp = static_cast<const D*>(a.coefp);
   const D* ri = static_cast<const D*>(a.r1inv);
-  if (a.nt) ksd::k_bupdate<D, NCW, S, U, true><<<nb, kBlock, 0, a.stream>>>(V, a.ld, a.k, cp, a.k, ri, part, a.pnb, st, a.dbg);
-  else ksd::k_bupdate<D, NCW, S, U, false><<<nb, kBlock, 0, a.stream>>>(V, a.ld, a.k, cp, a.k, ri, part, a.pnb, st, a.dbg);
+  if (a.nt) ksd::k_bupdate<D, NCW, S, U, true, NW, WB><<<nb, NT_, 0, a.stream>>>(V, a.ld, a.k, cp, a.k, ri, part, a.pnb, st, a.dbg);
+  else ksd::k_bupdate<D, NCW, S, U, false, NW, WB><<<nb, NT_, 0, a.stream>>>(V, a.ld, a.k, cp, a.k, ri, part, a.pnb, st, a.dbg);
   return nb;
 }
 
 // columns per wave: ceil(k / 4), rounded up to an instantiated width
 template <class D, int S> int by_ncw(int which, const BlkLaunchArgs& a) {
   const int need = (a.k + 3) / 4;
-  if constexpr (sizeof(D) == 8) {
+  if constexpr (sizeof(D) == 8 && S == 10) {
+    // wide form: eight waves, the block columns split two ways (ks_block_kernels.hpp)
+    if (need <= 4) return go<D, 4, S, 8, 2>(which, a);
+    if (need <= 5) return go<D, 5, S, 8, 2>(which, a);
+    if (need <= 6) return go<D, 6, S, 8, 2>(which, a);
+    if (need <= 7) return go<D, 7, S, 8, 2>(which, a);
+    if (need <= 8) return go<D, 8, S, 8, 2>(which, a);
+  } else if constexpr (sizeof(D) == 8) {
     if (need <= 4) return go<D, 4, S>(which, a);
     if (need <= 5) return go<D, 5, S>(which, a);
     if (need <= 6) return go<D, 6, S>(which, a);

@@ -55,37 +55,73 @@ template <class T> struct Dpe { static constexpr int value = (int)(sizeof(T) / 8
 __device__ __forceinline__ void put_acc(double* f, int idx, double v) { f[idx] = v; }
 __device__ __forceinline__ void put_acc(double* f, int idx, cd v) { f[2 * idx] = v.x; f[2 * idx + 1] = v.y; }
 
-// packs per lane and iteration, and the occupancy the kernels are compiled for: a lane keeps NCW x S accumulators, NCW x U
-// basis packs and 2 S U block packs; while that fits 256 registers TWO workgroups share a CU (measured on the 216^3 basis:
+// packs per lane and iteration, and the occupancy the kernels are compiled for: a lane keeps NCW x SB accumulators, NCW x U
+// basis packs and 2 S U block packs; while that fits 256 registers TWO waves share a SIMD (measured on the 216^3 basis:
 // pass 1 6.2-6.5 TB/s with two resident workgroups, 3.0-5.0 with one; pass 2 5.0 against 3.8) -- what counts is the number
 // of bytes in flight per CU.
-template <class T, int NCW, int S> constexpr int blk_u() { return S <= 5 ? 2 : 1; }
+//
+// WIDE form (NW = 8 waves, WB = 2): the waves form a WA x WB grid (WA = NW / WB); wave (wa, wb) keeps the basis columns
+// c = wa (mod WA) and accumulates against the block columns i = wb (mod WB) -- NCW x ceil(S / WB) accumulators, half of
+// what the four-wave form needs at the same k.  That is what lets blocks of 10 run with two waves per SIMD (the four-wave
+// instantiations need > 256 registers there: one wave per SIMD, 2.6-3.5 TB/s).  Each basis column is loaded by WB waves
+// (the second hit is served by the CU's L1).
+template <class T, int NCW, int S, int NW = 4> constexpr int blk_u() { return S <= 5 ? 2 : (NW == 8 && NCW <= 6 ? 2 : 1); }
 template <class T, int NCW, int S, int U> constexpr int blk_regs() {
   constexpr int D = (int)(sizeof(T) / 8);
   return 2 * (D * NCW * S + 2 * NCW * U + 2 * S * U + D * ((S * (S + 1) / 2 + 3) / 4)) + 44;
 }
-template <class T, int NCW, int S, int U> constexpr int blk_wpe() { return blk_regs<T, NCW, S, U>() <= 256 ? 2 : 1; }
+// workgroups per CU the kernels are compiled for (four-wave form: 2 while the registers allow; wide form: always 1 = two
+// waves per SIMD)
+template <class T, int NCW, int S, int U, int NW = 4> constexpr int blk_wpe() { return NW == 8 ? 1 : (blk_regs<T, NCW, S, U>() <= 256 ? 2 : 1); }
+// second argument of __launch_bounds__: waves per SIMD
+template <class T, int NCW, int S, int U, int NW> constexpr int blk_wps() { return blk_wpe<T, NCW, S, U, NW>() * NW / 4; }
 
 // upper-triangle index of Gram entry (i, i2), i <= i2
 __host__ __device__ __forceinline__ constexpr int gram_idx(int i, int i2) { return i2 * (i2 + 1) / 2 + i; }
 
+template <int V> using blk_ic = std::integral_constant<int, V>;
+// f(blk_ic<wb>) for the wave's (uniform, run-time) wb with a compile-time argument: register arrays stay statically indexed
+template <int WB, class F> __device__ __forceinline__ void blk_by_wb(int wb, F&& f) {
+  if constexpr (WB == 1) f(blk_ic<0>{});
+  else if constexpr (WB == 2) { if (wb == 0) f(blk_ic<0>{}); else f(blk_ic<1>{}); }
+  else { if (wb == 0) f(blk_ic<0>{}); else if (wb == 1) f(blk_ic<1>{}); else if (wb == 2) f(blk_ic<2>{}); else f(blk_ic<3>{}); }
+}
+
+// f(blk_ic<w>) for a wave-uniform run-time w < N: ONE jump instead of a compare-and-branch per dealt item (the per-entry
+// branches of the Gram triangle cost more than its arithmetic: 55 of them at s = 10 for 7 products per wave)
+template <int N, class F> __device__ __forceinline__ void blk_by_idx(int w, F&& f) {
+  static_assert(N == 1 || N == 2 || N == 4 || N == 8, "dealt over 1, 2, 4 or 8");
+  if constexpr (N == 1) f(blk_ic<0>{});
+  else if constexpr (N == 2) { if (w == 0) f(blk_ic<0>{}); else f(blk_ic<1>{}); }
+  else if constexpr (N == 4) {
+    switch (w) { case 0: f(blk_ic<0>{}); break; case 1: f(blk_ic<1>{}); break; case 2: f(blk_ic<2>{}); break; default: f(blk_ic<3>{}); break; }
+  } else {
+    switch (w) {
+      case 0: f(blk_ic<0>{}); break; case 1: f(blk_ic<1>{}); break; case 2: f(blk_ic<2>{}); break; case 3: f(blk_ic<3>{}); break;
+      case 4: f(blk_ic<4>{}); break; case 5: f(blk_ic<5>{}); break; case 6: f(blk_ic<6>{}); break; default: f(blk_ic<7>{}); break;
+    }
+  }
+}
+
 // Write the folded accumulators of one wave.  Flattened accumulator index (in elements of T):
-//   e < NCW*S        : column c = wave + 4 (e / S), right-hand side i = e % S  -> partial entry  i*k + c
-//   e = NCW*S + gi   : Gram entry g = 4 gi + wave (if < ng)                    -> partial entry  k*S + g
-template <class T, int NCW, int S, int NGW>
+//   e < NCW*SB       : column c = wa + WA (e / SB), right-hand side i = wb + WB (e % SB)  -> partial entry  i*k + c
+//   e = NCW*SB + gi  : Gram entry g = NW gi + wave (if < ng)                              -> partial entry  k*S + g
+template <class T, int NCW, int S, int NGW, int NW, int WB>
 __device__ __forceinline__ void store_folded(const double* f, int lane, int wave, int k, T* __restrict__ partial, int pnb) {
   constexpr int D = Dpe<T>::value;
-  constexpr int NE = NCW * S + NGW;            // elements
+  constexpr int WA = NW / WB, SB = (S + WB - 1) / WB;
+  constexpr int NE = NCW * SB + NGW;           // elements
   constexpr int P = next_pow2(NE * D);         // doubles, padded
   constexpr int NG = S * (S + 1) / 2;
+  const int wa = wave % WA, wb = wave / WA;
   auto put = [&](int didx, double v) {
     const int e = didx / D, part = didx % D;
     int entry = -1;
-    if (e < NCW * S) {
-      const int c = wave + 4 * (e / S), i = e % S;
-      if (c < k) entry = i * k + c;
+    if (e < NCW * SB) {
+      const int c = wa + WA * (e / SB), i = wb + WB * (e % SB);
+      if (c < k && i < S) entry = i * k + c;
     } else if (e < NE) {
-      const int g = 4 * (e - NCW * S) + wave;
+      const int g = NW * (e - NCW * SB) + wave;
       if (g < NG) entry = k * S + g;
     }
     if (entry >= 0) reinterpret_cast<double*>(partial + (int64_t)entry * pnb + blockIdx.x)[part] = v;
@@ -124,26 +160,28 @@ __global__ void __launch_bounds__(kBlock)
 // BDOTS (pass 1):  partial[i*k + c][b] = sum_{rows of b} conj(S[r,c]) Z[r,i],   partial[k*S + g(i,i2)][b] = sum conj(Z[r,i]) Z[r,i2]
 // S = V[:, 0:k), Z = V[:, k:k+S).
 // ---------------------------------------------------------------------------------------------------------------------------
-template <class T, int NCW, int S, int U, bool NT>
-__global__ void __launch_bounds__(kBlock, (blk_wpe<T, NCW, S, U>()))
+template <class T, int NCW, int S, int U, bool NT, int NW = 4, int WB = 1>
+__global__ void __launch_bounds__(64 * NW, (blk_wps<T, NCW, S, U, NW>()))
     k_bdots(const T* __restrict__ V, int64_t ldv, int k, T* __restrict__ partial, int pnb, const DevState* __restrict__ st) {
   if (st && st->breakdown >= 0) return;
   using P = typename Pack<T>::type;
   constexpr int R = Pack<T>::R;
-  constexpr int NG = S * (S + 1) / 2, NGW = (NG + 3) / 4;
+  constexpr int WA = NW / WB, SB = (S + WB - 1) / WB;
+  constexpr int NG = S * (S + 1) / 2, NGW = (NG + NW - 1) / NW;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wa = wave % WA, wb = wave / WA;
   const T* colp[NCW];
   bool valid[NCW];
-  T acc[NCW][S];
+  T acc[NCW][SB];
   T gacc[NGW];
 #pragma unroll
   for (int ii = 0; ii < NCW; ++ii) {
-    const int c = wave + 4 * ii;
+    const int c = wa + WA * ii;
     valid[ii] = c < k;
     colp[ii] = V + (int64_t)(valid[ii] ? c : 0) * ldv;
 #pragma unroll
-    for (int i = 0; i < S; ++i) acc[ii][i] = zero_of(T{});
+    for (int i = 0; i < SB; ++i) acc[ii][i] = zero_of(T{});
   }
 #pragma unroll
   for (int g = 0; g < NGW; ++g) gacc[g] = zero_of(T{});
@@ -178,26 +216,34 @@ __global__ void __launch_bounds__(kBlock, (blk_wpe<T, NCW, S, U>()))
         z[i][u] = ld_pack(Z + (int64_t)i * ldv + r[u]);
         if (!ok[u]) z[i][u] = zero_pack(T{});
       }
+    blk_by_idx<WB>(wb, [&](auto btag) {
+      constexpr int B = decltype(btag)::value;
 #pragma unroll
-    for (int ii = 0; ii < NCW; ++ii)
+      for (int ii = 0; ii < NCW; ++ii)
 #pragma unroll
-      for (int i = 0; i < S; ++i)
+        for (int jj = 0; jj < SB; ++jj)
+          if (B + WB * jj < S) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) dotp(acc[ii][i], v[ii][u], z[i][u]);
-    // Gram entries: entry g = (i, i2), i <= i2, belongs to wave g % 4 (uniform branch, static accumulator index g / 4)
+            for (int u = 0; u < U; ++u) dotp(acc[ii][jj], v[ii][u], z[B + WB * jj][u]);
+          }
+    });
+    // Gram entries: entry g = (i, i2), i <= i2, belongs to wave g % NW (static accumulator index g / NW)
+    blk_by_idx<NW>(wave, [&](auto wtag) {
+      constexpr int W = decltype(wtag)::value;
 #pragma unroll
-    for (int i2 = 0; i2 < S; ++i2)
+      for (int i2 = 0; i2 < S; ++i2)
 #pragma unroll
-      for (int i = 0; i <= i2; ++i) {
-        const int g = gram_idx(i, i2);
-        if ((g & 3) == wave) {
+        for (int i = 0; i <= i2; ++i) {
+          const int g = gram_idx(i, i2);
+          if ((g % NW) == W) {
 #pragma unroll
-          for (int u = 0; u < U; ++u) dotp(gacc[g >> 2], z[i][u], z[i2][u]);
+            for (int u = 0; u < U; ++u) dotp(gacc[g / NW], z[i][u], z[i2][u]);
+          }
         }
-      }
+    });
   }
   constexpr int D = Dpe<T>::value;
-  constexpr int NE = NCW * S + NGW;
+  constexpr int NE = NCW * SB + NGW;
   constexpr int PD = next_pow2(NE * D);
   double f[PD];
 #pragma unroll
@@ -205,59 +251,64 @@ __global__ void __launch_bounds__(kBlock, (blk_wpe<T, NCW, S, U>()))
 #pragma unroll
   for (int ii = 0; ii < NCW; ++ii)
 #pragma unroll
-    for (int i = 0; i < S; ++i) put_acc(f, ii * S + i, acc[ii][i]);
+    for (int i = 0; i < SB; ++i) put_acc(f, ii * SB + i, acc[ii][i]);
 #pragma unroll
-  for (int g = 0; g < NGW; ++g) put_acc(f, NCW * S + g, gacc[g]);
+  for (int g = 0; g < NGW; ++g) put_acc(f, NCW * SB + g, gacc[g]);
   fold_stage<PD, 32>(f, lane);
-  store_folded<T, NCW, S, NGW>(f, lane, wave, k, partial, pnb);
+  store_folded<T, NCW, S, NGW, NW, WB>(f, lane, wave, k, partial, pnb);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // BUPDATE (pass 2):  Qt = Z R1inv - S coefp  (in place over Z);  partial[i*k + c] = conj(S[:,c]) . Qt[:,i];  Gram of Qt.
 // coefp: k x S column-major (leading dimension ldc), r1inv: S x S upper triangular column-major (leading dimension S).
-// Every wave forms the partial row sums  t_w[i] = sum_{own columns} S[r,c] coefp[c,i]  -  sum_{own l = w mod 4} Z[r,l] r1inv[l,i],
-// the four meet in LDS (double buffered, one barrier per iteration),  Qt[r,i] = -(t_0 + t_1 + t_2 + t_3)[i].
-// Wave w stores the columns i = w mod 4.
+// Wave (wa, wb) forms, for the block columns i = wb (mod WB), the partial row sums
+//   t[i] = sum_{own columns c = wa mod WA} S[r,c] coefp[c,i]  -  sum_{l = wa mod WA} Z[r,l] r1inv[l,i];
+// the WA partial sums of every block column meet in LDS,  Qt[r,i] = -(t_0 + ... + t_{WA-1})[i]  (every wave forms all of Qt:
+// its inner products need the columns of its class, its share of the Gram matrix arbitrary pairs).  Wave w stores the
+// columns i = w (mod NW).
 // ---------------------------------------------------------------------------------------------------------------------------
 // Exchange buffer: double (one barrier per iteration) while one workgroup has the CU to itself; SINGLE (a second barrier per
 // iteration) in the instantiations compiled for two resident workgroups, so that both fit the CU's 160 KiB of LDS.
 // (Staging the written block in LDS and writing 16 KiB bursts per column -- what pays in k_axpy_dots_cs, which writes ONE
 // column in 96 KiB bursts -- was measured here and is slower: 710 against 651 us at k = 21, s = 5; five columns leave no room
 // for bursts of that size.)
-template <class T, int NCW, int S, int U, bool NT>
-__global__ void __launch_bounds__(kBlock, (blk_wpe<T, NCW, S, U>()))
+template <class T, int NCW, int S, int U, bool NT, int NW = 4, int WB = 1>
+__global__ void __launch_bounds__(64 * NW, (blk_wps<T, NCW, S, U, NW>()))
     k_bupdate(T* __restrict__ V, int64_t ldv, int k, const T* __restrict__ coefp, int ldc, const T* __restrict__ r1inv,
               T* __restrict__ partial, int pnb, const DevState* __restrict__ st, int dbg = 0) {
   if (st && st->breakdown >= 0) return;
   using P = typename Pack<T>::type;
   constexpr int R = Pack<T>::R;
-  constexpr int NG = S * (S + 1) / 2, NGW = (NG + 3) / 4;
-  constexpr int NB = blk_wpe<T, NCW, S, U>() == 2 ? 1 : 2;
-  __shared__ P tbuf[NB][4][U][S][64];
-  __shared__ T cf[4 * NCW][S];   // coefp rows (columns of the basis) as the waves index them: cf[c][i]
-  __shared__ T ri[S][S];         // r1inv[l][i], l <= i
+  constexpr int WA = NW / WB, SB = (S + WB - 1) / WB, SP = SB * WB;
+  constexpr int NG = S * (S + 1) / 2, NGW = (NG + NW - 1) / NW;
+  constexpr int NB = (blk_wpe<T, NCW, S, U, NW>() == 2 || 2 * (NW / WB) * U * S * 64 * (int)sizeof(typename Pack<T>::type) > 96 * 1024) ? 1 : 2;
+  constexpr int NTHREADS = 64 * NW;
+  __shared__ P tbuf[NB][WA][U][S][64];
+  __shared__ T cf[WA * NCW][SP];  // coefp rows (columns of the basis) as the waves index them: cf[c][i]; zero beyond S
+  __shared__ T ri[S][SP];         // r1inv[l][i], l <= i; zero elsewhere
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (int e = threadIdx.x; e < 4 * NCW * S; e += kBlock) {
-    const int c = e / S, i = e % S;
-    cf[c][i] = c < k ? coefp[c + (int64_t)i * ldc] : zero_of(T{});
+  const int wa = wave % WA, wb = wave / WA;
+  for (int e = threadIdx.x; e < WA * NCW * SP; e += NTHREADS) {
+    const int c = e / SP, i = e % SP;
+    cf[c][i] = (c < k && i < S) ? coefp[c + (int64_t)i * ldc] : zero_of(T{});
   }
-  for (int e = threadIdx.x; e < S * S; e += kBlock) {
+  for (int e = threadIdx.x; e < S * SP; e += NTHREADS) {
     const int l = e % S, i = e / S;
-    ri[l][i] = l <= i ? r1inv[l + i * S] : zero_of(T{});
+    ri[l][i] = (l <= i && i < S) ? r1inv[l + i * S] : zero_of(T{});
   }
   __syncthreads();
   const T* colp[NCW];
   bool valid[NCW];
-  T acc[NCW][S];
+  T acc[NCW][SB];
   T gacc[NGW];
 #pragma unroll
   for (int ii = 0; ii < NCW; ++ii) {
-    const int c = wave + 4 * ii;
+    const int c = wa + WA * ii;
     valid[ii] = c < k;
     colp[ii] = V + (int64_t)(valid[ii] ? c : 0) * ldv;
 #pragma unroll
-    for (int i = 0; i < S; ++i) acc[ii][i] = zero_of(T{});
+    for (int i = 0; i < SB; ++i) acc[ii][i] = zero_of(T{});
   }
 #pragma unroll
   for (int g = 0; g < NGW; ++g) gacc[g] = zero_of(T{});
@@ -285,74 +336,97 @@ __global__ void __launch_bounds__(kBlock, (blk_wpe<T, NCW, S, U>()))
         for (int u = 0; u < U; ++u) v[ii][u] = zero_pack(T{});
       }
     }
-    P t[U][S];
+    P t[U][SB];
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int i = 0; i < S; ++i) t[u][i] = zero_pack(T{});
-    // own Z columns (l = wave mod 4): t[i] -= Z_l r1inv[l, i], i >= l
+      for (int i = 0; i < SB; ++i) t[u][i] = zero_pack(T{});
+    // own Z columns (l = wa mod WA): t[i] -= Z_l r1inv[l, i], i >= l (r1inv is stored with zeros below the diagonal)
+    blk_by_idx<WA>(wa, [&](auto atag) {
+      constexpr int A = decltype(atag)::value;
 #pragma unroll
-    for (int l = 0; l < S; ++l) {
-      if ((l & 3) == wave) {
+      for (int l = 0; l < S; ++l) {
+        if ((l % WA) == A) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const P zl = ld_pack(Z + (int64_t)l * ldv + r[u]);
+          for (int u = 0; u < U; ++u) {
+            const P zl = ld_pack(Z + (int64_t)l * ldv + r[u]);
 #pragma unroll
-          for (int i = l; i < S; ++i) axpy_acc(t[u][i], zl, neg_(ri[l][i]));
+            for (int jj = 0; jj < SB; ++jj)
+              if (WB * jj + WB - 1 >= l) axpy_acc(t[u][jj], zl, neg_(ri[l][wb + WB * jj]));
+          }
         }
       }
-    }
+    });
 #pragma unroll
     for (int ii = 0; ii < NCW; ++ii) {
       if (valid[ii]) {
 #pragma unroll
-        for (int i = 0; i < S; ++i) {
-          const T g = cf[wave + 4 * ii][i];
+        for (int jj = 0; jj < SB; ++jj) {
+          const T g = cf[wa + WA * ii][wb + WB * jj];
 #pragma unroll
-          for (int u = 0; u < U; ++u) axpy_acc(t[u][i], v[ii][u], g);
+          for (int u = 0; u < U; ++u) axpy_acc(t[u][jj], v[ii][u], g);
         }
       }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int i = 0; i < S; ++i) tbuf[it & (NB - 1)][wave][u][i][lane] = t[u][i];
+      for (int jj = 0; jj < SB; ++jj)
+        if (wb + WB * jj < S) tbuf[it & (NB - 1)][wa][u][wb + WB * jj][lane] = t[u][jj];
     __syncthreads();
     P q[U][S];
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int i = 0; i < S; ++i) {
-        const P t0 = tbuf[it & (NB - 1)][0][u][i][lane], t1 = tbuf[it & (NB - 1)][1][u][i][lane];
-        const P t2 = tbuf[it & (NB - 1)][2][u][i][lane], t3 = tbuf[it & (NB - 1)][3][u][i][lane];
-        P qq = sub_pack(zero_pack(T{}), addp(addp(t0, t1), addp(t2, t3)));
+        P sum = tbuf[it & (NB - 1)][0][u][i][lane];
+#pragma unroll
+        for (int a2 = 1; a2 < WA; ++a2) sum = addp(sum, tbuf[it & (NB - 1)][a2][u][i][lane]);
+        P qq = sub_pack(zero_pack(T{}), sum);
         if (!ok[u]) qq = zero_pack(T{});
         q[u][i] = qq;
-        if ((i & 3) == wave && ok[u] && !(dbg & 1)) {  // (dbg & 1: timing probe without the write stream, & 4: cacheable stores)
-          if (dbg & 4) st_pack(Z + (int64_t)i * ldv + r[u], qq);
-          else st_pack_nt(Z + (int64_t)i * ldv + r[u], qq);
-        }
       }
+    if (!(dbg & 1)) {  // (dbg & 1: timing probe without the write stream, & 4: cacheable stores)
+      blk_by_idx<NW>(wave, [&](auto wtag) {
+        constexpr int W = decltype(wtag)::value;
 #pragma unroll
-    for (int ii = 0; ii < NCW; ++ii)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int i = 0; i < S; ++i)
+          for (int i = 0; i < S; ++i)
+            if ((i % NW) == W && ok[u]) {
+              if (dbg & 4) st_pack(Z + (int64_t)i * ldv + r[u], q[u][i]);
+              else st_pack_nt(Z + (int64_t)i * ldv + r[u], q[u][i]);
+            }
+      });
+    }
+    blk_by_idx<WB>(wb, [&](auto btag) {
+      constexpr int B = decltype(btag)::value;
 #pragma unroll
-        for (int u = 0; u < U; ++u) dotp(acc[ii][i], v[ii][u], q[u][i]);
+      for (int ii = 0; ii < NCW; ++ii)
 #pragma unroll
-    for (int i2 = 0; i2 < S; ++i2)
+        for (int jj = 0; jj < SB; ++jj)
+          if (B + WB * jj < S) {
 #pragma unroll
-      for (int i = 0; i <= i2; ++i) {
-        const int g = gram_idx(i, i2);
-        if ((g & 3) == wave) {
+            for (int u = 0; u < U; ++u) dotp(acc[ii][jj], v[ii][u], q[u][B + WB * jj]);
+          }
+    });
+    blk_by_idx<NW>(wave, [&](auto wtag) {
+      constexpr int W = decltype(wtag)::value;
 #pragma unroll
-          for (int u = 0; u < U; ++u) dotp(gacc[g >> 2], q[u][i], q[u][i2]);
+      for (int i2 = 0; i2 < S; ++i2)
+#pragma unroll
+        for (int i = 0; i <= i2; ++i) {
+          const int g = gram_idx(i, i2);
+          if ((g % NW) == W) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) dotp(gacc[g / NW], q[u][i], q[u][i2]);
+          }
         }
-      }
+    });
     if constexpr (NB == 1) __syncthreads();  // the single exchange buffer may be overwritten from here on
   }
   constexpr int D = Dpe<T>::value;
-  constexpr int NE = NCW * S + NGW;
+  constexpr int NE = NCW * SB + NGW;
   constexpr int PD = next_pow2(NE * D);
   double f[PD];
 #pragma unroll
@@ -360,11 +434,308 @@ __global__ void __launch_bounds__(kBlock, (blk_wpe<T, NCW, S, U>()))
 #pragma unroll
   for (int ii = 0; ii < NCW; ++ii)
 #pragma unroll
-    for (int i = 0; i < S; ++i) put_acc(f, ii * S + i, acc[ii][i]);
+    for (int i = 0; i < SB; ++i) put_acc(f, ii * SB + i, acc[ii][i]);
 #pragma unroll
-  for (int g = 0; g < NGW; ++g) put_acc(f, NCW * S + g, gacc[g]);
+  for (int g = 0; g < NGW; ++g) put_acc(f, NCW * SB + g, gacc[g]);
   fold_stage<PD, 32>(f, lane);
-  store_folded<T, NCW, S, NGW>(f, lane, wave, k, partial, pnb);
+  store_folded<T, NCW, S, NGW, NW, WB>(f, lane, wave, k, partial, pnb);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// RING forms (Float64, wide workgroups).  What bounds the register forms above once a wave keeps few columns: every wave
+// loads every block column itself, and the L2 serves ~12 TB/s of requests whoever asks -- at s = 10 with eight waves that
+// is four requests per byte of the basis (measured: 3.0 TB/s, unchanged by more loads in flight or by the load policy).
+// Here every 16-byte pack is fetched from memory ONCE per workgroup, by an asynchronous global -> LDS copy
+// (global_load_lds_dwordx4: no staging registers), into a ring of STAGES tiles of 64 packs x (k + s) columns; the waves
+// read their operands from the tile (ds_read_b128) while the copies of the next tiles are in flight.  One workgroup
+// barrier per tile; the copies are counted with s_waitcnt vmcnt(N) (the compiler does not see them: they are issued from
+// inline assembly, and nothing else in the loop uses the vector-memory counter).
+// ---------------------------------------------------------------------------------------------------------------------------
+// one 1-KiB copy: lane l's 16 bytes at gsrc -> LDS byte address lds_dst + 16 l (M0 carries the wave-uniform base)
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds16_nt(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// s_waitcnt vmcnt(n) with a run-time (wave-uniform) n <= 31, then the workgroup barrier
+__device__ __forceinline__ void wait_vm_barrier(int n) {
+#define KS_VMW(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier" ::: "memory"); break;
+  switch (n) {
+    KS_VMW(0) KS_VMW(1) KS_VMW(2) KS_VMW(3) KS_VMW(4) KS_VMW(5) KS_VMW(6) KS_VMW(7) KS_VMW(8) KS_VMW(9) KS_VMW(10) KS_VMW(11)
+    KS_VMW(12) KS_VMW(13) KS_VMW(14) KS_VMW(15) KS_VMW(16) KS_VMW(17) KS_VMW(18) KS_VMW(19) KS_VMW(20) KS_VMW(21) KS_VMW(22)
+    KS_VMW(23) KS_VMW(24) KS_VMW(25) KS_VMW(26) KS_VMW(27) KS_VMW(28) KS_VMW(29) KS_VMW(30) KS_VMW(31)
+    default: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
+  }
+#undef KS_VMW
+}
+
+// BDOTS, ring form: same result layout as k_bdots<double, NCW, S, ., ., NW, WB>.  Dynamic LDS: stages * (k + S) KiB.
+template <int NCW, int S, int NW, int WB>
+__global__ void __launch_bounds__(64 * NW, NW / 4)
+    k_bdots_ring(const double* __restrict__ V, int64_t ldv, int k, int stages, double* __restrict__ partial, int pnb,
+                 const DevState* __restrict__ st, int dbg = 0) {
+  if (st && st->breakdown >= 0) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ring_raw[];
+  constexpr int WA = NW / WB, SB = (S + WB - 1) / WB;
+  constexpr int NG = S * (S + 1) / 2, NGW = (NG + NW - 1) / NW;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wa = wave % WA, wb = wave / WA;
+  const int ncol = k + S;
+  const double2* ring = reinterpret_cast<const double2*>(ring_raw);
+  const uint32_t ring_lds = (uint32_t)(uintptr_t)ring_raw;   // LDS byte address (low half of the flat address)
+  double acc[NCW][SB];
+  double gacc[NGW];
+#pragma unroll
+  for (int ii = 0; ii < NCW; ++ii)
+#pragma unroll
+    for (int i = 0; i < SB; ++i) acc[ii][i] = 0.0;
+#pragma unroll
+  for (int g = 0; g < NGW; ++g) gacc[g] = 0.0;
+  int64_t pb, pe;
+  block_range(ldv / 2, blockIdx.x, gridDim.x, pb, pe);
+  const int niter = (int)((pe - pb + 63) / 64);
+  // copies of this wave per tile: columns wave, wave + NW, ... < ncol
+  const int nl = (ncol - wave + NW - 1) / NW;
+  auto issue = [&](int it) {  // tile `it` -> ring slot it % stages (rows clamped to the workgroup's range: the tail is masked below)
+    int64_t q = pb + (int64_t)it * 64 + lane;
+    if (q >= pe) q = pe - 1;
+    const double* src = V + q * 2;
+    const uint32_t slot = ring_lds + (uint32_t)((it % stages) * ncol) * 1024u;
+    if (dbg & 32) return;  // (probe: no copies)
+    if (dbg & 64) { for (int j = wave; j < ncol; j += NW) glds16_nt(src + (int64_t)j * ldv, slot + (uint32_t)j * 1024u); }
+    else { for (int j = wave; j < ncol; j += NW) glds16(src + (int64_t)j * ldv, slot + (uint32_t)j * 1024u); }
+  };
+  for (int it = 0; it < stages - 1; ++it) issue(it);
+  for (int it = 0; it < niter; ++it) {
+    // tile `it` has landed when at most (stages - 2) later tiles of this wave are outstanding; behind the barrier everybody's
+    // part of it is there and everybody has finished tile it - 1, whose slot the next copies overwrite
+    wait_vm_barrier((stages - 2) * nl);
+    issue(it + stages - 1);
+    if (dbg & 16) continue;  // (probe: copies only)
+    const double2* tile = ring + (size_t)((it % stages) * ncol) * 64;
+    const bool ok = pb + (int64_t)it * 64 + lane < pe;
+    double2 v[NCW];
+#pragma unroll
+    for (int ii = 0; ii < NCW; ++ii) {
+      const int c = wa + WA * ii;
+      v[ii] = c < k ? tile[c * 64 + lane] : make_double2(0.0, 0.0);
+    }
+    double2 z[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+      z[i] = tile[(k + i) * 64 + lane];
+      if (!ok) z[i] = make_double2(0.0, 0.0);
+    }
+    blk_by_idx<WB>(wb, [&](auto btag) {
+      constexpr int B = decltype(btag)::value;
+#pragma unroll
+      for (int ii = 0; ii < NCW; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < SB; ++jj)
+          if (B + WB * jj < S) dotp(acc[ii][jj], v[ii], z[B + WB * jj]);
+    });
+    blk_by_idx<NW>(wave, [&](auto wtag) {
+      constexpr int W = decltype(wtag)::value;
+#pragma unroll
+      for (int i2 = 0; i2 < S; ++i2)
+#pragma unroll
+        for (int i = 0; i <= i2; ++i) {
+          const int g = gram_idx(i, i2);
+          if ((g % NW) == W) dotp(gacc[g / NW], z[i], z[i2]);
+        }
+    });
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (copies of tiles past the end are still in flight)
+  constexpr int NE = NCW * SB + NGW;
+  constexpr int PD = next_pow2(NE);
+  double f[PD];
+#pragma unroll
+  for (int e = 0; e < PD; ++e) f[e] = 0.0;
+#pragma unroll
+  for (int ii = 0; ii < NCW; ++ii)
+#pragma unroll
+    for (int i = 0; i < SB; ++i) f[ii * SB + i] = acc[ii][i];
+#pragma unroll
+  for (int g = 0; g < NGW; ++g) f[NCW * SB + g] = gacc[g];
+  fold_stage<PD, 32>(f, lane);
+  store_folded<double, NCW, S, NGW, NW, WB>(f, lane, wave, k, partial, pnb);
+}
+
+// 16-byte streaming store from inline assembly (counted by hand on the vector-memory counter, like the copies)
+typedef double blk_d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gst16_nt(double* p, double2 v) {
+  blk_d2v w;
+  w.x = v.x;
+  w.y = v.y;
+  asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(w) : "memory");
+}
+__device__ __forceinline__ void lgkm_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// BUPDATE, ring form: same result as k_bupdate<double, NCW, S, ., ., NW, WB>.  Per tile of 64 packs:
+//   A  tile landed (counted wait + barrier); copies of tile it + stages - 1 issued
+//      partial row sums t over the wave's columns (operands from the tile) -> tbuf            barrier B
+//   1  every block column is finished by ONE wave: Qt_i = -(sum of its WA partials), stored to memory and to qbuf
+//                                                                                                barrier C
+//   2  inner products of the wave's columns with the block columns of its class, its share of the Gram triangle (qbuf)
+// Dynamic LDS: [ring: stages x (k + S) KiB | tbuf: WA x S KiB | qbuf: S KiB | coefficients].
+template <int NCW, int S, int NW, int WB>
+__global__ void __launch_bounds__(64 * NW, NW / 4)
+    k_bupdate_ring(double* __restrict__ V, int64_t ldv, int k, int stages, const double* __restrict__ coefp, int ldc,
+                   const double* __restrict__ r1inv, double* __restrict__ partial, int pnb, const DevState* __restrict__ st, int dbg) {
+  if (st && st->breakdown >= 0) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ring_raw[];
+  constexpr int WA = NW / WB, SB = (S + WB - 1) / WB, SP = SB * WB;
+  constexpr int NG = S * (S + 1) / 2, NGW = (NG + NW - 1) / NW;
+  constexpr int NTHREADS = 64 * NW;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wa = wave % WA, wb = wave / WA;
+  const int ncol = k + S;
+  const uint32_t ring_lds = (uint32_t)(uintptr_t)ring_raw;
+  double2* ring = reinterpret_cast<double2*>(ring_raw);
+  double2* tbuf = ring + (size_t)stages * ncol * 64;          // [WA][S][64]
+  double2* qbuf = tbuf + (size_t)WA * S * 64;                 // [S][64]
+  double* cf = reinterpret_cast<double*>(qbuf + (size_t)S * 64);  // [WA * NCW][SP]
+  double* ri = cf + WA * NCW * SP;                            // [S][SP]
+  for (int e = threadIdx.x; e < WA * NCW * SP; e += NTHREADS) {
+    const int c = e / SP, i = e % SP;
+    cf[e] = (c < k && i < S) ? coefp[c + (int64_t)i * ldc] : 0.0;
+  }
+  for (int e = threadIdx.x; e < S * SP; e += NTHREADS) {
+    const int l = e / SP, i = e % SP;
+    ri[e] = (l <= i && i < S) ? r1inv[l + i * S] : 0.0;
+  }
+  lgkm_barrier();
+  double acc[NCW][SB];
+  double gacc[NGW];
+#pragma unroll
+  for (int ii = 0; ii < NCW; ++ii)
+#pragma unroll
+    for (int i = 0; i < SB; ++i) acc[ii][i] = 0.0;
+#pragma unroll
+  for (int g = 0; g < NGW; ++g) gacc[g] = 0.0;
+  double* Z = V + (int64_t)k * ldv;
+  int64_t pb, pe;
+  block_range(ldv / 2, blockIdx.x, gridDim.x, pb, pe);
+  const int niter = (int)((pe - pb + 63) / 64);
+  const int nl = (ncol - wave + NW - 1) / NW;                 // copies of this wave per tile
+  // block columns this wave finishes (phase 1): i = wb + WB jj with jj % WA == wa
+  int nst = 0;
+#pragma unroll
+  for (int jj = 0; jj < SB; ++jj)
+    if ((jj % WA) == wa && wb + WB * jj < S) ++nst;
+  if (dbg & 1) nst = 0;
+  auto issue = [&](int it) {
+    int64_t q = pb + (int64_t)it * 64 + lane;
+    if (q >= pe) q = pe - 1;
+    const double* src = V + q * 2;
+    const uint32_t slot = ring_lds + (uint32_t)((it % stages) * ncol) * 1024u;
+    if (dbg & 64) { for (int j = wave; j < ncol; j += NW) glds16_nt(src + (int64_t)j * ldv, slot + (uint32_t)j * 1024u); }
+    else { for (int j = wave; j < ncol; j += NW) glds16(src + (int64_t)j * ldv, slot + (uint32_t)j * 1024u); }
+  };
+  for (int it = 0; it < stages - 1; ++it) issue(it);
+  for (int it = 0; it < niter; ++it) {
+    // issue order per tile: nl copies, then nst stores; tile `it` was copied (stages - 1) tiles ago, behind it are the
+    // copies of stages - 2 tiles and the stores of the last min(it, stages - 1) tiles
+    wait_vm_barrier((stages - 2) * nl + (it < stages - 1 ? it : stages - 1) * nst);
+    issue(it + stages - 1);
+    const double2* tile = ring + (size_t)((it % stages) * ncol) * 64;
+    const int64_t qi = pb + (int64_t)it * 64 + lane;
+    const bool ok = qi < pe;
+    double2 v[NCW];
+#pragma unroll
+    for (int ii = 0; ii < NCW; ++ii) {
+      const int c = wa + WA * ii;
+      v[ii] = c < k ? tile[c * 64 + lane] : make_double2(0.0, 0.0);
+    }
+    double2 t[SB];
+#pragma unroll
+    for (int jj = 0; jj < SB; ++jj) t[jj] = make_double2(0.0, 0.0);
+    blk_by_idx<WA>(wa, [&](auto atag) {
+      constexpr int A = decltype(atag)::value;
+#pragma unroll
+      for (int l = 0; l < S; ++l) {
+        if ((l % WA) == A) {
+          const double2 zl = tile[(k + l) * 64 + lane];
+#pragma unroll
+          for (int jj = 0; jj < SB; ++jj)
+            if (WB * jj + WB - 1 >= l) axpy_acc(t[jj], zl, -ri[l * SP + wb + WB * jj]);
+        }
+      }
+    });
+#pragma unroll
+    for (int ii = 0; ii < NCW; ++ii) {
+      if (wa + WA * ii < k) {
+#pragma unroll
+        for (int jj = 0; jj < SB; ++jj) axpy_acc(t[jj], v[ii], cf[(wa + WA * ii) * SP + wb + WB * jj]);
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < SB; ++jj)
+      if (wb + WB * jj < S) tbuf[(wa * S + wb + WB * jj) * 64 + lane] = t[jj];
+    lgkm_barrier();
+    // phase 1
+    blk_by_idx<WA>(wa, [&](auto atag) {
+      constexpr int A = decltype(atag)::value;
+#pragma unroll
+      for (int jj = 0; jj < SB; ++jj)
+        if ((jj % WA) == A) {
+          const int i = wb + WB * jj;
+          if (i < S) {
+            double2 sum = tbuf[(0 * S + i) * 64 + lane];
+#pragma unroll
+            for (int a2 = 1; a2 < WA; ++a2) sum = addp(sum, tbuf[(a2 * S + i) * 64 + lane]);
+            double2 qq = make_double2(-sum.x, -sum.y);
+            if (!ok) qq = make_double2(0.0, 0.0);
+            qbuf[i * 64 + lane] = qq;
+            if (ok && !(dbg & 1)) gst16_nt(Z + (int64_t)i * ldv + qi * 2, qq);
+          }
+        }
+    });
+    lgkm_barrier();
+    // phase 2
+    double2 q[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) q[i] = qbuf[i * 64 + lane];
+    blk_by_idx<WB>(wb, [&](auto btag) {
+      constexpr int B = decltype(btag)::value;
+#pragma unroll
+      for (int ii = 0; ii < NCW; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < SB; ++jj)
+          if (B + WB * jj < S) dotp(acc[ii][jj], v[ii], q[B + WB * jj]);
+    });
+    blk_by_idx<NW>(wave, [&](auto wtag) {
+      constexpr int W = decltype(wtag)::value;
+#pragma unroll
+      for (int i2 = 0; i2 < S; ++i2)
+#pragma unroll
+        for (int i = 0; i <= i2; ++i) {
+          const int g = gram_idx(i, i2);
+          if ((g % NW) == W) dotp(gacc[g / NW], q[i], q[i2]);
+        }
+    });
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  constexpr int NE = NCW * SB + NGW;
+  constexpr int PD = next_pow2(NE);
+  double f[PD];
+#pragma unroll
+  for (int e = 0; e < PD; ++e) f[e] = 0.0;
+#pragma unroll
+  for (int ii = 0; ii < NCW; ++ii)
+#pragma unroll
+    for (int i = 0; i < SB; ++i) f[ii * SB + i] = acc[ii][i];
+#pragma unroll
+  for (int g = 0; g < NGW; ++g) f[NCW * SB + g] = gacc[g];
+  fold_stage<PD, 32>(f, lane);
+  store_folded<double, NCW, S, NGW, NW, WB>(f, lane, wave, k, partial, pnb);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

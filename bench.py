@@ -357,6 +357,7 @@ def main():
                     state["blk_blocks"] = state.get("blk_blocks", 0) + len(blk)
                     state["blk_pivot_min"] = min(state.get("blk_pivot_min", 1.0), info["pivot_stage1"], info["pivot_stage2"])
                     state["blk_gram_dev"] = max(state.get("blk_gram_dev", 0.0), info["gram_dev"])
+                    state["blk_s_now"], state["blk_abandoned"] = info["s"], info["abandoned"]
                 if blk:
                     # s-step cycle: per block of s steps on kk columns  s products (the Newton shift is fused into the stencil
                     # kernel; other layouts pay a 24 n-byte pass per product) + k_bdots 8 n (kk + s) + k_bupdate 8 n (kk + 2 s)
@@ -624,7 +625,9 @@ def make_line(args, pkg, passes, order, world, rank, force_dist, wl, with_cpu_ba
         # s-step (block) expansion: steps per block; with it the basis is read twice per BLOCK (not per step)
         "sstep": {"s": sst, "block_cycles": state.get("blk_cycles", 0), "blocks": state.get("blk_blocks", 0),
                   "cycles_not_in_blocks": state.get("blk_irregular", 0), "smallest_pivot_ratio": state.get("blk_pivot_min"),
-                  "largest_gram_deviation": state.get("blk_gram_dev")} if sst else None,
+                  "largest_gram_deviation": state.get("blk_gram_dev"),
+                  # block size in force at the end (the library halves it after an abandoned block) and abandoned blocks
+                  "s_in_force": state.get("blk_s_now"), "abandoned_blocks": state.get("blk_abandoned")} if sst else None,
         "spmv_layout": {"csr-dvi": "csr-dvi: %d-entry (column-row, value) dictionary, 1 B per non-zero (bit-identical products)",
                         "csr-vi": "csr-vi: %d-entry value dictionary, 4 B per non-zero (bit-identical products)",
                         "stencil": "stencil-mask: %d-slot (column-row, value) dictionary in the kernel arguments, 1 bit per slot and row (bit-identical products)",

@@ -22,12 +22,15 @@ def main():
     n = m ** 3
     ws = ks.ArnoldiWorkspace(n, maxdim, np.float64)
     L = _lib.load()
-    shapes = [(21, 5), (26, 5), (31, 5), (36, 5), (21, 10), (31, 10), (25, 8), (33, 8), (21, 4), (37, 4), (21, 2), (39, 2)]
+    shapes = [(21, 5), (26, 5), (31, 5), (36, 5), (21, 10), (31, 10), (21, 8), (29, 8), (25, 8), (33, 8), (21, 4), (37, 4), (21, 2), (39, 2)]
     shapes = [(k, s) for k, s in shapes if k + s <= maxdim + 1]
+    if os.environ.get("BLK_S"):
+        shapes = [(k, s) for k, s in shapes if s in [int(x) for x in os.environ["BLK_S"].split(",")]]
     dbgs = [int(x) for x in os.environ.get("BLK_DBGS", "0,1,4").split(",")]
     for k, s in shapes:
         for which, name in ((0, "bdots"), (1, "bupdate")):
-            for dbg in (dbgs if which == 1 else [0]):
+            dbgs0 = [int(x) for x in os.environ.get("BLK_DBGS0", "0").split(",")]
+            for dbg in (dbgs if which == 1 else dbgs0):
                 ms, grid = C.c_double(), C.c_int()
                 _lib.check(L.ks_debug_blk_time(ws._h, k, s, which, 10, dbg, C.byref(ms), C.byref(grid)))
                 b = 8.0 * n * (k + s) if which == 0 else 8.0 * n * (k + (1 if dbg & 1 else 2) * s)
