@@ -635,6 +635,14 @@ class ArnoldiWorkspace:
         check(_lib.load().ks_workspace_sstep_info(self._h, C.byref(s), C.byref(b), C.byref(a), d))
         return dict(s=s.value, blocks=b.value, abandoned=a.value, pivot_stage1=d[0], pivot_stage2=d[1], gram_dev=d[2])
 
+    @property
+    def relation_info(self) -> dict:
+        """Restarts that cut through a 2 x 2 block of the real Schur form (ks_workspace_relation_info): count and the largest
+        dropped entry relative to ||H||_F.  After the first one the s-step expansion stays off for the run."""
+        b, w = C.c_int(), C.c_double()
+        check(_lib.load().ks_workspace_relation_info(self._h, C.byref(b), C.byref(w)))
+        return dict(breaks=b.value, worst_leak=w.value)
+
     def assert_arnoldi(self, k: int):
         """The caller vouches that columns 0..k are orthonormal and satisfy, with the H now in `self.H`, the Arnoldi
         relation of k steps (a restart the host language ran itself): re-enables the implicit second pass."""

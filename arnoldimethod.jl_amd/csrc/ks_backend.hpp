@@ -235,7 +235,14 @@ template <class T> struct HipBackend : ks::Backend<T> {
   }
 
   // Ritz values of the restart that just happened (Newton shifts of the next expansion's blocks)
-  void note_ritz(const cplx* lams, int m) override {
+  void note_ritz(const cplx* lams, int m, double leak = 0.0, double fro = 0.0) override {
+    if (leak > ws->relation_tol * fro) {
+      // the restart cut through a 2 x 2 block (RestartResult::leak): the relation of the kept columns is violated by `leak`.
+      // Blocks off for the rest of this run (a new start vector re-arms them); counted for ks_workspace_relation_info.
+      ws->relation_breaks++;
+      ws->relation_leak = std::max(ws->relation_leak, fro > 0.0 ? leak / fro : leak);
+      ws->sstep_eff = 0;
+    }
     if (ws->sstep < 2) return;
     ws->ritz.assign(lams, lams + m);
     ws->ritz_valid = true;

@@ -464,12 +464,12 @@ __device__ __forceinline__ void glds16_nt(const void* gsrc, uint32_t lds_dst) {
 }
 // s_waitcnt vmcnt(n) with a run-time (wave-uniform) n <= 31, then the workgroup barrier
 __device__ __forceinline__ void wait_vm_barrier(int n) {
-#define KS_VMW(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier" ::: "memory"); break;
+#define KS_VMW(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
   switch (n) {
     KS_VMW(0) KS_VMW(1) KS_VMW(2) KS_VMW(3) KS_VMW(4) KS_VMW(5) KS_VMW(6) KS_VMW(7) KS_VMW(8) KS_VMW(9) KS_VMW(10) KS_VMW(11)
     KS_VMW(12) KS_VMW(13) KS_VMW(14) KS_VMW(15) KS_VMW(16) KS_VMW(17) KS_VMW(18) KS_VMW(19) KS_VMW(20) KS_VMW(21) KS_VMW(22)
     KS_VMW(23) KS_VMW(24) KS_VMW(25) KS_VMW(26) KS_VMW(27) KS_VMW(28) KS_VMW(29) KS_VMW(30) KS_VMW(31)
-    default: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
   }
 #undef KS_VMW
 }
@@ -639,10 +639,39 @@ __global__ void __launch_bounds__(64 * NW, NW / 4)
     if (dbg & 64) { for (int j = wave; j < ncol; j += NW) glds16_nt(src + (int64_t)j * ldv, slot + (uint32_t)j * 1024u); }
     else { for (int j = wave; j < ncol; j += NW) glds16(src + (int64_t)j * ldv, slot + (uint32_t)j * 1024u); }
   };
+  // inner products of tile `it - 1` (its basis packs are still in registers, its block columns in qbuf) run in the same
+  // barrier interval as the partial row sums of tile `it`: two independent instruction streams per wave, two barriers per tile
+  auto phase2 = [&](const double2* vp) {
+    double2 q[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) q[i] = qbuf[i * 64 + lane];
+    blk_by_idx<WB>(wb, [&](auto btag) {
+      constexpr int B = decltype(btag)::value;
+#pragma unroll
+      for (int ii = 0; ii < NCW; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < SB; ++jj)
+          if (B + WB * jj < S) dotp(acc[ii][jj], vp[ii], q[B + WB * jj]);
+    });
+    blk_by_idx<NW>(wave, [&](auto wtag) {
+      constexpr int W = decltype(wtag)::value;
+#pragma unroll
+      for (int i2 = 0; i2 < S; ++i2)
+#pragma unroll
+        for (int i = 0; i <= i2; ++i) {
+          const int g = gram_idx(i, i2);
+          if ((g % NW) == W) dotp(gacc[g / NW], q[i], q[i2]);
+        }
+    });
+  };
+  double2 vprev[NCW];
+#pragma unroll
+  for (int ii = 0; ii < NCW; ++ii) vprev[ii] = make_double2(0.0, 0.0);
   for (int it = 0; it < stages - 1; ++it) issue(it);
   for (int it = 0; it < niter; ++it) {
     // issue order per tile: nl copies, then nst stores; tile `it` was copied (stages - 1) tiles ago, behind it are the
-    // copies of stages - 2 tiles and the stores of the last min(it, stages - 1) tiles
+    // copies of stages - 2 tiles and the stores of the last min(it, stages - 1) tiles.  Behind this barrier: tile `it` is in
+    // LDS, qbuf holds the block columns of tile it - 1, tbuf and the ring slot of tile it - 1 are free.
     wait_vm_barrier((stages - 2) * nl + (it < stages - 1 ? it : stages - 1) * nst);
     issue(it + stages - 1);
     const double2* tile = ring + (size_t)((it % stages) * ncol) * 64;
@@ -679,8 +708,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4)
 #pragma unroll
     for (int jj = 0; jj < SB; ++jj)
       if (wb + WB * jj < S) tbuf[(wa * S + wb + WB * jj) * 64 + lane] = t[jj];
+    if (it > 0) phase2(vprev);
     lgkm_barrier();
-    // phase 1
+    // phase 1: every block column is finished by one wave
     blk_by_idx<WA>(wa, [&](auto atag) {
       constexpr int A = decltype(atag)::value;
 #pragma unroll
@@ -698,30 +728,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4)
           }
         }
     });
-    lgkm_barrier();
-    // phase 2
-    double2 q[S];
 #pragma unroll
-    for (int i = 0; i < S; ++i) q[i] = qbuf[i * 64 + lane];
-    blk_by_idx<WB>(wb, [&](auto btag) {
-      constexpr int B = decltype(btag)::value;
-#pragma unroll
-      for (int ii = 0; ii < NCW; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < SB; ++jj)
-          if (B + WB * jj < S) dotp(acc[ii][jj], v[ii], q[B + WB * jj]);
-    });
-    blk_by_idx<NW>(wave, [&](auto wtag) {
-      constexpr int W = decltype(wtag)::value;
-#pragma unroll
-      for (int i2 = 0; i2 < S; ++i2)
-#pragma unroll
-        for (int i = 0; i <= i2; ++i) {
-          const int g = gram_idx(i, i2);
-          if ((g % NW) == W) dotp(gacc[g / NW], q[i], q[i2]);
-        }
-    });
+    for (int ii = 0; ii < NCW; ++ii) vprev[ii] = v[ii];
   }
+  lgkm_barrier();
+  if (niter > 0) phase2(vprev);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   constexpr int NE = NCW * SB + NGW;
   constexpr int PD = next_pow2(NE);

@@ -57,7 +57,7 @@ template <class T> struct Backend {
   }
   // the Ritz values (all maxdim eigenvalues of the active Hessenberg matrix) of the restart in progress: a backend with an
   // s-step expansion takes the Newton shifts of its next blocks from them
-  virtual void note_ritz(const cplx* lams, int m) { (void)lams; (void)m; }
+  virtual void note_ritz(const cplx* lams, int m, double leak = 0.0, double fro = 0.0) { (void)lams; (void)m; (void)leak; (void)fro; }
 };
 
 struct Params {
@@ -93,6 +93,13 @@ template <class T> struct RestartScratch {
 
 struct RestartResult {
   int k, nlock, purge, effective_nev;
+  // largest |entry| of the sorted Schur form BELOW the cut (rows k..maxdim-1 of the kept columns) and ||H||_F.  A Schur form
+  // is zero there; the one exception is a 2 x 2 block of a real Schur form that the selection splits (a complex pair whose
+  // members do not sit next to each other in the target's order: imaginary-part targets on a real matrix, src/run.jl:298-339):
+  // its sub-diagonal entry is then dropped by the truncation, and the Arnoldi relation of the kept columns is off by that
+  // much from here on -- in the reference as well.  The per-step expansion does not care; the s-step expansion, which leans
+  // on the relation of the earlier columns with O(1) coefficients, must not run on such a state (Backend::note_ritz).
+  double leak = 0.0, fro = 0.0;
 };
 
 inline double now_s() {
@@ -178,9 +185,15 @@ inline RestartResult restart_host_late(const Mat<T>& H, const Mat<T>& Q, int max
   KS_STAGE(2, t0__);
   partition_schur_three_way(H, Q, groups, maxdim);                     // :355
   KS_STAGE(3, t0__);
+  double leak = 0.0;
+  for (int j = 0; j < k; ++j)
+    for (int i2 = k; i2 < maxdim; ++i2) leak = std::max(leak, (double)std::abs(H(i2, j)));
   restore_arnoldi(H, nlock, k - 1, Q, s.G);                            // :360
   KS_STAGE(4, t0__);
-  return RestartResult{k, nlock, purge, effective_nev};
+  RestartResult res{k, nlock, purge, effective_nev};
+  res.leak = leak;
+  res.fro = fro;
+  return res;
 }
 
 template <class T>
@@ -219,7 +232,7 @@ inline History partialschur_driver(Backend<T>& be, const Mat<T>& H, const Mat<T>
     t0 = now_s();
     if (!early_done) restart_host_early(H, Q, maxdim, ordering, active, scratch);
     const RestartResult r = restart_host_late(H, Q, maxdim, mindim, nev, p.tol, active, scratch);
-    be.note_ritz(scratch.lams.data(), maxdim);
+    be.note_ritz(scratch.lams.data(), maxdim, r.leak, r.fro);
     hist.seconds_host += now_s() - t0;
     k = r.k;
 

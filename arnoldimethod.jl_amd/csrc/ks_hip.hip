@@ -706,6 +706,14 @@ int ks_workspace_sstep_info(const ks_workspace* ws, int* s, int* blocks, int* ab
   });
 }
 
+int ks_workspace_relation_info(const ks_workspace* ws, int* breaks, double* worst_leak) {
+  return guarded([&] {
+    KS_REQUIRE(ws, KS_ERR_ARGUMENT, "null workspace");
+    if (breaks) *breaks = ws->relation_breaks;
+    if (worst_leak) *worst_leak = ws->relation_leak;
+  });
+}
+
 // diagnostics: average duration of `reps` launches of one block kernel on the workspace's basis (contents irrelevant: the
 // kernels have no data-dependent control flow); which = 0 k_bdots, 1 k_bupdate.  Leaves columns k..k+s-1 overwritten.
 int ks_debug_blk_time(ks_workspace* ws, int k, int s, int which, int reps, int dbg, double* ms_per_launch, int* grid) {
@@ -1177,7 +1185,7 @@ int ks_restart(ks_workspace* ws, const ks_params* p, int active, int* k_out, int
       const ks::RestartResult r =
           ks::restart_host_step(H, Q, prm.maxdim, prm.mindim, prm.nev, ks::Ordering{prm.which}, prm.tol, active, sc);
       HipBackend<T> be(nullptr, ws);
-      be.note_ritz(sc.lams.data(), prm.maxdim);
+      be.note_ritz(sc.lams.data(), prm.maxdim, r.leak, r.fro);
       be.rotate_and_move(r.purge, prm.maxdim - r.purge, r.k - r.purge, Q, r.k, prm.maxdim);  // src/run.jl:363-365
       if (k_out) *k_out = r.k;
       if (nlock_out) *nlock_out = r.nlock;
@@ -1217,7 +1225,7 @@ int ks_expand_restart(ks_operator* A, ks_workspace* ws, const ks_params* p, int 
       double t1 = ks::now_s();
       if (!early_done) ks::restart_host_early(H, Q, prm.maxdim, ordering, active, sc);
       const ks::RestartResult r = ks::restart_host_late(H, Q, prm.maxdim, prm.mindim, prm.nev, prm.tol, active, sc);
-      be.note_ritz(sc.lams.data(), prm.maxdim);
+      be.note_ritz(sc.lams.data(), prm.maxdim, r.leak, r.fro);
       double t2 = ks::now_s();
       be.rotate_and_move(r.purge, prm.maxdim - r.purge, r.k - r.purge, Q, r.k, prm.maxdim);  // src/run.jl:363-365
       double t3 = ks::now_s();

@@ -110,6 +110,11 @@ struct ks_workspace {
   bool blk_tail = false;        // the T-lazy columns were produced by blocks (a batch continuing on them starts a new T)
   double blk_diag[3] = {1.0, 1.0, 0.0};  // of the last batch: worst pivot ratio of stage 1 / stage 2, largest |G_t - I| entry
   int blk_count = 0, blk_bails = 0;      // blocks completed / abandoned since creation
+  // restarts that cut through a 2 x 2 block of the real Schur form (ks::RestartResult::leak > relation_tol ||H||_F): the
+  // Arnoldi relation of the kept columns is violated from there on, blocks stay off for the rest of the run
+  int relation_breaks = 0;
+  double relation_leak = 0.0;            // largest leak / ||H||_F seen
+  double relation_tol = 1e-12;
   // REVERSE MAILBOX (k_rot_gate, ks_kernels.hpp): the restart rotation pre-enqueued behind a gate the host releases
   ksd::RotGate* gate_h = nullptr;      // pinned host (coherent)
   ksd::RotGate* gate_hd = nullptr;     // the same memory through its device pointer

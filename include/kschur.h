@@ -232,7 +232,7 @@ int ks_workspace_set_passes(ks_workspace* ws, int passes, double max_ratio);
  * pivot below pivot_min times its diagonal entry (breakdown, src/expansion.jl:99-102, or an ill-conditioned basis) is
  * abandoned before anything is committed and its steps are redone one at a time, which takes the reference's decisions.
  * Like the implicit second pass it needs the library's provenance of the factorisation; otherwise, and for host-callback
- * operators and maxdim > 64 the expansion runs step by step.  Default s = 8 (KS_SSTEP at creation; ComplexF64 uses the largest
+ * operators and maxdim > 64 the expansion runs step by step.  Default s = 10 (KS_SSTEP at creation; ComplexF64 uses the largest
  * instantiated size <= s, i.e. 5); s = 0 / 1: off -- every step then takes the reference's DGKS decisions.  A block is also abandoned when the Gram matrix of what its first stage wrote differs from I by more than
  * gram_dev_max in any entry (~ eps cond^2 of the Newton basis; the recovered H carries errors ~ eps cond): default 1e-8
  * keeps H at the per-step path's accuracy.  After an abandoned block the library lowers the block size for the following
@@ -244,6 +244,14 @@ int ks_workspace_set_passes(ks_workspace* ws, int passes, double max_ratio);
  * block - I) }. */
 int ks_workspace_set_sstep(ks_workspace* ws, int s, double pivot_min, double gram_dev_max);
 int ks_workspace_sstep_info(const ks_workspace* ws, int* s, int* blocks, int* abandoned, double* diag3);
+/* Restarts of the library's drivers (ks_partialschur, ks_expand_restart, ks_restart) whose selection cut through a 2 x 2 block
+ * of the real Schur form: the members of a complex pair are not neighbours in the target's order (imaginary-part targets on a
+ * real matrix; src/run.jl:298-339 keeps pairs together only when they are), the truncation of src/run.jl:363-365 then drops the
+ * block's sub-diagonal entry and the Arnoldi relation of the kept columns is off by that much from there on -- in the reference
+ * as well.  The per-step expansion is indifferent to it; the s-step expansion (which leans on the relation of the earlier
+ * columns) is switched off for the rest of the run when the dropped entry exceeds 1e-12 ||H||_F.  *breaks = such restarts
+ * since creation, *worst_leak = largest dropped entry / ||H||_F. */
+int ks_workspace_relation_info(const ks_workspace* ws, int* breaks, double* worst_leak);
 /* Diagnostics (tools/blk_bench.py): average duration of `reps` back-to-back launches of one streaming kernel of the s-step
  * expansion at basis size k and block size s (which = 0: first pass, 1: second pass), timed with HIP events on the
  * library's stream; *grid = workgroups launched.  dbg: probe flags of the kernels (1: second pass without its stores).

@@ -421,6 +421,14 @@ def solve(A, v1, nev, which, tol, mindim, maxdim, restarts, dtype, s=4, **kw):
         while purge < active and groups[purge] == 1:
             purge += 1
         sd.partition_schur_three_way(H, Q, groups)
+        # a selection that splits a 2 x 2 block of the real Schur form (complex pair not adjacent in the target's order) drops
+        # the block's sub-diagonal entry here: the relation of the kept columns is violated by that much from now on (in the
+        # reference too); blocks, which lean on it with O(1) coefficients, stay off for the rest of the run
+        # (csrc/ks_driver.hpp RestartResult::leak, HipBackend::note_ritz)
+        leak = float(np.abs(H[k:maxdim, :k]).max()) if k < maxdim else 0.0
+        if leak > 1e-12 * hfrob:
+            stats["relation_breaks"] = stats.get("relation_breaks", 0) + 1
+            stats["s_eff"] = 1
         sd.restore_arnoldi(H, nlock, k - 1, Q, G)
         m = maxdim
         Qe = np.zeros((m + 1, k - purge + 1), dtype=dtype)
