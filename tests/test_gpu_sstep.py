@@ -276,7 +276,7 @@ def test_blocks_stay_off_after_a_restart_that_split_a_conjugate_pair(seed):
         ws.close()
     (p1, n1, e1, rel1, info1), (p0, n0, e0, rel0, _) = out
     assert rel1["breaks"] > 0 and rel1["worst_leak"] > 1e-8 and info1["s"] == 0, (rel1, info1)
-    assert rel0["breaks"] == rel1["breaks"]
+    assert rel0["breaks"] > 0       # (the per-step run meets the same kind of restart; the counts differ with the trails)
     # at most one expansion ran in blocks (the one between the first and the second restart): the trails can differ in the last
     # bits from there, which this regime turns into different product counts -- both runs must still agree on what they lock
     # when they lock the same number
