@@ -305,8 +305,7 @@ def main():
         # s-step (block) expansion (include/kschur.h: ks_workspace_set_sstep): device-resident operator; with several ranks
         # the two reductions of a block are the only collectives of its s steps
         sstep = args.sstep if args.sstep >= 2 else 0
-        if sstep:
-            ws.set_sstep(sstep)
+        ws.set_sstep(sstep)     # (0 included: the library's own default is ON)
         ws.reinitialize(0, v1)
         ws.iterate_arnoldi(op, 1, mindim)  # initial expansion, src/run.jl:267 (untimed)
 

@@ -88,8 +88,7 @@ def main():
     v1 = M.start_vector(n).astype(dtype)
     if esz == 16:
         v1 = v1 + 1j * M.start_vector(n, seed=5)
-    if args.sstep >= 2:
-        ws.set_sstep(args.sstep)
+    ws.set_sstep(args.sstep if args.sstep >= 2 else 0)   # (0 included: the library's own default is ON)
     ws.reinitialize(0, v1)
     ws.iterate_arnoldi(op, 1, mindim)
     fmt = op.format
