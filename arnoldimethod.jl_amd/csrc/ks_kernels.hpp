@@ -863,82 +863,6 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-// WINDOWED form of the paired stencil product (Float64, single GPU, even n).  The gathers of k_spmv_stencil2 ask the L2
-// for 7 x 16 bytes per row pair -- 56 bytes per row, 564 MB per product at n = 1e7 -- and the L2 serves ~12 TB/s of requests
-// whoever asks (ks_block_kernels.hpp): 45-47 us, which is what the kernel takes with everything cache resident.  Here a
-// workgroup owns 2048 consecutive rows and copies the window x[r0 - D, r0 + 2048 + D) into LDS once (D = the largest
-// |column - row| among the NEAR dictionary slots, <= kStencilNear); near slots -- the row's own plane for a 3-D stencil --
-// are read from the window, only the far ones (the neighbouring planes) still gather from memory: (2048 + 2 D) / 2048 + 2
-// requests of 8 bytes per row instead of 7.  Same products added in the same (slot) order: bit-identical to every other layout.
-constexpr int kStencilNear = 512;
-constexpr int kStencilWinRows = 2048;
-template <class MT2>
-__global__ void __launch_bounds__(kBlock)
-    k_spmv_stencil2_win(const MT2* __restrict__ mask2, const StencilDict<double> d, int nslots, uint32_t nearmask, int D,
-                        const double* __restrict__ x, double* __restrict__ y, int64_t n, int ntiles,
-                        const DevState* __restrict__ st, int shifted, double theta, double sigma) {
-  if (st && st->breakdown >= 0) return;
-  __shared__ __attribute__((aligned(16))) double win[kStencilWinRows + 2 * kStencilNear];
-  const int tile = xcd_remap(blockIdx.x, ntiles);
-  const int64_t r0 = (int64_t)tile * kStencilWinRows;
-  const int64_t w0 = r0 - D;                       // (D even: 16-byte aligned window start)
-  const int64_t cmax = n - 2;                      // last admissible pair start (n even)
-  const int npk = (kStencilWinRows + 2 * D) / 2;   // packs of the window
-  for (int p = threadIdx.x; p < npk; p += kBlock) {
-    int64_t c = w0 + 2 * (int64_t)p;
-    c = c < 0 ? 0 : (c > cmax ? cmax : c);         // (positions outside [0, n) belong to absent slots only)
-    reinterpret_cast<double2*>(win)[p] = *reinterpret_cast<const double2*>(x + c);
-  }
-  __syncthreads();
-  constexpr int MB = (int)sizeof(MT2) * 4;
-  constexpr int Q = kStencilWinRows / (2 * kBlock);
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    const int lr = 2 * (q * kBlock + (int)threadIdx.x);   // local row of the pair
-    const int64_t r = r0 + lr;
-    if (r >= n) break;
-    const MT2 mm = mask2[r >> 1];
-    const uint32_t m0 = (uint32_t)(mm & (MT2)((((uint64_t)1) << MB) - 1)), m1 = (uint32_t)((uint64_t)mm >> MB);
-    double s0 = 0.0, s1 = 0.0;
-    constexpr int UN = 8;
-#pragma unroll
-    for (int k0 = 0; k0 < kStencilSlots; k0 += UN) {
-      if (k0 < nslots) {  // uniform
-        double xa[UN], xb[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-          const int dl = d.delta[k0 + u];
-          if ((nearmask >> (k0 + u)) & 1u) {  // uniform
-            const int i = lr + D + dl;        // window index of x[r + delta]
-            xa[u] = win[i];
-            xb[u] = win[i + 1];
-          } else {
-            const int64_t c = r + dl;
-            const int64_t lo = c < 0 ? 0 : (c > cmax ? cmax : c);
-            double a, b;
-            ld_pair_u(x + lo, a, b);
-            const int sh = (int)(c - lo);     // out-of-pair positions belong to absent slots
-            xa[u] = sh == 1 ? b : a;
-            xb[u] = sh == -1 ? a : b;
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-          const double p0 = mul_nc(d.val[k0 + u], xa[u]), p1 = mul_nc(d.val[k0 + u], xb[u]);
-          s0 = ((m0 >> (k0 + u)) & 1u) ? add_(s0, p0) : s0;
-          s1 = ((m1 >> (k0 + u)) & 1u) ? add_(s1, p1) : s1;
-        }
-      }
-    }
-    if (shifted) {
-      const double x0 = win[lr + D], x1 = win[lr + D + 1];
-      s0 = scl(sub_s(s0, mul_(theta, x0)), sigma);
-      s1 = scl(sub_s(s1, mul_(theta, x1)), sigma);
-    }
-    st_pack_nt(y + r, make_double2(s0, s1));
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Dense operator  y = A x  (mul!(y, A::Matrix, x), src/expansion.jl:121 with a dense A): A row-major with a
 // padded leading dimension (multiple of 2 elements, so every row starts 16-byte aligned).  One wave per row

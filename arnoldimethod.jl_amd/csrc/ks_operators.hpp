@@ -272,29 +272,6 @@ template <class D> struct CsrOp : ks_operator {
         if (ptr64) f(int64_t{});
         else f(int32_t{});
       };
-      if constexpr (sizeof(D) == 8) {
-        // windowed form (k_spmv_stencil2_win): near slots from an LDS copy of the workgroup's rows, far slots gathered
-        static const int win_env = env_int("KS_STENCIL_WIN", 1);
-        if (win_env && nstencil > 0 && nghost == 0 && smask2 && n_local >= 4 * ksd::kStencilWinRows && (n_local & 1) == 0) {
-          uint32_t nearmask = 0;
-          int dmax = 0, nnear = 0;
-          for (int k = 0; k < nstencil; ++k) {
-            const int a = std::abs(sdict.delta[k]);
-            if (a <= ksd::kStencilNear) { nearmask |= 1u << k; dmax = std::max(dmax, a); ++nnear; }
-          }
-          if (nnear >= 3) {
-            const int Dw = (dmax + 1) & ~1;
-            const int nt = (int)((n_local + ksd::kStencilWinRows - 1) / ksd::kStencilWinRows);
-            const double th = shift_on ? std::real(std::complex<double>(shift_theta)) : 0.0;
-            if (stencil_mask_bytes == 1)
-              ksd::k_spmv_stencil2_win<uint16_t><<<nt, kBlock, 0, s>>>(static_cast<const uint16_t*>(smask2), sdict, nstencil, nearmask, Dw, x, y, n_local, nt, st, shift_on ? 1 : 0, th, shift_sigma);
-            else
-              ksd::k_spmv_stencil2_win<uint64_t><<<nt, kBlock, 0, s>>>(static_cast<const uint64_t*>(smask2), sdict, nstencil, nearmask, Dw, x, y, n_local, nt, st, shift_on ? 1 : 0, th, shift_sigma);
-            KS_HIP(hipGetLastError());
-            return;
-          }
-        }
-      }
       if (nstencil > 0 && nghost == 0 && smask2 && n_local >= 2 && env_int("KS_STENCIL_PAIRS", 1)) {
         // two rows per lane, 16-byte gathers (no ghost columns: single GPU)
         const int nt = (int)(((n_local + 1) / 2 + kBlock - 1) / kBlock);
