@@ -502,23 +502,26 @@ __global__ void __launch_bounds__(64 * NW, NW / 4)
   const int niter = (int)((pe - pb + 63) / 64);
   // copies of this wave per tile: columns wave, wave + NW, ... < ncol
   const int nl = (ncol - wave + NW - 1) / NW;
-  auto issue = [&](int it) {  // tile `it` -> ring slot it % stages (rows clamped to the workgroup's range: the tail is masked below)
+  auto issue = [&](int it, int sl) {  // tile `it` -> ring slot sl = it % stages (rows clamped to the workgroup's range: the tail is masked below)
     int64_t q = pb + (int64_t)it * 64 + lane;
     if (q >= pe) q = pe - 1;
     const double* src = V + q * 2;
-    const uint32_t slot = ring_lds + (uint32_t)((it % stages) * ncol) * 1024u;
+    const uint32_t slot = ring_lds + (uint32_t)(sl * ncol) * 1024u;
     if (dbg & 32) return;  // (probe: no copies)
     if (dbg & 64) { for (int j = wave; j < ncol; j += NW) glds16_nt(src + (int64_t)j * ldv, slot + (uint32_t)j * 1024u); }
     else { for (int j = wave; j < ncol; j += NW) glds16(src + (int64_t)j * ldv, slot + (uint32_t)j * 1024u); }
   };
-  for (int it = 0; it < stages - 1; ++it) issue(it);
+  for (int it = 0; it < stages - 1; ++it) issue(it, it);
+  int sl_cur = 0, sl_new = stages - 1;   // it % stages, (it + stages - 1) % stages without the division
   for (int it = 0; it < niter; ++it) {
     // tile `it` has landed when at most (stages - 2) later tiles of this wave are outstanding; behind the barrier everybody's
     // part of it is there and everybody has finished tile it - 1, whose slot the next copies overwrite
     wait_vm_barrier((stages - 2) * nl);
-    issue(it + stages - 1);
+    issue(it + stages - 1, sl_new);
+    const double2* tile = ring + (size_t)(sl_cur * ncol) * 64;
+    sl_new = sl_cur;
+    sl_cur = sl_cur + 1 == stages ? 0 : sl_cur + 1;
     if (dbg & 16) continue;  // (probe: copies only)
-    const double2* tile = ring + (size_t)((it % stages) * ncol) * 64;
     const bool ok = pb + (int64_t)it * 64 + lane < pe;
     double2 v[NCW];
 #pragma unroll
@@ -631,11 +634,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4)
   for (int jj = 0; jj < SB; ++jj)
     if ((jj % WA) == wa && wb + WB * jj < S) ++nst;
   if (dbg & 1) nst = 0;
-  auto issue = [&](int it) {
+  auto issue = [&](int it, int sl) {
     int64_t q = pb + (int64_t)it * 64 + lane;
     if (q >= pe) q = pe - 1;
     const double* src = V + q * 2;
-    const uint32_t slot = ring_lds + (uint32_t)((it % stages) * ncol) * 1024u;
+    const uint32_t slot = ring_lds + (uint32_t)(sl * ncol) * 1024u;
     if (dbg & 64) { for (int j = wave; j < ncol; j += NW) glds16_nt(src + (int64_t)j * ldv, slot + (uint32_t)j * 1024u); }
     else { for (int j = wave; j < ncol; j += NW) glds16(src + (int64_t)j * ldv, slot + (uint32_t)j * 1024u); }
   };
@@ -667,14 +670,17 @@ __global__ void __launch_bounds__(64 * NW, NW / 4)
   double2 vprev[NCW];
 #pragma unroll
   for (int ii = 0; ii < NCW; ++ii) vprev[ii] = make_double2(0.0, 0.0);
-  for (int it = 0; it < stages - 1; ++it) issue(it);
+  for (int it = 0; it < stages - 1; ++it) issue(it, it);
+  int sl_cur = 0, sl_new = stages - 1;   // it % stages, (it + stages - 1) % stages
   for (int it = 0; it < niter; ++it) {
     // issue order per tile: nl copies, then nst stores; tile `it` was copied (stages - 1) tiles ago, behind it are the
     // copies of stages - 2 tiles and the stores of the last min(it, stages - 1) tiles.  Behind this barrier: tile `it` is in
     // LDS, qbuf holds the block columns of tile it - 1, tbuf and the ring slot of tile it - 1 are free.
     wait_vm_barrier((stages - 2) * nl + (it < stages - 1 ? it : stages - 1) * nst);
-    issue(it + stages - 1);
-    const double2* tile = ring + (size_t)((it % stages) * ncol) * 64;
+    issue(it + stages - 1, sl_new);
+    const double2* tile = ring + (size_t)(sl_cur * ncol) * 64;
+    sl_new = sl_cur;
+    sl_cur = sl_cur + 1 == stages ? 0 : sl_cur + 1;
     const int64_t qi = pb + (int64_t)it * 64 + lane;
     const bool ok = qi < pe;
     double2 v[NCW];
