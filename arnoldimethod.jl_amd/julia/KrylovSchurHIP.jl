@@ -46,7 +46,7 @@ using LinearAlgebra, SparseArrays, Random
 import ArnoldiMethod
 import ArnoldiMethod: ArnoldiWorkspace, PartialSchur
 
-export HipContext, HipOperator, HipWorkspace, HipBasis, HipColumn, HipColumns, hip_partialschur, hip_partialschur!, hip_partialeigen, set_sstep!
+export HipContext, HipOperator, HipWorkspace, HipBasis, HipColumn, HipColumns, hip_partialschur, hip_partialschur!, hip_partialeigen, set_sstep!, relation_breaks
 
 const LIB = get(ENV, "KSCHUR_LIB", joinpath(@__DIR__, "..", "libkschur_hip.so"))
 
@@ -290,11 +290,26 @@ end
 
 s-step (block) expansion for the fused `iterate_arnoldi!` / `partialschur` paths (include/kschur.h, ks_workspace_set_sstep):
 `s >= 2` takes the steps of an expansion in blocks of up to `s` -- two passes over the basis per block instead of per step.
-`0` switches it off (default).
+`0` switches it off; the library default is on (blocks of 10, `KS_SSTEP`).
 """
 function set_sstep!(w::HipWorkspace, s::Integer; pivot_min::Float64 = NaN, gram_dev_max::Float64 = NaN)
     check(ccall((:ks_workspace_set_sstep, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cdouble), w.h, s, pivot_min, gram_dev_max))
     w
+end
+
+"""
+    relation_breaks(w) -> (breaks, worst_leak)
+
+Restarts of the library's drivers that cut through a 2 x 2 block of the real Schur form (imaginary-part targets on a real
+operator: the members of a complex pair are not neighbours in the target's order, src/run.jl:298-339 / :363-365 then drop the
+block's sub-diagonal entry and the Arnoldi relation of the kept columns is off by that much).  After the first one the
+s-step expansion stays off for the run (include/kschur.h, ks_workspace_relation_info).  A caller that runs the restart
+itself (`partialschur!` of the reference on a `HipBasis`) is not seen by this guard: `set_sstep!(w, 0)` for such targets.
+"""
+function relation_breaks(w::HipWorkspace)
+    b = Ref{Cint}(0); l = Ref{Cdouble}(0.0)
+    check(ccall((:ks_workspace_relation_info, LIB), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cdouble}), w.h, b, l))
+    return (Int(b[]), l[])
 end
 
 "Array(view(V, :, j0+1:j0+ncols)): host copy of device columns"
