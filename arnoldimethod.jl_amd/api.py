@@ -688,10 +688,12 @@ def sstep_partition(dtype, k0: int, count: int, smax: int) -> list:
     cplx = np.dtype(dtype).kind == "c"
 
     def ok(k, s):
-        if not (1 <= s <= 5 or (not cplx and s in (8, 10))) or k < 1 or k + s > 65:
+        if not (1 <= s <= 5 or (not cplx and s in (8, 10, 20))) or k < 1 or k + s > 65:
             return False
         if cplx:
             return k <= 32
+        if s == 20:
+            return k <= 24
         if s == 10:
             return k <= 32
         return s <= 5 if k > 48 else True

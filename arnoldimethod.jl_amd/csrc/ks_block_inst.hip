@@ -79,8 +79,53 @@ template <int NCW, int S, int NW, int WB> int go_ring1(const BlkLaunchArgs& a) {
   return nb;
 }
 
+// large blocks (s = 20): ring forms of their own (k_bdots_ringL: 4 x 2 waves, k_bupdate_ringL: 2 x 4)
+template <int NCW4> int go_ringL0(const BlkLaunchArgs& a) {
+  const int ncol = a.k + ksd::kBlkL;
+  const int stages = std::min(3, (150 * 1024) / (ncol * 1024));
+  if (stages < 2) throw std::runtime_error("block kernels: ring does not fit the LDS");
+  const size_t smem = (size_t)stages * ncol * 1024;
+  auto kern = ksd::k_bdots_ringL<NCW4>;
+  static bool attr = false;
+  if (!attr) {
+    hipcheck(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "dynamic LDS size");
+    attr = true;
+  }
+  const int nb = cap(a, a.num_cu, 64, sizeof(double));
+  kern<<<nb, 512, smem, a.stream>>>(static_cast<const double*>(a.V), a.ld, a.k, stages, static_cast<double*>(a.partial), a.pnb,
+                                   static_cast<const ksd::DevState*>(a.st), a.dbg | (a.nt ? 64 : 0));
+  return nb;
+}
+template <int NCW2> int go_ringL1(const BlkLaunchArgs& a) {
+  constexpr int S = ksd::kBlkL;
+  const int ncol = a.k + S;
+  const size_t fixed = (size_t)(2 * S + S) * 1024 + (size_t)(2 * NCW2 * S + S * S) * 8;
+  const int stages = 2;
+  const size_t smem = (size_t)stages * ncol * 1024 + fixed;
+  if (smem > 160 * 1024) throw std::runtime_error("block kernels: ring does not fit the LDS");
+  auto kern = ksd::k_bupdate_ringL<NCW2>;
+  static bool attr = false;
+  if (!attr) {
+    hipcheck(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "dynamic LDS size");
+    attr = true;
+  }
+  const int nb = cap(a, a.num_cu, 64, sizeof(double));
+  kern<<<nb, 512, smem, a.stream>>>(static_cast<double*>(a.V), a.ld, a.k, stages, static_cast<const double*>(a.coefp), a.k,
+                                   static_cast<const double*>(a.r1inv), static_cast<double*>(a.partial), a.pnb,
+                                   static_cast<const ksd::DevState*>(a.st), a.dbg | (a.nt ? 64 : 0));
+  return nb;
+}
+
 template <class D, int NCW, int S, int NW = 4, int WB = 1> int go(int which, const BlkLaunchArgs& a) {
-  if constexpr (sizeof(D) == 8 && NW == 8) {
+  if constexpr (sizeof(D) == 8 && NW == 8 && S == 20) {
+    if (which == 0 && (ring_env() & 1)) return go_ringL0<NCW>(a);
+    if (which == 1 && (ring_env() & 2)) {
+      if (a.k <= 20) return go_ringL1<10>(a);
+      if (a.k <= 22) return go_ringL1<11>(a);
+      return go_ringL1<12>(a);
+    }
+  }
+  if constexpr (sizeof(D) == 8 && NW == 8 && S <= 10) {
     if (which == 0 && (ring_env() & 1)) return go_ring0<NCW, S, NW, WB>(a);
     if (which == 1 && (ring_env() & 2)) return go_ring1<NCW, S, NW, WB>(a);
   }
@@ -108,7 +153,10 @@ template <class D, int NCW, int S, int NW = 4, int WB = 1> int go(int which, con
 // columns per wave: ceil(k / 4), rounded up to an instantiated width
 template <class D, int S> int by_ncw(int which, const BlkLaunchArgs& a) {
   const int need = (a.k + 3) / 4;
-  if constexpr (sizeof(D) == 8 && S == 10) {
+  if constexpr (sizeof(D) == 8 && S == 20) {
+    // (register forms as the fall-back of the large-block ring kernels: correct, register bound)
+    if (need <= 6) return go<D, 6, S, 8, 2>(which, a);
+  } else if constexpr (sizeof(D) == 8 && S == 10) {
     // wide form: eight waves, the block columns split two ways (ks_block_kernels.hpp)
     if (need <= 4) return go<D, 4, S, 8, 2>(which, a);
     if (need <= 5) return go<D, 5, S, 8, 2>(which, a);
@@ -150,6 +198,7 @@ int ks_blk_launch_part1(int which, const BlkLaunchArgs& a) {
     case 5: return by_ncw<double, 5>(which, a);
     case 8: return by_ncw<double, 8>(which, a);
     case 10: return by_ncw<double, 10>(which, a);
+    case 20: return by_ncw<double, 20>(which, a);
     default: throw std::runtime_error("block kernels: block size not in this part");
   }
 }

@@ -21,7 +21,8 @@
 
 namespace ksd {
 
-constexpr int kBlkSMax = 10;                                   // largest block (steps per block)
+constexpr int kBlkSMax = 20;                                   // largest block (steps per block): Float64 20, ComplexF64 10 (blk_smax)
+template <class T> constexpr int blk_smax() { return sizeof(T) == 8 ? kBlkSMax : 10; }
 constexpr int kBlkGram = kBlkSMax * (kBlkSMax + 1) / 2;        // upper triangle of an s x s Gram matrix
 constexpr int kBlkHLds = 2048;                                 // ... and of H[0:k, 0:k-1)
 constexpr int kBlkTLds = 2048;                                 // elements of T the block algebra stages in LDS (16 / 32 KiB)
@@ -65,7 +66,7 @@ __device__ __forceinline__ void put_acc(double* f, int idx, cd v) { f[2 * idx] =
 // what the four-wave form needs at the same k.  That is what lets blocks of 10 run with two waves per SIMD (the four-wave
 // instantiations need > 256 registers there: one wave per SIMD, 2.6-3.5 TB/s).  Each basis column is loaded by WB waves
 // (the second hit is served by the CU's L1).
-template <class T, int NCW, int S, int NW = 4> constexpr int blk_u() { return S <= 5 ? 2 : (NW == 8 && NCW <= 6 ? 2 : 1); }
+template <class T, int NCW, int S, int NW = 4> constexpr int blk_u() { return S <= 5 ? 2 : (NW == 8 && NCW <= 6 && S <= 10 ? 2 : 1); }
 template <class T, int NCW, int S, int U> constexpr int blk_regs() {
   constexpr int D = (int)(sizeof(T) / 8);
   return 2 * (D * NCW * S + 2 * NCW * U + 2 * S * U + D * ((S * (S + 1) / 2 + 3) / 4)) + 44;
@@ -756,6 +757,320 @@ __global__ void __launch_bounds__(64 * NW, NW / 4)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// LARGE blocks (s = 20: one block per restart cycle at 20 / 40).  Same ring of tiles, two changes that keep a wave inside 256
+// registers: operands are read from the tile when they are used (five block columns at a time) instead of being held for the
+// whole tile, and the Gram triangle (210 entries) is dealt in 5 x 5 BLOCKS -- six off-diagonal ones (25 entries, ten columns to
+// read) to waves 0-5, the four diagonal ones (15 entries each) in pairs to waves 6 and 7 -- instead of entry by entry.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int kBlkL = 20;   // block size of the large form
+constexpr int kBlkLG = 5;   // columns per Gram group
+// group pair (a, b), a < b, of the off-diagonal block wave w < 6 owns
+__host__ __device__ __forceinline__ constexpr int blkl_a(int w) { return w < 3 ? 0 : (w < 5 ? 1 : 2); }
+__host__ __device__ __forceinline__ constexpr int blkl_b(int w) { return w < 3 ? w + 1 : (w < 5 ? w - 1 : 3); }
+// accumulator e of wave w -> Gram entry (i, i2), i <= i2 (false: padding)
+__device__ __forceinline__ bool blkl_gram_entry(int w, int e, int& i, int& i2) {
+  if (w < 6) {
+    if (e >= 25) return false;
+    i = kBlkLG * blkl_a(w) + e / kBlkLG;
+    i2 = kBlkLG * blkl_b(w) + e % kBlkLG;
+    return true;
+  }
+  if (e >= 30) return false;
+  const int g = 2 * (w - 6) + e / 15, t = e % 15;
+  int q = 0;
+  while ((q + 1) * (q + 2) / 2 <= t) ++q;
+  const int pp = t - q * (q + 1) / 2;
+  i = kBlkLG * g + pp;
+  i2 = kBlkLG * g + q;
+  return true;
+}
+// per-lane values -> wave totals -> put(index, total): P a power of two
+template <int P, class PUT> __device__ __forceinline__ void fold_put(double* f, int lane, PUT&& put) {
+  fold_stage<P, 32>(f, lane);
+  if constexpr (P >= 64) {
+#pragma unroll
+    for (int j = 0; j < P / 64; ++j) put(j + (P / 64) * lane, f[j]);
+  } else {
+    if ((lane & (64 / P - 1)) == 0) put(lane / (64 / P), f[0]);
+  }
+}
+// Gram accumulation of wave W from a column source rd(i) -> double2 (the block's columns of this lane's pack)
+template <int W, class RD> __device__ __forceinline__ void blkl_gram(double* gacc, RD&& rd) {
+  if constexpr (W < 6) {
+    constexpr int A = blkl_a(W), B = blkl_b(W);
+    double2 za[kBlkLG], zb[kBlkLG];
+#pragma unroll
+    for (int p2 = 0; p2 < kBlkLG; ++p2) { za[p2] = rd(kBlkLG * A + p2); zb[p2] = rd(kBlkLG * B + p2); }
+#pragma unroll
+    for (int p2 = 0; p2 < kBlkLG; ++p2)
+#pragma unroll
+      for (int q2 = 0; q2 < kBlkLG; ++q2) dotp(gacc[p2 * kBlkLG + q2], za[p2], zb[q2]);
+  } else {
+#pragma unroll
+    for (int d2 = 0; d2 < 2; ++d2) {
+      constexpr int G0 = 2 * (W - 6);
+      double2 za[kBlkLG];
+#pragma unroll
+      for (int p2 = 0; p2 < kBlkLG; ++p2) za[p2] = rd(kBlkLG * (G0 + d2) + p2);
+#pragma unroll
+      for (int q2 = 0; q2 < kBlkLG; ++q2)
+#pragma unroll
+        for (int p2 = 0; p2 <= q2; ++p2) dotp(gacc[15 * d2 + q2 * (q2 + 1) / 2 + p2], za[p2], za[q2]);
+    }
+  }
+}
+
+// BDOTS, large form: waves as a 4 x 2 grid (NCW = ceil(k / 4) <= 6, ten block columns per class)
+template <int NCW>
+__global__ void __launch_bounds__(512, 2)
+    k_bdots_ringL(const double* __restrict__ V, int64_t ldv, int k, int stages, double* __restrict__ partial, int pnb,
+                  const DevState* __restrict__ st, int dbg) {
+  if (st && st->breakdown >= 0) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ring_raw[];
+  constexpr int S = kBlkL, NW = 8, WB = 2, WA = 4, SB = S / WB;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wa = wave % WA, wb = wave / WA;
+  const int ncol = k + S;
+  const double2* ring = reinterpret_cast<const double2*>(ring_raw);
+  const uint32_t ring_lds = (uint32_t)(uintptr_t)ring_raw;
+  double acc[NCW][SB];
+  double gacc[30];
+#pragma unroll
+  for (int ii = 0; ii < NCW; ++ii)
+#pragma unroll
+    for (int i = 0; i < SB; ++i) acc[ii][i] = 0.0;
+#pragma unroll
+  for (int g = 0; g < 30; ++g) gacc[g] = 0.0;
+  int64_t pb, pe;
+  block_range(ldv / 2, blockIdx.x, gridDim.x, pb, pe);
+  const int niter = (int)((pe - pb + 63) / 64);
+  const int nl = (ncol - wave + NW - 1) / NW;
+  auto issue = [&](int it, int sl) {
+    int64_t q = pb + (int64_t)it * 64 + lane;
+    if (q >= pe) q = pe - 1;
+    const double* src = V + q * 2;
+    const uint32_t slot = ring_lds + (uint32_t)(sl * ncol) * 1024u;
+    if (dbg & 64) { for (int j = wave; j < ncol; j += NW) glds16_nt(src + (int64_t)j * ldv, slot + (uint32_t)j * 1024u); }
+    else { for (int j = wave; j < ncol; j += NW) glds16(src + (int64_t)j * ldv, slot + (uint32_t)j * 1024u); }
+  };
+  for (int it = 0; it < stages - 1; ++it) issue(it, it);
+  int sl_cur = 0, sl_new = stages - 1;
+  for (int it = 0; it < niter; ++it) {
+    wait_vm_barrier((stages - 2) * nl);
+    issue(it + stages - 1, sl_new);
+    const double2* tile = ring + (size_t)(sl_cur * ncol) * 64;
+    sl_new = sl_cur;
+    sl_cur = sl_cur + 1 == stages ? 0 : sl_cur + 1;
+    const bool ok = pb + (int64_t)it * 64 + lane < pe;
+    auto rdz = [&](int i) {
+      double2 z = tile[(k + i) * 64 + lane];
+      if (!ok) z = make_double2(0.0, 0.0);
+      return z;
+    };
+#pragma unroll
+    for (int jb = 0; jb < SB / kBlkLG; ++jb) {
+      double2 z5[kBlkLG];
+#pragma unroll
+      for (int j = 0; j < kBlkLG; ++j) z5[j] = rdz(wb + WB * (kBlkLG * jb + j));
+#pragma unroll
+      for (int ii = 0; ii < NCW; ++ii) {
+        const int c = wa + WA * ii;
+        if (c < k) {  // uniform
+          const double2 v = tile[c * 64 + lane];
+#pragma unroll
+          for (int j = 0; j < kBlkLG; ++j) dotp(acc[ii][kBlkLG * jb + j], v, z5[j]);
+        }
+      }
+    }
+    blk_by_idx<NW>(wave, [&](auto wtag) { blkl_gram<decltype(wtag)::value>(gacc, rdz); });
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  {
+    constexpr int P = next_pow2(NCW * SB);
+    double f[P];
+#pragma unroll
+    for (int e = 0; e < P; ++e) f[e] = 0.0;
+#pragma unroll
+    for (int ii = 0; ii < NCW; ++ii)
+#pragma unroll
+      for (int i = 0; i < SB; ++i) f[ii * SB + i] = acc[ii][i];
+    fold_put<P>(f, lane, [&](int e, double v) {
+      if (e < NCW * SB) {
+        const int c = wa + WA * (e / SB), i = wb + WB * (e % SB);
+        if (c < k) partial[(int64_t)(i * k + c) * pnb + blockIdx.x] = v;
+      }
+    });
+  }
+  {
+    double f[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) f[e] = e < 30 ? gacc[e] : 0.0;
+    fold_put<32>(f, lane, [&](int e, double v) {
+      int i, i2;
+      if (blkl_gram_entry(wave, e, i, i2)) partial[(int64_t)(k * S + gram_idx(i, i2)) * pnb + blockIdx.x] = v;
+    });
+  }
+}
+
+// BUPDATE, large form: waves as a 2 x 4 grid (NCW = ceil(k / 2) <= 12, five block columns per class); three barriers per tile
+// (partial row sums -> every block column finished by one wave -> inner products); two tiles in the ring.
+// Dynamic LDS: [ring: 2 x (k + 20) KiB | tbuf: 2 x 20 KiB | qbuf: 20 KiB | coefficients class-major].
+template <int NCW>
+__global__ void __launch_bounds__(512, 2)
+    k_bupdate_ringL(double* __restrict__ V, int64_t ldv, int k, int stages, const double* __restrict__ coefp, int ldc,
+                    const double* __restrict__ r1inv, double* __restrict__ partial, int pnb, const DevState* __restrict__ st, int dbg) {
+  if (st && st->breakdown >= 0) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ring_raw[];
+  constexpr int S = kBlkL, NW = 8, WB = 4, WA = 2, SB = S / WB;   // SB = 5 = kBlkLG
+  constexpr int NTHREADS = 64 * NW;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wa = wave % WA, wb = wave / WA;
+  const int ncol = k + S;
+  const uint32_t ring_lds = (uint32_t)(uintptr_t)ring_raw;
+  double2* ring = reinterpret_cast<double2*>(ring_raw);
+  double2* tbuf = ring + (size_t)stages * ncol * 64;              // [WA][S][64]
+  double2* qbuf = tbuf + (size_t)WA * S * 64;                     // [S][64]
+  double* cf = reinterpret_cast<double*>(qbuf + (size_t)S * 64);  // [WA * NCW][WB][SB]: coefficient (c, i = wb + WB jj)
+  double* ri = cf + WA * NCW * S;                                 // [S][WB][SB]: r1inv[l, i = wb + WB jj], zero below the diagonal
+  for (int e = threadIdx.x; e < WA * NCW * S; e += NTHREADS) {
+    const int c = e / S, r = e % S, b = r / SB, jj = r % SB, i = b + WB * jj;
+    cf[e] = c < k ? coefp[c + (int64_t)i * ldc] : 0.0;
+  }
+  for (int e = threadIdx.x; e < S * S; e += NTHREADS) {
+    const int l = e / S, r = e % S, b = r / SB, jj = r % SB, i = b + WB * jj;
+    ri[e] = l <= i ? r1inv[l + i * S] : 0.0;
+  }
+  lgkm_barrier();
+  double acc[NCW][SB];
+  double gacc[30];
+#pragma unroll
+  for (int ii = 0; ii < NCW; ++ii)
+#pragma unroll
+    for (int i = 0; i < SB; ++i) acc[ii][i] = 0.0;
+#pragma unroll
+  for (int g = 0; g < 30; ++g) gacc[g] = 0.0;
+  double* Z = V + (int64_t)k * ldv;
+  int64_t pb, pe;
+  block_range(ldv / 2, blockIdx.x, gridDim.x, pb, pe);
+  const int niter = (int)((pe - pb + 63) / 64);
+  const int nl = (ncol - wave + NW - 1) / NW;
+  // block columns this wave finishes: i = wb + WB jj with jj % WA == wa
+  int nst = (SB - wa + WA - 1) / WA;
+  if (dbg & 1) nst = 0;
+  auto issue = [&](int it, int sl) {
+    int64_t q = pb + (int64_t)it * 64 + lane;
+    if (q >= pe) q = pe - 1;
+    const double* src = V + q * 2;
+    const uint32_t slot = ring_lds + (uint32_t)(sl * ncol) * 1024u;
+    if (dbg & 64) { for (int j = wave; j < ncol; j += NW) glds16_nt(src + (int64_t)j * ldv, slot + (uint32_t)j * 1024u); }
+    else { for (int j = wave; j < ncol; j += NW) glds16(src + (int64_t)j * ldv, slot + (uint32_t)j * 1024u); }
+  };
+  for (int it = 0; it < stages - 1; ++it) issue(it, it);
+  int sl_cur = 0, sl_new = stages - 1;
+  for (int it = 0; it < niter; ++it) {
+    wait_vm_barrier((stages - 2) * nl + (it < stages - 1 ? it : stages - 1) * nst);
+    issue(it + stages - 1, sl_new);
+    const double2* tile = ring + (size_t)(sl_cur * ncol) * 64;
+    sl_new = sl_cur;
+    sl_cur = sl_cur + 1 == stages ? 0 : sl_cur + 1;
+    const int64_t qi = pb + (int64_t)it * 64 + lane;
+    const bool ok = qi < pe;
+    // partial row sums over the wave's columns, block columns of its class
+    double2 t[SB];
+#pragma unroll
+    for (int jj = 0; jj < SB; ++jj) t[jj] = make_double2(0.0, 0.0);
+    blk_by_idx<WA>(wa, [&](auto atag) {
+      constexpr int A = decltype(atag)::value;
+#pragma unroll
+      for (int l = 0; l < S; ++l) {
+        if ((l % WA) == A) {
+          const double2 zl = tile[(k + l) * 64 + lane];
+          const double* rr = ri + (l * WB + wb) * SB;
+#pragma unroll
+          for (int jj = 0; jj < SB; ++jj)
+            if (WB * jj + WB - 1 >= l) axpy_acc(t[jj], zl, -rr[jj]);
+        }
+      }
+    });
+#pragma unroll
+    for (int ii = 0; ii < NCW; ++ii) {
+      const int c = wa + WA * ii;
+      if (c < k) {  // uniform
+        const double2 v = tile[c * 64 + lane];
+        const double* cc = cf + (c * WB + wb) * SB;
+#pragma unroll
+        for (int jj = 0; jj < SB; ++jj) axpy_acc(t[jj], v, cc[jj]);
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < SB; ++jj) tbuf[(wa * S + wb + WB * jj) * 64 + lane] = t[jj];
+    lgkm_barrier();
+    // every block column is finished by one wave
+    blk_by_idx<WA>(wa, [&](auto atag) {
+      constexpr int A = decltype(atag)::value;
+#pragma unroll
+      for (int jj = 0; jj < SB; ++jj)
+        if ((jj % WA) == A) {
+          const int i = wb + WB * jj;
+          double2 sum = tbuf[(0 * S + i) * 64 + lane];
+#pragma unroll
+          for (int a2 = 1; a2 < WA; ++a2) sum = addp(sum, tbuf[(a2 * S + i) * 64 + lane]);
+          double2 qq = make_double2(-sum.x, -sum.y);
+          if (!ok) qq = make_double2(0.0, 0.0);
+          qbuf[i * 64 + lane] = qq;
+          if (ok && !(dbg & 1)) gst16_nt(Z + (int64_t)i * ldv + qi * 2, qq);
+        }
+    });
+    lgkm_barrier();
+    // inner products: own columns x block columns of the class; the wave's block(s) of the Gram triangle
+    {
+      double2 q5[SB];
+#pragma unroll
+      for (int jj = 0; jj < SB; ++jj) q5[jj] = qbuf[(wb + WB * jj) * 64 + lane];
+#pragma unroll
+      for (int ii = 0; ii < NCW; ++ii) {
+        const int c = wa + WA * ii;
+        if (c < k) {
+          const double2 v = tile[c * 64 + lane];
+#pragma unroll
+          for (int jj = 0; jj < SB; ++jj) dotp(acc[ii][jj], v, q5[jj]);
+        }
+      }
+    }
+    auto rdq = [&](int i) { return qbuf[i * 64 + lane]; };
+    blk_by_idx<NW>(wave, [&](auto wtag) { blkl_gram<decltype(wtag)::value>(gacc, rdq); });
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  {
+    constexpr int P = next_pow2(NCW * SB);
+    double f[P];
+#pragma unroll
+    for (int e = 0; e < P; ++e) f[e] = 0.0;
+#pragma unroll
+    for (int ii = 0; ii < NCW; ++ii)
+#pragma unroll
+      for (int i = 0; i < SB; ++i) f[ii * SB + i] = acc[ii][i];
+    fold_put<P>(f, lane, [&](int e, double v) {
+      if (e < NCW * SB) {
+        const int c = wa + WA * (e / SB), i = wb + WB * (e % SB);
+        if (c < k) partial[(int64_t)(i * k + c) * pnb + blockIdx.x] = v;
+      }
+    });
+  }
+  {
+    double f[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) f[e] = e < 30 ? gacc[e] : 0.0;
+    fold_put<32>(f, lane, [&](int e, double v) {
+      int i, i2;
+      if (blkl_gram_entry(wave, e, i, i2)) partial[(int64_t)(k * S + gram_idx(i, i2)) * pnb + blockIdx.x] = v;
+    });
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // FIN_BLK: reduction of the block's partial sums + the small algebra, one launch per stage.  Workgroup e reduces entry e
 // (k*s inner products + s(s+1)/2 Gram entries), the LAST workgroup to arrive (device-scope counter, as k_fin_step_t) does
 // the algebra with 256 threads.  Everything the algebra touches is O((k + s)^2 s): a few microseconds.
@@ -903,14 +1218,16 @@ __global__ void __launch_bounds__(kBlock)
   __shared__ T sm[kBlock];
   __shared__ int last_wg;
   __shared__ double sh_ratio;
-  __shared__ T rs[kBlkKMax * kBlkSMax + kBlkGram];
-  __shared__ T A1[kBlkKMax * kBlkSMax];      // stage 1: P;     stage 2: C
-  __shared__ T A2[kBlkKMax * kBlkSMax];      // stage 1: T P;   stage 2: T C, then PC
-  __shared__ T Gm[kBlkSMax * kBlkSMax], Xi[kBlkSMax * kBlkSMax], Rf[kBlkSMax * kBlkSMax];
-  __shared__ T zu[kBlkKMax + kBlkSMax], hk[kBlkKMax + kBlkSMax];
+  constexpr int SMX = blk_smax<T>();
+  constexpr int KS = (kBlkKMax - SMX) * SMX;   // k s with k + s <= kBlkKMax, s <= SMX (<= kBlkKMax / 2)
+  __shared__ T rs[KS + SMX * (SMX + 1) / 2];
+  __shared__ T A1[KS];      // stage 1: P;     stage 2: C
+  __shared__ T A2[KS];      // stage 1: T P;   stage 2: T C, then PC
+  __shared__ T Gm[SMX * SMX], Xi[SMX * SMX], Rf[SMX * SMX];
+  __shared__ T zu[kBlkKMax + SMX], hk[kBlkKMax + SMX];
   __shared__ T Tl[kBlkTLds];
   __shared__ T Hl[kBlkHLds];
-  __shared__ T rhs[(kBlkKMax + kBlkSMax) * (kBlkSMax - 1)];
+  __shared__ T rhs[kBlkKMax * (SMX - 1)];         // (k + s <= kBlkKMax rows, s - 1 right-hand sides)
   const int tid = threadIdx.x;
   const int ng = s * (s + 1) / 2, ne = k * s + ng;
 #ifdef KS_FIN_TIMING
@@ -1104,7 +1421,7 @@ __global__ void __launch_bounds__(kBlock)
     }
     __syncthreads();
     for (int r = tid; r < m; r += kBlock) {
-      T Mrow[kBlkSMax];
+      T Mrow[SMX];
       for (int i = 1; i < s; ++i) {
         T a = rhs[r + (i - 1) * m];
         for (int l = 0; l < i - 1; ++l) a = sub_(a, mul_(Mrow[l], Rf[l + (i - 1) * s]));

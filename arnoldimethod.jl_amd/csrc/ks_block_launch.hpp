@@ -24,16 +24,16 @@ struct BlkLaunchArgs {
 // which = 0: k_bdots (pass 1), 1: k_bupdate (pass 2).  Returns the number of workgroups launched (= partial sums per
 // entry); throws std::runtime_error for a shape without an instantiation (ks_blk_shape_ok says which exist).
 int ks_blk_launch_part0(int which, const BlkLaunchArgs& a);   // Float64, block sizes 1-4
-int ks_blk_launch_part1(int which, const BlkLaunchArgs& a);   // Float64, block sizes 5, 8, 10
+int ks_blk_launch_part1(int which, const BlkLaunchArgs& a);   // Float64, block sizes 5, 8, 10, 20
 int ks_blk_launch_part2(int which, const BlkLaunchArgs& a);   // ComplexF64, block sizes 1-5
 inline int ks_blk_launch(int which, const BlkLaunchArgs& a) {
   if (a.dtype != 0) return ks_blk_launch_part2(which, a);
   return a.s <= 4 ? ks_blk_launch_part0(which, a) : ks_blk_launch_part1(which, a);
 }
-// instantiated shapes: Float64 s in {1..5, 8, 10} (8 up to 48 columns, 10 up to 32), ComplexF64 s in {1..5} up to 32 columns
+// instantiated shapes: Float64 s in {1..5, 8, 10, 20} (8 up to 48 columns, 10 up to 32, 20 up to 24), ComplexF64 s in {1..5} up to 32 columns
 inline bool ks_blk_shape_ok(int dtype, int k, int s) {
   if (k < 1 || k + s > 65) return false;
   if (dtype != 0) return s >= 1 && s <= 5 && k <= 32;
   if (s >= 1 && s <= 5) return true;
-  return (s == 8 && k <= 48) || (s == 10 && k <= 32);
+  return (s == 8 && k <= 48) || (s == 10 && k <= 32) || (s == 20 && k <= 24);
 }

@@ -685,7 +685,7 @@ int ks_workspace_set_passes(ks_workspace* ws, int passes, double max_ratio) {
 int ks_workspace_set_sstep(ks_workspace* ws, int s, double pivot_min, double gram_dev_max) {
   return guarded([&] {
     KS_REQUIRE(ws, KS_ERR_ARGUMENT, "null workspace");
-    KS_REQUIRE(s >= 0 && s <= ksd::kBlkSMax, KS_ERR_ARGUMENT, "block size must be 0 (off) .. 10");
+    KS_REQUIRE(s >= 0 && s <= ksd::kBlkSMax, KS_ERR_ARGUMENT, "block size must be 0 (off) .. 20");
     ws->ctx->use();
     materialize(ws);
     ws->sstep = s;

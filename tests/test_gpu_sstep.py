@@ -71,7 +71,7 @@ def _lockstep(A, dtype, s, nev, mindim, maxdim, which, cycles, tol=1e-10, op_kw=
             return  # (a decision at the edge of tol went the other way: both valid, no longer comparable column by column)
 
 
-@pytest.mark.parametrize("s", [2, 3, 4, 5, 8, 10])
+@pytest.mark.parametrize("s", [2, 3, 4, 5, 8, 10, 20])
 def test_blocks_reproduce_the_per_step_expansion_float64(s):
     """Config 2's parameters (nev 20, 20/40, :SR) on the 20 x 21 x 22 Laplacian: the first restart cycle after the first
     restart is the first one taken in blocks.  Same Krylov space and positive sub-diagonals => the same H and V."""
@@ -113,7 +113,7 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("s", [2, 4, 5, 8, 10])
+@pytest.mark.parametrize("s", [2, 4, 5, 8, 10, 20])
 @pytest.mark.parametrize("case", list(CASES))
 def test_whole_solves_match_the_oracle(case, s):
     """partialschur with the s-step expansion against the oracle on the same start vector: identical matrix-vector counts

@@ -22,7 +22,7 @@ def main():
     n = m ** 3
     ws = ks.ArnoldiWorkspace(n, maxdim, np.float64)
     L = _lib.load()
-    shapes = [(21, 5), (26, 5), (31, 5), (36, 5), (21, 10), (31, 10), (21, 8), (29, 8), (25, 8), (33, 8), (21, 4), (37, 4), (21, 2), (39, 2)]
+    shapes = [(21, 5), (26, 5), (31, 5), (36, 5), (21, 10), (31, 10), (21, 20), (21, 8), (29, 8), (25, 8), (33, 8), (21, 4), (37, 4), (21, 2), (39, 2)]
     shapes = [(k, s) for k, s in shapes if k + s <= maxdim + 1]
     if os.environ.get("BLK_S"):
         shapes = [(k, s) for k, s in shapes if s in [int(x) for x in os.environ["BLK_S"].split(",")]]
