@@ -73,6 +73,8 @@ inline void blk_ensure_buffers(ks_workspace* ws) {
   const size_t sb = ws->dtype == KS_F64 ? sizeof(ksd::BlkScratch<double>) : sizeof(ksd::BlkScratch<cd>);
   KS_HIP(hipMalloc(&ws->bscr, sb));
   KS_HIP(hipMemset(ws->bscr, 0, sb));
+  KS_HIP(hipMalloc(&ws->bzero, 256));
+  KS_HIP(hipMemset(ws->bzero, 0, 256));
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------------------------------
@@ -82,7 +84,7 @@ template <class D> int launch_blk(ks_workspace* ws, int which, int k, int s) {
   auto* bs = static_cast<ksd::BlkScratch<D>*>(ws->bscr);
   BlkLaunchArgs a{};
   a.V = ws->V; a.ld = ws->ld; a.dtype = sizeof(D) == 8 ? 0 : 1; a.k = k; a.s = s;
-  a.partial = ws->bpart; a.pnb = ws->pnb; a.coefp = bs->coefp; a.r1inv = bs->r1inv; a.st = ws->st;
+  a.partial = ws->bpart; a.pnb = ws->pnb; a.coefp = bs->coefp; a.r1inv = bs->r1inv; a.zeros = ws->bzero; a.st = ws->st;
   a.dbg = blk_dbg(); a.nt = ws->v_nt ? 1 : 0; a.num_cu = ws->ctx->num_cu; a.bpc = ws->ctx->bpc; a.stream = ws->ctx->stream;
   try {
     return ks_blk_launch(which, a);

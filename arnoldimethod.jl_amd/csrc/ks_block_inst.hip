@@ -53,7 +53,7 @@ template <int NCW, int S, int NW, int WB> int go_ring0(const BlkLaunchArgs& a) {
   }
   const int nb = cap(a, a.num_cu, 64, sizeof(double));   // one workgroup per CU
   kern<<<nb, 64 * NW, smem, a.stream>>>(static_cast<const double*>(a.V), a.ld, a.k, stages, static_cast<double*>(a.partial), a.pnb,
-                                        static_cast<const ksd::DevState*>(a.st), a.dbg | (a.nt ? 64 : 0));
+                                        static_cast<const ksd::DevState*>(a.st), a.dbg | (a.nt ? 64 : 0), static_cast<const double*>(a.zeros));
   return nb;
 }
 
@@ -75,7 +75,7 @@ template <int NCW, int S, int NW, int WB> int go_ring1(const BlkLaunchArgs& a) {
   const int nb = cap(a, a.num_cu, 64, sizeof(double));
   kern<<<nb, 64 * NW, smem, a.stream>>>(static_cast<double*>(a.V), a.ld, a.k, stages, static_cast<const double*>(a.coefp), a.k,
                                         static_cast<const double*>(a.r1inv), static_cast<double*>(a.partial), a.pnb,
-                                        static_cast<const ksd::DevState*>(a.st), a.dbg | (a.nt ? 64 : 0));
+                                        static_cast<const ksd::DevState*>(a.st), a.dbg | (a.nt ? 64 : 0), static_cast<const double*>(a.zeros));
   return nb;
 }
 
@@ -93,7 +93,7 @@ template <int NCW4> int go_ringL0(const BlkLaunchArgs& a) {
   }
   const int nb = cap(a, a.num_cu, 64, sizeof(double));
   kern<<<nb, 512, smem, a.stream>>>(static_cast<const double*>(a.V), a.ld, a.k, stages, static_cast<double*>(a.partial), a.pnb,
-                                   static_cast<const ksd::DevState*>(a.st), a.dbg | (a.nt ? 64 : 0));
+                                   static_cast<const ksd::DevState*>(a.st), a.dbg | (a.nt ? 64 : 0), static_cast<const double*>(a.zeros));
   return nb;
 }
 template <int NCW2> int go_ringL1(const BlkLaunchArgs& a) {
@@ -112,7 +112,7 @@ template <int NCW2> int go_ringL1(const BlkLaunchArgs& a) {
   const int nb = cap(a, a.num_cu, 64, sizeof(double));
   kern<<<nb, 512, smem, a.stream>>>(static_cast<double*>(a.V), a.ld, a.k, stages, static_cast<const double*>(a.coefp), a.k,
                                    static_cast<const double*>(a.r1inv), static_cast<double*>(a.partial), a.pnb,
-                                   static_cast<const ksd::DevState*>(a.st), a.dbg | (a.nt ? 64 : 0));
+                                   static_cast<const ksd::DevState*>(a.st), a.dbg | (a.nt ? 64 : 0), static_cast<const double*>(a.zeros));
   return nb;
 }
 

@@ -479,7 +479,7 @@ __device__ __forceinline__ void wait_vm_barrier(int n) {
 template <int NCW, int S, int NW, int WB>
 __global__ void __launch_bounds__(64 * NW, NW / 4)
     k_bdots_ring(const double* __restrict__ V, int64_t ldv, int k, int stages, double* __restrict__ partial, int pnb,
-                 const DevState* __restrict__ st, int dbg = 0) {
+                 const DevState* __restrict__ st, int dbg, const double* __restrict__ zeros) {
   if (st && st->breakdown >= 0) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char ring_raw[];
   constexpr int WA = NW / WB, SB = (S + WB - 1) / WB;
@@ -504,13 +504,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4)
   // copies of this wave per tile: columns wave, wave + NW, ... < ncol
   const int nl = (ncol - wave + NW - 1) / NW;
   auto issue = [&](int it, int sl) {  // tile `it` -> ring slot sl = it % stages (rows clamped to the workgroup's range: the tail is masked below)
-    int64_t q = pb + (int64_t)it * 64 + lane;
-    if (q >= pe) q = pe - 1;
-    const double* src = V + q * 2;
+    const int64_t q = pb + (int64_t)it * 64 + lane;
+    const bool in = q < pe;              // packs past the workgroup's range are filled with zeros: nothing to mask afterwards
+    const double* src = V + (in ? q : pb) * 2;
     const uint32_t slot = ring_lds + (uint32_t)(sl * ncol) * 1024u;
     if (dbg & 32) return;  // (probe: no copies)
-    if (dbg & 64) { for (int j = wave; j < ncol; j += NW) glds16_nt(src + (int64_t)j * ldv, slot + (uint32_t)j * 1024u); }
-    else { for (int j = wave; j < ncol; j += NW) glds16(src + (int64_t)j * ldv, slot + (uint32_t)j * 1024u); }
+    if (dbg & 64) { for (int j = wave; j < ncol; j += NW) glds16_nt(in ? src + (int64_t)j * ldv : zeros, slot + (uint32_t)j * 1024u); }
+    else { for (int j = wave; j < ncol; j += NW) glds16(in ? src + (int64_t)j * ldv : zeros, slot + (uint32_t)j * 1024u); }
   };
   for (int it = 0; it < stages - 1; ++it) issue(it, it);
   int sl_cur = 0, sl_new = stages - 1;   // it % stages, (it + stages - 1) % stages without the division
@@ -532,10 +532,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4)
     }
     double2 z[S];
 #pragma unroll
-    for (int i = 0; i < S; ++i) {
-      z[i] = tile[(k + i) * 64 + lane];
-      if (!ok) z[i] = make_double2(0.0, 0.0);
-    }
+    for (int i = 0; i < S; ++i) z[i] = tile[(k + i) * 64 + lane];
     blk_by_idx<WB>(wb, [&](auto btag) {
       constexpr int B = decltype(btag)::value;
 #pragma unroll
@@ -591,7 +588,8 @@ __device__ __forceinline__ void lgkm_barrier() { asm volatile("s_waitcnt lgkmcnt
 template <int NCW, int S, int NW, int WB>
 __global__ void __launch_bounds__(64 * NW, NW / 4)
     k_bupdate_ring(double* __restrict__ V, int64_t ldv, int k, int stages, const double* __restrict__ coefp, int ldc,
-                   const double* __restrict__ r1inv, double* __restrict__ partial, int pnb, const DevState* __restrict__ st, int dbg) {
+                   const double* __restrict__ r1inv, double* __restrict__ partial, int pnb, const DevState* __restrict__ st, int dbg,
+                   const double* __restrict__ zeros) {
   if (st && st->breakdown >= 0) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char ring_raw[];
   constexpr int WA = NW / WB, SB = (S + WB - 1) / WB, SP = SB * WB;
@@ -636,12 +634,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4)
     if ((jj % WA) == wa && wb + WB * jj < S) ++nst;
   if (dbg & 1) nst = 0;
   auto issue = [&](int it, int sl) {
-    int64_t q = pb + (int64_t)it * 64 + lane;
-    if (q >= pe) q = pe - 1;
-    const double* src = V + q * 2;
+    const int64_t q = pb + (int64_t)it * 64 + lane;
+    const bool in = q < pe;              // packs past the workgroup's range are filled with zeros: nothing to mask afterwards
+    const double* src = V + (in ? q : pb) * 2;
     const uint32_t slot = ring_lds + (uint32_t)(sl * ncol) * 1024u;
-    if (dbg & 64) { for (int j = wave; j < ncol; j += NW) glds16_nt(src + (int64_t)j * ldv, slot + (uint32_t)j * 1024u); }
-    else { for (int j = wave; j < ncol; j += NW) glds16(src + (int64_t)j * ldv, slot + (uint32_t)j * 1024u); }
+    if (dbg & 64) { for (int j = wave; j < ncol; j += NW) glds16_nt(in ? src + (int64_t)j * ldv : zeros, slot + (uint32_t)j * 1024u); }
+    else { for (int j = wave; j < ncol; j += NW) glds16(in ? src + (int64_t)j * ldv : zeros, slot + (uint32_t)j * 1024u); }
   };
   // inner products of tile `it - 1` (its basis packs are still in registers, its block columns in qbuf) run in the same
   // barrier interval as the partial row sums of tile `it`: two independent instruction streams per wave, two barriers per tile
@@ -728,8 +726,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4)
             double2 sum = tbuf[(0 * S + i) * 64 + lane];
 #pragma unroll
             for (int a2 = 1; a2 < WA; ++a2) sum = addp(sum, tbuf[(a2 * S + i) * 64 + lane]);
-            double2 qq = make_double2(-sum.x, -sum.y);
-            if (!ok) qq = make_double2(0.0, 0.0);
+            const double2 qq = make_double2(-sum.x, -sum.y);   // (zero in rows past the end: their operands are)
             qbuf[i * 64 + lane] = qq;
             if (ok && !(dbg & 1)) gst16_nt(Z + (int64_t)i * ldv + qi * 2, qq);
           }
@@ -824,7 +821,7 @@ template <int W, class RD> __device__ __forceinline__ void blkl_gram(double* gac
 template <int NCW>
 __global__ void __launch_bounds__(512, 2)
     k_bdots_ringL(const double* __restrict__ V, int64_t ldv, int k, int stages, double* __restrict__ partial, int pnb,
-                  const DevState* __restrict__ st, int dbg) {
+                  const DevState* __restrict__ st, int dbg, const double* __restrict__ zeros) {
   if (st && st->breakdown >= 0) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char ring_raw[];
   constexpr int S = kBlkL, NW = 8, WB = 2, WA = 4, SB = S / WB;
@@ -847,12 +844,12 @@ __global__ void __launch_bounds__(512, 2)
   const int niter = (int)((pe - pb + 63) / 64);
   const int nl = (ncol - wave + NW - 1) / NW;
   auto issue = [&](int it, int sl) {
-    int64_t q = pb + (int64_t)it * 64 + lane;
-    if (q >= pe) q = pe - 1;
-    const double* src = V + q * 2;
+    const int64_t q = pb + (int64_t)it * 64 + lane;
+    const bool in = q < pe;              // packs past the workgroup's range are filled with zeros: nothing to mask afterwards
+    const double* src = V + (in ? q : pb) * 2;
     const uint32_t slot = ring_lds + (uint32_t)(sl * ncol) * 1024u;
-    if (dbg & 64) { for (int j = wave; j < ncol; j += NW) glds16_nt(src + (int64_t)j * ldv, slot + (uint32_t)j * 1024u); }
-    else { for (int j = wave; j < ncol; j += NW) glds16(src + (int64_t)j * ldv, slot + (uint32_t)j * 1024u); }
+    if (dbg & 64) { for (int j = wave; j < ncol; j += NW) glds16_nt(in ? src + (int64_t)j * ldv : zeros, slot + (uint32_t)j * 1024u); }
+    else { for (int j = wave; j < ncol; j += NW) glds16(in ? src + (int64_t)j * ldv : zeros, slot + (uint32_t)j * 1024u); }
   };
   for (int it = 0; it < stages - 1; ++it) issue(it, it);
   int sl_cur = 0, sl_new = stages - 1;
@@ -863,11 +860,7 @@ __global__ void __launch_bounds__(512, 2)
     sl_new = sl_cur;
     sl_cur = sl_cur + 1 == stages ? 0 : sl_cur + 1;
     const bool ok = pb + (int64_t)it * 64 + lane < pe;
-    auto rdz = [&](int i) {
-      double2 z = tile[(k + i) * 64 + lane];
-      if (!ok) z = make_double2(0.0, 0.0);
-      return z;
-    };
+    auto rdz = [&](int i) { return tile[(k + i) * 64 + lane]; };
 #pragma unroll
     for (int jb = 0; jb < SB / kBlkLG; ++jb) {
       double2 z5[kBlkLG];
@@ -919,7 +912,8 @@ __global__ void __launch_bounds__(512, 2)
 template <int NCW>
 __global__ void __launch_bounds__(512, 2)
     k_bupdate_ringL(double* __restrict__ V, int64_t ldv, int k, int stages, const double* __restrict__ coefp, int ldc,
-                    const double* __restrict__ r1inv, double* __restrict__ partial, int pnb, const DevState* __restrict__ st, int dbg) {
+                    const double* __restrict__ r1inv, double* __restrict__ partial, int pnb, const DevState* __restrict__ st, int dbg,
+                    const double* __restrict__ zeros) {
   if (st && st->breakdown >= 0) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char ring_raw[];
   constexpr int S = kBlkL, NW = 8, WB = 4, WA = 2, SB = S / WB;   // SB = 5 = kBlkLG
@@ -960,12 +954,12 @@ __global__ void __launch_bounds__(512, 2)
   int nst = (SB - wa + WA - 1) / WA;
   if (dbg & 1) nst = 0;
   auto issue = [&](int it, int sl) {
-    int64_t q = pb + (int64_t)it * 64 + lane;
-    if (q >= pe) q = pe - 1;
-    const double* src = V + q * 2;
+    const int64_t q = pb + (int64_t)it * 64 + lane;
+    const bool in = q < pe;              // packs past the workgroup's range are filled with zeros: nothing to mask afterwards
+    const double* src = V + (in ? q : pb) * 2;
     const uint32_t slot = ring_lds + (uint32_t)(sl * ncol) * 1024u;
-    if (dbg & 64) { for (int j = wave; j < ncol; j += NW) glds16_nt(src + (int64_t)j * ldv, slot + (uint32_t)j * 1024u); }
-    else { for (int j = wave; j < ncol; j += NW) glds16(src + (int64_t)j * ldv, slot + (uint32_t)j * 1024u); }
+    if (dbg & 64) { for (int j = wave; j < ncol; j += NW) glds16_nt(in ? src + (int64_t)j * ldv : zeros, slot + (uint32_t)j * 1024u); }
+    else { for (int j = wave; j < ncol; j += NW) glds16(in ? src + (int64_t)j * ldv : zeros, slot + (uint32_t)j * 1024u); }
   };
   for (int it = 0; it < stages - 1; ++it) issue(it, it);
   int sl_cur = 0, sl_new = stages - 1;
@@ -1017,8 +1011,7 @@ __global__ void __launch_bounds__(512, 2)
           double2 sum = tbuf[(0 * S + i) * 64 + lane];
 #pragma unroll
           for (int a2 = 1; a2 < WA; ++a2) sum = addp(sum, tbuf[(a2 * S + i) * 64 + lane]);
-          double2 qq = make_double2(-sum.x, -sum.y);
-          if (!ok) qq = make_double2(0.0, 0.0);
+          const double2 qq = make_double2(-sum.x, -sum.y);   // (zero in rows past the end: their operands are)
           qbuf[i * 64 + lane] = qq;
           if (ok && !(dbg & 1)) gst16_nt(Z + (int64_t)i * ldv + qi * 2, qq);
         }

@@ -15,6 +15,7 @@ struct BlkLaunchArgs {
   int pnb;
   const void* coefp;   // second pass: (T P) R1^-1, k x s, leading dimension k
   const void* r1inv;   // second pass: R1^-1, s x s
+  const void* zeros;   // >= 16 zero bytes in device memory (ring forms: source of the packs past a workgroup's rows)
   const void* st;      // DevState of the batch
   int dbg;             // probe flags (1: second pass without stores)
   int nt;              // non-temporal loads of the basis

@@ -107,6 +107,7 @@ struct ks_workspace {
   void* bpart = nullptr;        // device: partial sums of the block kernels, [entry][workgroup]
   void* bred = nullptr;         // device: reduced entries
   void* bscr = nullptr;         // device: ksd::BlkScratch
+  void* bzero = nullptr;        // device: 256 zero bytes (ring kernels copy them into the packs past a workgroup's rows)
   bool blk_tail = false;        // the T-lazy columns were produced by blocks (a batch continuing on them starts a new T)
   double blk_diag[3] = {1.0, 1.0, 0.0};  // of the last batch: worst pivot ratio of stage 1 / stage 2, largest |G_t - I| entry
   int blk_count = 0, blk_bails = 0;      // blocks completed / abandoned since creation
@@ -154,7 +155,7 @@ struct ks_workspace {
     (void)hipFree(scal); (void)hipHostFree(scal_h); (void)hipHostFree(coef_h);
     (void)hipFree(Qd); (void)hipHostFree(Qstage); (void)hipFree(tmp); (void)hipFree(tmp2); (void)hipFree(oop);
     (void)hipHostFree(Hstage_early); (void)hipHostFree(mbox); (void)hipFree(ctr);
-    (void)hipFree(bpart); (void)hipFree(bred); (void)hipFree(bscr);
+    (void)hipFree(bpart); (void)hipFree(bred); (void)hipFree(bscr); (void)hipFree(bzero);
     if (gate_armed && gate_h) {  // never leave a gate waiting: cancel, let the stream drain
       gate_h->cancel = 1;
       __atomic_store_n(&gate_h->flag, gate_seq, __ATOMIC_RELEASE);

@@ -5,7 +5,7 @@
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-export BLK_S=10 BLK_DBGS=0 BLK_DBGS0=0
+export BLK_S=${BLK_S:-10} BLK_DBGS=0 BLK_DBGS0=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA" "SQ_WAIT_ANY SQ_INSTS_SMEM"; do
   tag=$(echo $set | tr ' ' '_')
   rm -rf /tmp/bkc_$tag
@@ -16,9 +16,9 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_INST
 import csv, sys, collections, re
 by = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
-    m = re.search(r"k_b(dots|update)_ring<(\d+), (\d+)", r["Kernel_Name"])
+    m = re.search(r"k_b(dots|update)_ring(L?)<(\d+)", r["Kernel_Name"])
     if m:
-        by[f"k_b{m.group(1)}_ring<NCW={m.group(2)}>"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        by[f"k_b{m.group(1)}_ring{m.group(2)}<NCW={m.group(3)}>"][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("##", sys.argv[2])
 for k in sorted(by):
     print(f"  {k:28s}", "  ".join(f"{n} {sum(v) / len(v):14.0f}" for n, v in sorted(by[k].items())), f"({len(next(iter(by[k].values())))} launches)")
