@@ -1328,7 +1328,7 @@ __global__ void __launch_bounds__(kBlock)
     }
     if (tid == 0) st->blk_piv1 = fmin(st->blk_piv1, worst);
 #ifdef KS_FIN_TIMING
-    if (tid == 0 && k == 31) printf("[fin_blk stage 1 k=%d s=%d] reduce+elect %.2f | fetch %.2f | T^H %.2f | gram+chol+inv %.2f | rest %.2f us\n", k, s,
+    if (tid == 0 && (k == 31 || (k == 21 && s == 20))) printf("[fin_blk stage 1 k=%d s=%d] reduce+elect %.2f | fetch %.2f | T^H %.2f | gram+chol+inv %.2f | rest %.2f us\n", k, s,
                                     (tq[1] - tq[0]) * 0.01, (tq[2] - tq[1]) * 0.01, (tq[3] - tq[2]) * 0.01, (tq[4] - tq[3]) * 0.01, (wall_clock64() - tq[4]) * 0.01);
 #endif
     return;
@@ -1437,7 +1437,7 @@ __global__ void __launch_bounds__(kBlock)
     st->blk_gdev = fmax(st->blk_gdev, gdev);
   }
 #ifdef KS_FIN_TIMING
-  if (tid == 0 && k == 31) printf("[fin_blk stage 2 k=%d s=%d] reduce+elect %.2f | fetch %.2f | T^H %.2f | gram+chol+inv %.2f | T cols, R, PC %.2f | H %.2f us\n", k, s,
+  if (tid == 0 && (k == 31 || (k == 21 && s == 20))) printf("[fin_blk stage 2 k=%d s=%d] reduce+elect %.2f | fetch %.2f | T^H %.2f | gram+chol+inv %.2f | T cols, R, PC %.2f | H %.2f us\n", k, s,
                                   (tq[1] - tq[0]) * 0.01, (tq[2] - tq[1]) * 0.01, (tq[3] - tq[2]) * 0.01, (tq[4] - tq[3]) * 0.01, (tq[5] - tq[4]) * 0.01, (wall_clock64() - tq[5]) * 0.01);
 #endif
 }

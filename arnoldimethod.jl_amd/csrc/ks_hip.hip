@@ -629,7 +629,7 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     KS_HIP(hipMalloc(reinterpret_cast<void**>(&w->ctr), 64));
     KS_HIP(hipMemsetAsync(w->ctr, 0, 64, ctx->stream));
     w->passes = env_int("KS_PASSES", 2) == 3 ? 3 : 2;
-    w->sstep = std::max(0, std::min(env_int("KS_SSTEP", 10), ksd::kBlkSMax));  // s-step expansion: ON by default (KS_SSTEP=0: step by step)
+    w->sstep = std::max(0, std::min(env_int("KS_SSTEP", 20), ksd::kBlkSMax));  // s-step expansion: ON by default (KS_SSTEP=0: step by step)
     w->sstep_eff = w->sstep;
     if (const char* e = std::getenv("KS_SSTEP_GDEV_MAX")) w->blk_gdevmax = std::atof(e);
     if (const char* e = std::getenv("KS_SSTEP_PIVOT_MIN")) w->blk_pivmin = std::atof(e);

@@ -206,7 +206,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shift-invert", action="store_true", help="skip the side record of the sparse shift-invert operator (N = 1 only)")
     ap.add_argument("--no-profile", action="store_true", help="skip the second (HIP-event instrumented) pass")
-    ap.add_argument("--sstep", type=int, default=int(os.environ.get("KS_BENCH_SSTEP", "10")),
+    ap.add_argument("--sstep", type=int, default=int(os.environ.get("KS_BENCH_SSTEP", "20")),
                     help="s-step (block) expansion: steps per block (ks_workspace_set_sstep; 0 = the per-step expansion of rounds 2-3)")
     ap.add_argument("--config5", action="store_true", help="also measure BASELINE config 5 (464^3 over the ranks) as a second record; "
                                                            "default: only with 8 ranks")

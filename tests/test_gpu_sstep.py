@@ -234,7 +234,7 @@ def test_switch_off_is_the_per_step_path_bit_for_bit_and_callbacks_ignore_it(mon
     ws0._v1 = v1
     base, bh = pkg.partialschur_(pkg.csr_operator(A), ws0, **kw)
     ws = pkg.ArnoldiWorkspace(n, 24, np.float64)  # ... and one created with the default (on), switched to 5, then off
-    assert ws.sstep_info["s"] == 10
+    assert ws.sstep_info["s"] == 20
     ws.set_sstep(5)
     ws.set_sstep(0)
     ws._v1 = v1

@@ -88,8 +88,11 @@ def main():
         elif k in ("blk_dots", "blk_fused"):
             # s-step kernels: k_bdots<double, NCW, S, ...> reads the kb existing columns and the S new ones, k_bupdate reads the
             # same and writes the S; kb starts at `kstart` after every rotation and grows by S per block
-            mm = re.search(r"k_b(?:dots|update)(?:_ring<\d+, (\d+)|<double, \d+, (\d+))", name)   # (ring forms: <NCW, S, NW, WB>)
-            S = int(mm.group(1) or mm.group(2))
+            if re.search(r"k_b(?:dots|update)_ringL<", name):
+                S = 20                                                                            # (large-block ring forms: <NCW>)
+            else:
+                mm = re.search(r"k_b(?:dots|update)(?:_ring<\d+, (\d+)|<double, \d+, (\d+))", name)   # (ring forms: <NCW, S, NW, WB>)
+                S = int(mm.group(1) or mm.group(2))
             if k == "blk_dots":
                 kb = kstart if (blk_k is None) else blk_k
                 blk_k = kb

@@ -6,7 +6,7 @@
 set -u
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
-for cfg in cfg2 headline; do for s in 0 10; do for g in 0 1; do
+for cfg in cfg2 headline; do for s in 0 20; do for g in 0 1; do
   rm -rf /tmp/kt_$cfg$s$g
   KS_ROT_GATE=$g KS_SSTEP=$s rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_$cfg$s$g -- python tools/run_solver.py $cfg 25 > /tmp/rs_$cfg$s$g.txt 2>&1
   python tools/restart_bubble.py $(find /tmp/kt_$cfg$s$g -name '*kernel_trace.csv' | head -1) "$cfg KS_SSTEP=$s KS_ROT_GATE=$g"
@@ -14,5 +14,5 @@ for cfg in cfg2 headline; do for s in 0 10; do for g in 0 1; do
 done; done; done
 echo "# whole solves, wall time, un-profiled, alternating"
 for rep in 1 2 3; do for g in 0 1; do
-  KS_ROT_GATE=$g KS_SSTEP=10 python tools/run_solver.py cfg2 60 2>/dev/null | sed "s/^.*| restarts/cfg2 sstep=10 gate=$g: restarts/"
+  KS_ROT_GATE=$g KS_SSTEP=20 python tools/run_solver.py cfg2 60 2>/dev/null | sed "s/^.*| restarts/cfg2 sstep=20 gate=$g: restarts/"
 done; done
