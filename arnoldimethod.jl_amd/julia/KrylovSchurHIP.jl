@@ -290,7 +290,7 @@ end
 
 s-step (block) expansion for the fused `iterate_arnoldi!` / `partialschur` paths (include/kschur.h, ks_workspace_set_sstep):
 `s >= 2` takes the steps of an expansion in blocks of up to `s` -- two passes over the basis per block instead of per step.
-`0` switches it off; the library default is on (blocks of 10, `KS_SSTEP`).
+`0` switches it off; the library default is on (blocks of up to 20, `KS_SSTEP`).
 """
 function set_sstep!(w::HipWorkspace, s::Integer; pivot_min::Float64 = NaN, gram_dev_max::Float64 = NaN)
     check(ccall((:ks_workspace_set_sstep, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cdouble), w.h, s, pivot_min, gram_dev_max))

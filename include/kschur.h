@@ -232,7 +232,7 @@ int ks_workspace_set_passes(ks_workspace* ws, int passes, double max_ratio);
  * pivot below pivot_min times its diagonal entry (breakdown, src/expansion.jl:99-102, or an ill-conditioned basis) is
  * abandoned before anything is committed and its steps are redone one at a time, which takes the reference's decisions.
  * Like the implicit second pass it needs the library's provenance of the factorisation; otherwise, and for host-callback
- * operators and maxdim > 64 the expansion runs step by step.  Default s = 10 (KS_SSTEP at creation; ComplexF64 uses the largest
+ * operators and maxdim > 64 the expansion runs step by step.  Default s = 20 (KS_SSTEP at creation; instantiated block sizes: 1-5, 8 up to 48 existing columns, 10 up to 32, 20 up to 24; ComplexF64 uses the largest
  * instantiated size <= s, i.e. 5); s = 0 / 1: off -- every step then takes the reference's DGKS decisions.  A block is also abandoned when the Gram matrix of what its first stage wrote differs from I by more than
  * gram_dev_max in any entry (~ eps cond^2 of the Newton basis; the recovered H carries errors ~ eps cond): default 1e-8
  * keeps H at the per-step path's accuracy.  After an abandoned block the library lowers the block size for the following
