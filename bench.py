@@ -364,6 +364,10 @@ def main():
                     kk = k + 1
                     for sb in blk:
                         state["moved"] += sb * (spmv_b + shift_b) + 8.0 * n * (kk + sb) + 8.0 * n * (kk + 2 * sb)
+                        # FP64 work of the two block kernels per row: pass 1 (kk + (sb + 1) / 2) sb multiply-adds, pass 2
+                        # (kk + sb) sb (the update) + kk sb (inner products) + sb (sb + 1) / 2 (Gram triangle)
+                        state["blk_flops_dots"] = state.get("blk_flops_dots", 0.0) + 2.0 * n * (kk * sb + sb * (sb + 1) / 2.0)
+                        state["blk_flops_fused"] = state.get("blk_flops_fused", 0.0) + 2.0 * n * ((kk + sb) * sb + kk * sb + sb * (sb + 1) / 2.0)
                         kk += sb
                 for j in range(k + 1, maxdim + 1):
                     if not blk:
@@ -662,6 +666,11 @@ def make_line(args, pkg, passes, order, world, rank, force_dist, wl, with_cpu_ba
             "avg_launch_ms": d["ms"] / d["count"],
             "algorithmic_bytes_per_launch": d["bytes"] / d["count"],
             "traffic": traffic,
+            # the kernels of large blocks are not bound by memory alone: their FP64 vector rate beside the byte rate (flops of
+            # an average launch of the dominant class x its launches / their time; peak: 78.6 TFLOP/s FP64 vector on MI355X)
+            "fp64_vector": (lambda fl: {"achieved_TFLOPs": fl / 1e12, "peak_TFLOPs": 78.6, "frac": fl / 1e12 / 78.6})(
+                state.get("blk_flops_" + dom, 0.0) / max(1, state.get("blk_blocks", 0)) * d["count"] / (d["ms"] * 1e-3) / world)
+            if (sst and state.get("blk_cycles", 0) and dom in ("dots", "fused") and d["ms"] > 0) else None,
             "per_class": {k: {"ms_total": v["ms"], "launches": v["count"],
                               "GBps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 and v["bytes"] > 0 else None}
                           for k, v in prof.items()},
