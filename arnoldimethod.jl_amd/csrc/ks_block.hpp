@@ -107,6 +107,7 @@ void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::v
   int k = from;   // existing columns == index of the block's first step
   int first = 1;
   for (int s : sizes) {
+    op->shift_store_cacheable = s >= 10;   // (ks_operators.hpp: pays with one inner-product pass per ten or twenty products)
     for (int i = 0; i < s; ++i) {
       double tre, tim;
       if constexpr (sizeof(D) == 8) { tre = sh.theta[i]; tim = 0.0; }

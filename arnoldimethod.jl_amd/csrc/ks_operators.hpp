@@ -18,6 +18,13 @@ struct ks_operator {
   // library's own operators are linear and do not care, a HOST callback is handed the vector scaled to unit norm and its
   // result is scaled back (a user's inner solver may use absolute tolerances).  Set by the expansion before apply().
   double in_scale = 1.0;
+  // Newton products of a LONG block (s-step expansion, ks_block.hpp): the product is stored cacheably instead of streaming --
+  // the next product of the chain gathers exactly this vector (49 instead of 59 us at n = 1e7), and the dirty lines cost the
+  // ONE inner-product pass that follows a block of 20 less (+45 us) than the twenty products gain (headline 4 332 -> 4 501
+  // iterations/s; blocks of 10 with the ring form of pass 1: 3 836 -> 3 923).  With the register form of pass 1 and blocks of
+  // 5-8 it was the other way round (products 61 -> 51 us, pass 1 415 -> 510 us), so shorter blocks keep streaming stores.
+  // KS_SHIFT_PLAIN = 0 / 1 forces.
+  bool shift_store_cacheable = false;
   virtual ~ks_operator() = default;
   // y = A x on device pointers, enqueued on ctx->stream; `st` lets the kernels of a batch skip work
   // after a breakdown.
@@ -133,6 +140,10 @@ template <class D> struct CsrOp : ks_operator {
   bool shift_on = false;
   D shift_theta{};
   double shift_sigma = 1.0;
+  bool shift_plain() const {
+    static const int env = env_int("KS_SHIFT_PLAIN", -1);
+    return env >= 0 ? env != 0 : shift_store_cacheable;
+  }
   ksd::ShiftArg<D> shift_arg() const {
     ksd::ShiftArg<D> a;
     a.on = shift_on ? 1 : 0;
@@ -276,9 +287,9 @@ template <class D> struct CsrOp : ks_operator {
         // two rows per lane, 16-byte gathers (no ghost columns: single GPU)
         const int nt = (int)(((n_local + 1) / 2 + kBlock - 1) / kBlock);
         if (stencil_mask_bytes == 1)
-          ksd::k_spmv_stencil2<D, uint16_t><<<nt, kBlock, 0, s>>>(static_cast<const uint16_t*>(smask2), sdict, nstencil, x, y, n_local, nt, st, shift_on ? (1 | (env_int("KS_SHIFT_PLAIN", 0) ? 2 : 0)) : 0, shift_theta, shift_sigma);
+          ksd::k_spmv_stencil2<D, uint16_t><<<nt, kBlock, 0, s>>>(static_cast<const uint16_t*>(smask2), sdict, nstencil, x, y, n_local, nt, st, shift_on ? (1 | (shift_plain() ? 2 : 0)) : 0, shift_theta, shift_sigma);
         else
-          ksd::k_spmv_stencil2<D, uint64_t><<<nt, kBlock, 0, s>>>(static_cast<const uint64_t*>(smask2), sdict, nstencil, x, y, n_local, nt, st, shift_on ? (1 | (env_int("KS_SHIFT_PLAIN", 0) ? 2 : 0)) : 0, shift_theta, shift_sigma);
+          ksd::k_spmv_stencil2<D, uint64_t><<<nt, kBlock, 0, s>>>(static_cast<const uint64_t*>(smask2), sdict, nstencil, x, y, n_local, nt, st, shift_on ? (1 | (shift_plain() ? 2 : 0)) : 0, shift_theta, shift_sigma);
         KS_HIP(hipGetLastError());
         return;
       }
