@@ -90,6 +90,22 @@ def test_blocks_reproduce_the_per_step_expansion_float64(s):
     assert seen >= 1
 
 
+@pytest.mark.parametrize("mindim,maxdim", [(19, 40), (21, 42), (23, 44)])
+def test_large_blocks_at_every_instantiated_width(mindim, maxdim):
+    """Blocks of 20 exist for 20-24 existing columns (k_bdots_ringL<6>, k_bupdate_ringL<10 / 11 / 12>): lockstep against the
+    per-step path with the restart leaving 20, 22 and 24 columns."""
+    seen = 0
+    for cyc, Hs, Hb, Vs, Vb, rel, orth, info in _lockstep(laplace3d(20, 21, 22), np.float64, 20, 12, mindim, maxdim, "SR", 3):
+        if cyc == 0:
+            continue
+        assert info["blocks"] > 0 and info["abandoned"] == 0 and info["s"] == 20, info
+        assert np.abs(Hs - Hb).max() <= 1e-11 * np.abs(Hs).max(), (cyc, np.abs(Hs - Hb).max())
+        assert np.abs(Vs - Vb).max() <= 1e-9, (cyc, np.abs(Vs - Vb).max())
+        assert rel <= 1e-12 * np.linalg.norm(Hb) * 10 and orth <= 1e-13
+        seen += 1
+    assert seen >= 1
+
+
 @pytest.mark.parametrize("s", [2, 5])
 def test_blocks_reproduce_the_per_step_expansion_complex_and_nonsymmetric(s):
     for A, dtype, which in ((_complex_op(), np.complex128, "LM"), (_nonsym(), np.float64, "LM")):
