@@ -176,7 +176,11 @@ template <class T> struct HipBackend : ks::Backend<T> {
           ws->sstep_eff = ws->sstep_eff >= 4 ? ws->sstep_eff / 2 : (ws->sstep_eff > 2 ? 2 : 1);
           ws->blk_clean = 0;
         } else if (++ws->blk_clean >= 16 && ws->sstep_eff < ws->sstep) {
-          ws->sstep_eff = std::min(ws->sstep, std::max(2, ws->sstep_eff + 1));   // (probe a larger block again)
+          // (probe a larger block again: the next instantiated size -- 2 3 4 5 8 10 20 --, not one step more: from 10
+          // the sizes 11..19 would all run as blocks of 10)
+          int nxt = ws->sstep_eff + 1;
+          for (int cand : {2, 3, 4, 5, 8, 10, 20}) if (cand > ws->sstep_eff) { nxt = cand; break; }
+          ws->sstep_eff = std::min(ws->sstep, std::max(2, nxt));
           ws->blk_clean = 0;
         }
         stats.blocks += (int)blk_sizes.size() - (blk_bail >= 0 ? 1 : 0);
