@@ -15,12 +15,12 @@ CSRC = os.path.join(HERE, "csrc")
 SRC = os.path.join(CSRC, "ks_hip.hip")
 BLK = os.path.join(CSRC, "ks_block_inst.hip")
 HEADERS = [os.path.join(CSRC, f) for f in ("ks_kernels.hpp", "ks_p2p.hpp", "ks_driver.hpp", "ks_smalldense.hpp", "ks_context.hpp", "ks_operators.hpp", "ks_sptrsv.hpp",
-                                           "ks_workspace.hpp", "ks_backend.hpp", "ks_block.hpp", "ks_block_kernels.hpp", "ks_block_launch.hpp")]
+                                           "ks_workspace.hpp", "ks_backend.hpp", "ks_block.hpp", "ks_block_kernels.hpp", "ks_block_launch.hpp", "ks_block_mfma.hpp")]
 DEPS = [SRC, BLK] + HEADERS + [os.path.join(HERE, "..", "include", "kschur.h")]
 OUT = os.path.join(HERE, "libkschur_hip.so")
 OBJDIR = os.path.join(HERE, "build")   # git-ignored and gpurun-ignored scratch: only the .so travels
 # object -> (source, extra flags, the files it depends on)
-BLK_DEPS = [BLK] + [os.path.join(CSRC, f) for f in ("ks_kernels.hpp", "ks_p2p.hpp", "ks_block_kernels.hpp", "ks_block_launch.hpp")]
+BLK_DEPS = [BLK] + [os.path.join(CSRC, f) for f in ("ks_kernels.hpp", "ks_p2p.hpp", "ks_block_kernels.hpp", "ks_block_launch.hpp", "ks_block_mfma.hpp")]
 UNITS = {
     "ks_hip.o": (SRC, [], DEPS),
     "ks_block_inst0.o": (BLK, ["-DKS_BLK_PART=0"], BLK_DEPS),

@@ -8,6 +8,7 @@
 #include <string>
 
 #include "ks_block_kernels.hpp"
+#include "ks_block_mfma.hpp"
 #include "ks_block_launch.hpp"
 
 #ifndef KS_BLK_PART
@@ -116,7 +117,56 @@ template <int NCW2> int go_ringL1(const BlkLaunchArgs& a) {
   return nb;
 }
 
+
+// matrix-instruction forms (ks_block_mfma.hpp): row slabs per wave, no barrier in the loop.  KS_BLK_MFMA=0: the ring forms.
+inline int mfma_env() { static const int v = [] { const char* e = std::getenv("KS_BLK_MFMA"); return e ? std::atoi(e) : 3; }(); return v; }
+inline int mfma_ring_env() { static const int v = [] { const char* e = std::getenv("KS_BLK_MFMA_RING"); return e ? std::atoi(e) : 3; }(); return v; }
+template <int NGS, int NT> int go_mfma(int which, const BlkLaunchArgs& a) {
+  using C = ksd::BlkMfma<NGS, NT>;
+  int ring = mfma_ring_env();
+  while (ring > 2 && C::lds_bytes(ring) > 160 * 1024) --ring;
+  const size_t smem = C::lds_bytes(ring);
+  if (ring < 2 || smem > 160 * 1024) throw std::runtime_error("block kernels: slab ring does not fit the LDS");
+  const int nb = cap(a, a.num_cu, 64, sizeof(double));
+  const int dbg = a.dbg | (a.nt ? 64 : 0);
+  if (which == 0) {
+    auto kern = ksd::k_bdots_mfma<NGS, NT>;
+    static bool attr = false;
+    if (!attr) {
+      hipcheck(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "dynamic LDS size");
+      attr = true;
+    }
+    kern<<<nb, 512, smem, a.stream>>>(static_cast<const double*>(a.V), a.ld, a.k, a.s, ring, static_cast<double*>(a.partial), a.pnb,
+                                     static_cast<const ksd::DevState*>(a.st), dbg, static_cast<const double*>(a.zeros));
+  } else {
+    auto kern = ksd::k_bupdate_mfma<NGS, NT>;
+    static bool attr = false;
+    if (!attr) {
+      hipcheck(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "dynamic LDS size");
+      attr = true;
+    }
+    kern<<<nb, 512, smem, a.stream>>>(static_cast<double*>(a.V), a.ld, a.k, a.s, ring, static_cast<const double*>(a.coefp), a.k,
+                                     static_cast<const double*>(a.r1inv), static_cast<double*>(a.partial), a.pnb,
+                                     static_cast<const ksd::DevState*>(a.st), dbg, static_cast<const double*>(a.zeros));
+  }
+  return nb;
+}
+template <int NT> int go_mfma_by_k(int which, const BlkLaunchArgs& a) {
+  switch ((a.k + 3) / 4) {
+    case 1: return go_mfma<1, NT>(which, a);
+    case 2: return go_mfma<2, NT>(which, a);
+    case 3: return go_mfma<3, NT>(which, a);
+    case 4: return go_mfma<4, NT>(which, a);
+    case 5: return go_mfma<5, NT>(which, a);
+    case 6: return go_mfma<6, NT>(which, a);
+    default: throw std::runtime_error("block kernels: no matrix-instruction form for this many columns");
+  }
+}
+
 template <class D, int NCW, int S, int NW = 4, int WB = 1> int go(int which, const BlkLaunchArgs& a) {
+  if constexpr (sizeof(D) == 8 && S == 20) {
+    if ((mfma_env() >> which) & 1) return go_mfma_by_k<5>(which, a);
+  }
   if constexpr (sizeof(D) == 8 && NW == 8 && S == 20) {
     if (which == 0 && (ring_env() & 1)) return go_ringL0<NCW>(a);
     if (which == 1 && (ring_env() & 2)) {

@@ -1,0 +1,313 @@
+// gfx950 streaming kernels of the s-step expansion on the FP64 matrix instruction (v_mfma_f64_4x4x4_4b_f64), Float64 blocks
+// of up to 4 NT steps on up to 4 NGS existing columns.  Same results (entry layout of `partial`) as k_bdots / k_bupdate of
+// ks_block_kernels.hpp; the sums are taken in a different order (tests compare the two at rounding level).
+//
+// Why.  The vector forms keep one partial sum PER LANE for every inner product: 20 k + 210 accumulators at s = 20 do not fit
+// one wave, so the accumulators are dealt over the eight waves of a workgroup and EVERY wave reads every row of the tile from
+// LDS, in lock-step through three barriers per tile (k_bupdate_ringL: 0.42 of the HBM rate; memory, LDS and arithmetic phases
+// never overlap).  A 4x4x4 matrix instruction sums over the rows inside the instruction: a 4 x 4 tile of inner products is ONE
+// accumulator register pair per lane, the whole (k + s) x s result of a pass is 45 of them, and a wave can own a SLAB OF ROWS
+// with everything that belongs to it: no data is shared between waves, no barrier inside the loop, every wave runs its own ring
+// of asynchronous global -> LDS copies and drifts freely against the others (that is what overlaps the three pipes).
+// The FP64 matrix pipe is not extra arithmetic (tools/fp64_pipes.hip, profiles/r05_fp64_pipes.txt: 16.7 cycles per
+// instruction = the vector rate, and the two do not add up); what it buys is 256 multiply-adds per issued instruction with
+// 2 operand registers, and the 64-fold smaller accumulator footprint.
+//
+// Lane layout of D = A B + C, four independent 4x4x4 blocks b (tools/mfma4_layout.hip):
+//   A_b[i][k] in lane 16 k + 4 b + i,   B_b[k][j] in lane 16 k + 4 b + j,   D_b[i][j] in lane 16 i + 4 b + j
+// hence a result register read as the B operand is the same 4 x 4 matrix, read as the A operand it is its TRANSPOSE.
+//
+// Rows: a workgroup walks its row range in tiles of 64 packs (128 rows); wave w owns the 16 rows 16 w .. 16 w + 15 of every
+// tile (a SLAB), block b of an instruction the rows 4 b .. 4 b + 3 of the slab.
+// LDS slab: the k existing columns in 1-KiB groups of eight (column c at (c / 8) KiB + (c % 8) * 128 B, 16 rows of 8 B), then
+// the block's columns in the same way starting at a fresh group.  One global_load_lds_dwordx4 fills one group: lane l copies
+// pack l % 8 of column l / 8 (128 contiguous bytes per column).  Two read patterns:
+//   linear  (lane l: row l % 16, column l / 16 of a 4-column group)  = byte 8 l of the group's half          -> A of Z R - S c
+//   gather  (lane l: row 4 ((l / 4) % 4) + l / 16, column l % 4)                                              -> A / B of the inner products
+#pragma once
+
+#include "ks_block_kernels.hpp"
+
+namespace ksd {
+
+__device__ __forceinline__ double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ void wait_vm(int n) {
+#define KS_VMW(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory"); break;
+  switch (n) {
+    KS_VMW(0) KS_VMW(1) KS_VMW(2) KS_VMW(3) KS_VMW(4) KS_VMW(5) KS_VMW(6) KS_VMW(7) KS_VMW(8) KS_VMW(9) KS_VMW(10) KS_VMW(11)
+    KS_VMW(12) KS_VMW(13) KS_VMW(14) KS_VMW(15) KS_VMW(16) KS_VMW(17) KS_VMW(18) KS_VMW(19) KS_VMW(20) KS_VMW(21) KS_VMW(22)
+    KS_VMW(23) KS_VMW(24) KS_VMW(25) KS_VMW(26) KS_VMW(27) KS_VMW(28) KS_VMW(29) KS_VMW(30) KS_VMW(31) KS_VMW(32) KS_VMW(33)
+    KS_VMW(34) KS_VMW(35) KS_VMW(36) KS_VMW(37) KS_VMW(38) KS_VMW(39) KS_VMW(40)
+    default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+  }
+#undef KS_VMW
+}
+// 8-byte streaming store from inline assembly (counted by hand on the vector-memory counter)
+__device__ __forceinline__ void gst16(double* p, double2 v) {
+  blk_d2v w;
+  w.x = v.x;
+  w.y = v.y;
+  asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(p), "v"(w) : "memory");
+}
+__device__ __forceinline__ void gst8_nt(double* p, double v) { asm volatile("global_store_dwordx2 %0, %1, off nt" :: "v"(p), "v"(v) : "memory"); }
+
+template <int NGS, int NT> struct BlkMfma {
+  static constexpr int NJS = (NGS + 1) / 2, NJZ = (NT + 1) / 2, NJ = NJS + NJZ;   // 1-KiB groups (= copies) per slab
+  static constexpr int SLAB = NJ * 1024;                                          // bytes
+  static constexpr int NTS = NGS * NT, NTG = NT * (NT + 1) / 2, NTILE = NTS + NTG; // result tiles: S^H X, upper triangle of X^H X
+  static constexpr int MBYTES = NTILE * 128;                                       // coefficient tiles of the second pass
+  __host__ __device__ static constexpr int s_off(int g) { return (g / 2) * 1024 + (g % 2) * 512; }
+  __host__ __device__ static constexpr int z_off(int t) { return NJS * 1024 + (t / 2) * 1024 + (t % 2) * 512; }
+  __host__ __device__ static constexpr int gt(int a, int t) { return t * (t + 1) / 2 + a; }   // tile (a, t), a <= t, of the triangle
+  static constexpr size_t lds_bytes(int ring) { return (size_t)8 * ring * SLAB + MBYTES; }
+};
+
+// per-wave accumulators -> partial[entry][workgroup].  acc: NTILE registers in the D layout (one 4 x 4 tile per block b).
+template <int NGS, int NT>
+__device__ __forceinline__ void blkm_finish(double* acc, unsigned char* lds, int lane, int wave, int k, int s, double* __restrict__ partial, int pnb) {
+  using C = BlkMfma<NGS, NT>;
+  double* red = reinterpret_cast<double*>(lds);   // [wave][tile][16]
+  __syncthreads();                                // every wave is done with its ring
+#pragma unroll
+  for (int e = 0; e < C::NTILE; ++e) {
+    double v = acc[e];
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    if ((lane & 12) == 0) red[(wave * C::NTILE + e) * 16 + (lane >> 4) * 4 + (lane & 3)] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < C::NTILE * 16; e += 512) {
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v += red[w * C::NTILE * 16 + e];
+    const int tile = e >> 4, ii = (e >> 2) & 3, jj = e & 3;
+    int entry = -1;
+    if (tile < C::NTS) {
+      const int g = tile / NT, t = tile % NT, c = 4 * g + ii, i = 4 * t + jj;
+      if (c < k && i < s) entry = i * k + c;
+    } else {
+      int t = 0, rem = tile - C::NTS;
+      while (rem > t) { rem -= t + 1; ++t; }
+      const int a = rem, i = 4 * a + ii, i2 = 4 * t + jj;
+      if (i <= i2 && i2 < s) entry = k * s + gram_idx(i, i2);
+    }
+    if (entry >= 0) partial[(int64_t)entry * pnb + blockIdx.x] = v;
+  }
+}
+
+
+// rows of a workgroup: tiles of 64 packs.  Contiguous: one range per workgroup (block_range).  Interleaved: workgroup b takes the
+// tiles b, b + nb, b + 2 nb, ... -- at any moment the chip works on ONE window of ~nb consecutive tiles, so neighbouring
+// workgroups share the DRAM pages they open.
+__device__ __forceinline__ void blkm_rows(int64_t npacks, bool interleave, int64_t& pb, int64_t& pe, int64_t& tstep, int& niter) {
+  if (!interleave) {
+    block_range(npacks, blockIdx.x, gridDim.x, pb, pe);
+    tstep = 64;
+    niter = (int)((pe - pb + 63) / 64);
+  } else {
+    const int64_t ntiles = (npacks + 63) / 64;
+    pb = (int64_t)blockIdx.x * 64;
+    pe = npacks;
+    tstep = (int64_t)gridDim.x * 64;
+    niter = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+    if (niter < 0) niter = 0;
+  }
+}
+
+// the copies of one slab: S columns (zeros beyond k), block columns (zeros beyond s); rows past the range: zeros
+template <int NGS, int NT>
+__device__ __forceinline__ void blkm_issue(const double* __restrict__ V, int64_t ldv, int k, int s, int64_t pack0, int64_t pe, int lane,
+                                           uint32_t slab_lds, const double* __restrict__ zeros, bool nt) {
+  using C = BlkMfma<NGS, NT>;
+  const int64_t p = pack0 + (lane & 7);
+  const bool in = p < pe;
+  const int cl = lane >> 3;
+#pragma unroll
+  for (int j = 0; j < C::NJ; ++j) {
+    const int c = j < C::NJS ? 8 * j + cl : 8 * (j - C::NJS) + cl;     // column inside its region
+    const bool have = in && (j < C::NJS ? c < k : c < s);
+    const double* src = have ? V + (int64_t)(j < C::NJS ? c : k + c) * ldv + p * 2 : zeros;
+    if (nt) glds16_nt(src, slab_lds + (uint32_t)j * 1024u);
+    else glds16(src, slab_lds + (uint32_t)j * 1024u);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// pass 1:  partial[i k + c] = S[:, c] . Z[:, i],  partial[k s + g(i, i2)] = Z[:, i] . Z[:, i2]        (k <= 4 NGS, s <= 4 NT)
+// Dynamic LDS: 8 waves x ring x slab.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int NGS, int NT>
+__global__ void __launch_bounds__(512, 2)
+    k_bdots_mfma(const double* __restrict__ V, int64_t ldv, int k, int s, int ring, double* __restrict__ partial, int pnb,
+                 const DevState* __restrict__ st, int dbg, const double* __restrict__ zeros) {
+  if (st && st->breakdown >= 0) return;
+  using C = BlkMfma<NGS, NT>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned char* myring = lds_raw + (size_t)wave * ring * C::SLAB;
+  const uint32_t ring_lds = (uint32_t)(uintptr_t)myring;
+  const int gat = (lane & 3) * 128 + (4 * ((lane >> 2) & 3) + (lane >> 4)) * 8;
+  double acc[C::NTILE];
+#pragma unroll
+  for (int e = 0; e < C::NTILE; ++e) acc[e] = 0.0;
+  int64_t pb, pe, tstep;
+  int niter;
+  blkm_rows(ldv / 2, (dbg & 8) != 0, pb, pe, tstep, niter);
+  const bool nt = (dbg & 64) != 0;
+  auto issue = [&](int it, int sl) {
+    if (dbg & 32) return;
+    blkm_issue<NGS, NT>(V, ldv, k, s, pb + (int64_t)it * tstep + wave * 8, pe, lane, ring_lds + (uint32_t)(sl * C::SLAB), zeros, nt);
+  };
+  for (int it = 0; it < ring - 1; ++it) issue(it, it);
+  int sl_cur = 0, sl_new = ring - 1;
+  for (int it = 0; it < niter; ++it) {
+    wait_vm((ring - 2) * C::NJ);           // slab `it` has landed (copies of this wave complete in order)
+    issue(it + ring - 1, sl_new);          // into the slot of slab it - 1 (its reads have returned: lgkmcnt(0) above)
+    const unsigned char* slab = myring + (size_t)sl_cur * C::SLAB;
+    sl_new = sl_cur;
+    sl_cur = sl_cur + 1 == ring ? 0 : sl_cur + 1;
+    if (dbg & 16) continue;
+    double a[NGS], z[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) z[t] = *reinterpret_cast<const double*>(slab + C::z_off(t) + gat);
+#pragma unroll
+    for (int g = 0; g < NGS; ++g) a[g] = *reinterpret_cast<const double*>(slab + C::s_off(g) + gat);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q <= t; ++q) acc[C::NTS + C::gt(q, t)] = mfma4(z[q], z[t], acc[C::NTS + C::gt(q, t)]);
+#pragma unroll
+    for (int g = 0; g < NGS; ++g)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[g * NT + t] = mfma4(a[g], z[t], acc[g * NT + t]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  blkm_finish<NGS, NT>(acc, lds_raw, lane, wave, k, s, partial, pnb);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// pass 2:  Qt = Z R1inv - S coefp (in place over Z);  partial[i k + c] = S[:, c] . Qt[:, i];  Gram of Qt.
+// Per slab: Qt tile t = sum_g S_g M_{g,t} + sum_{u <= t} Z_u M'_{u,t}  (M = -coefp, M' = R1inv: upper triangular, so the
+// tiles below the diagonal are skipped), 4 x 4 coefficient tiles read from LDS in the B layout; the result registers are
+// stored, and ARE the operands of the inner products (as B: Qt, as A: Qt^T).
+// Dynamic LDS: 8 waves x ring x slab | coefficient tiles.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int NGS, int NT>
+__global__ void __launch_bounds__(512, 2)
+    k_bupdate_mfma(double* __restrict__ V, int64_t ldv, int k, int s, int ring, const double* __restrict__ coefp, int ldc,
+                   const double* __restrict__ r1inv, double* __restrict__ partial, int pnb, const DevState* __restrict__ st, int dbg,
+                   const double* __restrict__ zeros) {
+  if (st && st->breakdown >= 0) return;
+  using C = BlkMfma<NGS, NT>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned char* myring = lds_raw + (size_t)wave * ring * C::SLAB;
+  const uint32_t ring_lds = (uint32_t)(uintptr_t)myring;
+  double* mt = reinterpret_cast<double*>(lds_raw + (size_t)8 * ring * C::SLAB);   // [tile][k][j]
+  for (int e = threadIdx.x; e < C::NTILE * 16; e += 512) {
+    const int tile = e >> 4, kk = (e >> 2) & 3, jj = e & 3;
+    double v = 0.0;
+    if (tile < C::NTS) {
+      const int g = tile / NT, t = tile % NT, c = 4 * g + kk, i = 4 * t + jj;
+      if (c < k && i < s) v = -coefp[c + (int64_t)i * ldc];
+    } else {
+      int t = 0, rem = tile - C::NTS;
+      while (rem > t) { rem -= t + 1; ++t; }
+      const int l = 4 * rem + kk, i = 4 * t + jj;
+      if (l <= i && i < s) v = r1inv[l + i * s];
+    }
+    mt[e] = v;
+  }
+  __syncthreads();
+  const int lin = lane * 8;
+  const int gat = (lane & 3) * 128 + (4 * ((lane >> 2) & 3) + (lane >> 4)) * 8;
+  const double* mrd = mt + (lane >> 4) * 4 + (lane & 3);
+  double acc[C::NTILE];
+#pragma unroll
+  for (int e = 0; e < C::NTILE; ++e) acc[e] = 0.0;
+  int64_t pb, pe, tstep;
+  int niter;
+  blkm_rows(ldv / 2, (dbg & 8) != 0, pb, pe, tstep, niter);
+  const bool nt = (dbg & 64) != 0;
+  // stores of a slab: the result tiles go back into the slab's (consumed) block columns, from where the wave writes 16 bytes
+  // per lane, 128 contiguous bytes per column (dbg & 2: 8 bytes per lane straight from the result registers -- measured:
+  // 988 against ... us at k = 21, s = 20)
+  const bool direct = (dbg & 2) != 0;
+  const int nst = (dbg & 1) ? 0 : (direct ? NT : C::NJZ);
+  auto issue = [&](int it, int sl) {
+    blkm_issue<NGS, NT>(V, ldv, k, s, pb + (int64_t)it * tstep + wave * 8, pe, lane, ring_lds + (uint32_t)(sl * C::SLAB), zeros, nt);
+  };
+  // this lane's element of a result tile: row 4 b + i of the slab, column j of the tile
+  const int row = 4 * ((lane >> 2) & 3) + (lane >> 4), cj = lane & 3;
+  const int koff = (dbg & 128) ? k + 4 * NT : k;   // (probe: out of place, into the columns behind the block)
+  double* zst = V + (int64_t)(koff + cj) * ldv + row;
+  double* zst16 = V + (int64_t)(koff + (lane >> 3)) * ldv + (lane & 7) * 2;   // staged form: column lane / 8 (+ 8 per store), pack lane % 8
+  for (int it = 0; it < ring - 1; ++it) issue(it, it);
+  int sl_cur = 0, sl_new = ring - 1;
+  for (int it = 0; it < niter; ++it) {
+    // queue of this wave, oldest first: copies(it) stores(it - ring + 1) copies(it + 1) ... copies(it + ring - 2) stores(it - 1)
+    wait_vm((ring - 2) * C::NJ + (it < ring - 1 ? it : ring - 1) * nst);
+    issue(it + ring - 1, sl_new);
+    unsigned char* slab = myring + (size_t)sl_cur * C::SLAB;
+    sl_new = sl_cur;
+    sl_cur = sl_cur + 1 == ring ? 0 : sl_cur + 1;
+    const int64_t pack0 = pb + (int64_t)it * tstep + wave * 8;
+    double x[NGS], zx[NT], d[NT];
+#pragma unroll
+    for (int g = 0; g < NGS; ++g) x[g] = *reinterpret_cast<const double*>(slab + C::s_off(g) + lin);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) zx[u] = *reinterpret_cast<const double*>(slab + C::z_off(u) + lin);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) d[t] = 0.0;
+#pragma unroll
+    for (int g = 0; g < NGS; ++g)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) d[t] = mfma4(x[g], mrd[(g * NT + t) * 16], d[t]);
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int t = u; t < NT; ++t) d[t] = mfma4(zx[u], mrd[(C::NTS + C::gt(u, t)) * 16], d[t]);
+    if (nst) {
+      if (direct) {
+        const bool ok = pack0 + (row >> 1) < pe;
+        double* dst = zst + pack0 * 2;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (ok && 4 * t + cj < s) gst8_nt(dst + (int64_t)(4 * t) * ldv, d[t]);
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) *reinterpret_cast<double*>(slab + C::z_off(t) + gat) = d[t];
+        asm volatile("" ::: "memory");   // (the reads below are of another type: keep them behind the writes)
+        const bool ok = pack0 + (lane & 7) < pe;
+        double* dst = zst16 + pack0 * 2;
+#pragma unroll
+        for (int j = 0; j < C::NJZ; ++j) {
+          const double2 v = *reinterpret_cast<const double2*>(slab + C::NJS * 1024 + j * 1024 + lane * 16);
+          if (ok && 8 * j + (lane >> 3) < s) {
+            if (dbg & 256) gst16_nt(V + (int64_t)koff * ldv + (pack0 * (4 * NT) + j * 64 + lane) * 2, v);   // (probe: ONE write stream, same bytes)
+            else if (dbg & 4) gst16(dst + (int64_t)(8 * j) * ldv, v);
+            else gst16_nt(dst + (int64_t)(8 * j) * ldv, v);
+          }
+        }
+      }
+    }
+    double a[NGS];
+#pragma unroll
+    for (int g = 0; g < NGS; ++g) a[g] = *reinterpret_cast<const double*>(slab + C::s_off(g) + gat);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q <= t; ++q) acc[C::NTS + C::gt(q, t)] = mfma4(d[q], d[t], acc[C::NTS + C::gt(q, t)]);
+#pragma unroll
+    for (int g = 0; g < NGS; ++g)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[g * NT + t] = mfma4(a[g], d[t], acc[g * NT + t]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  blkm_finish<NGS, NT>(acc, lds_raw, lane, wave, k, s, partial, pnb);
+}
+
+}  // namespace ksd
