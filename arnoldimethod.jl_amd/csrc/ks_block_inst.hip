@@ -119,7 +119,7 @@ template <int NCW2> int go_ringL1(const BlkLaunchArgs& a) {
 
 
 // matrix-instruction forms (ks_block_mfma.hpp): row slabs per wave, no barrier in the loop.  KS_BLK_MFMA=0: the ring forms.
-inline int mfma_env() { static const int v = [] { const char* e = std::getenv("KS_BLK_MFMA"); return e ? std::atoi(e) : 3; }(); return v; }
+inline int mfma_env() { static const int v = [] { const char* e = std::getenv("KS_BLK_MFMA"); return e ? std::atoi(e) : 63; }(); return v; }
 inline int mfma_ring_env() { static const int v = [] { const char* e = std::getenv("KS_BLK_MFMA_RING"); return e ? std::atoi(e) : 3; }(); return v; }
 template <int NGS, int NT> int go_mfma(int which, const BlkLaunchArgs& a) {
   using C = ksd::BlkMfma<NGS, NT>;
@@ -151,21 +151,24 @@ template <int NGS, int NT> int go_mfma(int which, const BlkLaunchArgs& a) {
   }
   return nb;
 }
-template <int NT> int go_mfma_by_k(int which, const BlkLaunchArgs& a) {
-  switch ((a.k + 3) / 4) {
-    case 1: return go_mfma<1, NT>(which, a);
-    case 2: return go_mfma<2, NT>(which, a);
-    case 3: return go_mfma<3, NT>(which, a);
-    case 4: return go_mfma<4, NT>(which, a);
-    case 5: return go_mfma<5, NT>(which, a);
-    case 6: return go_mfma<6, NT>(which, a);
-    default: throw std::runtime_error("block kernels: no matrix-instruction form for this many columns");
+template <int NT, int MAXG, int G = 1> int go_mfma_by_k(int which, const BlkLaunchArgs& a) {
+  if constexpr (G > MAXG) {
+    throw std::runtime_error("block kernels: no matrix-instruction form for this many columns");
+  } else {
+    if ((a.k + 3) / 4 == G) return go_mfma<G, NT>(which, a);
+    return go_mfma_by_k<NT, MAXG, G + 1>(which, a);
   }
 }
 
 template <class D, int NCW, int S, int NW = 4, int WB = 1> int go(int which, const BlkLaunchArgs& a) {
   if constexpr (sizeof(D) == 8 && S == 20) {
-    if ((mfma_env() >> which) & 1) return go_mfma_by_k<5>(which, a);
+    if ((mfma_env() >> which) & 1) return go_mfma_by_k<5, 6>(which, a);
+  }
+  if constexpr (sizeof(D) == 8 && S == 10) {
+    if ((mfma_env() >> (which + 2)) & 1) return go_mfma_by_k<3, 8>(which, a);
+  }
+  if constexpr (sizeof(D) == 8 && S == 8) {
+    if ((mfma_env() >> (which + 4)) & 1) return go_mfma_by_k<2, 12>(which, a);
   }
   if constexpr (sizeof(D) == 8 && NW == 8 && S == 20) {
     if (which == 0 && (ring_env() & 1)) return go_ringL0<NCW>(a);

@@ -43,12 +43,6 @@ __device__ __forceinline__ void wait_vm(int n) {
 #undef KS_VMW
 }
 // 8-byte streaming store from inline assembly (counted by hand on the vector-memory counter)
-__device__ __forceinline__ void gst16(double* p, double2 v) {
-  blk_d2v w;
-  w.x = v.x;
-  w.y = v.y;
-  asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(p), "v"(w) : "memory");
-}
 __device__ __forceinline__ void gst8_nt(double* p, double v) { asm volatile("global_store_dwordx2 %0, %1, off nt" :: "v"(p), "v"(v) : "memory"); }
 
 template <int NGS, int NT> struct BlkMfma {
@@ -96,24 +90,6 @@ __device__ __forceinline__ void blkm_finish(double* acc, unsigned char* lds, int
 }
 
 
-// rows of a workgroup: tiles of 64 packs.  Contiguous: one range per workgroup (block_range).  Interleaved: workgroup b takes the
-// tiles b, b + nb, b + 2 nb, ... -- at any moment the chip works on ONE window of ~nb consecutive tiles, so neighbouring
-// workgroups share the DRAM pages they open.
-__device__ __forceinline__ void blkm_rows(int64_t npacks, bool interleave, int64_t& pb, int64_t& pe, int64_t& tstep, int& niter) {
-  if (!interleave) {
-    block_range(npacks, blockIdx.x, gridDim.x, pb, pe);
-    tstep = 64;
-    niter = (int)((pe - pb + 63) / 64);
-  } else {
-    const int64_t ntiles = (npacks + 63) / 64;
-    pb = (int64_t)blockIdx.x * 64;
-    pe = npacks;
-    tstep = (int64_t)gridDim.x * 64;
-    niter = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
-    if (niter < 0) niter = 0;
-  }
-}
-
 // the copies of one slab: S columns (zeros beyond k), block columns (zeros beyond s); rows past the range: zeros
 template <int NGS, int NT>
 __device__ __forceinline__ void blkm_issue(const double* __restrict__ V, int64_t ldv, int k, int s, int64_t pack0, int64_t pe, int lane,
@@ -151,13 +127,13 @@ __global__ void __launch_bounds__(512, 2)
   double acc[C::NTILE];
 #pragma unroll
   for (int e = 0; e < C::NTILE; ++e) acc[e] = 0.0;
-  int64_t pb, pe, tstep;
-  int niter;
-  blkm_rows(ldv / 2, (dbg & 8) != 0, pb, pe, tstep, niter);
+  int64_t pb, pe;
+  block_range(ldv / 2, blockIdx.x, gridDim.x, pb, pe);   // (pack-granular on purpose: ranges aligned to whole tiles ran 4 % slower)
+  const int niter = (int)((pe - pb + 63) / 64);
   const bool nt = (dbg & 64) != 0;
   auto issue = [&](int it, int sl) {
     if (dbg & 32) return;
-    blkm_issue<NGS, NT>(V, ldv, k, s, pb + (int64_t)it * tstep + wave * 8, pe, lane, ring_lds + (uint32_t)(sl * C::SLAB), zeros, nt);
+    blkm_issue<NGS, NT>(V, ldv, k, s, pb + (int64_t)it * 64 + wave * 8, pe, lane, ring_lds + (uint32_t)(sl * C::SLAB), zeros, nt);
   };
   for (int it = 0; it < ring - 1; ++it) issue(it, it);
   int sl_cur = 0, sl_new = ring - 1;
@@ -227,33 +203,31 @@ __global__ void __launch_bounds__(512, 2)
   double acc[C::NTILE];
 #pragma unroll
   for (int e = 0; e < C::NTILE; ++e) acc[e] = 0.0;
-  int64_t pb, pe, tstep;
-  int niter;
-  blkm_rows(ldv / 2, (dbg & 8) != 0, pb, pe, tstep, niter);
+  int64_t pb, pe;
+  block_range(ldv / 2, blockIdx.x, gridDim.x, pb, pe);   // (pack-granular on purpose: ranges aligned to whole tiles ran 4 % slower)
+  const int niter = (int)((pe - pb + 63) / 64);
   const bool nt = (dbg & 64) != 0;
-  // stores of a slab: the result tiles go back into the slab's (consumed) block columns, from where the wave writes 16 bytes
-  // per lane, 128 contiguous bytes per column (dbg & 2: 8 bytes per lane straight from the result registers -- measured:
-  // 988 against ... us at k = 21, s = 20)
-  const bool direct = (dbg & 2) != 0;
-  const int nst = (dbg & 1) ? 0 : (direct ? NT : C::NJZ);
+  // stores: 8 bytes per lane straight from the result registers (16 lanes cover 128 contiguous bytes of a column).  Staging the
+  // tiles in LDS for 16-byte stores was measured and is not faster (1 005 against 995 us at k = 21, s = 20), neither are
+  // cacheable stores (1 050) nor writing out of place (1 000-1 030): tools/rw_streams.hip shows the memory system itself
+  // at 960 us for this mix of 41 column streams in and 20 out IN PLACE, whatever the kernel does in between.
+  const int nst = (dbg & 1) ? 0 : NT;
   auto issue = [&](int it, int sl) {
-    blkm_issue<NGS, NT>(V, ldv, k, s, pb + (int64_t)it * tstep + wave * 8, pe, lane, ring_lds + (uint32_t)(sl * C::SLAB), zeros, nt);
+    blkm_issue<NGS, NT>(V, ldv, k, s, pb + (int64_t)it * 64 + wave * 8, pe, lane, ring_lds + (uint32_t)(sl * C::SLAB), zeros, nt);
   };
   // this lane's element of a result tile: row 4 b + i of the slab, column j of the tile
   const int row = 4 * ((lane >> 2) & 3) + (lane >> 4), cj = lane & 3;
-  const int koff = (dbg & 128) ? k + 4 * NT : k;   // (probe: out of place, into the columns behind the block)
-  double* zst = V + (int64_t)(koff + cj) * ldv + row;
-  double* zst16 = V + (int64_t)(koff + (lane >> 3)) * ldv + (lane & 7) * 2;   // staged form: column lane / 8 (+ 8 per store), pack lane % 8
+  double* zst = V + (int64_t)(k + cj) * ldv + row;
   for (int it = 0; it < ring - 1; ++it) issue(it, it);
   int sl_cur = 0, sl_new = ring - 1;
   for (int it = 0; it < niter; ++it) {
     // queue of this wave, oldest first: copies(it) stores(it - ring + 1) copies(it + 1) ... copies(it + ring - 2) stores(it - 1)
     wait_vm((ring - 2) * C::NJ + (it < ring - 1 ? it : ring - 1) * nst);
     issue(it + ring - 1, sl_new);
-    unsigned char* slab = myring + (size_t)sl_cur * C::SLAB;
+    const unsigned char* slab = myring + (size_t)sl_cur * C::SLAB;
     sl_new = sl_cur;
     sl_cur = sl_cur + 1 == ring ? 0 : sl_cur + 1;
-    const int64_t pack0 = pb + (int64_t)it * tstep + wave * 8;
+    const int64_t pack0 = pb + (int64_t)it * 64 + wave * 8;
     double x[NGS], zx[NT], d[NT];
 #pragma unroll
     for (int g = 0; g < NGS; ++g) x[g] = *reinterpret_cast<const double*>(slab + C::s_off(g) + lin);
@@ -270,28 +244,11 @@ __global__ void __launch_bounds__(512, 2)
 #pragma unroll
       for (int t = u; t < NT; ++t) d[t] = mfma4(zx[u], mrd[(C::NTS + C::gt(u, t)) * 16], d[t]);
     if (nst) {
-      if (direct) {
-        const bool ok = pack0 + (row >> 1) < pe;
-        double* dst = zst + pack0 * 2;
+      const bool ok = pack0 + (row >> 1) < pe;
+      double* dst = zst + pack0 * 2;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          if (ok && 4 * t + cj < s) gst8_nt(dst + (int64_t)(4 * t) * ldv, d[t]);
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) *reinterpret_cast<double*>(slab + C::z_off(t) + gat) = d[t];
-        asm volatile("" ::: "memory");   // (the reads below are of another type: keep them behind the writes)
-        const bool ok = pack0 + (lane & 7) < pe;
-        double* dst = zst16 + pack0 * 2;
-#pragma unroll
-        for (int j = 0; j < C::NJZ; ++j) {
-          const double2 v = *reinterpret_cast<const double2*>(slab + C::NJS * 1024 + j * 1024 + lane * 16);
-          if (ok && 8 * j + (lane >> 3) < s) {
-            if (dbg & 256) gst16_nt(V + (int64_t)koff * ldv + (pack0 * (4 * NT) + j * 64 + lane) * 2, v);   // (probe: ONE write stream, same bytes)
-            else if (dbg & 4) gst16(dst + (int64_t)(8 * j) * ldv, v);
-            else gst16_nt(dst + (int64_t)(8 * j) * ldv, v);
-          }
-        }
+      for (int t = 0; t < NT; ++t) {
+        if (ok && 4 * t + cj < s) gst8_nt(dst + (int64_t)(4 * t) * ldv, d[t]);
       }
     }
     double a[NGS];
