@@ -638,10 +638,13 @@ class ArnoldiWorkspace:
     @property
     def relation_info(self) -> dict:
         """Restarts that cut through a 2 x 2 block of the real Schur form (ks_workspace_relation_info): count and the largest
-        dropped entry relative to ||H||_F.  After the first one the s-step expansion stays off for the run."""
+        dropped entry relative to ||H||_F.  After the first one the s-step expansion stays off for the run.  `probes`: relation
+        measurements taken on factorisations a caller vouched for (ks_workspace_relation_probes)."""
         b, w = C.c_int(), C.c_double()
         check(_lib.load().ks_workspace_relation_info(self._h, C.byref(b), C.byref(w)))
-        return dict(breaks=b.value, worst_leak=w.value)
+        pr = C.c_int()
+        check(_lib.load().ks_workspace_relation_probes(self._h, C.byref(pr)))
+        return dict(breaks=b.value, worst_leak=w.value, probes=pr.value)
 
     def assert_arnoldi(self, k: int):
         """The caller vouches that columns 0..k are orthonormal and satisfy, with the H now in `self.H`, the Arnoldi

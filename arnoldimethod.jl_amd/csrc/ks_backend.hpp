@@ -60,6 +60,9 @@ template <class T> struct HipBackend : ks::Backend<T> {
     // the explicit form, which -- like the reference's iterate_arnoldi! -- reads neither.
     const bool trusted = prov_ok(ws, from);
     bool no_block = false;  // a block of this call was abandoned: the rest of the range runs step by step
+    // (columns still in factored form were produced by the library's previous call, no restart in between: nothing to measure,
+    // and materialising them here would change the rounding of a run that stays step by step)
+    if (trusted && ws->prov_vouched && !ws->t_lazy && ws->sstep_eff >= 2 && op->async_capable && from >= 2 && to - from + 1 >= 2) relation_probe(from, H);
     blk_shifts_from_saved_H();
     while (j0 <= to) {
       const double tb0 = ks::now_s();
@@ -236,6 +239,55 @@ template <class T> struct HipBackend : ks::Backend<T> {
       ws->ritz_valid = false;   // (note_ritz of a driver that does know them follows and takes precedence)
     }
     return early_stands;
+  }
+
+  // The factorisation of `from` columns was vouched for by a caller that ran the restart itself (the seam: the reference's
+  // _partialschur on a device basis, src/run.jl:298-365).  The library's own restart measures what its truncation drops
+  // (note_ritz below); here that restart was not seen, so the relation is MEASURED before blocks lean on it: a truncation
+  // that cut a 2 x 2 block of the real Schur form (imaginary-part targets on real operators, src/run.jl:321-326 does not pair
+  // the members) drops the sub-diagonal entry of the LAST kept column -- residual of that column's relation,
+  //   r = A v_c - V[:, 0:from) H[0:from, c],  c = from - 2,
+  // one operator product into the dead column `from` plus a strided row sample of r (a few MB of traffic): > relation_tol
+  // ||H||_F switches the blocks off for the run, exactly as a leaking restart of the library's own driver does.
+  void relation_probe(int from, const ks::Mat<T>& H) {
+    const int c = from - 2, nc = from;
+    hipStream_t s_ = ws->ctx->stream;
+    D* scratch = static_cast<D*>(ws->col(from));
+    op->in_scale = 1.0;
+    op->apply(ws->col(c), ws->col(from), nullptr);
+    // buffers of its own (nothing the expansion kernels keep state in is touched): [2 doubles | nc coefficients]
+    if (!ws->probe_dev) {
+      KS_HIP(hipMalloc(&ws->probe_dev, 16 + (size_t)(ws->maxdim + 2) * 16));
+      KS_HIP(hipHostMalloc(&ws->probe_host, 16 + (size_t)(ws->maxdim + 2) * 16));
+    }
+    double* out = static_cast<double*>(ws->probe_dev);
+    D* coef_d = reinterpret_cast<D*>(static_cast<char*>(ws->probe_dev) + 16);
+    D* coef_h = reinterpret_cast<D*>(static_cast<char*>(ws->probe_host) + 16);
+    double fro2 = 0.0;
+    for (int j = 0; j < from - 1; ++j)
+      for (int i = 0; i < from; ++i) fro2 += std::norm(std::complex<double>(H(i, j)));
+    for (int i = 0; i < nc; ++i) std::memcpy(&coef_h[i], &H(i, c), sizeof(D));
+    KS_HIP(hipMemcpyAsync(coef_d, coef_h, (size_t)nc * sizeof(D), hipMemcpyHostToDevice, s_));
+    KS_HIP(hipMemsetAsync(out, 0, 2 * sizeof(double), s_));
+    const int64_t nchunks = (ws->n + 15) / 16;
+    const int64_t stride = std::max<int64_t>(1, std::min<int64_t>(64, nchunks / 16384));
+    const int64_t sampled = (nchunks + stride - 1) / stride * 16;
+    const int grid = (int)((sampled + kBlock - 1) / kBlock);
+    ksd::k_relation_probe<D><<<grid, kBlock, 0, s_>>>(static_cast<const D*>(ws->V), ws->ld, nc, scratch, coef_d, ws->n, stride, out);
+    KS_HIP(hipGetLastError());
+    if (ws->ctx->distributed()) ws->ctx->allreduce(out, 2);
+    double* res = static_cast<double*>(ws->probe_host);
+    KS_HIP(hipMemcpyAsync(res, out, 2 * sizeof(double), hipMemcpyDeviceToHost, s_));
+    KS_HIP(hipStreamSynchronize(s_));
+    ws->ctx->check_comm();
+    ws->relation_probes++;
+    const double fro = std::sqrt(fro2);
+    const double leak = res[1] > 0.0 ? std::sqrt(res[0] * ((double)ws->n_global / res[1])) : 0.0;
+    if (!(leak <= ws->relation_tol * fro)) {   // (NaN counts as a break)
+      ws->relation_breaks++;
+      ws->relation_leak = std::max(ws->relation_leak, fro > 0.0 ? leak / fro : leak);
+      ws->sstep_eff = 0;
+    }
   }
 
   // Ritz values of the restart that just happened (Newton shifts of the next expansion's blocks)

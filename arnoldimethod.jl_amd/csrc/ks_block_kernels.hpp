@@ -158,6 +158,39 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Relation probe: out[0] += sum over SAMPLED rows of |w[r] - sum_{i < nc} V[r, i] coef[i]|^2, out[1] += sampled rows.
+// w = A V[:, c], coef = H[0:nc, c]: the residual of the Arnoldi relation of ONE column, on every `stride`-th chunk of 16 rows
+// (a violation of the relation is a multiple of a unit vector that the truncation dropped: a strided sample sees its share).
+// Guard only (threshold decisions far from rounding): the order of the atomic additions does not matter.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+    k_relation_probe(const T* __restrict__ V, int64_t ld, int nc, const T* __restrict__ w, const T* __restrict__ coef, int64_t n, int64_t stride,
+                     double* __restrict__ out) {
+  __shared__ double red[2][kBlock / 64];
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t row = (t >> 4) * stride * 16 + (t & 15);
+  double r2 = 0.0, cnt = 0.0;
+  if (row < n) {
+    T a = w[row];
+    for (int i = 0; i < nc; ++i) a = sub_(a, mul_(V[row + (int64_t)i * ld], coef[i]));
+    r2 = abs2_(a);
+    cnt = 1.0;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { r2 += __shfl_xor(r2, off, 64); cnt += __shfl_xor(cnt, off, 64); }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wv] = r2; red[1][wv] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < kBlock / 64; ++i) { a += red[0][i]; b += red[1][i]; }
+    atomicAdd(out, a);
+    atomicAdd(out + 1, b);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // BDOTS (pass 1):  partial[i*k + c][b] = sum_{rows of b} conj(S[r,c]) Z[r,i],   partial[k*S + g(i,i2)][b] = sum conj(Z[r,i]) Z[r,i2]
 // S = V[:, 0:k), Z = V[:, k:k+S).
 // ---------------------------------------------------------------------------------------------------------------------------

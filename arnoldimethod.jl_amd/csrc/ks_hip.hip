@@ -714,6 +714,13 @@ int ks_workspace_relation_info(const ks_workspace* ws, int* breaks, double* wors
   });
 }
 
+int ks_workspace_relation_probes(const ks_workspace* ws, int* probes) {
+  return guarded([&] {
+    KS_REQUIRE(ws && probes, KS_ERR_ARGUMENT, "null argument");
+    *probes = ws->relation_probes;
+  });
+}
+
 // diagnostics: average duration of `reps` launches of one block kernel on the workspace's basis (contents irrelevant: the
 // kernels have no data-dependent control flow); which = 0 k_bdots, 1 k_bupdate.  Leaves columns k..k+s-1 overwritten.
 int ks_debug_blk_time(ks_workspace* ws, int k, int s, int which, int reps, int dbg, double* ms_per_launch, int* grid) {
@@ -758,7 +765,7 @@ int ks_workspace_assert_arnoldi(ks_workspace* ws, int k) {
     KS_REQUIRE(ws, KS_ERR_ARGUMENT, "null workspace");
     KS_REQUIRE(k >= -1 && k <= ws->maxdim, KS_ERR_ARGUMENT, "k out of range");
     if (k < 0) prov_drop(ws);  // the caller withdraws: the next expansion runs the explicit form
-    else prov_set(ws, k);
+    else { prov_set(ws, k); ws->prov_vouched = true; }
   });
 }
 

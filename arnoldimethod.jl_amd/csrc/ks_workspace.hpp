@@ -68,6 +68,13 @@ struct ks_workspace {
   // step `from` takes the implicit form only if prov_k >= from - 1 AND the caller's H[:, 0:from-1) still equals the
   // shadow bit for bit; otherwise it runs the explicit three-pass form, which needs neither.  -1: unknown.
   int prov_k = -1;
+  // the provenance in force was ASSERTED by the caller (ks_workspace_assert_arnoldi after a restart the caller ran): the
+  // library has not seen that restart, in particular not what its truncation dropped (relation_breaks below).  Before such
+  // a factorisation is expanded in blocks the relation of its last column is measured (HipBackend::relation_probe).
+  bool prov_vouched = false;
+  int relation_probes = 0;      // probes run so far (ks_workspace_relation_probes)
+  void* probe_dev = nullptr;    // device / pinned host scratch of the probe: [sum, rows | coefficients]
+  void* probe_host = nullptr;
   std::vector<char> Hshadow;
   size_t off_T = 0, off_g = 0, ctl_bytes = 0;
   int ldt = 0;
@@ -153,6 +160,8 @@ struct ks_workspace {
     (void)hipFree(Vbase ? Vbase : V); (void)hipHostFree(H); (void)hipHostFree(Q); (void)hipFree(Hd); (void)hipHostFree(Hstage);
     (void)hipFree(Hscratch); (void)hipFree(partial); (void)hipFree(partial_s); (void)hipFree(partial2); (void)hipFree(coef); (void)hipFree(red);
     (void)hipFree(scal); (void)hipHostFree(scal_h); (void)hipHostFree(coef_h);
+    if (probe_dev) (void)hipFree(probe_dev);
+    if (probe_host) (void)hipHostFree(probe_host);
     (void)hipFree(Qd); (void)hipHostFree(Qstage); (void)hipFree(tmp); (void)hipFree(tmp2); (void)hipFree(oop);
     (void)hipHostFree(Hstage_early); (void)hipHostFree(mbox); (void)hipFree(ctr);
     (void)hipFree(bpart); (void)hipFree(bred); (void)hipFree(bscr); (void)hipFree(bzero);
@@ -643,11 +652,12 @@ inline bool use_deferred(const ks_workspace* ws, int to) {
 inline size_t h_bytes(const ks_workspace* ws) { return (size_t)(ws->maxdim + 1) * ws->maxdim * ws->esz; }
 inline void prov_set(ks_workspace* ws, int k) {
   ws->prov_k = k;
+  ws->prov_vouched = false;
   if (k < 0) return;
   ws->Hshadow.resize(h_bytes(ws));
   std::memcpy(ws->Hshadow.data(), ws->H, h_bytes(ws));
 }
-inline void prov_drop(ks_workspace* ws) { ws->prov_k = -1; }
+inline void prov_drop(ks_workspace* ws) { ws->prov_k = -1; ws->prov_vouched = false; }
 // may a batch that starts at step `from` lean on H[:, 0:from-1) and the relation of those steps?
 inline bool prov_ok(const ks_workspace* ws, int from) {
   if (ws->prov_k < from - 1) return false;

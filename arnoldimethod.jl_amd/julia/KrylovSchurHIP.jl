@@ -304,12 +304,20 @@ Restarts of the library's drivers that cut through a 2 x 2 block of the real Sch
 operator: the members of a complex pair are not neighbours in the target's order, src/run.jl:298-339 / :363-365 then drop the
 block's sub-diagonal entry and the Arnoldi relation of the kept columns is off by that much).  After the first one the
 s-step expansion stays off for the run (include/kschur.h, ks_workspace_relation_info).  A caller that runs the restart
-itself (`partialschur!` of the reference on a `HipBasis`) is not seen by this guard: `set_sstep!(w, 0)` for such targets.
+itself (`partialschur!` of the reference on a `HipBasis`) is covered as well: the expansion that follows `assert_arnoldi`
+measures the relation of the last kept column before it runs in blocks (`relation_probes`), and a violation counts here.
 """
 function relation_breaks(w::HipWorkspace)
     b = Ref{Cint}(0); l = Ref{Cdouble}(0.0)
     check(ccall((:ks_workspace_relation_info, LIB), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cdouble}), w.h, b, l))
     return (Int(b[]), l[])
+end
+
+"relation measurements taken on factorisations the caller vouched for (ks_workspace_relation_probes)"
+function relation_probes(w::HipWorkspace)
+    p = Ref{Cint}(0)
+    check(ccall((:ks_workspace_relation_probes, LIB), Cint, (Ptr{Cvoid}, Ptr{Cint}), w.h, p))
+    return Int(p[])
 end
 
 "Array(view(V, :, j0+1:j0+ncols)): host copy of device columns"

@@ -252,6 +252,13 @@ int ks_workspace_sstep_info(const ks_workspace* ws, int* s, int* blocks, int* ab
  * columns) is switched off for the rest of the run when the dropped entry exceeds 1e-12 ||H||_F.  *breaks = such restarts
  * since creation, *worst_leak = largest dropped entry / ||H||_F. */
 int ks_workspace_relation_info(const ks_workspace* ws, int* breaks, double* worst_leak);
+/* A caller that runs the restart itself (the reference's _partialschur on a device basis, src/run.jl:298-365) and then vouches
+ * for the result (ks_workspace_assert_arnoldi) is not seen by the guard above.  For such a factorisation the library MEASURES
+ * the relation before blocks lean on it: the residual of the last kept column, A v_c - V H[:, c] (one operator product into a
+ * dead column + a strided row sample), at the start of the ks_iterate_arnoldi that follows; more than 1e-12 ||H||_F counts as a
+ * break exactly like a leaking restart of the library's own drivers (blocks off for the run).  *probes = measurements taken
+ * since creation. */
+int ks_workspace_relation_probes(const ks_workspace* ws, int* probes);
 /* Diagnostics (tools/blk_bench.py): average duration of `reps` back-to-back launches of one streaming kernel of the s-step
  * expansion at basis size k and block size s (which = 0: first pass, 1: second pass), timed with HIP events on the
  * library's stream; *grid = workgroups launched.  dbg: probe flags of the kernels (1: second pass without its stores).

@@ -70,18 +70,20 @@ def _device_side(A, maxdim):
     return ctx, op, ws, dtype
 
 
-def _replay(A, kw, fused, vouch=True):
+def _replay(A, kw, fused, vouch=True, sstep=None, v1=None, restarts=200):
     """The oracle's `partialschur` body (src/run.jl:100-129) on a DeviceBasis.  Returns (PartialSchur, History, calls, ws)."""
     n = A.shape[0]
     nev = kw["nev"]
     mindim = kw.get("mindim", min(max(10, nev), n))
     maxdim = kw.get("maxdim", min(max(20, 2 * nev), n))
     ctx, op, ws, dtype = _device_side(A, maxdim)
+    if sstep is not None:
+        ws.set_sstep(sstep)
     V = DeviceBasis(ws)
     H = np.zeros((maxdim + 1, maxdim), dtype=dtype, order="F")  # CALLER-owned, not the workspace's pinned H
     Q = np.zeros((maxdim, maxdim), dtype=dtype, order="F")
     ows = oa.ArnoldiWorkspace(V, H, V_tmp=V.alias(), Q=Q)  # ArnoldiWorkspace(V, H; V_tmp, Q)  src/ArnoldiMethod.jl:81-92
-    v1 = _start_vector(n, np.dtype(dtype).kind == "c").astype(dtype)
+    v1 = (_start_vector(n, np.dtype(dtype).kind == "c") if v1 is None else np.asarray(v1)).astype(dtype)
 
     def _copy(v):
         v[:] = v1  # copyto!(v, v1)  src/run.jl:126
@@ -113,7 +115,7 @@ def _replay(A, kw, fused, vouch=True):
         if fused:
             oa.iterate_arnoldi = fused_iterate
         oa.reinitialize(ows, 0, _copy)  # src/run.jl:126
-        dec, hist = oa._partialschur(dev_op, ows, mindim, maxdim, nev, kw["tol"], 200, kw["which"], 0)
+        dec, hist = oa._partialschur(dev_op, ows, mindim, maxdim, nev, kw["tol"], restarts, kw["which"], 0)
     finally:
         oa.iterate_arnoldi = saved
     return dec, hist, V.calls, ws, v1, stats, (ctx, op)
@@ -182,5 +184,39 @@ def test_level2_takes_the_implicit_form_only_because_the_glue_vouches():
             info = ws.sstep_info
             assert prof["axpy"]["count"] == 0 and 0 < prof["fused"]["count"] <= hist.mvproducts, prof
             assert info["blocks"] > 0, info
+            # ... and every expansion after a restart of the caller's measured the relation it was about to lean on
+            rel = ws.relation_info
+            assert rel["probes"] >= hist.restarts - 1 > 0 and rel["breaks"] == 0, (rel, hist.restarts)
         else:
             assert prof["axpy"]["count"] == hist.mvproducts, prof
+
+
+@pytest.mark.parametrize("seed", [1, 3, 5])
+def test_level2_relation_probe_protects_a_caller_that_runs_the_restart_itself(seed):
+    """Imaginary-part target on a real operator (the ill-posed selection of tests/test_gpu_factored_basis_stress.py): the
+    reference's own restart (src/run.jl:298-339, :363-365 -- here the oracle's restatement, run by the CALLER on a device
+    basis) cuts a 2 x 2 block of the real Schur form and the Arnoldi relation of the kept columns is off by ~1e-5 ||H|| from
+    then on.  The library never sees that restart; blocks would amplify the error to O(1) residuals (round 4).  The
+    expansion that follows `assert_arnoldi` measures the relation of the last kept column (ks_workspace_relation_probes)
+    and switches the blocks off for the run.  Asserted: the probe ran and fired, no more than one expansion went in blocks,
+    and the solve is the per-step solve: same trail as a workspace with the blocks off whenever nothing ran in blocks."""
+    from test_gpu_factored_basis_stress import _ill_posed_case
+
+    A, v1, kw = _ill_posed_case(seed)
+    out = []
+    for sstep in (10, 0):
+        dec, hist, calls, ws, _, stats, keep = _replay(A, kw, fused=True, sstep=sstep, v1=v1, restarts=kw["restarts"])
+        Q = np.asarray(dec.Q)
+        orth = float(np.linalg.norm(Q.conj().T @ Q - np.eye(Q.shape[1]))) if Q.shape[1] else 0.0
+        res = float(np.linalg.norm(A @ Q - Q @ np.asarray(dec.R))) / sp.linalg.norm(A) if Q.shape[1] else 0.0
+        out.append((hist, np.sort_complex(np.asarray(dec.eigenvalues)), ws.relation_info, ws.sstep_info, orth, res))
+    (h1, e1, rel1, info1, orth1, res1), (h0, e0, rel0, info0, orth0, res0) = out
+    assert rel1["probes"] > 0 and rel1["breaks"] > 0 and rel1["worst_leak"] > 1e-9 and info1["s"] == 0, (rel1, info1)
+    assert info1["blocks"] <= 2 and info0["blocks"] == 0 and rel0["probes"] == 0, (info1, info0, rel0)
+    assert orth1 < 1e-11 * max(1, h1.nconverged) and orth0 < 1e-11 * max(1, h0.nconverged), (orth1, orth0)
+    if info1["blocks"] == 0 and info1["abandoned"] == 0:
+        assert (h1.mvproducts, h1.nconverged, h1.restarts) == (h0.mvproducts, h0.nconverged, h0.restarts), (h1, h0, info1, rel1)
+        if h1.nconverged:
+            assert np.abs(e1 - e0).max() <= 1e-9 * max(1.0, np.abs(e0).max())
+    else:
+        assert res1 <= 10 * res0 + 1e-6, (res1, res0)
