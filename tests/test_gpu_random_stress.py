@@ -53,6 +53,9 @@ def _case(seed):
     return A.astype(dtype), v1.astype(dtype), dict(nev=nev, which=which, tol=1e-9, mindim=mindim, maxdim=maxdim, restarts=60), kind
 
 
+_STRICT = {}   # seed -> did the case take the strict (trail-for-trail) branch; read by the population test at the end
+
+
 @pytest.mark.parametrize("seed", range(32))
 def test_random_case_against_the_oracle(seed):
     A, v1, kw, kind = _case(seed)
@@ -69,6 +72,7 @@ def test_random_case_against_the_oracle(seed):
         res_ref0 = np.linalg.norm(A @ ref.Q - ref.Q @ ref.R)
         well_posed = well_posed and res_ref0 <= 1e-4 * max(1.0, sp.linalg.norm(A))
     settled = rh.converged and rh.restarts <= 40
+    _STRICT[seed] = bool(well_posed and settled)
     if well_posed and settled:
         assert h.converged and h.nconverged == rh.nconverged and h.mvproducts == rh.mvproducts, tag
         scale = max(1.0, float(np.abs(ref.eigenvalues).max()))
@@ -83,3 +87,14 @@ def test_random_case_against_the_oracle(seed):
         res_ref = np.linalg.norm(A @ ref.Q - ref.Q @ ref.R) if rh.nconverged else 0.0
         assert res <= 10 * res_ref + 1e-8 * nb * max(1, h.nconverged), tag + f" residual {res:.2e} (oracle {res_ref:.2e})"
         assert np.linalg.norm(Q.conj().T @ Q - np.eye(Q.shape[1])) < 1e-11 * max(1, h.nconverged), tag
+
+
+def test_enough_cases_are_compared_trail_for_trail():
+    """The sweep above compares mvproducts / nconverged / Ritz values with the oracle only where the trail is a well-posed
+    quantity (see the comments there; the filter was widened in round 4 to admit the s-step default).  So that the filter
+    cannot quietly swallow the sweep: 12 of the 32 seeds take the strict branch (measured with the oracle alone: seeds 0 1 4
+    6 8 11 18 20 21 22 29 31); at least 10 must (two of slack for a BLAS that rounds the oracle differently)."""
+    if len(_STRICT) < 32:
+        pytest.skip("the sweep did not run in full in this process")
+    strict = sorted(k for k, v in _STRICT.items() if v)
+    assert len(strict) >= 10, strict
