@@ -73,13 +73,13 @@ KERNEL_NAMES = {
     "fused": "k_axpy_dots_cs (w -= V h, |w|^2 and c = V'w of the second DGKS pass, V read once)",
     "spmv": "k_spmv_csr",
     "scale": "k_scale",
-    "rotate": "k_rotate_mfma",
+    "rotate": "k_rotate_fma (restart rotation V <- V Q in place, src/run.jl:363-365)",
 }
 
 
 BLOCK_KERNEL_NAMES = {
-    "dots": "k_bdots (s-step pass 1: P = S'Z and Z'Z for a block of s vectors, basis read once per block)",
-    "fused": "k_bupdate (s-step pass 2: block = (Z - S coef) R1^-1 written in place, C = S'block and its Gram matrix; basis read once per block)",
+    "dots": "k_bdots_mfma (s-step pass 1: P = S'Z and Z'Z for a block of s vectors, basis read once per block)",
+    "fused": "k_bupdate_mfma (s-step pass 2: block = (Z - S coef) R1^-1 written in place, C = S'block and its Gram matrix; basis read once per block)",
 }
 
 
@@ -105,6 +105,16 @@ def step_bytes(n, nnz, j, reorth, bpn=12.0):
     if reorth:
         b += 16.0 * j * n + 16.0 * n
     return b
+
+
+def spmv_bytes(fmt, nnz, n):
+    """Bytes ONE product y = A x streams in the layout the library chose -- the same figure the library books per launch
+    (roofline.spmv.bytes_per_launch): matrix bytes + row pointers WHERE THE LAYOUT HAS THEM + x and y.  The stencil-mask layout
+    keeps one mask byte per row and no row pointers (17 B per row for the 7-point Laplacian); sliced ELLPACK one pointer per
+    64-row slice."""
+    lay = fmt["layout"]
+    ptr = 0.0 if lay == "stencil" else (4.0 * (n / 64.0 + 1) if lay.startswith("sell") else 4.0 * (n + 1))
+    return fmt["bytes_per_nnz"] * nnz + ptr + 16.0 * n
 
 
 def plain_csr_spmv(pkg, ctx, A_host, n, reps=20):
@@ -344,7 +354,7 @@ def main():
                 # bytes the launched kernels MUST move -- the traffic-true figure.  Implicit second pass (default): TWO
                 # passes over V per step (k_dots, k_axpy_dots_cs) whether or not the DGKS test asks for the second
                 # projection = SURVEY 8d's compulsory B_step(j); KS_PASSES=3: a third one (k_axpy) when it does
-                spmv_b = fmt["bytes_per_nnz"] * nnz_global + 4.0 * (n + 1) + 16.0 * n
+                spmv_b = spmv_bytes(fmt, nnz_global, n)
                 blk = []
                 if sstep:
                     info = ws.sstep_info
@@ -378,6 +388,7 @@ def main():
                     state["moved"] += st["reorth"] * 8.0 * n * ((k + 1 + maxdim) / 2.0 + 2)
                 state["t_expand"] += t1 - t0
                 state["t_restart"] += t2 - t1
+                state.setdefault("cycle_s", []).append(t2 - t0)
                 state["trail"].append((r["k"], r["nlock"]))
                 state["ritz"] = np.sort_complex(r["eigenvalues"][: r["k"]])
             state["k"], state["active"] = r["k"], r["nlock"]
@@ -617,13 +628,19 @@ def make_line(args, pkg, passes, order, world, rank, force_dist, wl, with_cpu_ba
     sst = passes[chosen].get("sstep", 0)
     out["value"] = state["steps"] / elapsed
     out["ms_per_step"] = 1e3 * elapsed / max(args.steps, 1)
+    cyc = sorted(state.get("cycle_s", []))
+    if cyc:   # spread of the timed cycles (the timed region is short: K cycles of a few ms)
+        out["cycle_ms"] = {"min": 1e3 * cyc[0], "median": 1e3 * cyc[len(cyc) // 2], "max": 1e3 * cyc[-1], "n": len(cyc)}
     layout = fmt["layout"]
     out["config"].update({
         "workload": f"laplace3d-7pt {m}^3 (n={n}, nnz={nnz_global}), nev={nev}, which=SR, mindim={mindim}, maxdim={maxdim}, "
                     f"tol=sqrt(eps), explicit v1 (splitmix64 seed 20240917); step = one Krylov-Schur restart cycle",
         "nnz": nnz_global,
         "arnoldi_iterations_timed": state["steps"],
-        "dgks_second_passes": state["reorth"],
+        # per-step cycles: steps whose DGKS test asked for the second projection (src/expansion.jl:91).  Block cycles take no
+        # such decision (the second stage is always part of a block): reported separately, not as DGKS passes
+        "dgks_second_passes": state["reorth"] if not state.get("blk_cycles", 0) else None,
+        "steps_in_blocks_with_second_stage": state["reorth"] if state.get("blk_cycles", 0) else None,
         "basis_passes_per_step": bp,  # 2: the DGKS second projection is carried in a triangular factor (implicit), 3: applied to the vector
         # s-step (block) expansion: steps per block; with it the basis is read twice per BLOCK (not per step)
         "sstep": {"s": sst, "block_cycles": state.get("blk_cycles", 0), "blocks": state.get("blk_blocks", 0),

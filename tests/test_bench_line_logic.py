@@ -91,3 +91,30 @@ def test_rccl_runs_first_and_alone_by_default():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'os.environ.get("KS_BENCH_TRANSPORTS", "rccl,p2p")' in src
     assert 'init_process_group("nccl"' not in src  # control plane over gloo: the library's communicator is the only RCCL user
+
+
+def test_spmv_bytes_follow_the_layout_and_a_block_cycle_moves_1156_n():
+    """DESIGN 3S "Bytes": a headline block cycle (20 steps from k = 21, one block of 20) moves 20 * 17 n + 8 n * 41 + 8 n * 61
+    = 1 156 n bytes -- the stencil-mask layout has no row pointers (17 B per row: one mask byte + x + y); VERDICT r4 found
+    4 (n + 1) booked per product on top.  Layouts with row pointers keep them."""
+    n, nnz = 216 ** 3, 70263936
+    st = dict(bytes_per_nnz=n / nnz, ndict=7, layout="stencil")     # one mask byte per row
+    assert abs(bench.spmv_bytes(st, nnz, n) - 17.0 * n) < 1.0
+    cycle = 20 * bench.spmv_bytes(st, nnz, n) + 8.0 * n * (21 + 20) + 8.0 * n * (21 + 40)
+    assert abs(cycle - 1156.0 * n) < 100.0
+    assert bench.spmv_bytes(dict(bytes_per_nnz=12.0, ndict=0, layout="csr"), nnz, n) == 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n
+    assert bench.spmv_bytes(dict(bytes_per_nnz=12.0, ndict=0, layout="sell"), nnz, n) == 12.0 * nnz + 4.0 * (n / 64.0 + 1) + 16.0 * n
+
+
+def test_block_cycles_report_no_dgks_passes_and_the_spread_of_the_timed_cycles():
+    p = _pass(0.3)
+    p["state"].update(blk_cycles=10, blk_blocks=10, cycle_s=[0.004, 0.0038, 0.0041, 0.0039, 0.0040, 0.0038, 0.0039, 0.0042, 0.0038, 0.0039])
+    p["sstep"] = 20
+    out = bench.make_line(ARGS, None, {"single": p}, ["single"], 1, 0, False, WL, False)
+    assert out["config"]["dgks_second_passes"] is None and out["config"]["steps_in_blocks_with_second_stage"] == 200
+    c = out["cycle_ms"]
+    assert c["n"] == 10 and c["min"] == 3.8 and c["max"] == 4.2 and c["min"] <= c["median"] <= c["max"]
+    assert out["roofline"]["kernel"].startswith("k_bupdate_mfma")
+    p0 = _pass(0.3)
+    out0 = bench.make_line(ARGS, None, {"single": p0}, ["single"], 1, 0, False, WL, False)
+    assert out0["config"]["dgks_second_passes"] == 200 and out0["config"]["steps_in_blocks_with_second_stage"] is None
