@@ -93,3 +93,26 @@ def test_line_survives_a_rank_that_dies_the_hard_way():
     r, d = _bench({"KS_BENCH_TRANSPORTS": "host,p2p", "KS_BENCH_INJECT_FAIL": "p2p:crash"})
     assert d["died_during"] == "p2p" and "value" in d["transports"]["host"], d
     assert d["value"] == d["transports"]["host"]["value"] and d["value"] > 0 and d["config"]["transport"] == "host"
+
+
+def test_eight_ranks_end_to_end_on_one_device():
+    """The driver's scaling run is `bench.py --gpus 8` under torch.distributed.run; no 8-GPU node has been available to any
+    round so far, so its first contact with one must not be the first run of that code path: the same command
+    line with all eight ranks on device 0 (peer-to-peer and host-staged transports; RCCL refuses eight ranks on one device), the
+    default block expansion, config 5's record riding along.  Asserted: ONE well-formed line, n_gpus 8, every rank's share in
+    the validation, the roofline block and both transports present."""
+    r, d = _bench({}, nproc=8, grid=64, timeout=900, extra_args=("--config5", "--config5-grid", "48"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert d["n_gpus"] == 8 and d["value"] > 0 and d["steps"] == 3 and d["scaling"] == "strong" and d["config"]["parallelism"] == "rows/8"
+    # the collective-structured (host-staged) pass must succeed.  The peer-to-peer pass spins inside kernels for its peers:
+    # with EIGHT processes time-sliced on one device a peer's kernel is sometimes not scheduled within the 30-s clock (measured:
+    # 1 run in 4 ends in CommTimeout here, none with 2-4 ranks; one rank per GPU has no such co-scheduling) -- the line must
+    # then carry that error and come from the surviving pass, which is the very property this file tests
+    assert set(d["transports"]) == {"p2p", "host"} and "value" in d["transports"]["host"], d["transports"]
+    assert "value" in d["transports"]["p2p"] or "CommTimeout" in d["transports"]["p2p"]["error"], d["transports"]
+    v = d["validation"]
+    assert v["ok"] and v["arnoldi_rel"] <= v["limit_rel"] and v["orth"] <= v["limit_orth"], v
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["fused_step"]["moved_frac"] > 0
+    assert d["config"]["sstep"]["s"] == 20 and d["config"]["sstep"]["block_cycles"] > 0, d["config"]["sstep"]
+    c5 = d["config5"]
+    assert c5["n_gpus"] == 8 and c5["value"] > 0 and c5["validation"]["ok"], c5
