@@ -80,6 +80,18 @@ template <class T> struct HipBackend : ks::Backend<T> {
           blk_make_shifts<D>(ws, std::min(ws->sstep_eff, ksd::kBlkSMax), blk_sh))
         blk_sizes = blk_partition(ws->dtype, j0, jend - j0 + 1, std::min(ws->sstep_eff, ksd::kBlkSMax));
       const bool bpath = !blk_sizes.empty();
+      if (ws->rot_pending) {
+        // the restart's rotation is still pending (rotate_tfold): this batch's first block does it in the sweep of its first
+        // pass when there is a kernel for the shape -- otherwise it runs now, the ordinary way
+        if (bpath && j0 == ws->rot_out0 + ws->rot_rr && ks_blk_rot_ok(ws->rot_cin, j0, blk_sizes[0])) {
+          ws->rot_pending = false;
+          ws->rot_fuse = true;
+          ws->t_lazy = false;
+          ws->t_hi = -1;
+        } else {
+          rot_flush(ws);
+        }
+      }
       if (tpath && (bpath || ws->blk_tail || !(ws->t_lazy && j0 == ws->t_hi + 1))) {
         materialize(ws);   // whatever is lazy (either kind) becomes ordinary: this batch starts a new T
         ws->ntrue = j0;
@@ -357,8 +369,12 @@ template <class T> struct HipBackend : ks::Backend<T> {
   void rotate_and_move(int c0, int c, int r, const ks::Mat<T>& Q, int dst, int src) override {
     const bool own = ws->prov_k == src;  // the library's own factorisation of `src` steps is being truncated to `dst`
     if (ws->t_lazy) {
+      ws->rot_defer_ok = own && r > 0;   // (may stay pending for the next expansion's fused first pass: ks_workspace::rot_pending)
       rotate_tfold<T>(ws, c0, c, r, r > 0 ? &Q(c0, c0) : nullptr, Q.ld, c0, src, dst);
+      ws->rot_defer_ok = false;
+      const bool pend = ws->rot_pending;
       reset_lazy(ws);
+      if (pend) { ws->t_lazy = true; ws->ntrue = ws->rot_out0 + ws->rot_rr; ws->t_hi = ws->ntrue - 1; }
     } else {
       rotate(c0, c, r, Q);
       col_copy(dst, src);

@@ -80,10 +80,12 @@ inline void blk_ensure_buffers(ks_workspace* ws) {
 // ---- launchers ----------------------------------------------------------------------------------------------------------------
 // (the ~200 instantiations of the two streaming kernels live in translation units of their own: ks_block_inst.hip)
 inline int& blk_dbg() { static int v = env_int("KS_BLK_DBG", 0); return v; }
-template <class D> int launch_blk(ks_workspace* ws, int which, int k, int s) {
+template <class D> int launch_blk(ks_workspace* ws, int which, int k, int s, bool zscratch = false) {
   auto* bs = static_cast<ksd::BlkScratch<D>*>(ws->bscr);
   BlkLaunchArgs a{};
   a.V = ws->V; a.ld = ws->ld; a.dtype = sizeof(D) == 8 ? 0 : 1; a.k = k; a.s = s;
+  if (zscratch) { a.zsrc = ws->zscratch; a.ldz = ws->ld; }
+  if (which == 2) { a.cin = ws->rot_cin; a.out0 = ws->rot_out0; a.rotm = ws->Qd; }
   a.partial = ws->bpart; a.pnb = ws->pnb; a.coefp = bs->coefp; a.r1inv = bs->r1inv; a.zeros = ws->bzero; a.st = ws->st;
   a.dbg = blk_dbg(); a.nt = ws->v_nt ? 1 : 0; a.num_cu = ws->ctx->num_cu; a.bpc = ws->ctx->bpc; a.stream = ws->ctx->stream;
   try {
@@ -107,13 +109,30 @@ void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::v
   int k = from;   // existing columns == index of the block's first step
   int first = 1;
   for (int s : sizes) {
+    // FUSED RESTART ROTATION (ks_workspace::rot_pending -> rot_fuse): the first block after a restart whose rotation is still
+    // pending writes its Newton chain to scratch columns -- the chain starts from the stored last column of the OLD basis, the
+    // residual direction up to the Gram deviation of the block that wrote it (rotate_tfold admits <= 1e-12) --, then ONE kernel
+    // rotates the basis and takes the first pass; the second pass reads the chain from the scratch columns and writes the block
+    // to its place.
+    const bool fuse = first && ws->rot_fuse;
+    ws->rot_fuse = false;
+    char* zs = nullptr;
+    if (fuse) {
+      if (!ws->zscratch) {
+        KS_HIP(hipMalloc(&ws->zscratch, (size_t)ws->ld * ksd::kBlkSMax * sizeof(D)));
+        KS_HIP(hipMemsetAsync(ws->zscratch, 0, (size_t)ws->ld * ksd::kBlkSMax * sizeof(D), s_));   // the pad rows (n .. ld) stay zero: operators write rows < n only
+      }
+      zs = static_cast<char*>(ws->zscratch);
+    }
+    auto zcol = [&](int i) -> void* { return fuse ? static_cast<void*>(zs + (size_t)i * ws->ld * sizeof(D)) : ws->col(k + i); };
     op->shift_store_cacheable = s >= 10;   // (ks_operators.hpp: pays with one inner-product pass per ten or twenty products)
     for (int i = 0; i < s; ++i) {
       double tre, tim;
       if constexpr (sizeof(D) == 8) { tre = sh.theta[i]; tim = 0.0; }
       else { tre = sh.theta[i].x; tim = sh.theta[i].y; }
       op->in_scale = 1.0;
-      op->apply_shifted(ws->col(k - 1 + i), ws->col(k + i), tre, tim, sh.sigma[i], ws->ld, ws->st);
+      const void* src = i == 0 ? (fuse ? ws->col(ws->maxdim) : ws->col(k - 1)) : zcol(i - 1);
+      op->apply_shifted(src, zcol(i), tre, tim, sh.sigma[i], ws->ld, ws->st);
     }
     const int ne = k * s + s * (s + 1) / 2;
     int nb1, nb2;
@@ -135,14 +154,19 @@ void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::v
                                                 ws->blk_gdevmax, ws->st, ws->ctr);
       }
     };
-    {
+    if (fuse) {
+      // reads the old basis and Z, writes the rotated columns
+      ProfScope ps(cx, KSP_ROTATE, nb8 * (ws->rot_cin + s + ws->rot_rr));
+      nb1 = launch_blk<D>(ws, 2, k, s, true);
+      ws->rot_fused_count++;
+    } else {
       ProfScope ps(cx, KSP_DOTS, nb8 * (k + s));               // reads S[:, 0:k) and Z
       nb1 = launch_blk<D>(ws, 0, k, s);
     }
     fin(1, nb1);
     {
       ProfScope ps(cx, KSP_FUSED, nb8 * (k + 2 * s));          // reads S[:, 0:k) and Z, writes the block
-      nb2 = launch_blk<D>(ws, 1, k, s);
+      nb2 = launch_blk<D>(ws, 1, k, s, fuse);
     }
     fin(2, nb2);
     k += s;

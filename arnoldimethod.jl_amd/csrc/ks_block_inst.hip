@@ -119,7 +119,7 @@ template <int NCW2> int go_ringL1(const BlkLaunchArgs& a) {
 
 
 // matrix-instruction forms (ks_block_mfma.hpp): row slabs per wave, no barrier in the loop.  KS_BLK_MFMA=0: the ring forms.
-inline int mfma_env() { static const int v = [] { const char* e = std::getenv("KS_BLK_MFMA"); return e ? std::atoi(e) : 63; }(); return v; }
+inline int mfma_env() { static const int v = [] { const char* e = std::getenv("KS_BLK_MFMA"); return e ? std::atoi(e) : 127; }(); return v; }
 inline int mfma_ring_env() { static const int v = [] { const char* e = std::getenv("KS_BLK_MFMA_RING"); return e ? std::atoi(e) : 3; }(); return v; }
 template <int NGS, int NT> int go_mfma(int which, const BlkLaunchArgs& a) {
   using C = ksd::BlkMfma<NGS, NT>;
@@ -145,7 +145,8 @@ template <int NGS, int NT> int go_mfma(int which, const BlkLaunchArgs& a) {
       hipcheck(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "dynamic LDS size");
       attr = true;
     }
-    kern<<<nb, 512, smem, a.stream>>>(static_cast<double*>(a.V), a.ld, a.k, a.s, ring, static_cast<const double*>(a.coefp), a.k,
+    const double* zb = a.zsrc ? static_cast<const double*>(a.zsrc) : static_cast<const double*>(a.V) + (int64_t)a.k * a.ld;
+    kern<<<nb, 512, smem, a.stream>>>(static_cast<double*>(a.V), a.ld, a.k, zb, a.zsrc ? a.ldz : a.ld, a.s, ring, static_cast<const double*>(a.coefp), a.k,
                                      static_cast<const double*>(a.r1inv), static_cast<double*>(a.partial), a.pnb,
                                      static_cast<const ksd::DevState*>(a.st), dbg, static_cast<const double*>(a.zeros));
   }
@@ -159,6 +160,44 @@ template <int NT, int MAXG, int G = 1> int go_mfma_by_k(int which, const BlkLaun
     return go_mfma_by_k<NT, MAXG, G + 1>(which, a);
   }
 }
+
+#if KS_BLK_PART == 1
+// restart rotation fused with the first pass (k_brotdots_mfma): the instantiated (column groups in, column tiles out, block tiles)
+template <int NGX, int NTK, int NT> int go_rot(const BlkLaunchArgs& a) {
+  using C = ksd::BlkRot<NGX, NTK, NT>;
+  int ring = mfma_ring_env();
+  while (ring > 2 && C::lds_bytes(ring) > 160 * 1024) --ring;
+  const size_t smem = C::lds_bytes(ring);
+  if (ring < 2 || smem > 160 * 1024) throw std::runtime_error("block kernels: slab ring of the fused rotation does not fit the LDS");
+  const int nb = cap(a, a.num_cu, 64, sizeof(double));
+  auto kern = ksd::k_brotdots_mfma<NGX, NTK, NT>;
+  static bool attr = false;
+  if (!attr) {
+    hipcheck(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "dynamic LDS size");
+    attr = true;
+  }
+  kern<<<nb, 512, smem, a.stream>>>(static_cast<double*>(a.V), a.ld, a.cin, static_cast<const double*>(a.rotm), a.out0, a.k,
+                                   static_cast<const double*>(a.zsrc), a.ldz, a.s, ring, static_cast<double*>(a.partial), a.pnb,
+                                   a.dbg | (a.nt ? 64 : 0), static_cast<const double*>(a.zeros));
+  return nb;
+}
+#define KS_ROT_SHAPES(X) X(11, 6, 5) X(11, 7, 3) X(11, 8, 3) X(11, 8, 2) X(6, 3, 3) X(6, 4, 3) X(6, 4, 2)
+inline bool rot_shape(int cin, int k, int s, int& ngx, int& ntk, int& nt) {
+  ngx = (cin + 3) / 4; ntk = (k + 3) / 4; nt = (s + 3) / 4;
+#define KS_ROT_HAS(A, B, C_) if (ngx == A && ntk == B && nt == C_) return true;
+  KS_ROT_SHAPES(KS_ROT_HAS)
+#undef KS_ROT_HAS
+  return false;
+}
+inline int go_rot_by_shape(const BlkLaunchArgs& a) {
+  int ngx, ntk, nt;
+  if (!a.zsrc || !a.rotm || !rot_shape(a.cin, a.k, a.s, ngx, ntk, nt)) throw std::runtime_error("block kernels: no fused rotation for this shape");
+#define KS_ROT_GO(A, B, C_) if (ngx == A && ntk == B && nt == C_) return go_rot<A, B, C_>(a);
+  KS_ROT_SHAPES(KS_ROT_GO)
+#undef KS_ROT_GO
+  throw std::runtime_error("block kernels: no fused rotation for this shape");
+}
+#endif
 
 template <class D, int NCW, int S, int NW = 4, int WB = 1> int go(int which, const BlkLaunchArgs& a) {
   if constexpr (sizeof(D) == 8 && S == 20) {
@@ -246,7 +285,16 @@ int ks_blk_launch_part0(int which, const BlkLaunchArgs& a) {
   }
 }
 #elif KS_BLK_PART == 1
+bool ks_blk_rot_ok(int cin, int k, int s) {
+  int a, b, c;
+  // (the second pass must be the matrix-instruction form too: only it reads the block from scratch columns)
+  const int bit2 = s == 20 ? 1 : (s == 10 ? 3 : (s == 8 ? 5 : -1));
+  if (bit2 < 0 || !((mfma_env() >> bit2) & 1) || !((mfma_env() >> 6) & 1)) return false;
+  if (!(s == 20 ? k <= 24 : (s == 10 ? k <= 32 : k <= 48))) return false;
+  return k >= 1 && cin >= k && rot_shape(cin, k, s, a, b, c);
+}
 int ks_blk_launch_part1(int which, const BlkLaunchArgs& a) {
+  if (which == 2) return go_rot_by_shape(a);
   switch (a.s) {
     case 5: return by_ncw<double, 5>(which, a);
     case 8: return by_ncw<double, 8>(which, a);

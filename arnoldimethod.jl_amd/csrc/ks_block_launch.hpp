@@ -21,13 +21,23 @@ struct BlkLaunchArgs {
   int nt;              // non-temporal loads of the basis
   int num_cu, bpc;     // device CUs, cap on resident workgroups per CU (ks_ctx::bpc)
   hipStream_t stream;
+  // block columns read from elsewhere than V[:, k : k + s) (matrix-instruction forms of the second pass and the fused
+  // rotation: the Newton chain was written to scratch columns); null: in place
+  const void* zsrc = nullptr;
+  int64_t ldz = 0;
+  // which = 2 (restart rotation fused with the first pass, k_brotdots_mfma): V[:, out0 : k) <- V[:, 0:cin) M, M = cin x (k - out0)
+  int cin = 0, out0 = 0;
+  const void* rotm = nullptr;
 };
-// which = 0: k_bdots (pass 1), 1: k_bupdate (pass 2).  Returns the number of workgroups launched (= partial sums per
+// which = 0: k_bdots (pass 1), 1: k_bupdate (pass 2), 2: restart rotation + pass 1 in one sweep (part 1 only).  Returns the number of workgroups launched (= partial sums per
 // entry); throws std::runtime_error for a shape without an instantiation (ks_blk_shape_ok says which exist).
 int ks_blk_launch_part0(int which, const BlkLaunchArgs& a);   // Float64, block sizes 1-4
 int ks_blk_launch_part1(int which, const BlkLaunchArgs& a);   // Float64, block sizes 5, 8, 10, 20
 int ks_blk_launch_part2(int which, const BlkLaunchArgs& a);   // ComplexF64, block sizes 1-5
+// which = 2: is there a fused rotation + first pass for this shape?  (Float64; cin old columns -> k new ones, block of s)
+bool ks_blk_rot_ok(int cin, int k, int s);
 inline int ks_blk_launch(int which, const BlkLaunchArgs& a) {
+  if (which == 2) return ks_blk_launch_part1(which, a);
   if (a.dtype != 0) return ks_blk_launch_part2(which, a);
   return a.s <= 4 ? ks_blk_launch_part0(which, a) : ks_blk_launch_part1(which, a);
 }

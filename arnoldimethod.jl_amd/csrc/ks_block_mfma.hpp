@@ -90,10 +90,11 @@ __device__ __forceinline__ void blkm_finish(double* acc, unsigned char* lds, int
 }
 
 
-// the copies of one slab: S columns (zeros beyond k), block columns (zeros beyond s); rows past the range: zeros
+// the copies of one slab: S columns (zeros beyond k), block columns Zb[:, 0:s) (zeros beyond s; in place: Zb = V + k ldv);
+// rows past the range: zeros
 template <int NGS, int NT>
-__device__ __forceinline__ void blkm_issue(const double* __restrict__ V, int64_t ldv, int k, int s, int64_t pack0, int64_t pe, int lane,
-                                           uint32_t slab_lds, const double* __restrict__ zeros, bool nt) {
+__device__ __forceinline__ void blkm_issue(const double* __restrict__ V, int64_t ldv, int k, const double* __restrict__ Zb, int64_t ldz, int s,
+                                           int64_t pack0, int64_t pe, int lane, uint32_t slab_lds, const double* __restrict__ zeros, bool nt) {
   using C = BlkMfma<NGS, NT>;
   const int64_t p = pack0 + (lane & 7);
   const bool in = p < pe;
@@ -102,7 +103,7 @@ __device__ __forceinline__ void blkm_issue(const double* __restrict__ V, int64_t
   for (int j = 0; j < C::NJ; ++j) {
     const int c = j < C::NJS ? 8 * j + cl : 8 * (j - C::NJS) + cl;     // column inside its region
     const bool have = in && (j < C::NJS ? c < k : c < s);
-    const double* src = have ? V + (int64_t)(j < C::NJS ? c : k + c) * ldv + p * 2 : zeros;
+    const double* src = have ? (j < C::NJS ? V + (int64_t)c * ldv : Zb + (int64_t)c * ldz) + p * 2 : zeros;
     if (nt) glds16_nt(src, slab_lds + (uint32_t)j * 1024u);
     else glds16(src, slab_lds + (uint32_t)j * 1024u);
   }
@@ -133,7 +134,7 @@ __global__ void __launch_bounds__(512, 2)
   const bool nt = (dbg & 64) != 0;
   auto issue = [&](int it, int sl) {
     if (dbg & 32) return;
-    blkm_issue<NGS, NT>(V, ldv, k, s, pb + (int64_t)it * 64 + wave * 8, pe, lane, ring_lds + (uint32_t)(sl * C::SLAB), zeros, nt);
+    blkm_issue<NGS, NT>(V, ldv, k, V + (int64_t)k * ldv, ldv, s, pb + (int64_t)it * 64 + wave * 8, pe, lane, ring_lds + (uint32_t)(sl * C::SLAB), zeros, nt);
   };
   for (int it = 0; it < ring - 1; ++it) issue(it, it);
   int sl_cur = 0, sl_new = ring - 1;
@@ -163,7 +164,8 @@ __global__ void __launch_bounds__(512, 2)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// pass 2:  Qt = Z R1inv - S coefp (in place over Z);  partial[i k + c] = S[:, c] . Qt[:, i];  Gram of Qt.
+// pass 2:  Qt = Z R1inv - S coefp -> V[:, k : k + s)  (Z = Zb[:, 0:s): the same columns when in place, or scratch columns the
+// Newton chain was written to);  partial[i k + c] = S[:, c] . Qt[:, i];  Gram of Qt.
 // Per slab: Qt tile t = sum_g S_g M_{g,t} + sum_{u <= t} Z_u M'_{u,t}  (M = -coefp, M' = R1inv: upper triangular, so the
 // tiles below the diagonal are skipped), 4 x 4 coefficient tiles read from LDS in the B layout; the result registers are
 // stored, and ARE the operands of the inner products (as B: Qt, as A: Qt^T).
@@ -171,9 +173,9 @@ __global__ void __launch_bounds__(512, 2)
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int NGS, int NT>
 __global__ void __launch_bounds__(512, 2)
-    k_bupdate_mfma(double* __restrict__ V, int64_t ldv, int k, int s, int ring, const double* __restrict__ coefp, int ldc,
-                   const double* __restrict__ r1inv, double* __restrict__ partial, int pnb, const DevState* __restrict__ st, int dbg,
-                   const double* __restrict__ zeros) {
+    k_bupdate_mfma(double* __restrict__ V, int64_t ldv, int k, const double* __restrict__ Zb, int64_t ldz, int s, int ring,
+                   const double* __restrict__ coefp, int ldc, const double* __restrict__ r1inv, double* __restrict__ partial, int pnb,
+                   const DevState* __restrict__ st, int dbg, const double* __restrict__ zeros) {
   if (st && st->breakdown >= 0) return;
   using C = BlkMfma<NGS, NT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -213,7 +215,7 @@ __global__ void __launch_bounds__(512, 2)
   // at 960 us for this mix of 41 column streams in and 20 out IN PLACE, whatever the kernel does in between.
   const int nst = (dbg & 1) ? 0 : NT;
   auto issue = [&](int it, int sl) {
-    blkm_issue<NGS, NT>(V, ldv, k, s, pb + (int64_t)it * 64 + wave * 8, pe, lane, ring_lds + (uint32_t)(sl * C::SLAB), zeros, nt);
+    blkm_issue<NGS, NT>(V, ldv, k, Zb, ldz, s, pb + (int64_t)it * 64 + wave * 8, pe, lane, ring_lds + (uint32_t)(sl * C::SLAB), zeros, nt);
   };
   // this lane's element of a result tile: row 4 b + i of the slab, column j of the tile
   const int row = 4 * ((lane >> 2) & 3) + (lane >> 4), cj = lane & 3;
@@ -265,6 +267,122 @@ __global__ void __launch_bounds__(512, 2)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   blkm_finish<NGS, NT>(acc, lds_raw, lane, wave, k, s, partial, pnb);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// RESTART ROTATION + pass 1 in ONE sweep (src/run.jl:363-365 followed by the first block of src/expansion.jl:116-133).
+//   V[:, out0 : knew) <- V[:, 0:cin) M          M = T Q of the restart, cin x (knew - out0), leading dimension cin
+//   partial           <- S_new' Z, Z' Z          S_new = V[:, 0:knew) after the rotation (columns below out0 are untouched),
+//                                                Z = Zb[:, 0:s): the Newton chain, written to scratch columns BEFORE this kernel
+// Separately the two kernels read cin + (knew + s) columns and write knew - out0; fused, the rotated columns never travel back
+// in: cin + s read, knew - out0 written (headline: 82 column passes instead of 102).  The rotated tile of a slab is the result
+// register of its matrix instructions -- stored, and, read as the A operand (= its transpose), multiplied with the block's
+// columns.  Columns below out0 take an identity block of M (they are inputs of the inner products too).
+// Dynamic LDS: 8 waves x ring x slab(cin + s columns) | coefficient tiles.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int NGX, int NTK, int NT> struct BlkRot {
+  static constexpr int NJX = (NGX + 1) / 2, NJZ = (NT + 1) / 2, NJ = NJX + NJZ;
+  static constexpr int SLAB = NJ * 1024;
+  static constexpr int NTM = NGX * NTK;                                             // coefficient tiles
+  static constexpr int NTS = NTK * NT, NTG = NT * (NT + 1) / 2, NTILE = NTS + NTG;  // result tiles (as BlkMfma<NTK, NT>)
+  __host__ __device__ static constexpr int x_off(int g) { return (g / 2) * 1024 + (g % 2) * 512; }
+  __host__ __device__ static constexpr int z_off(int t) { return NJX * 1024 + (t / 2) * 1024 + (t % 2) * 512; }
+  __host__ __device__ static constexpr int gt(int a, int t) { return t * (t + 1) / 2 + a; }
+  static constexpr size_t lds_bytes(int ring) { return (size_t)8 * ring * SLAB + (size_t)NTM * 128; }
+};
+
+template <int NGX, int NTK, int NT>
+__global__ void __launch_bounds__(512, 2)
+    k_brotdots_mfma(double* __restrict__ V, int64_t ldv, int cin, const double* __restrict__ M, int out0, int knew,
+                    const double* __restrict__ Zb, int64_t ldz, int s, int ring, double* __restrict__ partial, int pnb, int dbg,
+                    const double* __restrict__ zeros) {
+  using C = BlkRot<NGX, NTK, NT>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned char* myring = lds_raw + (size_t)wave * ring * C::SLAB;
+  const uint32_t ring_lds = (uint32_t)(uintptr_t)myring;
+  double* mt = reinterpret_cast<double*>(lds_raw + (size_t)8 * ring * C::SLAB);   // [g][t][kk][jj]
+  for (int e = threadIdx.x; e < C::NTM * 16; e += 512) {
+    const int tile = e >> 4, kk = (e >> 2) & 3, jj = e & 3;
+    const int g = tile / NTK, t = tile % NTK, c = 4 * g + kk, j = 4 * t + jj;
+    double v = 0.0;
+    if (c < cin && j < knew) v = j < out0 ? (c == j ? 1.0 : 0.0) : M[c + (int64_t)(j - out0) * cin];
+    mt[e] = v;
+  }
+  __syncthreads();
+  const int lin = lane * 8;
+  const int gat = (lane & 3) * 128 + (4 * ((lane >> 2) & 3) + (lane >> 4)) * 8;
+  const double* mrd = mt + (lane >> 4) * 4 + (lane & 3);
+  double acc[C::NTILE];
+#pragma unroll
+  for (int e = 0; e < C::NTILE; ++e) acc[e] = 0.0;
+  int64_t pb, pe;
+  block_range(ldv / 2, blockIdx.x, gridDim.x, pb, pe);
+  const int niter = (int)((pe - pb + 63) / 64);
+  const bool nt = (dbg & 64) != 0;
+  // store instructions per slab: the 4-column tiles that hold an output column (wave-uniform: the count must be exact)
+  const int t_lo = out0 >> 2, t_hi = (knew - 1) >> 2;
+  const int nst = (dbg & 1) ? 0 : (t_hi - t_lo + 1);
+  auto issue = [&](int it, int sl) {
+    const int64_t p = pb + (int64_t)it * 64 + wave * 8 + (lane & 7);
+    const bool in = p < pe;
+    const int cl = lane >> 3;
+    const uint32_t slab_lds = ring_lds + (uint32_t)(sl * C::SLAB);
+#pragma unroll
+    for (int j = 0; j < C::NJ; ++j) {
+      const int c = j < C::NJX ? 8 * j + cl : 8 * (j - C::NJX) + cl;
+      const bool have = in && (j < C::NJX ? c < cin : c < s);
+      const double* src = have ? (j < C::NJX ? V + (int64_t)c * ldv : Zb + (int64_t)c * ldz) + p * 2 : zeros;
+      if (nt) glds16_nt(src, slab_lds + (uint32_t)j * 1024u);
+      else glds16(src, slab_lds + (uint32_t)j * 1024u);
+    }
+  };
+  const int row = 4 * ((lane >> 2) & 3) + (lane >> 4), cj = lane & 3;
+  double* vst = V + (int64_t)cj * ldv + row;
+  for (int it = 0; it < ring - 1; ++it) issue(it, it);
+  int sl_cur = 0, sl_new = ring - 1;
+  for (int it = 0; it < niter; ++it) {
+    wait_vm((ring - 2) * C::NJ + (it < ring - 1 ? it : ring - 1) * nst);
+    issue(it + ring - 1, sl_new);
+    const unsigned char* slab = myring + (size_t)sl_cur * C::SLAB;
+    sl_new = sl_cur;
+    sl_cur = sl_cur + 1 == ring ? 0 : sl_cur + 1;
+    const int64_t pack0 = pb + (int64_t)it * 64 + wave * 8;
+    double x[NGX], d[NTK], z[NT];
+#pragma unroll
+    for (int g = 0; g < NGX; ++g) x[g] = *reinterpret_cast<const double*>(slab + C::x_off(g) + lin);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) z[u] = *reinterpret_cast<const double*>(slab + C::z_off(u) + gat);
+#pragma unroll
+    for (int t = 0; t < NTK; ++t) d[t] = 0.0;
+#pragma unroll
+    for (int g = 0; g < NGX; ++g)
+#pragma unroll
+      for (int t = 0; t < NTK; ++t) d[t] = mfma4(x[g], mrd[(g * NTK + t) * 16], d[t]);
+    if (nst) {
+      const bool ok = pack0 + (row >> 1) < pe;
+      double* dst = vst + pack0 * 2;
+#pragma unroll
+      for (int t = 0; t < NTK; ++t) {
+        if (t >= t_lo && t <= t_hi) {   // (uniform)
+          const int j = 4 * t + cj;
+          if (ok && j >= out0 && j < knew) gst8_nt(dst + (int64_t)(4 * t) * ldv, d[t]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int q = 0; q <= u; ++q) acc[C::NTS + C::gt(q, u)] = mfma4(z[q], z[u], acc[C::NTS + C::gt(q, u)]);
+#pragma unroll
+    for (int t = 0; t < NTK; ++t)
+#pragma unroll
+      for (int u = 0; u < NT; ++u) acc[t * NT + u] = mfma4(d[t], z[u], acc[t * NT + u]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  blkm_finish<NTK, NT>(acc, lds_raw, lane, wave, knew, s, partial, pnb);
 }
 
 }  // namespace ksd

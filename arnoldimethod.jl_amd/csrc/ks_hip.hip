@@ -721,6 +721,13 @@ int ks_workspace_relation_probes(const ks_workspace* ws, int* probes) {
   });
 }
 
+int ks_workspace_fused_rotations(const ks_workspace* ws, int* count) {
+  return guarded([&] {
+    KS_REQUIRE(ws && count, KS_ERR_ARGUMENT, "null argument");
+    *count = ws->rot_fused_count;
+  });
+}
+
 // diagnostics: average duration of `reps` launches of one block kernel on the workspace's basis (contents irrelevant: the
 // kernels have no data-dependent control flow); which = 0 k_bdots, 1 k_bupdate.  Leaves columns k..k+s-1 overwritten.
 int ks_debug_blk_time(ks_workspace* ws, int k, int s, int which, int reps, int dbg, double* ms_per_launch, int* grid) {

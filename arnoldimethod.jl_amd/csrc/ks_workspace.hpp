@@ -73,6 +73,16 @@ struct ks_workspace {
   // a factorisation is expanded in blocks the relation of its last column is measured (HipBackend::relation_probe).
   bool prov_vouched = false;
   int relation_probes = 0;      // probes run so far (ks_workspace_relation_probes)
+  // DEFERRED RESTART ROTATION (Float64).  The rotation of a library-run restart (rotate_tfold) is not launched at once: its
+  // coefficient matrix T Q goes to the device and the rotation stays PENDING, because the expansion that normally follows can do
+  // it in the same sweep as the first pass of its first block (k_brotdots_mfma: the rotated columns never travel back in).
+  // While pending the workspace reports itself T-lazy with an empty lazy range, so that every reader's materialize() call
+  // flushes it (rot_flush: the ordinary rotation kernel) first.  rot_fuse: the expansion being enqueued took it over.
+  bool rot_pending = false, rot_fuse = false;
+  int rot_cin = 0, rot_rr = 0, rot_out0 = 0;
+  int rot_fused_count = 0;      // rotations done by the fused kernel (ks_workspace_fused_rotations)
+  bool rot_defer_ok = false;    // set by the library's restart drivers around their rotate_and_move (never by the verbs)
+  void* zscratch = nullptr;     // device: ld x kBlkSMax elements, the Newton chain of a block whose first pass is fused
   void* probe_dev = nullptr;    // device / pinned host scratch of the probe: [sum, rows | coefficients]
   void* probe_host = nullptr;
   std::vector<char> Hshadow;
@@ -160,6 +170,7 @@ struct ks_workspace {
     (void)hipFree(Vbase ? Vbase : V); (void)hipHostFree(H); (void)hipHostFree(Q); (void)hipFree(Hd); (void)hipHostFree(Hstage);
     (void)hipFree(Hscratch); (void)hipFree(partial); (void)hipFree(partial_s); (void)hipFree(partial2); (void)hipFree(coef); (void)hipFree(red);
     (void)hipFree(scal); (void)hipHostFree(scal_h); (void)hipHostFree(coef_h);
+    if (zscratch) (void)hipFree(zscratch);
     if (probe_dev) (void)hipFree(probe_dev);
     if (probe_host) (void)hipHostFree(probe_host);
     (void)hipFree(Qd); (void)hipHostFree(Qstage); (void)hipFree(tmp); (void)hipFree(tmp2); (void)hipFree(oop);
@@ -418,8 +429,10 @@ inline void reset_lazy(ks_workspace* ws) {
   ws->lazy_hi = -1;
 }
 template <class D> void materialize_t(ks_workspace* ws);
+inline void rot_flush(ks_workspace* ws);
 inline void materialize(ks_workspace* ws) {
   gate_cancel(ws);
+  rot_flush(ws);
   if (ws->t_lazy) {  // implicit second pass: V_true = S T, one in-place triangular product over the T-lazy columns
     if (ws->dtype == KS_F64) materialize_t<double>(ws);
     else materialize_t<cd>(ws);
@@ -976,6 +989,7 @@ inline bool gate_arm(ks_workspace* ws) {
 template <class T> void rotate_tfold(ks_workspace* ws, int c0, int c, int r, const T* Qh, int ldq, int out0, int src, int dst) {
   using D = typename DevT<T>::type;
   ws->ctx->use();
+  rot_flush(ws);   // (a rotation still pending is input of this one)
   const bool gated = ws->gate_armed;
   if (!gated) KS_HIP(hipStreamSynchronize(ws->ctx->stream));  // Qstage may still be in flight from a previous rotation
   const int rr = r + (src >= 0 ? 1 : 0);
@@ -1012,6 +1026,27 @@ template <class T> void rotate_tfold(ks_workspace* ws, int c0, int c, int r, con
     }
   }
   const bool extra_elsewhere = src >= 0 && dst != out0 + r;
+  if constexpr (sizeof(T) == 8) {
+    // a restart's rotation (all maxdim + 1 columns in, the residual direction next to the truncated basis) with blocks in
+    // force: leave it to the expansion that follows (see ks_workspace::rot_pending).  That expansion starts its Newton chain
+    // from the STORED last column instead of the rotated residual direction (which does not exist yet): the two agree to the
+    // Gram deviation of the block that wrote it (stored = true column up to R_2 = I + delta), so only after a batch that ended
+    // in a block and whose deviation is at rounding level (<= 1e-12; accepted blocks may carry up to gram_dev_max = 1e-8,
+    // those take the ordinary sequence)
+    static const int defer_on = env_int("KS_ROT_DEFER", 1);
+    if (defer_on && ws->rot_defer_ok && src == ws->maxdim && !extra_elsewhere && cin == ws->maxdim + 1 && ws->sstep_eff >= 8 && ws->blk_tail && tl && thi == ws->maxdim &&
+        ws->blk_diag[2] <= 1e-12) {
+      gate_cancel(ws);   // (a pre-enqueued rotation returns at once)
+      KS_HIP(hipMemcpyAsync(ws->Qd, qs, (size_t)cin * rr * sizeof(T), hipMemcpyHostToDevice, ws->ctx->stream));
+      ws->rot_pending = true;
+      ws->rot_cin = cin; ws->rot_rr = rr; ws->rot_out0 = out0;
+      ws->t_lazy = true;            // "lazy" with an empty range: every reader flushes through materialize()
+      ws->ntrue = out0 + rr;
+      ws->t_hi = out0 + rr - 1;
+      ws->blk_tail = false;
+      return;
+    }
+  }
   if (gated) {
     if constexpr (sizeof(T) == 8) {
       if (cin == ws->gate_cin && rr <= ws->gate_rmax && __atomic_load_n(&ws->gate_h->timed_out, __ATOMIC_ACQUIRE) != ws->gate_seq) {
@@ -1034,6 +1069,15 @@ template <class T> void rotate_tfold(ks_workspace* ws, int c0, int c, int r, con
   ws->t_lazy = false;
   ws->t_hi = -1;
   ws->blk_tail = false;
+}
+
+// the pending rotation as the ordinary kernel (somebody other than a fused first pass is about to read V)
+inline void rot_flush(ks_workspace* ws) {
+  if (!ws->rot_pending) return;
+  ws->rot_pending = false;
+  ws->t_lazy = false;
+  ws->t_hi = -1;
+  rotate_device<double>(ws, 0, ws->rot_cin, ws->rot_rr, ws->rot_out0, -1);
 }
 
 // all T-lazy columns -> ordinary columns, in place (verbs outside the expansion / restart pair are about to read V)

@@ -259,6 +259,10 @@ int ks_workspace_relation_info(const ks_workspace* ws, int* breaks, double* wors
  * break exactly like a leaking restart of the library's own drivers (blocks off for the run).  *probes = measurements taken
  * since creation. */
 int ks_workspace_relation_probes(const ks_workspace* ws, int* probes);
+/* Restart rotations (src/run.jl:363-365) that ran fused with the first pass of the block expansion that followed them
+ * (k_brotdots_mfma: the rotation of a library-run restart stays pending until the next expansion is enqueued; any other reader of
+ * the basis flushes it through the ordinary rotation kernel first).  KS_ROT_DEFER=0 switches the deferral off. */
+int ks_workspace_fused_rotations(const ks_workspace* ws, int* count);
 /* Diagnostics (tools/blk_bench.py): average duration of `reps` back-to-back launches of one streaming kernel of the s-step
  * expansion at basis size k and block size s (which = 0: first pass, 1: second pass), timed with HIP events on the
  * library's stream; *grid = workgroups launched.  dbg: probe flags of the kernels (1: second pass without its stores).
