@@ -79,6 +79,7 @@ KERNEL_NAMES = {
 
 BLOCK_KERNEL_NAMES = {
     "dots": "k_bdots_mfma (s-step pass 1: P = S'Z and Z'Z for a block of s vectors, basis read once per block)",
+    "rotate": "k_brotdots_mfma (restart rotation V <- V (T Q), src/run.jl:363-365, fused with s-step pass 1 of the next block: old basis and block read once, rotated columns written, P = S'Z and Z'Z accumulated in the same sweep)",
     "fused": "k_bupdate_mfma (s-step pass 2: block = (Z - S coef) R1^-1 written in place, C = S'block and its Gram matrix; basis read once per block)",
 }
 
@@ -329,7 +330,8 @@ def main():
             # in one library call (with the explicit second pass, KS_PASSES=3, the restart's Schur factorisation overlaps the
             # tail of the expansion; with the default two-pass expansion H is final only when the batch ends)
             # (KS_BENCH_SPLIT_CYCLE=1: the two calls ks_iterate_arnoldi + ks_restart of rounds 1-2, bit-identical results)
-            blocks0 = ws.sstep_info["blocks"] if (sstep and timed) else 0
+            info0 = ws.sstep_info if (sstep and timed) else {}
+            blocks0, fused0 = info0.get("blocks", 0), info0.get("fused_rotations", 0)
             t0 = time.perf_counter()
             if split_cycle:
                 st = ws.iterate_arnoldi(op, k + 1, maxdim)
@@ -372,8 +374,14 @@ def main():
                     # kernel; other layouts pay a 24 n-byte pass per product) + k_bdots 8 n (kk + s) + k_bupdate 8 n (kk + 2 s)
                     shift_b = 0.0 if fmt["layout"] == "stencil" else 24.0 * n
                     kk = k + 1
-                    for sb in blk:
-                        state["moved"] += sb * (spmv_b + shift_b) + 8.0 * n * (kk + sb) + 8.0 * n * (kk + 2 * sb)
+                    # the rotation of the PREVIOUS restart ran fused with this cycle's first pass (k_brotdots_mfma): that launch
+                    # reads the maxdim + 1 old columns and the block, writes the rotated ones (all but the locked prefix) --
+                    # instead of pass 1's 8 n (kk + s); its bytes belong to this expansion's wall time
+                    fused_rot = info["fused_rotations"] - fused0 > 0
+                    state["fused_rotations"] = state.get("fused_rotations", 0) + (1 if fused_rot else 0)
+                    for ib, sb in enumerate(blk):
+                        p1 = 8.0 * n * ((maxdim + 1) + sb + (kk - min(state["active"], kk - 1))) if (fused_rot and ib == 0) else 8.0 * n * (kk + sb)
+                        state["moved"] += sb * (spmv_b + shift_b) + p1 + 8.0 * n * (kk + 2 * sb)
                         # FP64 work of the two block kernels per row: pass 1 (kk + (sb + 1) / 2) sb multiply-adds, pass 2
                         # (kk + sb) sb (the update) + kk sb (inner products) + sb (sb + 1) / 2 (Gram triangle)
                         state["blk_flops_dots"] = state.get("blk_flops_dots", 0.0) + 2.0 * n * (kk * sb + sb * (sb + 1) / 2.0)
@@ -647,7 +655,10 @@ def make_line(args, pkg, passes, order, world, rank, force_dist, wl, with_cpu_ba
                   "cycles_not_in_blocks": state.get("blk_irregular", 0), "smallest_pivot_ratio": state.get("blk_pivot_min"),
                   "largest_gram_deviation": state.get("blk_gram_dev"),
                   # block size in force at the end (the library halves it after an abandoned block) and abandoned blocks
-                  "s_in_force": state.get("blk_s_now"), "abandoned_blocks": state.get("blk_abandoned")} if sst else None,
+                  "s_in_force": state.get("blk_s_now"), "abandoned_blocks": state.get("blk_abandoned"),
+                  # cycles whose restart rotation ran fused with the first pass of the next block (its time and bytes are then
+                  # part of expand_seconds / moved_bytes, not of restart_seconds)
+                  "fused_rotations": state.get("fused_rotations", 0)} if sst else None,
         "spmv_layout": {"csr-dvi": "csr-dvi: %d-entry (column-row, value) dictionary, 1 B per non-zero (bit-identical products)",
                         "csr-vi": "csr-vi: %d-entry value dictionary, 4 B per non-zero (bit-identical products)",
                         "stencil": "stencil-mask: %d-slot (column-row, value) dictionary in the kernel arguments, 1 bit per slot and row (bit-identical products)",
@@ -672,11 +683,13 @@ def make_line(args, pkg, passes, order, world, rank, force_dist, wl, with_cpu_ba
         dom = max(classes, key=lambda k: classes[k]["ms"])
         d = classes[dom]
         ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-        traffic = pmc_traffic(("blk_" + dom) if (sst and state.get("blk_cycles", 0) and dom in BLOCK_KERNEL_NAMES) else dom) if (m == 216 and world == 1 and not force_dist) else None
+        blk_dom = sst and state.get("blk_cycles", 0) and dom in BLOCK_KERNEL_NAMES and (dom != "rotate" or state.get("fused_rotations", 0))
+        traffic = pmc_traffic(("blk_" + dom) if blk_dom else dom) if (m == 216 and world == 1 and not force_dist) else None
         if traffic is not None:
             traffic["measured_in_run"] = False  # read from the committed PMC passes (profiles/), not collected by this run
         roof.update({
-            "kernel": (BLOCK_KERNEL_NAMES if sst and state.get("blk_cycles", 0) else KERNEL_NAMES).get(dom, KERNEL_NAMES[dom]),
+            "kernel": ({k: v for k, v in BLOCK_KERNEL_NAMES.items() if k != "rotate" or state.get("fused_rotations", 0)}
+                       if sst and state.get("blk_cycles", 0) else KERNEL_NAMES).get(dom, KERNEL_NAMES[dom]),
             "achieved": ach,
             "frac": ach / HBM_PEAK_GBS,
             "launches": d["count"],
@@ -705,7 +718,8 @@ def make_line(args, pkg, passes, order, world, rank, force_dist, wl, with_cpu_ba
         roof.update({"kernel": "fused step (no per-kernel events)", "achieved": moved_gbs, "frac": moved_gbs / HBM_PEAK_GBS})
     roof["fused_step"] = {
         "what": ("S-STEP EXPANSION: per block of s steps, s operator products + two passes over the basis (k_bdots reads 8 n (k + s), "
-                 "k_bupdate reads 8 n (k + s) and writes 8 n s); moved_* prices exactly those launches.  survey_compulsory_frac and "
+                 "k_bupdate reads 8 n (k + s) and writes 8 n s; where the restart rotation ran fused with the first pass -- config.sstep.fused_rotations -- "
+                 "that launch reads maxdim + 1 + s columns and writes the rotated ones, and belongs to the expansion); moved_* prices exactly those launches.  survey_compulsory_frac and "
                  "algorithmic_* price the same wall time with the PER-STEP byte counts of SURVEY 8d (two / four passes over V per step): "
                  "speeds relative to those op sequences, NOT bandwidths -- they exceed the HBM peak because the block form does not move "
                  "those bytes.  " if sst and state.get("blk_cycles", 0) else "") +
