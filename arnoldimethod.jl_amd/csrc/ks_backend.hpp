@@ -88,10 +88,22 @@ template <class T> struct HipBackend : ks::Backend<T> {
           ws->rot_fuse = true;
           ws->t_lazy = false;
           ws->t_hi = -1;
+          if constexpr (sizeof(D) == 8) {
+            if (ws->spec_valid && blk_sizes[0] >= ws->spec_ne && ws->spec_sh.size() == sizeof(blk_sh)) {
+              // the first spec_ne products of this block's chain are already in the scratch columns (enqueued behind the
+              // previous expansion): the whole batch takes the shift sequence they were made with
+              std::memcpy(&blk_sh, ws->spec_sh.data(), sizeof(blk_sh));
+              ws->spec_adopt = ws->spec_ne;
+              ws->spec_used++;
+              ws->spec_valid = false;
+            }
+          }
+          spec_drop(ws);
         } else {
           rot_flush(ws);
         }
       }
+      spec_drop(ws);   // (whatever was not adopted just now is void: this batch writes to V)
       if (tpath && (bpath || ws->blk_tail || !(ws->t_lazy && j0 == ws->t_hi + 1))) {
         materialize(ws);   // whatever is lazy (either kind) becomes ordinary: this batch starts a new T
         ws->ntrue = j0;
@@ -133,9 +145,16 @@ template <class T> struct HipBackend : ks::Backend<T> {
       double tq0 = dbg ? ks::now_s() : 0.0, tq1 = 0, tq2 = 0;
       if (mb) publish_control(ws, j0, ws->Hstage_dev, 1, seq, tpath);
       else fetch_state_enqueue(ws, j0, tpath);
+      if constexpr (sizeof(D) == 8) {
+        if (bpath && jend == to && to == ws->maxdim) spec_enqueue(blk_sh);
+      }
       // reverse mailbox: the restart that follows this (last) batch will rotate the factored basis -- put that rotation into
       // the stream NOW, behind a gate the host releases when it has Q (ks_workspace.hpp: gate_arm / rotate_tfold)
-      if (early && tpath && mb && jend == to) gate_arm(ws);
+      // (not behind a block batch with the deferral on: that restart leaves its rotation pending for the next expansion's
+      // fused first pass -- ks_workspace::rot_pending -- and a gate would only be cancelled)
+      static const int defer_on = env_int("KS_ROT_DEFER", 1);
+      const bool will_defer = defer_on && bpath && sizeof(D) == 8 && ws->sstep_eff >= 8 && to == ws->maxdim;
+      if (early && tpath && mb && jend == to && !will_defer) gate_arm(ws);
       if (do_early) {
         mbox_wait(ws, 0, seq);
         if (dbg) tq1 = ks::now_s();
@@ -251,6 +270,30 @@ template <class T> struct HipBackend : ks::Backend<T> {
       ws->ritz_valid = false;   // (note_ritz of a driver that does know them follows and takes precedence)
     }
     return early_stands;
+  }
+
+  // The first products of the NEXT expansion's Newton chain, behind the batch that just went into the stream (see
+  // ks_workspace::spec_valid).  Only where the restart that follows can leave its rotation pending (the library's own drivers,
+  // Float64, blocks of >= 8) and the operator's product is enqueued without host participation.
+  void spec_enqueue(const ksd::BlkShifts<D>& sh) {
+    static const int on = env_int("KS_SPEC_CHAIN", 1);
+    if (!on || !ws->gate_allowed || ws->sstep_eff < 8 || !op->async_capable || ws->ctx->hc.allreduce != nullptr) return;
+    const int ne = std::min(10, ws->maxdim - (ws->mindim_hint + ws->maxdim) / 2 - 1);
+    if (ne < 2) return;
+    if (!ws->zscratch) {
+      KS_HIP(hipMalloc(&ws->zscratch, (size_t)ws->ld * ksd::kBlkSMax * sizeof(D)));
+      KS_HIP(hipMemsetAsync(ws->zscratch, 0, (size_t)ws->ld * ksd::kBlkSMax * sizeof(D), ws->ctx->stream));
+    }
+    char* zs = static_cast<char*>(ws->zscratch);
+    op->shift_store_cacheable = true;
+    for (int i = 0; i < ne; ++i) {
+      op->in_scale = 1.0;
+      const void* src = i == 0 ? ws->col(ws->maxdim) : static_cast<const void*>(zs + (size_t)(i - 1) * ws->ld * sizeof(D));
+      op->apply_shifted(src, zs + (size_t)i * ws->ld * sizeof(D), sh.theta[i], 0.0, sh.sigma[i], ws->ld, ws->st);
+    }
+    ws->spec_sh.assign(reinterpret_cast<const char*>(&sh), reinterpret_cast<const char*>(&sh) + sizeof(sh));
+    ws->spec_ne = ne;
+    ws->spec_valid = true;
   }
 
   // The factorisation of `from` columns was vouched for by a caller that ran the restart itself (the seam: the reference's

@@ -126,7 +126,9 @@ void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::v
     }
     auto zcol = [&](int i) -> void* { return fuse ? static_cast<void*>(zs + (size_t)i * ws->ld * sizeof(D)) : ws->col(k + i); };
     op->shift_store_cacheable = s >= 10;   // (ks_operators.hpp: pays with one inner-product pass per ten or twenty products)
-    for (int i = 0; i < s; ++i) {
+    const int adopted = fuse ? ws->spec_adopt : 0;   // products of this chain that ran speculatively behind the previous expansion
+    ws->spec_adopt = 0;
+    for (int i = adopted; i < s; ++i) {
       double tre, tim;
       if constexpr (sizeof(D) == 8) { tre = sh.theta[i]; tim = 0.0; }
       else { tre = sh.theta[i].x; tim = sh.theta[i].y; }

@@ -814,6 +814,7 @@ int ks_workspace_destroy(ks_workspace* ws) {
   return guarded([&] {
     if (!ws) return;
     (void)hipSetDevice(ws->ctx->device);
+    gate_cancel(ws);   // (a synchronisation behind an armed gate would wait for its time-out)
     (void)hipStreamSynchronize(ws->ctx->stream);
     delete ws;
   });
@@ -1148,6 +1149,7 @@ int ks_partialschur(ks_operator* A, ks_workspace* ws, const ks_params* p, const 
       ks::Mat<T> Q(static_cast<T*>(ws->Q), prm.maxdim, prm.maxdim, ws->maxdim);
       HipBackend<T> be(A, ws);
       GateScope gate_scope(ws);  // every expansion of the driver's loop is followed by the restart: its rotation may be pre-enqueued
+      ws->mindim_hint = prm.mindim;
       if (prm.initialize) be.reinitialize(prm.start_from - 1, prm.start_from == 1 ? static_cast<const T*>(v1_host) : nullptr);
       // partialschur! trusts the workspace it is handed (src/run.jl:152-179: V[:, 1:start_from-1] and H hold a partial
       // Schur decomposition, the start column is in place): so does the provenance from here on
@@ -1232,6 +1234,7 @@ int ks_expand_restart(ks_operator* A, ks_workspace* ws, const ks_params* p, int 
       const ks::Ordering ordering{prm.which};
       HipBackend<T> be(A, ws);
       GateScope gate_scope(ws);
+      ws->mindim_hint = prm.mindim;
       ks::ExpandStats st;
       double t0 = ks::now_s();
       const bool early_done = be.iterate_arnoldi_early(k_in + 1, prm.maxdim, H, st,

@@ -2197,29 +2197,35 @@ __global__ void __launch_bounds__(kBlock)
 // that is cancelled (breakdown in the last batch, an exception in the host step) or times out marks the parameters
 // cancelled and the rotation behind it returns immediately.
 struct RotGate {
-  uint64_t flag;          // host -> device: sequence number of the release (pinned, polled by the gate)
+  // host -> device (pinned, polled by the gate): (sequence number << 1) | cancel.  Release and cancellation are ONE word tied to
+  // the sequence number (round-4 advice: a `cancel` field of its own could be re-armed to 0 before a gate kernel that had not
+  // started yet read it -- which happens as soon as other kernels sit in the stream in front of the gate -- and the stale
+  // rotation behind it then ran); a gate that finds a LATER sequence number was superseded and counts as cancelled.
+  uint64_t flag;
   int32_t c, r, out0, extra_out, ldq, cancel, nq, pad_;
   uint64_t timed_out;     // device -> host: the gate gave up waiting (sequence number)
 };
 static __global__ void __launch_bounds__(kBlock) k_rot_gate(RotGate* __restrict__ host, uint64_t seq, RotGate* __restrict__ dev,
                                                             const double* __restrict__ q_host, double* __restrict__ q_dev,
                                                             long long timeout_ticks) {
-  __shared__ int state;   // 1: released, 2: gave up
+  __shared__ int state;   // 1: released, 2: gave up, 3: cancelled
   if (threadIdx.x == 0) {
     const long long t0 = wall_clock64();
     int st = 0;
     while (st == 0) {
-      if (__hip_atomic_load(&host->flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == seq) st = 1;
+      const uint64_t f = __hip_atomic_load(&host->flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((f >> 1) == seq) st = (f & 1u) ? 3 : 1;
+      else if ((f >> 1) > seq) st = 3;           // superseded: cancelled
       else if (wall_clock64() - t0 > timeout_ticks) st = 2;
       else __builtin_amdgcn_s_sleep(8);
     }
     state = st;
   }
   __syncthreads();
-  if (state == 2) {
+  if (state != 1) {
     if (threadIdx.x == 0) {
       dev->cancel = 1;
-      __hip_atomic_store(&host->timed_out, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (state == 2) __hip_atomic_store(&host->timed_out, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     return;
   }
@@ -2227,7 +2233,7 @@ static __global__ void __launch_bounds__(kBlock) k_rot_gate(RotGate* __restrict_
   for (int i = threadIdx.x; i < nq; i += kBlock) q_dev[i] = q_host[i];
   if (threadIdx.x == 0) {
     dev->c = host->c; dev->r = host->r; dev->out0 = host->out0; dev->extra_out = host->extra_out; dev->ldq = host->ldq;
-    dev->cancel = host->cancel;
+    dev->cancel = 0;
   }
 }
 

@@ -83,6 +83,20 @@ struct ks_workspace {
   int rot_fused_count = 0;      // rotations done by the fused kernel (ks_workspace_fused_rotations)
   bool rot_defer_ok = false;    // set by the library's restart drivers around their rotate_and_move (never by the verbs)
   void* zscratch = nullptr;     // device: ld x kBlkSMax elements, the Newton chain of a block whose first pass is fused
+  // SPECULATIVE CHAIN (the host step off the critical path).  When an expansion that ends at maxdim ran in blocks,
+  // the first spec_ne products of the NEXT expansion's Newton chain are enqueued right behind it -- before the host has even
+  // received H: they need the stored last column (the chain's start, see rot_pending) and shifts, for which the Ritz values of
+  // the restart BEFORE the one about to happen are taken (one restart staler than otherwise; tests/sstep_model.py: the
+  // conditioning of the Newton basis does not notice as long as ALL shifts of a block come from the same Leja sequence).  The
+  // device works on them while the host runs the Schur / reorder / restore step.  The next expansion adopts them (and the
+  // shift sequence they were made with) if its first block is a fused one of at least spec_ne steps; anything else that
+  // touches V in between drops them.  spec_sh: the BlkShifts<double> they were made with (raw bytes).
+  bool spec_valid = false;
+  int spec_ne = 0;
+  std::vector<char> spec_sh;
+  int spec_adopt = 0;                   // products the block being enqueued adopts (set by the fuse decision, consumed by enqueue_steps_blk)
+  int spec_used = 0, spec_wasted = 0;   // speculations adopted / dropped (diagnostics)
+  int mindim_hint = 0;                  // mindim of the restart driver in charge (0: unknown -> no speculation)
   void* probe_dev = nullptr;    // device / pinned host scratch of the probe: [sum, rows | coefficients]
   void* probe_host = nullptr;
   std::vector<char> Hshadow;
@@ -167,6 +181,11 @@ struct ks_workspace {
     return tmp2;
   }
   ~ks_workspace() {
+    if (gate_armed && gate_h) {  // never leave a gate waiting, and never free what the rotation behind it reads: cancel, drain
+      __atomic_store_n(&gate_h->flag, (gate_seq << 1) | 1u, __ATOMIC_RELEASE);
+      gate_armed = false;
+      (void)hipStreamSynchronize(ctx->stream);
+    }
     (void)hipFree(Vbase ? Vbase : V); (void)hipHostFree(H); (void)hipHostFree(Q); (void)hipFree(Hd); (void)hipHostFree(Hstage);
     (void)hipFree(Hscratch); (void)hipFree(partial); (void)hipFree(partial_s); (void)hipFree(partial2); (void)hipFree(coef); (void)hipFree(red);
     (void)hipFree(scal); (void)hipHostFree(scal_h); (void)hipHostFree(coef_h);
@@ -176,11 +195,6 @@ struct ks_workspace {
     (void)hipFree(Qd); (void)hipHostFree(Qstage); (void)hipFree(tmp); (void)hipFree(tmp2); (void)hipFree(oop);
     (void)hipHostFree(Hstage_early); (void)hipHostFree(mbox); (void)hipFree(ctr);
     (void)hipFree(bpart); (void)hipFree(bred); (void)hipFree(bscr); (void)hipFree(bzero);
-    if (gate_armed && gate_h) {  // never leave a gate waiting: cancel, let the stream drain
-      gate_h->cancel = 1;
-      __atomic_store_n(&gate_h->flag, gate_seq, __ATOMIC_RELEASE);
-      (void)hipStreamSynchronize(ctx->stream);
-    }
     (void)hipHostFree(gate_h); (void)hipFree(gate_d);
   }
 };
@@ -873,8 +887,7 @@ void gemm_tall_chunked(ks_workspace* ws, const TV* V, int c, int r, const TY* Yd
 // cancel a pre-enqueued rotation (its gate is released with the cancel mark: the rotation behind it returns at once)
 inline void gate_cancel(ks_workspace* ws) {
   if (!ws->gate_armed) return;
-  ws->gate_h->cancel = 1;
-  __atomic_store_n(&ws->gate_h->flag, ws->gate_seq, __ATOMIC_RELEASE);
+  __atomic_store_n(&ws->gate_h->flag, (ws->gate_seq << 1) | 1u, __ATOMIC_RELEASE);
   ws->gate_armed = false;
 }
 template <class D> void rotate_device(ks_workspace* ws, int c0, int c, int r, int out0 = 0, int extra_out = -1, bool gated = false) {
@@ -973,7 +986,6 @@ inline bool gate_arm(ks_workspace* ws) {
       !ws->use_mbox || (rot_env && std::string(rot_env) != "fma") || env_int("KS_ROTATE_VALU", 0))
     return false;
   const int cin = ws->maxdim + 1;
-  ws->gate_h->cancel = 0;
   ws->gate_seq += 1;
   ksd::k_rot_gate<<<1, kBlock, 0, ws->ctx->stream>>>(ws->gate_hd, ws->gate_seq, ws->gate_d, static_cast<const double*>(ws->Qstage_dev),
                                                      static_cast<double*>(ws->Qd), timeout_ticks);
@@ -1053,7 +1065,7 @@ template <class T> void rotate_tfold(ks_workspace* ws, int c0, int c, int r, con
         // reverse mailbox: T Q is in the pinned stage, the gate copies it and the queued rotation runs
         ksd::RotGate* g = ws->gate_h;
         g->c = cin; g->r = rr; g->out0 = out0; g->extra_out = extra_elsewhere ? dst : -1; g->ldq = cin; g->nq = cin * rr; g->cancel = 0;
-        __atomic_store_n(&g->flag, ws->gate_seq, __ATOMIC_RELEASE);
+        __atomic_store_n(&g->flag, ws->gate_seq << 1, __ATOMIC_RELEASE);
         ws->gate_armed = false;
         ws->t_lazy = false;
         ws->t_hi = -1;
@@ -1072,8 +1084,12 @@ template <class T> void rotate_tfold(ks_workspace* ws, int c0, int c, int r, con
 }
 
 // the pending rotation as the ordinary kernel (somebody other than a fused first pass is about to read V)
+inline void spec_drop(ks_workspace* ws) {
+  if (ws->spec_valid) { ws->spec_valid = false; ws->spec_wasted++; }
+}
 inline void rot_flush(ks_workspace* ws) {
   if (!ws->rot_pending) return;
+  spec_drop(ws);   // (the chain's start column is about to be overwritten)
   ws->rot_pending = false;
   ws->t_lazy = false;
   ws->t_hi = -1;
