@@ -633,9 +633,10 @@ class ArnoldiWorkspace:
         s, b, a = C.c_int(), C.c_int(), C.c_int()
         d = (C.c_double * 3)()
         check(_lib.load().ks_workspace_sstep_info(self._h, C.byref(s), C.byref(b), C.byref(a), d))
-        fr = C.c_int()
-        check(_lib.load().ks_workspace_fused_rotations(self._h, C.byref(fr)))
-        return dict(s=s.value, blocks=b.value, abandoned=a.value, pivot_stage1=d[0], pivot_stage2=d[1], gram_dev=d[2], fused_rotations=fr.value)
+        fr, sa, sd = C.c_int(), C.c_int(), C.c_int()
+        check(_lib.load().ks_workspace_fused_rotations(self._h, C.byref(fr), C.byref(sa), C.byref(sd)))
+        return dict(s=s.value, blocks=b.value, abandoned=a.value, pivot_stage1=d[0], pivot_stage2=d[1], gram_dev=d[2], fused_rotations=fr.value,
+                    chains_adopted=sa.value, chains_dropped=sd.value)
 
     @property
     def relation_info(self) -> dict:

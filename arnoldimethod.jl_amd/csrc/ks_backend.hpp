@@ -152,8 +152,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
       // the stream NOW, behind a gate the host releases when it has Q (ks_workspace.hpp: gate_arm / rotate_tfold)
       // (not behind a block batch with the deferral on: that restart leaves its rotation pending for the next expansion's
       // fused first pass -- ks_workspace::rot_pending -- and a gate would only be cancelled)
-      static const int defer_on = env_int("KS_ROT_DEFER", 1);
-      const bool will_defer = defer_on && bpath && sizeof(D) == 8 && ws->sstep_eff >= 8 && to == ws->maxdim;
+      const bool will_defer = ws->rot_defer_on && bpath && sizeof(D) == 8 && ws->sstep_eff >= 8 && to == ws->maxdim;
       if (early && tpath && mb && jend == to && !will_defer) gate_arm(ws);
       if (do_early) {
         mbox_wait(ws, 0, seq);
@@ -276,8 +275,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
   // ks_workspace::spec_valid).  Only where the restart that follows can leave its rotation pending (the library's own drivers,
   // Float64, blocks of >= 8) and the operator's product is enqueued without host participation.
   void spec_enqueue(const ksd::BlkShifts<D>& sh) {
-    static const int on = env_int("KS_SPEC_CHAIN", 1);
-    if (!on || !ws->gate_allowed || ws->sstep_eff < 8 || !op->async_capable || ws->ctx->hc.allreduce != nullptr) return;
+    if (!ws->spec_on || !ws->rot_defer_on || !ws->gate_allowed || ws->sstep_eff < 8 || !op->async_capable || ws->ctx->hc.allreduce != nullptr) return;
     const int ne = std::min(10, ws->maxdim - (ws->mindim_hint + ws->maxdim) / 2 - 1);
     if (ne < 2) return;
     if (!ws->zscratch) {

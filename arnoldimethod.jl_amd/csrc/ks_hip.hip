@@ -631,6 +631,8 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     w->passes = env_int("KS_PASSES", 2) == 3 ? 3 : 2;
     w->sstep = std::max(0, std::min(env_int("KS_SSTEP", 20), ksd::kBlkSMax));  // s-step expansion: ON by default (KS_SSTEP=0: step by step)
     w->sstep_eff = w->sstep;
+    w->rot_defer_on = env_int("KS_ROT_DEFER", 1) != 0;   // restart rotation left pending for the next expansion's fused first pass
+    w->spec_on = env_int("KS_SPEC_CHAIN", 1) != 0;        // first products of the next expansion behind the previous one
     if (const char* e = std::getenv("KS_SSTEP_GDEV_MAX")) w->blk_gdevmax = std::atof(e);
     if (const char* e = std::getenv("KS_SSTEP_PIVOT_MIN")) w->blk_pivmin = std::atof(e);
     if (const char* mr = std::getenv("KS_IMPLICIT_MAX_RATIO")) w->max_ratio = std::atof(mr);
@@ -721,10 +723,12 @@ int ks_workspace_relation_probes(const ks_workspace* ws, int* probes) {
   });
 }
 
-int ks_workspace_fused_rotations(const ks_workspace* ws, int* count) {
+int ks_workspace_fused_rotations(const ks_workspace* ws, int* count, int* spec_adopted, int* spec_dropped) {
   return guarded([&] {
-    KS_REQUIRE(ws && count, KS_ERR_ARGUMENT, "null argument");
-    *count = ws->rot_fused_count;
+    KS_REQUIRE(ws, KS_ERR_ARGUMENT, "null workspace");
+    if (count) *count = ws->rot_fused_count;
+    if (spec_adopted) *spec_adopted = ws->spec_used;
+    if (spec_dropped) *spec_dropped = ws->spec_wasted;
   });
 }
 

@@ -78,6 +78,7 @@ struct ks_workspace {
   // it in the same sweep as the first pass of its first block (k_brotdots_mfma: the rotated columns never travel back in).
   // While pending the workspace reports itself T-lazy with an empty lazy range, so that every reader's materialize() call
   // flushes it (rot_flush: the ordinary rotation kernel) first.  rot_fuse: the expansion being enqueued took it over.
+  bool rot_defer_on = true, spec_on = true;   // KS_ROT_DEFER / KS_SPEC_CHAIN at creation
   bool rot_pending = false, rot_fuse = false;
   int rot_cin = 0, rot_rr = 0, rot_out0 = 0;
   int rot_fused_count = 0;      // rotations done by the fused kernel (ks_workspace_fused_rotations)
@@ -1045,8 +1046,7 @@ template <class T> void rotate_tfold(ks_workspace* ws, int c0, int c, int r, con
     // Gram deviation of the block that wrote it (stored = true column up to R_2 = I + delta), so only after a batch that ended
     // in a block and whose deviation is at rounding level (<= 1e-12; accepted blocks may carry up to gram_dev_max = 1e-8,
     // those take the ordinary sequence)
-    static const int defer_on = env_int("KS_ROT_DEFER", 1);
-    if (defer_on && ws->rot_defer_ok && src == ws->maxdim && !extra_elsewhere && cin == ws->maxdim + 1 && ws->sstep_eff >= 8 && ws->blk_tail && tl && thi == ws->maxdim &&
+    if (ws->rot_defer_on && ws->rot_defer_ok && src == ws->maxdim && !extra_elsewhere && cin == ws->maxdim + 1 && ws->sstep_eff >= 8 && ws->blk_tail && tl && thi == ws->maxdim &&
         ws->blk_diag[2] <= 1e-12) {
       gate_cancel(ws);   // (a pre-enqueued rotation returns at once)
       KS_HIP(hipMemcpyAsync(ws->Qd, qs, (size_t)cin * rr * sizeof(T), hipMemcpyHostToDevice, ws->ctx->stream));

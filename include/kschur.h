@@ -261,8 +261,12 @@ int ks_workspace_relation_info(const ks_workspace* ws, int* breaks, double* wors
 int ks_workspace_relation_probes(const ks_workspace* ws, int* probes);
 /* Restart rotations (src/run.jl:363-365) that ran fused with the first pass of the block expansion that followed them
  * (k_brotdots_mfma: the rotation of a library-run restart stays pending until the next expansion is enqueued; any other reader of
- * the basis flushes it through the ordinary rotation kernel first).  KS_ROT_DEFER=0 switches the deferral off. */
-int ks_workspace_fused_rotations(const ks_workspace* ws, int* count);
+ * the basis flushes it through the ordinary rotation kernel first; KS_ROT_DEFER=0 at workspace creation switches the deferral
+ * off), and what became of the speculative Newton chains (the first products of the next expansion, enqueued behind the previous
+ * one so that the device works while the host runs the restart step, src/run.jl:278-360; KS_SPEC_CHAIN=0 switches them off):
+ * *spec_adopted = chains the next expansion took over, *spec_dropped = chains that were void by then (the restart did not leave
+ * its rotation pending, or something else touched the basis in between).  Any pointer may be null. */
+int ks_workspace_fused_rotations(const ks_workspace* ws, int* count, int* spec_adopted, int* spec_dropped);
 /* Diagnostics (tools/blk_bench.py): average duration of `reps` back-to-back launches of one streaming kernel of the s-step
  * expansion at basis size k and block size s (which = 0: first pass, 1: second pass), timed with HIP events on the
  * library's stream; *grid = workgroups launched.  dbg: probe flags of the kernels (1: second pass without its stores).

@@ -417,3 +417,68 @@ def test_blocks_with_real_ranks_on_one_gpu(nproc, mode, transport, s):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("-> OK") == nproc and "same: True" in r.stdout, r.stdout[-3000:]
     assert r.stdout.count("blocks>0") == nproc, r.stdout[-3000:]
+
+
+# ------------------------------------------------------------------ fused restart rotation + speculative chain (round 5)
+def _cycles(monkeypatch, defer, spec, grid=(40, 41, 42), ncycles=6, reader=None):
+    """`ncycles` restart cycles (ks_expand_restart: expansion + restart per call) of config 2's parameters on a workspace created
+    with the given switches; `reader(ws, cycle)` may look at the basis between the calls."""
+    monkeypatch.setenv("KS_ROT_DEFER", "1" if defer else "0")
+    monkeypatch.setenv("KS_SPEC_CHAIN", "1" if spec else "0")
+    mx, my, mz = grid
+    n = mx * my * mz
+    M = pkg.matrices
+    op = pkg.csr_operator(M.to_scipy(*M.laplace3d_csr(mx, my, mz), n))
+    ws = pkg.ArnoldiWorkspace(n, 40, np.float64)
+    ws.reinitialize(0, M.start_vector(n))
+    ws.iterate_arnoldi(op, 1, 20)
+    k, active, trail, ritz, seen = 20, 0, [], None, []
+    for c in range(ncycles):
+        r = ws.expand_restart(op, k, active, 20, "SR", 1e-10, 20, 40)
+        k, active = r["k"], min(r["nlock"], 19)
+        trail.append((k, active))
+        ritz = np.sort_complex(r["eigenvalues"][:k])
+        if reader is not None:
+            seen.append(reader(ws, c, k))
+    rel, orth = ws.arnoldi_relation(op, k)
+    hn = float(np.linalg.norm(np.array(ws.H)[: k + 1, :k]))
+    info = ws.sstep_info
+    ws.close()
+    return dict(trail=trail, ritz=ritz, rel=rel / hn, orth=orth, info=info, seen=seen)
+
+
+def test_fused_rotation_and_speculative_chain_match_the_plain_sequence(monkeypatch):
+    """The restart rotation left pending and done in the sweep of the next block's first pass (k_brotdots_mfma; the chain then
+    starts from the STORED last column and lives in scratch columns), without and with the speculative chain (first products
+    enqueued behind the previous expansion, shifts one restart staler), against the plain sequence (rotation kernel, chain in
+    place, fresh shifts): same restart trail, Ritz values to 1e-10, the device-side Arnoldi relation and orthogonality at the
+    level of the plain sequence.  Asserted as well: the fused path really ran (one fused rotation per cycle after the first
+    block cycle) and every speculation was adopted."""
+    plain = _cycles(monkeypatch, False, False)
+    fused = _cycles(monkeypatch, True, False)
+    spec = _cycles(monkeypatch, True, True)
+    assert plain["info"]["fused_rotations"] == 0 and plain["info"]["chains_adopted"] == 0, plain["info"]
+    assert fused["info"]["fused_rotations"] == 4 and fused["info"]["chains_adopted"] == 0, fused["info"]    # cycles 2..5 of 0..5
+    # (the chain enqueued behind the LAST cycle is dropped by the relation check that reads the basis afterwards)
+    assert spec["info"]["fused_rotations"] == 4 and spec["info"]["chains_adopted"] == 4 and spec["info"]["chains_dropped"] == 1, spec["info"]
+    for r in (fused, spec):
+        assert r["info"]["abandoned"] == 0 and r["trail"] == plain["trail"], (r["trail"], plain["trail"], r["info"])
+        assert np.abs(r["ritz"] - plain["ritz"]).max() <= 1e-10 * np.abs(plain["ritz"]).max()
+        assert r["rel"] <= max(1e-12, 3 * plain["rel"]) and r["orth"] <= 1e-12, (r["rel"], plain["rel"], r["orth"])
+
+
+def test_pending_rotation_is_flushed_for_every_reader(monkeypatch):
+    """After a library-run restart the rotation may still be PENDING (ks_workspace::rot_pending) when the call returns.
+    Whoever reads the basis before the next expansion must see the rotated columns: a download of V after every cycle gives
+    what a workspace with the deferral off gives (the flush is the same rotation kernel on the same coefficients: compared to
+    1e-14), the speculative chain enqueued for the expansion that would have followed is dropped, and the run continues."""
+    def rd(ws, c, k):
+        return np.array(ws.cols(0, k + 1))
+    a = _cycles(monkeypatch, True, True, grid=(20, 21, 22), ncycles=4, reader=rd)
+    b = _cycles(monkeypatch, False, False, grid=(20, 21, 22), ncycles=4, reader=rd)
+    assert a["trail"] == b["trail"]
+    for c, (Va, Vb) in enumerate(zip(a["seen"], b["seen"])):
+        assert Va.shape == Vb.shape and np.abs(Va - Vb).max() <= 1e-14, (c, float(np.abs(Va - Vb).max()))
+    # every pending rotation was flushed by the reader (none ran fused), every chain dropped
+    assert a["info"]["fused_rotations"] == 0 and a["info"]["chains_adopted"] == 0 and a["info"]["chains_dropped"] >= 2, a["info"]
+    assert a["rel"] <= 1e-12 and a["orth"] <= 1e-12
