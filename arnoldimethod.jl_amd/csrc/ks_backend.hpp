@@ -146,7 +146,12 @@ template <class T> struct HipBackend : ks::Backend<T> {
       if (mb) publish_control(ws, j0, ws->Hstage_dev, 1, seq, tpath);
       else fetch_state_enqueue(ws, j0, tpath);
       if constexpr (sizeof(D) == 8) {
-        if (bpath && jend == to && to == ws->maxdim) spec_enqueue(blk_sh);
+        // (only where the next expansion can be expected to adopt them: this one already had the shape of a fused first block,
+        // and the last speculation was not dropped -- after a drop the next eight cycles go without)
+        if (bpath && jend == to && to == ws->maxdim && ks_blk_rot_ok(ws->maxdim + 1, j0, blk_sizes[0])) {
+          if (ws->spec_backoff > 0) --ws->spec_backoff;
+          else spec_enqueue(blk_sh);
+        }
       }
       // reverse mailbox: the restart that follows this (last) batch will rotate the factored basis -- put that rotation into
       // the stream NOW, behind a gate the host releases when it has Q (ks_workspace.hpp: gate_arm / rotate_tfold)

@@ -95,6 +95,7 @@ struct ks_workspace {
   bool spec_valid = false;
   int spec_ne = 0;
   std::vector<char> spec_sh;
+  int spec_backoff = 0;                 // cycles to go without speculation after a dropped one
   int spec_adopt = 0;                   // products the block being enqueued adopts (set by the fuse decision, consumed by enqueue_steps_blk)
   int spec_used = 0, spec_wasted = 0;   // speculations adopted / dropped (diagnostics)
   int mindim_hint = 0;                  // mindim of the restart driver in charge (0: unknown -> no speculation)
@@ -1085,7 +1086,7 @@ template <class T> void rotate_tfold(ks_workspace* ws, int c0, int c, int r, con
 
 // the pending rotation as the ordinary kernel (somebody other than a fused first pass is about to read V)
 inline void spec_drop(ks_workspace* ws) {
-  if (ws->spec_valid) { ws->spec_valid = false; ws->spec_wasted++; }
+  if (ws->spec_valid) { ws->spec_valid = false; ws->spec_wasted++; ws->spec_backoff = 8; }
 }
 inline void rot_flush(ks_workspace* ws) {
   if (!ws->rot_pending) return;

@@ -480,5 +480,5 @@ def test_pending_rotation_is_flushed_for_every_reader(monkeypatch):
     for c, (Va, Vb) in enumerate(zip(a["seen"], b["seen"])):
         assert Va.shape == Vb.shape and np.abs(Va - Vb).max() <= 1e-14, (c, float(np.abs(Va - Vb).max()))
     # every pending rotation was flushed by the reader (none ran fused), every chain dropped
-    assert a["info"]["fused_rotations"] == 0 and a["info"]["chains_adopted"] == 0 and a["info"]["chains_dropped"] >= 2, a["info"]
+    assert a["info"]["fused_rotations"] == 0 and a["info"]["chains_adopted"] == 0 and a["info"]["chains_dropped"] >= 1, a["info"]   # (after a drop the library speculates again only eight cycles later)
     assert a["rel"] <= 1e-12 and a["orth"] <= 1e-12

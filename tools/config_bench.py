@@ -165,7 +165,8 @@ def main():
         "config": args.config, "workload": f"{what}, nev={nev}, which={which}, mindim={mindim}, maxdim={maxdim}, dtype={'c128' if esz == 16 else 'f64'}",
         "iters_per_s": state["steps"] / elapsed, "ms_per_cycle": 1e3 * elapsed / args.steps, "iterations": state["steps"],
         "dgks_second_passes": state["reorth"], "spmv_layout": fmt, "per_class": per,
-        "sstep": {"requested": args.sstep, "in_force": ws.sstep_info["s"], "block_cycles": state.get("blk_cycles", 0), "abandoned": state.get("abandoned", 0)} if args.sstep >= 2 else None,
+        "sstep": {"requested": args.sstep, "in_force": ws.sstep_info["s"], "block_cycles": state.get("blk_cycles", 0), "abandoned": state.get("abandoned", 0),
+                  **{k: ws.sstep_info[k] for k in ("fused_rotations", "chains_adopted", "chains_dropped")}} if args.sstep >= 2 else None,
         "validation": {"arnoldi_rel": rel / hnorm if hnorm else None, "orth": orth, "k": state["k"], "locked": state["active"]},
         "expansion": {"moved_GBps": moved, "moved_frac": moved / PEAK, "expand_seconds": state["t_expand"], "restart_seconds": state["t_restart"]},
     }
