@@ -1123,65 +1123,121 @@ __device__ __forceinline__ cd inv_(cd a) {
 
 __device__ __forceinline__ double bcast_(double v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ cd bcast_(cd v, int src) { return cd{__shfl(v.x, src, 64), __shfl(v.y, src, 64)}; }
+// the same with a COMPILE-TIME source lane: v_readlane_b32 (a scalar register, no LDS round trip)
+template <int SRC> __device__ __forceinline__ double rdlane_(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)(b & 0xffffffffll), SRC), hi = __builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), SRC);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int SRC> __device__ __forceinline__ cd rdlane_(cd v) { return cd{rdlane_<SRC>(v.x), rdlane_<SRC>(v.y)}; }
 
 // Cholesky R^H R = G of an s x s Hermitian matrix given by its upper triangle in LDS (column stride s), in place: on exit
 // the upper triangle holds R.  All threads of the workgroup call it; returns the smallest pivot ratio d_i / G_ii (<= 0 when
 // the matrix is not positive definite); the factorisation stops (and the caller bails) at the first ratio <= pivmin.
 // Done by WAVE 0 in registers: lane l owns column l, column i of R travels by lane broadcasts -- no barrier and no LDS round
 // trip inside the s dependent steps (the first version, thread 0 + two barriers per step, cost 10 us of a 28 us kernel).
-template <class T> __device__ double chol_upper_lds(T* G, int s, double pivmin, double* sh_ratio) {
+// (FP64 division and square root are ~300-cycle software sequences on this part and the s steps are sequential: the first
+// version paid three of them per step, 10 us at s = 20.  Now: the pivot test by cross-multiplication, 1 / sqrt(d) from the
+// hardware estimate + two Newton steps (full double precision, not correctly rounded -- every rank runs the same code, so the
+// replicated decisions stay identical), one division at the very end for the reported ratio; the reciprocals of the diagonal
+// go to dinv[] for tri_inv_lds.)
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  y = y * fma(-0.5 * d * y, y, 1.5);
+  y = y * fma(-0.5 * d * y, y, 1.5);
+  return y;
+}
+// step I of the factorisation (lane l owns column l; the source lane of every broadcast is the compile-time I)
+template <class T, int I>
+__device__ __forceinline__ void chol_steps(T (&r)[kBlkSMax], int s, int lane, double pivmin, double& wd, double& wg, bool& okay, double& myinv) {
+  if constexpr (I < kBlkSMax) {
+    if (I < s && okay) {  // (uniform)
+      double d = real_of(r[I]);
+      const double gii = d;
+#pragma unroll
+      for (int p = 0; p < I; ++p) d -= abs2_(r[p]);
+      const double di = rdlane_<I>(d), gi = rdlane_<I>(gii);
+      const bool pos = gi > 0.0 && di > pivmin * gi;   // ratio = di / gi > pivmin
+      if (!(gi > 0.0)) { wd = 0.0; wg = 1.0; }
+      else if (di * wg < wd * gi) { wd = di; wg = gi; }
+      if (!pos) {
+        okay = false;
+      } else {
+        const double rinv = rsqrt_nr(di), rii = di * rinv;
+        T a = r[I];
+        // two accumulation chains (the products are independent: the chain of subtractions was the step's critical path)
+        T a0 = zero_of(T{}), a1 = zero_of(T{});
+#pragma unroll
+        for (int p = 0; p + 1 < I; p += 2) {
+          a0 = fma_(conj_(rdlane_<I>(r[p])), r[p], a0);
+          a1 = fma_(conj_(rdlane_<I>(r[p + 1])), r[p + 1], a1);
+        }
+        if constexpr (I % 2 == 1) a0 = fma_(conj_(rdlane_<I>(r[I - 1])), r[I - 1], a0);
+        a = sub_(a, add_(a0, a1));
+        r[I] = lane == I ? from_real(rii, T{}) : scl(a, rinv);
+        if (lane == I) myinv = rinv;
+      }
+    }
+    chol_steps<T, I + 1>(r, s, lane, pivmin, wd, wg, okay, myinv);
+  }
+}
+template <class T> __device__ double chol_upper_lds(T* G, int s, double pivmin, double* sh_ratio, double* dinv) {
   const int tid = threadIdx.x;
   if (tid < 64) {
     const int lane = tid;
     T r[kBlkSMax];
 #pragma unroll
     for (int i = 0; i < kBlkSMax; ++i) r[i] = (lane < s && i <= lane && i < s) ? G[i + lane * s] : zero_of(T{});
-    double worst = 1.0;
+    double wd = 1.0, wg = 1.0;   // the smallest pivot ratio seen so far, as a fraction wd / wg
     bool okay = true;
-#pragma unroll
-    for (int i = 0; i < kBlkSMax; ++i) {
-      if (i < s && okay) {  // (uniform)
-        double d = real_of(r[i]);
-        const double gii = d;
-#pragma unroll
-        for (int p = 0; p < i; ++p) d -= abs2_(r[p]);
-        const double di = __shfl(d, i, 64), gi = __shfl(gii, i, 64);
-        const double ratio = gi > 0.0 ? di / gi : 0.0;
-        worst = fmin(worst, ratio);
-        if (!(ratio > pivmin)) {
-          okay = false;
-        } else {
-          const double rii = sqrt(di), rinv = 1.0 / rii;
-          T a = r[i];
-#pragma unroll
-          for (int p = 0; p < i; ++p) a = sub_(a, mul_(conj_(bcast_(r[p], i)), r[p]));
-          r[i] = lane == i ? from_real(rii, T{}) : scl(a, rinv);
-        }
-      }
-    }
+    double myinv = 0.0;
+    chol_steps<T, 0>(r, s, lane, pivmin, wd, wg, okay, myinv);
     if (okay && lane < s) {
 #pragma unroll
       for (int i = 0; i < kBlkSMax; ++i)
         if (i <= lane && i < s) G[i + lane * s] = r[i];
+      dinv[lane] = myinv;
     }
-    if (lane == 0) *sh_ratio = worst;
+    if (lane == 0) *sh_ratio = wd / wg;
   }
   __syncthreads();
   const double w = *sh_ratio;
   __syncthreads();
   return w;
 }
-// X = R^-1 (upper triangular, column stride s): thread c < s computes column c by back substitution
-template <class T> __device__ void tri_inv_lds(const T* Rm, T* X, int s) {
+// X = R^-1 (upper triangular, column stride s): thread c < s computes column c by back substitution.  The column lives in
+// REGISTERS (statically unrolled over the largest block size, predicated on the run-time s and c): the first version kept it in
+// LDS behind run-time indices -- 190 dependent LDS round trips for the last column, ~10 us of a 30-us kernel.
+template <class T> __device__ void tri_inv_lds(const T* Rm, T* X, int s, const double* dinv) {
+  constexpr int SMX = blk_smax<T>();
   const int c = threadIdx.x;
   if (c < s) {
-    for (int i = 0; i < s; ++i) X[i + c * s] = zero_of(T{});
-    X[c + c * s] = inv_(Rm[c + c * s]);
-    for (int i = c - 1; i >= 0; --i) {
-      T a = zero_of(T{});
-      for (int l = i + 1; l <= c; ++l) a = fma_(Rm[i + l * s], X[l + c * s], a);
-      X[i + c * s] = mul_(neg_(a), inv_(Rm[i + i * s]));
+    T x[SMX];
+#pragma unroll
+    for (int i = 0; i < SMX; ++i) x[i] = zero_of(T{});
+#pragma unroll
+    for (int i = SMX - 1; i >= 0; --i) {
+      if (i < s) {   // (uniform)
+        // x[l] is zero for l > c (never assigned) and for l >= s: the row of R is read unconditionally (loads first, then the
+        // chain -- behind per-entry predicates every load waited for its own branch), entries past s replaced by zero
+        T rrow[SMX];
+#pragma unroll
+        for (int l = i + 1; l < SMX; ++l) rrow[l] = l < s ? Rm[i + l * s] : zero_of(T{});
+        T a0 = zero_of(T{}), a1 = zero_of(T{});
+#pragma unroll
+        for (int l = i + 1; l + 1 < SMX; l += 2) {
+          a0 = fma_(rrow[l], x[l], a0);
+          a1 = fma_(rrow[l + 1], x[l + 1], a1);
+        }
+        if ((SMX - (i + 1)) % 2 == 1) a0 = fma_(rrow[SMX - 1], x[SMX - 1], a0);
+        const double di = dinv[i];   // 1 / R[i, i] (real, from the Cholesky steps)
+        const T val = i == c ? from_real(di, T{}) : scl(neg_(add_(a0, a1)), di);
+        x[i] = i <= c ? val : zero_of(T{});
+      }
     }
+#pragma unroll
+    for (int i = 0; i < SMX; ++i)
+      if (i < s) X[i + c * s] = x[i];
   }
   __syncthreads();
 }
@@ -1245,6 +1301,8 @@ __global__ void __launch_bounds__(kBlock)
   __shared__ int last_wg;
   __shared__ double sh_ratio;
   constexpr int SMX = blk_smax<T>();
+  __shared__ double dinvs[kBlkSMax];
+  __shared__ T rfinv[SMX];
   constexpr int KS = (kBlkKMax - SMX) * SMX;   // k s with k + s <= kBlkKMax, s <= SMX (<= kBlkKMax / 2)
   __shared__ T rs[KS + SMX * (SMX + 1) / 2];
   __shared__ T A1[KS];      // stage 1: P;     stage 2: C
@@ -1330,7 +1388,9 @@ __global__ void __launch_bounds__(kBlock)
     __syncthreads();
   }
   const bool too_far = stage == 2 && !(gdev <= gdevmax);
-  const double worst = too_far ? 0.0 : chol_upper_lds(Gm, s, stage == 1 ? pivmin : 0.25, &sh_ratio);
+  KS_TQ(6);
+  const double worst = too_far ? 0.0 : chol_upper_lds(Gm, s, stage == 1 ? pivmin : 0.25, &sh_ratio, dinvs);
+  KS_TQ(7);
   if (too_far || !(worst > (stage == 1 ? pivmin : 0.25))) {
     // the block is (numerically) rank deficient: a breakdown, or a Newton basis too ill-conditioned to trust.  Nothing of
     // this block has been committed to T / H; the host redoes its steps one at a time (the per-step path takes the
@@ -1343,7 +1403,7 @@ __global__ void __launch_bounds__(kBlock)
     }
     return;
   }
-  tri_inv_lds(Gm, Xi, s);
+  tri_inv_lds(Gm, Xi, s, dinvs);
   KS_TQ(4);
   if (stage == 1) {
     t_times(tb, tld, ntrue, k, s, A1, A2);   // T P
@@ -1361,8 +1421,8 @@ __global__ void __launch_bounds__(kBlock)
     }
     if (tid == 0) st->blk_piv1 = fmin(st->blk_piv1, worst);
 #ifdef KS_FIN_TIMING
-    if (tid == 0 && (k == 31 || (k == 21 && s == 20))) printf("[fin_blk stage 1 k=%d s=%d] reduce+elect %.2f | fetch %.2f | T^H %.2f | gram+chol+inv %.2f | rest %.2f us\n", k, s,
-                                    (tq[1] - tq[0]) * 0.01, (tq[2] - tq[1]) * 0.01, (tq[3] - tq[2]) * 0.01, (tq[4] - tq[3]) * 0.01, (wall_clock64() - tq[4]) * 0.01);
+    if (tid == 0 && (k == 31 || (k == 21 && s == 20))) printf("[fin_blk stage 1 k=%d s=%d] reduce+elect %.2f | fetch %.2f | T^H %.2f | gram %.2f chol %.2f inv %.2f | rest %.2f us\n", k, s,
+                                    (tq[1] - tq[0]) * 0.01, (tq[2] - tq[1]) * 0.01, (tq[3] - tq[2]) * 0.01, (tq[6] - tq[3]) * 0.01, (tq[7] - tq[6]) * 0.01, (tq[4] - tq[7]) * 0.01, (wall_clock64() - tq[4]) * 0.01);
 #endif
     return;
   }
@@ -1388,6 +1448,7 @@ __global__ void __launch_bounds__(kBlock)
     Rf[e] = v;
   }
   __syncthreads();
+  if (tid < s) rfinv[tid] = inv_(Rf[tid + tid * s]);   // (read behind the next barrier: one division per column instead of one per row and column)
   for (int e = tid; e < k * s; e += kBlock) {
     const int r = e % k, i = e / k;
     T v = bs->P[e];
@@ -1447,13 +1508,23 @@ __global__ void __launch_bounds__(kBlock)
     }
     __syncthreads();
     for (int r = tid; r < m; r += kBlock) {
+      // (row of M in registers, statically unrolled and predicated on s: behind run-time indices it lived in scratch memory,
+      // ~25 us of the stage)
       T Mrow[SMX];
-      for (int i = 1; i < s; ++i) {
-        T a = rhs[r + (i - 1) * m];
-        for (int l = 0; l < i - 1; ++l) a = sub_(a, mul_(Mrow[l], Rf[l + (i - 1) * s]));
-        Mrow[i - 1] = mul_(a, inv_(Rf[(i - 1) + (i - 1) * s]));
+#pragma unroll
+      for (int i = 1; i < SMX; ++i) {
+        Mrow[i - 1] = zero_of(T{});
+        if (i < s) {
+          T a = rhs[r + (i - 1) * m];
+#pragma unroll
+          for (int l = 0; l < SMX - 2; ++l)
+            if (l < i - 1) a = sub_(a, mul_(Mrow[l], Rf[l + (i - 1) * s]));
+          Mrow[i - 1] = mul_(a, rfinv[i - 1]);
+        }
       }
-      for (int i = 1; i < s; ++i) Hd[r + (int64_t)(k - 1 + i) * ldh] = Mrow[i - 1];
+#pragma unroll
+      for (int i = 1; i < SMX; ++i)
+        if (i < s) Hd[r + (int64_t)(k - 1 + i) * ldh] = Mrow[i - 1];
     }
     for (int e = tid; e < (ldh - m) * (s - 1); e += kBlock) {
       const int r = m + e % (ldh - m), i = 1 + e / (ldh - m);
