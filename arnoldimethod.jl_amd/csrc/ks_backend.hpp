@@ -205,8 +205,8 @@ template <class T> struct HipBackend : ks::Backend<T> {
         ws->blk_diag[0] = ws->st_h->blk_piv1;
         ws->blk_diag[1] = ws->st_h->blk_piv2;
         ws->blk_diag[2] = ws->st_h->blk_gdev;
-        int done = 0;
-        for (int sz : blk_sizes) { if (j0 + done + sz - 1 <= last_done) { done += sz; ws->blk_count++; } }
+        int done = 0, done_blocks = 0;
+        for (int sz : blk_sizes) { if (j0 + done + sz - 1 <= last_done) { done += sz; ws->blk_count++; ++done_blocks; } }
         if (blk_bail >= 0) {
           // abandoned: the rest of this range goes step by step; and since what fails is usually the conditioning of the
           // Newton basis (a spectrum the real / few shifts do not cover), later batches use smaller blocks -- 5 -> 2 -> off
@@ -221,7 +221,11 @@ template <class T> struct HipBackend : ks::Backend<T> {
           ws->sstep_eff = std::min(ws->sstep, std::max(2, nxt));
           ws->blk_clean = 0;
         }
-        stats.blocks += (int)blk_sizes.size() - (blk_bail >= 0 ? 1 : 0);
+        stats.blocks += done_blocks;   // (blocks behind an abandoned one were skipped on the device: not counted)
+      } else if (tpath && ws->sstep_eff == 1 && ws->sstep >= 2 && blk_bail < 0 && bail < 0 && bd < 0) {
+        // blocks were lowered all the way to "off" by abandoned ones (not by a broken relation: that is sstep_eff = 0 and stays):
+        // clean per-step batches count too, so that the probe of a larger block after 16 of them is reachable from here
+        if (++ws->blk_clean >= 16) { ws->sstep_eff = 2; ws->blk_clean = 0; }
       }
       if (early_ran && bd >= 0) {  // the last step broke down: withdraw (rare; the caller redoes the early part)
         std::memcpy(H.p, ws->Hbackup.data(), ws->Hbackup.size());

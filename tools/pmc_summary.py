@@ -31,6 +31,8 @@ def load(path):
 
 
 def klass(name):
+    if name.startswith("k_brotdots"):
+        return "blk_rotate"
     if name.startswith("k_bdots"):
         return "blk_dots"
     if name.startswith("k_bupdate"):
@@ -85,10 +87,18 @@ def main():
             continue
         if k == "spmv":
             alg = bpn * nnz + aux * (n + 1) + 2 * col
+        elif k == "blk_rotate":
+            # restart rotation fused with the first pass (k_brotdots_mfma<NGX, NTK, NT>): reads the old basis and the block,
+            # writes the rotated columns; the block that follows starts on `kstart` columns
+            S = 4 * int(re.search(r"k_brotdots_mfma<\d+, \d+, (\d+)>", name).group(1))
+            blk_k = kstart
+            alg = col * (rot_cols + S)
         elif k in ("blk_dots", "blk_fused"):
             # s-step kernels: k_bdots<double, NCW, S, ...> reads the kb existing columns and the S new ones, k_bupdate reads the
             # same and writes the S; kb starts at `kstart` after every rotation and grows by S per block
-            if re.search(r"k_b(?:dots|update)_ringL<", name):
+            if re.search(r"k_b(?:dots|update)_mfma<", name):
+                S = 4 * int(re.search(r"_mfma<\d+, (\d+)>", name).group(1))                       # (matrix-instruction forms: <NGS, NT>; s = 4 NT on the headline)
+            elif re.search(r"k_b(?:dots|update)_ringL<", name):
                 S = 20                                                                            # (large-block ring forms: <NCW>)
             else:
                 mm = re.search(r"k_b(?:dots|update)(?:_ring<\d+, (\d+)|<double, \d+, (\d+))", name)   # (ring forms: <NCW, S, NW, WB>)
