@@ -119,45 +119,48 @@ template <int NCW2> int go_ringL1(const BlkLaunchArgs& a) {
 
 
 // matrix-instruction forms (ks_block_mfma.hpp): row slabs per wave, no barrier in the loop.  KS_BLK_MFMA=0: the ring forms.
-inline int mfma_env() { static const int v = [] { const char* e = std::getenv("KS_BLK_MFMA"); return e ? std::atoi(e) : 127; }(); return v; }
+inline int mfma_env() { static const int v = [] { const char* e = std::getenv("KS_BLK_MFMA"); return e ? std::atoi(e) : 255; }(); return v; }
 inline int mfma_ring_env() { static const int v = [] { const char* e = std::getenv("KS_BLK_MFMA_RING"); return e ? std::atoi(e) : 3; }(); return v; }
-template <int NGS, int NT> int go_mfma(int which, const BlkLaunchArgs& a) {
+template <int NGS, int NT, bool CX = false> int go_mfma(int which, const BlkLaunchArgs& a) {
   using C = ksd::BlkMfma<NGS, NT>;
   int ring = mfma_ring_env();
-  while (ring > 2 && C::lds_bytes(ring) > 160 * 1024) --ring;
-  const size_t smem = C::lds_bytes(ring);
+  while (ring > 2 && C::lds_bytes(ring, CX) > 160 * 1024) --ring;
+  const size_t smem = C::lds_bytes(ring, CX);
   if (ring < 2 || smem > 160 * 1024) throw std::runtime_error("block kernels: slab ring does not fit the LDS");
-  const int nb = cap(a, a.num_cu, 64, sizeof(double));
+  constexpr int RV = CX ? 2 : 1;                       // ComplexF64: the real view of the basis (2 n rows, leading dimension 2 ld)
+  const int nb = cap(a, a.num_cu, 64, CX ? 16 : 8);
   const int dbg = a.dbg | (a.nt ? 64 : 0);
+  double* Vr = static_cast<double*>(a.V);
+  const int64_t ldr = a.ld * RV;
   if (which == 0) {
-    auto kern = ksd::k_bdots_mfma<NGS, NT>;
+    auto kern = ksd::k_bdots_mfma<NGS, NT, CX>;
     static bool attr = false;
     if (!attr) {
       hipcheck(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "dynamic LDS size");
       attr = true;
     }
-    kern<<<nb, 512, smem, a.stream>>>(static_cast<const double*>(a.V), a.ld, a.k, a.s, ring, static_cast<double*>(a.partial), a.pnb,
+    kern<<<nb, 512, smem, a.stream>>>(Vr, ldr, a.k, a.s, ring, static_cast<double*>(a.partial), a.pnb,
                                      static_cast<const ksd::DevState*>(a.st), dbg, static_cast<const double*>(a.zeros));
   } else {
-    auto kern = ksd::k_bupdate_mfma<NGS, NT>;
+    auto kern = ksd::k_bupdate_mfma<NGS, NT, CX>;
     static bool attr = false;
     if (!attr) {
       hipcheck(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "dynamic LDS size");
       attr = true;
     }
-    const double* zb = a.zsrc ? static_cast<const double*>(a.zsrc) : static_cast<const double*>(a.V) + (int64_t)a.k * a.ld;
-    kern<<<nb, 512, smem, a.stream>>>(static_cast<double*>(a.V), a.ld, a.k, zb, a.zsrc ? a.ldz : a.ld, a.s, ring, static_cast<const double*>(a.coefp), a.k,
+    const double* zb = a.zsrc ? static_cast<const double*>(a.zsrc) : Vr + (int64_t)a.k * ldr;
+    kern<<<nb, 512, smem, a.stream>>>(Vr, ldr, a.k, zb, a.zsrc ? a.ldz * RV : ldr, a.s, ring, static_cast<const double*>(a.coefp), a.k,
                                      static_cast<const double*>(a.r1inv), static_cast<double*>(a.partial), a.pnb,
                                      static_cast<const ksd::DevState*>(a.st), dbg, static_cast<const double*>(a.zeros));
   }
   return nb;
 }
-template <int NT, int MAXG, int G = 1> int go_mfma_by_k(int which, const BlkLaunchArgs& a) {
+template <int NT, int MAXG, int G = 1, bool CX = false> int go_mfma_by_k(int which, const BlkLaunchArgs& a) {
   if constexpr (G > MAXG) {
     throw std::runtime_error("block kernels: no matrix-instruction form for this many columns");
   } else {
-    if ((a.k + 3) / 4 == G) return go_mfma<G, NT>(which, a);
-    return go_mfma_by_k<NT, MAXG, G + 1>(which, a);
+    if ((a.k + 3) / 4 == G) return go_mfma<G, NT, CX>(which, a);
+    return go_mfma_by_k<NT, MAXG, G + 1, CX>(which, a);
   }
 }
 
@@ -304,7 +307,10 @@ int ks_blk_launch_part1(int which, const BlkLaunchArgs& a) {
   }
 }
 #else
+bool ks_blk_cx_mfma_on() { return ((mfma_env() >> 7) & 1) != 0; }
 int ks_blk_launch_part2(int which, const BlkLaunchArgs& a) {
+  // ComplexF64 blocks of 8 / 10 on the matrix instruction (real view of the basis, ks_block_mfma.hpp); bit 7 of KS_BLK_MFMA
+  if ((a.s == 8 || a.s == 10) && ((mfma_env() >> 7) & 1) && a.k <= 32) return a.s == 10 ? go_mfma_by_k<3, 8, 1, true>(which, a) : go_mfma_by_k<2, 8, 1, true>(which, a);
   switch (a.s) {
     case 1: return by_ncw<cd, 1>(which, a);
     case 2: return by_ncw<cd, 2>(which, a);

@@ -34,6 +34,8 @@ struct BlkLaunchArgs {
 int ks_blk_launch_part0(int which, const BlkLaunchArgs& a);   // Float64, block sizes 1-4
 int ks_blk_launch_part1(int which, const BlkLaunchArgs& a);   // Float64, block sizes 5, 8, 10, 20
 int ks_blk_launch_part2(int which, const BlkLaunchArgs& a);   // ComplexF64, block sizes 1-5
+// ComplexF64 blocks of 8 / 10 exist on the matrix instruction only: are those forms on (KS_BLK_MFMA bit 7)?
+bool ks_blk_cx_mfma_on();
 // which = 2: is there a fused rotation + first pass for this shape?  (Float64; cin old columns -> k new ones, block of s)
 bool ks_blk_rot_ok(int cin, int k, int s);
 inline int ks_blk_launch(int which, const BlkLaunchArgs& a) {
@@ -41,10 +43,10 @@ inline int ks_blk_launch(int which, const BlkLaunchArgs& a) {
   if (a.dtype != 0) return ks_blk_launch_part2(which, a);
   return a.s <= 4 ? ks_blk_launch_part0(which, a) : ks_blk_launch_part1(which, a);
 }
-// instantiated shapes: Float64 s in {1..5, 8, 10, 20} (8 up to 48 columns, 10 up to 32, 20 up to 24), ComplexF64 s in {1..5} up to 32 columns
+// instantiated shapes: Float64 s in {1..5, 8, 10, 20} (8 up to 48 columns, 10 up to 32, 20 up to 24), ComplexF64 s in {1..5, 8, 10} up to 32 columns
 inline bool ks_blk_shape_ok(int dtype, int k, int s) {
   if (k < 1 || k + s > 65) return false;
-  if (dtype != 0) return s >= 1 && s <= 5 && k <= 32;
+  if (dtype != 0) return ((s >= 1 && s <= 5) || ((s == 8 || s == 10) && ks_blk_cx_mfma_on())) && k <= 32;   // (8, 10: matrix-instruction forms only)
   if (s >= 1 && s <= 5) return true;
   return (s == 8 && k <= 48) || (s == 10 && k <= 32) || (s == 20 && k <= 24);
 }

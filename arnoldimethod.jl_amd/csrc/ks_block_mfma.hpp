@@ -53,28 +53,31 @@ template <int NGS, int NT> struct BlkMfma {
   __host__ __device__ static constexpr int s_off(int g) { return (g / 2) * 1024 + (g % 2) * 512; }
   __host__ __device__ static constexpr int z_off(int t) { return NJS * 1024 + (t / 2) * 1024 + (t % 2) * 512; }
   __host__ __device__ static constexpr int gt(int a, int t) { return t * (t + 1) / 2 + a; }   // tile (a, t), a <= t, of the triangle
-  static constexpr size_t lds_bytes(int ring) { return (size_t)8 * ring * SLAB + MBYTES; }
+  static constexpr size_t lds_bytes(int ring, bool cx = false) { return (size_t)8 * ring * SLAB + (cx ? 2 : 1) * (size_t)MBYTES; }
 };
 
-// per-wave accumulators -> partial[entry][workgroup].  acc: NTILE registers in the D layout (one 4 x 4 tile per block b).
-template <int NGS, int NT>
+// per-wave accumulators -> partial[entry][workgroup].  acc: NTILE registers in the D layout (one 4 x 4 tile per block b);
+// CX: NTILE more with the imaginary parts, `partial` holds complex entries (two doubles each).
+template <int NGS, int NT, bool CX = false>
 __device__ __forceinline__ void blkm_finish(double* acc, unsigned char* lds, int lane, int wave, int k, int s, double* __restrict__ partial, int pnb) {
   using C = BlkMfma<NGS, NT>;
-  double* red = reinterpret_cast<double*>(lds);   // [wave][tile][16]
+  constexpr int NA = CX ? 2 * C::NTILE : C::NTILE;
+  double* red = reinterpret_cast<double*>(lds);   // [wave][acc][16]
   __syncthreads();                                // every wave is done with its ring
 #pragma unroll
-  for (int e = 0; e < C::NTILE; ++e) {
+  for (int e = 0; e < NA; ++e) {
     double v = acc[e];
     v += __shfl_xor(v, 4, 64);
     v += __shfl_xor(v, 8, 64);
-    if ((lane & 12) == 0) red[(wave * C::NTILE + e) * 16 + (lane >> 4) * 4 + (lane & 3)] = v;
+    if ((lane & 12) == 0) red[(wave * NA + e) * 16 + (lane >> 4) * 4 + (lane & 3)] = v;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < C::NTILE * 16; e += 512) {
+  for (int e = threadIdx.x; e < NA * 16; e += 512) {
     double v = 0.0;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) v += red[w * C::NTILE * 16 + e];
-    const int tile = e >> 4, ii = (e >> 2) & 3, jj = e & 3;
+    for (int w = 0; w < 8; ++w) v += red[w * NA * 16 + e];
+    const int part = (e >> 4) / C::NTILE;          // 0: real parts, 1: imaginary parts
+    const int tile = (e >> 4) % C::NTILE, ii = (e >> 2) & 3, jj = e & 3;
     int entry = -1;
     if (tile < C::NTS) {
       const int g = tile / NT, t = tile % NT, c = 4 * g + ii, i = 4 * t + jj;
@@ -85,7 +88,7 @@ __device__ __forceinline__ void blkm_finish(double* acc, unsigned char* lds, int
       const int a = rem, i = 4 * a + ii, i2 = 4 * t + jj;
       if (i <= i2 && i2 < s) entry = k * s + gram_idx(i, i2);
     }
-    if (entry >= 0) partial[(int64_t)entry * pnb + blockIdx.x] = v;
+    if (entry >= 0) partial[((int64_t)entry * pnb + blockIdx.x) * (CX ? 2 : 1) + part] = v;
   }
 }
 
@@ -113,7 +116,12 @@ __device__ __forceinline__ void blkm_issue(const double* __restrict__ V, int64_t
 // pass 1:  partial[i k + c] = S[:, c] . Z[:, i],  partial[k s + g(i, i2)] = Z[:, i] . Z[:, i2]        (k <= 4 NGS, s <= 4 NT)
 // Dynamic LDS: 8 waves x ring x slab.
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int NGS, int NT>
+// ComplexF64 (CX): the SAME kernel on the real view of the basis -- a complex column of n rows is a real column of 2 n rows
+// (re, im interleaved; a 16-byte pack is one complex element, a slab 8 complex rows) -- plus the imaginary parts:
+//   x^H y = sum_rows x_row y_row  +  i sum_rows x_row (P y)_row,     (P y)_re = y_im,  (P y)_im = -y_re
+// P y is the operand read at the partner row (byte offset ^ 8) with the sign of the row's parity: one more LDS read and one more
+// matrix instruction per tile.  `partial` then holds complex entries.
+template <int NGS, int NT, bool CX = false>
 __global__ void __launch_bounds__(512, 2)
     k_bdots_mfma(const double* __restrict__ V, int64_t ldv, int k, int s, int ring, double* __restrict__ partial, int pnb,
                  const DevState* __restrict__ st, int dbg, const double* __restrict__ zeros) {
@@ -125,9 +133,11 @@ __global__ void __launch_bounds__(512, 2)
   unsigned char* myring = lds_raw + (size_t)wave * ring * C::SLAB;
   const uint32_t ring_lds = (uint32_t)(uintptr_t)myring;
   const int gat = (lane & 3) * 128 + (4 * ((lane >> 2) & 3) + (lane >> 4)) * 8;
-  double acc[C::NTILE];
+  const double psign = ((lane >> 4) & 1) ? -1.0 : 1.0;   // (P y) of this lane's row: + y[partner] on real rows, - on imaginary ones
+  constexpr int NA = CX ? 2 * C::NTILE : C::NTILE;
+  double acc[NA];
 #pragma unroll
-  for (int e = 0; e < C::NTILE; ++e) acc[e] = 0.0;
+  for (int e = 0; e < NA; ++e) acc[e] = 0.0;
   int64_t pb, pe;
   block_range(ldv / 2, blockIdx.x, gridDim.x, pb, pe);   // (pack-granular on purpose: ranges aligned to whole tiles ran 4 % slower)
   const int niter = (int)((pe - pb + 63) / 64);
@@ -145,22 +155,32 @@ __global__ void __launch_bounds__(512, 2)
     sl_new = sl_cur;
     sl_cur = sl_cur + 1 == ring ? 0 : sl_cur + 1;
     if (dbg & 16) continue;
-    double a[NGS], z[NT];
+    double a[NGS], z[NT], zp[CX ? NT : 1];
 #pragma unroll
     for (int t = 0; t < NT; ++t) z[t] = *reinterpret_cast<const double*>(slab + C::z_off(t) + gat);
+    if constexpr (CX) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) zp[t] = psign * *reinterpret_cast<const double*>(slab + C::z_off(t) + (gat ^ 8));
+    }
 #pragma unroll
     for (int g = 0; g < NGS; ++g) a[g] = *reinterpret_cast<const double*>(slab + C::s_off(g) + gat);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int q = 0; q <= t; ++q) acc[C::NTS + C::gt(q, t)] = mfma4(z[q], z[t], acc[C::NTS + C::gt(q, t)]);
+      for (int q = 0; q <= t; ++q) {
+        acc[C::NTS + C::gt(q, t)] = mfma4(z[q], z[t], acc[C::NTS + C::gt(q, t)]);
+        if constexpr (CX) acc[C::NTILE + C::NTS + C::gt(q, t)] = mfma4(z[q], zp[t], acc[C::NTILE + C::NTS + C::gt(q, t)]);
+      }
 #pragma unroll
     for (int g = 0; g < NGS; ++g)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[g * NT + t] = mfma4(a[g], z[t], acc[g * NT + t]);
+      for (int t = 0; t < NT; ++t) {
+        acc[g * NT + t] = mfma4(a[g], z[t], acc[g * NT + t]);
+        if constexpr (CX) acc[C::NTILE + g * NT + t] = mfma4(a[g], zp[t], acc[C::NTILE + g * NT + t]);
+      }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  blkm_finish<NGS, NT>(acc, lds_raw, lane, wave, k, s, partial, pnb);
+  blkm_finish<NGS, NT, CX>(acc, lds_raw, lane, wave, k, s, partial, pnb);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -171,7 +191,10 @@ __global__ void __launch_bounds__(512, 2)
 // stored, and ARE the operands of the inner products (as B: Qt, as A: Qt^T).
 // Dynamic LDS: 8 waves x ring x slab | coefficient tiles.
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int NGS, int NT>
+// ComplexF64 (CX), on the real view as in pass 1: a complex coefficient m acts on a column as  m_re x + m_im (J x),
+// (J x)_re = -x_im, (J x)_im = x_re  (the operand read at the partner row with a sign); the inner products take P Qt from the
+// result registers of the partner rows (lane ^ 16).  coefp / r1inv are complex then (ldc, s in complex elements).
+template <int NGS, int NT, bool CX = false>
 __global__ void __launch_bounds__(512, 2)
     k_bupdate_mfma(double* __restrict__ V, int64_t ldv, int k, const double* __restrict__ Zb, int64_t ldz, int s, int ring,
                    const double* __restrict__ coefp, int ldc, const double* __restrict__ r1inv, double* __restrict__ partial, int pnb,
@@ -183,28 +206,34 @@ __global__ void __launch_bounds__(512, 2)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned char* myring = lds_raw + (size_t)wave * ring * C::SLAB;
   const uint32_t ring_lds = (uint32_t)(uintptr_t)myring;
-  double* mt = reinterpret_cast<double*>(lds_raw + (size_t)8 * ring * C::SLAB);   // [tile][k][j]
-  for (int e = threadIdx.x; e < C::NTILE * 16; e += 512) {
-    const int tile = e >> 4, kk = (e >> 2) & 3, jj = e & 3;
+  constexpr int CD = CX ? 2 : 1;   // doubles per coefficient
+  double* mt = reinterpret_cast<double*>(lds_raw + (size_t)8 * ring * C::SLAB);   // [part][tile][k][j]  (part: real, imaginary)
+  for (int e = threadIdx.x; e < CD * C::NTILE * 16; e += 512) {
+    const int part = (e >> 4) / C::NTILE;
+    const int tile = (e >> 4) % C::NTILE, kk = (e >> 2) & 3, jj = e & 3;
     double v = 0.0;
     if (tile < C::NTS) {
       const int g = tile / NT, t = tile % NT, c = 4 * g + kk, i = 4 * t + jj;
-      if (c < k && i < s) v = -coefp[c + (int64_t)i * ldc];
+      if (c < k && i < s) v = -coefp[(c + (int64_t)i * ldc) * CD + part];
     } else {
       int t = 0, rem = tile - C::NTS;
       while (rem > t) { rem -= t + 1; ++t; }
       const int l = 4 * rem + kk, i = 4 * t + jj;
-      if (l <= i && i < s) v = r1inv[l + i * s];
+      if (l <= i && i < s) v = r1inv[(l + i * s) * CD + part];
     }
     mt[e] = v;
   }
   __syncthreads();
   const int lin = lane * 8;
   const int gat = (lane & 3) * 128 + (4 * ((lane >> 2) & 3) + (lane >> 4)) * 8;
+  const double jsign = (lane & 1) ? 1.0 : -1.0;           // (J x) of the linear pattern's row (row = lane % 16)
+  const double psign = ((lane >> 4) & 1) ? -1.0 : 1.0;    // (P y) of the result layout's row (row = 4 b + lane / 16)
   const double* mrd = mt + (lane >> 4) * 4 + (lane & 3);
-  double acc[C::NTILE];
+  const double* mri = mrd + C::NTILE * 16;
+  constexpr int NA = CX ? 2 * C::NTILE : C::NTILE;
+  double acc[NA];
 #pragma unroll
-  for (int e = 0; e < C::NTILE; ++e) acc[e] = 0.0;
+  for (int e = 0; e < NA; ++e) acc[e] = 0.0;
   int64_t pb, pe;
   block_range(ldv / 2, blockIdx.x, gridDim.x, pb, pe);   // (pack-granular on purpose: ranges aligned to whole tiles ran 4 % slower)
   const int niter = (int)((pe - pb + 63) / 64);
@@ -245,6 +274,20 @@ __global__ void __launch_bounds__(512, 2)
     for (int u = 0; u < NT; ++u)
 #pragma unroll
       for (int t = u; t < NT; ++t) d[t] = mfma4(zx[u], mrd[(C::NTS + C::gt(u, t)) * 16], d[t]);
+    if constexpr (CX) {
+#pragma unroll
+      for (int g = 0; g < NGS; ++g) {
+        const double xj = jsign * *reinterpret_cast<const double*>(slab + C::s_off(g) + (lin ^ 8));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) d[t] = mfma4(xj, mri[(g * NT + t) * 16], d[t]);
+      }
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const double zj = jsign * *reinterpret_cast<const double*>(slab + C::z_off(u) + (lin ^ 8));
+#pragma unroll
+        for (int t = u; t < NT; ++t) d[t] = mfma4(zj, mri[(C::NTS + C::gt(u, t)) * 16], d[t]);
+      }
+    }
     if (nst) {
       const bool ok = pack0 + (row >> 1) < pe;
       double* dst = zst + pack0 * 2;
@@ -253,20 +296,30 @@ __global__ void __launch_bounds__(512, 2)
         if (ok && 4 * t + cj < s) gst8_nt(dst + (int64_t)(4 * t) * ldv, d[t]);
       }
     }
-    double a[NGS];
+    double a[NGS], dp[CX ? NT : 1];
 #pragma unroll
     for (int g = 0; g < NGS; ++g) a[g] = *reinterpret_cast<const double*>(slab + C::s_off(g) + gat);
+    if constexpr (CX) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) dp[t] = psign * __shfl_xor(d[t], 16, 64);
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int q = 0; q <= t; ++q) acc[C::NTS + C::gt(q, t)] = mfma4(d[q], d[t], acc[C::NTS + C::gt(q, t)]);
+      for (int q = 0; q <= t; ++q) {
+        acc[C::NTS + C::gt(q, t)] = mfma4(d[q], d[t], acc[C::NTS + C::gt(q, t)]);
+        if constexpr (CX) acc[C::NTILE + C::NTS + C::gt(q, t)] = mfma4(d[q], dp[t], acc[C::NTILE + C::NTS + C::gt(q, t)]);
+      }
 #pragma unroll
     for (int g = 0; g < NGS; ++g)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[g * NT + t] = mfma4(a[g], d[t], acc[g * NT + t]);
+      for (int t = 0; t < NT; ++t) {
+        acc[g * NT + t] = mfma4(a[g], d[t], acc[g * NT + t]);
+        if constexpr (CX) acc[C::NTILE + g * NT + t] = mfma4(a[g], dp[t], acc[C::NTILE + g * NT + t]);
+      }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  blkm_finish<NGS, NT>(acc, lds_raw, lane, wave, k, s, partial, pnb);
+  blkm_finish<NGS, NT, CX>(acc, lds_raw, lane, wave, k, s, partial, pnb);
 }
 
 

@@ -121,6 +121,23 @@ def test_blocks_reproduce_the_per_step_expansion_complex_and_nonsymmetric(s):
         assert seen == 1
 
 
+@pytest.mark.parametrize("s", [8, 10])
+def test_complex_blocks_of_8_and_10_on_the_matrix_instruction(s):
+    """ComplexF64 blocks beyond 5 exist on the matrix instruction only (round 5: the real kernels on the real view of the basis --
+    a complex column of n rows is a real column of 2 n rows -- plus one more instruction per tile for the imaginary parts,
+    ks_block_mfma.hpp): lockstep with the per-step expansion on config 4's kind of operator."""
+    seen = 0
+    for cyc, Hs, Hb, Vs, Vb, rel, orth, info in _lockstep(_complex_op(), np.complex128, s, 6, 10, 20, "LM", 3):
+        if cyc == 0:
+            continue
+        assert info["blocks"] > 0 and info["abandoned"] == 0 and info["s"] == s, info
+        assert np.abs(Hs - Hb).max() <= 1e-11 * np.abs(Hs).max()
+        assert np.abs(Vs - Vb).max() <= 1e-9
+        assert rel <= 1e-12 * np.linalg.norm(Hb) * 10 and orth <= 1e-13
+        seen += 1
+    assert seen == 2
+
+
 CASES = {
     "config1-readme-tridiagonal": (lambda: laplace1d(100), np.float64, dict(nev=10, which="SR", mindim=10, maxdim=20, tol=1e-12)),
     "config2-parameters": (lambda: laplace3d(14, 15, 16), np.float64, dict(nev=20, which="SR", mindim=20, maxdim=40, tol=1e-12)),
