@@ -222,7 +222,7 @@ int ks_workspace_passes(const ks_workspace* ws, int* passes);
 int ks_workspace_set_passes(ks_workspace* ws, int passes, double max_ratio);
 /* S-STEP (block) EXPANSION -- a faster form of iterate_arnoldi!(A, arnoldi, from:to), src/expansion.jl:116-133, for
  * device-resident operators on one GPU.  s >= 2: the steps of a range are taken in blocks of up to s (instantiated sizes:
- * 1-5, 8, 10, 20 for Float64 -- 8 / 10 / 20 on the FP64 matrix instruction --, 1-5 for ComplexF64): s operator products build a Newton basis (shifts = Leja-ordered Ritz values
+ * 1-5, 8, 10, 20 for Float64, 1-5, 8, 10 for ComplexF64 -- 8 / 10 / 20 on the FP64 matrix instruction --): s operator products build a Newton basis (shifts = Leja-ordered Ritz values
  * of the previous restart, so the first expansion of a run still goes step by step), then TWO passes over the basis
  * orthogonalise the whole block (block classical Gram-Schmidt with Pythagorean inner products, applied twice, both times
  * carried in the triangular factor of the implicit second pass) and the s Hessenberg columns follow from the basis
@@ -233,7 +233,7 @@ int ks_workspace_set_passes(ks_workspace* ws, int passes, double max_ratio);
  * abandoned before anything is committed and its steps are redone one at a time, which takes the reference's decisions.
  * Like the implicit second pass it needs the library's provenance of the factorisation; otherwise, and for host-callback
  * operators and maxdim > 64 the expansion runs step by step.  Default s = 20 (KS_SSTEP at creation; 20 up to 24 existing
- * columns, 10 up to 32, 8 up to 48, 1-5 beyond; ComplexF64 uses the largest instantiated size <= s, i.e. 5); s = 0 / 1: off --
+ * columns, 10 up to 32, 8 up to 48, 1-5 beyond; ComplexF64: 10 / 8 up to 32 columns, 1-5 beyond); s = 0 / 1: off --
  * every step then takes the reference's DGKS decisions.  A block is also abandoned when the Gram matrix of what its first
  * stage wrote differs from I by more than
  * gram_dev_max in any entry (~ eps cond^2 of the Newton basis; the recovered H carries errors ~ eps cond): default 1e-8
