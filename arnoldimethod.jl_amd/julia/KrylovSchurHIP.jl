@@ -320,6 +320,19 @@ function relation_probes(w::HipWorkspace)
     return Int(p[])
 end
 
+"""
+    fused_rotations(w) -> (fused, chains_adopted, chains_dropped)
+
+Restart rotations that ran inside the first sweep of the block expansion that followed them, and what became of the speculative
+Newton chains (include/kschur.h, ks_workspace_fused_rotations).  Only the library's own restart drivers (`hip_partialschur`)
+leave a rotation pending; a restart run by the reference's `partialschur!` on a `HipBasis` rotates through `mul!` at once.
+"""
+function fused_rotations(w::HipWorkspace)
+    f = Ref{Cint}(0); a = Ref{Cint}(0); d = Ref{Cint}(0)
+    check(ccall((:ks_workspace_fused_rotations, LIB), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}), w.h, f, a, d))
+    return (Int(f[]), Int(a[]), Int(d[]))
+end
+
 "Array(view(V, :, j0+1:j0+ncols)): host copy of device columns"
 function columns(w::HipWorkspace{T}, j0::Integer, ncols::Integer) where {T}
     out = Matrix{T}(undef, w.n, ncols)
