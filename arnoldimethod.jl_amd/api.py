@@ -635,8 +635,10 @@ class ArnoldiWorkspace:
         check(_lib.load().ks_workspace_sstep_info(self._h, C.byref(s), C.byref(b), C.byref(a), d))
         fr, sa, sd = C.c_int(), C.c_int(), C.c_int()
         check(_lib.load().ks_workspace_fused_rotations(self._h, C.byref(fr), C.byref(sa), C.byref(sd)))
+        sr = C.c_int()
+        check(_lib.load().ks_workspace_split_rotations(self._h, C.byref(sr)))
         return dict(s=s.value, blocks=b.value, abandoned=a.value, pivot_stage1=d[0], pivot_stage2=d[1], gram_dev=d[2], fused_rotations=fr.value,
-                    chains_adopted=sa.value, chains_dropped=sd.value)
+                    split_rotations=sr.value, chains_adopted=sa.value, chains_dropped=sd.value)
 
     @property
     def relation_info(self) -> dict:
@@ -687,34 +689,17 @@ class ArnoldiWorkspace:
 
 
 def sstep_partition(dtype, k0: int, count: int, smax: int) -> list:
-    """Block sizes the s-step expansion uses for `count` steps on top of `k0` existing columns (mirror of blk_partition,
-    csrc/ks_block.hpp: instantiated sizes 1-5, 8 (up to 48 columns), 10 (up to 32) for Float64, 1-5 for ComplexF64; [] = not block-capable).  For byte
-    accounting in benchmarks: a block of s steps on k columns reads 8 n (k + s) + 8 n (k + s) and writes 8 n s bytes
-    (x2 for ComplexF64) next to its s operator products."""
-    cplx = np.dtype(dtype).kind == "c"
-
-    def ok(k, s):
-        if not (1 <= s <= 5 or (not cplx and s in (8, 10, 20))) or k < 1 or k + s > 65:
-            return False
-        if cplx:
-            return k <= 32
-        if s == 20:
-            return k <= 24
-        if s == 10:
-            return k <= 32
-        return s <= 5 if k > 48 else True
-
-    out, k = [], k0
-    while count > 0:
-        s = min(count, smax)
-        while s > 1 and not ok(k, s):
-            s -= 1
-        if not ok(k, s):
-            return []
-        out.append(s)
-        k += s
-        count -= s
-    return out
+    """Block sizes the s-step expansion uses for `count` steps on top of `k0` existing columns (ks_sstep_partition: the
+    library's own blk_partition, csrc/ks_block.hpp -- the sizes depend on which kernel forms are switched on; [] = not
+    block-capable).  For byte accounting in benchmarks: a block of s steps on k columns reads 8 n (k + s) + 8 n (k + s) and
+    writes 8 n s bytes (x2 for ComplexF64) next to its s operator products."""
+    if k0 < 1 or count < 1 or smax < 1:
+        return []
+    cap = 64
+    out = (C.c_int * cap)()
+    nb = C.c_int(0)
+    check(_lib.load().ks_sstep_partition(_dtype_code(dtype), int(k0), int(count), int(smax), out, cap, C.byref(nb)))
+    return [int(out[i]) for i in range(min(nb.value, cap))]
 
 
 # ------------------------------------------------------------------ results

@@ -83,20 +83,23 @@ template <class T> struct HipBackend : ks::Backend<T> {
       if (ws->rot_pending) {
         // the restart's rotation is still pending (rotate_tfold): this batch's first block does it in the sweep of its first
         // pass when there is a kernel for the shape -- otherwise it runs now, the ordinary way
-        if (bpath && j0 == ws->rot_out0 + ws->rot_rr && ks_blk_rot_ok(ws->rot_cin, j0, blk_sizes[0])) {
+        // (no fused kernel for the shape: the ordinary rotation kernel runs first and both passes read the chain from
+        // the scratch columns -- rot_split; what this buys is the speculative chain)
+        const bool fused_ok = bpath && ks_blk_rot_ok(ws->dtype == KS_F64 ? 0 : 1, ws->rot_cin, j0, blk_sizes[0]);
+        const bool split_ok = bpath && ws->spec_on && ks_blk_zsrc_ok(ws->dtype == KS_F64 ? 0 : 1, j0, blk_sizes[0]);
+        if (bpath && j0 == ws->rot_out0 + ws->rot_rr && (fused_ok || split_ok)) {
           ws->rot_pending = false;
           ws->rot_fuse = true;
+          ws->rot_split = !fused_ok;
           ws->t_lazy = false;
           ws->t_hi = -1;
-          if constexpr (sizeof(D) == 8) {
-            if (ws->spec_valid && blk_sizes[0] >= ws->spec_ne && ws->spec_sh.size() == sizeof(blk_sh)) {
-              // the first spec_ne products of this block's chain are already in the scratch columns (enqueued behind the
-              // previous expansion): the whole batch takes the shift sequence they were made with
-              std::memcpy(&blk_sh, ws->spec_sh.data(), sizeof(blk_sh));
-              ws->spec_adopt = ws->spec_ne;
-              ws->spec_used++;
-              ws->spec_valid = false;
-            }
+          if (ws->spec_valid && blk_sizes[0] >= ws->spec_ne && ws->spec_sh.size() == sizeof(blk_sh)) {
+            // the first spec_ne products of this block's chain are already in the scratch columns (enqueued behind the
+            // previous expansion): the whole batch takes the shift sequence they were made with
+            std::memcpy(&blk_sh, ws->spec_sh.data(), sizeof(blk_sh));
+            ws->spec_adopt = ws->spec_ne;
+            ws->spec_used++;
+            ws->spec_valid = false;
           }
           spec_drop(ws);
         } else {
@@ -145,19 +148,18 @@ template <class T> struct HipBackend : ks::Backend<T> {
       double tq0 = dbg ? ks::now_s() : 0.0, tq1 = 0, tq2 = 0;
       if (mb) publish_control(ws, j0, ws->Hstage_dev, 1, seq, tpath);
       else fetch_state_enqueue(ws, j0, tpath);
-      if constexpr (sizeof(D) == 8) {
-        // (only where the next expansion can be expected to adopt them: this one already had the shape of a fused first block,
-        // and the last speculation was not dropped -- after a drop the next eight cycles go without)
-        if (bpath && jend == to && to == ws->maxdim && ks_blk_rot_ok(ws->maxdim + 1, j0, blk_sizes[0])) {
-          if (ws->spec_backoff > 0) --ws->spec_backoff;
-          else spec_enqueue(blk_sh);
-        }
+      // (only where the next expansion can be expected to adopt them: this one already had the shape of a first block that reads
+      // its chain from scratch columns, and the last speculation was not dropped -- after a drop the next eight cycles go without)
+      if (bpath && jend == to && to == ws->maxdim &&
+          (ks_blk_rot_ok(ws->dtype == KS_F64 ? 0 : 1, ws->maxdim + 1, j0, blk_sizes[0]) || ks_blk_zsrc_ok(ws->dtype == KS_F64 ? 0 : 1, j0, blk_sizes[0]))) {
+        if (ws->spec_backoff > 0) --ws->spec_backoff;
+        else spec_enqueue(blk_sh, j0);
       }
       // reverse mailbox: the restart that follows this (last) batch will rotate the factored basis -- put that rotation into
       // the stream NOW, behind a gate the host releases when it has Q (ks_workspace.hpp: gate_arm / rotate_tfold)
       // (not behind a block batch with the deferral on: that restart leaves its rotation pending for the next expansion's
       // fused first pass -- ks_workspace::rot_pending -- and a gate would only be cancelled)
-      const bool will_defer = ws->rot_defer_on && bpath && sizeof(D) == 8 && ws->sstep_eff >= 8 && to == ws->maxdim;
+      const bool will_defer = ws->rot_defer_on && bpath && ws->sstep_eff >= 8 && to == ws->maxdim;
       if (early && tpath && mb && jend == to && !will_defer) gate_arm(ws);
       if (do_early) {
         mbox_wait(ws, 0, seq);
@@ -283,9 +285,11 @@ template <class T> struct HipBackend : ks::Backend<T> {
   // The first products of the NEXT expansion's Newton chain, behind the batch that just went into the stream (see
   // ks_workspace::spec_valid).  Only where the restart that follows can leave its rotation pending (the library's own drivers,
   // Float64, blocks of >= 8) and the operator's product is enqueued without host participation.
-  void spec_enqueue(const ksd::BlkShifts<D>& sh) {
+  void spec_enqueue(const ksd::BlkShifts<D>& sh, int k_now) {
     if (!ws->spec_on || !ws->rot_defer_on || !ws->gate_allowed || ws->sstep_eff < 8 || !op->async_capable || ws->ctx->hc.allreduce != nullptr) return;
-    const int ne = std::min(10, ws->maxdim - (ws->mindim_hint + ws->maxdim) / 2 - 1);
+    // as many products as the next first block will certainly have: it starts from about as many columns as this one did (two
+    // more are tolerated: a locked vector, a 2 x 2 block kept whole)
+    const int ne = std::min(10, ws->maxdim - k_now - 2);
     if (ne < 2) return;
     if (!ws->zscratch) {
       KS_HIP(hipMalloc(&ws->zscratch, (size_t)ws->ld * ksd::kBlkSMax * sizeof(D)));
@@ -296,7 +300,10 @@ template <class T> struct HipBackend : ks::Backend<T> {
     for (int i = 0; i < ne; ++i) {
       op->in_scale = 1.0;
       const void* src = i == 0 ? ws->col(ws->maxdim) : static_cast<const void*>(zs + (size_t)(i - 1) * ws->ld * sizeof(D));
-      op->apply_shifted(src, zs + (size_t)i * ws->ld * sizeof(D), sh.theta[i], 0.0, sh.sigma[i], ws->ld, ws->st);
+      double tre, tim;
+      if constexpr (sizeof(D) == 8) { tre = sh.theta[i]; tim = 0.0; }
+      else { tre = sh.theta[i].x; tim = sh.theta[i].y; }
+      op->apply_shifted(src, zs + (size_t)i * ws->ld * sizeof(D), tre, tim, sh.sigma[i], ws->ld, ws->st);
     }
     ws->spec_sh.assign(reinterpret_cast<const char*>(&sh), reinterpret_cast<const char*>(&sh) + sizeof(sh));
     ws->spec_ne = ne;

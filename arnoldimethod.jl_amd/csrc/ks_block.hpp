@@ -115,7 +115,9 @@ void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::v
     // rotates the basis and takes the first pass; the second pass reads the chain from the scratch columns and writes the block
     // to its place.
     const bool fuse = first && ws->rot_fuse;
+    const bool split = fuse && ws->rot_split;   // no fused kernel for the shape: the ordinary rotation, then both passes on the scratch columns
     ws->rot_fuse = false;
+    ws->rot_split = false;
     char* zs = nullptr;
     if (fuse) {
       if (!ws->zscratch) {
@@ -123,6 +125,11 @@ void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::v
         KS_HIP(hipMemsetAsync(ws->zscratch, 0, (size_t)ws->ld * ksd::kBlkSMax * sizeof(D), s_));   // the pad rows (n .. ld) stay zero: operators write rows < n only
       }
       zs = static_cast<char*>(ws->zscratch);
+    }
+    if (split) {
+      // (in place: reads the old basis including its last column -- the chain's start, which it does not write: out0 + rr <= maxdim)
+      rotate_device<D>(ws, 0, ws->rot_cin, ws->rot_rr, ws->rot_out0, -1);
+      ws->rot_split_count++;
     }
     auto zcol = [&](int i) -> void* { return fuse ? static_cast<void*>(zs + (size_t)i * ws->ld * sizeof(D)) : ws->col(k + i); };
     op->shift_store_cacheable = s >= 10;   // (ks_operators.hpp: pays with one inner-product pass per ten or twenty products)
@@ -156,14 +163,14 @@ void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::v
                                                 ws->blk_gdevmax, ws->st, ws->ctr);
       }
     };
-    if (fuse) {
+    if (fuse && !split) {
       // reads the old basis and Z, writes the rotated columns
       ProfScope ps(cx, KSP_ROTATE, nb8 * (ws->rot_cin + s + ws->rot_rr));
       nb1 = launch_blk<D>(ws, 2, k, s, true);
       ws->rot_fused_count++;
     } else {
       ProfScope ps(cx, KSP_DOTS, nb8 * (k + s));               // reads S[:, 0:k) and Z
-      nb1 = launch_blk<D>(ws, 0, k, s);
+      nb1 = launch_blk<D>(ws, 0, k, s, fuse);
     }
     fin(1, nb1);
     {

@@ -139,7 +139,8 @@ template <int NGS, int NT, bool CX = false> int go_mfma(int which, const BlkLaun
       hipcheck(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "dynamic LDS size");
       attr = true;
     }
-    kern<<<nb, 512, smem, a.stream>>>(Vr, ldr, a.k, a.s, ring, static_cast<double*>(a.partial), a.pnb,
+    const double* zb = a.zsrc ? static_cast<const double*>(a.zsrc) : Vr + (int64_t)a.k * ldr;
+    kern<<<nb, 512, smem, a.stream>>>(Vr, ldr, a.k, zb, a.zsrc ? a.ldz * RV : ldr, a.s, ring, static_cast<double*>(a.partial), a.pnb,
                                      static_cast<const ksd::DevState*>(a.st), dbg, static_cast<const double*>(a.zeros));
   } else {
     auto kern = ksd::k_bupdate_mfma<NGS, NT, CX>;
@@ -164,38 +165,49 @@ template <int NT, int MAXG, int G = 1, bool CX = false> int go_mfma_by_k(int whi
   }
 }
 
-#if KS_BLK_PART == 1
+#if KS_BLK_PART >= 1
 // restart rotation fused with the first pass (k_brotdots_mfma): the instantiated (column groups in, column tiles out, block tiles)
-template <int NGX, int NTK, int NT> int go_rot(const BlkLaunchArgs& a) {
+// -- Float64 in part 1, ComplexF64 (real view of the basis) in part 2
+template <int NGX, int NTK, int NT, bool CX> int go_rot(const BlkLaunchArgs& a) {
   using C = ksd::BlkRot<NGX, NTK, NT>;
   int ring = mfma_ring_env();
-  while (ring > 2 && C::lds_bytes(ring) > 160 * 1024) --ring;
-  const size_t smem = C::lds_bytes(ring);
+  while (ring > 2 && C::lds_bytes(ring, CX) > 160 * 1024) --ring;
+  const size_t smem = C::lds_bytes(ring, CX);
   if (ring < 2 || smem > 160 * 1024) throw std::runtime_error("block kernels: slab ring of the fused rotation does not fit the LDS");
-  const int nb = cap(a, a.num_cu, 64, sizeof(double));
-  auto kern = ksd::k_brotdots_mfma<NGX, NTK, NT>;
+  constexpr int RV = CX ? 2 : 1;
+  const int nb = cap(a, a.num_cu, 64, CX ? 16 : 8);
+  auto kern = ksd::k_brotdots_mfma<NGX, NTK, NT, CX>;
   static bool attr = false;
   if (!attr) {
     hipcheck(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "dynamic LDS size");
     attr = true;
   }
-  kern<<<nb, 512, smem, a.stream>>>(static_cast<double*>(a.V), a.ld, a.cin, static_cast<const double*>(a.rotm), a.out0, a.k,
-                                   static_cast<const double*>(a.zsrc), a.ldz, a.s, ring, static_cast<double*>(a.partial), a.pnb,
+  kern<<<nb, 512, smem, a.stream>>>(static_cast<double*>(a.V), a.ld * RV, a.cin, static_cast<const double*>(a.rotm), a.out0, a.k,
+                                   static_cast<const double*>(a.zsrc), a.ldz * RV, a.s, ring, static_cast<double*>(a.partial), a.pnb,
                                    a.dbg | (a.nt ? 64 : 0), static_cast<const double*>(a.zeros));
   return nb;
 }
+#if KS_BLK_PART == 1
 #define KS_ROT_SHAPES(X) X(11, 6, 5) X(11, 7, 3) X(11, 8, 3) X(11, 8, 2) X(6, 3, 3) X(6, 4, 3) X(6, 4, 2)
+constexpr bool kRotCX = false;
+#else
+#define KS_ROT_SHAPES(X) X(6, 3, 3) X(6, 4, 3) X(6, 4, 2)
+constexpr bool kRotCX = true;
+#endif
+// (the block's tile count is rounded up to an instantiated one: the kernel takes s at run time, missing columns are zeros)
 inline bool rot_shape(int cin, int k, int s, int& ngx, int& ntk, int& nt) {
-  ngx = (cin + 3) / 4; ntk = (k + 3) / 4; nt = (s + 3) / 4;
-#define KS_ROT_HAS(A, B, C_) if (ngx == A && ntk == B && nt == C_) return true;
+  ngx = (cin + 3) / 4; ntk = (k + 3) / 4;
+  const int need = (s + 3) / 4;
+  nt = 0;
+#define KS_ROT_HAS(A, B, C_) if (ngx == A && ntk == B && need <= C_ && (nt == 0 || C_ < nt)) nt = C_;
   KS_ROT_SHAPES(KS_ROT_HAS)
 #undef KS_ROT_HAS
-  return false;
+  return nt != 0;
 }
 inline int go_rot_by_shape(const BlkLaunchArgs& a) {
   int ngx, ntk, nt;
   if (!a.zsrc || !a.rotm || !rot_shape(a.cin, a.k, a.s, ngx, ntk, nt)) throw std::runtime_error("block kernels: no fused rotation for this shape");
-#define KS_ROT_GO(A, B, C_) if (ngx == A && ntk == B && nt == C_) return go_rot<A, B, C_>(a);
+#define KS_ROT_GO(A, B, C_) if (ngx == A && ntk == B && nt == C_) return go_rot<A, B, C_, kRotCX>(a);
   KS_ROT_SHAPES(KS_ROT_GO)
 #undef KS_ROT_GO
   throw std::runtime_error("block kernels: no fused rotation for this shape");
@@ -288,12 +300,23 @@ int ks_blk_launch_part0(int which, const BlkLaunchArgs& a) {
   }
 }
 #elif KS_BLK_PART == 1
-bool ks_blk_rot_ok(int cin, int k, int s) {
-  int a, b, c;
-  // (the second pass must be the matrix-instruction form too: only it reads the block from scratch columns)
+int ks_blk_mfma_nt_f64(int k, int s) {
+  const int m = mfma_env();
+  if (s < 1 || k < 1) return 0;
+  // (the class follows from s alone -- the same one the instantiated sizes 8 / 10 / 20 dispatch to)
+  if (s <= 8) return (k <= 48 && ((m >> 4) & 3) == 3) ? 2 : 0;
+  if (s <= 12) return (k <= 32 && ((m >> 2) & 3) == 3) ? 3 : 0;
+  return (s <= 20 && k <= 24 && (m & 3) == 3) ? 5 : 0;
+}
+// second pass of a block on the matrix instruction (only that form reads the block from scratch columns)?
+static bool pass2_mfma(int k, int s) {
   const int bit2 = s == 20 ? 1 : (s == 10 ? 3 : (s == 8 ? 5 : -1));
-  if (bit2 < 0 || !((mfma_env() >> bit2) & 1) || !((mfma_env() >> 6) & 1)) return false;
-  if (!(s == 20 ? k <= 24 : (s == 10 ? k <= 32 : k <= 48))) return false;
+  if (bit2 >= 0) return ((mfma_env() >> bit2) & 1) && (s == 20 ? k <= 24 : (s == 10 ? k <= 32 : k <= 48));
+  return s > 5 && ks_blk_mfma_nt_f64(k, s) > 0;
+}
+bool ks_blk_rot_ok_f64(int cin, int k, int s) {
+  int a, b, c;
+  if (!pass2_mfma(k, s) || !((mfma_env() >> 6) & 1)) return false;
   return k >= 1 && cin >= k && rot_shape(cin, k, s, a, b, c);
 }
 int ks_blk_launch_part1(int which, const BlkLaunchArgs& a) {
@@ -303,14 +326,34 @@ int ks_blk_launch_part1(int which, const BlkLaunchArgs& a) {
     case 8: return by_ncw<double, 8>(which, a);
     case 10: return by_ncw<double, 10>(which, a);
     case 20: return by_ncw<double, 20>(which, a);
-    default: throw std::runtime_error("block kernels: block size not in this part");
+    default:
+      // sizes without register / ring forms: the matrix-instruction kernel of the next tile count (run-time s)
+      switch (ks_blk_mfma_nt_f64(a.k, a.s)) {
+        case 2: return go_mfma_by_k<2, 12>(which, a);
+        case 3: return go_mfma_by_k<3, 8>(which, a);
+        case 5: return go_mfma_by_k<5, 6>(which, a);
+        default: throw std::runtime_error("block kernels: block size not in this part");
+      }
   }
 }
 #else
-bool ks_blk_cx_mfma_on() { return ((mfma_env() >> 7) & 1) != 0; }
+int ks_blk_mfma_nt_c64(int k, int s) {
+  if (!((mfma_env() >> 7) & 1) || k < 1 || k > 32 || s < 1) return 0;
+  return s <= 8 ? 2 : (s <= 10 ? 3 : 0);   // (k_fin_blk<cd> holds factors of up to 10 x 10: blk_smax)
+}
+bool ks_blk_rot_ok_c64(int cin, int k, int s) {
+  int a, b, c;
+  if (!(s > 5 && ks_blk_mfma_nt_c64(k, s) > 0) || !((mfma_env() >> 6) & 1)) return false;
+  return k >= 1 && cin >= k && rot_shape(cin, k, s, a, b, c);
+}
 int ks_blk_launch_part2(int which, const BlkLaunchArgs& a) {
-  // ComplexF64 blocks of 8 / 10 on the matrix instruction (real view of the basis, ks_block_mfma.hpp); bit 7 of KS_BLK_MFMA
-  if ((a.s == 8 || a.s == 10) && ((mfma_env() >> 7) & 1) && a.k <= 32) return a.s == 10 ? go_mfma_by_k<3, 8, 1, true>(which, a) : go_mfma_by_k<2, 8, 1, true>(which, a);
+  if (which == 2) return go_rot_by_shape(a);
+  // ComplexF64 blocks beyond 5 run on the matrix instruction only (real view of the basis, ks_block_mfma.hpp); bit 7 of KS_BLK_MFMA
+  if (a.s > 5) {
+    const int nt = ks_blk_mfma_nt_c64(a.k, a.s);
+    if (nt == 2) return go_mfma_by_k<2, 8, 1, true>(which, a);
+    if (nt == 3) return go_mfma_by_k<3, 8, 1, true>(which, a);
+  }
   switch (a.s) {
     case 1: return by_ncw<cd, 1>(which, a);
     case 2: return by_ncw<cd, 2>(which, a);

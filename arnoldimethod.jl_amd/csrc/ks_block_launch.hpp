@@ -21,7 +21,7 @@ struct BlkLaunchArgs {
   int nt;              // non-temporal loads of the basis
   int num_cu, bpc;     // device CUs, cap on resident workgroups per CU (ks_ctx::bpc)
   hipStream_t stream;
-  // block columns read from elsewhere than V[:, k : k + s) (matrix-instruction forms of the second pass and the fused
+  // block columns read from elsewhere than V[:, k : k + s) (matrix-instruction forms of both passes and the fused
   // rotation: the Newton chain was written to scratch columns); null: in place
   const void* zsrc = nullptr;
   int64_t ldz = 0;
@@ -34,19 +34,29 @@ struct BlkLaunchArgs {
 int ks_blk_launch_part0(int which, const BlkLaunchArgs& a);   // Float64, block sizes 1-4
 int ks_blk_launch_part1(int which, const BlkLaunchArgs& a);   // Float64, block sizes 5, 8, 10, 20
 int ks_blk_launch_part2(int which, const BlkLaunchArgs& a);   // ComplexF64, block sizes 1-5
-// ComplexF64 blocks of 8 / 10 exist on the matrix instruction only: are those forms on (KS_BLK_MFMA bit 7)?
-bool ks_blk_cx_mfma_on();
-// which = 2: is there a fused rotation + first pass for this shape?  (Float64; cin old columns -> k new ones, block of s)
-bool ks_blk_rot_ok(int cin, int k, int s);
+// The matrix-instruction forms (ks_block_mfma.hpp) take the block size at run time -- a block of s steps runs on the kernel of
+// ceil(s / 4) column tiles, the missing columns are zeros --, so every size up to 4 NT of an instantiated tile count NT exists:
+// Float64 NT = 2 (s <= 8, up to 48 columns), 3 (s <= 12, up to 32), 5 (s <= 20, up to 24); ComplexF64 NT = 2, 3 (s <= 10) up to 32 columns.
+// Tile count for (dtype, k, s) if those forms are switched on (KS_BLK_MFMA) for BOTH passes, else 0.
+int ks_blk_mfma_nt_f64(int k, int s);
+int ks_blk_mfma_nt_c64(int k, int s);
+inline int ks_blk_mfma_nt(int dtype, int k, int s) { return dtype == 0 ? ks_blk_mfma_nt_f64(k, s) : ks_blk_mfma_nt_c64(k, s); }
+// both passes of this block can read its columns from scratch columns (BlkLaunchArgs::zsrc: matrix-instruction forms only)
+inline bool ks_blk_zsrc_ok(int dtype, int k, int s) { return s > 5 && ks_blk_mfma_nt(dtype, k, s) > 0; }
+// which = 2: is there a fused rotation + first pass for this shape?  (cin old columns -> k new ones, block of s)
+bool ks_blk_rot_ok_f64(int cin, int k, int s);
+bool ks_blk_rot_ok_c64(int cin, int k, int s);
+inline bool ks_blk_rot_ok(int dtype, int cin, int k, int s) { return dtype == 0 ? ks_blk_rot_ok_f64(cin, k, s) : ks_blk_rot_ok_c64(cin, k, s); }
 inline int ks_blk_launch(int which, const BlkLaunchArgs& a) {
-  if (which == 2) return ks_blk_launch_part1(which, a);
   if (a.dtype != 0) return ks_blk_launch_part2(which, a);
   return a.s <= 4 ? ks_blk_launch_part0(which, a) : ks_blk_launch_part1(which, a);
 }
-// instantiated shapes: Float64 s in {1..5, 8, 10, 20} (8 up to 48 columns, 10 up to 32, 20 up to 24), ComplexF64 s in {1..5, 8, 10} up to 32 columns
+// shapes with a kernel: block sizes 1-5 in the register forms (ComplexF64 up to 32 columns); Float64 8 (up to 48 columns), 10 (up
+// to 32), 20 (up to 24) in register / ring forms; everything else up to 20 (ComplexF64: 10) on the matrix instruction only
 inline bool ks_blk_shape_ok(int dtype, int k, int s) {
-  if (k < 1 || k + s > 65) return false;
-  if (dtype != 0) return ((s >= 1 && s <= 5) || ((s == 8 || s == 10) && ks_blk_cx_mfma_on())) && k <= 32;   // (8, 10: matrix-instruction forms only)
-  if (s >= 1 && s <= 5) return true;
-  return (s == 8 && k <= 48) || (s == 10 && k <= 32) || (s == 20 && k <= 24);
+  if (k < 1 || s < 1 || k + s > 65) return false;
+  if (dtype != 0) return k <= 32 && (s <= 5 || ks_blk_mfma_nt_c64(k, s) > 0);
+  if (s <= 5) return true;
+  if ((s == 8 && k <= 48) || (s == 10 && k <= 32) || (s == 20 && k <= 24)) return true;
+  return ks_blk_mfma_nt_f64(k, s) > 0;
 }

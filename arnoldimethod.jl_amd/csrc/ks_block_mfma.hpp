@@ -114,6 +114,7 @@ __device__ __forceinline__ void blkm_issue(const double* __restrict__ V, int64_t
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // pass 1:  partial[i k + c] = S[:, c] . Z[:, i],  partial[k s + g(i, i2)] = Z[:, i] . Z[:, i2]        (k <= 4 NGS, s <= 4 NT)
+// Z = Zb[:, 0:s): the columns V[:, k : k + s) (in place), or scratch columns the Newton chain was written to.
 // Dynamic LDS: 8 waves x ring x slab.
 // ---------------------------------------------------------------------------------------------------------------------------
 // ComplexF64 (CX): the SAME kernel on the real view of the basis -- a complex column of n rows is a real column of 2 n rows
@@ -123,8 +124,8 @@ __device__ __forceinline__ void blkm_issue(const double* __restrict__ V, int64_t
 // matrix instruction per tile.  `partial` then holds complex entries.
 template <int NGS, int NT, bool CX = false>
 __global__ void __launch_bounds__(512, 2)
-    k_bdots_mfma(const double* __restrict__ V, int64_t ldv, int k, int s, int ring, double* __restrict__ partial, int pnb,
-                 const DevState* __restrict__ st, int dbg, const double* __restrict__ zeros) {
+    k_bdots_mfma(const double* __restrict__ V, int64_t ldv, int k, const double* __restrict__ Zb, int64_t ldz, int s, int ring,
+                 double* __restrict__ partial, int pnb, const DevState* __restrict__ st, int dbg, const double* __restrict__ zeros) {
   if (st && st->breakdown >= 0) return;
   using C = BlkMfma<NGS, NT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -144,7 +145,7 @@ __global__ void __launch_bounds__(512, 2)
   const bool nt = (dbg & 64) != 0;
   auto issue = [&](int it, int sl) {
     if (dbg & 32) return;
-    blkm_issue<NGS, NT>(V, ldv, k, V + (int64_t)k * ldv, ldv, s, pb + (int64_t)it * 64 + wave * 8, pe, lane, ring_lds + (uint32_t)(sl * C::SLAB), zeros, nt);
+    blkm_issue<NGS, NT>(V, ldv, k, Zb, ldz, s, pb + (int64_t)it * 64 + wave * 8, pe, lane, ring_lds + (uint32_t)(sl * C::SLAB), zeros, nt);
   };
   for (int it = 0; it < ring - 1; ++it) issue(it, it);
   int sl_cur = 0, sl_new = ring - 1;
@@ -342,10 +343,13 @@ template <int NGX, int NTK, int NT> struct BlkRot {
   __host__ __device__ static constexpr int x_off(int g) { return (g / 2) * 1024 + (g % 2) * 512; }
   __host__ __device__ static constexpr int z_off(int t) { return NJX * 1024 + (t / 2) * 1024 + (t % 2) * 512; }
   __host__ __device__ static constexpr int gt(int a, int t) { return t * (t + 1) / 2 + a; }
-  static constexpr size_t lds_bytes(int ring) { return (size_t)8 * ring * SLAB + (size_t)NTM * 128; }
+  static constexpr size_t lds_bytes(int ring, bool cx = false) { return (size_t)8 * ring * SLAB + (cx ? 2 : 1) * (size_t)NTM * 128; }
 };
 
-template <int NGX, int NTK, int NT>
+// ComplexF64 (CX), on the real view as in the two passes: M is complex (interleaved), a coefficient m acts on a column as
+// m_re x + m_im (J x) -- the operand read at the partner row with a sign --, the inner products take P z from the partner rows of
+// the block's columns (one more LDS read and one more matrix instruction per tile); `partial` holds complex entries.
+template <int NGX, int NTK, int NT, bool CX = false>
 __global__ void __launch_bounds__(512, 2)
     k_brotdots_mfma(double* __restrict__ V, int64_t ldv, int cin, const double* __restrict__ M, int out0, int knew,
                     const double* __restrict__ Zb, int64_t ldz, int s, int ring, double* __restrict__ partial, int pnb, int dbg,
@@ -356,21 +360,27 @@ __global__ void __launch_bounds__(512, 2)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned char* myring = lds_raw + (size_t)wave * ring * C::SLAB;
   const uint32_t ring_lds = (uint32_t)(uintptr_t)myring;
-  double* mt = reinterpret_cast<double*>(lds_raw + (size_t)8 * ring * C::SLAB);   // [g][t][kk][jj]
-  for (int e = threadIdx.x; e < C::NTM * 16; e += 512) {
-    const int tile = e >> 4, kk = (e >> 2) & 3, jj = e & 3;
+  constexpr int CD = CX ? 2 : 1;   // doubles per coefficient
+  double* mt = reinterpret_cast<double*>(lds_raw + (size_t)8 * ring * C::SLAB);   // [part][g][t][kk][jj]  (part: real, imaginary)
+  for (int e = threadIdx.x; e < CD * C::NTM * 16; e += 512) {
+    const int part = (e >> 4) / C::NTM;
+    const int tile = (e >> 4) % C::NTM, kk = (e >> 2) & 3, jj = e & 3;
     const int g = tile / NTK, t = tile % NTK, c = 4 * g + kk, j = 4 * t + jj;
     double v = 0.0;
-    if (c < cin && j < knew) v = j < out0 ? (c == j ? 1.0 : 0.0) : M[c + (int64_t)(j - out0) * cin];
+    if (c < cin && j < knew) v = j < out0 ? ((c == j && part == 0) ? 1.0 : 0.0) : M[(c + (int64_t)(j - out0) * cin) * CD + part];
     mt[e] = v;
   }
   __syncthreads();
   const int lin = lane * 8;
   const int gat = (lane & 3) * 128 + (4 * ((lane >> 2) & 3) + (lane >> 4)) * 8;
+  const double jsign = (lane & 1) ? 1.0 : -1.0;           // (J x) of the linear pattern's row (row = lane % 16)
+  const double psign = ((lane >> 4) & 1) ? -1.0 : 1.0;    // (P y) of the gather pattern's row
   const double* mrd = mt + (lane >> 4) * 4 + (lane & 3);
-  double acc[C::NTILE];
+  const double* mri = mrd + C::NTM * 16;
+  constexpr int NA = CX ? 2 * C::NTILE : C::NTILE;
+  double acc[NA];
 #pragma unroll
-  for (int e = 0; e < C::NTILE; ++e) acc[e] = 0.0;
+  for (int e = 0; e < NA; ++e) acc[e] = 0.0;
   int64_t pb, pe;
   block_range(ldv / 2, blockIdx.x, gridDim.x, pb, pe);
   const int niter = (int)((pe - pb + 63) / 64);
@@ -403,17 +413,29 @@ __global__ void __launch_bounds__(512, 2)
     sl_new = sl_cur;
     sl_cur = sl_cur + 1 == ring ? 0 : sl_cur + 1;
     const int64_t pack0 = pb + (int64_t)it * 64 + wave * 8;
-    double x[NGX], d[NTK], z[NT];
+    double x[NGX], d[NTK], z[NT], zp[CX ? NT : 1];
 #pragma unroll
     for (int g = 0; g < NGX; ++g) x[g] = *reinterpret_cast<const double*>(slab + C::x_off(g) + lin);
 #pragma unroll
     for (int u = 0; u < NT; ++u) z[u] = *reinterpret_cast<const double*>(slab + C::z_off(u) + gat);
+    if constexpr (CX) {
+#pragma unroll
+      for (int u = 0; u < NT; ++u) zp[u] = psign * *reinterpret_cast<const double*>(slab + C::z_off(u) + (gat ^ 8));
+    }
 #pragma unroll
     for (int t = 0; t < NTK; ++t) d[t] = 0.0;
 #pragma unroll
     for (int g = 0; g < NGX; ++g)
 #pragma unroll
       for (int t = 0; t < NTK; ++t) d[t] = mfma4(x[g], mrd[(g * NTK + t) * 16], d[t]);
+    if constexpr (CX) {
+#pragma unroll
+      for (int g = 0; g < NGX; ++g) {
+        const double xj = jsign * *reinterpret_cast<const double*>(slab + C::x_off(g) + (lin ^ 8));
+#pragma unroll
+        for (int t = 0; t < NTK; ++t) d[t] = mfma4(xj, mri[(g * NTK + t) * 16], d[t]);
+      }
+    }
     if (nst) {
       const bool ok = pack0 + (row >> 1) < pe;
       double* dst = vst + pack0 * 2;
@@ -428,14 +450,20 @@ __global__ void __launch_bounds__(512, 2)
 #pragma unroll
     for (int u = 0; u < NT; ++u)
 #pragma unroll
-      for (int q = 0; q <= u; ++q) acc[C::NTS + C::gt(q, u)] = mfma4(z[q], z[u], acc[C::NTS + C::gt(q, u)]);
+      for (int q = 0; q <= u; ++q) {
+        acc[C::NTS + C::gt(q, u)] = mfma4(z[q], z[u], acc[C::NTS + C::gt(q, u)]);
+        if constexpr (CX) acc[C::NTILE + C::NTS + C::gt(q, u)] = mfma4(z[q], zp[u], acc[C::NTILE + C::NTS + C::gt(q, u)]);
+      }
 #pragma unroll
     for (int t = 0; t < NTK; ++t)
 #pragma unroll
-      for (int u = 0; u < NT; ++u) acc[t * NT + u] = mfma4(d[t], z[u], acc[t * NT + u]);
+      for (int u = 0; u < NT; ++u) {
+        acc[t * NT + u] = mfma4(d[t], z[u], acc[t * NT + u]);
+        if constexpr (CX) acc[C::NTILE + t * NT + u] = mfma4(d[t], zp[u], acc[C::NTILE + t * NT + u]);
+      }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  blkm_finish<NTK, NT>(acc, lds_raw, lane, wave, knew, s, partial, pnb);
+  blkm_finish<NTK, NT, CX>(acc, lds_raw, lane, wave, knew, s, partial, pnb);
 }
 
 }  // namespace ksd

@@ -732,6 +732,25 @@ int ks_workspace_fused_rotations(const ks_workspace* ws, int* count, int* spec_a
   });
 }
 
+int ks_workspace_split_rotations(const ks_workspace* ws, int* count) {
+  return guarded([&] {
+    KS_REQUIRE(ws && count, KS_ERR_ARGUMENT, "null argument");
+    *count = ws->rot_split_count;
+  });
+}
+
+int ks_sstep_partition(int dtype, int k0, int count, int smax, int* out, int cap, int* nblocks) {
+  return guarded([&] {
+    KS_REQUIRE(nblocks && (out || cap == 0), KS_ERR_ARGUMENT, "null argument");
+    KS_REQUIRE(dtype == KS_F64 || dtype == KS_C64, KS_ERR_ARGUMENT, "dtype");
+    *nblocks = 0;
+    if (k0 < 1 || count < 1 || smax < 1) return;
+    const auto sizes = blk_partition(dtype, k0, count, std::min(smax, dtype == KS_F64 ? ksd::kBlkSMax : ksd::blk_smax<cd>()));
+    *nblocks = (int)sizes.size();
+    for (int i = 0; i < (int)sizes.size() && i < cap; ++i) out[i] = sizes[i];
+  });
+}
+
 // diagnostics: average duration of `reps` launches of one block kernel on the workspace's basis (contents irrelevant: the
 // kernels have no data-dependent control flow); which = 0 k_bdots, 1 k_bupdate.  Leaves columns k..k+s-1 overwritten.
 int ks_debug_blk_time(ks_workspace* ws, int k, int s, int which, int reps, int dbg, double* ms_per_launch, int* grid) {

@@ -80,6 +80,8 @@ struct ks_workspace {
   // flushes it (rot_flush: the ordinary rotation kernel) first.  rot_fuse: the expansion being enqueued took it over.
   bool rot_defer_on = true, spec_on = true;   // KS_ROT_DEFER / KS_SPEC_CHAIN at creation
   bool rot_pending = false, rot_fuse = false;
+  bool rot_split = false;       // rot_fuse without a fused kernel for the shape: ordinary rotation, then both passes read the chain from scratch columns
+  int rot_split_count = 0;
   int rot_cin = 0, rot_rr = 0, rot_out0 = 0;
   int rot_fused_count = 0;      // rotations done by the fused kernel (ks_workspace_fused_rotations)
   bool rot_defer_ok = false;    // set by the library's restart drivers around their rotate_and_move (never by the verbs)
@@ -1040,7 +1042,7 @@ template <class T> void rotate_tfold(ks_workspace* ws, int c0, int c, int r, con
     }
   }
   const bool extra_elsewhere = src >= 0 && dst != out0 + r;
-  if constexpr (sizeof(T) == 8) {
+  {
     // a restart's rotation (all maxdim + 1 columns in, the residual direction next to the truncated basis) with blocks in
     // force: leave it to the expansion that follows (see ks_workspace::rot_pending).  That expansion starts its Newton chain
     // from the STORED last column instead of the rotated residual direction (which does not exist yet): the two agree to the
@@ -1094,7 +1096,8 @@ inline void rot_flush(ks_workspace* ws) {
   ws->rot_pending = false;
   ws->t_lazy = false;
   ws->t_hi = -1;
-  rotate_device<double>(ws, 0, ws->rot_cin, ws->rot_rr, ws->rot_out0, -1);
+  if (ws->dtype == KS_F64) rotate_device<double>(ws, 0, ws->rot_cin, ws->rot_rr, ws->rot_out0, -1);
+  else rotate_device<cd>(ws, 0, ws->rot_cin, ws->rot_rr, ws->rot_out0, -1);
 }
 
 // all T-lazy columns -> ordinary columns, in place (verbs outside the expansion / restart pair are about to read V)

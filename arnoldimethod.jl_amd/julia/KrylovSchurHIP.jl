@@ -333,6 +333,29 @@ function fused_rotations(w::HipWorkspace)
     return (Int(f[]), Int(a[]), Int(d[]))
 end
 
+"""
+    split_rotations(w) -> Int
+
+Pending restart rotations that ran through the ordinary kernel in front of a first block reading its Newton chain from scratch
+columns (ComplexF64, Float64 shapes without a fused kernel; include/kschur.h, ks_workspace_split_rotations).
+"""
+function split_rotations(w::HipWorkspace)
+    c = Ref{Cint}(0)
+    check(ccall((:ks_workspace_split_rotations, LIB), Cint, (Ptr{Cvoid}, Ptr{Cint}), w.h, c))
+    return Int(c[])
+end
+
+"""
+    sstep_partition(T, k0, count, smax) -> Vector{Int}
+
+Block sizes the library uses for `count` steps of `iterate_arnoldi!` on top of `k0` columns (include/kschur.h, ks_sstep_partition).
+"""
+function sstep_partition(::Type{T}, k0::Integer, count::Integer, smax::Integer) where {T}
+    out = Vector{Cint}(undef, 64); nb = Ref{Cint}(0)
+    GC.@preserve out check(ccall((:ks_sstep_partition, LIB), Cint, (Cint, Cint, Cint, Cint, Ptr{Cint}, Cint, Ptr{Cint}), dtype_code(T), k0, count, smax, pointer(out), 64, nb))
+    return Int.(out[1:min(Int(nb[]), 64)])
+end
+
 "Array(view(V, :, j0+1:j0+ncols)): host copy of device columns"
 function columns(w::HipWorkspace{T}, j0::Integer, ncols::Integer) where {T}
     out = Matrix{T}(undef, w.n, ncols)

@@ -222,7 +222,8 @@ int ks_workspace_passes(const ks_workspace* ws, int* passes);
 int ks_workspace_set_passes(ks_workspace* ws, int passes, double max_ratio);
 /* S-STEP (block) EXPANSION -- a faster form of iterate_arnoldi!(A, arnoldi, from:to), src/expansion.jl:116-133, for
  * device-resident operators on one GPU.  s >= 2: the steps of a range are taken in blocks of up to s (instantiated sizes:
- * 1-5, 8, 10, 20 for Float64, 1-5, 8, 10 for ComplexF64 -- 8 / 10 / 20 on the FP64 matrix instruction --): s operator products build a Newton basis (shifts = Leja-ordered Ritz values
+ * 1-20 for Float64, 1-10 for ComplexF64; beyond 5 on the FP64 matrix instruction, whose kernels take the block size at run
+ * time -- ks_sstep_partition says how a range of steps is cut into blocks): s operator products build a Newton basis (shifts = Leja-ordered Ritz values
  * of the previous restart, so the first expansion of a run still goes step by step), then TWO passes over the basis
  * orthogonalise the whole block (block classical Gram-Schmidt with Pythagorean inner products, applied twice, both times
  * carried in the triangular factor of the implicit second pass) and the s Hessenberg columns follow from the basis
@@ -232,8 +233,9 @@ int ks_workspace_set_passes(ks_workspace* ws, int passes, double max_ratio);
  * pivot below pivot_min times its diagonal entry (breakdown, src/expansion.jl:99-102, or an ill-conditioned basis) is
  * abandoned before anything is committed and its steps are redone one at a time, which takes the reference's decisions.
  * Like the implicit second pass it needs the library's provenance of the factorisation; otherwise, and for host-callback
- * operators and maxdim > 64 the expansion runs step by step.  Default s = 20 (KS_SSTEP at creation; 20 up to 24 existing
- * columns, 10 up to 32, 8 up to 48, 1-5 beyond; ComplexF64: 10 / 8 up to 32 columns, 1-5 beyond); s = 0 / 1: off --
+ * operators and maxdim > 64 the expansion runs step by step.  Default s = 20 (KS_SSTEP at creation; blocks of up to 20 on
+ * up to 24 existing columns, up to 12 on up to 32, up to 8 on up to 48, 1-5 beyond; ComplexF64: up to 10 on up to 32 columns,
+ * 1-5 beyond); s = 0 / 1: off --
  * every step then takes the reference's DGKS decisions.  A block is also abandoned when the Gram matrix of what its first
  * stage wrote differs from I by more than
  * gram_dev_max in any entry (~ eps cond^2 of the Newton basis; the recovered H carries errors ~ eps cond): default 1e-8
@@ -246,6 +248,11 @@ int ks_workspace_set_passes(ks_workspace* ws, int passes, double max_ratio);
  * block - I) }. */
 int ks_workspace_set_sstep(ks_workspace* ws, int s, double pivot_min, double gram_dev_max);
 int ks_workspace_sstep_info(const ks_workspace* ws, int* s, int* blocks, int* abandoned, double* diag3);
+/* How iterate_arnoldi!(A, arnoldi, from:to) (src/expansion.jl:116-133) is cut into blocks: `count` steps on top of k0 existing
+ * columns with block sizes <= smax, for dtype KS_F64 / KS_C64 -- the sizes the library itself would use (they depend on which
+ * kernel forms KS_BLK_MFMA left on), for byte accounting in benchmarks.  Writes at most cap sizes to out and returns how many
+ * blocks there are in *nblocks (0: the range cannot run in blocks). */
+int ks_sstep_partition(int dtype, int k0, int count, int smax, int* out, int cap, int* nblocks);
 /* Restarts of the library's drivers (ks_partialschur, ks_expand_restart, ks_restart) whose selection cut through a 2 x 2 block
  * of the real Schur form: the members of a complex pair are not neighbours in the target's order (imaginary-part targets on a
  * real matrix; src/run.jl:298-339 keeps pairs together only when they are), the truncation of src/run.jl:363-365 then drops the
@@ -269,6 +276,11 @@ int ks_workspace_relation_probes(const ks_workspace* ws, int* probes);
  * *spec_adopted = chains the next expansion took over, *spec_dropped = chains that were void by then (the restart did not leave
  * its rotation pending, or something else touched the basis in between).  Any pointer may be null. */
 int ks_workspace_fused_rotations(const ks_workspace* ws, int* count, int* spec_adopted, int* spec_dropped);
+/* Pending restart rotations (src/run.jl:363-365) for whose shape or element type there is no fused kernel (ComplexF64; Float64
+ * shapes outside the instantiated ones): the ordinary rotation kernel runs when the next expansion is enqueued and BOTH passes of
+ * its first block read the Newton chain from scratch columns -- what this buys is that the speculative chain (above) can run
+ * behind the previous expansion for these shapes too.  *count = such rotations since creation. */
+int ks_workspace_split_rotations(const ks_workspace* ws, int* count);
 /* Diagnostics (tools/blk_bench.py): average duration of `reps` back-to-back launches of one streaming kernel of the s-step
  * expansion at basis size k and block size s (which = 0: first pass, 1: second pass), timed with HIP events on the
  * library's stream; *grid = workgroups launched.  dbg: probe flags of the kernels (1: second pass without its stores).

@@ -138,6 +138,55 @@ def test_complex_blocks_of_8_and_10_on_the_matrix_instruction(s):
     assert seen == 2
 
 
+@pytest.mark.parametrize("s", [6, 7, 9, 11, 12, 13, 15, 17, 19])
+def test_any_block_size_on_the_matrix_instruction_float64(s):
+    """The matrix-instruction kernels take the block size at run time (a block of s steps runs on the kernel of ceil(s / 4)
+    column tiles, the missing columns are zeros): every size up to 20 is a block size, not only 8 / 10 / 20.  Lockstep against
+    the per-step expansion with `s` as the cap (config 2's parameters: 20 steps from 20 or 21 columns are cut as
+    ks_sstep_partition says -- e.g. 13 + 7, 19 + 1, 6 + 6 + 6 + 2)."""
+    part = pkg.sstep_partition(np.float64, 21, 19, s)
+    assert part and max(part) == s and sum(part) == 19, part
+    seen = 0
+    for cyc, Hs, Hb, Vs, Vb, rel, orth, info in _lockstep(laplace3d(20, 21, 22), np.float64, s, 20, 20, 40, "SR", 3):
+        if cyc == 0:
+            continue
+        assert info["blocks"] > 0 and info["abandoned"] == 0 and info["s"] == s, info
+        assert info["pivot_stage2"] > 0.999 and info["gram_dev"] < 1e-10, info
+        assert np.abs(Hs - Hb).max() <= 1e-11 * np.abs(Hs).max(), (cyc, np.abs(Hs - Hb).max())
+        assert np.abs(Vs - Vb).max() <= 1e-9, (cyc, np.abs(Vs - Vb).max())
+        assert rel <= 1e-12 * np.linalg.norm(Hb) * 10 and orth <= 1e-13
+        seen += 1
+    assert seen >= 1
+
+
+@pytest.mark.parametrize("s", [6, 7, 9])
+def test_any_block_size_on_the_matrix_instruction_complex(s):
+    """ComplexF64: every size up to 10 (k_fin_blk<cd> holds factors of up to 10 x 10)."""
+    assert pkg.sstep_partition(np.complex128, 11, 9, 20) == [9] and pkg.sstep_partition(np.complex128, 10, 10, s)[0] == s
+    seen = 0
+    for cyc, Hs, Hb, Vs, Vb, rel, orth, info in _lockstep(_complex_op(), np.complex128, s, 6, 10, 20, "LM", 3):
+        if cyc == 0:
+            continue
+        assert info["blocks"] > 0 and info["abandoned"] == 0 and info["s"] == s, info
+        assert np.abs(Hs - Hb).max() <= 1e-11 * np.abs(Hs).max()
+        assert np.abs(Vs - Vb).max() <= 1e-9
+        assert rel <= 1e-12 * np.linalg.norm(Hb) * 10 and orth <= 1e-13
+        seen += 1
+    assert seen == 2
+
+
+def test_partition_takes_one_block_where_the_kernels_allow(monkeypatch):
+    """ks_sstep_partition (= the library's blk_partition): 9 steps on 11 columns are ONE block (config 3 after a restart that kept
+    a 2 x 2 block whole; round 4: 8 + 1), 19 on 21 one block, 15 on 25 are 12 + 3 (blocks of up to 12 up to 32 columns)."""
+    assert pkg.sstep_partition(np.float64, 11, 9, 20) == [9]
+    assert pkg.sstep_partition(np.float64, 21, 19, 20) == [19]
+    assert pkg.sstep_partition(np.float64, 25, 15, 20) == [12, 3]
+    assert pkg.sstep_partition(np.float64, 33, 7, 20) == [7]
+    assert pkg.sstep_partition(np.float64, 50, 14, 20) == [5, 5, 4]
+    assert pkg.sstep_partition(np.float64, 21, 20, 20) == [20] and pkg.sstep_partition(np.float64, 21, 20, 5) == [5, 5, 5, 5]
+    assert pkg.sstep_partition(np.complex128, 6, 14, 20) == [10, 4]
+
+
 CASES = {
     "config1-readme-tridiagonal": (lambda: laplace1d(100), np.float64, dict(nev=10, which="SR", mindim=10, maxdim=20, tol=1e-12)),
     "config2-parameters": (lambda: laplace3d(14, 15, 16), np.float64, dict(nev=20, which="SR", mindim=20, maxdim=40, tol=1e-12)),
@@ -146,7 +195,7 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("s", [2, 4, 5, 8, 10, 20])
+@pytest.mark.parametrize("s", [2, 4, 5, 7, 8, 9, 10, 13, 20])
 @pytest.mark.parametrize("case", list(CASES))
 def test_whole_solves_match_the_oracle(case, s):
     """partialschur with the s-step expansion against the oracle on the same start vector: identical matrix-vector counts
@@ -437,22 +486,29 @@ def test_blocks_with_real_ranks_on_one_gpu(nproc, mode, transport, s):
 
 
 # ------------------------------------------------------------------ fused restart rotation + speculative chain (round 5)
-def _cycles(monkeypatch, defer, spec, grid=(40, 41, 42), ncycles=6, reader=None):
-    """`ncycles` restart cycles (ks_expand_restart: expansion + restart per call) of config 2's parameters on a workspace created
-    with the given switches; `reader(ws, cycle)` may look at the basis between the calls."""
+def _cycles(monkeypatch, defer, spec, grid=(40, 41, 42), ncycles=6, reader=None, A=None, dtype=np.float64, nev=20, mindim=20, maxdim=40, which="SR"):
+    """`ncycles` restart cycles (ks_expand_restart: expansion + restart per call) of config 2's parameters (or of the given
+    operator / parameters) on a workspace created with the given switches; `reader(ws, cycle)` may look at the basis between the
+    calls."""
     monkeypatch.setenv("KS_ROT_DEFER", "1" if defer else "0")
     monkeypatch.setenv("KS_SPEC_CHAIN", "1" if spec else "0")
-    mx, my, mz = grid
-    n = mx * my * mz
     M = pkg.matrices
-    op = pkg.csr_operator(M.to_scipy(*M.laplace3d_csr(mx, my, mz), n))
-    ws = pkg.ArnoldiWorkspace(n, 40, np.float64)
-    ws.reinitialize(0, M.start_vector(n))
-    ws.iterate_arnoldi(op, 1, 20)
-    k, active, trail, ritz, seen = 20, 0, [], None, []
+    if A is None:
+        mx, my, mz = grid
+        n = mx * my * mz
+        op = pkg.csr_operator(M.to_scipy(*M.laplace3d_csr(mx, my, mz), n))
+        v1 = M.start_vector(n)
+    else:
+        n = A.shape[0]
+        op = pkg.csr_operator(A.astype(dtype))
+        v1 = _start(dtype, n)
+    ws = pkg.ArnoldiWorkspace(n, maxdim, dtype)
+    ws.reinitialize(0, v1)
+    ws.iterate_arnoldi(op, 1, mindim)
+    k, active, trail, ritz, seen = mindim, 0, [], None, []
     for c in range(ncycles):
-        r = ws.expand_restart(op, k, active, 20, "SR", 1e-10, 20, 40)
-        k, active = r["k"], min(r["nlock"], 19)
+        r = ws.expand_restart(op, k, active, nev, which, 1e-10, mindim, maxdim)
+        k, active = r["k"], min(r["nlock"], nev - 1)
         trail.append((k, active))
         ritz = np.sort_complex(r["eigenvalues"][:k])
         if reader is not None:
@@ -482,6 +538,37 @@ def test_fused_rotation_and_speculative_chain_match_the_plain_sequence(monkeypat
         assert r["info"]["abandoned"] == 0 and r["trail"] == plain["trail"], (r["trail"], plain["trail"], r["info"])
         assert np.abs(r["ritz"] - plain["ritz"]).max() <= 1e-10 * np.abs(plain["ritz"]).max()
         assert r["rel"] <= max(1e-12, 3 * plain["rel"]) and r["orth"] <= 1e-12, (r["rel"], plain["rel"], r["orth"])
+
+
+@pytest.mark.parametrize("case", ["complex-fused", "complex-30-columns", "real-30-columns", "nonsymmetric-9-or-10"])
+def test_pending_rotation_and_speculative_chain_beyond_the_headline_shapes(monkeypatch, case):
+    """(a) ComplexF64 at config 4's shape: k_brotdots_mfma on the real view of the basis (complex coefficients, imaginary parts of
+    the inner products) + the speculative chain with complex shifts.  (b) Shapes outside the instantiated fused rotations (31
+    columns in, either element type): the pending rotation runs through the ordinary kernel when the next expansion is enqueued
+    and BOTH passes of its first block read the Newton chain from scratch columns (k_bdots_mfma / k_bupdate_mfma with a column
+    source), so the speculative chain runs behind the previous expansion for these shapes too.  (c) A real nonsymmetric operator
+    whose restarts leave 10 or 11 columns (a 2 x 2 block kept whole) -- blocks of 10 and of 9, fused rotations of both shapes.
+    Against the plain sequence: same trail, Ritz values to 1e-10, relation and orthogonality at its level; the paths really ran."""
+    kw = {"complex-fused": dict(A=_complex_op(), dtype=np.complex128, nev=6, mindim=10, maxdim=20, which="LM"),
+          "complex-30-columns": dict(A=_complex_op(), dtype=np.complex128, nev=8, mindim=15, maxdim=30, which="LM"),
+          "real-30-columns": dict(grid=(20, 21, 22), nev=12, mindim=15, maxdim=30, which="SR"),
+          "nonsymmetric-9-or-10": dict(A=_nonsym(), dtype=np.float64, nev=8, mindim=10, maxdim=20, which="LM")}[case]
+    plain = _cycles(monkeypatch, False, False, ncycles=7, **kw)
+    spec = _cycles(monkeypatch, True, True, ncycles=7, **kw)
+    pi, si = plain["info"], spec["info"]
+    assert pi["fused_rotations"] == 0 and pi["split_rotations"] == 0 and pi["chains_adopted"] == 0, pi
+    assert si["abandoned"] == 0 and pi["abandoned"] == 0, (si, pi)
+    if case == "nonsymmetric-9-or-10":
+        # (the deferral is taken only behind a block whose Gram deviation is <= 1e-12 -- the chain starts from the STORED last
+        # column --; with real shifts on this spectrum most blocks are at 1e-11..1e-10: few rotations stay pending, by design)
+        assert si["split_rotations"] == 0 and si["blocks"] >= 6, si
+    elif case == "complex-fused":
+        assert si["fused_rotations"] >= 4 and si["split_rotations"] == 0 and si["chains_adopted"] >= 3, si
+    else:
+        assert si["fused_rotations"] == 0 and si["split_rotations"] >= 4 and si["chains_adopted"] >= 4, si
+    assert spec["trail"] == plain["trail"], (spec["trail"], plain["trail"])
+    assert np.abs(spec["ritz"] - plain["ritz"]).max() <= 1e-10 * np.abs(plain["ritz"]).max()
+    assert spec["rel"] <= max(1e-12, 3 * plain["rel"]) and spec["orth"] <= 1e-12, (spec["rel"], plain["rel"], spec["orth"])
 
 
 def test_pending_rotation_is_flushed_for_every_reader(monkeypatch):
