@@ -287,9 +287,9 @@ template <class T> struct HipBackend : ks::Backend<T> {
   // Float64, blocks of >= 8) and the operator's product is enqueued without host participation.
   void spec_enqueue(const ksd::BlkShifts<D>& sh, int k_now) {
     if (!ws->spec_on || !ws->rot_defer_on || !ws->gate_allowed || ws->sstep_eff < 8 || !op->async_capable || ws->ctx->hc.allreduce != nullptr) return;
-    // as many products as the next first block will certainly have: it starts from about as many columns as this one did (two
-    // more are tolerated: a locked vector, a 2 x 2 block kept whole)
-    const int ne = std::min(10, ws->maxdim - k_now - 2);
+    // as many products as the next first block will certainly have: it starts from about as many columns as this one did (Float64:
+    // one more is tolerated -- a 2 x 2 block of the real Schur form kept whole; ComplexF64 restarts keep exactly mindim columns)
+    const int ne = std::min(10, ws->maxdim - k_now - (sizeof(D) == 8 ? 1 : 0));
     if (ne < 2) return;
     if (!ws->zscratch) {
       KS_HIP(hipMalloc(&ws->zscratch, (size_t)ws->ld * ksd::kBlkSMax * sizeof(D)));
@@ -297,6 +297,26 @@ template <class T> struct HipBackend : ks::Backend<T> {
     }
     char* zs = static_cast<char*>(ws->zscratch);
     op->shift_store_cacheable = true;
+    // on a stream of their own behind the last second pass (ks_workspace::spec_stream): the first product runs next to the final
+    // reduction + algebra kernel of the block and the publication of H instead of behind them
+    ks_ctx* cx = ws->ctx;
+    hipStream_t main_stream = cx->stream;
+    bool side = ws->spec_side && !cx->profiling && !cx->distributed() && op->ctx == cx;
+    if (side && !ws->spec_stream) {
+      KS_HIP(hipStreamCreateWithFlags(&ws->spec_stream, hipStreamNonBlocking));
+      KS_HIP(hipEventCreateWithFlags(&ws->ev_pass2, hipEventDisableTiming));
+      KS_HIP(hipEventCreateWithFlags(&ws->ev_spec, hipEventDisableTiming));
+      side = false;   // (no second pass has recorded its event yet: this once on the main stream)
+    }
+    if (side && !ws->ev_pass2_recorded) side = false;
+    struct StreamSwap {   // (exception-safe: an operator error must not leave the context on the side stream)
+      ks_ctx* c; hipStream_t back; bool on;
+      ~StreamSwap() { if (on) c->stream = back; }
+    } swap{cx, main_stream, side};
+    if (side) {
+      KS_HIP(hipStreamWaitEvent(ws->spec_stream, ws->ev_pass2, 0));
+      cx->stream = ws->spec_stream;
+    }
     for (int i = 0; i < ne; ++i) {
       op->in_scale = 1.0;
       const void* src = i == 0 ? ws->col(ws->maxdim) : static_cast<const void*>(zs + (size_t)(i - 1) * ws->ld * sizeof(D));
@@ -304,6 +324,12 @@ template <class T> struct HipBackend : ks::Backend<T> {
       if constexpr (sizeof(D) == 8) { tre = sh.theta[i]; tim = 0.0; }
       else { tre = sh.theta[i].x; tim = sh.theta[i].y; }
       op->apply_shifted(src, zs + (size_t)i * ws->ld * sizeof(D), tre, tim, sh.sigma[i], ws->ld, ws->st);
+    }
+    if (side) {
+      cx->stream = main_stream;
+      swap.on = false;
+      KS_HIP(hipEventRecord(ws->ev_spec, ws->spec_stream));
+      KS_HIP(hipStreamWaitEvent(main_stream, ws->ev_spec, 0));   // everything enqueued later is ordered behind the chain, as on one stream
     }
     ws->spec_sh.assign(reinterpret_cast<const char*>(&sh), reinterpret_cast<const char*>(&sh) + sizeof(sh));
     ws->spec_ne = ne;
@@ -352,7 +378,10 @@ template <class T> struct HipBackend : ks::Backend<T> {
     ws->relation_probes++;
     const double fro = std::sqrt(fro2);
     const double leak = res[1] > 0.0 ? std::sqrt(res[0] * ((double)ws->n_global / res[1])) : 0.0;
-    if (!(leak <= ws->relation_tol * fro)) {   // (NaN counts as a break)
+    // (a MEASURED residual carries the rounding of the column's whole history -- 3e-13 .. 1.1e-12 ||H||_F behind blocks of 13-20,
+    // where the library's own restart compares an exactly known dropped entry: ten times its tolerance here; a cut 2 x 2 block
+    // shows up at 1e-9 .. 1e-5)
+    if (!(leak <= 10.0 * ws->relation_tol * fro)) {   // (NaN counts as a break)
       ws->relation_breaks++;
       ws->relation_leak = std::max(ws->relation_leak, fro > 0.0 ? leak / fro : leak);
       ws->sstep_eff = 0;

@@ -264,7 +264,8 @@ int ks_workspace_relation_info(const ks_workspace* ws, int* breaks, double* wors
 /* A caller that runs the restart itself (the reference's _partialschur on a device basis, src/run.jl:298-365) and then vouches
  * for the result (ks_workspace_assert_arnoldi) is not seen by the guard above.  For such a factorisation the library MEASURES
  * the relation before blocks lean on it: the residual of the last kept column, A v_c - V H[:, c] (one operator product into a
- * dead column + a strided row sample), at the start of the ks_iterate_arnoldi that follows; more than 1e-12 ||H||_F counts as a
+ * dead column + a strided row sample), at the start of the ks_iterate_arnoldi that follows; more than 1e-11 ||H||_F (a measured residual carries the rounding of
+ * the column's history, up to ~1e-12 behind large blocks; a cut block shows at 1e-9 .. 1e-5) counts as a
  * break exactly like a leaking restart of the library's own drivers (blocks off for the run).  *probes = measurements taken
  * since creation. */
 int ks_workspace_relation_probes(const ks_workspace* ws, int* probes);

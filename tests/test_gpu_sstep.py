@@ -565,10 +565,24 @@ def test_pending_rotation_and_speculative_chain_beyond_the_headline_shapes(monke
     elif case == "complex-fused":
         assert si["fused_rotations"] >= 4 and si["split_rotations"] == 0 and si["chains_adopted"] >= 3, si
     else:
-        assert si["fused_rotations"] == 0 and si["split_rotations"] >= 4 and si["chains_adopted"] >= 4, si
+        assert si["fused_rotations"] == 0 and si["split_rotations"] >= 4 and si["chains_adopted"] >= 3, si   # (one chain is dropped on the way, the library then speculates again only eight cycles later)
     assert spec["trail"] == plain["trail"], (spec["trail"], plain["trail"])
     assert np.abs(spec["ritz"] - plain["ritz"]).max() <= 1e-10 * np.abs(plain["ritz"]).max()
     assert spec["rel"] <= max(1e-12, 3 * plain["rel"]) and spec["orth"] <= 1e-12, (spec["rel"], plain["rel"], spec["orth"])
+
+
+def test_speculative_chain_on_its_own_stream_is_bit_identical(monkeypatch):
+    """KS_SPEC_SIDE (default 1): the speculative products run on a stream of their own behind the last second pass -- next to the
+    block's final reduction + algebra kernel -- and the main stream waits for them before anything enqueued later.  Same kernels on
+    the same data in the same order as on one stream: bit-identical Ritz values and trail, for Float64 and ComplexF64."""
+    for kw in (dict(grid=(30, 31, 32)), dict(A=_complex_op(), dtype=np.complex128, nev=6, mindim=10, maxdim=20, which="LM")):
+        monkeypatch.setenv("KS_SPEC_SIDE", "1")
+        a = _cycles(monkeypatch, True, True, ncycles=7, **kw)
+        monkeypatch.setenv("KS_SPEC_SIDE", "0")
+        b = _cycles(monkeypatch, True, True, ncycles=7, **kw)
+        assert a["info"]["chains_adopted"] >= 4 and a["info"]["chains_adopted"] == b["info"]["chains_adopted"], (a["info"], b["info"])
+        assert a["trail"] == b["trail"] and np.array_equal(a["ritz"], b["ritz"])
+        assert a["rel"] == b["rel"] and a["orth"] == b["orth"]
 
 
 def test_pending_rotation_is_flushed_for_every_reader(monkeypatch):
