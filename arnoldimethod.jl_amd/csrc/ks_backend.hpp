@@ -284,7 +284,9 @@ template <class T> struct HipBackend : ks::Backend<T> {
 
   // The first products of the NEXT expansion's Newton chain, behind the batch that just went into the stream (see
   // ks_workspace::spec_valid).  Only where the restart that follows can leave its rotation pending (the library's own drivers,
-  // Float64, blocks of >= 8) and the operator's product is enqueued without host participation.
+  // blocks of >= 8) and the operator's product is enqueued without host participation.
+  // (Measured and withdrawn, round 5: the same products on a stream of their own behind the last second pass, next to the block's
+  // final reduction + algebra kernel -- no gain on any configuration, the cross-stream waits cost what the overlap buys.)
   void spec_enqueue(const ksd::BlkShifts<D>& sh, int k_now) {
     if (!ws->spec_on || !ws->rot_defer_on || !ws->gate_allowed || ws->sstep_eff < 8 || !op->async_capable || ws->ctx->hc.allreduce != nullptr) return;
     // as many products as the next first block will certainly have: it starts from about as many columns as this one did (Float64:
@@ -297,26 +299,6 @@ template <class T> struct HipBackend : ks::Backend<T> {
     }
     char* zs = static_cast<char*>(ws->zscratch);
     op->shift_store_cacheable = true;
-    // on a stream of their own behind the last second pass (ks_workspace::spec_stream): the first product runs next to the final
-    // reduction + algebra kernel of the block and the publication of H instead of behind them
-    ks_ctx* cx = ws->ctx;
-    hipStream_t main_stream = cx->stream;
-    bool side = ws->spec_side && !cx->profiling && !cx->distributed() && op->ctx == cx;
-    if (side && !ws->spec_stream) {
-      KS_HIP(hipStreamCreateWithFlags(&ws->spec_stream, hipStreamNonBlocking));
-      KS_HIP(hipEventCreateWithFlags(&ws->ev_pass2, hipEventDisableTiming));
-      KS_HIP(hipEventCreateWithFlags(&ws->ev_spec, hipEventDisableTiming));
-      side = false;   // (no second pass has recorded its event yet: this once on the main stream)
-    }
-    if (side && !ws->ev_pass2_recorded) side = false;
-    struct StreamSwap {   // (exception-safe: an operator error must not leave the context on the side stream)
-      ks_ctx* c; hipStream_t back; bool on;
-      ~StreamSwap() { if (on) c->stream = back; }
-    } swap{cx, main_stream, side};
-    if (side) {
-      KS_HIP(hipStreamWaitEvent(ws->spec_stream, ws->ev_pass2, 0));
-      cx->stream = ws->spec_stream;
-    }
     for (int i = 0; i < ne; ++i) {
       op->in_scale = 1.0;
       const void* src = i == 0 ? ws->col(ws->maxdim) : static_cast<const void*>(zs + (size_t)(i - 1) * ws->ld * sizeof(D));
@@ -324,12 +306,6 @@ template <class T> struct HipBackend : ks::Backend<T> {
       if constexpr (sizeof(D) == 8) { tre = sh.theta[i]; tim = 0.0; }
       else { tre = sh.theta[i].x; tim = sh.theta[i].y; }
       op->apply_shifted(src, zs + (size_t)i * ws->ld * sizeof(D), tre, tim, sh.sigma[i], ws->ld, ws->st);
-    }
-    if (side) {
-      cx->stream = main_stream;
-      swap.on = false;
-      KS_HIP(hipEventRecord(ws->ev_spec, ws->spec_stream));
-      KS_HIP(hipStreamWaitEvent(main_stream, ws->ev_spec, 0));   // everything enqueued later is ordered behind the chain, as on one stream
     }
     ws->spec_sh.assign(reinterpret_cast<const char*>(&sh), reinterpret_cast<const char*>(&sh) + sizeof(sh));
     ws->spec_ne = ne;

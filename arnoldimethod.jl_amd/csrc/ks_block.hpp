@@ -177,8 +177,6 @@ void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::v
       ProfScope ps(cx, KSP_FUSED, nb8 * (k + 2 * s));          // reads S[:, 0:k) and Z, writes the block
       nb2 = launch_blk<D>(ws, 1, k, s, fuse);
     }
-    // (the speculative chain of the NEXT expansion is ordered behind this point, not behind the reduction that follows)
-    if (ws->ev_pass2) { KS_HIP(hipEventRecord(ws->ev_pass2, s_)); ws->ev_pass2_recorded = true; }
     fin(2, nb2);
     k += s;
     first = 0;

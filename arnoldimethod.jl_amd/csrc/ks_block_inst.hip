@@ -191,7 +191,7 @@ template <int NGX, int NTK, int NT, bool CX> int go_rot(const BlkLaunchArgs& a) 
 #define KS_ROT_SHAPES(X) X(11, 6, 5) X(11, 7, 3) X(11, 8, 3) X(11, 8, 2) X(6, 3, 3) X(6, 4, 3) X(6, 4, 2)
 constexpr bool kRotCX = false;
 #else
-#define KS_ROT_SHAPES(X) X(6, 3, 3) X(6, 4, 3) X(6, 4, 2)
+#define KS_ROT_SHAPES(X) X(6, 3, 3) X(6, 4, 3) X(6, 4, 2) X(11, 6, 3)
 constexpr bool kRotCX = true;
 #endif
 // (the block's tile count is rounded up to an instantiated one: the kernel takes s at run time, missing columns are zeros)

@@ -632,7 +632,6 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     w->sstep = std::max(0, std::min(env_int("KS_SSTEP", 20), ksd::kBlkSMax));  // s-step expansion: ON by default (KS_SSTEP=0: step by step)
     w->sstep_eff = w->sstep;
     w->rot_defer_on = env_int("KS_ROT_DEFER", 1) != 0;   // restart rotation left pending for the next expansion's fused first pass
-    w->spec_side = env_int("KS_SPEC_SIDE", 1) != 0;       // ... on a stream of their own, next to the block's final reduction kernel
     w->spec_on = env_int("KS_SPEC_CHAIN", 1) != 0;        // first products of the next expansion behind the previous one
     if (const char* e = std::getenv("KS_SSTEP_GDEV_MAX")) w->blk_gdevmax = std::atof(e);
     if (const char* e = std::getenv("KS_SSTEP_PIVOT_MIN")) w->blk_pivmin = std::atof(e);

@@ -95,14 +95,6 @@ struct ks_workspace {
   // shift sequence they were made with) if its first block is a fused one of at least spec_ne steps; anything else that
   // touches V in between drops them.  spec_sh: the BlkShifts<double> they were made with (raw bytes).
   bool spec_valid = false;
-  // The speculative products run on a stream of their own, ordered behind the last second pass (ev_pass2) -- next to the block's
-  // final reduction + algebra kernel (one workgroup busy for 30-50 us, the rest of the device idle) and the publication of H --
-  // and the main stream waits for them (ev_spec) before anything enqueued later: same ordering as on one stream for everything
-  // that follows.  KS_SPEC_SIDE=0, profiling, several ranks: on the main stream.
-  hipStream_t spec_stream = nullptr;
-  hipEvent_t ev_pass2 = nullptr, ev_spec = nullptr;
-  bool ev_pass2_recorded = false;
-  bool spec_side = true;                // KS_SPEC_SIDE at creation
   int spec_ne = 0;
   std::vector<char> spec_sh;
   int spec_backoff = 0;                 // cycles to go without speculation after a dropped one
@@ -198,9 +190,6 @@ struct ks_workspace {
       gate_armed = false;
       (void)hipStreamSynchronize(ctx->stream);
     }
-    if (spec_stream) { (void)hipStreamSynchronize(spec_stream); (void)hipStreamDestroy(spec_stream); }
-    if (ev_pass2) (void)hipEventDestroy(ev_pass2);
-    if (ev_spec) (void)hipEventDestroy(ev_spec);
     (void)hipFree(Vbase ? Vbase : V); (void)hipHostFree(H); (void)hipHostFree(Q); (void)hipFree(Hd); (void)hipHostFree(Hstage);
     (void)hipFree(Hscratch); (void)hipFree(partial); (void)hipFree(partial_s); (void)hipFree(partial2); (void)hipFree(coef); (void)hipFree(red);
     (void)hipFree(scal); (void)hipHostFree(scal_h); (void)hipHostFree(coef_h);
