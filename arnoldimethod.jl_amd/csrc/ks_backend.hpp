@@ -87,6 +87,10 @@ template <class T> struct HipBackend : ks::Backend<T> {
         // the scratch columns -- rot_split; what this buys is the speculative chain)
         const bool fused_ok = bpath && ks_blk_rot_ok(ws->dtype == KS_F64 ? 0 : 1, ws->rot_cin, j0, blk_sizes[0]);
         const bool split_ok = bpath && ws->spec_on && ks_blk_zsrc_ok(ws->dtype == KS_F64 ? 0 : 1, j0, blk_sizes[0]);
+        static const int defer_dbg = env_int("KS_DEFER_DEBUG", 0);
+        if (defer_dbg)
+          std::fprintf(stderr, "[adopt] bpath %d j0 %d out0+rr %d fused_ok %d split_ok %d spec_valid %d blk0 %d spec_ne %d backoff %d\n", (int)bpath, j0, ws->rot_out0 + ws->rot_rr,
+                       (int)fused_ok, (int)split_ok, (int)ws->spec_valid, bpath ? blk_sizes[0] : 0, ws->spec_ne, ws->spec_backoff);
         if (bpath && j0 == ws->rot_out0 + ws->rot_rr && (fused_ok || split_ok)) {
           ws->rot_pending = false;
           ws->rot_fuse = true;
@@ -99,6 +103,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
             std::memcpy(&blk_sh, ws->spec_sh.data(), sizeof(blk_sh));
             ws->spec_adopt = ws->spec_ne;
             ws->spec_used++;
+            ws->spec_backoff_len = 1;
             ws->spec_valid = false;
           }
           spec_drop(ws);
@@ -149,9 +154,15 @@ template <class T> struct HipBackend : ks::Backend<T> {
       if (mb) publish_control(ws, j0, ws->Hstage_dev, 1, seq, tpath);
       else fetch_state_enqueue(ws, j0, tpath);
       // (only where the next expansion can be expected to adopt them: this one already had the shape of a first block that reads
-      // its chain from scratch columns, and the last speculation was not dropped -- after a drop the next eight cycles go without)
+      // its chain from scratch columns, and the last speculation was not dropped -- after a drop the next 1, 2, 4, 8 cycles go without)
       if (bpath && jend == to && to == ws->maxdim &&
           (ks_blk_rot_ok(ws->dtype == KS_F64 ? 0 : 1, ws->maxdim + 1, j0, blk_sizes[0]) || ks_blk_zsrc_ok(ws->dtype == KS_F64 ? 0 : 1, j0, blk_sizes[0]))) {
+        // (the last batch's Gram deviation was above the gate of the pending rotation: put the last block's share of the
+        // difference between the stored and the true last column back -- ks_workspace::z0_valid)
+        if (ws->rot_defer_on && ws->spec_on && ws->gate_allowed && ws->sstep_eff >= 8 && (ws->blk_count == 0 || ws->blk_diag[2] > 1e-12))   // (no block completed yet: the deviation is not known, be safe once)
+          z0_enqueue(to - blk_sizes.back() + 1, blk_sizes.back(), to);
+        static const int defer_dbg2 = env_int("KS_DEFER_DEBUG", 0);
+        if (defer_dbg2) std::fprintf(stderr, "[spec] enqueue? backoff %d j0 %d blk0 %d z0 %d\n", ws->spec_backoff, j0, blk_sizes[0], (int)ws->z0_valid);
         if (ws->spec_backoff > 0) --ws->spec_backoff;
         else spec_enqueue(blk_sh, j0);
       }
@@ -287,6 +298,21 @@ template <class T> struct HipBackend : ks::Backend<T> {
   // blocks of >= 8) and the operator's product is enqueued without host participation.
   // (Measured and withdrawn, round 5: the same products on a stream of their own behind the last second pass, next to the block's
   // final reduction + algebra kernel -- no gain on any configuration, the cross-stream waits cost what the overlap buys.)
+  void ensure_zscratch() {
+    if (ws->zscratch) return;
+    KS_HIP(hipMalloc(&ws->zscratch, (size_t)ws->ld * (ksd::kBlkSMax + 1) * sizeof(D)));
+    KS_HIP(hipMemsetAsync(ws->zscratch, 0, (size_t)ws->ld * (ksd::kBlkSMax + 1) * sizeof(D), ws->ctx->stream));
+  }
+  D* z0_col() { return reinterpret_cast<D*>(static_cast<char*>(ws->zscratch) + (size_t)ksd::kBlkSMax * ws->ld * sizeof(D)); }
+  // z0 = V[:, k0 : last] T[k0 : last, last]: the true last column without its (rounding-level) share along the columns below k0
+  void z0_enqueue(int k0, int s, int last) {
+    ensure_zscratch();
+    const D* Tm = static_cast<const D*>(ws->Td);
+    ksd::k_lincomb_cols<D><<<ws->nb, kBlock, 0, ws->ctx->stream>>>(z0_col(), static_cast<const D*>(ws->col(k0)), ws->ld, s, Tm + k0 + (int64_t)last * ws->ldt, 1, ws->n, ws->st);
+    KS_HIP(hipGetLastError());
+    ws->z0_valid = true;
+    ws->z0_k0 = k0;
+  }
   void spec_enqueue(const ksd::BlkShifts<D>& sh, int k_now) {
     if (!ws->spec_on || !ws->rot_defer_on || !ws->gate_allowed || ws->sstep_eff < 8 || !op->async_capable || ws->ctx->hc.allreduce != nullptr) return;
     // as many products as the next first block will certainly have: it starts from about as many columns as this one did (Float64:
@@ -294,14 +320,14 @@ template <class T> struct HipBackend : ks::Backend<T> {
     const int ne = std::min(10, ws->maxdim - k_now - (sizeof(D) == 8 ? 1 : 0));
     if (ne < 2) return;
     if (!ws->zscratch) {
-      KS_HIP(hipMalloc(&ws->zscratch, (size_t)ws->ld * ksd::kBlkSMax * sizeof(D)));
-      KS_HIP(hipMemsetAsync(ws->zscratch, 0, (size_t)ws->ld * ksd::kBlkSMax * sizeof(D), ws->ctx->stream));
+      KS_HIP(hipMalloc(&ws->zscratch, (size_t)ws->ld * (ksd::kBlkSMax + 1) * sizeof(D)));
+      KS_HIP(hipMemsetAsync(ws->zscratch, 0, (size_t)ws->ld * (ksd::kBlkSMax + 1) * sizeof(D), ws->ctx->stream));
     }
     char* zs = static_cast<char*>(ws->zscratch);
     op->shift_store_cacheable = true;
     for (int i = 0; i < ne; ++i) {
       op->in_scale = 1.0;
-      const void* src = i == 0 ? ws->col(ws->maxdim) : static_cast<const void*>(zs + (size_t)(i - 1) * ws->ld * sizeof(D));
+      const void* src = i == 0 ? (ws->z0_valid ? static_cast<const void*>(z0_col()) : ws->col(ws->maxdim)) : static_cast<const void*>(zs + (size_t)(i - 1) * ws->ld * sizeof(D));
       double tre, tim;
       if constexpr (sizeof(D) == 8) { tre = sh.theta[i]; tim = 0.0; }
       else { tre = sh.theta[i].x; tim = sh.theta[i].y; }

@@ -550,7 +550,8 @@ def test_pending_rotation_and_speculative_chain_beyond_the_headline_shapes(monke
     whose restarts leave 10 or 11 columns (a 2 x 2 block kept whole) -- blocks of 10 and of 9, fused rotations of both shapes.
     Against the plain sequence: same trail, Ritz values to 1e-10, relation and orthogonality at its level; the paths really ran."""
     kw = {"complex-fused": dict(A=_complex_op(), dtype=np.complex128, nev=6, mindim=10, maxdim=20, which="LM"),
-          "complex-20-40": dict(A=_complex_op(), dtype=np.complex128, nev=12, mindim=20, maxdim=40, which="LM"),
+          "complex-20-40": dict(A=(laplace3d(20, 21, 22) + 1j * sp.diags(0.3 * np.cos(np.arange(9240)))).tocsr().astype(np.complex128),
+                                dtype=np.complex128, nev=12, mindim=20, maxdim=40, which="LM"),
           "complex-30-columns": dict(A=_complex_op(), dtype=np.complex128, nev=8, mindim=15, maxdim=30, which="LM"),
           "real-30-columns": dict(grid=(20, 21, 22), nev=12, mindim=15, maxdim=30, which="SR"),
           "nonsymmetric-9-or-10": dict(A=_nonsym(), dtype=np.float64, nev=8, mindim=10, maxdim=20, which="LM")}[case]
@@ -560,14 +561,15 @@ def test_pending_rotation_and_speculative_chain_beyond_the_headline_shapes(monke
     assert pi["fused_rotations"] == 0 and pi["split_rotations"] == 0 and pi["chains_adopted"] == 0, pi
     assert si["abandoned"] == 0 and pi["abandoned"] == 0, (si, pi)
     if case == "nonsymmetric-9-or-10":
-        # (the deferral is taken only behind a block whose Gram deviation is <= 1e-12 -- the chain starts from the STORED last
-        # column --; with real shifts on this spectrum most blocks are at 1e-11..1e-10: few rotations stay pending, by design)
-        assert si["split_rotations"] == 0 and si["blocks"] >= 6, si
+        # (with real shifts on this spectrum the blocks' Gram deviation is 1e-11..1e-10, above the 1e-12 a chain started from the
+        # STORED last column needs: the library puts the last block's share of the difference back -- ks_workspace_corrected_starts --
+        # and the rotations stay pending all the same)
+        assert si["split_rotations"] == 0 and si["blocks"] >= 6 and si["fused_rotations"] >= 3 and si["corrected_starts"] >= 2, si
     elif case in ("complex-fused", "complex-20-40"):
-        assert si["fused_rotations"] >= 4 and si["split_rotations"] == 0 and si["chains_adopted"] >= 3, si
+        assert si["fused_rotations"] >= (4 if case == "complex-fused" else 3) and si["split_rotations"] == 0 and si["chains_adopted"] >= (3 if case == "complex-fused" else 2), si
     else:
         # (not every restart defers -- only behind a block with Gram deviation <= 1e-12 --, and after a dropped chain the library
-        # speculates again only eight cycles later)
+        # backs off for 1, 2, 4, 8 cycles)
         assert si["fused_rotations"] == 0 and si["split_rotations"] >= 2 and si["chains_adopted"] >= 2, si
     assert spec["trail"] == plain["trail"], (spec["trail"], plain["trail"])
     assert np.abs(spec["ritz"] - plain["ritz"]).max() <= 1e-10 * np.abs(plain["ritz"]).max()
@@ -587,5 +589,5 @@ def test_pending_rotation_is_flushed_for_every_reader(monkeypatch):
     for c, (Va, Vb) in enumerate(zip(a["seen"], b["seen"])):
         assert Va.shape == Vb.shape and np.abs(Va - Vb).max() <= 1e-14, (c, float(np.abs(Va - Vb).max()))
     # every pending rotation was flushed by the reader (none ran fused), every chain dropped
-    assert a["info"]["fused_rotations"] == 0 and a["info"]["chains_adopted"] == 0 and a["info"]["chains_dropped"] >= 1, a["info"]   # (after a drop the library speculates again only eight cycles later)
+    assert a["info"]["fused_rotations"] == 0 and a["info"]["chains_adopted"] == 0 and a["info"]["chains_dropped"] >= 1, a["info"]   # (after a drop the library backs off for 1, 2, 4, 8 cycles)
     assert a["rel"] <= 1e-12 and a["orth"] <= 1e-12
