@@ -157,12 +157,8 @@ template <class T> struct HipBackend : ks::Backend<T> {
       // its chain from scratch columns, and the last speculation was not dropped -- after a drop the next 1, 2, 4, 8 cycles go without)
       if (bpath && jend == to && to == ws->maxdim &&
           (ks_blk_rot_ok(ws->dtype == KS_F64 ? 0 : 1, ws->maxdim + 1, j0, blk_sizes[0]) || ks_blk_zsrc_ok(ws->dtype == KS_F64 ? 0 : 1, j0, blk_sizes[0]))) {
-        // (the last batch's Gram deviation was above the gate of the pending rotation: put the last block's share of the
-        // difference between the stored and the true last column back -- ks_workspace::z0_valid)
-        if (ws->rot_defer_on && ws->spec_on && ws->gate_allowed && ws->sstep_eff >= 8 && (ws->blk_count == 0 || ws->blk_diag[2] > 1e-12))   // (no block completed yet: the deviation is not known, be safe once)
-          z0_enqueue(to - blk_sizes.back() + 1, blk_sizes.back(), to);
         static const int defer_dbg2 = env_int("KS_DEFER_DEBUG", 0);
-        if (defer_dbg2) std::fprintf(stderr, "[spec] enqueue? backoff %d j0 %d blk0 %d z0 %d\n", ws->spec_backoff, j0, blk_sizes[0], (int)ws->z0_valid);
+        if (defer_dbg2) std::fprintf(stderr, "[spec] enqueue? backoff %d j0 %d blk0 %d\n", ws->spec_backoff, j0, blk_sizes[0]);
         if (ws->spec_backoff > 0) --ws->spec_backoff;
         else spec_enqueue(blk_sh, j0);
       }
@@ -298,21 +294,6 @@ template <class T> struct HipBackend : ks::Backend<T> {
   // blocks of >= 8) and the operator's product is enqueued without host participation.
   // (Measured and withdrawn, round 5: the same products on a stream of their own behind the last second pass, next to the block's
   // final reduction + algebra kernel -- no gain on any configuration, the cross-stream waits cost what the overlap buys.)
-  void ensure_zscratch() {
-    if (ws->zscratch) return;
-    KS_HIP(hipMalloc(&ws->zscratch, (size_t)ws->ld * (ksd::kBlkSMax + 1) * sizeof(D)));
-    KS_HIP(hipMemsetAsync(ws->zscratch, 0, (size_t)ws->ld * (ksd::kBlkSMax + 1) * sizeof(D), ws->ctx->stream));
-  }
-  D* z0_col() { return reinterpret_cast<D*>(static_cast<char*>(ws->zscratch) + (size_t)ksd::kBlkSMax * ws->ld * sizeof(D)); }
-  // z0 = V[:, k0 : last] T[k0 : last, last]: the true last column without its (rounding-level) share along the columns below k0
-  void z0_enqueue(int k0, int s, int last) {
-    ensure_zscratch();
-    const D* Tm = static_cast<const D*>(ws->Td);
-    ksd::k_lincomb_cols<D><<<ws->nb, kBlock, 0, ws->ctx->stream>>>(z0_col(), static_cast<const D*>(ws->col(k0)), ws->ld, s, Tm + k0 + (int64_t)last * ws->ldt, 1, ws->n, ws->st);
-    KS_HIP(hipGetLastError());
-    ws->z0_valid = true;
-    ws->z0_k0 = k0;
-  }
   void spec_enqueue(const ksd::BlkShifts<D>& sh, int k_now) {
     if (!ws->spec_on || !ws->rot_defer_on || !ws->gate_allowed || ws->sstep_eff < 8 || !op->async_capable || ws->ctx->hc.allreduce != nullptr) return;
     // as many products as the next first block will certainly have: it starts from about as many columns as this one did (Float64:
@@ -320,14 +301,14 @@ template <class T> struct HipBackend : ks::Backend<T> {
     const int ne = std::min(10, ws->maxdim - k_now - (sizeof(D) == 8 ? 1 : 0));
     if (ne < 2) return;
     if (!ws->zscratch) {
-      KS_HIP(hipMalloc(&ws->zscratch, (size_t)ws->ld * (ksd::kBlkSMax + 1) * sizeof(D)));
-      KS_HIP(hipMemsetAsync(ws->zscratch, 0, (size_t)ws->ld * (ksd::kBlkSMax + 1) * sizeof(D), ws->ctx->stream));
+      KS_HIP(hipMalloc(&ws->zscratch, (size_t)ws->ld * ksd::kBlkSMax * sizeof(D)));
+      KS_HIP(hipMemsetAsync(ws->zscratch, 0, (size_t)ws->ld * ksd::kBlkSMax * sizeof(D), ws->ctx->stream));
     }
     char* zs = static_cast<char*>(ws->zscratch);
     op->shift_store_cacheable = true;
     for (int i = 0; i < ne; ++i) {
       op->in_scale = 1.0;
-      const void* src = i == 0 ? (ws->z0_valid ? static_cast<const void*>(z0_col()) : ws->col(ws->maxdim)) : static_cast<const void*>(zs + (size_t)(i - 1) * ws->ld * sizeof(D));
+      const void* src = i == 0 ? ws->col(ws->maxdim) : static_cast<const void*>(zs + (size_t)(i - 1) * ws->ld * sizeof(D));
       double tre, tim;
       if constexpr (sizeof(D) == 8) { tre = sh.theta[i]; tim = 0.0; }
       else { tre = sh.theta[i].x; tim = sh.theta[i].y; }

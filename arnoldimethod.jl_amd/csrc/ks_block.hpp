@@ -121,8 +121,8 @@ void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::v
     char* zs = nullptr;
     if (fuse) {
       if (!ws->zscratch) {
-        KS_HIP(hipMalloc(&ws->zscratch, (size_t)ws->ld * (ksd::kBlkSMax + 1) * sizeof(D)));
-        KS_HIP(hipMemsetAsync(ws->zscratch, 0, (size_t)ws->ld * (ksd::kBlkSMax + 1) * sizeof(D), s_));   // the pad rows (n .. ld) stay zero: operators write rows < n only
+        KS_HIP(hipMalloc(&ws->zscratch, (size_t)ws->ld * ksd::kBlkSMax * sizeof(D)));
+        KS_HIP(hipMemsetAsync(ws->zscratch, 0, (size_t)ws->ld * ksd::kBlkSMax * sizeof(D), s_));   // the pad rows (n .. ld) stay zero: operators write rows < n only
       }
       zs = static_cast<char*>(ws->zscratch);
     }
@@ -140,11 +140,9 @@ void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::v
       if constexpr (sizeof(D) == 8) { tre = sh.theta[i]; tim = 0.0; }
       else { tre = sh.theta[i].x; tim = sh.theta[i].y; }
       op->in_scale = 1.0;
-      // (chain start of a pending rotation: the stored last column of the old basis, or its corrected version -- ks_workspace::z0_valid)
-      const void* src = i == 0 ? (fuse ? (ws->rot_from_z0 ? static_cast<const void*>(zs + (size_t)ksd::kBlkSMax * ws->ld * sizeof(D)) : ws->col(ws->maxdim)) : ws->col(k - 1)) : zcol(i - 1);
+      const void* src = i == 0 ? (fuse ? ws->col(ws->maxdim) : ws->col(k - 1)) : zcol(i - 1);
       op->apply_shifted(src, zcol(i), tre, tim, sh.sigma[i], ws->ld, ws->st);
     }
-    if (fuse) ws->rot_from_z0 = false;
     const int ne = k * s + s * (s + 1) / 2;
     int nb1, nb2;
     // reduction + small algebra of one stage.  Several ranks: reduce -> ONE all-reduce of k s + s (s + 1) / 2 elements over

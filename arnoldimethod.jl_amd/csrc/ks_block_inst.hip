@@ -188,7 +188,7 @@ template <int NGX, int NTK, int NT, bool CX> int go_rot(const BlkLaunchArgs& a) 
   return nb;
 }
 #if KS_BLK_PART == 1
-#define KS_ROT_SHAPES(X) X(11, 6, 5) X(11, 7, 3) X(11, 8, 3) X(11, 8, 2) X(6, 3, 3) X(6, 4, 3) X(6, 4, 2)
+#define KS_ROT_SHAPES(X) X(11, 6, 5) X(11, 7, 4) X(11, 7, 3) X(11, 8, 3) X(11, 8, 2) X(6, 3, 3) X(6, 4, 3) X(6, 4, 2)
 constexpr bool kRotCX = false;
 #else
 #define KS_ROT_SHAPES(X) X(6, 3, 3) X(6, 4, 3) X(6, 4, 2) X(11, 6, 3)
@@ -306,6 +306,7 @@ int ks_blk_mfma_nt_f64(int k, int s) {
   // (the class follows from s alone -- the same one the instantiated sizes 8 / 10 / 20 dispatch to)
   if (s <= 8) return (k <= 48 && ((m >> 4) & 3) == 3) ? 2 : 0;
   if (s <= 12) return (k <= 32 && ((m >> 2) & 3) == 3) ? 3 : 0;
+  if (s <= 16 && k <= 28 && k > 24) return (m & 3) == 3 ? 4 : 0;   // (up to 24 columns the 5-tile kernels take these sizes too)
   return (s <= 20 && k <= 24 && (m & 3) == 3) ? 5 : 0;
 }
 // second pass of a block on the matrix instruction (only that form reads the block from scratch columns)?
@@ -331,6 +332,7 @@ int ks_blk_launch_part1(int which, const BlkLaunchArgs& a) {
       switch (ks_blk_mfma_nt_f64(a.k, a.s)) {
         case 2: return go_mfma_by_k<2, 12>(which, a);
         case 3: return go_mfma_by_k<3, 8>(which, a);
+        case 4: return go_mfma_by_k<4, 7, 7>(which, a);   // (25-28 columns only: seven column groups)
         case 5: return go_mfma_by_k<5, 6>(which, a);
         default: throw std::runtime_error("block kernels: block size not in this part");
       }

@@ -739,13 +739,6 @@ int ks_workspace_split_rotations(const ks_workspace* ws, int* count) {
   });
 }
 
-int ks_workspace_corrected_starts(const ks_workspace* ws, int* count) {
-  return guarded([&] {
-    KS_REQUIRE(ws && count, KS_ERR_ARGUMENT, "null argument");
-    *count = ws->z0_count;
-  });
-}
-
 int ks_sstep_partition(int dtype, int k0, int count, int smax, int* out, int cap, int* nblocks) {
   return guarded([&] {
     KS_REQUIRE(nblocks && (out || cap == 0), KS_ERR_ARGUMENT, "null argument");

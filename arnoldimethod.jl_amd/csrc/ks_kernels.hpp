@@ -2390,25 +2390,4 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-// y = X[:, 0:nc) coef  (the corrected start column of a Newton chain, ks_workspace::z0_valid: a handful of columns)
-template <class T>
-__global__ void __launch_bounds__(kBlock)
-    k_lincomb_cols(T* __restrict__ y, const T* __restrict__ X, int64_t ldx, int nc, const T* __restrict__ coef, int64_t cstride, int64_t n,
-                   const DevState* __restrict__ st) {
-  if (st && st->breakdown >= 0) return;
-  for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < n; row += (int64_t)gridDim.x * kBlock) {
-    T s = zero_of(T{});
-    for (int c = 0; c < nc; ++c) {
-      const T g = coef[c * cstride];
-      const T v = X[(int64_t)c * ldx + row];
-      if constexpr (sizeof(T) == 8) s = fma(v, g, s);
-      else {
-        s.x += v.x * g.x - v.y * g.y;
-        s.y += v.x * g.y + v.y * g.x;
-      }
-    }
-    y[row] = s;
-  }
-}
-
 }  // namespace ksd

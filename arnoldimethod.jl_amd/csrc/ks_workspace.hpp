@@ -85,17 +85,7 @@ struct ks_workspace {
   int rot_cin = 0, rot_rr = 0, rot_out0 = 0;
   int rot_fused_count = 0;      // rotations done by the fused kernel (ks_workspace_fused_rotations)
   bool rot_defer_ok = false;    // set by the library's restart drivers around their rotate_and_move (never by the verbs)
-  void* zscratch = nullptr;     // device: ld x (kBlkSMax + 1) elements, the Newton chain of a block whose first pass is fused + the corrected start column
-  // Corrected start column of the next chain (z0_col): the chain of a pending rotation starts from the STORED last column, which
-  // is the true one only up to the Gram deviation of the block that wrote it.  Where that deviation is routinely above the gate
-  // (real shifts on a complex spectrum: 1e-11 .. 1e-10), the part of the difference that lives in the last block's own columns is
-  // put back by one small kernel behind the batch:  z0 = V[:, k0 : maxdim] T[k0 : maxdim, maxdim]  (s + 1 column passes); what
-  // is left out is the part along the columns below k0, ||T[0:k0, maxdim]|| -- the second-stage coefficients, at rounding level --,
-  // and THAT is what the gate then looks at.  z0_valid: computed behind the last batch; rot_from_z0: the pending rotation's chain
-  // starts from it.
-  bool z0_valid = false, rot_from_z0 = false;
-  int z0_k0 = 0;
-  int z0_count = 0;             // pending rotations whose chain started from a corrected column (diagnostics)
+  void* zscratch = nullptr;     // device: ld x kBlkSMax elements, the Newton chain of a block whose first pass is fused
   // SPECULATIVE CHAIN (the host step off the critical path).  When an expansion that ends at maxdim ran in blocks,
   // the first spec_ne products of the NEXT expansion's Newton chain are enqueued right behind it -- before the host has even
   // received H: they need the stored last column (the chain's start, see rot_pending) and shifts, for which the Ritz values of
@@ -1060,23 +1050,13 @@ template <class T> void rotate_tfold(ks_workspace* ws, int c0, int c, int r, con
     // Gram deviation of the block that wrote it (stored = true column up to R_2 = I + delta), so only after a batch that ended
     // in a block and whose deviation is at rounding level (<= 1e-12; accepted blocks may carry up to gram_dev_max = 1e-8,
     // those take the ordinary sequence)
-    bool start_ok = ws->blk_diag[2] <= 1e-12, from_z0 = false;
-    if (ws->z0_valid && tl && src == ws->maxdim && src >= tlo && src <= thi) {
-      // (a corrected start column exists -- and the speculative chain, if any, was started from it: what it leaves out)
-      double nn = 0.0;
-      const T* tc = Th + (size_t)src * ldt;
-      for (int k = 0; k < ws->z0_k0 && k < src; ++k) nn += std::norm(std::complex<double>(tc[k]));
-      from_z0 = std::sqrt(nn) <= 1e-12 * std::abs(std::complex<double>(tc[src]));
-      start_ok = from_z0;
-    }
+    const bool start_ok = ws->blk_diag[2] <= 1e-12;
     static const int defer_dbg = env_int("KS_DEFER_DEBUG", 0);
     if (defer_dbg)
-      std::fprintf(stderr, "[defer] on %d ok %d src %d extra %d cin %d sstep_eff %d blk_tail %d tl %d thi %d gdev %.2e z0 %d from_z0 %d\n", (int)ws->rot_defer_on, (int)ws->rot_defer_ok,
-                   src, (int)extra_elsewhere, cin, ws->sstep_eff, (int)ws->blk_tail, (int)tl, thi, ws->blk_diag[2], (int)ws->z0_valid, (int)from_z0);
+      std::fprintf(stderr, "[defer] on %d ok %d src %d extra %d cin %d sstep_eff %d blk_tail %d tl %d thi %d gdev %.2e\n", (int)ws->rot_defer_on, (int)ws->rot_defer_ok,
+                   src, (int)extra_elsewhere, cin, ws->sstep_eff, (int)ws->blk_tail, (int)tl, thi, ws->blk_diag[2]);
     if (ws->rot_defer_on && ws->rot_defer_ok && src == ws->maxdim && !extra_elsewhere && cin == ws->maxdim + 1 && ws->sstep_eff >= 8 && ws->blk_tail && tl && thi == ws->maxdim &&
         start_ok) {
-      ws->rot_from_z0 = from_z0;
-      if (from_z0) ws->z0_count++;
       gate_cancel(ws);   // (a pre-enqueued rotation returns at once)
       KS_HIP(hipMemcpyAsync(ws->Qd, qs, (size_t)cin * rr * sizeof(T), hipMemcpyHostToDevice, ws->ctx->stream));
       ws->rot_pending = true;
@@ -1117,13 +1097,11 @@ inline void spec_drop(ks_workspace* ws) {
   // (a dropped chain costs the device s products it would otherwise not do: back off 1, 2, 4, 8 cycles on consecutive drops --
   // a reader between two calls is a one-off, a shape that never adopts is not --, an adopted chain resets the length)
   if (ws->spec_valid) { ws->spec_valid = false; ws->spec_wasted++; ws->spec_backoff = ws->spec_backoff_len; ws->spec_backoff_len = std::min(8, 2 * ws->spec_backoff_len); }
-  ws->z0_valid = false;   // (the corrected start column belongs to the factorisation as the last batch left it)
 }
 inline void rot_flush(ks_workspace* ws) {
   if (!ws->rot_pending) return;
   spec_drop(ws);   // (the chain's start column is about to be overwritten)
   ws->rot_pending = false;
-  ws->rot_from_z0 = false;
   ws->t_lazy = false;
   ws->t_hi = -1;
   if (ws->dtype == KS_F64) rotate_device<double>(ws, 0, ws->rot_cin, ws->rot_rr, ws->rot_out0, -1);

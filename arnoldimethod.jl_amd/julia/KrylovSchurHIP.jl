@@ -346,17 +346,6 @@ function split_rotations(w::HipWorkspace)
 end
 
 """
-    corrected_starts(w) -> Int
-
-Pending rotations whose Newton chain started from a corrected last column (include/kschur.h, ks_workspace_corrected_starts).
-"""
-function corrected_starts(w::HipWorkspace)
-    c = Ref{Cint}(0)
-    check(ccall((:ks_workspace_corrected_starts, LIB), Cint, (Ptr{Cvoid}, Ptr{Cint}), w.h, c))
-    return Int(c[])
-end
-
-"""
     sstep_partition(T, k0, count, smax) -> Vector{Int}
 
 Block sizes the library uses for `count` steps of `iterate_arnoldi!` on top of `k0` columns (include/kschur.h, ks_sstep_partition).

@@ -234,7 +234,7 @@ int ks_workspace_set_passes(ks_workspace* ws, int passes, double max_ratio);
  * abandoned before anything is committed and its steps are redone one at a time, which takes the reference's decisions.
  * Like the implicit second pass it needs the library's provenance of the factorisation; otherwise, and for host-callback
  * operators and maxdim > 64 the expansion runs step by step.  Default s = 20 (KS_SSTEP at creation; blocks of up to 20 on
- * up to 24 existing columns, up to 12 on up to 32, up to 8 on up to 48, 1-5 beyond; ComplexF64: up to 10 on up to 32 columns,
+ * up to 24 existing columns, up to 16 on up to 28, up to 12 on up to 32, up to 8 on up to 48, 1-5 beyond; ComplexF64: up to 10 on up to 32 columns,
  * 1-5 beyond); s = 0 / 1: off --
  * every step then takes the reference's DGKS decisions.  A block is also abandoned when the Gram matrix of what its first
  * stage wrote differs from I by more than
@@ -282,13 +282,6 @@ int ks_workspace_fused_rotations(const ks_workspace* ws, int* count, int* spec_a
  * its first block read the Newton chain from scratch columns -- what this buys is that the speculative chain (above) can run
  * behind the previous expansion for these shapes too.  *count = such rotations since creation. */
 int ks_workspace_split_rotations(const ks_workspace* ws, int* count);
-/* A pending rotation's Newton chain starts from the STORED last column of the old basis, which is the true column
- * (src/run.jl:365 moves THAT one) only up to the Gram deviation of the block that wrote it: the rotation stays pending only when
- * that deviation is <= 1e-12.  Where it is routinely larger (real shifts on a complex spectrum: 1e-11 .. 1e-10) the library puts
- * the last block's share of the difference back with one small kernel behind the batch (z0 = V[:, k0:m] T[k0:m, m], s + 1 column
- * passes) and gates on what that leaves out instead (||T[0:k0, m]||, the second-stage coefficients).  *count = pending
- * rotations since creation whose chain started from such a corrected column. */
-int ks_workspace_corrected_starts(const ks_workspace* ws, int* count);
 /* Diagnostics (tools/blk_bench.py): average duration of `reps` back-to-back launches of one streaming kernel of the s-step
  * expansion at basis size k and block size s (which = 0: first pass, 1: second pass), timed with HIP events on the
  * library's stream; *grid = workgroups launched.  dbg: probe flags of the kernels (1: second pass without its stores).

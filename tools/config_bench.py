@@ -166,7 +166,7 @@ def main():
         "iters_per_s": state["steps"] / elapsed, "ms_per_cycle": 1e3 * elapsed / args.steps, "iterations": state["steps"],
         "dgks_second_passes": state["reorth"], "spmv_layout": fmt, "per_class": per,
         "sstep": {"requested": args.sstep, "in_force": ws.sstep_info["s"], "block_cycles": state.get("blk_cycles", 0), "abandoned": state.get("abandoned", 0),
-                  **{k: ws.sstep_info[k] for k in ("fused_rotations", "split_rotations", "corrected_starts", "chains_adopted", "chains_dropped", "gram_dev")}} if args.sstep >= 2 else None,
+                  **{k: ws.sstep_info[k] for k in ("fused_rotations", "split_rotations", "chains_adopted", "chains_dropped", "gram_dev")}} if args.sstep >= 2 else None,
         "validation": {"arnoldi_rel": rel / hnorm if hnorm else None, "orth": orth, "k": state["k"], "locked": state["active"]},
         "expansion": {"moved_GBps": moved, "moved_frac": moved / PEAK, "expand_seconds": state["t_expand"], "restart_seconds": state["t_restart"]},
     }
