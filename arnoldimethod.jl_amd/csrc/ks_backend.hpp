@@ -159,8 +159,11 @@ template <class T> struct HipBackend : ks::Backend<T> {
           (ks_blk_rot_ok(ws->dtype == KS_F64 ? 0 : 1, ws->maxdim + 1, j0, blk_sizes[0]) || ks_blk_zsrc_ok(ws->dtype == KS_F64 ? 0 : 1, j0, blk_sizes[0]))) {
         static const int defer_dbg2 = env_int("KS_DEFER_DEBUG", 0);
         if (defer_dbg2) std::fprintf(stderr, "[spec] enqueue? backoff %d j0 %d blk0 %d\n", ws->spec_backoff, j0, blk_sizes[0]);
+        // (and the rotation will stay pending only behind a block whose Gram deviation passes the gate of rotate_tfold: where the last
+        // batch's did not -- real shifts on a complex spectrum sit at 1e-11 .. 1e-10 every time -- the chain would be dropped)
+        const bool gate_likely = ws->blk_count == 0 || ws->blk_diag[2] <= 1e-12;
         if (ws->spec_backoff > 0) --ws->spec_backoff;
-        else spec_enqueue(blk_sh, j0);
+        else if (gate_likely) spec_enqueue(blk_sh, j0);
       }
       // reverse mailbox: the restart that follows this (last) batch will rotate the factored basis -- put that rotation into
       // the stream NOW, behind a gate the host releases when it has Q (ks_workspace.hpp: gate_arm / rotate_tfold)

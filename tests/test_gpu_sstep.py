@@ -464,7 +464,9 @@ def test_whole_solves_at_full_size_default_blocks_against_the_per_step_expansion
     tag = f"default: {h1} ({h1.restarts} restarts, res {res1:.2e}, {info1}) | per-step: {h0} ({h0.restarts} restarts, res {res0:.2e})"
     print(tag)
     assert h1.converged and h0.converged and h1.nconverged >= 20 and h0.nconverged >= 20, tag
-    assert info1["s"] == 20 and info1["blocks"] >= h1.restarts and info1["abandoned"] == 0 and rel1["breaks"] == 0 and info0["blocks"] == 0, tag
+    # (every expansion after the first restart runs in blocks -- since the block size is a run-time quantity, in exactly ONE block:
+    # the first expansion has no Ritz values to take shifts from)
+    assert info1["s"] == 20 and info1["blocks"] >= h1.restarts - 1 and info1["abandoned"] == 0 and rel1["breaks"] == 0 and info0["blocks"] == 0, tag
     slack = 0.15 if len(set(grid)) == 3 else 0.5
     assert abs(h1.mvproducts - h0.mvproducts) <= slack * h0.mvproducts, tag
     assert res1 <= 2 * res0 + 1e-12 and res0 <= 2 * res1 + 1e-12 and max(res1, res0) <= 10 * tol * 12.0 * np.sqrt(20), tag
