@@ -495,7 +495,10 @@ def _run_ranks(nproc, mode, m=16, extra_env=None, timeout=420):
 
 @pytest.mark.parametrize("nproc,mode,transport,s", [(2, "laplace", "p2p", 5), (3, "laplace", "p2p", 8), (4, "hashed", "p2p", 4), (3, "complex", "p2p", 3),
                                                     (2, "laplace", "host", 5), (3, "hashed", "host", 2),
-                                                    (2, "laplace", "p2p", 10), (3, "wide", "host", 10)])
+                                                    (2, "laplace", "p2p", 10), (3, "wide", "host", 10),
+                                                    # (block sizes at run time: one block of 17-18 per cycle; ComplexF64 blocks of 10 on the
+                                                    # matrix instruction; pending rotations in the split form + speculative chains on every rank)
+                                                    (2, "laplace", "p2p", 20), (2, "complex", "p2p", 10)])
 def test_blocks_with_real_ranks_on_one_gpu(nproc, mode, transport, s):
     """Rows of A and V split over `nproc` processes sharing device 0 (peer-to-peer regions, or the host-staged transport =
     the RCCL launch structure reduce -> all-reduce -> algebra): per block two all-reduces of k s + s (s + 1) / 2 elements, every
