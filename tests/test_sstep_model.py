@@ -5,7 +5,8 @@ What is pinned here is the ALGORITHM the device kernels implement: Newton-basis 
 basis read twice per block, two-stage block Gram-Schmidt with Pythagorean inner products, the Hessenberg columns recovered
 from the basis recurrence.  Same Krylov space as the reference, so on well-posed problems: identical matrix-vector counts and
 restart trails, Ritz values to 1e-10, residuals and orthogonality at the oracle's level -- for s = 2, 4, 5 (the sizes the
-review asked for) and 8, 10 (what the device also instantiates), BASELINE configs 1-4 in miniature."""
+review asked for), 8, 10 and a few of the sizes in between and beyond (the device takes any size up to 20), BASELINE
+configs 1-4 in miniature."""
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -37,7 +38,8 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("s", [2, 4, 5, 8, 10])
+# (7, 9, 13, 19: the device's matrix-instruction kernels take the block size at run time -- round 5 --, so every size is one)
+@pytest.mark.parametrize("s", [2, 4, 5, 7, 8, 9, 10, 13, 19])
 @pytest.mark.parametrize("case", list(CASES))
 def test_block_expansion_reproduces_the_reference(case, s):
     build, dtype, kw = CASES[case]
