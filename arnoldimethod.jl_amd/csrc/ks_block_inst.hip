@@ -304,16 +304,16 @@ int ks_blk_mfma_nt_f64(int k, int s) {
   const int m = mfma_env();
   if (s < 1 || k < 1) return 0;
   // (the class follows from s alone -- the same one the instantiated sizes 8 / 10 / 20 dispatch to)
-  if (s <= 8) return (k <= 48 && ((m >> 4) & 3) == 3) ? 2 : 0;
-  if (s <= 12) return (k <= 32 && ((m >> 2) & 3) == 3) ? 3 : 0;
+  if (s <= 8) return (k <= 64 && ((m >> 4) & 3) == 3) ? 2 : 0;
+  if (s <= 12) return (k <= 48 && ((m >> 2) & 3) == 3) ? 3 : 0;
   if (s <= 16 && k <= 28 && k > 24) return (m & 3) == 3 ? 4 : 0;   // (up to 24 columns the 5-tile kernels take these sizes too)
   return (s <= 20 && k <= 24 && (m & 3) == 3) ? 5 : 0;
 }
 // second pass of a block on the matrix instruction (only that form reads the block from scratch columns)?
 static bool pass2_mfma(int k, int s) {
   const int bit2 = s == 20 ? 1 : (s == 10 ? 3 : (s == 8 ? 5 : -1));
-  if (bit2 >= 0) return ((mfma_env() >> bit2) & 1) && (s == 20 ? k <= 24 : (s == 10 ? k <= 32 : k <= 48));
-  return s > 5 && ks_blk_mfma_nt_f64(k, s) > 0;
+  if (bit2 >= 0 && (s == 20 ? k <= 24 : (s == 10 ? k <= 32 : k <= 48))) return ((mfma_env() >> bit2) & 1) != 0;
+  return s > 5 && ks_blk_mfma_nt_f64(k, s) > 0;   // (also 8 / 10 beyond the widths of their register / ring forms)
 }
 bool ks_blk_rot_ok_f64(int cin, int k, int s) {
   int a, b, c;
@@ -322,7 +322,9 @@ bool ks_blk_rot_ok_f64(int cin, int k, int s) {
 }
 int ks_blk_launch_part1(int which, const BlkLaunchArgs& a) {
   if (which == 2) return go_rot_by_shape(a);
-  switch (a.s) {
+  // (8 / 10 beyond the widths of their register / ring forms exist on the matrix instruction only: the default branch)
+  const bool wide = (a.s == 8 && a.k > 48) || (a.s == 10 && a.k > 32);
+  switch (wide ? 0 : a.s) {
     case 5: return by_ncw<double, 5>(which, a);
     case 8: return by_ncw<double, 8>(which, a);
     case 10: return by_ncw<double, 10>(which, a);
@@ -330,8 +332,8 @@ int ks_blk_launch_part1(int which, const BlkLaunchArgs& a) {
     default:
       // sizes without register / ring forms: the matrix-instruction kernel of the next tile count (run-time s)
       switch (ks_blk_mfma_nt_f64(a.k, a.s)) {
-        case 2: return go_mfma_by_k<2, 12>(which, a);
-        case 3: return go_mfma_by_k<3, 8>(which, a);
+        case 2: return go_mfma_by_k<2, 16>(which, a);
+        case 3: return go_mfma_by_k<3, 12>(which, a);
         case 4: return go_mfma_by_k<4, 7, 7>(which, a);   // (25-28 columns only: seven column groups)
         case 5: return go_mfma_by_k<5, 6>(which, a);
         default: throw std::runtime_error("block kernels: block size not in this part");

@@ -36,7 +36,7 @@ int ks_blk_launch_part1(int which, const BlkLaunchArgs& a);   // Float64, block 
 int ks_blk_launch_part2(int which, const BlkLaunchArgs& a);   // ComplexF64, block sizes 1-5
 // The matrix-instruction forms (ks_block_mfma.hpp) take the block size at run time -- a block of s steps runs on the kernel of
 // ceil(s / 4) column tiles, the missing columns are zeros --, so every size up to 4 NT of an instantiated tile count NT exists:
-// Float64 NT = 2 (s <= 8, up to 48 columns), 3 (s <= 12, up to 32), 4 (s <= 16, 25-28 columns), 5 (s <= 20, up to 24); ComplexF64 NT = 2, 3 (s <= 10) up to 32 columns.
+// Float64 NT = 2 (s <= 8, up to 64 columns), 3 (s <= 12, up to 48), 4 (s <= 16, 25-28 columns), 5 (s <= 20, up to 24); ComplexF64 NT = 2, 3 (s <= 10) up to 32 columns.
 // Tile count for (dtype, k, s) if those forms are switched on (KS_BLK_MFMA) for BOTH passes, else 0.
 int ks_blk_mfma_nt_f64(int k, int s);
 int ks_blk_mfma_nt_c64(int k, int s);

@@ -234,7 +234,7 @@ int ks_workspace_set_passes(ks_workspace* ws, int passes, double max_ratio);
  * abandoned before anything is committed and its steps are redone one at a time, which takes the reference's decisions.
  * Like the implicit second pass it needs the library's provenance of the factorisation; otherwise, and for host-callback
  * operators and maxdim > 64 the expansion runs step by step.  Default s = 20 (KS_SSTEP at creation; blocks of up to 20 on
- * up to 24 existing columns, up to 16 on up to 28, up to 12 on up to 32, up to 8 on up to 48, 1-5 beyond; ComplexF64: up to 10 on up to 32 columns,
+ * up to 24 existing columns, up to 16 on up to 28, up to 12 on up to 48, up to 8 on up to 64; ComplexF64: up to 10 on up to 32 columns,
  * 1-5 beyond); s = 0 / 1: off --
  * every step then takes the reference's DGKS decisions.  A block is also abandoned when the Gram matrix of what its first
  * stage wrote differs from I by more than

@@ -124,6 +124,25 @@ def test_blocks_of_13_to_16_on_25_to_28_columns(mindim, maxdim):
     assert seen >= 1
 
 
+@pytest.mark.parametrize("mindim,maxdim", [(30, 60), (40, 64)])
+def test_wide_bases_in_blocks(mindim, maxdim):
+    """Large Krylov dimensions (the reference's defaults for nev = 30 / 32: mindim = nev, maxdim = 2 nev): blocks of up to 12 on up
+    to 48 columns and of up to 8 on up to 64 (k_bdots_mfma / k_bupdate_mfma<9..12, 3> and <13..16, 2>) -- 30 steps on 31 columns are
+    12 + 12 + 6 instead of 8 + 8 + 5 + 5 + 4.  Lockstep against the per-step path."""
+    part = pkg.sstep_partition(np.float64, mindim + 1, maxdim - mindim, 20)
+    assert part and max(part) >= 8 and len(part) <= 3, part
+    seen = 0
+    for cyc, Hs, Hb, Vs, Vb, rel, orth, info in _lockstep(laplace3d(20, 21, 22), np.float64, 20, 12, mindim, maxdim, "SR", 3):
+        if cyc == 0:
+            continue
+        assert info["blocks"] > 0 and info["abandoned"] == 0 and info["s"] == 20, info
+        assert np.abs(Hs - Hb).max() <= 1e-11 * np.abs(Hs).max(), (cyc, np.abs(Hs - Hb).max())
+        assert np.abs(Vs - Vb).max() <= 1e-9, (cyc, np.abs(Vs - Vb).max())
+        assert rel <= 1e-12 * np.linalg.norm(Hb) * 10 and orth <= 1e-13
+        seen += 1
+    assert seen >= 1
+
+
 @pytest.mark.parametrize("s", [2, 5])
 def test_blocks_reproduce_the_per_step_expansion_complex_and_nonsymmetric(s):
     for A, dtype, which in ((_complex_op(), np.complex128, "LM"), (_nonsym(), np.float64, "LM")):
@@ -202,7 +221,7 @@ def test_partition_takes_one_block_where_the_kernels_allow(monkeypatch):
     assert pkg.sstep_partition(np.float64, 25, 16, 20) == [16] and pkg.sstep_partition(np.float64, 28, 13, 20) == [13]
     assert pkg.sstep_partition(np.float64, 29, 15, 20) == [12, 3] and pkg.sstep_partition(np.float64, 29, 12, 20) == [12]
     assert pkg.sstep_partition(np.float64, 33, 7, 20) == [7]
-    assert pkg.sstep_partition(np.float64, 50, 14, 20) == [5, 5, 4]
+    assert pkg.sstep_partition(np.float64, 50, 14, 20) == [8, 6] and pkg.sstep_partition(np.float64, 31, 30, 20) == [12, 12, 6]
     assert pkg.sstep_partition(np.float64, 21, 20, 20) == [20] and pkg.sstep_partition(np.float64, 21, 20, 5) == [5, 5, 5, 5]
     assert pkg.sstep_partition(np.complex128, 6, 14, 20) == [10, 4]
 

@@ -15,7 +15,7 @@ def test_ranges_are_cut_into_as_few_blocks_as_the_tile_counts_allow():
     assert pkg.sstep_partition(f, 25, 16, 20) == [16]            # 20/40 with 4 locked vectors (src/run.jl:316): 4-tile kernels
     assert pkg.sstep_partition(f, 28, 13, 20) == [13]
     assert pkg.sstep_partition(f, 29, 12, 20) == [12] and pkg.sstep_partition(f, 29, 15, 20) == [12, 3]
-    assert pkg.sstep_partition(f, 33, 7, 20) == [7] and pkg.sstep_partition(f, 50, 14, 20) == [5, 5, 4]
+    assert pkg.sstep_partition(f, 33, 7, 20) == [7] and pkg.sstep_partition(f, 50, 14, 20) == [8, 6] and pkg.sstep_partition(f, 31, 30, 20) == [12, 12, 6]
     assert pkg.sstep_partition(c, 11, 9, 20) == [9] and pkg.sstep_partition(c, 6, 14, 20) == [10, 4]
     assert pkg.sstep_partition(c, 33, 7, 20) == []               # ComplexF64 block kernels stop at 32 columns
     assert pkg.sstep_partition(f, 21, 20, 5) == [5, 5, 5, 5] and pkg.sstep_partition(f, 21, 20, 1) == [1] * 20

@@ -24,6 +24,9 @@ def main():
     L = _lib.load()
     shapes = [(21, 5), (26, 5), (31, 5), (36, 5), (21, 10), (31, 10), (21, 20), (21, 8), (29, 8), (25, 8), (33, 8), (21, 4), (37, 4), (21, 2), (39, 2)]
     shapes = [(k, s) for k, s in shapes if k + s <= maxdim + 1]
+    if os.environ.get("BLK_SHAPES"):   # e.g. BLK_SHAPES=31:12,43:12,55:6,50:8 (k:s pairs; run-time block sizes, wide bases)
+        shapes = [tuple(int(v) for v in x.split(":")) for x in os.environ["BLK_SHAPES"].split(",")]
+        shapes = [(k, s) for k, s in shapes if k + s <= maxdim + 1]
     if os.environ.get("BLK_S"):
         shapes = [(k, s) for k, s in shapes if s in [int(x) for x in os.environ["BLK_S"].split(",")]]
     dbgs = [int(x) for x in os.environ.get("BLK_DBGS", "0,1,4").split(",")]
