@@ -63,6 +63,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
     // (columns still in factored form were produced by the library's previous call, no restart in between: nothing to measure,
     // and materialising them here would change the rounding of a run that stays step by step)
     if (trusted && ws->prov_vouched && !ws->t_lazy && ws->sstep_eff >= 2 && op->async_capable && from >= 2 && to - from + 1 >= 2) relation_probe(from, H);
+    drift_probe_collect();   // (a watch enqueued behind the previous expansion: may switch the blocks off for this one)
     blk_shifts_from_saved_H();
     while (j0 <= to) {
       const double tb0 = ks::now_s();
@@ -80,6 +81,11 @@ template <class T> struct HipBackend : ks::Backend<T> {
           blk_make_shifts<D>(ws, std::min(ws->sstep_eff, ksd::kBlkSMax), blk_sh))
         blk_sizes = blk_partition(ws->dtype, j0, jend - j0 + 1, std::min(ws->sstep_eff, ksd::kBlkSMax));
       const bool bpath = !blk_sizes.empty();
+      if (bpath) {   // (a partition that ends early: this batch goes as far as the blocks do, the next one takes the rest step by step)
+        int covered = 0;
+        for (int sz : blk_sizes) covered += sz;
+        jend = std::min(jend, j0 + covered - 1);
+      }
       if (ws->rot_pending) {
         // the restart's rotation is still pending (rotate_tfold): this batch's first block does it in the sweep of its first
         // pass when there is a kernel for the shape -- otherwise it runs now, the ordinary way
@@ -164,6 +170,12 @@ template <class T> struct HipBackend : ks::Backend<T> {
         const bool gate_likely = ws->blk_count == 0 || ws->blk_diag[2] <= 1e-12;
         if (ws->spec_backoff > 0) --ws->spec_backoff;
         else if (gate_likely) spec_enqueue(blk_sh, j0);
+      }
+      // drift watch: behind the publication of H and the speculative chain (the host is not kept waiting for it; the result is
+      // read when the next expansion starts -- the restart in between synchronises with the stream)
+      if (bpath && jend == to && to == ws->maxdim && j0 >= 2 && !ws->rp_inflight && ++ws->rp_count >= ws->rp_every) {
+        ws->rp_count = 0;
+        drift_probe_enqueue(j0, H);
       }
       // reverse mailbox: the restart that follows this (last) batch will rotate the factored basis -- put that rotation into
       // the stream NOW, behind a gate the host releases when it has Q (ks_workspace.hpp: gate_arm / rotate_tfold)
@@ -374,8 +386,105 @@ template <class T> struct HipBackend : ks::Backend<T> {
     }
   }
 
+  // Drift watch (ks_workspace::probe_col): residual of column c = from - 2 of the relation this batch leaned on,
+  //   r = A v_c - V[:, 0:from) H[0:from, c]
+  // (columns below `from` are ordinary and untouched by the batch, H[:, c] is the caller's), enqueued behind the batch.
+  void drift_probe_enqueue(int from, const ks::Mat<T>& H) {
+    const int c = from - 2, nc = from;
+    hipStream_t s_ = ws->ctx->stream;
+    if (!ws->probe_dev) {
+      KS_HIP(hipMalloc(&ws->probe_dev, 16 + (size_t)(ws->maxdim + 2) * 16));
+      KS_HIP(hipHostMalloc(&ws->probe_host, 16 + (size_t)(ws->maxdim + 2) * 16));
+    }
+    if (!ws->probe_col) {
+      KS_HIP(hipMalloc(&ws->probe_col, (size_t)ws->ld * sizeof(D)));
+      KS_HIP(hipMemsetAsync(ws->probe_col, 0, (size_t)ws->ld * sizeof(D), s_));
+    }
+    D* scratch = static_cast<D*>(ws->probe_col);
+    op->in_scale = 1.0;
+    op->apply(ws->col(c), scratch, ws->st);
+    if (!ws->ctx->distributed()) {
+      // one launch, no copies: coefficients by value, the sums written to the pinned words by the last workgroup
+      if (!ws->watch_acc) {
+        KS_HIP(hipMalloc(&ws->watch_acc, 32));
+        KS_HIP(hipMemsetAsync(ws->watch_acc, 0, 32, s_));
+        KS_HIP(hipHostGetDevicePointer(&ws->probe_host_dev, ws->probe_host, 0));
+      }
+      ksd::ProbeCoef<D> pc;
+      double fro2w = 0.0;
+      for (int j = 0; j < from - 1; ++j)
+        for (int i = 0; i < from; ++i) fro2w += std::norm(std::complex<double>(H(i, j)));
+      for (int i = 0; i < nc; ++i) std::memcpy(&pc.c[i], &H(i, c), sizeof(D));
+      const int64_t nchunks_w = (ws->n + 15) / 16;
+      const int64_t stride_w = std::max<int64_t>(1, std::min<int64_t>(256, nchunks_w / 4096));   // (~65 000 sampled rows)
+      const int64_t sampled_w = (nchunks_w + stride_w - 1) / stride_w * 16;
+      const int grid_w = (int)((sampled_w + kBlock - 1) / kBlock);
+      double* hres = static_cast<double*>(ws->probe_host);
+      hres[0] = 0.0; hres[1] = 0.0; hres[2] = 0.0;   // (a batch that breaks down leaves them: no measurement)
+      ws->rp_seq += 1.0;
+      ksd::k_relation_watch<D><<<grid_w, kBlock, 0, s_>>>(static_cast<const D*>(ws->V), ws->ld, nc, scratch, pc, ws->n, stride_w, static_cast<double*>(ws->watch_acc),
+                                                         static_cast<double*>(ws->probe_host_dev), ws->rp_seq, ws->st);
+      KS_HIP(hipGetLastError());
+      ws->rp_fro = std::sqrt(fro2w);
+      ws->rp_inflight = true;
+      return;
+    }
+    double* out = static_cast<double*>(ws->probe_dev);
+    D* coef_d = reinterpret_cast<D*>(static_cast<char*>(ws->probe_dev) + 16);
+    D* coef_h = reinterpret_cast<D*>(static_cast<char*>(ws->probe_host) + 16);
+    double fro2 = 0.0;
+    for (int j = 0; j < from - 1; ++j)
+      for (int i = 0; i < from; ++i) fro2 += std::norm(std::complex<double>(H(i, j)));
+    for (int i = 0; i < nc; ++i) std::memcpy(&coef_h[i], &H(i, c), sizeof(D));
+    KS_HIP(hipMemcpyAsync(coef_d, coef_h, (size_t)nc * sizeof(D), hipMemcpyHostToDevice, s_));
+    KS_HIP(hipMemsetAsync(out, 0, 2 * sizeof(double), s_));
+    const int64_t nchunks = (ws->n + 15) / 16;
+    const int64_t stride = std::max<int64_t>(1, std::min<int64_t>(64, nchunks / 16384));
+    const int64_t sampled = (nchunks + stride - 1) / stride * 16;
+    const int grid = (int)((sampled + kBlock - 1) / kBlock);
+    ksd::k_relation_probe<D><<<grid, kBlock, 0, s_>>>(static_cast<const D*>(ws->V), ws->ld, nc, scratch, coef_d, ws->n, stride, out);
+    KS_HIP(hipGetLastError());
+    if (ws->ctx->distributed()) ws->ctx->allreduce(out, 2);
+    KS_HIP(hipMemcpyAsync(ws->probe_host, out, 2 * sizeof(double), hipMemcpyDeviceToHost, s_));
+    ws->rp_fro = std::sqrt(fro2);
+    ws->rp_inflight = true;   // (read at the start of the next expansion, behind the restart's synchronisation)
+  }
+  // (after the batch's results arrived: the copy above completed before the publication behind it started)
+  void drift_probe_collect() {
+    if (!ws->rp_inflight) return;
+    ws->rp_inflight = false;
+    const double* res = static_cast<const double*>(ws->probe_host);
+    if (!ws->ctx->distributed()) {
+      // (written by the last workgroup of k_relation_watch; a batch that stopped early, or a stream that was not synchronised in
+      // between -- a caller that went straight into the next expansion --, leaves the sequence word behind: no measurement)
+      if (__atomic_load_n(reinterpret_cast<const volatile uint64_t*>(&res[2]), __ATOMIC_ACQUIRE) == 0 || res[2] != ws->rp_seq) return;
+    } else if (ws->st_h->breakdown >= 0 || ws->st_h->blk_bail >= 0) {
+      return;
+    }
+    const double fro = ws->rp_fro;
+    const double leak = res[1] > 0.0 ? std::sqrt(res[0] * ((double)ws->n_global / res[1])) : 0.0;
+    ws->relation_probes++;
+    ws->rp_done++;
+    const double rel = fro > 0.0 ? leak / fro : leak;
+    static const int watch_dbg = env_int("KS_DEFER_DEBUG", 0);
+    if (watch_dbg) std::fprintf(stderr, "[watch] probe %d rel %.3e (leak %.3e fro %.3e) every %d prov_k %d\n", ws->rp_done, rel, leak, fro, ws->rp_every, ws->prov_k);
+    // (the restart's locking drops couplings of up to tol |lambda| per converged pair, by design -- src/run.jl:330 --, and the
+    // kept columns inherit them: 2.8e-11 ||H||_F at tol = 1e-12 on the miniature of config 2; a drift passes any level within a
+    // few cycles)
+    const double limit = std::max(1e-10, 30.0 * ws->watch_tol), quiet = std::max(2e-12, 0.1 * ws->watch_tol);
+    if (!(rel <= limit)) {   // (NaN counts as a break)
+      ws->relation_breaks++;
+      ws->relation_leak = std::max(ws->relation_leak, rel);
+      ws->sstep_eff = 0;
+    }
+    const bool calm = rel <= quiet && !(rel > 4.0 * ws->rp_last && rel > 5e-13);
+    ws->rp_every = (ws->rp_done >= 4 && calm) ? 2 : 1;
+    ws->rp_last = rel;
+  }
+
   // Ritz values of the restart that just happened (Newton shifts of the next expansion's blocks)
-  void note_ritz(const cplx* lams, int m, double leak = 0.0, double fro = 0.0) override {
+  void note_ritz(const cplx* lams, int m, double leak = 0.0, double fro = 0.0, double tol = 0.0) override {
+    ws->watch_tol = tol > 0.0 && std::isfinite(tol) ? tol : 0.0;   // (what the restart's locking may legitimately drop: scale of the drift watch)
     if (leak > ws->relation_tol * fro) {
       // the restart cut through a 2 x 2 block (RestartResult::leak): the relation of the kept columns is violated by `leak`.
       // Blocks off for the rest of this run (a new start vector re-arms them); counted for ks_workspace_relation_info.

@@ -15,14 +15,15 @@
 // ---- block sizes ------------------------------------------------------------------------------------------------------------
 // instantiated shapes: ks_blk_shape_ok (ks_block_launch.hpp)
 inline bool blk_shape_ok(int dtype, int k, int s) { return ks_blk_shape_ok(dtype == KS_F64 ? 0 : 1, k, s); }
-// split `count` steps starting with k0 existing columns into block sizes <= smax
+// split `count` steps starting with k0 existing columns into block sizes <= smax; where the kernels stop (ComplexF64 beyond
+// 32 / 48 columns) the partition ends early: the steps behind it run one at a time
 inline std::vector<int> blk_partition(int dtype, int k0, int count, int smax) {
   std::vector<int> out;
   int k = k0;
   while (count > 0) {
     int s = std::min(count, smax);
     while (s > 1 && !blk_shape_ok(dtype, k, s)) --s;
-    if (!blk_shape_ok(dtype, k, s)) return {};
+    if (!blk_shape_ok(dtype, k, s)) break;
     out.push_back(s);
     k += s;
     count -= s;

@@ -342,8 +342,9 @@ int ks_blk_launch_part1(int which, const BlkLaunchArgs& a) {
 }
 #else
 int ks_blk_mfma_nt_c64(int k, int s) {
-  if (!((mfma_env() >> 7) & 1) || k < 1 || k > 32 || s < 1) return 0;
-  return s <= 8 ? 2 : (s <= 10 ? 3 : 0);   // (k_fin_blk<cd> holds factors of up to 10 x 10: blk_smax)
+  if (!((mfma_env() >> 7) & 1) || k < 1 || k > 48 || s < 1) return 0;
+  if (s <= 8) return 2;                       // (up to 48 columns)
+  return (s <= 10 && k <= 32) ? 3 : 0;        // (k_fin_blk<cd> holds factors of up to 10 x 10: blk_smax)
 }
 bool ks_blk_rot_ok_c64(int cin, int k, int s) {
   int a, b, c;
@@ -353,9 +354,9 @@ bool ks_blk_rot_ok_c64(int cin, int k, int s) {
 int ks_blk_launch_part2(int which, const BlkLaunchArgs& a) {
   if (which == 2) return go_rot_by_shape(a);
   // ComplexF64 blocks beyond 5 run on the matrix instruction only (real view of the basis, ks_block_mfma.hpp); bit 7 of KS_BLK_MFMA
-  if (a.s > 5) {
+  if (a.s > 5 || a.k > 32) {
     const int nt = ks_blk_mfma_nt_c64(a.k, a.s);
-    if (nt == 2) return go_mfma_by_k<2, 8, 1, true>(which, a);
+    if (nt == 2) return go_mfma_by_k<2, 12, 1, true>(which, a);
     if (nt == 3) return go_mfma_by_k<3, 8, 1, true>(which, a);
   }
   switch (a.s) {

@@ -135,6 +135,49 @@ __device__ __forceinline__ void store_folded(const double* f, int lane, int wave
   }
 }
 
+// The same measurement for the drift watch of block runs (every first or second restart cycle: no copies around it): the
+// coefficients travel as a kernel argument, the last workgroup to arrive writes the two sums to the pinned host words `host2`
+// (visible when the kernel ends, i.e. before the publication of H behind it) and clears the accumulators for the next use.
+template <class T> struct ProbeCoef { T c[kBlkKMax]; };
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+    k_relation_watch(const T* __restrict__ V, int64_t ld, int nc, const T* __restrict__ w, const ProbeCoef<T> coef, int64_t n, int64_t stride,
+                     double* __restrict__ acc /* [sum, rows, ticket] */, double* __restrict__ host2, double seq, const DevState* __restrict__ st) {
+  if (st && st->breakdown >= 0) return;
+  __shared__ double red[2][kBlock / 64];
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t row = (t >> 4) * stride * 16 + (t & 15);
+  double r2 = 0.0, cnt = 0.0;
+  if (row < n) {
+    T a = w[row];
+    for (int i = 0; i < nc; ++i) a = sub_(a, mul_(V[row + (int64_t)i * ld], coef.c[i]));
+    r2 = abs2_(a);
+    cnt = 1.0;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { r2 += __shfl_xor(r2, off, 64); cnt += __shfl_xor(cnt, off, 64); }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wv] = r2; red[1][wv] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < kBlock / 64; ++i) { a += red[0][i]; b += red[1][i]; }
+    atomicAdd(acc, a);
+    atomicAdd(acc + 1, b);
+    __threadfence();
+    unsigned* ticket = reinterpret_cast<unsigned*>(acc + 2);
+    if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+      __threadfence();
+      host2[0] = atomicAdd(acc, 0.0);
+      host2[1] = atomicAdd(acc + 1, 0.0);
+      acc[0] = 0.0; acc[1] = 0.0; *ticket = 0u;
+      __threadfence_system();
+      host2[2] = seq;   // (last: the host takes the sums only when it finds its sequence number)
+      __threadfence_system();
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // z = sigma (y - theta x): the Newton-basis step after a plain operator product (operators without a fused form)
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1387,7 +1430,29 @@ __global__ void __launch_bounds__(kBlock)
     gdev = sh_ratio;
     __syncthreads();
   }
-  const bool too_far = stage == 2 && !(gdev <= gdevmax);
+  // A COLLAPSING chain (stage 1): z_i = sigma (A z_{i-1} - theta_i z_{i-1}) is computed with an error of eps ||A|| ||z_{i-1}||, and
+  // the H recovery divides by the UNSCALED factor -- its pivots carry the norms of the chain --, so a step that shrinks the
+  // vector by a factor f (a shift next to an eigenvalue whose invariant subspace dominates the vector: a tight cluster) puts an
+  // error of eps / f into H.  The pivot test above is relative to each column's own norm and does not see it.  Below
+  // f = 3e-4 (norm^2 ratio 1e-7: errors beyond 1e-12) the block is abandoned like a rank-deficient one; the per-step path meets
+  // the same situation as a near-breakdown and takes the reference's decisions (src/expansion.jl:91-102).
+  bool collapse = false;
+  if (stage == 1) {
+    if (tid == 0) {
+      double prev = 1.0;   // (z_0 is a basis column)
+      bool bad = false;
+      for (int i = 0; i < s; ++i) {
+        const double g = real_of(Gin[gram_idx(i, i)]);
+        if (!(g > 1e-7 * prev)) bad = true;
+        prev = g;
+      }
+      sh_ratio = bad ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    collapse = sh_ratio != 0.0;
+    __syncthreads();
+  }
+  const bool too_far = (stage == 2 && !(gdev <= gdevmax)) || collapse;
   KS_TQ(6);
   const double worst = too_far ? 0.0 : chol_upper_lds(Gm, s, stage == 1 ? pivmin : 0.25, &sh_ratio, dinvs);
   KS_TQ(7);

@@ -36,7 +36,7 @@ int ks_blk_launch_part1(int which, const BlkLaunchArgs& a);   // Float64, block 
 int ks_blk_launch_part2(int which, const BlkLaunchArgs& a);   // ComplexF64, block sizes 1-5
 // The matrix-instruction forms (ks_block_mfma.hpp) take the block size at run time -- a block of s steps runs on the kernel of
 // ceil(s / 4) column tiles, the missing columns are zeros --, so every size up to 4 NT of an instantiated tile count NT exists:
-// Float64 NT = 2 (s <= 8, up to 64 columns), 3 (s <= 12, up to 48), 4 (s <= 16, 25-28 columns), 5 (s <= 20, up to 24); ComplexF64 NT = 2, 3 (s <= 10) up to 32 columns.
+// Float64 NT = 2 (s <= 8, up to 64 columns), 3 (s <= 12, up to 48), 4 (s <= 16, 25-28 columns), 5 (s <= 20, up to 24); ComplexF64 NT = 2 (s <= 8, up to 48 columns), 3 (s <= 10, up to 32).
 // Tile count for (dtype, k, s) if those forms are switched on (KS_BLK_MFMA) for BOTH passes, else 0.
 int ks_blk_mfma_nt_f64(int k, int s);
 int ks_blk_mfma_nt_c64(int k, int s);
@@ -55,7 +55,7 @@ inline int ks_blk_launch(int which, const BlkLaunchArgs& a) {
 // to 32), 20 (up to 24) in register / ring forms; everything else up to 20 (ComplexF64: 10) on the matrix instruction only
 inline bool ks_blk_shape_ok(int dtype, int k, int s) {
   if (k < 1 || s < 1 || k + s > 65) return false;
-  if (dtype != 0) return k <= 32 && (s <= 5 || ks_blk_mfma_nt_c64(k, s) > 0);
+  if (dtype != 0) return (s <= 5 && k <= 32) || ks_blk_mfma_nt_c64(k, s) > 0;   // (33-48 columns: matrix-instruction forms for every size)
   if (s <= 5) return true;
   if ((s == 8 && k <= 48) || (s == 10 && k <= 32) || (s == 20 && k <= 24)) return true;
   return ks_blk_mfma_nt_f64(k, s) > 0;

@@ -57,7 +57,7 @@ template <class T> struct Backend {
   }
   // the Ritz values (all maxdim eigenvalues of the active Hessenberg matrix) of the restart in progress: a backend with an
   // s-step expansion takes the Newton shifts of its next blocks from them
-  virtual void note_ritz(const cplx* lams, int m, double leak = 0.0, double fro = 0.0) { (void)lams; (void)m; (void)leak; (void)fro; }
+  virtual void note_ritz(const cplx* lams, int m, double leak = 0.0, double fro = 0.0, double tol = 0.0) { (void)lams; (void)m; (void)leak; (void)fro; (void)tol; }
 };
 
 struct Params {
@@ -232,7 +232,7 @@ inline History partialschur_driver(Backend<T>& be, const Mat<T>& H, const Mat<T>
     t0 = now_s();
     if (!early_done) restart_host_early(H, Q, maxdim, ordering, active, scratch);
     const RestartResult r = restart_host_late(H, Q, maxdim, mindim, nev, p.tol, active, scratch);
-    be.note_ritz(scratch.lams.data(), maxdim, r.leak, r.fro);
+    be.note_ritz(scratch.lams.data(), maxdim, r.leak, r.fro, p.tol);
     hist.seconds_host += now_s() - t0;
     k = r.k;
 

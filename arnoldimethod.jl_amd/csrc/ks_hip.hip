@@ -1224,7 +1224,7 @@ int ks_restart(ks_workspace* ws, const ks_params* p, int active, int* k_out, int
       const ks::RestartResult r =
           ks::restart_host_step(H, Q, prm.maxdim, prm.mindim, prm.nev, ks::Ordering{prm.which}, prm.tol, active, sc);
       HipBackend<T> be(nullptr, ws);
-      be.note_ritz(sc.lams.data(), prm.maxdim, r.leak, r.fro);
+      be.note_ritz(sc.lams.data(), prm.maxdim, r.leak, r.fro, prm.tol);
       be.rotate_and_move(r.purge, prm.maxdim - r.purge, r.k - r.purge, Q, r.k, prm.maxdim);  // src/run.jl:363-365
       if (k_out) *k_out = r.k;
       if (nlock_out) *nlock_out = r.nlock;
@@ -1265,7 +1265,7 @@ int ks_expand_restart(ks_operator* A, ks_workspace* ws, const ks_params* p, int 
       double t1 = ks::now_s();
       if (!early_done) ks::restart_host_early(H, Q, prm.maxdim, ordering, active, sc);
       const ks::RestartResult r = ks::restart_host_late(H, Q, prm.maxdim, prm.mindim, prm.nev, prm.tol, active, sc);
-      be.note_ritz(sc.lams.data(), prm.maxdim, r.leak, r.fro);
+      be.note_ritz(sc.lams.data(), prm.maxdim, r.leak, r.fro, prm.tol);
       double t2 = ks::now_s();
       be.rotate_and_move(r.purge, prm.maxdim - r.purge, r.k - r.purge, Q, r.k, prm.maxdim);  // src/run.jl:363-365
       double t3 = ks::now_s();

@@ -104,6 +104,23 @@ struct ks_workspace {
   int mindim_hint = 0;                  // mindim of the restart driver in charge (0: unknown -> no speculation)
   void* probe_dev = nullptr;    // device / pinned host scratch of the probe: [sum, rows | coefficients]
   void* probe_host = nullptr;
+  // DRIFT WATCH of block runs (HipBackend::drift_probe_enqueue / drift_probe_collect).  The H recovery of a block expresses
+  // A q_j through the relation of the EARLIER columns (A V_k = V_{k+1} H_k) with O(1) coefficients; where the new directions are
+  // small against the block's components in the old basis and the restart does not damp -- a non-normal operator with hundreds of
+  // eigenvalues within 1e-3 of the wanted end, tests/test_gpu_random_stress.py seed 17 -- an error of that relation GROWS from
+  // cycle to cycle (1e-15 -> 1e-8 in 12 cycles with blocks of 10 or more; stable with blocks of <= 8 and step by step), and
+  // nothing in a block's own diagnostics shows it.  So the relation is measured: the residual of the last kept column of the
+  // factorisation the batch started from, one product + a strided row sample enqueued BEHIND the batch (no synchronisation:
+  // the result rides back with H), every cycle for the first four block cycles and whenever the residual is above 2e-12 ||H||_F
+  // or growing, every second cycle otherwise; above max(1e-10, 30 tol) ||H||_F the blocks go off for the run
+  // (ks_workspace_relation_info).
+  void* probe_col = nullptr;    // device: one column (the product of the watch)
+  void* watch_acc = nullptr;    // device: [sum, rows, ticket] of k_relation_watch
+  void* probe_host_dev = nullptr;   // device address of probe_host
+  int rp_every = 1, rp_count = 0, rp_done = 0;
+  bool rp_inflight = false;
+  double rp_fro = 0.0, rp_last = 0.0, rp_seq = 0.0;
+  double watch_tol = 0.0;       // convergence tolerance of the driver that ran the last restart (note_ritz), 0: not known
   std::vector<char> Hshadow;
   size_t off_T = 0, off_g = 0, ctl_bytes = 0;
   int ldt = 0;
@@ -195,6 +212,8 @@ struct ks_workspace {
     (void)hipFree(Hscratch); (void)hipFree(partial); (void)hipFree(partial_s); (void)hipFree(partial2); (void)hipFree(coef); (void)hipFree(red);
     (void)hipFree(scal); (void)hipHostFree(scal_h); (void)hipHostFree(coef_h);
     if (zscratch) (void)hipFree(zscratch);
+    if (probe_col) (void)hipFree(probe_col);
+    if (watch_acc) (void)hipFree(watch_acc);
     if (probe_dev) (void)hipFree(probe_dev);
     if (probe_host) (void)hipHostFree(probe_host);
     (void)hipFree(Qd); (void)hipHostFree(Qstage); (void)hipFree(tmp); (void)hipFree(tmp2); (void)hipFree(oop);

@@ -235,7 +235,7 @@ int ks_workspace_set_passes(ks_workspace* ws, int passes, double max_ratio);
  * Like the implicit second pass it needs the library's provenance of the factorisation; otherwise, and for host-callback
  * operators and maxdim > 64 the expansion runs step by step.  Default s = 20 (KS_SSTEP at creation; blocks of up to 20 on
  * up to 24 existing columns, up to 16 on up to 28, up to 12 on up to 48, up to 8 on up to 64; ComplexF64: up to 10 on up to 32 columns,
- * 1-5 beyond); s = 0 / 1: off --
+ * up to 8 on up to 48, single steps beyond); s = 0 / 1: off --
  * every step then takes the reference's DGKS decisions.  A block is also abandoned when the Gram matrix of what its first
  * stage wrote differs from I by more than
  * gram_dev_max in any entry (~ eps cond^2 of the Newton basis; the recovered H carries errors ~ eps cond): default 1e-8
@@ -251,7 +251,8 @@ int ks_workspace_sstep_info(const ks_workspace* ws, int* s, int* blocks, int* ab
 /* How iterate_arnoldi!(A, arnoldi, from:to) (src/expansion.jl:116-133) is cut into blocks: `count` steps on top of k0 existing
  * columns with block sizes <= smax, for dtype KS_F64 / KS_C64 -- the sizes the library itself would use (they depend on which
  * kernel forms KS_BLK_MFMA left on), for byte accounting in benchmarks.  Writes at most cap sizes to out and returns how many
- * blocks there are in *nblocks (0: the range cannot run in blocks). */
+ * blocks there are in *nblocks (0: the range cannot run in blocks).  The sizes may cover only a PREFIX of the range: where the
+ * kernels stop (ComplexF64 beyond 48 columns) the remaining steps run one at a time. */
 int ks_sstep_partition(int dtype, int k0, int count, int smax, int* out, int cap, int* nblocks);
 /* Restarts of the library's drivers (ks_partialschur, ks_expand_restart, ks_restart) whose selection cut through a 2 x 2 block
  * of the real Schur form: the members of a complex pair are not neighbours in the target's order (imaginary-part targets on a

@@ -254,6 +254,14 @@ def expand_block2(A, st, frm, to, shifts, s_max, stats, pivot_min=1e-6, scale=No
         # ---- pass 1 ----
         both = inner(np.hstack([S[:, :k], Z]), Z)      # ONE reduction: S^H Z and Z^H Z
         Praw, GZ = both[:k], both[k:]
+        # a COLLAPSING chain: a step that shrinks the vector by a factor f puts an error of eps / f into the recovered H (the
+        # recovery divides by the unscaled factor, whose pivots carry the chain's norms); the pivot test of chol_upper is relative
+        # to each column's own norm and does not see it.  Below f = 3e-4 the block is abandoned (k_fin_blk stage 1)
+        prev_n2 = 1.0
+        for g_ in np.real(np.diag(GZ)):
+            if not g_ > 1e-7 * prev_n2:
+                raise BlockBail(j, f"Newton chain collapsed: norm^2 {g_:.1e} after {prev_n2:.1e} (k = {k})")
+            prev_n2 = g_
         P = T[:k, :k].conj().T @ Praw
         R1, piv1 = chol_upper(GZ - P.conj().T @ P, pivot_min, k, j)
         R1inv = tri_inv(R1)

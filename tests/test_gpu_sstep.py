@@ -143,6 +143,26 @@ def test_wide_bases_in_blocks(mindim, maxdim):
     assert seen >= 1
 
 
+@pytest.mark.parametrize("mindim,maxdim", [(24, 48), (30, 60)])
+def test_wide_complex_bases_in_blocks(mindim, maxdim):
+    """ComplexF64 on wide bases: blocks of up to 10 up to 32 columns, of up to 8 up to 48 (k_*_mfma<9..12, 2, CX>); beyond 48 columns
+    the partition ENDS and the remaining steps of the range run one at a time (24/48: 10 + 8 + 6; 30/60: 10 + 8, then 12 single
+    steps -- before, such a range ran entirely step by step).  Lockstep against the per-step path."""
+    A = (laplace3d(20, 21, 22) + 1j * sp.diags(0.3 * np.cos(np.arange(9240)))).tocsr().astype(np.complex128)
+    part = pkg.sstep_partition(np.complex128, mindim + 1, maxdim - mindim, 20)
+    assert part == ([10, 8, 6] if maxdim == 48 else [10, 8]), part
+    seen = 0
+    for cyc, Hs, Hb, Vs, Vb, rel, orth, info in _lockstep(A, np.complex128, 10, 12, mindim, maxdim, "LM", 3):
+        if cyc == 0:
+            continue
+        assert info["blocks"] >= 2 * cyc and info["abandoned"] == 0 and info["s"] == 10, info
+        assert np.abs(Hs - Hb).max() <= 1e-11 * np.abs(Hs).max(), (cyc, np.abs(Hs - Hb).max())
+        assert np.abs(Vs - Vb).max() <= 1e-9, (cyc, np.abs(Vs - Vb).max())
+        assert rel <= 1e-12 * np.linalg.norm(Hb) * 10 and orth <= 1e-13
+        seen += 1
+    assert seen >= 1
+
+
 @pytest.mark.parametrize("s", [2, 5])
 def test_blocks_reproduce_the_per_step_expansion_complex_and_nonsymmetric(s):
     for A, dtype, which in ((_complex_op(), np.complex128, "LM"), (_nonsym(), np.float64, "LM")):
