@@ -260,7 +260,12 @@ int ks_sstep_partition(int dtype, int k0, int count, int smax, int* out, int cap
  * block's sub-diagonal entry and the Arnoldi relation of the kept columns is off by that much from there on -- in the reference
  * as well.  The per-step expansion is indifferent to it; the s-step expansion (which leans on the relation of the earlier
  * columns) is switched off for the rest of the run when the dropped entry exceeds 1e-12 ||H||_F.  *breaks = such restarts
- * since creation, *worst_leak = largest dropped entry / ||H||_F. */
+ * since creation, *worst_leak = largest dropped entry / ||H||_F.
+ * Counted here as well: a relation that DRIFTS under the block expansion (a non-normal operator with a large cluster at the
+ * wanted end: each block expresses A q_j through the relation of the earlier columns, and there an error of it grows from cycle
+ * to cycle).  Block runs of the library's drivers measure the relation of the last kept column every first or second restart
+ * cycle (one operator product + a row sample behind the speculative chain; ks_workspace_relation_probes counts them); above
+ * max(1e-10, 30 tol) ||H||_F the blocks go off for the rest of the run. */
 int ks_workspace_relation_info(const ks_workspace* ws, int* breaks, double* worst_leak);
 /* A caller that runs the restart itself (the reference's _partialschur on a device basis, src/run.jl:298-365) and then vouches
  * for the result (ks_workspace_assert_arnoldi) is not seen by the guard above.  For such a factorisation the library MEASURES

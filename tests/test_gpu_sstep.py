@@ -322,6 +322,37 @@ def test_breakdown_inside_a_block_goes_back_to_single_steps():
     assert rel <= 1e-12 * max(1.0, np.linalg.norm(H)) * 10 + 10 * 1e-10 and orth <= 1e-12, (rel, orth, rel0, orth0, ws2.sstep_info)
 
 
+def test_drift_watch_switches_the_blocks_off_on_a_nonnormal_cluster():
+    """Seed 17 of tests/test_gpu_random_stress.py: diag(690 values within 1e-9 of 1 | 2..9) + 1e-3 x sparse random (nonsymmetric),
+    :SR, 13/58.  With blocks of 10 or more the Arnoldi relation drifts by a factor ~20 per restart cycle (each block expresses
+    A q_j through the relation of the earlier columns; 1e-15 -> 1e-8 in 12 cycles -- blocks of <= 8 and the per-step path stay at
+    1e-15) until a Ritz pair is 'converged' with a true residual of 1e-5 ||A||; nothing in a single block's diagnostics shows it.
+    The library MEASURES the relation of the last kept column behind every first or second block cycle (drift watch) and
+    switches the blocks off: asserted here -- it fired, the run continued step by step, and whatever converged is a Schur pair
+    to the solver's tolerance.  On a healthy problem (config 2's parameters in miniature) the watch runs and stays silent."""
+    from test_gpu_random_stress import _case
+
+    A, v1, kw, kind = _case(17)
+    assert kind == "cluster" and kw["maxdim"] == 58
+    for s in (20, 10):
+        ws = pkg.ArnoldiWorkspace(A.shape[0], kw["maxdim"], A.dtype)
+        ws.set_sstep(s)
+        ws._v1 = v1
+        dec, h = pkg.partialschur_(pkg.csr_operator(A), ws, **kw)
+        rel, info = ws.relation_info, ws.sstep_info
+        assert rel["breaks"] >= 1 and rel["probes"] >= 4 and info["s"] == 0 and info["blocks"] > 0, (rel, info)
+        assert 1e-10 < rel["worst_leak"] < 1e-5, rel      # caught between the limit (max(1e-10, 30 tol) = 3e-8) and twenty times that
+        if h.nconverged:
+            Q, R = np.array(dec.Q), np.array(dec.R)
+            assert np.linalg.norm(A @ Q - Q @ R) <= 1e-8 * sp.linalg.norm(A) * h.nconverged, (h, rel)
+    build, dtype, kw2 = CASES["config2-parameters"]
+    A2 = build()
+    ws = pkg.ArnoldiWorkspace(A2.shape[0], kw2["maxdim"], dtype)
+    ws._v1 = _start(dtype, A2.shape[0])
+    F, hist = pkg.partialschur_(pkg.csr_operator(A2), ws, restarts=300, **kw2)
+    assert hist.converged and ws.relation_info["breaks"] == 0 and ws.relation_info["probes"] >= 4, ws.relation_info
+
+
 def test_ill_conditioned_newton_basis_is_abandoned_and_the_block_size_lowered():
     """test/partial_schur.jl:122-138's operator (dense random 100 x 100: one eigenvalue at 50, the rest in a complex disc of
     radius ~3).  With REAL shifts a block of 5 has cond ~1e7 (tests/test_sstep_model.py measures it): the written block's Gram
