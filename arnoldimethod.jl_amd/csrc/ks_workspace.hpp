@@ -843,6 +843,7 @@ template <class D> bool reinit_column(ks_workspace* ws, int j, const void* v1_ho
     ws->hfull_valid = false;
     ws->sstep_eff = ws->sstep;
     ws->blk_clean = 0;
+    ws->rp_inflight = false; ws->rp_every = 1; ws->rp_count = 0; ws->rp_done = 0; ws->rp_last = 0.0; ws->watch_tol = 0.0;   // (the drift watch starts afresh too)
     col_scale<D>(ws, j, 1.0 / rnorm);
     return true;
   }
