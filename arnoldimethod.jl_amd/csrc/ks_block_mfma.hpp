@@ -243,7 +243,9 @@ __global__ void __launch_bounds__(512, 2)
   // tiles in LDS for 16-byte stores was measured and is not faster (1 005 against 995 us at k = 21, s = 20), neither are
   // cacheable stores (1 050) nor writing out of place (1 000-1 030): tools/rw_streams.hip shows the memory system itself
   // at 960 us for this mix of 41 column streams in and 20 out IN PLACE, whatever the kernel does in between.
-  const int nst = (dbg & 1) ? 0 : NT;
+  // (exactly the tiles that have a column < s: a tile whose lanes are all predicated off issues NO store and would let the wait
+  // below count one copy too few -- s = 13..16 on the 5-tile kernels, ComplexF64 s <= 4 on the 2-tile ones)
+  const int nst = (dbg & 1) ? 0 : (s + 3) / 4;
   auto issue = [&](int it, int sl) {
     blkm_issue<NGS, NT>(V, ldv, k, Zb, ldz, s, pb + (int64_t)it * 64 + wave * 8, pe, lane, ring_lds + (uint32_t)(sl * C::SLAB), zeros, nt);
   };
@@ -294,7 +296,9 @@ __global__ void __launch_bounds__(512, 2)
       double* dst = zst + pack0 * 2;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (ok && 4 * t + cj < s) gst8_nt(dst + (int64_t)(4 * t) * ldv, d[t]);
+        if (4 * t < s) {   // wave-uniform: tile t issues a store (lane cj = 0 of a row in range is active) or none at all
+          if (ok && 4 * t + cj < s) gst8_nt(dst + (int64_t)(4 * t) * ldv, d[t]);
+        }
       }
     }
     double a[NGS], dp[CX ? NT : 1];

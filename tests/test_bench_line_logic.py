@@ -118,3 +118,27 @@ def test_block_cycles_report_no_dgks_passes_and_the_spread_of_the_timed_cycles()
     p0 = _pass(0.3)
     out0 = bench.make_line(ARGS, None, {"single": p0}, ["single"], 1, 0, False, WL, False)
     assert out0["config"]["dgks_second_passes"] == 200 and out0["config"]["steps_in_blocks_with_second_stage"] is None
+
+
+def test_traffic_fractions_book_speculative_products_to_the_interval_they_ran_in():
+    """Round 5's line divided every byte of a cycle by the expansion interval although 10 of its 20 products had run during the
+    previous restart interval (0.652 against a true 0.545).  The quoted figure is bytes over the WHOLE cycle time; the
+    expansion-interval figure takes the speculative bytes out of its numerator."""
+    n = 216 ** 3
+    spmv_b = 17.0 * n
+    moved = 20 * (20 * spmv_b + 6.611e9 + 4.918e9)          # 20 block cycles of the headline
+    spec_bytes = 20 * bench.spec_chain_products(20) * spmv_b  # 10 products per cycle ran speculatively
+    assert bench.spec_chain_products(20) == 10 and bench.spec_chain_products(5) == 4 and bench.spec_chain_products(1) == 0
+    tf = bench.traffic_fractions(moved, spec_bytes, 20 * 2.869e-3, 20 * 0.558e-3, 1, 8000.0)
+    assert abs(tf["cycle_frac"] - moved / (20 * 3.427e-3) / 1e9 / 8000.0) < 1e-12
+    assert 0.53 < tf["cycle_frac"] < 0.56                                   # the reviewer's recomputation: 0.545
+    assert abs(tf["expand_frac"] - (moved - spec_bytes) / (20 * 2.869e-3) / 1e9 / 8000.0) < 1e-12
+    assert 0.56 < tf["expand_frac"] < 0.59 and tf["expand_frac"] < moved / (20 * 2.869e-3) / 1e9 / 8000.0   # 0.577, not 0.652
+    # the line: a state with adopted chains
+    p = _pass(0.3)
+    p["state"].update(spec_products=100, spec_bytes=100 * spmv_b)
+    fs = bench.make_line(ARGS, None, {"single": p}, ["single"], 1, 0, False, WL, False)["roofline"]["fused_step"]
+    st = p["state"]
+    assert fs["moved_frac"] == fs["cycle_frac"] == st["moved"] / (st["t_expand"] + st["t_restart"]) / 1e9 / 8000.0
+    assert fs["expand_interval_frac"] == (st["moved"] - 100 * spmv_b) / st["t_expand"] / 1e9 / 8000.0
+    assert fs["spec_products"] == 100 and "WHOLE cycle time" in fs["what"]

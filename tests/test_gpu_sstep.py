@@ -163,6 +163,30 @@ def test_wide_complex_bases_in_blocks(mindim, maxdim):
     assert seen >= 1
 
 
+@pytest.mark.parametrize("dtype,mindim,maxdim", [(np.float64, 20, 36), (np.float64, 22, 35), (np.float64, 20, 34), (np.complex128, 40, 44), (np.complex128, 35, 45)])
+def test_blocks_whose_last_tile_is_empty(dtype, mindim, maxdim):
+    """k_bupdate_mfma counts its own stores in the waits of its copy ring: a 4-column tile with no column below s issues none
+    (Float64 13-16 steps on <= 24 columns run on the 5-tile kernels with tile 4 empty, ComplexF64 <= 4 steps on 33-48 columns on
+    the 2-tile kernels with tile 1 empty) and the count must say so, or a ring slot is read before its copy has landed
+    (ks_block_mfma.hpp, `nst`).  Six cycles in lockstep with the per-step path on each shape."""
+    cx = np.dtype(dtype).kind == "c"
+    A = laplace3d(20, 21, 22)
+    if cx:
+        A = (A + 1j * sp.diags(0.3 * np.cos(np.arange(9240)))).tocsr().astype(np.complex128)
+    part = pkg.sstep_partition(dtype, mindim + 1, maxdim - mindim, 20)
+    assert any((b % 4 in (1, 2, 3) or b <= 4) for b in part), part
+    seen = 0
+    for cyc, Hs, Hb, Vs, Vb, rel, orth, info in _lockstep(A, dtype, 20, 12, mindim, maxdim, "LM" if cx else "SR", 6):
+        if cyc == 0:
+            continue
+        assert info["blocks"] > 0 and info["abandoned"] == 0, info
+        assert np.abs(Hs - Hb).max() <= 1e-11 * np.abs(Hs).max(), (cyc, np.abs(Hs - Hb).max())
+        assert np.abs(Vs - Vb).max() <= 1e-9, (cyc, np.abs(Vs - Vb).max())
+        assert rel <= 1e-12 * np.linalg.norm(Hb) * 10 and orth <= 1e-13
+        seen += 1
+    assert seen >= 1
+
+
 @pytest.mark.parametrize("s", [2, 5])
 def test_blocks_reproduce_the_per_step_expansion_complex_and_nonsymmetric(s):
     for A, dtype, which in ((_complex_op(), np.complex128, "LM"), (_nonsym(), np.float64, "LM")):

@@ -109,7 +109,6 @@ def main():
         t2 = time.perf_counter()
         if timed:
             state["steps"] += maxdim - k
-            state["reorth"] += st["reorth"]
             info = ws.sstep_info
             blk = ks.sstep_partition(dtype, k + 1, maxdim - k, info["s"]) if (args.sstep >= 2 and info["s"] >= 2) else []
             if blk and info["blocks"] - state.get("blocks_seen", 0) != len(blk):
@@ -117,6 +116,8 @@ def main():
             state["blocks_seen"] = info["blocks"]
             state["abandoned"] = info["abandoned"]
             state["blk_cycles"] = state.get("blk_cycles", 0) + (1 if blk else 0)
+            if not blk:
+                state["reorth"] += st["reorth"]            # (DGKS second passes exist on per-step cycles only)
             if blk:  # per block of s steps on kk columns: s products (+ 3 esz n for the shift unless fused) + two passes
                 shift_b = 0.0 if fmt["layout"] == "stencil" else 3.0 * esz * n
                 kk = k + 1
@@ -160,7 +161,9 @@ def main():
         if v["count"]:
             gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 and v["bytes"] > 0 else None
             per[k_] = {"launches": v["count"], "avg_us": 1e3 * v["ms"] / v["count"], "GBps": gbs, "frac": gbs / PEAK if gbs else None}
-    moved = state["moved"] / max(state["t_expand"], 1e-12) / 1e9
+    # bytes over the WHOLE cycle time: speculative products of the next expansion run during the restart interval (bench.py,
+    # traffic_fractions), so the expansion interval alone is not what the bytes of a cycle were moved in
+    moved = state["moved"] / max(state["t_expand"] + state["t_restart"], 1e-12) / 1e9
     out = {
         "config": args.config, "workload": f"{what}, nev={nev}, which={which}, mindim={mindim}, maxdim={maxdim}, dtype={'c128' if esz == 16 else 'f64'}",
         "iters_per_s": state["steps"] / elapsed, "ms_per_cycle": 1e3 * elapsed / args.steps, "iterations": state["steps"],

@@ -1,0 +1,148 @@
+// k_spmv_stencil_slab (csrc/ks_spmv_slab.hpp) against the library's k_spmv_stencil2 on an m x my x mz 7-point Laplacian:
+// time with the caches flushed between launches (plain / shifted / shifted with cacheable stores), time of a chain of 20
+// products, and bit-identity of the results, for several (waves per workgroup, ring slots, workgroup order, segments) shapes.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/spmv_slab.hip -o tools/_build/spmv_slab
+//   tools/_build/spmv_slab [m [my [mz]]]                all variants
+//   tools/_build/spmv_slab m my mz only V reps           only variant V (0 = k_spmv_stencil2), `reps` launches (for rocprofv3 --pmc)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../arnoldimethod.jl_amd/csrc/ks_spmv_slab.hpp"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+using namespace ksd;
+
+__global__ void k_flush(const double* __restrict__ a, double* __restrict__ out, long n) {
+  double s = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += __builtin_nontemporal_load(a + i);
+  if (s == 1.2345) out[0] = s;
+}
+
+struct Problem {
+  long n, P; int nz; uint16_t* dm; long nmask; StencilDict<double> d; double* xs;
+};
+static int g_allodd = 0;
+struct Variant { const char* name; int nw, ns, order, wg_per_cu; };
+
+template <int NW, int NS>
+void launch_slab(const Problem& pr, const double* x, double* y, int order, int wgs, int shifted, int nseg_override) {
+  using G = SlabGeom<NW, NS>;
+  static int attr = 0;
+  const unsigned odd = slab_odd_mask(pr.d.delta, 7, pr.P);
+  auto kern = odd == 0x14u ? &k_spmv_stencil_slab<NW, NS, 0x14u> : (odd == 0x36u ? &k_spmv_stencil_slab<NW, NS, 0x36u> : &k_spmv_stencil_slab<NW, NS, 0xffu>);
+  if (g_allodd) kern = &k_spmv_stencil_slab<NW, NS, 0xffu>;
+  if (attr < 8) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); ++attr; }
+  const int nslab = (pr.nz + NW - 1) / NW;
+  int nseg = nseg_override > 0 ? nseg_override : (wgs / nslab > 0 ? wgs / nslab : 1);
+  long sl = (pr.P + nseg - 1) / nseg;
+  sl = (sl + 3) & ~3L;
+  nseg = (int)((pr.P + sl - 1) / sl);
+  kern<<<nslab * nseg, NW * 64, G::lds_bytes>>>(pr.dm, pr.nmask, pr.d, 7, x, pr.n, y, pr.n, pr.P, pr.nz, (int)sl, nseg, nslab, order, nullptr, shifted, 0.37, 0.125);
+}
+
+static int g_nseg = 0;
+void launch(int var, const Problem& pr, const double* x, double* y, int shifted) {
+  const int nt = (int)((pr.n + 511) / 512);
+  switch (var) {
+    case 0: k_spmv_stencil2<double, uint16_t><<<nt, 256>>>(pr.dm, pr.d, 7, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
+    case 1: launch_slab<8, 7>(pr, x, y, 0, 256, shifted, g_nseg); break;
+    case 2: launch_slab<8, 7>(pr, x, y, 1, 256, shifted, g_nseg); break;
+    case 3: launch_slab<8, 6>(pr, x, y, 0, 256, shifted, g_nseg); break;
+    case 4: launch_slab<8, 5>(pr, x, y, 0, 256, shifted, g_nseg); break;
+    case 5: launch_slab<8, 4>(pr, x, y, 0, 256, shifted, g_nseg); break;
+    case 6: launch_slab<12, 5>(pr, x, y, 0, 256, shifted, g_nseg); break;
+    case 7: launch_slab<16, 4>(pr, x, y, 0, 256, shifted, g_nseg); break;
+    case 8: launch_slab<4, 6>(pr, x, y, 0, 512, shifted, g_nseg); break;    // 78 KB: two workgroups per CU
+    case 9: launch_slab<6, 7>(pr, x, y, 0, 256, shifted, g_nseg); break;
+    case 10: launch_slab<4, 4>(pr, x, y, 0, 768, shifted, g_nseg); break;   // 52 KB: three workgroups per CU
+    case 11: launch_slab<8, 7>(pr, x, y, 0, 512, shifted, g_nseg); break;   // twice the workgroups (two rounds)
+    default: printf("no variant %d\n", var); exit(1);
+  }
+}
+const char* vname(int var) {
+  static const char* names[] = {"k_spmv_stencil2", "slab<8,7> z-order", "slab<8,7> seg-order", "slab<8,6>", "slab<8,5>", "slab<8,4>", "slab<12,5>",
+                                "slab<16,4>", "slab<4,6> 2/CU", "slab<6,7>", "slab<4,4> 3/CU", "slab<8,7> 512 wgs"};
+  return names[var];
+}
+constexpr int kNVar = 12;
+
+int main(int argc, char** argv) {
+  const int m = argc > 1 ? atoi(argv[1]) : 216;
+  const int my = argc > 2 ? atoi(argv[2]) : m, mz = argc > 3 ? atoi(argv[3]) : m;
+  const long n = (long)m * my * mz;
+  Problem pr{};
+  pr.n = n; pr.P = (long)m * my; pr.nz = mz;
+  const long del[7] = {-(long)m * my, -m, -1, 0, 1, m, (long)m * my};
+  for (int k = 0; k < 7; ++k) { pr.d.delta[k] = (int)del[k]; pr.d.val[k] = k == 3 ? 6.0 : -1.0; }
+  if (slab_far_stride(pr.d.delta, 7, n) != pr.P) { printf("the slab form does not take this grid (P = %ld)\n", pr.P); return 1; }
+  std::vector<uint16_t> mask((n + 1) / 2 + 1, 0);
+  for (long r = 0; r < n; ++r) {
+    const long xx = r % m, yy = (r / m) % my, zz = r / ((long)m * my);
+    unsigned b = 8;
+    if (zz > 0) b |= 1; if (yy > 0) b |= 2; if (xx > 0) b |= 4; if (xx < m - 1) b |= 16; if (yy < my - 1) b |= 32; if (zz < mz - 1) b |= 64;
+    if (r & 1) mask[r >> 1] |= (uint16_t)(b << 8); else mask[r >> 1] = (uint16_t)b;
+  }
+  pr.nmask = (long)mask.size();
+  double *y1, *y2, *big, *out;
+  CK(hipMalloc(&pr.dm, mask.size() * 2)); CK(hipMemcpy(pr.dm, mask.data(), mask.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMalloc(&pr.xs, n * 8)); CK(hipMalloc(&y1, n * 8)); CK(hipMalloc(&y2, n * 8)); CK(hipMalloc(&big, (1L << 28) * 8)); CK(hipMalloc(&out, 64));
+  std::vector<double> h(n), r1(n), r2(n);
+  srand(1);
+  for (auto& v : h) v = rand() / (double)RAND_MAX - 0.5;
+  CK(hipMemcpy(pr.xs, h.data(), n * 8, hipMemcpyHostToDevice));
+  CK(hipMemset(big, 0, (1L << 28) * 8));
+  const double MB = (1.0 * n + 16.0 * n) / 1e6;
+  if (argc > 6 && !strcmp(argv[4], "only")) {
+    const int var = atoi(argv[5]), reps = atoi(argv[6]);
+    if (argc > 7) g_nseg = atoi(argv[7]);
+    for (int i = 0; i < reps; ++i) { k_flush<<<2048, 256>>>(big, out, 1L << 28); launch(var, pr, pr.xs, y1, 1); }
+    CK(hipDeviceSynchronize());
+    printf("%s: %d launches\n", vname(var), reps);
+    return 0;
+  }
+  if (argc > 4) g_nseg = atoi(argv[4]);
+  if (argc > 5) g_allodd = atoi(argv[5]);
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int shifted : {0, 1, 3}) {
+    launch(0, pr, pr.xs, y1, shifted);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(r1.data(), y1, n * 8, hipMemcpyDeviceToHost));
+    for (int var = 0; var < kNVar; ++var) {
+      float best = 1e9f, sum = 0;
+      CK(hipMemset(y2, 0xff, n * 8));
+      for (int rep = 0; rep < 7; ++rep) {
+        k_flush<<<2048, 256>>>(big, out, 1L << 28);
+        CK(hipEventRecord(a));
+        launch(var, pr, pr.xs, y2, shifted);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { printf("%s: %s\n", vname(var), hipGetErrorString(e)); break; }
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        if (rep) { best = ms < best ? ms : best; sum += ms; }
+      }
+      CK(hipMemcpy(r2.data(), y2, n * 8, hipMemcpyDeviceToHost));
+      long bad = 0, first = -1;
+      for (long i = 0; i < n; ++i) if (memcmp(&r1[i], &r2[i], 8)) { if (first < 0) first = i; ++bad; }
+      printf("%d x %d x %d shifted=%d  %-22s best %.1f us (%.0f GB/s)  mean %.1f us   %s", m, my, mz, shifted, vname(var), best * 1e3, MB / best, sum / 6 * 1e3,
+             bad ? "DIFFER" : "bit-identical");
+      if (bad) printf(" (%ld rows, first %ld = plane %ld offset %ld)", bad, first, first / pr.P, first % pr.P);
+      printf("\n");
+      fflush(stdout);
+    }
+  }
+  // back to back (a chain: the product of one launch is the input of the next, cacheable stores), 20 launches
+  for (int var = 0; var < kNVar; ++var) {
+    k_flush<<<2048, 256>>>(big, out, 1L << 28);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < 20; ++i) {
+      const double* src = i == 0 ? pr.xs : (i & 1 ? y1 : y2);
+      double* dst = (i & 1) ? y2 : y1;
+      launch(var, pr, src, dst, 3);
+    }
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    printf("chain of 20 (%s): %.1f us per product\n", vname(var), ms * 1e3 / 20);
+  }
+  return 0;
+}
