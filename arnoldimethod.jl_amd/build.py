@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SRC = os.path.join(CSRC, "ks_hip.hip")
 BLK = os.path.join(CSRC, "ks_block_inst.hip")
-HEADERS = [os.path.join(CSRC, f) for f in ("ks_kernels.hpp", "ks_p2p.hpp", "ks_driver.hpp", "ks_smalldense.hpp", "ks_context.hpp", "ks_operators.hpp", "ks_sptrsv.hpp",
+HEADERS = [os.path.join(CSRC, f) for f in ("ks_kernels.hpp", "ks_spmv_march.hpp", "ks_p2p.hpp", "ks_driver.hpp", "ks_smalldense.hpp", "ks_context.hpp", "ks_operators.hpp", "ks_sptrsv.hpp",
                                            "ks_workspace.hpp", "ks_backend.hpp", "ks_block.hpp", "ks_block_kernels.hpp", "ks_block_launch.hpp", "ks_block_mfma.hpp")]
 DEPS = [SRC, BLK] + HEADERS + [os.path.join(HERE, "..", "include", "kschur.h")]
 OUT = os.path.join(HERE, "libkschur_hip.so")

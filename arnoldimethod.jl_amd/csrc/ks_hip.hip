@@ -26,6 +26,7 @@
 #include "../../include/kschur.h"
 #include "ks_driver.hpp"
 #include "ks_kernels.hpp"
+#include "ks_spmv_march.hpp"   // persistent form of the paired stencil SpMV
 #include "ks_block_kernels.hpp"  // kernels of the s-step (block) expansion (the streaming ones are instantiated in ks_block_inst.hip)
 #include "ks_block_launch.hpp"
 

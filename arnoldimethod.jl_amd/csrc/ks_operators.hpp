@@ -144,6 +144,58 @@ template <class D> struct CsrOp : ks_operator {
     static const int env = env_int("KS_SHIFT_PLAIN", -1);
     return env >= 0 ? env != 0 : shift_store_cacheable;
   }
+  // ---- marching form of the paired stencil kernel (ks_spmv_march.hpp; Float64, one GPU, at most 8 slots) ----
+  static bool march_on() {
+    static const int env = env_int("KS_STENCIL_MARCH", 1);
+    return env != 0;
+  }
+  // Workgroups per XCD (= tiles of 512 rows an XCD takes per round).  With a far stride P (the xy-plane of a 3-D grid) the
+  // kernel is fastest when ONE ROUND COVERS ONE PLANE: the z + 1 taps of a round are then the rows the next round owns, the only
+  // first-touch stream of a round is one band of x, and every other load finds its line in the XCD's L2 one or two rounds old --
+  // measured on 216^3 (tools/spmv_slab.hip sweep, profiles/r06_spmv_march.txt): 34.0 us at 92 against 40.8 at 100, 44.9 at 128,
+  // 41.9 at 60.  Without a far stride (or when a plane is more than the device holds at once): 96 per XCD (3 per CU).
+  int march_slots(int ntiles) const {
+    static const int env = env_int("KS_MARCH_S", 0);
+    int S = 96;
+    if (env > 0) S = env;
+    else {
+      int64_t P = 0;
+      for (int k = 0; k < nstencil; ++k) P = std::max<int64_t>(P, std::llabs((long long)sdict.delta[k]));
+      int64_t per = P / 512 + 1;            // tiles of one far stride, rounded up
+      while (per > 224) per = (per + 1) / 2;  // (7 workgroups per CU fit: keep every workgroup of a round resident)
+      if (per >= 48) S = (int)per;
+    }
+    S = std::min(S, std::max(1, (ntiles + 7) / 8));
+    return S;
+  }
+  void launch_march(const D* x, D* y, int nt, const DevState* st, hipStream_t s) const {
+    if constexpr (std::is_same<D, double>::value) {
+      const int sh = shift_on ? (1 | (shift_plain() ? 2 : 0)) : 0;
+      const uint16_t* m2 = static_cast<const uint16_t*>(smask2);
+      const int G = 8 * march_slots(nt);
+      int kown = -1;
+      for (int k = 0; k < nstencil; ++k)
+        if (sdict.delta[k] == 0) kown = k;
+      auto go = [&](auto ns_tag, auto ko_tag) {
+        ksd::k_spmv_stencil_march<decltype(ns_tag)::value, decltype(ko_tag)::value><<<G, kBlock, 0, s>>>(m2, sdict, x, y, n_local, nt, st, sh, shift_theta, shift_sigma);
+      };
+      using M1 = std::integral_constant<int, -1>;
+      // the slot of the rows' own entry is a compile-time constant for the common stencils (3-, 5-, 7-point); otherwise one more load
+      if (nstencil == 7 && kown == 3) go(std::integral_constant<int, 7>{}, std::integral_constant<int, 3>{});
+      else if (nstencil == 5 && kown == 2) go(std::integral_constant<int, 5>{}, std::integral_constant<int, 2>{});
+      else if (nstencil == 3 && kown == 1) go(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
+      else switch (nstencil) {
+        case 1: go(std::integral_constant<int, 1>{}, M1{}); break;
+        case 2: go(std::integral_constant<int, 2>{}, M1{}); break;
+        case 3: go(std::integral_constant<int, 3>{}, M1{}); break;
+        case 4: go(std::integral_constant<int, 4>{}, M1{}); break;
+        case 5: go(std::integral_constant<int, 5>{}, M1{}); break;
+        case 6: go(std::integral_constant<int, 6>{}, M1{}); break;
+        case 7: go(std::integral_constant<int, 7>{}, M1{}); break;
+        default: go(std::integral_constant<int, 8>{}, M1{}); break;
+      }
+    }
+  }
   ksd::ShiftArg<D> shift_arg() const {
     ksd::ShiftArg<D> a;
     a.on = shift_on ? 1 : 0;
@@ -286,6 +338,14 @@ template <class D> struct CsrOp : ks_operator {
       if (nstencil > 0 && nghost == 0 && smask2 && n_local >= 2 && env_int("KS_STENCIL_PAIRS", 1)) {
         // two rows per lane, 16-byte gathers (no ghost columns: single GPU)
         const int nt = (int)(((n_local + 1) / 2 + kBlock - 1) / kBlock);
+        if constexpr (std::is_same<D, double>::value) {
+          // Float64, at most 8 slots: the persistent software-pipelined form (ks_spmv_march.hpp)
+          if (stencil_mask_bytes == 1 && nstencil <= 8 && march_on()) {
+            launch_march(x, y, nt, st, s);
+            KS_HIP(hipGetLastError());
+            return;
+          }
+        }
         if (stencil_mask_bytes == 1)
           ksd::k_spmv_stencil2<D, uint16_t><<<nt, kBlock, 0, s>>>(static_cast<const uint16_t*>(smask2), sdict, nstencil, x, y, n_local, nt, st, shift_on ? (1 | (shift_plain() ? 2 : 0)) : 0, shift_theta, shift_sigma);
         else

@@ -1,0 +1,209 @@
+// SpMV, stencil-mask layout, MARCHING form (gfx950):  y = A x  or the Newton step  y = sigma (A x - theta x)  of mul!(y, A, x),
+// src/expansion.jl:121 -- the paired kernel k_spmv_stencil2 (ks_kernels.hpp) turned into a persistent, software-pipelined loop
+// with a lean instruction stream.
+//
+// What the counters say about k_spmv_stencil2 (profiles/r06_spmv_probe.txt): 22.2 M vector instructions per launch (282 per wave
+// of 128 rows: 64-bit clamped addresses and "which half of the clamped pair" selects for every slot) keep the vector ALUs busy
+// for about half of its 44 us, and a wave lives for one load round trip + its arithmetic + one store round trip (s_endpgm
+// waits for the stores), so what a CU holds in flight is bounded by 32 waves x 128 rows.  Here
+//   * a workgroup walks tiles t, t + G, t + 2 G, ... (G workgroups; per XCD a contiguous range of tiles, so the rows in flight
+//     on one XCD are a band that sweeps through its planes and the z - 1 / z + 1 taps hit the same L2);
+//   * the loads of the NEXT tile (NS pairs + the rows' own pair + the masks) are issued before the arithmetic of the current
+//     one: two tiles per wave in flight, stores never waited for;
+//   * interior tiles (every slot of every row inside [0, n)) need no clamping at all: the address of slot k is a SCALAR base
+//     (x + 512 t + delta_k) plus the lane's constant byte offset, the loaded pair IS the wanted pair; the few tiles next to the
+//     ends of the vector take the clamped path of k_spmv_stencil2;
+//   * products are masked with and-masks from v_bfe_i32 (+0.0 for an absent slot: s + 0.0 == s bit for bit, s is never -0.0)
+//     instead of compare + two selects.
+// Products rounded separately, added in slot order: y is bit-identical to every other layout.
+#pragma once
+
+#include <type_traits>
+
+#include "ks_kernels.hpp"
+
+namespace ksd {
+
+typedef double f64x2m __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double and_mask(double p, int bm) {
+  const uint64_t u = __builtin_bit_cast(uint64_t, p);
+  const uint32_t lo = (uint32_t)u & (uint32_t)bm, hi = (uint32_t)(u >> 32) & (uint32_t)bm;
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
+// tile of workgroup slot `slot` (0 .. S - 1) of XCD `xcd` in round `it`: XCD j owns tiles [T_j, T_{j+1})
+__device__ __forceinline__ int march_tile(int xcd, int slot, int it, int S, int ntiles, int& tend) {
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int t0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  tend = t0 + (xcd < r ? q + 1 : q);
+  return t0 + slot + it * S;
+}
+
+// loads and stores of the loop: scalar base + the lane's constant byte offset, issued from inline assembly and counted by hand
+__device__ __forceinline__ void march_ld16(f64x2m& dst, uint32_t voff, const void* sbase) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void march_ld_u16(uint32_t& dst, uint32_t voff, const void* sbase) {
+  asm volatile("global_load_ushort %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void march_st16(uint32_t voff, f64x2m v, void* sbase, bool plain) {
+  if (plain) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+
+// KOWN: the slot with delta 0 (its pair is the rows' own pair of the Newton step), -1: none -- the own pair is one more load
+template <int NSLOT, int KOWN>
+__global__ void __launch_bounds__(kBlock)
+    k_spmv_stencil_march(const uint16_t* __restrict__ mask2, const StencilDict<double> d, const double* __restrict__ x,
+                         double* __restrict__ y, int64_t n, int ntiles, const DevState* __restrict__ st, int shifted, double theta,
+                         double sigma) {
+  if (st && st->breakdown >= 0) return;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, S = gridDim.x >> 3;   // (the host launches a multiple of 8 workgroups)
+  int64_t dmin = 0, dmax = 0;
+#pragma unroll
+  for (int k = 0; k < NSLOT; ++k) {
+    dmin = d.delta[k] < dmin ? d.delta[k] : dmin;
+    dmax = d.delta[k] > dmax ? d.delta[k] : dmax;
+  }
+  const uint32_t lane_b = threadIdx.x * 16u, lane_m = threadIdx.x * 2u;   // byte offsets of this lane's pair / mask inside a tile
+  const bool plain_st = (shifted & 2) != 0;
+  int tend;
+  int t = march_tile(xcd, slot, 0, S, ntiles, tend);
+  constexpr int NL = NSLOT + (KOWN < 0 ? 1 : 0) + 1;   // loads of a tile
+
+  struct Tile {
+    f64x2m v[NSLOT], own;
+    uint32_t m;
+  };
+  auto issue = [&](int tt, Tile& T) {
+    const int64_t r0 = (int64_t)tt * 512;
+    const double* b[NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+      b[k] = x + (r0 + d.delta[k]);
+      asm volatile("" : "+s"(b[k]));
+    }
+    const double* bo = x + r0;
+    const uint16_t* bm = mask2 + (r0 >> 1);
+    asm volatile("" : "+s"(bo));
+    asm volatile("" : "+s"(bm));
+    asm volatile("s_nop 4" ::: "memory");   // (a base that came through v_readfirstlane must not be read by the next 5 instructions)
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) march_ld16(T.v[k], lane_b, b[k]);
+    if constexpr (KOWN < 0) march_ld16(T.own, lane_b, bo);
+    march_ld_u16(T.m, lane_m, bm);
+  };
+  // nwait: vector-memory operations that may still be outstanding once this tile's loads have landed (wave-uniform; one of
+  // 0, 1, NL, NL + 1).  ONE consumer site per register set: with two sites hipcc ties the set to different registers per site
+  // and copies it in front of the wait (seen in the ISA), which reads registers whose loads have not landed.
+  auto finish = [&](int tt, Tile& T, int nwait) {
+    // a wait-only statement, THEN empty statements that redefine the tile's registers: consumers depend on the redefinitions
+    // and cannot be hoisted above them (hipcc hoisted the v_bfe of the masks right behind the load without them), the
+    // redefinitions cannot move above the wait (volatile order), and any register copy hipcc makes for a tie lands behind it
+    if (nwait == NL + 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NL + 1) : "memory");
+    else if (nwait == NL) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NL) : "memory");
+    else if (nwait == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) asm volatile("" : "+v"(T.v[k]));
+    if constexpr (KOWN < 0) asm volatile("" : "+v"(T.own));
+    asm volatile("" : "+v"(T.m));
+    const int m0 = (int)(T.m & 0xffu), m1 = (int)(T.m >> 8);
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+      const double p0 = mul_nc(d.val[k], T.v[k].x), p1 = mul_nc(d.val[k], T.v[k].y);
+      s0 = add_(s0, and_mask(p0, __builtin_amdgcn_sbfe(m0, k, 1)));
+      s1 = add_(s1, and_mask(p1, __builtin_amdgcn_sbfe(m1, k, 1)));
+    }
+    if (shifted) {
+      const f64x2m o = KOWN < 0 ? T.own : T.v[KOWN < 0 ? 0 : KOWN];
+      s0 = scl(sub_s(s0, mul_(theta, o.x)), sigma);
+      s1 = scl(sub_s(s1, mul_(theta, o.y)), sigma);
+    }
+    f64x2m o2;
+    o2.x = s0;
+    o2.y = s1;
+    double* by = y + (int64_t)tt * 512;
+    asm volatile("" : "+s"(by));
+    march_st16(lane_b, o2, by, plain_st);
+  };
+  // the clamped path of k_spmv_stencil2 for the tiles next to the ends of the vector (no pipelining)
+  auto edge = [&](int tt) {
+    const int64_t r = (int64_t)tt * 512 + 2 * (int64_t)threadIdx.x;
+    if (r >= n) return;
+    const bool two = r + 1 < n;
+    const uint32_t m = mask2[r >> 1];
+    const uint32_t m0 = m & 0xffu, m1 = m >> 8;
+    const int64_t cmax = n - 2;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+      const int64_t c = r + d.delta[k];
+      int64_t lo = c < 0 ? 0 : (c > cmax ? cmax : c);
+      if (cmax < 0) lo = 0;
+      const int sh = (int)(c - lo);
+      double xa, xb;
+      if (n >= 2) ld_pair_u(x + lo, xa, xb);
+      else { xa = x[0]; xb = x[0]; }
+      const double v0 = sh == 1 ? xb : xa, v1 = sh == -1 ? xa : xb;
+      const double p0 = mul_nc(d.val[k], v0), p1 = mul_nc(d.val[k], v1);
+      s0 = ((m0 >> k) & 1u) ? add_(s0, p0) : s0;
+      s1 = ((m1 >> k) & 1u) ? add_(s1, p1) : s1;
+    }
+    if (shifted) {
+      double x0, x1;
+      if (two) ld_pair_u(x + r, x0, x1);
+      else { x0 = x[r]; x1 = x0; }
+      s0 = scl(sub_s(s0, mul_(theta, x0)), sigma);
+      s1 = scl(sub_s(s1, mul_(theta, x1)), sigma);
+    }
+    if (two) {
+      if (plain_st) st_pack(y + r, make_double2(s0, s1));
+      else st_pack_nt(y + r, make_double2(s0, s1));
+    } else {
+      if (plain_st) y[r] = s0;
+      else st_elem_nt(y + r, s0);
+    }
+  };
+
+  // the interior tiles (rows [512 t, 512 t + 512) with every slot inside [0, n) and the last lane's pairs inside x) are one
+  // range [t_lo, t_hi) of tile indices; the others sit at the two ends of the vector
+  int64_t lo64 = (-dmin + 511) / 512, hi64 = (n - dmax - 1) / 512;   // r0 + dmin >= 0;  r0 + 512 + dmax + 1 <= n
+  if (n - dmax - 1 < 0) hi64 = 0;
+  if (hi64 > ntiles) hi64 = ntiles;
+  if (lo64 > hi64) lo64 = hi64;
+  const int t_lo = (int)lo64, t_hi = (int)hi64;
+  // edge tiles of this workgroup's sequence first (a handful per launch, on the first and last XCD only)
+  if (t < t_lo || tend > t_hi) {
+    for (int te = t; te < tend; te += S)
+      if (te < t_lo || te >= t_hi) edge(te);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  while (t < t_lo) t += S;
+  const int hi = tend < t_hi ? tend : t_hi;
+  if (t >= hi) return;
+  // software pipeline over the interior tiles, unrolled by two so that the two register sets never move.  Queue of a wave,
+  // oldest first:  loads(t) [store(t - S)] loads(t + S) | store(t) ...: the loads of tile t have landed when at most
+  // NL (first tile) / NL + 1 (the store of the tile before) later operations are outstanding, 1 / 0 when nothing was issued behind
+  Tile A, B;
+  issue(t, A);
+  bool first = true;
+  for (;;) {
+    const int tn = t + S;
+    const bool has_b = tn < hi;
+    if (has_b) issue(tn, B);
+    finish(t, A, has_b ? (first ? NL : NL + 1) : (first ? 0 : 1));
+    first = false;
+    if (!has_b) break;
+    t = tn + S;
+    const bool has_a = t < hi;
+    if (has_a) issue(t, A);
+    finish(tn, B, has_a ? NL + 1 : 1);
+    if (!has_a) break;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace ksd

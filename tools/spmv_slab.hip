@@ -9,7 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
-#include "../arnoldimethod.jl_amd/csrc/ks_spmv_slab.hpp"
+#include "spmv_slab_kernel.hpp"
+#include "../arnoldimethod.jl_amd/csrc/ks_spmv_march.hpp"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 using namespace ksd;
 
@@ -22,7 +23,7 @@ __global__ void k_flush(const double* __restrict__ a, double* __restrict__ out, 
 struct Problem {
   long n, P; int nz; uint16_t* dm; long nmask; StencilDict<double> d; double* xs;
 };
-static int g_allodd = 0;
+static int g_allodd = 0, g_dbg = 0;
 struct Variant { const char* name; int nw, ns, order, wg_per_cu; };
 
 template <int NW, int NS>
@@ -38,10 +39,10 @@ void launch_slab(const Problem& pr, const double* x, double* y, int order, int w
   long sl = (pr.P + nseg - 1) / nseg;
   sl = (sl + 3) & ~3L;
   nseg = (int)((pr.P + sl - 1) / sl);
-  kern<<<nslab * nseg, NW * 64, G::lds_bytes>>>(pr.dm, pr.nmask, pr.d, 7, x, pr.n, y, pr.n, pr.P, pr.nz, (int)sl, nseg, nslab, order, nullptr, shifted, 0.37, 0.125);
+  kern<<<nslab * nseg, NW * 64, G::lds_bytes>>>(pr.dm, pr.nmask, pr.d, 7, x, pr.n, y, pr.n, pr.P, pr.nz, (int)sl, nseg, nslab, order | (g_dbg << 1), nullptr, shifted, 0.37, 0.125);
 }
 
-static int g_nseg = 0;
+static int g_nseg = 0, g_G = 768;
 void launch(int var, const Problem& pr, const double* x, double* y, int shifted) {
   const int nt = (int)((pr.n + 511) / 512);
   switch (var) {
@@ -57,15 +58,21 @@ void launch(int var, const Problem& pr, const double* x, double* y, int shifted)
     case 9: launch_slab<6, 7>(pr, x, y, 0, 256, shifted, g_nseg); break;
     case 10: launch_slab<4, 4>(pr, x, y, 0, 768, shifted, g_nseg); break;   // 52 KB: three workgroups per CU
     case 11: launch_slab<8, 7>(pr, x, y, 0, 512, shifted, g_nseg); break;   // twice the workgroups (two rounds)
+    case 12: k_spmv_stencil_march<7, 3><<<256 * 4, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
+    case 13: k_spmv_stencil_march<7, 3><<<256 * 6, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
+    case 14: k_spmv_stencil_march<7, 3><<<256 * 8, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
+    case 15: k_spmv_stencil_march<7, 3><<<256 * 3, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
+    case 16: k_spmv_stencil_march<7, 3><<<256 * 5, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
+    case 17: k_spmv_stencil_march<7, 3><<<g_G, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
     default: printf("no variant %d\n", var); exit(1);
   }
 }
 const char* vname(int var) {
   static const char* names[] = {"k_spmv_stencil2", "slab<8,7> z-order", "slab<8,7> seg-order", "slab<8,6>", "slab<8,5>", "slab<8,4>", "slab<12,5>",
-                                "slab<16,4>", "slab<4,6> 2/CU", "slab<6,7>", "slab<4,4> 3/CU", "slab<8,7> 512 wgs"};
+                                "slab<16,4>", "slab<4,6> 2/CU", "slab<6,7>", "slab<4,4> 3/CU", "slab<8,7> 512 wgs", "march 4 wg/CU", "march 6 wg/CU", "march 8 wg/CU", "march 3 wg/CU", "march 5 wg/CU"};
   return names[var];
 }
-constexpr int kNVar = 12;
+constexpr int kNVar = 17;
 
 int main(int argc, char** argv) {
   const int m = argc > 1 ? atoi(argv[1]) : 216;
@@ -96,13 +103,46 @@ int main(int argc, char** argv) {
   if (argc > 6 && !strcmp(argv[4], "only")) {
     const int var = atoi(argv[5]), reps = atoi(argv[6]);
     if (argc > 7) g_nseg = atoi(argv[7]);
+    if (argc > 8) g_dbg = atoi(argv[8]);
     for (int i = 0; i < reps; ++i) { k_flush<<<2048, 256>>>(big, out, 1L << 28); launch(var, pr, pr.xs, y1, 1); }
     CK(hipDeviceSynchronize());
     printf("%s: %d launches\n", vname(var), reps);
     return 0;
   }
+  if (argc > 4 && !strcmp(argv[4], "sweep")) {
+    // the marching kernel over the number of workgroups G (S = G / 8 tiles per XCD and round): cold time and chain time
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    launch(0, pr, pr.xs, y1, 3);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(r1.data(), y1, n * 8, hipMemcpyDeviceToHost));
+    for (int ai = 5; ai < argc; ++ai) {
+      g_G = atoi(argv[ai]) * 8;
+      float best = 1e9f;
+      CK(hipMemset(y2, 0xff, n * 8));
+      for (int rep = 0; rep < 6; ++rep) {
+        k_flush<<<2048, 256>>>(big, out, 1L << 28);
+        CK(hipEventRecord(a));
+        launch(17, pr, pr.xs, y2, 3);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        if (rep) best = ms < best ? ms : best;
+      }
+      CK(hipMemcpy(r2.data(), y2, n * 8, hipMemcpyDeviceToHost));
+      const bool same = !memcmp(r1.data(), r2.data(), n * 8);
+      k_flush<<<2048, 256>>>(big, out, 1L << 28);
+      CK(hipEventRecord(a));
+      for (int i = 0; i < 20; ++i) launch(17, pr, i == 0 ? pr.xs : (i & 1 ? y1 : y2), (i & 1) ? y2 : y1, 3);
+      CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+      float ms; CK(hipEventElapsedTime(&ms, a, b));
+      printf("%d x %d x %d  march S=%d (G=%d, %.2f wg/CU, plane = %.1f tiles)  cold %.1f us  chain %.1f us  %s\n", m, my, mz, g_G / 8, g_G, g_G / 256.0, pr.P / 512.0,
+             best * 1e3, ms * 1e3 / 20, same ? "bit-identical" : "DIFFER");
+      fflush(stdout);
+    }
+    return 0;
+  }
   if (argc > 4) g_nseg = atoi(argv[4]);
   if (argc > 5) g_allodd = atoi(argv[5]);
+  if (argc > 6) g_dbg = atoi(argv[6]);
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   for (int shifted : {0, 1, 3}) {
     launch(0, pr, pr.xs, y1, shifted);

@@ -1,3 +1,8 @@
+// EXPERIMENT (round 6, measured and NOT adopted: profiles/r06_spmv_slab.txt -- 45-54 us against 43-45 us of k_spmv_stencil2 and 34 us
+// of the marching kernel that went into the library, csrc/ks_spmv_march.hpp).  Correct (bit-identical on the first run) but bound by
+// its own instruction stream and by the barrier that couples the waves: with 8-16 waves per CU nothing overlaps the ~200 vector
+// instructions per 128 rows, and deeper rings (fewer waves) are slower, not faster.  Kept as the record of the attempt.
+//
 // SpMV, stencil-mask layout, SLAB form (gfx950):  y = A x  or the Newton step  y = sigma (A x - theta x)  of mul!(y, A, x),
 // src/expansion.jl:121, for a matrix in the one-bit-per-slot-and-row layout of k_spmv_stencil (ks_kernels.hpp) whose slots are
 //     delta_k = dv_k P + dp_k,   dv_k in {-1, 0, +1},  |dp_k| <= 256,
@@ -25,7 +30,7 @@
 
 #include <utility>
 
-#include "ks_block_kernels.hpp"  // glds16
+#include "../arnoldimethod.jl_amd/csrc/ks_block_kernels.hpp"  // glds16
 
 namespace ksd {
 
@@ -117,6 +122,8 @@ __global__ void __launch_bounds__(NW * 64)
   const int v = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int w = xcd_remap(blockIdx.x, gridDim.x);
   int seg, slab;
+  const int dbg = order >> 1;   // (probes of tools/spmv_slab.hip: 1 no arithmetic, 2 no stores, 4 no x copies, 8 no mask copies)
+  order &= 1;
   if (order == 0) { seg = w / nslab; slab = w - seg * nslab; }
   else { slab = w / nseg; seg = w - slab * nseg; }
   const int z = slab * NW + v;
@@ -145,7 +152,7 @@ __global__ void __launch_bounds__(NW * 64)
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int64_t r = base + (int64_t)j * 256 + p * 128 + 2 * lane;
-      const bool ok = live && r >= 0 && r + 2 <= nxr;
+      const bool ok = live && r >= 0 && r + 2 <= nxr && !(dbg & 4);
       glds16(ok ? x + r : x, ring + (uint32_t)sl * 2048u + (uint32_t)p * 1024u);
     }
   };
@@ -156,7 +163,7 @@ __global__ void __launch_bounds__(NW * 64)
   };
   auto issue_m = [&](int j, int sl) {
     const int64_t i = ((row0 + (int64_t)j * 256) >> 1) + 2 * lane;   // two 16-bit masks per lane
-    const bool ok = j < nb_wg && i + 2 <= nmask;
+    const bool ok = j < nb_wg && i + 2 <= nmask && !(dbg & 8);
     glds4(ok ? mask2 + i : mask2, mring + (uint32_t)sl * 256u);
   };
 
@@ -171,14 +178,15 @@ __global__ void __launch_bounds__(NW * 64)
       sm = sm + 1 == NS ? 0 : sm + 1;
     }
   }
-  const int ops_p = 2 * nld + 1, ops_s = 2 * nld + 3;   // vector-memory operations of a prologue step / of a loop step
+  const int nstore = (dbg & 2) ? 0 : 2;
+  const int ops_p = 2 * nld + 1, ops_s = 2 * nld + 1 + nstore;   // vector-memory operations of a prologue step / of a loop step
   int sb = 1, smb = 0;                                   // slots of block b
   const bool plain_st = (shifted & 2) != 0;
   for (int b = 0; b < nb_wg; ++b) {
     // block b + 1 of the x streams and mask block b have landed when at most this many LATER operations are outstanding
     // (operations of one wave complete in order): the rest of the step that issued block b + 1, then D - 1 whole steps
     int nwait = 0;
-    if (b < nb_v) nwait = b < D ? 1 + (D - b - 1) * ops_p + b * ops_s : 3 + (D - 1) * ops_s;
+    if (b < nb_v) nwait = b < D ? 1 + (D - b - 1) * ops_p + b * ops_s : 1 + nstore + (D - 1) * ops_s;
     slab_wait_barrier(nwait);
     if (active) {
       issue_x(b + 1 + D, sx);   // into the slot of block b - 2: everybody is past step b - 1
@@ -222,6 +230,8 @@ __global__ void __launch_bounds__(NW * 64)
         if (shifted) own = *reinterpret_cast<const f64x2a*>(lds + (v + 1) * G::kRingBytes + pos0 * 8);
         // phase 2: products rounded separately, added in slot order under the row's mask (as k_spmv_stencil2)
         double s0 = 0.0, s1 = 0.0;
+        if (dbg & 1) { s0 = v0[3]; s1 = v1[3]; }
+        else
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const double p0 = mul_nc(d.val[k], v0[k]), p1 = mul_nc(d.val[k], v1[k]);
@@ -233,7 +243,8 @@ __global__ void __launch_bounds__(NW * 64)
           s1 = scl(sub_s(s1, mul_(theta, own.y)), sigma);
         }
         double* yp = y + row0 + t;
-        if (t + 1 < len) {
+        if ((dbg & 2) && s0 != 1.2345e-300) {
+        } else if (t + 1 < len) {
           f64x2a o;
           o.x = s0;
           o.y = s1;
