@@ -149,21 +149,23 @@ template <class D> struct CsrOp : ks_operator {
     static const int env = env_int("KS_STENCIL_MARCH", 1);
     return env != 0;
   }
-  // Workgroups per XCD (= tiles of 512 rows an XCD takes per round).  With a far stride P (the xy-plane of a 3-D grid) the
-  // kernel is fastest when ONE ROUND COVERS ONE PLANE: the z + 1 taps of a round are then the rows the next round owns, the only
-  // first-touch stream of a round is one band of x, and every other load finds its line in the XCD's L2 one or two rounds old --
-  // measured on 216^3 (tools/spmv_slab.hip sweep, profiles/r06_spmv_march.txt): 34.0 us at 92 against 40.8 at 100, 44.9 at 128,
-  // 41.9 at 60.  Without a far stride (or when a plane is more than the device holds at once): 96 per XCD (3 per CU).
+  // Workgroups per XCD (= tiles of 512 rows an XCD takes per round).  With a far stride P (the xy-plane of a 3-D grid) a round
+  // that covers a WHOLE NUMBER OF PLANES keeps the z - 1 / z + 1 taps of a round in step with the rows other rounds own.  How much
+  // that buys depends on where x comes from (tools/spmv_slab.hip, profiles/r06_spmv_sweep.txt, r06_spmv_columns.txt, 216^3):
+  //   x and y ping-pong between two buffers that stay in the 256-MB Infinity Cache:   34.0 us at 92 (one plane), 40 at 184-192
+  //     (two planes), 41-45 in between and beyond (k_spmv_stencil2: 43-44);
+  //   the solver's chain (column i -> column i + 1 of a basis that does not fit the cache):   48.7 at 192, 50.5 at 92, 49-55 for
+  //     k_spmv_stencil2 -- a plain copy of the same columns takes 29-31 there, the same kernel with ONE slot 36.
+  // The solver lives in the second regime: two planes per round (5-6 workgroups per CU), a multiple of one plane in general.
   int march_slots(int ntiles) const {
     static const int env = env_int("KS_MARCH_S", 0);
-    int S = 96;
+    int S = 192;
     if (env > 0) S = env;
     else {
       int64_t P = 0;
       for (int k = 0; k < nstencil; ++k) P = std::max<int64_t>(P, std::llabs((long long)sdict.delta[k]));
-      int64_t per = P / 512 + 1;            // tiles of one far stride, rounded up
-      while (per > 224) per = (per + 1) / 2;  // (7 workgroups per CU fit: keep every workgroup of a round resident)
-      if (per >= 48) S = (int)per;
+      const int64_t per = P / 512 + 1;                         // tiles of one far stride, rounded up
+      if (per >= 16 && per <= 224) S = (int)(per * ((160 + per - 1) / per)) <= 224 ? (int)(per * ((160 + per - 1) / per)) : (int)per;
     }
     S = std::min(S, std::max(1, (ntiles + 7) / 8));
     return S;

@@ -52,8 +52,30 @@ __device__ __forceinline__ void march_st16(uint32_t voff, f64x2m v, void* sbase,
   else asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 
-// KOWN: the slot with delta 0 (its pair is the rows' own pair of the Newton step), -1: none -- the own pair is one more load
-template <int NSLOT, int KOWN>
+__device__ __forceinline__ void march_ld8(double& dst, uint32_t voff, const void* sbase) {
+  asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+// lane i <- lane i - 1 (lane 0 keeps `edge`) / lane i <- lane i + 1 (lane 63 keeps `edge`): DPP wave shifts, no LDS, no memory
+__device__ __forceinline__ double wave_shr1(double edge, double src) {
+  const uint64_t e = __builtin_bit_cast(uint64_t, edge), v = __builtin_bit_cast(uint64_t, src);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)e, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(e >> 32), (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_shl1(double edge, double src) {
+  const uint64_t e = __builtin_bit_cast(uint64_t, edge), v = __builtin_bit_cast(uint64_t, src);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)e, (int)(uint32_t)v, 0x130, 0xf, 0xf, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(e >> 32), (int)(uint32_t)(v >> 32), 0x130, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
+// KOWN: the slot with delta 0 (its pair is the rows' own pair of the Newton step), -1: none -- the own pair is one more load.
+// KM1 / KP1 (both or neither, and only with KOWN >= 0): the slots with delta -1 / +1.  Their pairs (x[r-1], x[r]) and (x[r+1], x[r+2])
+// are NOT loaded: x[r], x[r+1] are the own pair, x[r-1] / x[r+2] the neighbouring lanes' (wave shifts), and the two values a wave
+// lacks at its ends come with one 8-byte load in which the lanes read only two distinct addresses.  Two 16-byte loads of nine
+// vector-memory operations per tile less: in the solver's chain the address/L1 path is what the taps cost (one +- pair of taps
+// = 4-6 us of a 50-us product, profiles/r06_spmv_columns.txt).
+template <int NSLOT, int KOWN, int KM1 = -1, int KP1 = -1>
 __global__ void __launch_bounds__(kBlock)
     k_spmv_stencil_march(const uint16_t* __restrict__ mask2, const StencilDict<double> d, const double* __restrict__ x,
                          double* __restrict__ y, int64_t n, int ntiles, const DevState* __restrict__ st, int shifted, double theta,
@@ -70,10 +92,16 @@ __global__ void __launch_bounds__(kBlock)
   const bool plain_st = (shifted & 2) != 0;
   int tend;
   int t = march_tile(xcd, slot, 0, S, ntiles, tend);
-  constexpr int NL = NSLOT + (KOWN < 0 ? 1 : 0) + 1;   // loads of a tile
+  constexpr bool NEAR = KM1 >= 0 && KP1 >= 0 && KOWN >= 0;
+  static_assert((KM1 >= 0) == (KP1 >= 0) && (KM1 < 0 || KOWN >= 0), "delta -1 and +1 come from the own pair: all three slots or none");
+  constexpr int NL = NSLOT + (KOWN < 0 ? 1 : 0) + 1 - (NEAR ? 1 : 0);   // loads of a tile (NEAR: two pairs less, one edge load more)
+  // the wave's two missing neighbours: lanes 0-31 read x[first row - 1], lanes 32-63 x[last row + 1] (two distinct addresses)
+  // (byte offsets from x + first row of the tile - 1: the 32-bit offset of a scalar-base load is unsigned)
+  const uint32_t lane_e = ((threadIdx.x >> 6) * 128u + ((threadIdx.x & 32u) ? 129u : 0u)) * 8u;
 
   struct Tile {
     f64x2m v[NSLOT], own;
+    double edge;
     uint32_t m;
   };
   auto issue = [&](int tt, Tile& T) {
@@ -86,12 +114,16 @@ __global__ void __launch_bounds__(kBlock)
     }
     const double* bo = x + r0;
     const uint16_t* bm = mask2 + (r0 >> 1);
+    const double* be = x + (r0 - 1);
     asm volatile("" : "+s"(bo));
     asm volatile("" : "+s"(bm));
+    asm volatile("" : "+s"(be));
     asm volatile("s_nop 4" ::: "memory");   // (a base that came through v_readfirstlane must not be read by the next 5 instructions)
 #pragma unroll
-    for (int k = 0; k < NSLOT; ++k) march_ld16(T.v[k], lane_b, b[k]);
+    for (int k = 0; k < NSLOT; ++k)
+      if (!(NEAR && (k == KM1 || k == KP1))) march_ld16(T.v[k], lane_b, b[k]);
     if constexpr (KOWN < 0) march_ld16(T.own, lane_b, bo);
+    if constexpr (NEAR) march_ld8(T.edge, lane_e, be);
     march_ld_u16(T.m, lane_m, bm);
   };
   // nwait: vector-memory operations that may still be outstanding once this tile's loads have landed (wave-uniform; one of
@@ -106,8 +138,17 @@ __global__ void __launch_bounds__(kBlock)
     else if (nwait == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int k = 0; k < NSLOT; ++k) asm volatile("" : "+v"(T.v[k]));
+    for (int k = 0; k < NSLOT; ++k)
+      if (!(NEAR && (k == KM1 || k == KP1))) asm volatile("" : "+v"(T.v[k]));
     if constexpr (KOWN < 0) asm volatile("" : "+v"(T.own));
+    if constexpr (NEAR) {
+      asm volatile("" : "+v"(T.edge));
+      const f64x2m o = T.v[KOWN < 0 ? 0 : KOWN];
+      T.v[KM1 < 0 ? 0 : KM1].x = wave_shr1(T.edge, o.y);   // x[r - 1]: the lane below's second row
+      T.v[KM1 < 0 ? 0 : KM1].y = o.x;
+      T.v[KP1 < 0 ? 0 : KP1].x = o.y;
+      T.v[KP1 < 0 ? 0 : KP1].y = wave_shl1(T.edge, o.x);   // x[r + 2]: the lane above's first row
+    }
     asm volatile("" : "+v"(T.m));
     const int m0 = (int)(T.m & 0xffu), m1 = (int)(T.m >> 8);
     double s0 = 0.0, s1 = 0.0;

@@ -17,6 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import isa_audit  # noqa: E402
 
 INSTANCES = [(7, 3), (5, 2), (3, 1), (1, -1), (4, -1), (7, -1), (8, -1)]
+NEAR_INSTANCES = [(7, 3, 2, 4), (5, 2, 1, 3)]   # the +-1 taps from the neighbouring lanes (tools/spmv_slab.hip measures it; not dispatched)
 
 
 @pytest.fixture(scope="module")
@@ -28,15 +29,25 @@ def listing(tmp_path_factory):
     src = d / "march_inst.hip"
     inst = "\n".join(f"template __global__ void ksd::k_spmv_stencil_march<{ns}, {ko}>(const uint16_t*, const ksd::StencilDict<double>, const double*, double*, "
                      f"int64_t, int, const ksd::DevState*, int, double, double);" for ns, ko in INSTANCES)
+    inst += "\n" + "\n".join(f"template __global__ void ksd::k_spmv_stencil_march<{a}, {b}, {c}, {e}>(const uint16_t*, const ksd::StencilDict<double>, const double*, double*, "
+                             f"int64_t, int, const ksd::DevState*, int, double, double);" for a, b, c, e in NEAR_INSTANCES)
     src.write_text(f'#include "{ROOT}/arnoldimethod.jl_amd/csrc/ks_spmv_march.hpp"\n{inst}\n')
     out = d / "march_inst.s"
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", str(src), "-o", str(out)])
     return out.read_text()
 
 
+@pytest.mark.parametrize("a,b,c,e", NEAR_INSTANCES)
+def test_the_form_with_neighbour_lane_taps(listing, a, b, c, e):
+    nloads, bad = isa_audit.audit(listing, f"k_spmv_stencil_marchILi{a}ELi{b}ELi{c}ELi{e}E")
+    nl = a - 2 + 1 + 1   # two pairs less, the edge load, the masks
+    assert nloads >= 3 * nl and nloads % nl == 0, nloads
+    assert not bad, bad[:5]
+
+
 @pytest.mark.parametrize("ns,ko", INSTANCES)
 def test_no_compiler_instruction_touches_a_register_in_flight(listing, ns, ko):
-    tag = f"k_spmv_stencil_marchILi{ns}ELi{ko}E" if ko >= 0 else f"k_spmv_stencil_marchILi{ns}ELin{-ko}E"
+    tag = f"k_spmv_stencil_marchILi{ns}ELi{ko}ELin1ELin1E" if ko >= 0 else f"k_spmv_stencil_marchILi{ns}ELin{-ko}ELin1ELin1E"
     nloads, bad = isa_audit.audit(listing, tag)
     # at least three issue sites (prologue, the two halves of the unrolled loop; hipcc duplicates them for the short kernels), each:
     # one load per slot (+ the own pair) + the masks

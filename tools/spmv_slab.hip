@@ -20,6 +20,16 @@ __global__ void k_flush(const double* __restrict__ a, double* __restrict__ out, 
   if (s == 1.2345) out[0] = s;
 }
 
+// reference: what the memory system gives a plain copy in the same chain (16-byte loads, cacheable or streaming 16-byte stores)
+__global__ void __launch_bounds__(256) k_copy_ref(const double* __restrict__ x, double* __restrict__ y, long n, int nt_store) {
+  typedef double v2 __attribute__((ext_vector_type(2)));
+  const long np = n / 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < np; i += (long)gridDim.x * 256) {
+    const v2 v = *reinterpret_cast<const v2*>(x + 2 * i);
+    if (nt_store) __builtin_nontemporal_store(v, reinterpret_cast<v2*>(y + 2 * i));
+    else *reinterpret_cast<v2*>(y + 2 * i) = v;
+  }
+}
 struct Problem {
   long n, P; int nz; uint16_t* dm; long nmask; StencilDict<double> d; double* xs;
 };
@@ -43,6 +53,8 @@ void launch_slab(const Problem& pr, const double* x, double* y, int order, int w
 }
 
 static int g_nseg = 0, g_G = 768;
+static uint16_t* g_m1 = nullptr;   // all-ones masks (slot ladder)
+static StencilDict<double> g_d1{}, g_d3{}, g_d5{}, g_d3f{};
 void launch(int var, const Problem& pr, const double* x, double* y, int shifted) {
   const int nt = (int)((pr.n + 511) / 512);
   switch (var) {
@@ -63,6 +75,12 @@ void launch(int var, const Problem& pr, const double* x, double* y, int shifted)
     case 14: k_spmv_stencil_march<7, 3><<<256 * 8, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
     case 15: k_spmv_stencil_march<7, 3><<<256 * 3, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
     case 16: k_spmv_stencil_march<7, 3><<<256 * 5, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
+    case 23: k_spmv_stencil_march<7, 3, 2, 4><<<g_G, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
+    case 19: k_spmv_stencil_march<1, 0><<<g_G, 256>>>(g_m1, g_d1, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
+    case 20: k_spmv_stencil_march<3, 1><<<g_G, 256>>>(g_m1, g_d3, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
+    case 21: k_spmv_stencil_march<5, 2><<<g_G, 256>>>(g_m1, g_d5, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
+    case 22: k_spmv_stencil_march<3, 1><<<g_G, 256>>>(g_m1, g_d3f, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
+    case 18: k_copy_ref<<<g_G, 256>>>(x, y, pr.n, (shifted & 2) ? 0 : 1); break;
     case 17: k_spmv_stencil_march<7, 3><<<g_G, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
     default: printf("no variant %d\n", var); exit(1);
   }
@@ -109,6 +127,51 @@ int main(int argc, char** argv) {
     printf("%s: %d launches\n", vname(var), reps);
     return 0;
   }
+  if (argc > 4 && !strcmp(argv[4], "columns")) {
+    // the chain the solver runs: product i reads column i and writes column i + 1 of a 21-column basis (1.7 GB at 216^3: nothing
+    // stays in the 256-MB Infinity Cache but the column just written), cacheable stores, three passes; per-launch HIP events.
+    //   ... columns V0 [S1 S2 ...]: variant V0 (0 = k_spmv_stencil2) and the marching kernel at S1, S2, ... slots per XCD
+    // slot ladder (variants 19-22; S + 20000 / 30000 / 40000 / 50000): the marching kernel with 1 slot (delta 0: a scaled copy), 3 slots
+    // (-1, 0, +1), 5 slots (+- nx added), 3 slots (-P, 0, +P), all masks set -- where the time of the 7-slot product goes
+    { std::vector<uint16_t> ones(mask.size(), 0xffff); CK(hipMalloc(&g_m1, ones.size() * 2)); CK(hipMemcpy(g_m1, ones.data(), ones.size() * 2, hipMemcpyHostToDevice));
+      g_d1.delta[0] = 0; g_d1.val[0] = 6.0;
+      const long d3[3] = {-1, 0, 1}, d5[5] = {-m, -1, 0, 1, m}, d3f[3] = {-pr.P, 0, pr.P};
+      for (int k = 0; k < 3; ++k) { g_d3.delta[k] = (int)d3[k]; g_d3.val[k] = k == 1 ? 6.0 : -1.0; g_d3f.delta[k] = (int)d3f[k]; g_d3f.val[k] = k == 1 ? 6.0 : -1.0; }
+      for (int k = 0; k < 5; ++k) { g_d5.delta[k] = (int)d5[k]; g_d5.val[k] = k == 2 ? 6.0 : -1.0; } }
+    const int ncol = 21;
+    const long ld = (n + 511) / 512 * 512 + 512;
+    double* V; CK(hipMalloc(&V, (size_t)ncol * ld * 8));
+    CK(hipMemset(V, 0, (size_t)ncol * ld * 8));
+    CK(hipMemcpy(V, h.data(), n * 8, hipMemcpyHostToDevice));
+    std::vector<hipEvent_t> ev(21);
+    for (auto& evt : ev) CK(hipEventCreate(&evt));
+    for (int ai = 5; ai < argc; ++ai) {
+      int sarg = atoi(argv[ai]);
+      int shf = 3;
+      if (sarg < 0) { sarg = -sarg; shf = 1; }            // negative: streaming (nt) stores instead of cacheable ones
+      int var = sarg == 0 ? 0 : 17;
+      if (sarg >= 60000) { sarg -= 60000; var = 23; }
+      else if (sarg >= 50000) { sarg -= 50000; var = 22; }
+      else if (sarg >= 40000) { sarg -= 40000; var = 21; }
+      else if (sarg >= 30000) { sarg -= 30000; var = 20; }
+      else if (sarg >= 20000) { sarg -= 20000; var = 19; }
+      else if (sarg >= 10000) { sarg -= 10000; shf = 1; }
+      if (sarg >= 5000) { sarg -= 5000; var = 18; }       // 5000 + S: the plain copy with 8 S workgroups
+      if (sarg) g_G = sarg * 8;
+      double tot = 0; float mn = 1e9f, mx = 0; std::vector<float> per(20, 0.f);
+      for (int pass = 0; pass < 4; ++pass) {
+        for (int i = 0; i < 20; ++i) { CK(hipEventRecord(ev[i])); launch(var, pr, V + (size_t)i * ld, V + (size_t)(i + 1) * ld, shf); }
+        CK(hipEventRecord(ev[20])); CK(hipEventSynchronize(ev[20]));
+        if (!pass) continue;
+        for (int i = 0; i < 20; ++i) { float ms; CK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); tot += ms; mn = ms < mn ? ms : mn; mx = ms > mx ? ms : mx; per[i] += ms / 3; }
+      }
+      printf("%d x %d x %d  columns chain  %s stores  %-18s S=%-4d  mean %.1f us  min %.1f  max %.1f   per product:", m, my, mz, shf == 3 ? "cacheable" : "streaming", var == 18 ? "plain copy" : var == 19 ? "march 1 slot" : var == 20 ? "march -1 0 +1" : var == 21 ? "march 5 near" : var == 22 ? "march -P 0 +P" : var == 23 ? "march near-by-dpp" : var ? "march" : "k_spmv_stencil2", var ? g_G / 8 : 0, tot / 60 * 1e3, mn * 1e3, mx * 1e3);
+      for (int i = 0; i < 20; ++i) printf(" %.0f", per[i] * 1e3);
+      printf("\n");
+      fflush(stdout);
+    }
+    return 0;
+  }
   if (argc > 4 && !strcmp(argv[4], "sweep")) {
     // the marching kernel over the number of workgroups G (S = G / 8 tiles per XCD and round): cold time and chain time
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -116,13 +179,15 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(r1.data(), y1, n * 8, hipMemcpyDeviceToHost));
     for (int ai = 5; ai < argc; ++ai) {
-      g_G = atoi(argv[ai]) * 8;
+      int sv = atoi(argv[ai]);
+      const int mvar = sv < 0 ? 23 : 17;      // negative: the form with the +-1 taps from the neighbouring lanes
+      g_G = (sv < 0 ? -sv : sv) * 8;
       float best = 1e9f;
       CK(hipMemset(y2, 0xff, n * 8));
       for (int rep = 0; rep < 6; ++rep) {
         k_flush<<<2048, 256>>>(big, out, 1L << 28);
         CK(hipEventRecord(a));
-        launch(17, pr, pr.xs, y2, 3);
+        launch(mvar, pr, pr.xs, y2, 3);
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
         if (rep) best = ms < best ? ms : best;
@@ -131,10 +196,10 @@ int main(int argc, char** argv) {
       const bool same = !memcmp(r1.data(), r2.data(), n * 8);
       k_flush<<<2048, 256>>>(big, out, 1L << 28);
       CK(hipEventRecord(a));
-      for (int i = 0; i < 20; ++i) launch(17, pr, i == 0 ? pr.xs : (i & 1 ? y1 : y2), (i & 1) ? y2 : y1, 3);
+      for (int i = 0; i < 20; ++i) launch(mvar, pr, i == 0 ? pr.xs : (i & 1 ? y1 : y2), (i & 1) ? y2 : y1, 3);
       CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
       float ms; CK(hipEventElapsedTime(&ms, a, b));
-      printf("%d x %d x %d  march S=%d (G=%d, %.2f wg/CU, plane = %.1f tiles)  cold %.1f us  chain %.1f us  %s\n", m, my, mz, g_G / 8, g_G, g_G / 256.0, pr.P / 512.0,
+      printf("%d x %d x %d  march%s S=%d (G=%d, %.2f wg/CU, plane = %.1f tiles)  cold %.1f us  chain %.1f us  %s\n", m, my, mz, mvar == 23 ? " (near taps by dpp)" : "", g_G / 8, g_G, g_G / 256.0, pr.P / 512.0,
              best * 1e3, ms * 1e3 / 20, same ? "bit-identical" : "DIFFER");
       fflush(stdout);
     }
