@@ -92,9 +92,11 @@ def to_scipy(indptr, indices, data, ncols):
     return sp.csr_matrix((data, indices, indptr), shape=(len(indptr) - 1, ncols))
 
 
-def hashed_nonsymmetric_csr(n: int, seed: int = 7):
+def hashed_nonsymmetric_csr(n: int, seed: int = 7, planted=None):
     """Portable stand-in for sprand(n, n, 5/n): row i has 1 + (h mod 9) entries at hashed columns,
-    values uniform [0,1); duplicates summed.  Returns a scipy CSR matrix."""
+    values uniform [0,1); duplicates summed.  `planted`: list of (a, b) -> the leading rows are replaced by 2x2 blocks
+    [a b; -b a] on the diagonal (b == 0: one row with the real entry a): exact, separated eigenvalues a +- i b of the
+    matrix (the planted rows have no other entries), as oracle.matrices.hashed_nonsymmetric plants them.  Returns a scipy CSR matrix."""
     import scipy.sparse as sp
 
     idx = np.arange(n, dtype=np.uint64)
@@ -107,7 +109,21 @@ def hashed_nonsymmetric_csr(n: int, seed: int = 7):
         rows.append(r.astype(np.int64))
         cols.append(c)
         vals.append(uniform_hash(seed + 2, r * np.uint64(64) + np.uint64(t + 1)))
-    A = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr()
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    if planted:
+        pr, pc, pv, p = [], [], [], 0
+        for a, b in planted:
+            if b == 0:
+                pr += [p]; pc += [p]; pv += [a]
+                p += 1
+            else:
+                pr += [p, p, p + 1, p + 1]; pc += [p, p + 1, p, p + 1]; pv += [a, b, -b, a]
+                p += 2
+        keep = rows >= p
+        rows = np.concatenate([rows[keep], np.array(pr, dtype=np.int64)])
+        cols = np.concatenate([cols[keep], np.array(pc, dtype=np.int64)])
+        vals = np.concatenate([vals[keep], np.array(pv, dtype=np.float64)])
+    A = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
     A.sum_duplicates()
     A.sort_indices()
     return A
