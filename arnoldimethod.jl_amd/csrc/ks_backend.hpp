@@ -45,6 +45,13 @@ template <class T> struct HipBackend : ks::Backend<T> {
       (void)hipStreamSynchronize(ws->ctx->stream);
       try { reset_lazy(ws); } catch (...) {}
       prov_drop(ws);
+      // a pending / adopted rotation, a speculative chain and a drift watch in flight all belong to the factorisation that just
+      // became undefined: an exception between the adoption (rot_fuse, spec_adopt) and the first block kernel must not leave them
+      // for the batch that follows the re-initialisation (it would rotate a fresh basis with a stale Q and skip products)
+      ws->rot_pending = ws->rot_fuse = ws->rot_split = false;
+      ws->spec_valid = false;
+      ws->spec_adopt = 0;
+      ws->rp_inflight = false;
       throw;
     }
   }
@@ -62,8 +69,10 @@ template <class T> struct HipBackend : ks::Backend<T> {
     bool no_block = false;  // a block of this call was abandoned: the rest of the range runs step by step
     // (columns still in factored form were produced by the library's previous call, no restart in between: nothing to measure,
     // and materialising them here would change the rounding of a run that stays step by step)
+    // (a watch enqueued behind the previous expansion: may switch the blocks off for this one.  BEFORE the relation probe: the two
+    // share the pinned words -- the probe's coefficients start where the watch keeps its sequence word)
+    drift_probe_collect();
     if (trusted && ws->prov_vouched && !ws->t_lazy && ws->sstep_eff >= 2 && op->async_capable && from >= 2 && to - from + 1 >= 2) relation_probe(from, H);
-    drift_probe_collect();   // (a watch enqueued behind the previous expansion: may switch the blocks off for this one)
     blk_shifts_from_saved_H();
     while (j0 <= to) {
       const double tb0 = ks::now_s();
@@ -97,7 +106,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
         if (defer_dbg)
           std::fprintf(stderr, "[adopt] bpath %d j0 %d out0+rr %d fused_ok %d split_ok %d spec_valid %d blk0 %d spec_ne %d backoff %d\n", (int)bpath, j0, ws->rot_out0 + ws->rot_rr,
                        (int)fused_ok, (int)split_ok, (int)ws->spec_valid, bpath ? blk_sizes[0] : 0, ws->spec_ne, ws->spec_backoff);
-        if (bpath && j0 == ws->rot_out0 + ws->rot_rr && (fused_ok || split_ok)) {
+        if (bpath && j0 == ws->rot_out0 + ws->rot_rr && (fused_ok || split_ok) && ensure_zscratch<D>(ws)) {
           ws->rot_pending = false;
           ws->rot_fuse = true;
           ws->rot_split = !fused_ok;
@@ -315,10 +324,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
     // one more is tolerated -- a 2 x 2 block of the real Schur form kept whole; ComplexF64 restarts keep exactly mindim columns)
     const int ne = std::min(10, ws->maxdim - k_now - (sizeof(D) == 8 ? 1 : 0));
     if (ne < 2) return;
-    if (!ws->zscratch) {
-      KS_HIP(hipMalloc(&ws->zscratch, (size_t)ws->ld * ksd::kBlkSMax * sizeof(D)));
-      KS_HIP(hipMemsetAsync(ws->zscratch, 0, (size_t)ws->ld * ksd::kBlkSMax * sizeof(D), ws->ctx->stream));
-    }
+    if (!ensure_zscratch<D>(ws)) return;
     char* zs = static_cast<char*>(ws->zscratch);
     op->shift_store_cacheable = true;
     for (int i = 0; i < ne; ++i) {
@@ -397,7 +403,11 @@ template <class T> struct HipBackend : ks::Backend<T> {
       KS_HIP(hipHostMalloc(&ws->probe_host, 16 + (size_t)(ws->maxdim + 2) * 16));
     }
     if (!ws->probe_col) {
-      KS_HIP(hipMalloc(&ws->probe_col, (size_t)ws->ld * sizeof(D)));
+      if (hipMalloc(&ws->probe_col, (size_t)ws->ld * sizeof(D)) != hipSuccess) {   // (no room for one more column: no watch, no failure)
+        (void)hipGetLastError();
+        ws->probe_col = nullptr;
+        return;
+      }
       KS_HIP(hipMemsetAsync(ws->probe_col, 0, (size_t)ws->ld * sizeof(D), s_));
     }
     D* scratch = static_cast<D*>(ws->probe_col);
@@ -446,8 +456,12 @@ template <class T> struct HipBackend : ks::Backend<T> {
     KS_HIP(hipGetLastError());
     if (ws->ctx->distributed()) ws->ctx->allreduce(out, 2);
     KS_HIP(hipMemcpyAsync(ws->probe_host, out, 2 * sizeof(double), hipMemcpyDeviceToHost, s_));
+    // (several ranks: no sequence word travels with the sums -- an event behind the copy says whether they have arrived; a restart
+    // whose rotation went through an armed gate does not synchronise the stream, and zeros read too early would pass for "calm")
+    if (!ws->rp_event) KS_HIP(hipEventCreateWithFlags(&ws->rp_event, hipEventDisableTiming));
+    KS_HIP(hipEventRecord(ws->rp_event, s_));
     ws->rp_fro = std::sqrt(fro2);
-    ws->rp_inflight = true;   // (read at the start of the next expansion, behind the restart's synchronisation)
+    ws->rp_inflight = true;   // (read at the start of the next expansion)
   }
   // (after the batch's results arrived: the copy above completed before the publication behind it started)
   void drift_probe_collect() {
@@ -458,8 +472,12 @@ template <class T> struct HipBackend : ks::Backend<T> {
       // (written by the last workgroup of k_relation_watch; a batch that stopped early, or a stream that was not synchronised in
       // between -- a caller that went straight into the next expansion --, leaves the sequence word behind: no measurement)
       if (__atomic_load_n(reinterpret_cast<const volatile uint64_t*>(&res[2]), __ATOMIC_ACQUIRE) == 0 || res[2] != ws->rp_seq) return;
-    } else if (ws->st_h->breakdown >= 0 || ws->st_h->blk_bail >= 0) {
-      return;
+    } else {
+      if (!ws->rp_event || hipEventQuery(ws->rp_event) != hipSuccess) {   // the copy has not completed: no measurement this time
+        (void)hipGetLastError();
+        return;
+      }
+      if (ws->st_h->breakdown >= 0 || ws->st_h->blk_bail >= 0) return;
     }
     const double fro = ws->rp_fro;
     const double leak = res[1] > 0.0 ? std::sqrt(res[0] * ((double)ws->n_global / res[1])) : 0.0;

@@ -98,6 +98,24 @@ template <class D> int launch_blk(ks_workspace* ws, int which, int k, int s, boo
 
 // Steps from..to as blocks of the given sizes.  Every column is an ordinary one on entry (the caller materialised): T = I
 // below `from`, ws->ntrue == from.
+// The scratch columns of a block whose first pass is fused with the restart rotation (and of the speculative chain):
+// blk_smax<D>() columns of ld elements -- 1.6 GB at n = 1e7, Float64, on top of a 3.3-GB basis (documented in include/kschur.h).
+// Allocated on first use; false when the device has no room: the caller then takes the path that needs none (ordinary rotation,
+// chain written to the basis) -- a workspace that fitted the device before the fused rotation existed must still run.
+template <class D> bool ensure_zscratch(ks_workspace* ws) {
+  if (ws->zscratch) return true;
+  const size_t zbytes = (size_t)ws->ld * ksd::blk_smax<D>() * sizeof(D);
+  if (hipMalloc(&ws->zscratch, zbytes) != hipSuccess) {
+    (void)hipGetLastError();
+    ws->zscratch = nullptr;
+    ws->spec_on = false;        // no speculative chains either
+    ws->rot_defer_on = false;   // restarts rotate at once from here on
+    return false;
+  }
+  KS_HIP(hipMemsetAsync(ws->zscratch, 0, zbytes, ws->ctx->stream));   // the pad rows (n .. ld) stay zero: operators write rows < n only
+  return true;
+}
+
 template <class D>
 void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::vector<int>& sizes, const ksd::BlkShifts<D>& sh) {
   ks_ctx* cx = ws->ctx;
@@ -121,10 +139,7 @@ void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::v
     ws->rot_split = false;
     char* zs = nullptr;
     if (fuse) {
-      if (!ws->zscratch) {
-        KS_HIP(hipMalloc(&ws->zscratch, (size_t)ws->ld * ksd::kBlkSMax * sizeof(D)));
-        KS_HIP(hipMemsetAsync(ws->zscratch, 0, (size_t)ws->ld * ksd::kBlkSMax * sizeof(D), s_));   // the pad rows (n .. ld) stay zero: operators write rows < n only
-      }
+      KS_REQUIRE(ws->zscratch != nullptr, KS_ERR_INTERNAL, "fused rotation without scratch columns (the adoption allocates them)");
       zs = static_cast<char*>(ws->zscratch);
     }
     if (split) {

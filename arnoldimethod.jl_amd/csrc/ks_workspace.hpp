@@ -118,6 +118,7 @@ struct ks_workspace {
   void* watch_acc = nullptr;    // device: [sum, rows, ticket] of k_relation_watch
   void* probe_host_dev = nullptr;   // device address of probe_host
   int rp_every = 1, rp_count = 0, rp_done = 0;
+  hipEvent_t rp_event = nullptr;   // several ranks: recorded behind the copy of a watch's sums (drift_probe_collect asks it)
   bool rp_inflight = false;
   double rp_fro = 0.0, rp_last = 0.0, rp_seq = 0.0;
   double watch_tol = 0.0;       // convergence tolerance of the driver that ran the last restart (note_ritz), 0: not known
@@ -212,6 +213,7 @@ struct ks_workspace {
     (void)hipFree(Hscratch); (void)hipFree(partial); (void)hipFree(partial_s); (void)hipFree(partial2); (void)hipFree(coef); (void)hipFree(red);
     (void)hipFree(scal); (void)hipHostFree(scal_h); (void)hipHostFree(coef_h);
     if (zscratch) (void)hipFree(zscratch);
+    if (rp_event) (void)hipEventDestroy(rp_event);
     if (probe_col) (void)hipFree(probe_col);
     if (watch_acc) (void)hipFree(watch_acc);
     if (probe_dev) (void)hipFree(probe_dev);

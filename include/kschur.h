@@ -283,6 +283,11 @@ int ks_workspace_relation_probes(const ks_workspace* ws, int* probes);
  * *spec_adopted = chains the next expansion took over, *spec_dropped = chains that were void by then (the restart did not leave
  * its rotation pending, or something else touched the basis in between).  Any pointer may be null. */
 int ks_workspace_fused_rotations(const ks_workspace* ws, int* count, int* spec_adopted, int* spec_dropped);
+/* Memory: the fused rotation and the speculative chain keep the Newton chain of a block in scratch columns of their own -- 20
+ * (Float64) / 10 (ComplexF64) columns of the workspace's leading dimension, allocated at the first restart that leaves its rotation
+ * pending (1.6 GB at n = 1e7 next to a 3.3-GB basis of 41 columns); the drift watch keeps one more column.  When the device has no
+ * room for them the library falls back to the paths that need none (rotation at once, no speculation, no watch) instead of failing:
+ * a workspace that fits the device without these features runs with them switched off. */
 /* Pending restart rotations (src/run.jl:363-365) for whose shape or element type there is no fused kernel (ComplexF64; Float64
  * shapes outside the instantiated ones): the ordinary rotation kernel runs when the next expansion is enqueued and BOTH passes of
  * its first block read the Newton chain from scratch columns -- what this buys is that the speculative chain (above) can run
