@@ -456,7 +456,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
     KS_HIP(hipGetLastError());
     if (ws->ctx->distributed()) ws->ctx->allreduce(out, 2);
     KS_HIP(hipMemcpyAsync(ws->probe_host, out, 2 * sizeof(double), hipMemcpyDeviceToHost, s_));
-    // (several ranks: no sequence word travels with the sums -- an event behind the copy says whether they have arrived; a restart
+    // (several ranks: no sequence word travels with the sums -- an event behind the copy is what the collection waits for; a restart
     // whose rotation went through an armed gate does not synchronise the stream, and zeros read too early would pass for "calm")
     if (!ws->rp_event) KS_HIP(hipEventCreateWithFlags(&ws->rp_event, hipEventDisableTiming));
     KS_HIP(hipEventRecord(ws->rp_event, s_));
@@ -473,10 +473,11 @@ template <class T> struct HipBackend : ks::Backend<T> {
       // between -- a caller that went straight into the next expansion --, leaves the sequence word behind: no measurement)
       if (__atomic_load_n(reinterpret_cast<const volatile uint64_t*>(&res[2]), __ATOMIC_ACQUIRE) == 0 || res[2] != ws->rp_seq) return;
     } else {
-      if (!ws->rp_event || hipEventQuery(ws->rp_event) != hipSuccess) {   // the copy has not completed: no measurement this time
-        (void)hipGetLastError();
-        return;
-      }
+      // WAIT for the copy (it was enqueued a whole restart ago: normally long done).  Not a query: whether a rank sees the sums
+      // must not depend on its timing -- the ranks take every decision alike (a rank that skipped a measurement would skip the
+      // next watch's all-reduce too, and the others would wait for it forever)
+      if (!ws->rp_event) return;
+      KS_HIP(hipEventSynchronize(ws->rp_event));
       if (ws->st_h->breakdown >= 0 || ws->st_h->blk_bail >= 0) return;
     }
     const double fro = ws->rp_fro;

@@ -178,9 +178,12 @@ def test_blocks_whose_last_tile_is_empty(dtype, mindim, maxdim):
         if cyc == 0:
             continue
         assert info["blocks"] > 0 and info["abandoned"] == 0, info
-        assert np.abs(Hs - Hb).max() <= 1e-11 * np.abs(Hs).max(), (cyc, np.abs(Hs - Hb).max())
-        assert np.abs(Vs - Vb).max() <= 1e-9, (cyc, np.abs(Vs - Vb).max())
-        assert rel <= 1e-12 * np.linalg.norm(Hb) * 10 and orth <= 1e-13
+        if cyc == 1:   # (the first block cycle starts from identical columns; afterwards the restarts of two valid computations --
+                       # 40 of 44 Ritz values kept, nearly degenerate pairs among them -- move the leading columns apart by 1e-10)
+            assert np.abs(Hs - Hb).max() <= 1e-11 * np.abs(Hs).max(), (cyc, np.abs(Hs - Hb).max())
+            assert np.abs(Vs - Vb).max() <= 1e-9, (cyc, np.abs(Vs - Vb).max())
+        # ... and EVERY cycle against the invariants: a slab read before its copy landed is garbage in the block, not rounding
+        assert rel <= 1e-12 * np.linalg.norm(Hb) * 10 and orth <= 1e-13, (cyc, rel, orth)
         seen += 1
     assert seen >= 1
 
