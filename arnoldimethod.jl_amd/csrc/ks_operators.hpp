@@ -181,6 +181,27 @@ template <class D> struct CsrOp : ks_operator {
       auto go = [&](auto ns_tag, auto ko_tag) {
         ksd::k_spmv_stencil_march<decltype(ns_tag)::value, decltype(ko_tag)::value><<<G, kBlock, 0, s>>>(m2, sdict, x, y, n_local, nt, st, sh, shift_theta, shift_sigma);
       };
+      // the 3-D 7-point shape (far, near, near, own, near, near, far with the near taps within 256 rows): the window form -- the five
+      // near taps of a tile from one copy of its rows in LDS (ks_spmv_march.hpp; 47 against 49 us in the solver's chain,
+      // profiles/r06_spmv_columns.txt).  KS_MARCH_WINDOW=0: the register form for every shape.
+      static const int window = env_int("KS_MARCH_WINDOW", 1);
+      if (window && nstencil == 7 && kown == 3) {
+        bool shape = std::llabs((long long)sdict.delta[0]) > 256 && std::llabs((long long)sdict.delta[6]) > 256;
+        unsigned odd = 0;
+        for (int k = 1; k <= 5; ++k) {
+          shape = shape && std::llabs((long long)sdict.delta[k]) <= 256;
+          if (sdict.delta[k] & 1) odd |= 1u << k;
+        }
+        if (shape) {
+          auto gw = [&](auto odd_tag) {
+            ksd::k_spmv_stencil_marchw<7, 0x3eu, decltype(odd_tag)::value, 3><<<G, kBlock, 0, s>>>(m2, sdict, x, y, n_local, nt, st, sh, shift_theta, shift_sigma);
+          };
+          if (odd == 0x14u) gw(std::integral_constant<unsigned, 0x14u>{});        // nx even: only +-1 are odd
+          else if (odd == 0x36u) gw(std::integral_constant<unsigned, 0x36u>{});   // nx odd
+          else gw(std::integral_constant<unsigned, 0x3eu>{});                     // anything else: every near tap as two 8-byte reads
+          return;
+        }
+      }
       using M1 = std::integral_constant<int, -1>;
       // the slot of the rows' own entry is a compile-time constant for the common stencils (3-, 5-, 7-point); otherwise one more load
       if (nstencil == 7 && kown == 3) go(std::integral_constant<int, 7>{}, std::integral_constant<int, 3>{});

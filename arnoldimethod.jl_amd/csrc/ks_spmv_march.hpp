@@ -18,6 +18,7 @@
 // Products rounded separately, added in slot order: y is bit-identical to every other layout.
 #pragma once
 
+#include <algorithm>
 #include <type_traits>
 
 #include "ks_kernels.hpp"
@@ -242,6 +243,199 @@ __global__ void __launch_bounds__(kBlock)
     const bool has_a = t < hi;
     if (has_a) issue(t, A);
     finish(tn, B, has_a ? NL + 1 : 1);
+    if (!has_a) break;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// WINDOW form of the marching kernel: the NEAR taps (|delta| <= 256: -nx, -1, 0, +1, +nx of a 3-D grid) of a tile come from ONE
+// copy of the rows [512 t - 256, 512 t + 768) in LDS -- 8 KiB per tile, filled by asynchronous global -> LDS copies (two 1-KiB
+// pieces per wave, no registers), shared by the four waves -- instead of five 16-byte gathers per lane.  In the chain the solver
+// runs, every pair of taps that goes through the address / L1 path costs 5-8 us of a 50-us product whether or not its lines are
+// in L2 (profiles/r06_spmv_columns.txt: 1 slot 36 us, +-1 38, +-nx 45, +-P 50): per tile the vector-memory path moves 8 (window) +
+// 8 (two far pairs) + 4 (store) + 0.5 KiB instead of 36.5.  Far taps and masks as in k_spmv_stencil_march (registers, one tile
+// ahead); two window buffers, ONE workgroup barrier per tile: behind it every wave's pieces of tile t have landed and everybody
+// has finished reading the buffer of tile t - 1, which the copies of tile t + 1 then overwrite.
+//   NEARM: bit k = slot k is a near tap (the host checks |delta_k| <= 256 for those, > 256 for the others)
+//   ODDM:  bit k = near slot k is read as two 8-byte elements (delta odd or unknown); clear: one aligned 16-byte read (delta even)
+//   KOWN:  the near slot with delta 0 (the rows' own pair of the Newton step; required)
+__device__ __forceinline__ void march_glds16(uint32_t voff, const void* sbase, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+template <int NSLOT, unsigned NEARM, unsigned ODDM, int KOWN>
+__global__ void __launch_bounds__(kBlock)
+    k_spmv_stencil_marchw(const uint16_t* __restrict__ mask2, const StencilDict<double> d, const double* __restrict__ x,
+                          double* __restrict__ y, int64_t n, int ntiles, const DevState* __restrict__ st, int shifted, double theta,
+                          double sigma) {
+  static_assert(KOWN >= 0 && ((NEARM >> KOWN) & 1u), "the own pair is a near tap");
+  if (st && st->breakdown >= 0) return;
+  __shared__ __attribute__((aligned(16))) unsigned char win[2][8192];
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, S = gridDim.x >> 3;
+  int64_t dmin = -256, dmax = 256;
+#pragma unroll
+  for (int k = 0; k < NSLOT; ++k) {
+    dmin = d.delta[k] < dmin ? d.delta[k] : dmin;
+    dmax = d.delta[k] > dmax ? d.delta[k] : dmax;
+  }
+  const uint32_t lane_b = threadIdx.x * 16u, lane_m = threadIdx.x * 2u;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t lane_w = (threadIdx.x & 63u) * 16u;          // this lane's 16 bytes inside a 1-KiB piece
+  const uint32_t win0 = (uint32_t)(uintptr_t)&win[0][0];
+  const bool plain_st = (shifted & 2) != 0;
+  int tend;
+  int t = march_tile(xcd, slot, 0, S, ntiles, tend);
+  constexpr int NFAR = NSLOT - __builtin_popcount(NEARM & ((1u << NSLOT) - 1u));
+  constexpr int NL = 2 + NFAR + 1;   // vector-memory loads of a tile and wave: two window pieces, the far pairs, the masks
+
+  struct Tile {
+    f64x2m v[NSLOT];   // (far slots only)
+    uint32_t m;
+  };
+  auto issue = [&](int tt, Tile& T, int buf) {
+    const int64_t r0 = (int64_t)tt * 512;
+    const double* b[NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+      b[k] = x + (r0 + d.delta[k]);
+      asm volatile("" : "+s"(b[k]));
+    }
+    const double* bw = x + (r0 - 256 + (int64_t)wave * 256);   // this wave's two pieces: window elements [256 w, 256 w + 256)
+    const uint16_t* bm = mask2 + (r0 >> 1);
+    uint32_t ldst = win0 + (uint32_t)buf * 8192u + (uint32_t)wave * 2048u;
+    asm volatile("" : "+s"(bw));
+    asm volatile("" : "+s"(bm));
+    asm volatile("" : "+s"(ldst));
+    asm volatile("s_nop 4" ::: "memory");
+    march_glds16(lane_w, bw, ldst);
+    march_glds16(lane_w + 1024u, bw, ldst + 1024u);
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k)
+      if (!((NEARM >> k) & 1u)) march_ld16(T.v[k], lane_b, b[k]);
+    march_ld_u16(T.m, lane_m, bm);
+  };
+  // behind the wait and the barrier: near pairs from the window, far pairs from the registers
+  auto finish = [&](int tt, Tile& T, int buf, bool first) {
+    if (first) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");   // (the store of the tile before may still be on its way)
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k)
+      if (!((NEARM >> k) & 1u)) asm volatile("" : "+v"(T.v[k]));
+    asm volatile("" : "+v"(T.m));
+  };
+  auto compute = [&](int tt, Tile& T, int buf) {
+    const unsigned char* w = &win[0][0] + buf * 8192 + (256 * 8) + threadIdx.x * 16;   // element 256 + 2 T: this lane's own pair
+    f64x2m v[NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+      if ((NEARM >> k) & 1u) {
+        const int off = (int)d.delta[k] * 8;   // scalar
+        if (((ODDM >> k) & 1u) == 0) {   // (a constant once the loop is unrolled)
+          v[k] = *reinterpret_cast<const f64x2m*>(w + off);
+        } else {
+          typedef double f64x2u8 __attribute__((ext_vector_type(2), aligned(8)));
+          const f64x2u8 p = *reinterpret_cast<const f64x2u8*>(w + off);
+          v[k].x = p.x;
+          v[k].y = p.y;
+        }
+      } else {
+        v[k] = T.v[k];
+      }
+    }
+    const int m0 = (int)(T.m & 0xffu), m1 = (int)(T.m >> 8);
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+      const double p0 = mul_nc(d.val[k], v[k].x), p1 = mul_nc(d.val[k], v[k].y);
+      s0 = add_(s0, and_mask(p0, __builtin_amdgcn_sbfe(m0, k, 1)));
+      s1 = add_(s1, and_mask(p1, __builtin_amdgcn_sbfe(m1, k, 1)));
+    }
+    if (shifted) {
+      s0 = scl(sub_s(s0, mul_(theta, v[KOWN].x)), sigma);
+      s1 = scl(sub_s(s1, mul_(theta, v[KOWN].y)), sigma);
+    }
+    f64x2m o2;
+    o2.x = s0;
+    o2.y = s1;
+    double* by = y + (int64_t)tt * 512;
+    asm volatile("" : "+s"(by));
+    // (the window reads above have returned before the store is issued: their values are its operands; the next barrier is
+    // therefore behind every read of this buffer)
+    march_st16(lane_b, o2, by, plain_st);
+  };
+  // the clamped path of k_spmv_stencil2 for the tiles next to the ends of the vector
+  auto edge = [&](int tt) {
+    const int64_t r = (int64_t)tt * 512 + 2 * (int64_t)threadIdx.x;
+    if (r >= n) return;
+    const bool two = r + 1 < n;
+    const uint32_t m = mask2[r >> 1];
+    const uint32_t m0 = m & 0xffu, m1 = m >> 8;
+    const int64_t cmax = n - 2;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+      const int64_t c = r + d.delta[k];
+      int64_t lo = c < 0 ? 0 : (c > cmax ? cmax : c);
+      if (cmax < 0) lo = 0;
+      const int sh = (int)(c - lo);
+      double xa, xb;
+      if (n >= 2) ld_pair_u(x + lo, xa, xb);
+      else { xa = x[0]; xb = x[0]; }
+      const double v0 = sh == 1 ? xb : xa, v1 = sh == -1 ? xa : xb;
+      const double p0 = mul_nc(d.val[k], v0), p1 = mul_nc(d.val[k], v1);
+      s0 = ((m0 >> k) & 1u) ? add_(s0, p0) : s0;
+      s1 = ((m1 >> k) & 1u) ? add_(s1, p1) : s1;
+    }
+    if (shifted) {
+      double x0, x1;
+      if (two) ld_pair_u(x + r, x0, x1);
+      else { x0 = x[r]; x1 = x0; }
+      s0 = scl(sub_s(s0, mul_(theta, x0)), sigma);
+      s1 = scl(sub_s(s1, mul_(theta, x1)), sigma);
+    }
+    if (two) {
+      if (plain_st) st_pack(y + r, make_double2(s0, s1));
+      else st_pack_nt(y + r, make_double2(s0, s1));
+    } else {
+      if (plain_st) y[r] = s0;
+      else st_elem_nt(y + r, s0);
+    }
+  };
+  // interior tiles: every slot of every row AND the whole window inside [0, n)
+  int64_t lo64 = (-dmin + 511) / 512, hi64 = (n - (dmax > 768 ? dmax + 1 : 768)) / 512;   // r0 + dmin >= 0;  r0 + max(512 + dmax + 1, 768) <= n
+  if (n - 512 - dmax - 1 < 0 || n < 768) hi64 = 0;
+  else hi64 = std::min<int64_t>((n - 512 - dmax - 1) / 512, (n - 768) / 512) + 1;
+  if (hi64 > ntiles) hi64 = ntiles;
+  if (lo64 > hi64) lo64 = hi64;
+  const int t_lo = (int)lo64, t_hi = (int)hi64;
+  if (t < t_lo || tend > t_hi) {
+    for (int te = t; te < tend; te += S)
+      if (te < t_lo || te >= t_hi) edge(te);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  while (t < t_lo) t += S;
+  const int hi = tend < t_hi ? tend : t_hi;
+  // (every wave of a workgroup runs the same number of rounds: the barriers match)
+  if (t >= hi) return;
+  Tile A, B;
+  issue(t, A, 0);
+  bool first = true;
+  for (;;) {
+    const int tn = t + S;
+    const bool has_b = tn < hi;
+    finish(t, A, 0, first);
+    if (has_b) issue(tn, B, 1);
+    compute(t, A, 0);
+    first = false;
+    if (!has_b) break;
+    t = tn + S;
+    const bool has_a = t < hi;
+    finish(tn, B, 1, false);
+    if (has_a) issue(t, A, 0);
+    compute(tn, B, 1);
     if (!has_a) break;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -17,6 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import isa_audit  # noqa: E402
 
 INSTANCES = [(7, 3), (5, 2), (3, 1), (1, -1), (4, -1), (7, -1), (8, -1)]
+WINDOW_INSTANCES = [(7, 0x3E, 0x14, 3), (7, 0x3E, 0x36, 3), (7, 0x3E, 0x3E, 3)]   # the window form the solver launches for 3-D 7-point shapes
 NEAR_INSTANCES = [(7, 3, 2, 4), (5, 2, 1, 3)]   # the +-1 taps from the neighbouring lanes (tools/spmv_slab.hip measures it; not dispatched)
 
 
@@ -31,10 +32,21 @@ def listing(tmp_path_factory):
                      f"int64_t, int, const ksd::DevState*, int, double, double);" for ns, ko in INSTANCES)
     inst += "\n" + "\n".join(f"template __global__ void ksd::k_spmv_stencil_march<{a}, {b}, {c}, {e}>(const uint16_t*, const ksd::StencilDict<double>, const double*, double*, "
                              f"int64_t, int, const ksd::DevState*, int, double, double);" for a, b, c, e in NEAR_INSTANCES)
+    inst += "\n" + "\n".join(f"template __global__ void ksd::k_spmv_stencil_marchw<{a}, {b}u, {c}u, {e}>(const uint16_t*, const ksd::StencilDict<double>, const double*, double*, "
+                             f"int64_t, int, const ksd::DevState*, int, double, double);" for a, b, c, e in WINDOW_INSTANCES)
     src.write_text(f'#include "{ROOT}/arnoldimethod.jl_amd/csrc/ks_spmv_march.hpp"\n{inst}\n')
     out = d / "march_inst.s"
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", str(src), "-o", str(out)])
     return out.read_text()
+
+
+@pytest.mark.parametrize("a,b,c,e", WINDOW_INSTANCES)
+def test_the_window_form(listing, a, b, c, e):
+    """register loads of the window form: the two far pairs and the masks, at three issue sites (the window pieces are LDS copies:
+    no register in flight); and its LDS reads sit behind the hand-written wait + barrier (the audit treats any vmcnt wait as one)"""
+    nloads, bad = isa_audit.audit(listing, f"k_spmv_stencil_marchwILi{a}ELj{b}ELj{c}ELi{e}E")
+    assert nloads >= 3 * 3 and nloads % 3 == 0, nloads
+    assert not bad, bad[:5]
 
 
 @pytest.mark.parametrize("a,b,c,e", NEAR_INSTANCES)

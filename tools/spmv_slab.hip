@@ -75,6 +75,7 @@ void launch(int var, const Problem& pr, const double* x, double* y, int shifted)
     case 14: k_spmv_stencil_march<7, 3><<<256 * 8, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
     case 15: k_spmv_stencil_march<7, 3><<<256 * 3, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
     case 16: k_spmv_stencil_march<7, 3><<<256 * 5, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
+    case 24: k_spmv_stencil_marchw<7, 0x3eu, 0x14u, 3><<<g_G, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
     case 23: k_spmv_stencil_march<7, 3, 2, 4><<<g_G, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
     case 19: k_spmv_stencil_march<1, 0><<<g_G, 256>>>(g_m1, g_d1, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
     case 20: k_spmv_stencil_march<3, 1><<<g_G, 256>>>(g_m1, g_d3, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
@@ -150,7 +151,8 @@ int main(int argc, char** argv) {
       int shf = 3;
       if (sarg < 0) { sarg = -sarg; shf = 1; }            // negative: streaming (nt) stores instead of cacheable ones
       int var = sarg == 0 ? 0 : 17;
-      if (sarg >= 60000) { sarg -= 60000; var = 23; }
+      if (sarg >= 70000) { sarg -= 70000; var = 24; }
+      else if (sarg >= 60000) { sarg -= 60000; var = 23; }
       else if (sarg >= 50000) { sarg -= 50000; var = 22; }
       else if (sarg >= 40000) { sarg -= 40000; var = 21; }
       else if (sarg >= 30000) { sarg -= 30000; var = 20; }
@@ -165,7 +167,7 @@ int main(int argc, char** argv) {
         if (!pass) continue;
         for (int i = 0; i < 20; ++i) { float ms; CK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); tot += ms; mn = ms < mn ? ms : mn; mx = ms > mx ? ms : mx; per[i] += ms / 3; }
       }
-      printf("%d x %d x %d  columns chain  %s stores  %-18s S=%-4d  mean %.1f us  min %.1f  max %.1f   per product:", m, my, mz, shf == 3 ? "cacheable" : "streaming", var == 18 ? "plain copy" : var == 19 ? "march 1 slot" : var == 20 ? "march -1 0 +1" : var == 21 ? "march 5 near" : var == 22 ? "march -P 0 +P" : var == 23 ? "march near-by-dpp" : var ? "march" : "k_spmv_stencil2", var ? g_G / 8 : 0, tot / 60 * 1e3, mn * 1e3, mx * 1e3);
+      printf("%d x %d x %d  columns chain  %s stores  %-18s S=%-4d  mean %.1f us  min %.1f  max %.1f   per product:", m, my, mz, shf == 3 ? "cacheable" : "streaming", var == 18 ? "plain copy" : var == 19 ? "march 1 slot" : var == 20 ? "march -1 0 +1" : var == 21 ? "march 5 near" : var == 22 ? "march -P 0 +P" : var == 23 ? "march near-by-dpp" : var == 24 ? "march LDS window" : var ? "march" : "k_spmv_stencil2", var ? g_G / 8 : 0, tot / 60 * 1e3, mn * 1e3, mx * 1e3);
       for (int i = 0; i < 20; ++i) printf(" %.0f", per[i] * 1e3);
       printf("\n");
       fflush(stdout);
@@ -180,7 +182,8 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(r1.data(), y1, n * 8, hipMemcpyDeviceToHost));
     for (int ai = 5; ai < argc; ++ai) {
       int sv = atoi(argv[ai]);
-      const int mvar = sv < 0 ? 23 : 17;      // negative: the form with the +-1 taps from the neighbouring lanes
+      int mvar = sv < 0 ? 23 : 17;      // negative: the form with the +-1 taps from the neighbouring lanes
+      if (sv >= 70000) { sv -= 70000; mvar = 24; }   // 70000 + S: the window form
       g_G = (sv < 0 ? -sv : sv) * 8;
       float best = 1e9f;
       CK(hipMemset(y2, 0xff, n * 8));
@@ -199,7 +202,7 @@ int main(int argc, char** argv) {
       for (int i = 0; i < 20; ++i) launch(mvar, pr, i == 0 ? pr.xs : (i & 1 ? y1 : y2), (i & 1) ? y2 : y1, 3);
       CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
       float ms; CK(hipEventElapsedTime(&ms, a, b));
-      printf("%d x %d x %d  march%s S=%d (G=%d, %.2f wg/CU, plane = %.1f tiles)  cold %.1f us  chain %.1f us  %s\n", m, my, mz, mvar == 23 ? " (near taps by dpp)" : "", g_G / 8, g_G, g_G / 256.0, pr.P / 512.0,
+      printf("%d x %d x %d  march%s S=%d (G=%d, %.2f wg/CU, plane = %.1f tiles)  cold %.1f us  chain %.1f us  %s\n", m, my, mz, mvar == 23 ? " (near taps by dpp)" : mvar == 24 ? " (LDS window)" : "", g_G / 8, g_G, g_G / 256.0, pr.P / 512.0,
              best * 1e3, ms * 1e3 / 20, same ? "bit-identical" : "DIFFER");
       fflush(stdout);
     }
