@@ -791,6 +791,22 @@ def make_line(args, pkg, passes, order, world, rank, force_dist, wl, with_cpu_ba
     return out
 
 
+def julia_runtests(julia, timeout=600):
+    """First contact with the reference's own language: when the box has a `julia` that can load ArnoldiMethod, run
+    arnoldimethod.jl_amd/julia/runtests.jl (the reference's test/expansion.jl and test/partial_schur.jl on a device basis through
+    the reference's own partialschur!) and record what happened -- never part of the timed region, never fatal.  None: no Julia."""
+    if not julia:
+        return None
+    import subprocess
+
+    script = os.path.join(ROOT, "arnoldimethod.jl_amd", "julia", "runtests.jl")
+    try:
+        r = subprocess.run([julia, "--startup-file=no", script], capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+        return {"rc": r.returncode, "tail": (r.stdout + r.stderr)[-1500:]}
+    except Exception as e:  # noqa: BLE001
+        return {"rc": None, "tail": f"{type(e).__name__}: {e}"[:500]}
+
+
 def cpu_baseline(pkg, A_host, n, nev, which, mindim, maxdim):
     """The reference's op sequence on the host cores (oracle/cpu_backend.cpp, kind "port": Julia is not in the image --
     `julia_on_box` records whether the GPU box has one).  Bounded samples of the same workload:
@@ -803,6 +819,7 @@ def cpu_baseline(pkg, A_host, n, nev, which, mindim, maxdim):
 
     out = {"value": None, "unit": "iters/s", "cores": 0, "kind": "port", "sample": "", "julia_on_box": shutil.which("julia"),
            "logical_cpus": os.cpu_count(), "cpu_quota": CPU_BUDGET}
+    out["julia_runtests"] = julia_runtests(out["julia_on_box"])
     try:
         from oracle import cpuref
 

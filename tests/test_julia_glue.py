@@ -286,3 +286,40 @@ def test_glue_vouches_for_the_factorisation_before_the_fused_expansion():
     a, b = body.find(":ks_workspace_assert_arnoldi"), body.find(":ks_iterate_arnoldi")
     assert 0 <= a < b, "assert_arnoldi must precede ks_iterate_arnoldi in iterate_arnoldi!"
     assert "three passes over V per step" not in src
+
+
+def test_runtests_file_is_well_formed_and_only_uses_what_exists():
+    """arnoldimethod.jl_amd/julia/runtests.jl (the reference's test sets on a device basis) cannot be executed here either: block
+    structure balanced, every KrylovSchurHIP name it uses is exported by the module, every reference name it imports is one the
+    reference's own tests import, and every test set cites the reference lines it replays; bench.py runs it when the box has Julia."""
+    rt = open(os.path.join(ROOT, "arnoldimethod.jl_amd", "julia", "runtests.jl")).read()
+    code = "\n".join(l.split("#")[0] for l in rt.splitlines())
+    flat = code
+    while re.search(r"\[[^\[\]]*\]", flat):     # `x[end]`, `[f(k) for k = 1:10]`: keywords inside brackets open / close nothing
+        flat = re.sub(r"\[[^\[\]]*\]", "", flat)
+    code, full = flat, code
+    opens = len(re.findall(r"\b(begin|for|function|if|let|while|do|struct|module|try)\b", code))
+    ends = len(re.findall(r"\bend\b", code))
+    assert opens == ends, (opens, ends)
+    jl = open(JL).read()
+    exported = set(re.search(r"^export (.*)$", jl, flags=re.M).group(1).replace(" ", "").split(","))
+    for name in ("HipContext", "HipOperator", "HipBasis", "hip_partialschur"):
+        assert name in exported and re.search(r"\b%s\b" % name, rt), name
+    used = set(re.findall(r"\b(Hip[A-Za-z]+|hip_[a-z_!]+)\b", full)) - {"hip_workspace"}
+    assert used <= exported, used - exported
+    imported = re.search(r"^using ArnoldiMethod: (.*)$", rt, flags=re.M).group(1).replace(" ", "").split(",")
+    for name in imported:
+        assert re.search(r"\b%s\b" % re.escape(name), jl) or name in ("partialeigen", "eigenvalues", "partialschur", "partialschur!"), name
+    sets = re.findall(r"@testset \"([^\"]+)\"", rt)
+    assert len(sets) >= 12
+    cites = re.findall(r"# -+ (test/[a-z_]+\.jl:\d+-\d+|readme\.md:\d+-\d+)", rt)
+    assert len(cites) >= 12, cites
+    ref = "/root/reference"
+    if os.path.isdir(ref):   # (only in the build container: the GPU box has no reference)
+        for c in cites:
+            f, rng = c.split(":")
+            a, b = map(int, rng.split("-"))
+            nl = len(open(os.path.join(ref, f)).read().splitlines())
+            assert 1 <= a <= b <= nl, c
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert "runtests.jl" in bench and "julia_runtests" in bench
