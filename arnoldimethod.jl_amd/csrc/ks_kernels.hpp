@@ -2204,6 +2204,10 @@ struct RotGate {
   uint64_t flag;
   int32_t c, r, out0, extra_out, ldq, cancel, nq, pad_;
   uint64_t timed_out;     // device -> host: the gate gave up waiting (sequence number)
+  // device -> host: (sequence number << 1) | (0: took the release, 1: gave up / was cancelled), written as soon as the gate has
+  // decided.  The host reads it back after releasing: a gate that gave up between the host's last look at `timed_out` and its
+  // release would otherwise leave the host believing in a rotation that never ran (round-4 advice).
+  uint64_t taken;
 };
 static __global__ void __launch_bounds__(kBlock) k_rot_gate(RotGate* __restrict__ host, uint64_t seq, RotGate* __restrict__ dev,
                                                             const double* __restrict__ q_host, double* __restrict__ q_dev,
@@ -2220,6 +2224,7 @@ static __global__ void __launch_bounds__(kBlock) k_rot_gate(RotGate* __restrict_
       else __builtin_amdgcn_s_sleep(8);
     }
     state = st;
+    __hip_atomic_store(&host->taken, (seq << 1) | (st == 1 ? 0u : 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
   if (state != 1) {

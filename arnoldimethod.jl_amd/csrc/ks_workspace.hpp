@@ -1098,10 +1098,23 @@ template <class T> void rotate_tfold(ks_workspace* ws, int c0, int c, int r, con
         g->c = cin; g->r = rr; g->out0 = out0; g->extra_out = extra_elsewhere ? dst : -1; g->ldq = cin; g->nq = cin * rr; g->cancel = 0;
         __atomic_store_n(&g->flag, ws->gate_seq << 1, __ATOMIC_RELEASE);
         ws->gate_armed = false;
-        ws->t_lazy = false;
-        ws->t_hi = -1;
-        ws->blk_tail = false;
-        return;
+        // which way did the gate go?  It answers within one poll of the word it spins on (a few microseconds); it may have given
+        // up between the look at `timed_out` above and the release -- then the rotation behind it has returned without
+        // rotating and the ordinary sequence below does it.  (No answer within 2 ms: the gate kernel has not STARTED polling yet --
+        // other work sits in front of it -- and will find the word released when it does: it cannot time out any more.)
+        bool took = true;
+        const double t_ack = ks::now_s();
+        for (;;) {
+          const uint64_t a = __atomic_load_n(&g->taken, __ATOMIC_ACQUIRE);
+          if ((a >> 1) == ws->gate_seq) { took = (a & 1u) == 0; break; }
+          if (ks::now_s() - t_ack > 2e-3) break;
+        }
+        if (took) {
+          ws->t_lazy = false;
+          ws->t_hi = -1;
+          ws->blk_tail = false;
+          return;
+        }
       }
     }
     gate_cancel(ws);  // (shape does not fit what was enqueued, or the gate gave up: the ordinary sequence)

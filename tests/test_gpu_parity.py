@@ -1020,7 +1020,8 @@ def _block_cycles_keep_the_relation(op, dtype, v1, nev, which, mindim, maxdim, c
         r = ws.restart(active, nev, which, tol, mindim, maxdim)
         k, active = r["k"], min(r["nlock"], nev - 1)
     info = ws.sstep_info
-    assert info["blocks"] > 0, info
+    if os.environ.get("KS_SSTEP", "") not in ("0", "1"):   # (the suite is also run with the block form switched off from outside)
+        assert info["blocks"] > 0, info
     return worst, info
 
 
