@@ -571,6 +571,13 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
       w->Vbase = w->V;
     }
     KS_HIP(hipMemsetAsync(w->V, 0, vbytes, ctx->stream));
+    if (env_int("KS_ZS_EARLY", 0)) {
+      // experiment (round 6, the out-of-place lottery of k_bupdate_mfma: 0.86 against 0.98 ms for the same launch, fixed per process):
+      // the scratch columns of the fused rotation allocated right behind the basis instead of lazily after everything else
+      const size_t zbytes = (size_t)w->ld * (dtype == KS_F64 ? ksd::kBlkSMax : 10) * esz;
+      if (hipMalloc(&w->zscratch, zbytes) == hipSuccess) KS_HIP(hipMemsetAsync(w->zscratch, 0, zbytes, ctx->stream));
+      else { (void)hipGetLastError(); w->zscratch = nullptr; }
+    }
     const size_t hbytes = (size_t)(maxdim + 1) * maxdim * esz, qbytes = (size_t)maxdim * maxdim * esz;
     const size_t qxbytes = (size_t)(maxdim + 1) * (maxdim + 1) * esz;  // T-folded rotations: one more row and column
     KS_HIP(hipHostMalloc(&w->H, hbytes));

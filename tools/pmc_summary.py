@@ -90,14 +90,14 @@ def main():
         elif k == "blk_rotate":
             # restart rotation fused with the first pass (k_brotdots_mfma<NGX, NTK, NT>): reads the old basis and the block,
             # writes the rotated columns; the block that follows starts on `kstart` columns
-            S = 4 * int(re.search(r"k_brotdots_mfma<\d+, \d+, (\d+)>", name).group(1))
+            S = 4 * int(re.search(r"k_brotdots_mfma<\d+, \d+, (\d+)[,>]", name).group(1))   # (<NGX, NTK, NT[, CX]>)
             blk_k = kstart
             alg = col * (rot_cols + S)
         elif k in ("blk_dots", "blk_fused"):
             # s-step kernels: k_bdots<double, NCW, S, ...> reads the kb existing columns and the S new ones, k_bupdate reads the
             # same and writes the S; kb starts at `kstart` after every rotation and grows by S per block
             if re.search(r"k_b(?:dots|update)_mfma<", name):
-                S = 4 * int(re.search(r"_mfma<\d+, (\d+)>", name).group(1))                       # (matrix-instruction forms: <NGS, NT>; s = 4 NT on the headline)
+                S = 4 * int(re.search(r"_mfma<\d+, (\d+)[,>]", name).group(1))                       # (matrix-instruction forms: <NGS, NT>; s = 4 NT on the headline)
             elif re.search(r"k_b(?:dots|update)_ringL<", name):
                 S = 20                                                                            # (large-block ring forms: <NCW>)
             else:
