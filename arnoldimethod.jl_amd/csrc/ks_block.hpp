@@ -113,6 +113,7 @@ template <class D> bool ensure_zscratch(ks_workspace* ws) {
     return false;
   }
   KS_HIP(hipMemsetAsync(ws->zscratch, 0, zbytes, ws->ctx->stream));   // the pad rows (n .. ld) stay zero: operators write rows < n only
+  if (env_int("KS_ADDR_DEBUG", 0)) std::fprintf(stderr, "[addr] V %p zscratch %p ld %lld bytes/col %lld\n", ws->V, ws->zscratch, (long long)ws->ld, (long long)(ws->ld * sizeof(D)));
   return true;
 }
 
