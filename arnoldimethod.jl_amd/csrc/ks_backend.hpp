@@ -695,6 +695,28 @@ template <class D> double placement_trio_ms(ks_workspace* w, hipEvent_t a, hipEv
   return best;
 }
 
+// The probe of a workspace that will run the BLOCK expansion: the second pass of one large block in place (k existing columns,
+// s new ones: 8 n (k + 2 s) bytes, zeros in, zeros out).  This is the launch whose time is BIMODAL with the basis' allocation --
+// 850-870 against 950-1000 us at n = 1e7, k = 21, s = 20, the same in place and from the scratch columns, unchanged by a fresh
+// allocation of the scratch columns, different between two allocations of the basis in one process
+// (tools/bupdate_lottery.py, profiles/r06_bupdate_lottery.txt) -- while the per-step launches above do not tell candidates apart.
+template <class D> double placement_block_ms(ks_workspace* w, int k, int s, hipEvent_t a, hipEvent_t b) {
+  ks_ctx* c = w->ctx;
+  blk_ensure_buffers(w);
+  reset_state(w);
+  float best = 1e30f;
+  for (int rep = 0; rep < 4; ++rep) {  // rep 0 warms up
+    KS_HIP(hipEventRecord(a, c->stream));
+    launch_blk<D>(w, 1, k, s);
+    KS_HIP(hipEventRecord(b, c->stream));
+    KS_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    KS_HIP(hipEventElapsedTime(&ms, a, b));
+    if (rep > 0) best = std::min(best, ms);
+  }
+  return best;
+}
+
 // Search policy (round 2: opt-in, bounded and exception-safe).  KS_PLACE_TRIALS=N (N >= 2) times N candidate
 // allocations of V and keeps the fastest; it HOLDS its candidates while it runs (a freed block would simply be handed
 // out again), at most KS_PLACE_MAX_X (default 2) times the basis size and only while half of the free memory stays
@@ -720,12 +742,21 @@ template <class D> void tune_placement(ks_workspace* w, size_t vbytes) {
   // the SpMV, which re-reads every x element seven times and lives on L2 hits, runs 2.3x SLOWER (42 -> 96 us): the
   // solver as a whole loses (669 vs 677 iterations/s, profiles/r02_placement_ab.txt).  Plain candidates are
   // indistinguishable from each other on the boxes measured.  KS_PLACE_TRIALS >= 2 opts in.
-  static const int trials = env_int("KS_PLACE_TRIALS", 1);
+  // Round 6: ON (three candidates) for a workspace that runs the block expansion in Float64 and has a block kernel for the
+  // probe's shape -- there the candidates DO differ (placement_block_ms) and the search costs three allocations of the basis held
+  // for a few milliseconds; everything else as before (KS_PLACE_TRIALS=1 switches it off, >= 2 forces it).
+  const int blk_k = w->maxdim / 2 + 1, blk_s = w->maxdim + 1 - blk_k;
+  const bool blk_probe = sizeof(D) == 8 && w->sstep >= 8 && blk_s >= 8 && blk_shape_ok(w->dtype, blk_k, blk_s) && !w->ctx->distributed();
+  static const int trials_env = env_int("KS_PLACE_TRIALS", -1);
+  // (how often a fresh allocation lands in the fast cluster depends on the box: 13 of 18 processes on one, 1 of 18 candidates on
+  // another -- up to ten candidates (held for ~20 ms each), and the search ends with the first one that streams at the fast cluster's rate)
+  const int trials = trials_env >= 0 ? trials_env : (blk_probe ? 10 : 1);
+  const double blk_fast_ms = 8.0 * (double)w->n * (blk_k + 2 * blk_s) / 5.5e12 * 1e3;   // 5.5 TB/s: 0.86-0.89 ms against 0.95-1.00 at n = 1e7
   // measured: +3 % at 3.3 GB, +1.5 % at 1.6 GB, nothing at 0.8 GB, -2 % at 0.4 GB (there the calibration, which
   // revisits the same columns, sees the memory-side cache more than the placement)
   static const int min_mb = env_int("KS_PLACE_MIN_MB", 1024);
   static const int budget_ms = env_int("KS_PLACE_BUDGET_MS", 1500);
-  static const int max_x = std::max(2, env_int("KS_PLACE_MAX_X", 2));  // total footprint of held candidates / basis size
+  static const int max_x = std::max(2, env_int("KS_PLACE_MAX_X", 10));  // total footprint of held candidates / basis size
   static const int debug = env_int("KS_PLACE_DEBUG", 0);
   if (trials <= 1 || vbytes < ((size_t)min_mb << 20) || w->guard) return;
   ks_ctx* c = w->ctx;
@@ -740,7 +771,7 @@ template <class D> void tune_placement(ks_workspace* w, size_t vbytes) {
   const auto t0 = std::chrono::steady_clock::now();
   for (size_t k = 0;; ++k) {
     w->V = pc.cand[k];
-    const double ms = placement_trio_ms<D>(w, ev.a, ev.b);
+    const double ms = blk_probe ? placement_block_ms<D>(w, blk_k, blk_s, ev.a, ev.b) : placement_trio_ms<D>(w, ev.a, ev.b);
     if (debug) std::fprintf(stderr, "[ks] placement candidate %zu @%p: %.3f ms\n", k, pc.cand[k], ms);
     if (ms < best_ms) { best_ms = ms; pc.keep = k; }
     worst_ms = std::max(worst_ms, ms);
@@ -748,6 +779,7 @@ template <class D> void tune_placement(ks_workspace* w, size_t vbytes) {
     if ((int)pc.cand.size() >= trials || spent > budget_ms) break;
     if ((int)pc.cand.size() + 1 > max_x) break;                      // footprint cap: held candidates <= max_x * V
     if (pc.cand.size() >= 4 && best_ms <= 0.955 * worst_ms) break;   // a candidate from the fast cluster was found
+    if (blk_probe && (best_ms <= blk_fast_ms || (pc.cand.size() >= 2 && best_ms <= 0.93 * worst_ms))) break;   // (block probe: the two clusters are 10-15 % apart)
     size_t free_b = 0, total_b = 0;
     KS_HIP(hipMemGetInfo(&free_b, &total_b));
     if (free_b / 2 < vbytes) { pc.failed++; break; }                 // never take more than half of what is left

@@ -771,6 +771,20 @@ int ks_debug_blk_time(ks_workspace* ws, int k, int s, int which, int reps, int d
     prov_drop(ws);
     blk_ensure_buffers(ws);
     reset_state(ws);
+    // (probe flags of this entry point itself: 256 = the second pass reads the block from the SCRATCH columns, as behind a fused
+    // rotation; 512 = ... after giving the scratch columns a fresh allocation -- the new one is made before the old one is freed, so
+    // that the allocator cannot hand the same pages back: tools/bupdate_lottery.py)
+    const bool zs = (dbg & 256) != 0, reroll = (dbg & 512) != 0;
+    dbg &= 255;
+    if (zs) {
+      void* old = reroll ? ws->zscratch : nullptr;
+      if (reroll) ws->zscratch = nullptr;
+      bool ok = false;
+      if (ws->dtype == KS_F64) ok = ensure_zscratch<double>(ws);
+      else ok = ensure_zscratch<cd>(ws);
+      if (old) { KS_HIP(hipStreamSynchronize(ws->ctx->stream)); (void)hipFree(old); }
+      KS_REQUIRE(ok, KS_ERR_INTERNAL, "no room for the scratch columns");
+    }
     const int saved = blk_dbg();
     blk_dbg() = dbg;
     hipEvent_t a, b;
@@ -779,8 +793,8 @@ int ks_debug_blk_time(ks_workspace* ws, int k, int s, int which, int reps, int d
     int nb = 0;
     auto run = [&](int n) {
       for (int i = 0; i < n; ++i) {
-        if (ws->dtype == KS_F64) nb = launch_blk<double>(ws, which, k, s);
-        else nb = launch_blk<cd>(ws, which, k, s);
+        if (ws->dtype == KS_F64) nb = launch_blk<double>(ws, which, k, s, zs);
+        else nb = launch_blk<cd>(ws, which, k, s, zs);
       }
     };
     run(2);  // warm-up

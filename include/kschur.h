@@ -206,8 +206,12 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
 int ks_workspace_destroy(ks_workspace* ws);
 /* What the placement search of ks_workspace_create did: candidates timed (0: basis too small or
  * KS_PLACE_TRIALS=1, search skipped), the calibration time of the kept / the slowest candidate, and how many
- * candidate allocations were refused or skipped for lack of free memory.  The search holds at most
- * KS_PLACE_MAX_X (default 2) times the basis size at once. */
+ * allocations the device refused.  Round 6: ON by default (up to 10 candidates, ending with the first one in the fast cluster) for
+ * a Float64 workspace of at least KS_PLACE_MIN_MB (1024) MB on one GPU that runs the block expansion -- the second pass of a large
+ * block is 12 % faster on some allocations of the basis than on others (bimodal, decided by the physical pages; profiles/
+ * r06_bupdate_lottery.txt); off otherwise (KS_PLACE_TRIALS >= 2 forces it).  The search holds its candidates while it runs: never
+ * more than KS_PLACE_MAX_X (default 10) times the basis size at once, never more than half of the free device memory, at most
+ * KS_PLACE_BUDGET_MS (1500) milliseconds; every loser is freed before ks_workspace_create returns. */
 int ks_workspace_placement(const ks_workspace* ws, int* candidates, double* best_ms, double* worst_ms, int* refused);
 /* How many times the fused expansion reads the basis per step on this workspace: 2 = implicit second pass (default:
  * the DGKS second projection, src/expansion.jl:93-94, is carried in a small triangular factor instead of being applied
