@@ -279,7 +279,7 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("s", [2, 4, 5, 7, 8, 9, 10, 13, 20])
+@pytest.mark.parametrize("s", [2, 4, 5, 8, 10, 13, 20])   # (7 and 9 went in round 6: run-time block sizes have tests of their own, the suite has a time limit)
 @pytest.mark.parametrize("case", list(CASES))
 def test_whole_solves_match_the_oracle(case, s):
     """partialschur with the s-step expansion against the oracle on the same start vector: identical matrix-vector counts
