@@ -192,6 +192,26 @@ template <class D> struct CsrOp : ks_operator {
           shape = shape && std::llabs((long long)sdict.delta[k]) <= 256;
           if (sdict.delta[k] & 1) odd |= 1u << k;
         }
+        // ... and where the planes are large enough to give every XCD a dozen in-plane tiles, the Z-MARCHING form: a workgroup
+        // keeps its tile and walks up the planes, the far taps come from registers / the next plane's window (41-42 us against
+        // 46-47 for the window form and 50-56 for k_spmv_stencil2 in the solver's chain, profiles/r06_spmv_columns.txt).
+        // KS_MARCH_Z=0 switches it off, KS_MARCH_ZR sets the number of z-ranges.
+        static const int zmarch = env_int("KS_MARCH_Z", 1), zr_env = env_int("KS_MARCH_ZR", 0);
+        const int64_t Pz = sdict.delta[6];
+        if (shape && zmarch && sdict.delta[0] == -Pz && (Pz & 1) == 0 && Pz >= 8 * 8 * 512) {
+          const int nzp = (int)((n_local + Pz - 1) / Pz), cmax = (int)(((Pz + 511) / 512 + 7) / 8);
+          int nzr = zr_env > 0 ? zr_env : std::max(1, (288 + cmax / 2) / cmax);
+          nzr = std::max(1, std::min(nzr, nzp / 4));
+          if (nzp >= 8) {
+            auto gz = [&](auto odd_tag) {
+              ksd::k_spmv_stencil_marchz<7, 0x3eu, decltype(odd_tag)::value, 3, 0, 6><<<8 * cmax * nzr, kBlock, 0, s>>>(m2, sdict, x, y, n_local, nzr, st, sh, shift_theta, shift_sigma);
+            };
+            if (odd == 0x14u) gz(std::integral_constant<unsigned, 0x14u>{});
+            else if (odd == 0x36u) gz(std::integral_constant<unsigned, 0x36u>{});
+            else gz(std::integral_constant<unsigned, 0x3eu>{});
+            return;
+          }
+        }
         if (shape) {
           auto gw = [&](auto odd_tag) {
             ksd::k_spmv_stencil_marchw<7, 0x3eu, decltype(odd_tag)::value, 3><<<G, kBlock, 0, s>>>(m2, sdict, x, y, n_local, nt, st, sh, shift_theta, shift_sigma);

@@ -441,4 +441,187 @@ __global__ void __launch_bounds__(kBlock)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Z-MARCHING form: a workgroup keeps ONE tile of 512 in-plane offsets and walks UP the planes of a z-range, row r -> r + P per
+// step.  The far taps then never touch the memory path: x[r - P] is the own pair of the step before (kept in registers),
+// x[r + P] the own pair of the NEXT plane's window, which is copied two steps ahead anyway -- per step and workgroup the
+// vector-memory path moves one window (8 KiB), the masks and the store (4 KiB) instead of 36.5 KiB (k_spmv_stencil_march) or
+// 20.5 (the window form).  Three window buffers (planes z, z + 1 landed, z + 2 in flight), one barrier per step.
+// Work items: (in-plane tile, z-range); XCD j owns a contiguous range of the ceil(P / 512) in-plane tiles for ALL z-ranges, so
+// that the overlapping windows of neighbouring tiles meet in one L2.  Steps whose windows leave [0, n) (first tile of the first
+// plane, last tiles of the last planes) take the clamped path of k_spmv_stencil2.
+//   KFM / KFP: the slots with delta -P / +P (the only far taps);  NEARM, ODDM, KOWN as in the window form;  nzr: z-ranges
+template <int NSLOT, unsigned NEARM, unsigned ODDM, int KOWN, int KFM, int KFP>
+__global__ void __launch_bounds__(kBlock)
+    k_spmv_stencil_marchz(const uint16_t* __restrict__ mask2, const StencilDict<double> d, const double* __restrict__ x,
+                          double* __restrict__ y, int64_t n, int nzr, const DevState* __restrict__ st, int shifted, double theta,
+                          double sigma) {
+  static_assert(KOWN >= 0 && ((NEARM >> KOWN) & 1u) && !((NEARM >> KFM) & 1u) && !((NEARM >> KFP) & 1u), "own pair near, -P / +P far");
+  if (st && st->breakdown >= 0) return;
+  __shared__ __attribute__((aligned(16))) unsigned char win[3][8192];
+  const int64_t P = d.delta[KFP];
+  const int nz = (int)((n + P - 1) / P), ntp = (int)((P + 511) / 512);
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  int cnt;
+  const int tj0 = march_tile(xcd, 0, 0, 0, ntp, cnt);   // XCD j owns in-plane tiles [tj0, cnt) (march_tile returns the end in `cnt`)
+  cnt -= tj0;
+  if (cnt <= 0) return;
+  const int zr = slot / cnt, tile = tj0 + slot % cnt;
+  if (zr >= nzr) return;
+  const int za = (int)((int64_t)zr * nz / nzr), zb = (int)((int64_t)(zr + 1) * nz / nzr);
+  const int64_t off0 = (int64_t)tile * 512;
+  const uint32_t lane_b = threadIdx.x * 16u, lane_m = threadIdx.x * 2u;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t lane_w = (threadIdx.x & 63u) * 16u;
+  const uint32_t win0 = (uint32_t)(uintptr_t)&win[0][0];
+  const bool plain_st = (shifted & 2) != 0;
+  const bool lane_in = off0 + 2 * (int64_t)threadIdx.x + 1 < P;                 // this lane's pair belongs to the plane (P is even)
+  const int nst = (off0 + 128 * (int64_t)wave + 1 < P) ? 1 : 0;                  // does this wave store anything at all (uniform)
+  auto r0_of = [&](int z) { return (int64_t)z * P + off0; };
+  auto win_ok = [&](int z) { const int64_t r0 = r0_of(z); return z >= 0 && r0 - 256 >= 0 && r0 + 768 <= n; };
+  // a step is interior when its window is loadable, its rows all exist, and so is the next plane's window -- or nothing of the tile exists there
+  auto interior = [&](int z) { return win_ok(z) && r0_of(z) + 512 <= n && (win_ok(z + 1) || r0_of(z + 1) >= n); };
+
+  auto edge = [&](int z) {   // the clamped path of k_spmv_stencil2 on the rows of this tile in plane z
+    const int64_t r = r0_of(z) + 2 * (int64_t)threadIdx.x;
+    if (!lane_in || r >= n) return;
+    const bool two = r + 1 < n;
+    const uint32_t m = mask2[r >> 1];
+    const uint32_t m0 = m & 0xffu, m1 = m >> 8;
+    const int64_t cmax = n - 2;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+      const int64_t c = r + d.delta[k];
+      int64_t lo = c < 0 ? 0 : (c > cmax ? cmax : c);
+      if (cmax < 0) lo = 0;
+      const int sh = (int)(c - lo);
+      double xa, xb;
+      if (n >= 2) ld_pair_u(x + lo, xa, xb);
+      else { xa = x[0]; xb = x[0]; }
+      const double v0 = sh == 1 ? xb : xa, v1 = sh == -1 ? xa : xb;
+      const double p0 = mul_nc(d.val[k], v0), p1 = mul_nc(d.val[k], v1);
+      s0 = ((m0 >> k) & 1u) ? add_(s0, p0) : s0;
+      s1 = ((m1 >> k) & 1u) ? add_(s1, p1) : s1;
+    }
+    if (shifted) {
+      double x0, x1;
+      if (two) ld_pair_u(x + r, x0, x1);
+      else { x0 = x[r]; x1 = x0; }
+      s0 = scl(sub_s(s0, mul_(theta, x0)), sigma);
+      s1 = scl(sub_s(s1, mul_(theta, x1)), sigma);
+    }
+    if (two) {
+      if (plain_st) st_pack(y + r, make_double2(s0, s1));
+      else st_pack_nt(y + r, make_double2(s0, s1));
+    } else {
+      if (plain_st) y[r] = s0;
+      else st_elem_nt(y + r, s0);
+    }
+  };
+  int zi0 = za, zi1 = zb;
+  while (zi0 < zi1 && !interior(zi0)) ++zi0;
+  while (zi1 > zi0 && !interior(zi1 - 1)) --zi1;
+  if (zi0 > za || zi1 < zb) {
+    for (int z = za; z < zb; ++z)
+      if (z < zi0 || z >= zi1) edge(z);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (zi0 >= zi1) return;   // (uniform over the workgroup: the barriers below match)
+
+  // window of plane zz into buffer `buf`; a plane whose window leaves the vector is replaced by plane `zsafe` (never read then)
+  auto issue_w = [&](int zz, int zsafe, int buf) {
+    const int zu = win_ok(zz) ? zz : zsafe;
+    const double* bw = x + (r0_of(zu) - 256 + (int64_t)wave * 256);
+    uint32_t ldst = win0 + (uint32_t)buf * 8192u + (uint32_t)wave * 2048u;
+    asm volatile("" : "+s"(bw));
+    asm volatile("" : "+s"(ldst));
+    asm volatile("s_nop 4" ::: "memory");
+    march_glds16(lane_w, bw, ldst);
+    march_glds16(lane_w + 1024u, bw, ldst + 1024u);
+  };
+  auto issue_m = [&](int zz, uint32_t& m) {
+    const uint16_t* bm = mask2 + (r0_of(zz) >> 1);
+    asm volatile("" : "+s"(bm));
+    asm volatile("s_nop 4" ::: "memory");
+    march_ld_u16(m, lane_m, bm);
+  };
+  f64x2m prev;   // the own pair of the plane below (x[r - P], x[r + 1 - P])
+  {
+    const double* bp = x + (zi0 >= 1 ? r0_of(zi0 - 1) : r0_of(zi0));
+    asm volatile("" : "+s"(bp));
+    asm volatile("s_nop 4" ::: "memory");
+    march_ld16(prev, lane_b, bp);
+  }
+  uint32_t mA, mB;
+  issue_w(zi0, zi0, 0);
+  issue_w(zi0 + 1, zi0, 1);
+  issue_m(zi0, mA);
+  int bc = 0, bn = 1, b2 = 2;   // buffers of plane z, z + 1, z + 2
+  auto step = [&](int z, uint32_t& m, uint32_t& mnext, bool first, bool has_next) {
+    // landed: window z + 1 (and everything older) and the masks of this step; only the store of the step before may be on its way
+    if (first || nst == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
+    asm volatile("" : "+v"(m));
+    if (first) asm volatile("" : "+v"(prev));
+    issue_w(z + 2, z, b2);                 // (overwrites the window of plane z - 1: everybody is past step z - 1)
+    if (has_next) issue_m(z + 1, mnext);
+    const unsigned char* w = &win[0][0] + bc * 8192 + (256 * 8) + threadIdx.x * 16;
+    f64x2m v[NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+      if ((NEARM >> k) & 1u) {
+        const int off = (int)d.delta[k] * 8;
+        if (((ODDM >> k) & 1u) == 0) {
+          v[k] = *reinterpret_cast<const f64x2m*>(w + off);
+        } else {
+          typedef double f64x2u8 __attribute__((ext_vector_type(2), aligned(8)));
+          const f64x2u8 p = *reinterpret_cast<const f64x2u8*>(w + off);
+          v[k].x = p.x;
+          v[k].y = p.y;
+        }
+      }
+    }
+    v[KFM] = prev;
+    v[KFP] = *reinterpret_cast<const f64x2m*>(&win[0][0] + bn * 8192 + (256 * 8) + threadIdx.x * 16);
+    const int m0 = (int)(m & 0xffu), m1 = (int)(m >> 8);
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+      const double p0 = mul_nc(d.val[k], v[k].x), p1 = mul_nc(d.val[k], v[k].y);
+      s0 = add_(s0, and_mask(p0, __builtin_amdgcn_sbfe(m0, k, 1)));
+      s1 = add_(s1, and_mask(p1, __builtin_amdgcn_sbfe(m1, k, 1)));
+    }
+    if (shifted) {
+      s0 = scl(sub_s(s0, mul_(theta, v[KOWN].x)), sigma);
+      s1 = scl(sub_s(s1, mul_(theta, v[KOWN].y)), sigma);
+    }
+    prev = v[KOWN];
+    f64x2m o2;
+    o2.x = s0;
+    o2.y = s1;
+    double* by = y + r0_of(z);
+    asm volatile("" : "+s"(by));
+    if (lane_in) march_st16(lane_b, o2, by, plain_st);   // (a wave with no lane in the plane issues nothing: nst == 0 above)
+    const int tb = bc;
+    bc = bn;
+    bn = b2;
+    b2 = tb;
+  };
+  int z = zi0;
+  bool first = true;
+  for (;;) {
+    const bool h1 = z + 1 < zi1;
+    step(z, mA, mB, first, h1);
+    first = false;
+    if (!h1) break;
+    ++z;
+    const bool h2 = z + 1 < zi1;
+    step(z, mB, mA, false, h2);
+    if (!h2) break;
+    ++z;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace ksd

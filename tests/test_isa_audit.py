@@ -18,6 +18,7 @@ import isa_audit  # noqa: E402
 
 INSTANCES = [(7, 3), (5, 2), (3, 1), (1, -1), (4, -1), (7, -1), (8, -1)]
 WINDOW_INSTANCES = [(7, 0x3E, 0x14, 3), (7, 0x3E, 0x36, 3), (7, 0x3E, 0x3E, 3)]   # the window form the solver launches for 3-D 7-point shapes
+ZMARCH_INSTANCES = [(7, 0x3E, 0x14, 3, 0, 6), (7, 0x3E, 0x36, 3, 0, 6), (7, 0x3E, 0x3E, 3, 0, 6)]   # the z-marching form (large planes)
 NEAR_INSTANCES = [(7, 3, 2, 4), (5, 2, 1, 3)]   # the +-1 taps from the neighbouring lanes (tools/spmv_slab.hip measures it; not dispatched)
 
 
@@ -32,6 +33,8 @@ def listing(tmp_path_factory):
                      f"int64_t, int, const ksd::DevState*, int, double, double);" for ns, ko in INSTANCES)
     inst += "\n" + "\n".join(f"template __global__ void ksd::k_spmv_stencil_march<{a}, {b}, {c}, {e}>(const uint16_t*, const ksd::StencilDict<double>, const double*, double*, "
                              f"int64_t, int, const ksd::DevState*, int, double, double);" for a, b, c, e in NEAR_INSTANCES)
+    inst += "\n" + "\n".join(f"template __global__ void ksd::k_spmv_stencil_marchz<{a}, {b}u, {c}u, {e}, {f}, {g}>(const uint16_t*, const ksd::StencilDict<double>, const double*, double*, "
+                             f"int64_t, int, const ksd::DevState*, int, double, double);" for a, b, c, e, f, g in ZMARCH_INSTANCES)
     inst += "\n" + "\n".join(f"template __global__ void ksd::k_spmv_stencil_marchw<{a}, {b}u, {c}u, {e}>(const uint16_t*, const ksd::StencilDict<double>, const double*, double*, "
                              f"int64_t, int, const ksd::DevState*, int, double, double);" for a, b, c, e in WINDOW_INSTANCES)
     src.write_text(f'#include "{ROOT}/arnoldimethod.jl_amd/csrc/ks_spmv_march.hpp"\n{inst}\n')
@@ -46,6 +49,15 @@ def test_the_window_form(listing, a, b, c, e):
     no register in flight); and its LDS reads sit behind the hand-written wait + barrier (the audit treats any vmcnt wait as one)"""
     nloads, bad = isa_audit.audit(listing, f"k_spmv_stencil_marchwILi{a}ELj{b}ELj{c}ELi{e}E")
     assert nloads >= 3 * 3 and nloads % 3 == 0, nloads
+    assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("a,b,c,e,f,g", ZMARCH_INSTANCES)
+def test_the_z_marching_form(listing, a, b, c, e, f, g):
+    """register loads of the z-marching form: the own pair of the plane below (once, in the prologue) and the masks (prologue + the
+    two halves of the unrolled loop); windows are LDS copies"""
+    nloads, bad = isa_audit.audit(listing, f"k_spmv_stencil_marchzILi{a}ELj{b}ELj{c}ELi{e}ELi{f}ELi{g}E")
+    assert nloads >= 4, nloads
     assert not bad, bad[:5]
 
 

@@ -52,7 +52,7 @@ void launch_slab(const Problem& pr, const double* x, double* y, int order, int w
   kern<<<nslab * nseg, NW * 64, G::lds_bytes>>>(pr.dm, pr.nmask, pr.d, 7, x, pr.n, y, pr.n, pr.P, pr.nz, (int)sl, nseg, nslab, order | (g_dbg << 1), nullptr, shifted, 0.37, 0.125);
 }
 
-static int g_nseg = 0, g_G = 768;
+static int g_nseg = 0, g_G = 768, g_nzr = 16;
 static uint16_t* g_m1 = nullptr;   // all-ones masks (slot ladder)
 static StencilDict<double> g_d1{}, g_d3{}, g_d5{}, g_d3f{};
 void launch(int var, const Problem& pr, const double* x, double* y, int shifted) {
@@ -75,6 +75,11 @@ void launch(int var, const Problem& pr, const double* x, double* y, int shifted)
     case 14: k_spmv_stencil_march<7, 3><<<256 * 8, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
     case 15: k_spmv_stencil_march<7, 3><<<256 * 3, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
     case 16: k_spmv_stencil_march<7, 3><<<256 * 5, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
+    case 25: {
+      const int ntp = (int)((pr.P + 511) / 512), cmax = (ntp + 7) / 8;
+      k_spmv_stencil_marchz<7, 0x3eu, 0x14u, 3, 0, 6><<<8 * cmax * g_nzr, 256>>>(pr.dm, pr.d, x, y, pr.n, g_nzr, nullptr, shifted, 0.37, 0.125);
+      break;
+    }
     case 24: k_spmv_stencil_marchw<7, 0x3eu, 0x14u, 3><<<g_G, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
     case 23: k_spmv_stencil_march<7, 3, 2, 4><<<g_G, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
     case 19: k_spmv_stencil_march<1, 0><<<g_G, 256>>>(g_m1, g_d1, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
@@ -151,7 +156,8 @@ int main(int argc, char** argv) {
       int shf = 3;
       if (sarg < 0) { sarg = -sarg; shf = 1; }            // negative: streaming (nt) stores instead of cacheable ones
       int var = sarg == 0 ? 0 : 17;
-      if (sarg >= 70000) { sarg -= 70000; var = 24; }
+      if (sarg >= 80000) { g_nzr = sarg - 80000; sarg = 1; var = 25; }
+      else if (sarg >= 70000) { sarg -= 70000; var = 24; }
       else if (sarg >= 60000) { sarg -= 60000; var = 23; }
       else if (sarg >= 50000) { sarg -= 50000; var = 22; }
       else if (sarg >= 40000) { sarg -= 40000; var = 21; }
@@ -159,7 +165,7 @@ int main(int argc, char** argv) {
       else if (sarg >= 20000) { sarg -= 20000; var = 19; }
       else if (sarg >= 10000) { sarg -= 10000; shf = 1; }
       if (sarg >= 5000) { sarg -= 5000; var = 18; }       // 5000 + S: the plain copy with 8 S workgroups
-      if (sarg) g_G = sarg * 8;
+      if (sarg && var != 25) g_G = sarg * 8;
       double tot = 0; float mn = 1e9f, mx = 0; std::vector<float> per(20, 0.f);
       for (int pass = 0; pass < 4; ++pass) {
         for (int i = 0; i < 20; ++i) { CK(hipEventRecord(ev[i])); launch(var, pr, V + (size_t)i * ld, V + (size_t)(i + 1) * ld, shf); }
@@ -167,7 +173,7 @@ int main(int argc, char** argv) {
         if (!pass) continue;
         for (int i = 0; i < 20; ++i) { float ms; CK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); tot += ms; mn = ms < mn ? ms : mn; mx = ms > mx ? ms : mx; per[i] += ms / 3; }
       }
-      printf("%d x %d x %d  columns chain  %s stores  %-18s S=%-4d  mean %.1f us  min %.1f  max %.1f   per product:", m, my, mz, shf == 3 ? "cacheable" : "streaming", var == 18 ? "plain copy" : var == 19 ? "march 1 slot" : var == 20 ? "march -1 0 +1" : var == 21 ? "march 5 near" : var == 22 ? "march -P 0 +P" : var == 23 ? "march near-by-dpp" : var == 24 ? "march LDS window" : var ? "march" : "k_spmv_stencil2", var ? g_G / 8 : 0, tot / 60 * 1e3, mn * 1e3, mx * 1e3);
+      printf("%d x %d x %d  columns chain  %s stores  %-18s S=%-4d  mean %.1f us  min %.1f  max %.1f   per product:", m, my, mz, shf == 3 ? "cacheable" : "streaming", var == 18 ? "plain copy" : var == 19 ? "march 1 slot" : var == 20 ? "march -1 0 +1" : var == 21 ? "march 5 near" : var == 22 ? "march -P 0 +P" : var == 23 ? "march near-by-dpp" : var == 24 ? "march LDS window" : var == 25 ? "z-march (S = z-ranges)" : var ? "march" : "k_spmv_stencil2", var == 25 ? g_nzr : var ? g_G / 8 : 0, tot / 60 * 1e3, mn * 1e3, mx * 1e3);
       for (int i = 0; i < 20; ++i) printf(" %.0f", per[i] * 1e3);
       printf("\n");
       fflush(stdout);
@@ -183,7 +189,8 @@ int main(int argc, char** argv) {
     for (int ai = 5; ai < argc; ++ai) {
       int sv = atoi(argv[ai]);
       int mvar = sv < 0 ? 23 : 17;      // negative: the form with the +-1 taps from the neighbouring lanes
-      if (sv >= 70000) { sv -= 70000; mvar = 24; }   // 70000 + S: the window form
+      if (sv >= 80000) { g_nzr = sv - 80000; sv = 1; mvar = 25; }   // 80000 + z-ranges: the z-marching form
+      else if (sv >= 70000) { sv -= 70000; mvar = 24; }   // 70000 + S: the window form
       g_G = (sv < 0 ? -sv : sv) * 8;
       float best = 1e9f;
       CK(hipMemset(y2, 0xff, n * 8));
@@ -202,7 +209,7 @@ int main(int argc, char** argv) {
       for (int i = 0; i < 20; ++i) launch(mvar, pr, i == 0 ? pr.xs : (i & 1 ? y1 : y2), (i & 1) ? y2 : y1, 3);
       CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
       float ms; CK(hipEventElapsedTime(&ms, a, b));
-      printf("%d x %d x %d  march%s S=%d (G=%d, %.2f wg/CU, plane = %.1f tiles)  cold %.1f us  chain %.1f us  %s\n", m, my, mz, mvar == 23 ? " (near taps by dpp)" : mvar == 24 ? " (LDS window)" : "", g_G / 8, g_G, g_G / 256.0, pr.P / 512.0,
+      printf("%d x %d x %d  march%s S=%d (G=%d, %.2f wg/CU, plane = %.1f tiles)  cold %.1f us  chain %.1f us  %s\n", m, my, mz, mvar == 23 ? " (near taps by dpp)" : mvar == 24 ? " (LDS window)" : mvar == 25 ? " (z-march; S = z-ranges)" : "", mvar == 25 ? g_nzr : g_G / 8, g_G, g_G / 256.0, pr.P / 512.0,
              best * 1e3, ms * 1e3 / 20, same ? "bit-identical" : "DIFFER");
       fflush(stdout);
     }
