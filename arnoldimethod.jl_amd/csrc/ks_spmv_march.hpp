@@ -451,16 +451,21 @@ __global__ void __launch_bounds__(kBlock)
 // that the overlapping windows of neighbouring tiles meet in one L2.  Steps whose windows leave [0, n) (first tile of the first
 // plane, last tiles of the last planes) take the clamped path of k_spmv_stencil2.
 //   KFM / KFP: the slots with delta -P / +P (the only far taps);  NEARM, ODDM, KOWN as in the window form;  nzr: z-ranges
-template <int NSLOT, unsigned NEARM, unsigned ODDM, int KOWN, int KFM, int KFP>
-__global__ void __launch_bounds__(kBlock)
+//   TW: threads of a workgroup (256 / 512): the tile is 2 TW in-plane offsets, the window 2 TW + 512 rows (2x / 1.5x its tile)
+template <int NSLOT, unsigned NEARM, unsigned ODDM, int KOWN, int KFM, int KFP, int NB = 3, int TW = 256>
+__global__ void __launch_bounds__(TW)
     k_spmv_stencil_marchz(const uint16_t* __restrict__ mask2, const StencilDict<double> d, const double* __restrict__ x,
                           double* __restrict__ y, int64_t n, int nzr, const DevState* __restrict__ st, int shifted, double theta,
                           double sigma) {
   static_assert(KOWN >= 0 && ((NEARM >> KOWN) & 1u) && !((NEARM >> KFM) & 1u) && !((NEARM >> KFP) & 1u), "own pair near, -P / +P far");
   if (st && st->breakdown >= 0) return;
-  __shared__ __attribute__((aligned(16))) unsigned char win[3][8192];
+  constexpr int kTile = 2 * TW, kWinB = (kTile + 512) * 8, kPieces = (kTile + 512) / 128, kWaves = TW / 64;
+  static_assert(TW == 256 || TW == 512, "four or eight waves");
+  static_assert(NB == 3 || TW == 256, "the wait counts of the four-buffer form assume two window pieces per wave");
+  static_assert(NB == 3 || NB == 4, "planes z, z + 1 resident; one or two more in flight");
+  __shared__ __attribute__((aligned(16))) unsigned char win[NB][kWinB];
   const int64_t P = d.delta[KFP];
-  const int nz = (int)((n + P - 1) / P), ntp = (int)((P + 511) / 512);
+  const int nz = (int)((n + P - 1) / P), ntp = (int)((P + kTile - 1) / kTile);
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   int cnt;
   const int tj0 = march_tile(xcd, 0, 0, 0, ntp, cnt);   // XCD j owns in-plane tiles [tj0, cnt) (march_tile returns the end in `cnt`)
@@ -469,7 +474,7 @@ __global__ void __launch_bounds__(kBlock)
   const int zr = slot / cnt, tile = tj0 + slot % cnt;
   if (zr >= nzr) return;
   const int za = (int)((int64_t)zr * nz / nzr), zb = (int)((int64_t)(zr + 1) * nz / nzr);
-  const int64_t off0 = (int64_t)tile * 512;
+  const int64_t off0 = (int64_t)tile * kTile;
   const uint32_t lane_b = threadIdx.x * 16u, lane_m = threadIdx.x * 2u;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t lane_w = (threadIdx.x & 63u) * 16u;
@@ -478,9 +483,9 @@ __global__ void __launch_bounds__(kBlock)
   const bool lane_in = off0 + 2 * (int64_t)threadIdx.x + 1 < P;                 // this lane's pair belongs to the plane (P is even)
   const int nst = (off0 + 128 * (int64_t)wave + 1 < P) ? 1 : 0;                  // does this wave store anything at all (uniform)
   auto r0_of = [&](int z) { return (int64_t)z * P + off0; };
-  auto win_ok = [&](int z) { const int64_t r0 = r0_of(z); return z >= 0 && r0 - 256 >= 0 && r0 + 768 <= n; };
+  auto win_ok = [&](int z) { const int64_t r0 = r0_of(z); return z >= 0 && r0 - 256 >= 0 && r0 + kTile + 256 <= n; };
   // a step is interior when its window is loadable, its rows all exist, and so is the next plane's window -- or nothing of the tile exists there
-  auto interior = [&](int z) { return win_ok(z) && r0_of(z) + 512 <= n && (win_ok(z + 1) || r0_of(z + 1) >= n); };
+  auto interior = [&](int z) { return win_ok(z) && r0_of(z) + kTile <= n && (win_ok(z + 1) || r0_of(z + 1) >= n); };
 
   auto edge = [&](int z) {   // the clamped path of k_spmv_stencil2 on the rows of this tile in plane z
     const int64_t r = r0_of(z) + 2 * (int64_t)threadIdx.x;
@@ -532,13 +537,14 @@ __global__ void __launch_bounds__(kBlock)
   // window of plane zz into buffer `buf`; a plane whose window leaves the vector is replaced by plane `zsafe` (never read then)
   auto issue_w = [&](int zz, int zsafe, int buf) {
     const int zu = win_ok(zz) ? zz : zsafe;
-    const double* bw = x + (r0_of(zu) - 256 + (int64_t)wave * 256);
-    uint32_t ldst = win0 + (uint32_t)buf * 8192u + (uint32_t)wave * 2048u;
+    // pieces of 128 rows: wave w copies piece w and, while there are that many, piece w + kWaves
+    const double* bw = x + (r0_of(zu) - 256 + (int64_t)wave * 128);
+    uint32_t ldst = win0 + (uint32_t)buf * (uint32_t)kWinB + (uint32_t)wave * 1024u;
     asm volatile("" : "+s"(bw));
     asm volatile("" : "+s"(ldst));
     asm volatile("s_nop 4" ::: "memory");
     march_glds16(lane_w, bw, ldst);
-    march_glds16(lane_w + 1024u, bw, ldst + 1024u);
+    if (wave + kWaves < kPieces) march_glds16(lane_w + (uint32_t)kWaves * 1024u, bw, ldst + (uint32_t)kWaves * 1024u);
   };
   auto issue_m = [&](int zz, uint32_t& m) {
     const uint16_t* bm = mask2 + (r0_of(zz) >> 1);
@@ -556,17 +562,27 @@ __global__ void __launch_bounds__(kBlock)
   uint32_t mA, mB;
   issue_w(zi0, zi0, 0);
   issue_w(zi0 + 1, zi0, 1);
+  if constexpr (NB == 4) issue_w(zi0 + 2, zi0, 2);
   issue_m(zi0, mA);
-  int bc = 0, bn = 1, b2 = 2;   // buffers of plane z, z + 1, z + 2
+  int bc = 0;   // buffer of plane z (plane z + i: (bc + i) % NB)
   auto step = [&](int z, uint32_t& m, uint32_t& mnext, bool first, bool has_next) {
-    // landed: window z + 1 (and everything older) and the masks of this step; only the store of the step before may be on its way
-    if (first || nst == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
+    // landed: window z + 1 (and everything older) and the masks of this step.  Queue of the wave behind the masks of this step
+    // (issued in the step before): [NB == 4: the two window pieces issued right behind them] [the store of the step before]
+    constexpr int NW_LATE = NB == 4 ? 2 : 0;
+    if (first) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (nst == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NW_LATE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NW_LATE + 1) : "memory");
     asm volatile("" : "+v"(m));
     if (first) asm volatile("" : "+v"(prev));
-    issue_w(z + 2, z, b2);                 // (overwrites the window of plane z - 1: everybody is past step z - 1)
-    if (has_next) issue_m(z + 1, mnext);
-    const unsigned char* w = &win[0][0] + bc * 8192 + (256 * 8) + threadIdx.x * 16;
+    const int bn = bc + 1 == NB ? 0 : bc + 1, b2 = bc == 0 ? NB - 1 : bc - 1;   // plane z + 1; the slot of plane z - 1 = of plane z + NB - 1
+    if constexpr (NB == 3) {
+      issue_w(z + 2, z, b2);               // (overwrites the window of plane z - 1: everybody is past step z - 1)
+      if (has_next) issue_m(z + 1, mnext);
+    } else {
+      if (has_next) issue_m(z + 1, mnext); // masks FIRST: the wait for them must not drag the window behind them along
+      issue_w(z + 3, z, b2);
+    }
+    const unsigned char* w = &win[0][0] + bc * kWinB + (256 * 8) + threadIdx.x * 16;
     f64x2m v[NSLOT];
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k) {
@@ -583,7 +599,7 @@ __global__ void __launch_bounds__(kBlock)
       }
     }
     v[KFM] = prev;
-    v[KFP] = *reinterpret_cast<const f64x2m*>(&win[0][0] + bn * 8192 + (256 * 8) + threadIdx.x * 16);
+    v[KFP] = *reinterpret_cast<const f64x2m*>(&win[0][0] + bn * kWinB + (256 * 8) + threadIdx.x * 16);
     const int m0 = (int)(m & 0xffu), m1 = (int)(m >> 8);
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
@@ -603,10 +619,7 @@ __global__ void __launch_bounds__(kBlock)
     double* by = y + r0_of(z);
     asm volatile("" : "+s"(by));
     if (lane_in) march_st16(lane_b, o2, by, plain_st);   // (a wave with no lane in the plane issues nothing: nst == 0 above)
-    const int tb = bc;
     bc = bn;
-    bn = b2;
-    b2 = tb;
   };
   int z = zi0;
   bool first = true;

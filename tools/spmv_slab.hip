@@ -52,7 +52,7 @@ void launch_slab(const Problem& pr, const double* x, double* y, int order, int w
   kern<<<nslab * nseg, NW * 64, G::lds_bytes>>>(pr.dm, pr.nmask, pr.d, 7, x, pr.n, y, pr.n, pr.P, pr.nz, (int)sl, nseg, nslab, order | (g_dbg << 1), nullptr, shifted, 0.37, 0.125);
 }
 
-static int g_nseg = 0, g_G = 768, g_nzr = 16;
+static int g_nseg = 0, g_G = 768, g_nzr = 16, g_nb = 3;
 static uint16_t* g_m1 = nullptr;   // all-ones masks (slot ladder)
 static StencilDict<double> g_d1{}, g_d3{}, g_d5{}, g_d3f{};
 void launch(int var, const Problem& pr, const double* x, double* y, int shifted) {
@@ -77,7 +77,11 @@ void launch(int var, const Problem& pr, const double* x, double* y, int shifted)
     case 16: k_spmv_stencil_march<7, 3><<<256 * 5, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
     case 25: {
       const int ntp = (int)((pr.P + 511) / 512), cmax = (ntp + 7) / 8;
-      k_spmv_stencil_marchz<7, 0x3eu, 0x14u, 3, 0, 6><<<8 * cmax * g_nzr, 256>>>(pr.dm, pr.d, x, y, pr.n, g_nzr, nullptr, shifted, 0.37, 0.125);
+      if (g_nb == 5) {   // 512-thread workgroups: tiles of 1024 in-plane offsets
+        const int ntp2 = (int)((pr.P + 1023) / 1024), cmax2 = (ntp2 + 7) / 8;
+        k_spmv_stencil_marchz<7, 0x3eu, 0x14u, 3, 0, 6, 3, 512><<<8 * cmax2 * g_nzr, 512>>>(pr.dm, pr.d, x, y, pr.n, g_nzr, nullptr, shifted, 0.37, 0.125);
+      } else if (g_nb == 4) k_spmv_stencil_marchz<7, 0x3eu, 0x14u, 3, 0, 6, 4><<<8 * cmax * g_nzr, 256>>>(pr.dm, pr.d, x, y, pr.n, g_nzr, nullptr, shifted, 0.37, 0.125);
+      else k_spmv_stencil_marchz<7, 0x3eu, 0x14u, 3, 0, 6><<<8 * cmax * g_nzr, 256>>>(pr.dm, pr.d, x, y, pr.n, g_nzr, nullptr, shifted, 0.37, 0.125);
       break;
     }
     case 24: k_spmv_stencil_marchw<7, 0x3eu, 0x14u, 3><<<g_G, 256>>>(pr.dm, pr.d, x, y, pr.n, nt, nullptr, shifted, 0.37, 0.125); break;
@@ -156,7 +160,9 @@ int main(int argc, char** argv) {
       int shf = 3;
       if (sarg < 0) { sarg = -sarg; shf = 1; }            // negative: streaming (nt) stores instead of cacheable ones
       int var = sarg == 0 ? 0 : 17;
-      if (sarg >= 80000) { g_nzr = sarg - 80000; sarg = 1; var = 25; }
+      if (sarg >= 100000) { g_nzr = sarg - 100000; g_nb = 5; sarg = 1; var = 25; }
+      else if (sarg >= 90000) { g_nzr = sarg - 90000; g_nb = 4; sarg = 1; var = 25; }
+      else if (sarg >= 80000) { g_nzr = sarg - 80000; g_nb = 3; sarg = 1; var = 25; }
       else if (sarg >= 70000) { sarg -= 70000; var = 24; }
       else if (sarg >= 60000) { sarg -= 60000; var = 23; }
       else if (sarg >= 50000) { sarg -= 50000; var = 22; }
@@ -189,7 +195,9 @@ int main(int argc, char** argv) {
     for (int ai = 5; ai < argc; ++ai) {
       int sv = atoi(argv[ai]);
       int mvar = sv < 0 ? 23 : 17;      // negative: the form with the +-1 taps from the neighbouring lanes
-      if (sv >= 80000) { g_nzr = sv - 80000; sv = 1; mvar = 25; }   // 80000 + z-ranges: the z-marching form
+      if (sv >= 100000) { g_nzr = sv - 100000; g_nb = 5; sv = 1; mvar = 25; }   // 100000 + z-ranges: 512-thread workgroups
+      else if (sv >= 90000) { g_nzr = sv - 90000; g_nb = 4; sv = 1; mvar = 25; }   // 90000 + z-ranges: ... with four window buffers
+      else if (sv >= 80000) { g_nzr = sv - 80000; g_nb = 3; sv = 1; mvar = 25; }   // 80000 + z-ranges: the z-marching form
       else if (sv >= 70000) { sv -= 70000; mvar = 24; }   // 70000 + S: the window form
       g_G = (sv < 0 ? -sv : sv) * 8;
       float best = 1e9f;
