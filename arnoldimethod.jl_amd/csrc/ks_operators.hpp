@@ -146,8 +146,7 @@ template <class D> struct CsrOp : ks_operator {
   }
   // ---- marching form of the paired stencil kernel (ks_spmv_march.hpp; Float64, one GPU, at most 8 slots) ----
   static bool march_on() {
-    static const int env = env_int("KS_STENCIL_MARCH", 1);
-    return env != 0;
+    return env_int("KS_STENCIL_MARCH", 1) != 0;   // (read per launch: the tests switch the forms inside one process)
   }
   // Workgroups per XCD (= tiles of 512 rows an XCD takes per round).  With a far stride P (the xy-plane of a 3-D grid) a round
   // that covers a WHOLE NUMBER OF PLANES keeps the z - 1 / z + 1 taps of a round in step with the rows other rounds own.  How much
@@ -158,7 +157,7 @@ template <class D> struct CsrOp : ks_operator {
   //     k_spmv_stencil2 -- a plain copy of the same columns takes 29-31 there, the same kernel with ONE slot 36.
   // The solver lives in the second regime: two planes per round (5-6 workgroups per CU), a multiple of one plane in general.
   int march_slots(int ntiles) const {
-    static const int env = env_int("KS_MARCH_S", 0);
+    const int env = env_int("KS_MARCH_S", 0);
     int S = 192;
     if (env > 0) S = env;
     else {
@@ -184,7 +183,7 @@ template <class D> struct CsrOp : ks_operator {
       // the 3-D 7-point shape (far, near, near, own, near, near, far with the near taps within 256 rows): the window form -- the five
       // near taps of a tile from one copy of its rows in LDS (ks_spmv_march.hpp; 47 against 49 us in the solver's chain,
       // profiles/r06_spmv_columns.txt).  KS_MARCH_WINDOW=0: the register form for every shape.
-      static const int window = env_int("KS_MARCH_WINDOW", 1);
+      const int window = env_int("KS_MARCH_WINDOW", 1);
       if (window && nstencil == 7 && kown == 3) {
         bool shape = std::llabs((long long)sdict.delta[0]) > 256 && std::llabs((long long)sdict.delta[6]) > 256;
         unsigned odd = 0;
@@ -196,7 +195,7 @@ template <class D> struct CsrOp : ks_operator {
         // keeps its tile and walks up the planes, the far taps come from registers / the next plane's window (41-42 us against
         // 46-47 for the window form and 50-56 for k_spmv_stencil2 in the solver's chain, profiles/r06_spmv_columns.txt).
         // KS_MARCH_Z=0 switches it off, KS_MARCH_ZR sets the number of z-ranges.
-        static const int zmarch = env_int("KS_MARCH_Z", 1), zr_env = env_int("KS_MARCH_ZR", 0);
+        const int zmarch = env_int("KS_MARCH_Z", 1), zr_env = env_int("KS_MARCH_ZR", 0);
         const int64_t Pz = sdict.delta[6];
         if (shape && zmarch && sdict.delta[0] == -Pz && (Pz & 1) == 0 && Pz >= 8 * 8 * 512) {
           const int nzp = (int)((n_local + Pz - 1) / Pz), cmax = (int)(((Pz + 511) / 512 + 7) / 8);

@@ -71,7 +71,7 @@ KERNEL_NAMES = {
     "dots": "k_dots (h = V'w, |w|^2)",
     "axpy": "k_axpy (w -= V c, |w|^2; second DGKS pass)",
     "fused": "k_axpy_dots_cs (w -= V h, |w|^2 and c = V'w of the second DGKS pass, V read once)",
-    "spmv": "k_spmv_csr",
+    "spmv": "SpMV kernel of the layout in use (config.spmv_layout; stencil-mask, Float64, one GPU: k_spmv_stencil_march*)",
     "scale": "k_scale",
     "rotate": "k_rotate_fma (restart rotation V <- V Q in place, src/run.jl:363-365)",
 }

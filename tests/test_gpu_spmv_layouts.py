@@ -346,3 +346,46 @@ def test_column_blocked_csr_is_bit_identical(dtype, monkeypatch):
         Bd = sp.diags([rng.standard_normal(1_000_000 - abs(k)) for k in (-3, -1, 0, 1, 3)], [-3, -1, 0, 1, 3], format="csr")
         _, fb, _ = _apply(Bd, xh, dtype)
         assert fb["layout"] != "csr-cb", fb
+
+
+@pytest.mark.parametrize("grid", [(182, 182, 9), (181, 182, 10), (256, 128, 8), (64, 64, 70)])
+def test_marching_forms_of_the_stencil_product_are_bit_identical(grid, monkeypatch):
+    """Float64 stencil-mask products on one GPU go through the persistent kernels of csrc/ks_spmv_march.hpp: the z-marching form
+    where a plane has >= 64 tiles of 512 rows and there are >= 8 planes (the first three grids: nx even, nx odd -- the near taps
+    +-nx then sit at odd offsets --, a power-of-two plane), the window form for smaller planes (the last grid), the register form
+    behind them.  Every form, k_spmv_stencil2 and the CSR row blocks must give the SAME bits (products rounded separately, added in
+    slot order under the row's mask), for the plain product and -- through two block cycles of the expansion, whose Newton steps
+    y = sigma (A x - theta x) are fused into these kernels -- for the shifted one: identical Hessenberg matrices, bit for bit."""
+    from test_gpu_sstep import _lockstep
+
+    mx, my, mz = grid
+    A = laplace3d(mx, my, mz)
+    n = A.shape[0]
+    rng = np.random.default_rng(5)
+    xv = rnd(rng, np.float64, n)
+    forms = {"default": {}, "window": {"KS_MARCH_Z": "0"}, "registers": {"KS_MARCH_Z": "0", "KS_MARCH_WINDOW": "0"}, "stencil2": {"KS_STENCIL_MARCH": "0"},
+             "z-ranges 5": {"KS_MARCH_ZR": "5"}}
+    ys, Hs = {}, {}
+    ctx = None
+    for name, env in forms.items():
+        for k_ in ("KS_MARCH_Z", "KS_MARCH_WINDOW", "KS_STENCIL_MARCH", "KS_MARCH_ZR"):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        y, f, op = _apply(A, xv, np.float64, ctx)
+        ctx = op.ctx
+        assert f["layout"] == "stencil"
+        ys[name] = y
+        for cyc, _Hs, Hb, _Vs, _Vb, rel, orth, info in _lockstep(A, np.float64, 8, 6, 8, 16, "SR", 2):
+            if cyc == 1:
+                assert info["blocks"] > 0 and info["abandoned"] == 0, (name, info)
+                Hs[name] = Hb
+    ref = A @ xv
+    np.testing.assert_allclose(ys["default"], ref, rtol=0, atol=1e-13 * np.abs(ref).max())
+    for name in forms:
+        assert np.array_equal(ys[name].view(np.uint64), ys["default"].view(np.uint64)), name
+        assert np.array_equal(Hs[name].view(np.uint64), Hs["default"].view(np.uint64)), name
+    monkeypatch.delenv("KS_MARCH_ZR", raising=False)
+    monkeypatch.setenv("KS_SPMV_FORMAT", "csr")
+    y0, f0, _ = _apply(A, xv, np.float64, ctx)
+    assert f0["layout"] == "csr" and np.array_equal(y0.view(np.uint64), ys["default"].view(np.uint64))
