@@ -1358,7 +1358,7 @@ __global__ void __launch_bounds__(kBlock)
   const int tid = threadIdx.x;
   const int ng = s * (s + 1) / 2, ne = k * s + ng;
 #ifdef KS_FIN_TIMING
-  long long tq[8] = {wall_clock64(), 0, 0, 0, 0, 0, 0, 0};
+  long long tq[12] = {wall_clock64(), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define KS_TQ(i) tq[i] = wall_clock64()
 #else
 #define KS_TQ(i) ((void)0)
@@ -1534,6 +1534,7 @@ __global__ void __launch_bounds__(kBlock)
   const T* hb = h_lds ? Hl : Hd;
   const int64_t hld = h_lds ? k : ldh;
   __syncthreads();
+  KS_TQ(8);
   // H column k-1:  (zeta_1 / sigma_1 + theta_1 zeta_0 - H[:, 0:k-1) u[0:k-1)) / u[k-1]
   for (int r = tid; r < m; r += kBlock) {
     T a = scl(zeta(1, r), 1.0 / sh.sigma[0]);
@@ -1552,6 +1553,7 @@ __global__ void __launch_bounds__(kBlock)
   }
   __syncthreads();
   for (int r = tid; r < ldh; r += kBlock) Hd[r + (int64_t)(k - 1) * ldh] = r < m ? hk[r] : zero_of(T{});
+  KS_TQ(9);
   // H columns k .. k+s-2:  M R_{s-1} = rhs,  rhs[:, i-1] = zeta_{i+1} / sigma_{i+1} + theta_{i+1} zeta_i - Hext PC[:, i-1]
   // (Hext = [ H[:, 0:k-1) | hk ]);  all (row, column) pairs of rhs in parallel, then a row-parallel forward substitution
   if (s > 1) {
@@ -1572,6 +1574,7 @@ __global__ void __launch_bounds__(kBlock)
       rhs[e] = sub_(a, add_(h0, h1));
     }
     __syncthreads();
+    KS_TQ(10);
     for (int r = tid; r < m; r += kBlock) {
       // (row of M in registers, statically unrolled and predicated on s: behind run-time indices it lived in scratch memory,
       // ~25 us of the stage)
@@ -1606,8 +1609,9 @@ __global__ void __launch_bounds__(kBlock)
     st->blk_gdev = fmax(st->blk_gdev, gdev);
   }
 #ifdef KS_FIN_TIMING
-  if (tid == 0 && (k == 31 || (k == 21 && s == 20))) printf("[fin_blk stage 2 k=%d s=%d] reduce+elect %.2f | fetch %.2f | T^H %.2f | gram+chol+inv %.2f | T cols, R, PC %.2f | H %.2f us\n", k, s,
-                                  (tq[1] - tq[0]) * 0.01, (tq[2] - tq[1]) * 0.01, (tq[3] - tq[2]) * 0.01, (tq[4] - tq[3]) * 0.01, (tq[5] - tq[4]) * 0.01, (wall_clock64() - tq[5]) * 0.01);
+  if (tid == 0 && (k == 31 || (k == 21 && s == 20))) printf("[fin_blk stage 2 k=%d s=%d] reduce+elect %.2f | fetch %.2f | T^H %.2f | gram %.2f chol %.2f inv %.2f | T cols, R, PC %.2f | H to LDS %.2f col k-1 %.2f rhs %.2f subst+rest %.2f us\n", k, s,
+                                  (tq[1] - tq[0]) * 0.01, (tq[2] - tq[1]) * 0.01, (tq[3] - tq[2]) * 0.01, (tq[6] - tq[3]) * 0.01, (tq[7] - tq[6]) * 0.01, (tq[4] - tq[7]) * 0.01, (tq[5] - tq[4]) * 0.01,
+                                  (tq[8] - tq[5]) * 0.01, (tq[9] - tq[8]) * 0.01, (tq[10] - tq[9]) * 0.01, (wall_clock64() - tq[10]) * 0.01);
 #endif
 }
 
