@@ -170,10 +170,10 @@ void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::v
       const D* part = static_cast<const D*>(ws->bpart);
       D* red = static_cast<D*>(ws->bred);
       if (!cx->distributed()) {
-        ksd::k_fin_blk<D><<<ne, kBlock, 0, s_>>>(stage, 0, part, nbp, ws->pnb, k, s, red, Hd, ldh, Tm, ws->ldt, ws->ntrue, bs, sh, first, ws->blk_pivmin,
+        ksd::k_fin_blk<D><<<(ne + 3) / 4, kBlock, 0, s_>>>(stage, 0, part, nbp, ws->pnb, k, s, red, Hd, ldh, Tm, ws->ldt, ws->ntrue, bs, sh, first, ws->blk_pivmin,
                                                  ws->blk_gdevmax, ws->st, ws->ctr);
       } else {
-        ksd::k_fin_blk<D><<<ne, kBlock, 0, s_>>>(stage, 1, part, nbp, ws->pnb, k, s, red, Hd, ldh, Tm, ws->ldt, ws->ntrue, bs, sh, first, ws->blk_pivmin,
+        ksd::k_fin_blk<D><<<(ne + 3) / 4, kBlock, 0, s_>>>(stage, 1, part, nbp, ws->pnb, k, s, red, Hd, ldh, Tm, ws->ldt, ws->ntrue, bs, sh, first, ws->blk_pivmin,
                                                  ws->blk_gdevmax, ws->st, ws->ctr);
         cx->allreduce(reinterpret_cast<double*>(red), ne * (int)(sizeof(D) / 8));
         ksd::k_fin_blk<D><<<1, kBlock, 0, s_>>>(stage, 2, part, nbp, ws->pnb, k, s, red, Hd, ldh, Tm, ws->ldt, ws->ntrue, bs, sh, first, ws->blk_pivmin,

@@ -1174,115 +1174,82 @@ template <int SRC> __device__ __forceinline__ double rdlane_(double v) {
 }
 template <int SRC> __device__ __forceinline__ cd rdlane_(cd v) { return cd{rdlane_<SRC>(v.x), rdlane_<SRC>(v.y)}; }
 
-// Cholesky R^H R = G of an s x s Hermitian matrix given by its upper triangle in LDS (column stride s), in place: on exit
-// the upper triangle holds R.  All threads of the workgroup call it; returns the smallest pivot ratio d_i / G_ii (<= 0 when
-// the matrix is not positive definite); the factorisation stops (and the caller bails) at the first ratio <= pivmin.
-// Done by WAVE 0 in registers: lane l owns column l, column i of R travels by lane broadcasts -- no barrier and no LDS round
-// trip inside the s dependent steps (the first version, thread 0 + two barriers per step, cost 10 us of a 28 us kernel).
-// (FP64 division and square root are ~300-cycle software sequences on this part and the s steps are sequential: the first
-// version paid three of them per step, 10 us at s = 20.  Now: the pivot test by cross-multiplication, 1 / sqrt(d) from the
-// hardware estimate + two Newton steps (full double precision, not correctly rounded -- every rank runs the same code, so the
-// replicated decisions stay identical), one division at the very end for the reported ratio; the reciprocals of the diagonal
-// go to dinv[] for tri_inv_lds.)
+// Cholesky R^H R = G of an s x s Hermitian matrix given by its upper triangle in LDS (column stride s) AND the inverse of the
+// factor: on exit the upper triangle of G holds R and X = R^-1 (full s x s, zeros below the diagonal).  All threads of the
+// workgroup call it; returns the smallest pivot ratio d_i / G_ii (<= 0 when the matrix is not positive definite); the
+// factorisation stops (and the caller bails) at the first ratio <= pivmin.
+// One ENTRY of the upper triangle per thread (s (s + 1) / 2 <= 210 of the 256), the entry in a register, a compact loop over the
+// s steps with ONE barrier each:
+//   factorisation (right-looking): the owners of row p + 1 publish their updated, still unscaled entries; after the barrier every
+//     thread reads the pivot d and the two entries of the pivot row it needs, forms 1 / sqrt(d) itself (hardware estimate + two
+//     Newton steps: full double precision, not correctly rounded -- every thread and every rank runs the same code on the same
+//     numbers, so the replicated decisions stay identical; the pivot test by cross-multiplication) and subtracts the outer
+//     product from its entry;
+//   inverse: the same row operations applied to the identity leave R^-H (the elimination [G | I] -> [R | R^-H]): entry (l, q) of it
+//     is touched in steps q .. l, entry (q, l) of G in steps 0 .. q -- the thread that owns the one owns the other, the pivot row
+//     of the identity part is published beside the pivot row of G, and the inverse costs no step and no barrier of its own.
+// A step is an LDS round trip, ~12 dependent FP64 operations and a barrier: ~260 ns measured, 5 us at s = 20.  (Two variants
+// that lost: the back substitution as a second loop of s steps -- 10.5 us for the pair --, and column c of R^-1 as dot products
+// with column c of R in the shadow of step c + 1 -- the dot of up to 19 terms is LDS round trips in a row, longer than the step.)
+// (What came before, for the record -- profiles/r06_fin_blk_timing.txt: wave 0 alone with a column per lane in registers, the
+// rows travelling by v_readlane, the s steps unrolled: 17 us for the pair at s = 20, right-looking or left-looking, one uniform
+// branch per entry or none, broadcasts batched ahead of the fmas or not.  ONE wave running ~20 KB of straight-line 8-byte
+// instructions once is bound by its instruction fetch -- ~1 byte per cycle measured --, not by the arithmetic or the latencies.)
 __device__ __forceinline__ double rsqrt_nr(double d) {
   double y = __builtin_amdgcn_rsq(d);
   y = y * fma(-0.5 * d * y, y, 1.5);
   y = y * fma(-0.5 * d * y, y, 1.5);
   return y;
 }
-// step I of the factorisation (lane l owns column l; the source lane of every broadcast is the compile-time I)
-template <class T, int I>
-__device__ __forceinline__ void chol_steps(T (&r)[kBlkSMax], int s, int lane, double pivmin, double& wd, double& wg, bool& okay, double& myinv) {
-  if constexpr (I < kBlkSMax) {
-    if (I < s && okay) {  // (uniform)
-      double d = real_of(r[I]);
-      const double gii = d;
-#pragma unroll
-      for (int p = 0; p < I; ++p) d -= abs2_(r[p]);
-      const double di = rdlane_<I>(d), gi = rdlane_<I>(gii);
-      const bool pos = gi > 0.0 && di > pivmin * gi;   // ratio = di / gi > pivmin
-      if (!(gi > 0.0)) { wd = 0.0; wg = 1.0; }
-      else if (di * wg < wd * gi) { wd = di; wg = gi; }
-      if (!pos) {
-        okay = false;
-      } else {
-        const double rinv = rsqrt_nr(di), rii = di * rinv;
-        T a = r[I];
-        // two accumulation chains (the products are independent: the chain of subtractions was the step's critical path)
-        T a0 = zero_of(T{}), a1 = zero_of(T{});
-#pragma unroll
-        for (int p = 0; p + 1 < I; p += 2) {
-          a0 = fma_(conj_(rdlane_<I>(r[p])), r[p], a0);
-          a1 = fma_(conj_(rdlane_<I>(r[p + 1])), r[p + 1], a1);
-        }
-        if constexpr (I % 2 == 1) a0 = fma_(conj_(rdlane_<I>(r[I - 1])), r[I - 1], a0);
-        a = sub_(a, add_(a0, a1));
-        r[I] = lane == I ? from_real(rii, T{}) : scl(a, rinv);
-        if (lane == I) myinv = rinv;
-      }
-    }
-    chol_steps<T, I + 1>(r, s, lane, pivmin, wd, wg, okay, myinv);
-  }
-}
-template <class T> __device__ double chol_upper_lds(T* G, int s, double pivmin, double* sh_ratio, double* dinv) {
-  const int tid = threadIdx.x;
-  if (tid < 64) {
-    const int lane = tid;
-    T r[kBlkSMax];
-#pragma unroll
-    for (int i = 0; i < kBlkSMax; ++i) r[i] = (lane < s && i <= lane && i < s) ? G[i + lane * s] : zero_of(T{});
-    double wd = 1.0, wg = 1.0;   // the smallest pivot ratio seen so far, as a fraction wd / wg
-    bool okay = true;
-    double myinv = 0.0;
-    chol_steps<T, 0>(r, s, lane, pivmin, wd, wg, okay, myinv);
-    if (okay && lane < s) {
-#pragma unroll
-      for (int i = 0; i < kBlkSMax; ++i)
-        if (i <= lane && i < s) G[i + lane * s] = r[i];
-      dinv[lane] = myinv;
-    }
-    if (lane == 0) *sh_ratio = wd / wg;
-  }
-  __syncthreads();
-  const double w = *sh_ratio;
-  __syncthreads();
-  return w;
-}
-// X = R^-1 (upper triangular, column stride s): thread c < s computes column c by back substitution.  The column lives in
-// REGISTERS (statically unrolled over the largest block size, predicated on the run-time s and c): the first version kept it in
-// LDS behind run-time indices -- 190 dependent LDS round trips for the last column, ~10 us of a 30-us kernel.
-template <class T> __device__ void tri_inv_lds(const T* Rm, T* X, int s, const double* dinv) {
+template <class T> __device__ double chol_inv_coop(T* G, T* X, int s, double pivmin) {
   constexpr int SMX = blk_smax<T>();
-  const int c = threadIdx.x;
-  if (c < s) {
-    T x[SMX];
-#pragma unroll
-    for (int i = 0; i < SMX; ++i) x[i] = zero_of(T{});
-#pragma unroll
-    for (int i = SMX - 1; i >= 0; --i) {
-      if (i < s) {   // (uniform)
-        // x[l] is zero for l > c (never assigned) and for l >= s: the row of R is read unconditionally (loads first, then the
-        // chain -- behind per-entry predicates every load waited for its own branch), entries past s replaced by zero
-        T rrow[SMX];
-#pragma unroll
-        for (int l = i + 1; l < SMX; ++l) rrow[l] = l < s ? Rm[i + l * s] : zero_of(T{});
-        T a0 = zero_of(T{}), a1 = zero_of(T{});
-#pragma unroll
-        for (int l = i + 1; l + 1 < SMX; l += 2) {
-          a0 = fma_(rrow[l], x[l], a0);
-          a1 = fma_(rrow[l + 1], x[l + 1], a1);
-        }
-        if ((SMX - (i + 1)) % 2 == 1) a0 = fma_(rrow[SMX - 1], x[SMX - 1], a0);
-        const double di = dinv[i];   // 1 / R[i, i] (real, from the Cholesky steps)
-        const T val = i == c ? from_real(di, T{}) : scl(neg_(add_(a0, a1)), di);
-        x[i] = i <= c ? val : zero_of(T{});
-      }
+  static_assert(SMX * (SMX + 1) / 2 <= kBlock, "one entry of the upper triangle per thread");
+  __shared__ T urow[2][SMX];        // the pivot row of G, unscaled (double-buffered over the steps)
+  __shared__ T yrow[2][SMX];        // the pivot row of the eliminated identity, unscaled
+  __shared__ double g0[SMX];
+  const int tid = threadIdx.x, ng = s * (s + 1) / 2;
+  int l = 0;                        // this thread's entry (q, l), q <= l
+  while ((l + 1) * (l + 2) / 2 <= tid) ++l;
+  const int q = tid - l * (l + 1) / 2;
+  const bool mine = tid < ng;
+  T g = mine ? G[q + l * s] : zero_of(T{});
+  T y = from_real(mine && q == l ? 1.0 : 0.0, T{});   // entry (l, q) of the eliminated identity
+  if (mine && q == l) g0[l] = real_of(g);
+  if (mine && q == 0) urow[0][l] = g;
+  if (tid == 0) yrow[0][0] = y;
+  for (int e = tid; e < s * s; e += kBlock)
+    if (e % s > e / s) X[e] = zero_of(T{});
+  __syncthreads();
+  double wd = 1.0, wg = 1.0;   // the smallest pivot ratio seen so far, as a fraction wd / wg
+  for (int p = 0; p < s; ++p) {
+    const T* u = urow[p & 1];
+    const T* yv = yrow[p & 1];
+    // ONE update  t -= conj(a) b / d  per thread and step, the operands picked by address (a wave that ran the two kinds of update
+    // as the two sides of a branch paid both latencies in a row: 470 ns per step instead of 260):
+    //   q > p:        entry (q, l) of G:         a = G[p, q], b = G[p, l]
+    //   q <= p < l:   entry (l, q) of R^-H:      a = G[p, l], b = Y[p, q]
+    const bool up = q > p;
+    const T a_in = mine ? (up ? u[q] : u[l]) : u[p], b_in = mine ? (up ? u[l] : yv[q <= p ? q : 0]) : u[p];
+    const double di = real_of(u[p]), gi = g0[p];
+    const bool pos = gi > 0.0 && di > pivmin * gi;   // ratio = di / gi > pivmin
+    if (!(gi > 0.0)) { wd = 0.0; wg = 1.0; }
+    else if (di * wg < wd * gi) { wd = di; wg = gi; }
+    if (!pos) break;   // (uniform: every thread reads the same numbers)
+    const double rinv = rsqrt_nr(di);
+    const T A = scl(a_in, rinv), B = scl(b_in, rinv);
+    const T r = sub_(up ? g : y, mul_(conj_(A), B));
+    if (mine) {
+      if (up) g = r;
+      else if (l > p) y = r;
+      if (q == p + 1) urow[(p + 1) & 1][l] = g;
+      if (l == p + 1) yrow[(p + 1) & 1][q] = y;
+      if (q == p) G[p + l * s] = l == p ? from_real(di * rinv, T{}) : A;   // row p of R is final
+      if (l == p) X[q + p * s] = conj_(scl(y, rinv));                      // row p of R^-H is final
     }
-#pragma unroll
-    for (int i = 0; i < SMX; ++i)
-      if (i < s) X[i + c * s] = x[i];
+    __syncthreads();
   }
   __syncthreads();
+  return wd / wg;
 }
 
 // The non-trivial columns ntrue..k-1 of T as the algebra reads them: element (l, c) at tb[l + (c - ntrue) * tld] -- staged in
@@ -1339,18 +1306,18 @@ __global__ void __launch_bounds__(kBlock)
     k_fin_blk(int stage, int mode, const T* __restrict__ partial, int nb, int pnb, int k, int s, T* __restrict__ red, T* __restrict__ Hd,
               int ldh, T* __restrict__ Tm, int ldt, int ntrue, BlkScratch<T>* __restrict__ bs, BlkShifts<T> sh, int first,
               double pivmin, double gdevmax, DevState* __restrict__ st, unsigned* __restrict__ counter) {
-  if (st->breakdown >= 0) return;
-  __shared__ T sm[kBlock];
+  const int bd_flag = st->breakdown;   // (tested behind the loads of the reduction: one round trip to memory instead of two in a row)
   __shared__ int last_wg;
-  __shared__ double sh_ratio;
+  __shared__ double redv[kBlock / 64][3];
   constexpr int SMX = blk_smax<T>();
-  __shared__ double dinvs[kBlkSMax];
   __shared__ T rfinv[SMX];
   constexpr int KS = (kBlkKMax - SMX) * SMX;   // k s with k + s <= kBlkKMax, s <= SMX (<= kBlkKMax / 2)
   __shared__ T rs[KS + SMX * (SMX + 1) / 2];
   __shared__ T A1[KS];      // stage 1: P;     stage 2: C
   __shared__ T A2[KS];      // stage 1: T P;   stage 2: T C, then PC
   __shared__ T Gm[SMX * SMX], Xi[SMX * SMX], Rf[SMX * SMX];
+  __shared__ T R1l[SMX * SMX];   // stage 2: stage 1's factor and P (global memory behind bs: fetched with everything else up front --
+  __shared__ T Pl[KS];           // every dependent round trip to memory in the middle of the algebra is ~1 us of this kernel)
   __shared__ T zu[kBlkKMax + SMX], hk[kBlkKMax + SMX];
   __shared__ T Tl[kBlkTLds];
   __shared__ T Hl[kBlkHLds];
@@ -1358,26 +1325,53 @@ __global__ void __launch_bounds__(kBlock)
   const int tid = threadIdx.x;
   const int ng = s * (s + 1) / 2, ne = k * s + ng;
 #ifdef KS_FIN_TIMING
-  long long tq[12] = {wall_clock64(), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tq[16] = {wall_clock64(), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define KS_TQ(i) tq[i] = wall_clock64()
 #else
 #define KS_TQ(i) ((void)0)
 #endif
+  if (mode == 2 && bd_flag >= 0) return;
   if (mode != 2) {
-    const int c = blockIdx.x;
-    const T v = block_sum(partial + (int64_t)c * pnb, nb, sm);
-    if (tid == 0) {
-      red[c] = v;
+    // one WAVE per sum (the producers run one workgroup per CU: 256 partial sums each -- a workgroup per sum was 630 workgroups
+    // of one load per thread, two barriers each, and with this kernel's LDS footprint they did not fit on the chip at once)
+    const int c = blockIdx.x * (kBlock / 64) + (tid >> 6), lane = tid & 63;
+    T v = zero_of(T{});
+    if (c < ne) {
+      const T* pp = partial + (int64_t)c * pnb;
+      T v0 = zero_of(T{}), v1 = zero_of(T{}), v2 = zero_of(T{}), v3 = zero_of(T{});
+      int b = lane;
+      for (; b + 192 < nb; b += 256) {
+        v0 = add_(v0, pp[b]);
+        v1 = add_(v1, pp[b + 64]);
+        v2 = add_(v2, pp[b + 128]);
+        v3 = add_(v3, pp[b + 192]);
+      }
+      for (; b < nb; b += 64) v0 = add_(v0, pp[b]);
+      KS_TQ(11);
+      v = wave_sum(add_(add_(v0, v1), add_(v2, v3)));
+    }
+    if (bd_flag >= 0) return;   // (the same on every workgroup; nothing has been written)
+    KS_TQ(12);
+    if (c < ne && lane == 0) {
       if (mode == 0) {
-        __threadfence();
-        last_wg = (atomicAdd(counter, 1u) == gridDim.x - 1) ? 1 : 0;
+        st_agent(red + c, v);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the sum is where the elected workgroup will read it before this one takes its ticket)
+      } else {
+        red[c] = v;
       }
     }
     if (mode == 1) return;
+    KS_TQ(13);
     __syncthreads();
+    if (tid == 0) last_wg = (atomicAdd(counter, 1u) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    KS_TQ(14);
     if (!last_wg) return;
-    if (tid == 0) *counter = 0u;
-    __threadfence();
+    if (tid == 0) *counter = 0u;   // (ordered against the next launch by the end of this kernel; the sums are read with agent-scope loads)
+#ifdef KS_FIN_TIMING
+    if (tid == 0 && k == 21 && s == 20) printf("[fin_blk reduce] loads issued+landed %.2f | wave sum %.2f | store + fence %.2f | barrier, atomic, barrier %.2f us\n",
+                                                (tq[11] - tq[0]) * 0.01, (tq[12] - tq[11]) * 0.01, (tq[13] - tq[12]) * 0.01, (tq[14] - tq[13]) * 0.01);
+#endif
   }
   KS_TQ(1);
   for (int e = tid; e < ne; e += kBlock) rs[e] = ld_agent(red + e);
@@ -1391,70 +1385,104 @@ __global__ void __launch_bounds__(kBlock)
     }
   const T* tb = t_lds ? Tl : Tm + (int64_t)ntrue * ldt;
   const int64_t tld = t_lds ? k : ldt;
+  // H[0:k, 0:k-1) -> LDS (coalesced; a thread of the H recovery walks ALONG a row of H: from memory that is a chain of L2 round trips)
+  const bool h_lds = stage == 2 && k * (k - 1) <= kBlkHLds;
+  if (stage == 2) {
+    for (int e = tid; e < s * s; e += kBlock) R1l[e] = bs->R1[e];
+    for (int e = tid; e < k * s; e += kBlock) Pl[e] = bs->P[e];
+    // zu = u (coordinates of z_0 in V_k)
+    for (int r = tid; r < k; r += kBlock) zu[r] = first ? from_real(r == k - 1 ? 1.0 : 0.0, T{}) : bs->u[r];
+    if (h_lds)
+      for (int e = tid; e < k * (k - 1); e += kBlock) Hl[e] = Hd[(e % k) + (int64_t)(e / k) * ldh];
+  }
   __syncthreads();
   const T* Gin = rs + k * s;
   KS_TQ(2);
   // A1 = T^H (raw inner products)
   th_times(tb, tld, ntrue, k, s, rs, A1);
   KS_TQ(3);
-  // Gm = Gin - A1^H A1   (upper triangle)
-  for (int g = tid; g < ng; g += kBlock) {
-    int i2 = 0;
-    while ((i2 + 1) * (i2 + 2) / 2 <= g) ++i2;
-    const int i = g - i2 * (i2 + 1) / 2;
-    T a = Gin[g];
-    for (int c = 0; c < k; ++c) a = sub_(a, mul_(conj_(A1[i * k + c]), A1[i2 * k + c]));
-    if (i == i2) a = from_real(real_of(a), T{});
-    Gm[i + i2 * s] = a;
+  // Gm = Gin - A1^H A1   (upper triangle; one entry per thread: ng <= 210), and in the same pass what the acceptance tests need,
+  // reduced over the workgroup in one go (wave butterflies, then the wave results through LDS behind the barrier Gm needs anyway):
+  //   stage 2: how far the block that stage 1 wrote is from orthonormal: G_t = I + delta, delta ~ eps cond(R_1)^2 (the cancellation
+  //     in G_Z - P^H P amplified by the conditioning of the Newton basis).  The recovered Hessenberg columns carry errors of order
+  //     eps cond(R_1), so a block is only accepted while |delta|_max <= gdevmax (default 1e-8: cond <= ~1e4, H at the per-step
+  //     path's accuracy; tests/test_sstep_model.py); beyond that it is abandoned like a rank-deficient one and the host lowers
+  //     s.  Also |Gm - I|_max: decides below whether Gm needs a factorisation at all.
+  //   stage 1: a COLLAPSING chain: z_i = sigma (A z_{i-1} - theta_i z_{i-1}) is computed with an error of eps ||A|| ||z_{i-1}||,
+  //     and the H recovery divides by the UNSCALED factor -- its pivots carry the norms of the chain --, so a step that shrinks
+  //     the vector by a factor f (a shift next to an eigenvalue whose invariant subspace dominates the vector: a tight cluster)
+  //     puts an error of eps / f into H.  The pivot test of the factorisation is relative to each column's own norm and does not
+  //     see it.  Below f = 3e-4 (norm^2 ratio 1e-7: errors beyond 1e-12) the block is abandoned like a rank-deficient one; the
+  //     per-step path meets the same situation as a near-breakdown and takes the reference's decisions (src/expansion.jl:91-102).
+  static_assert(SMX * (SMX + 1) / 2 <= kBlock, "one entry of the Gram matrix per thread");
+  {
+    double dv1 = 0.0, dv2 = 0.0, bad = 0.0;
+    if (tid < ng) {
+      int i2 = 0;
+      while ((i2 + 1) * (i2 + 2) / 2 <= tid) ++i2;
+      const int i = tid - i2 * (i2 + 1) / 2;
+      T a = Gin[tid];
+      T a0 = zero_of(T{}), a1 = zero_of(T{});
+      int c = 0;
+      for (; c + 1 < k; c += 2) {
+        a0 = fma_(conj_(A1[i * k + c]), A1[i2 * k + c], a0);
+        a1 = fma_(conj_(A1[i * k + c + 1]), A1[i2 * k + c + 1], a1);
+      }
+      if (c < k) a0 = fma_(conj_(A1[i * k + c]), A1[i2 * k + c], a0);
+      a = sub_(a, add_(a0, a1));
+      if (i == i2) a = from_real(real_of(a), T{});
+      Gm[i + i2 * s] = a;
+      const T del = from_real(i == i2 ? 1.0 : 0.0, T{});
+      if (stage == 2) {
+        dv1 = abs2_(sub_(Gin[tid], del));
+        dv2 = abs2_(sub_(a, del));
+      } else if (i == i2) {
+        const double gd = real_of(Gin[tid]), prev = i ? real_of(Gin[gram_idx(i - 1, i - 1)]) : 1.0;   // (z_0 is a basis column)
+        if (!(gd > 1e-7 * prev)) bad = 1.0;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      dv1 = fmax(dv1, __shfl_xor(dv1, off, 64));
+      dv2 = fmax(dv2, __shfl_xor(dv2, off, 64));
+      bad = fmax(bad, __shfl_xor(bad, off, 64));
+    }
+    if ((tid & 63) == 0) { redv[tid >> 6][0] = dv1; redv[tid >> 6][1] = dv2; redv[tid >> 6][2] = bad; }
   }
   __syncthreads();
-  // How far the block that stage 1 wrote is from orthonormal: G_t = I + delta, delta ~ eps cond(R_1)^2 (the cancellation in
-  // G_Z - P^H P amplified by the conditioning of the Newton basis).  The recovered Hessenberg columns carry errors of order
-  // eps cond(R_1), so a block is only accepted while delta <= gdevmax (default 1e-8: cond <= ~1e4, H at the per-step path's
-  // accuracy; tests/test_sstep_model.py); beyond that it is abandoned like a rank-deficient one and the host lowers s.
-  double gdev = 0.0;
-  if (stage == 2) {
-    if (tid < 64) {  // ng <= 55 entries: one wave, |entry - delta|^2, wave maximum
-      double dv = 0.0;
-      if (tid < ng) {
-        int i2 = 0;
-        while ((i2 + 1) * (i2 + 2) / 2 <= tid) ++i2;
-        const int i = tid - i2 * (i2 + 1) / 2;
-        dv = abs2_(sub_(Gin[tid], from_real(i == i2 ? 1.0 : 0.0, T{})));
-      }
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) dv = fmax(dv, __shfl_xor(dv, off, 64));
-      if (tid == 0) sh_ratio = sqrt(dv);
-    }
-    __syncthreads();
-    gdev = sh_ratio;
-    __syncthreads();
-  }
-  // A COLLAPSING chain (stage 1): z_i = sigma (A z_{i-1} - theta_i z_{i-1}) is computed with an error of eps ||A|| ||z_{i-1}||, and
-  // the H recovery divides by the UNSCALED factor -- its pivots carry the norms of the chain --, so a step that shrinks the
-  // vector by a factor f (a shift next to an eigenvalue whose invariant subspace dominates the vector: a tight cluster) puts an
-  // error of eps / f into H.  The pivot test above is relative to each column's own norm and does not see it.  Below
-  // f = 3e-4 (norm^2 ratio 1e-7: errors beyond 1e-12) the block is abandoned like a rank-deficient one; the per-step path meets
-  // the same situation as a near-breakdown and takes the reference's decisions (src/expansion.jl:91-102).
+  double gdev = 0.0, mdev = 0.0;
   bool collapse = false;
-  if (stage == 1) {
-    if (tid == 0) {
-      double prev = 1.0;   // (z_0 is a basis column)
-      bool bad = false;
-      for (int i = 0; i < s; ++i) {
-        const double g = real_of(Gin[gram_idx(i, i)]);
-        if (!(g > 1e-7 * prev)) bad = true;
-        prev = g;
-      }
-      sh_ratio = bad ? 1.0 : 0.0;
-    }
-    __syncthreads();
-    collapse = sh_ratio != 0.0;
-    __syncthreads();
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) {
+    gdev = fmax(gdev, redv[w][0]);
+    mdev = fmax(mdev, redv[w][1]);
+    collapse = collapse || redv[w][2] != 0.0;
   }
+  gdev = sqrt(gdev);
+  mdev = sqrt(mdev);
   const bool too_far = (stage == 2 && !(gdev <= gdevmax)) || collapse;
   KS_TQ(6);
-  const double worst = too_far ? 0.0 : chol_upper_lds(Gm, s, stage == 1 ? pivmin : 0.25, &sh_ratio, dinvs);
+  // stage 2, Gm = I + E with |E|_max <= 1e-9 (the usual case: E ~ eps cond(R_1)^2): R = I + striu(E) + diag(E) / 2 and
+  // R^-1 = I - striu(E) - diag(E) / 2 are the factor and its inverse up to terms of order s |E|^2 <= 2e-17 -- below the rounding
+  // of the factorisation they replace, whose 2 s dependent steps are ~10 us of this kernel.
+  const bool first_order = stage == 2 && !too_far && mdev <= 1e-9;
+  double worst;
+  if (first_order) {
+    for (int e = tid; e < s * s; e += kBlock) {
+      const int i = e % s, i2 = e / s;
+      if (i <= i2) {
+        const T g = Gm[e];
+        Gm[e] = i == i2 ? from_real(1.0 + 0.5 * (real_of(g) - 1.0), T{}) : g;
+        Xi[e] = i == i2 ? from_real(1.0 - 0.5 * (real_of(g) - 1.0), T{}) : neg_(g);
+      } else {
+        Xi[e] = zero_of(T{});
+      }
+    }
+    __syncthreads();
+    worst = 1.0 - 2.0 * s * mdev;   // (a lower bound of every pivot ratio d_i / G_ii)
+  } else {
+    worst = too_far ? 0.0 : chol_inv_coop(Gm, Xi, s, stage == 1 ? pivmin : 0.25);
+  }
   KS_TQ(7);
   if (too_far || !(worst > (stage == 1 ? pivmin : 0.25))) {
     // the block is (numerically) rank deficient: a breakdown, or a Newton basis too ill-conditioned to trust.  Nothing of
@@ -1468,7 +1496,6 @@ __global__ void __launch_bounds__(kBlock)
     }
     return;
   }
-  tri_inv_lds(Gm, Xi, s, dinvs);
   KS_TQ(4);
   if (stage == 1) {
     t_times(tb, tld, ntrue, k, s, A1, A2);   // T P
@@ -1486,13 +1513,14 @@ __global__ void __launch_bounds__(kBlock)
     }
     if (tid == 0) st->blk_piv1 = fmin(st->blk_piv1, worst);
 #ifdef KS_FIN_TIMING
-    if (tid == 0 && (k == 31 || (k == 21 && s == 20))) printf("[fin_blk stage 1 k=%d s=%d] reduce+elect %.2f | fetch %.2f | T^H %.2f | gram %.2f chol %.2f inv %.2f | rest %.2f us\n", k, s,
-                                    (tq[1] - tq[0]) * 0.01, (tq[2] - tq[1]) * 0.01, (tq[3] - tq[2]) * 0.01, (tq[6] - tq[3]) * 0.01, (tq[7] - tq[6]) * 0.01, (tq[4] - tq[7]) * 0.01, (wall_clock64() - tq[4]) * 0.01);
+    if (tid == 0 && (k == 31 || (k == 21 && s == 20))) printf("[fin_blk stage 1 k=%d s=%d] reduce+elect %.2f | fetch %.2f | T^H %.2f | gram+tests %.2f factor+inverse %.2f | rest %.2f us\n", k, s,
+                                    (tq[1] - tq[0]) * 0.01, (tq[2] - tq[1]) * 0.01, (tq[3] - tq[2]) * 0.01, (tq[6] - tq[3]) * 0.01, (tq[7] - tq[6]) * 0.01, (wall_clock64() - tq[4]) * 0.01);
 #endif
     return;
   }
   // ---------------- stage 2: A1 = C, Gm = R2, Xi = R2^-1 ----------------
   t_times(tb, tld, ntrue, k, s, A1, A2);     // T C
+  KS_TQ(12);
   // new columns of T
   for (int e = tid; e < (k + s) * s; e += kBlock) {
     const int r = e % (k + s), i = e / (k + s);
@@ -1505,35 +1533,29 @@ __global__ void __launch_bounds__(kBlock)
     }
     Tm[r + (int64_t)(k + i) * ldt] = a;
   }
+  KS_TQ(13);
   // R = R2 R1 (upper x upper),  PC = P + C R1
   for (int e = tid; e < s * s; e += kBlock) {
     const int a_ = e % s, b = e / s;
     T v = zero_of(T{});
-    for (int l = a_; l <= b; ++l) v = fma_(Gm[a_ + l * s], bs->R1[l + b * s], v);
+    for (int l = a_; l <= b; ++l) v = fma_(Gm[a_ + l * s], R1l[l + b * s], v);
     Rf[e] = v;
   }
   __syncthreads();
   if (tid < s) rfinv[tid] = inv_(Rf[tid + tid * s]);   // (read behind the next barrier: one division per column instead of one per row and column)
   for (int e = tid; e < k * s; e += kBlock) {
     const int r = e % k, i = e / k;
-    T v = bs->P[e];
-    for (int l = 0; l <= i; ++l) v = fma_(A1[l * k + r], bs->R1[l + i * s], v);
+    T v = Pl[e];
+    for (int l = 0; l <= i; ++l) v = fma_(A1[l * k + r], R1l[l + i * s], v);
     A2[e] = v;
   }
-  // zu = u (coordinates of z_0 in V_k)
-  for (int r = tid; r < k; r += kBlock) zu[r] = first ? from_real(r == k - 1 ? 1.0 : 0.0, T{}) : bs->u[r];
   __syncthreads();
   // zeta_i[r] for i >= 1:  r < k: A2[(i-1) k + r],  r = k + a: Rf[a + (i-1) s]
   auto zeta = [&](int i, int r) -> T { return r < k ? A2[(i - 1) * k + r] : Rf[(r - k) + (i - 1) * s]; };
   const int m = k + s;
   KS_TQ(5);
-  // H[0:k, 0:k-1) -> LDS (coalesced; a thread below walks ALONG a row of H: from memory that is a chain of L2 round trips)
-  const bool h_lds = k * (k - 1) <= kBlkHLds;
-  if (h_lds)
-    for (int e = tid; e < k * (k - 1); e += kBlock) Hl[e] = Hd[(e % k) + (int64_t)(e / k) * ldh];
   const T* hb = h_lds ? Hl : Hd;
   const int64_t hld = h_lds ? k : ldh;
-  __syncthreads();
   KS_TQ(8);
   // H column k-1:  (zeta_1 / sigma_1 + theta_1 zeta_0 - H[:, 0:k-1) u[0:k-1)) / u[k-1]
   for (int r = tid; r < m; r += kBlock) {
@@ -1564,11 +1586,15 @@ __global__ void __launch_bounds__(kBlock)
       const T* pc = A2 + (i - 1) * k;
       if (r < k) {
         int c = r > 0 ? r - 1 : 0;
-        for (; c + 1 < k - 1; c += 2) {
-          h0 = fma_(hb[r + c * hld], pc[c], h0);
-          h1 = fma_(hb[r + (c + 1) * hld], pc[c + 1], h1);
+        for (; c + 3 < k - 1; c += 4) {   // (eight LDS reads in flight per trip: a trip is one LDS latency whatever it carries)
+          const T b0 = hb[r + c * hld], b1 = hb[r + (c + 1) * hld], b2 = hb[r + (c + 2) * hld], b3 = hb[r + (c + 3) * hld];
+          const T p0 = pc[c], p1 = pc[c + 1], p2 = pc[c + 2], p3 = pc[c + 3];
+          h0 = fma_(b0, p0, h0);
+          h1 = fma_(b1, p1, h1);
+          h0 = fma_(b2, p2, h0);
+          h1 = fma_(b3, p3, h1);
         }
-        if (c < k - 1) h0 = fma_(hb[r + c * hld], pc[c], h0);
+        for (; c < k - 1; ++c) h0 = fma_(hb[r + c * hld], pc[c], h0);
       }
       h0 = fma_(hk[r], pc[k - 1], h0);
       rhs[e] = sub_(a, add_(h0, h1));
@@ -1594,6 +1620,7 @@ __global__ void __launch_bounds__(kBlock)
       for (int i = 1; i < SMX; ++i)
         if (i < s) Hd[r + (int64_t)(k - 1 + i) * ldh] = Mrow[i - 1];
     }
+    KS_TQ(14);
     for (int e = tid; e < (ldh - m) * (s - 1); e += kBlock) {
       const int r = m + e % (ldh - m), i = 1 + e / (ldh - m);
       Hd[r + (int64_t)(k - 1 + i) * ldh] = zero_of(T{});
@@ -1609,9 +1636,9 @@ __global__ void __launch_bounds__(kBlock)
     st->blk_gdev = fmax(st->blk_gdev, gdev);
   }
 #ifdef KS_FIN_TIMING
-  if (tid == 0 && (k == 31 || (k == 21 && s == 20))) printf("[fin_blk stage 2 k=%d s=%d] reduce+elect %.2f | fetch %.2f | T^H %.2f | gram %.2f chol %.2f inv %.2f | T cols, R, PC %.2f | H to LDS %.2f col k-1 %.2f rhs %.2f subst+rest %.2f us\n", k, s,
-                                  (tq[1] - tq[0]) * 0.01, (tq[2] - tq[1]) * 0.01, (tq[3] - tq[2]) * 0.01, (tq[6] - tq[3]) * 0.01, (tq[7] - tq[6]) * 0.01, (tq[4] - tq[7]) * 0.01, (tq[5] - tq[4]) * 0.01,
-                                  (tq[8] - tq[5]) * 0.01, (tq[9] - tq[8]) * 0.01, (tq[10] - tq[9]) * 0.01, (wall_clock64() - tq[10]) * 0.01);
+  if (tid == 0 && (k == 31 || (k == 21 && s == 20))) printf("[fin_blk stage 2 k=%d s=%d] reduce+elect %.2f | fetch %.2f | T^H %.2f | gram+tests %.2f factor+inverse %.2f | T C %.2f T cols %.2f R, PC %.2f | col k-1 %.2f rhs %.2f subst %.2f rest %.2f us\n", k, s,
+                                  (tq[1] - tq[0]) * 0.01, (tq[2] - tq[1]) * 0.01, (tq[3] - tq[2]) * 0.01, (tq[6] - tq[3]) * 0.01, (tq[7] - tq[6]) * 0.01, (tq[12] - tq[4]) * 0.01, (tq[13] - tq[12]) * 0.01, (tq[5] - tq[13]) * 0.01,
+                                  (tq[9] - tq[8]) * 0.01, (tq[10] - tq[9]) * 0.01, (tq[14] - tq[10]) * 0.01, (wall_clock64() - tq[14]) * 0.01);
 #endif
 }
 

@@ -1577,6 +1577,16 @@ __device__ __forceinline__ cd ld_agent(const cd* p) {
   return cd{ld_agent(q), ld_agent(q + 1)};
 }
 
+// ... and the store that goes with them: written THROUGH to where the other workgroups' agent-scope loads read, complete once
+// the wave's vmcnt reaches zero.  (A plain store + __threadfence() makes the same promise by writing back EVERY dirty line of
+// this XCD's L2 -- behind a kernel that streamed gigabytes through it that is 4 - 6 us: profiles/r06_fin_blk_timing.txt.)
+__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(cd* p, cd v) {
+  double* q = reinterpret_cast<double*>(p);
+  st_agent(q, v.x);
+  st_agent(q + 1, v.y);
+}
+
 // FIN_STEP_T: ONE reduction kernel per Arnoldi step.  The second reduction of step jm (c_raw, ||w'||^2 from the projection
 // kernel) is not needed before the NEXT step's first reduction (s = S^H y', |y'|^2 from k_dots): the operator and k_dots of
 // step jm+1 work on stored columns only.  So both are reduced by the same launch -- 2j+3 workgroups, one election, one
@@ -1686,17 +1696,18 @@ __global__ void __launch_bounds__(kBlock)
     tk1 = wall_clock64();
 #endif
     if (tid == 0) {
-      red[c] = s;
       if (mode != 1) {
-        __threadfence();
+        st_agent(red + c, s);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the sum has landed where the elected workgroup reads it: no L2 write-back -- st_agent)
         last_wg = (atomicAdd(counter, 1u) == gridDim.x - 1) ? 1 : 0;
+      } else {
+        red[c] = s;
       }
     }
     if (mode == 1) return;
     __syncthreads();
     if (!last_wg) return;
     if (tid == 0) *counter = 0u;  // armed for the next launch (stream order)
-    __threadfence();
 #ifdef KS_FIN_TIMING
     tk2 = wall_clock64();
 #endif

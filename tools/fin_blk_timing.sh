@@ -7,11 +7,11 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd $REPO
-KS_EXTRA_HIPCC_FLAGS=-DKS_FIN_TIMING python -m arnoldimethod.jl_amd.build > $OUT/fin_blk_build.log 2>&1 || { tail -5 $OUT/fin_blk_build.log; exit 1; }
+KS_EXTRA_HIPCC_FLAGS=-DKS_FIN_TIMING python arnoldimethod.jl_amd/build.py > $OUT/fin_blk_build.log 2>&1 || { tail -5 $OUT/fin_blk_build.log; exit 1; }
 {
   echo "== bench workload (216^3), 6 cycles"
-  python bench.py --steps 4 --warmup 2 2>&1 | grep "fin_blk stage" | tail -8
+  python bench.py --steps 4 --warmup 2 2>&1 | grep "fin_blk" | tail -8
   echo "== config 2 (100^3)"
-  python tools/config_bench.py 2 --sstep 20 --steps 4 --warmup 2 2>&1 | grep "fin_blk stage" | tail -8
+  python tools/config_bench.py 2 --sstep 20 --steps 4 --warmup 2 2>&1 | grep "fin_blk" | tail -8
 } > $OUT/fin_blk_timing.txt
 cat $OUT/fin_blk_timing.txt
