@@ -49,6 +49,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
       // became undefined: an exception between the adoption (rot_fuse, spec_adopt) and the first block kernel must not leave them
       // for the batch that follows the re-initialisation (it would rotate a fresh basis with a stale Q and skip products)
       ws->rot_pending = ws->rot_fuse = ws->rot_split = false;
+      ws->rot_true_start = ws->chain_true = ws->ztrue_valid = false;
       ws->spec_valid = false;
       ws->spec_adopt = 0;
       ws->rp_inflight = false;
@@ -106,13 +107,20 @@ template <class T> struct HipBackend : ks::Backend<T> {
         if (defer_dbg)
           std::fprintf(stderr, "[adopt] bpath %d j0 %d out0+rr %d fused_ok %d split_ok %d spec_valid %d blk0 %d spec_ne %d backoff %d\n", (int)bpath, j0, ws->rot_out0 + ws->rot_rr,
                        (int)fused_ok, (int)split_ok, (int)ws->spec_valid, bpath ? blk_sizes[0] : 0, ws->spec_ne, ws->spec_backoff);
-        if (bpath && j0 == ws->rot_out0 + ws->rot_rr && (fused_ok || split_ok) && ensure_zscratch<D>(ws)) {
+        // (a rotation granted on condition of a true start -- ks_workspace::rot_true_start --: a speculative chain qualifies only if
+        // it started from the true column; without one that column is formed now, while the old basis and its T still stand)
+        const bool need_true = ws->rot_true_start;
+        const bool spec_fits = ws->spec_valid && bpath && blk_sizes[0] >= ws->spec_ne && ws->spec_sh.size() == sizeof(blk_sh) && (!need_true || ws->spec_true);
+        if (bpath && j0 == ws->rot_out0 + ws->rot_rr && (fused_ok || split_ok) && ensure_zscratch<D>(ws) &&
+            (!need_true || spec_fits || true_start_enqueue<D>(ws))) {
           ws->rot_pending = false;
+          ws->rot_true_start = false;
           ws->rot_fuse = true;
           ws->rot_split = !fused_ok;
+          ws->chain_true = spec_fits ? ws->spec_true : need_true;
           ws->t_lazy = false;
           ws->t_hi = -1;
-          if (ws->spec_valid && blk_sizes[0] >= ws->spec_ne && ws->spec_sh.size() == sizeof(blk_sh)) {
+          if (spec_fits) {
             // the first spec_ne products of this block's chain are already in the scratch columns (enqueued behind the
             // previous expansion): the whole batch takes the shift sequence they were made with
             std::memcpy(&blk_sh, ws->spec_sh.data(), sizeof(blk_sh));
@@ -127,6 +135,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
         }
       }
       spec_drop(ws);   // (whatever was not adopted just now is void: this batch writes to V)
+      ws->ztrue_valid = false;   // (and so is the true last column of the basis as it stood)
       if (tpath && (bpath || ws->blk_tail || !(ws->t_lazy && j0 == ws->t_hi + 1))) {
         materialize(ws);   // whatever is lazy (either kind) becomes ordinary: this batch starts a new T
         ws->ntrue = j0;
@@ -168,6 +177,13 @@ template <class T> struct HipBackend : ks::Backend<T> {
       double tq0 = dbg ? ks::now_s() : 0.0, tq1 = 0, tq2 = 0;
       if (mb) publish_control(ws, j0, ws->Hstage_dev, 1, seq, tpath);
       else fetch_state_enqueue(ws, j0, tpath);
+      // drift watch: behind the publication of H, IN FRONT of the speculative chain (the host is not kept waiting for it; the result
+      // is read when the next expansion starts: by then the chain may still be running -- the restart no longer synchronises with
+      // the stream, ks_workspace.hpp: qstage_wait --, the watch in front of it has long finished: drift_probe_collect)
+      if (bpath && jend == to && to == ws->maxdim && j0 >= 2 && !ws->rp_inflight && ++ws->rp_count >= ws->rp_every) {
+        ws->rp_count = 0;
+        drift_probe_enqueue(j0, H);
+      }
       // (only where the next expansion can be expected to adopt them: this one already had the shape of a first block that reads
       // its chain from scratch columns, and the last speculation was not dropped -- after a drop the next 1, 2, 4, 8 cycles go without)
       if (bpath && jend == to && to == ws->maxdim &&
@@ -176,15 +192,11 @@ template <class T> struct HipBackend : ks::Backend<T> {
         if (defer_dbg2) std::fprintf(stderr, "[spec] enqueue? backoff %d j0 %d blk0 %d\n", ws->spec_backoff, j0, blk_sizes[0]);
         // (and the rotation will stay pending only behind a block whose Gram deviation passes the gate of rotate_tfold: where the last
         // batch's did not -- real shifts on a complex spectrum sit at 1e-11 .. 1e-10 every time -- the chain would be dropped)
-        const bool gate_likely = ws->blk_count == 0 || ws->blk_diag[2] <= 1e-12;
+        // round 6: there the chain starts from the TRUE last column, formed on the device first (ks_workspace::ztrue), and the
+        // rotation stays pending behind any accepted block
+        const bool start_stored = ws->blk_count == 0 || ws->blk_diag[2] <= 1e-12;
         if (ws->spec_backoff > 0) --ws->spec_backoff;
-        else if (gate_likely) spec_enqueue(blk_sh, j0);
-      }
-      // drift watch: behind the publication of H and the speculative chain (the host is not kept waiting for it; the result is
-      // read when the next expansion starts -- the restart in between synchronises with the stream)
-      if (bpath && jend == to && to == ws->maxdim && j0 >= 2 && !ws->rp_inflight && ++ws->rp_count >= ws->rp_every) {
-        ws->rp_count = 0;
-        drift_probe_enqueue(j0, H);
+        else spec_enqueue(blk_sh, j0, !start_stored);
       }
       // reverse mailbox: the restart that follows this (last) batch will rotate the factored basis -- put that rotation into
       // the stream NOW, behind a gate the host releases when it has Q (ks_workspace.hpp: gate_arm / rotate_tfold)
@@ -318,18 +330,20 @@ template <class T> struct HipBackend : ks::Backend<T> {
   // blocks of >= 8) and the operator's product is enqueued without host participation.
   // (Measured and withdrawn, round 5: the same products on a stream of their own behind the last second pass, next to the block's
   // final reduction + algebra kernel -- no gain on any configuration, the cross-stream waits cost what the overlap buys.)
-  void spec_enqueue(const ksd::BlkShifts<D>& sh, int k_now) {
+  void spec_enqueue(const ksd::BlkShifts<D>& sh, int k_now, bool from_true) {
     if (!ws->spec_on || !ws->rot_defer_on || !ws->gate_allowed || ws->sstep_eff < 8 || !op->async_capable || ws->ctx->hc.allreduce != nullptr) return;
+    if (from_true && (!ws->true_start_on || ws->maxdim + 1 > 40)) return;
     // as many products as the next first block will certainly have: it starts from about as many columns as this one did (Float64:
     // one more is tolerated -- a 2 x 2 block of the real Schur form kept whole; ComplexF64 restarts keep exactly mindim columns)
     const int ne = std::min(10, ws->maxdim - k_now - (sizeof(D) == 8 ? 1 : 0));
     if (ne < 2) return;
     if (!ensure_zscratch<D>(ws)) return;
+    if (from_true && !true_start_enqueue<D>(ws)) return;
     char* zs = static_cast<char*>(ws->zscratch);
     op->shift_store_cacheable = true;
     for (int i = 0; i < ne; ++i) {
       op->in_scale = 1.0;
-      const void* src = i == 0 ? ws->col(ws->maxdim) : static_cast<const void*>(zs + (size_t)(i - 1) * ws->ld * sizeof(D));
+      const void* src = i == 0 ? (from_true ? static_cast<const void*>(ws->ztrue) : ws->col(ws->maxdim)) : static_cast<const void*>(zs + (size_t)(i - 1) * ws->ld * sizeof(D));
       double tre, tim;
       if constexpr (sizeof(D) == 8) { tre = sh.theta[i]; tim = 0.0; }
       else { tre = sh.theta[i].x; tim = sh.theta[i].y; }
@@ -337,6 +351,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
     }
     ws->spec_sh.assign(reinterpret_cast<const char*>(&sh), reinterpret_cast<const char*>(&sh) + sizeof(sh));
     ws->spec_ne = ne;
+    ws->spec_true = from_true;
     ws->spec_valid = true;
   }
 
@@ -357,7 +372,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
     // buffers of its own (nothing the expansion kernels keep state in is touched): [2 doubles | nc coefficients]
     if (!ws->probe_dev) {
       KS_HIP(hipMalloc(&ws->probe_dev, 16 + (size_t)(ws->maxdim + 2) * 16));
-      KS_HIP(hipHostMalloc(&ws->probe_host, 16 + (size_t)(ws->maxdim + 2) * 16));
+      KS_HIP(hipHostMalloc(&ws->probe_host, 16 + (size_t)(ws->maxdim + 2) * 16, hipHostMallocCoherent | hipHostMallocMapped));   // (polled while the stream runs)
     }
     double* out = static_cast<double*>(ws->probe_dev);
     D* coef_d = reinterpret_cast<D*>(static_cast<char*>(ws->probe_dev) + 16);
@@ -400,7 +415,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
     hipStream_t s_ = ws->ctx->stream;
     if (!ws->probe_dev) {
       KS_HIP(hipMalloc(&ws->probe_dev, 16 + (size_t)(ws->maxdim + 2) * 16));
-      KS_HIP(hipHostMalloc(&ws->probe_host, 16 + (size_t)(ws->maxdim + 2) * 16));
+      KS_HIP(hipHostMalloc(&ws->probe_host, 16 + (size_t)(ws->maxdim + 2) * 16, hipHostMallocCoherent | hipHostMallocMapped));   // (polled while the stream runs)
     }
     if (!ws->probe_col) {
       if (hipMalloc(&ws->probe_col, (size_t)ws->ld * sizeof(D)) != hipSuccess) {   // (no room for one more column: no watch, no failure)
@@ -471,7 +486,14 @@ template <class T> struct HipBackend : ks::Backend<T> {
     if (!ws->ctx->distributed()) {
       // (written by the last workgroup of k_relation_watch; a batch that stopped early, or a stream that was not synchronised in
       // between -- a caller that went straight into the next expansion --, leaves the sequence word behind: no measurement)
-      if (__atomic_load_n(reinterpret_cast<const volatile uint64_t*>(&res[2]), __ATOMIC_ACQUIRE) == 0 || res[2] != ws->rp_seq) return;
+      // (the watch sits in front of the speculative chain and takes one product + a row sample: by the time the host has run its
+      // restart step it has normally finished; where the host was quicker, a bounded wait -- the decision this measurement feeds
+      // must not slip a cycle: a drift grows 20-90x per cycle)
+      const volatile double* seqw = &res[2];
+      const double t_w = ks::now_s();
+      while (*seqw != ws->rp_seq && ks::now_s() - t_w < 2e-3) {}
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      if (*seqw != ws->rp_seq) return;
     } else {
       // WAIT for the copy (it was enqueued a whole restart ago: normally long done).  Not a query: whether a rank sees the sums
       // must not depend on its timing -- the ranks take every decision alike (a rank that skipped a measurement would skip the

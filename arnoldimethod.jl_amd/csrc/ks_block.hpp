@@ -117,6 +117,35 @@ template <class D> bool ensure_zscratch(ks_workspace* ws) {
   return true;
 }
 
+// The true last column of the basis as it stands, S[:, 0:maxdim] T[0:maxdim, maxdim] with the device-resident T (k_fin_blk's), into
+// the scratch column ztrue (ks_workspace::ztrue): the start of a chain behind a block whose Gram deviation is above rounding level.
+// In stream order behind the batch that wrote T; before anything rotates the basis or resets T.  false: no kernel for the width
+// (maxdim + 1 > 40) or no room -- the caller rotates at once instead.
+template <class D> bool true_start_enqueue(ks_workspace* ws) {
+  if (ws->ztrue_valid) return true;
+  const int cin = ws->maxdim + 1;
+  if (cin > 40) return false;
+  if (!ws->ztrue) {
+    if (hipMalloc(&ws->ztrue, (size_t)ws->ld * sizeof(D)) != hipSuccess) { (void)hipGetLastError(); ws->ztrue = nullptr; return false; }
+    KS_HIP(hipMemsetAsync(ws->ztrue, 0, (size_t)ws->ld * sizeof(D), ws->ctx->stream));   // (pad rows stay zero)
+  }
+  ks_ctx* cx = ws->ctx;
+  ProfScope ps(cx, KSP_ROTATE, (double)ws->n * sizeof(D) * (cin + 1));
+  const D* Vc = static_cast<const D*>(ws->col(0));
+  const D* tcol = static_cast<const D*>(ws->Td) + (size_t)ws->maxdim * ws->ldt;
+  D* out = static_cast<D*>(ws->ztrue);
+  const size_t smem = (size_t)cin * sizeof(D);
+  const int nb = cap_blocks(ws, cx->num_cu * 4, kBlock);
+  if (cin <= 8) ksd::k_rotate_valu<D, 8><<<nb, kBlock, smem, cx->stream>>>(Vc, ws->ld, cin, 1, tcol, ws->ldt, out, ws->ld, -1);
+  else if (cin <= 16) ksd::k_rotate_valu<D, 16><<<nb, kBlock, smem, cx->stream>>>(Vc, ws->ld, cin, 1, tcol, ws->ldt, out, ws->ld, -1);
+  else if (cin <= 24) ksd::k_rotate_valu<D, 24><<<nb, kBlock, smem, cx->stream>>>(Vc, ws->ld, cin, 1, tcol, ws->ldt, out, ws->ld, -1);
+  else ksd::k_rotate_valu<D, 40><<<nb, kBlock, smem, cx->stream>>>(Vc, ws->ld, cin, 1, tcol, ws->ldt, out, ws->ld, -1);
+  KS_HIP(hipGetLastError());
+  ws->ztrue_valid = true;
+  ws->true_starts++;
+  return true;
+}
+
 template <class D>
 void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::vector<int>& sizes, const ksd::BlkShifts<D>& sh) {
   ks_ctx* cx = ws->ctx;
@@ -136,8 +165,10 @@ void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::v
     // to its place.
     const bool fuse = first && ws->rot_fuse;
     const bool split = fuse && ws->rot_split;   // no fused kernel for the shape: the ordinary rotation, then both passes on the scratch columns
+    const bool chain_true = fuse && ws->chain_true;   // the chain starts from the true last column (true_start_enqueue), not the stored one
     ws->rot_fuse = false;
     ws->rot_split = false;
+    ws->chain_true = false;
     char* zs = nullptr;
     if (fuse) {
       KS_REQUIRE(ws->zscratch != nullptr, KS_ERR_INTERNAL, "fused rotation without scratch columns (the adoption allocates them)");
@@ -157,7 +188,7 @@ void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::v
       if constexpr (sizeof(D) == 8) { tre = sh.theta[i]; tim = 0.0; }
       else { tre = sh.theta[i].x; tim = sh.theta[i].y; }
       op->in_scale = 1.0;
-      const void* src = i == 0 ? (fuse ? ws->col(ws->maxdim) : ws->col(k - 1)) : zcol(i - 1);
+      const void* src = i == 0 ? (fuse ? (chain_true ? static_cast<const void*>(ws->ztrue) : ws->col(ws->maxdim)) : ws->col(k - 1)) : zcol(i - 1);
       op->apply_shifted(src, zcol(i), tre, tim, sh.sigma[i], ws->ld, ws->st);
     }
     const int ne = k * s + s * (s + 1) / 2;

@@ -86,6 +86,18 @@ struct ks_workspace {
   int rot_fused_count = 0;      // rotations done by the fused kernel (ks_workspace_fused_rotations)
   bool rot_defer_ok = false;    // set by the library's restart drivers around their rotate_and_move (never by the verbs)
   void* zscratch = nullptr;     // device: ld x kBlkSMax elements, the Newton chain of a block whose first pass is fused
+  // TRUE START of a chain (round 6).  The chain of a fused / speculative block starts from the STORED last column, which is the
+  // true residual direction only up to the Gram deviation of the block that wrote it.  Behind a block whose deviation is above
+  // rounding level (real shifts on a complex spectrum: 1e-11 .. 1e-10 every time) the true column S T[:, maxdim] is formed once
+  // (one product of maxdim + 1 columns with a column of the device-resident T, into the scratch column `ztrue`) and the chain
+  // starts from it: the rotation may stay pending behind ANY accepted block.
+  void* ztrue = nullptr;        // device: ld elements, allocated on first use
+  bool true_start_on = false;   // KS_TRUE_START at creation (default 0: measured slower on config 3)
+  bool ztrue_valid = false;     // ztrue holds S T[:, maxdim] of the basis as it stands (no batch, rotation or reader since)
+  bool rot_true_start = false;  // the pending rotation was granted on condition that the chain starts from ztrue
+  bool spec_true = false;       // the speculative chain in the scratch columns started from ztrue
+  bool chain_true = false;      // the adopted first block starts its chain from ztrue (consumed by enqueue_steps_blk)
+  int true_starts = 0;          // products S T[:, maxdim] formed so far
   // SPECULATIVE CHAIN (the host step off the critical path).  When an expansion that ends at maxdim ran in blocks,
   // the first spec_ne products of the NEXT expansion's Newton chain are enqueued right behind it -- before the host has even
   // received H: they need the stored last column (the chain's start, see rot_pending) and shifts, for which the Ritz values of
@@ -118,6 +130,10 @@ struct ks_workspace {
   void* watch_acc = nullptr;    // device: [sum, rows, ticket] of k_relation_watch
   void* probe_host_dev = nullptr;   // device address of probe_host
   int rp_every = 1, rp_count = 0, rp_done = 0;
+  // recorded behind every upload of the rotation coefficients from the pinned stage (rotate_tfold): what the NEXT rotation has to
+  // wait for before it rewrites the stage -- not the whole stream, which by then holds the speculative chain of the next expansion
+  hipEvent_t qstage_evt = nullptr;
+  bool qstage_marked = false;
   hipEvent_t rp_event = nullptr;   // several ranks: recorded behind the copy of a watch's sums (drift_probe_collect asks it)
   bool rp_inflight = false;
   double rp_fro = 0.0, rp_last = 0.0, rp_seq = 0.0;
@@ -213,7 +229,9 @@ struct ks_workspace {
     (void)hipFree(Hscratch); (void)hipFree(partial); (void)hipFree(partial_s); (void)hipFree(partial2); (void)hipFree(coef); (void)hipFree(red);
     (void)hipFree(scal); (void)hipHostFree(scal_h); (void)hipHostFree(coef_h);
     if (zscratch) (void)hipFree(zscratch);
+    if (ztrue) (void)hipFree(ztrue);
     if (rp_event) (void)hipEventDestroy(rp_event);
+    if (qstage_evt) (void)hipEventDestroy(qstage_evt);
     if (probe_col) (void)hipFree(probe_col);
     if (watch_acc) (void)hipFree(watch_acc);
     if (probe_dev) (void)hipFree(probe_dev);
@@ -1025,12 +1043,32 @@ inline bool gate_arm(ks_workspace* ws) {
   return true;
 }
 
+// the pinned stage of the rotation coefficients is about to be rewritten: wait for the upload that last read it.  One process, one
+// rank: only for that upload (an event behind it) -- a hipStreamSynchronize here waited for the whole speculative chain of the next
+// expansion, which is in the stream by the time the restart reaches its rotation, and the host could enqueue nothing behind it
+// until the chain had run (round 6: ~50 us of idle device per cycle at the headline, 10-15 % of a config-4 cycle).  The host-staged
+// transport keeps the stream synchronisation (no chain is speculated there; its exchanges are host work between drained streams);
+// RCCL and the peer-to-peer transport speculate chains and take the event (every rank enqueues the same sequence either way).
+inline void qstage_wait(ks_workspace* ws) {
+  static const int evt_on = env_int("KS_QSTAGE_EVENT", 1);
+  if (evt_on && ws->ctx->hc.allreduce == nullptr && ws->qstage_marked) {
+    KS_HIP(hipEventSynchronize(ws->qstage_evt));
+    return;
+  }
+  KS_HIP(hipStreamSynchronize(ws->ctx->stream));
+}
+inline void qstage_mark(ks_workspace* ws) {
+  if (!ws->qstage_evt) KS_HIP(hipEventCreateWithFlags(&ws->qstage_evt, hipEventDisableTiming));
+  KS_HIP(hipEventRecord(ws->qstage_evt, ws->ctx->stream));
+  ws->qstage_marked = true;
+}
+
 template <class T> void rotate_tfold(ks_workspace* ws, int c0, int c, int r, const T* Qh, int ldq, int out0, int src, int dst) {
   using D = typename DevT<T>::type;
   ws->ctx->use();
   rot_flush(ws);   // (a rotation still pending is input of this one)
   const bool gated = ws->gate_armed;
-  if (!gated) KS_HIP(hipStreamSynchronize(ws->ctx->stream));  // Qstage may still be in flight from a previous rotation
+  if (!gated) qstage_wait(ws);  // Qstage may still be in flight from a previous rotation
   const int rr = r + (src >= 0 ? 1 : 0);
   const int cin = std::max(c0 + c, src + 1);
   KS_REQUIRE(cin <= ws->maxdim + 1 && rr <= ws->maxdim + 1, KS_ERR_INTERNAL, "T-folded rotation out of range");
@@ -1072,7 +1110,12 @@ template <class T> void rotate_tfold(ks_workspace* ws, int c0, int c, int r, con
     // Gram deviation of the block that wrote it (stored = true column up to R_2 = I + delta), so only after a batch that ended
     // in a block and whose deviation is at rounding level (<= 1e-12; accepted blocks may carry up to gram_dev_max = 1e-8,
     // those take the ordinary sequence)
-    const bool start_ok = ws->blk_diag[2] <= 1e-12;
+    // round 6: above that level the chain starts from the TRUE column instead (ks_workspace::ztrue), formed on the device from
+    // the basis and T as they stand -- any accepted block qualifies where that product has a kernel (maxdim + 1 <= 40 columns)
+    const bool true_start_on = ws->true_start_on;
+    const bool start_stored = ws->blk_diag[2] <= 1e-12;
+    const bool start_true = !start_stored && true_start_on && cin <= 40 && ws->blk_diag[2] <= ws->blk_gdevmax;
+    const bool start_ok = start_stored || start_true;
     static const int defer_dbg = env_int("KS_DEFER_DEBUG", 0);
     if (defer_dbg)
       std::fprintf(stderr, "[defer] on %d ok %d src %d extra %d cin %d sstep_eff %d blk_tail %d tl %d thi %d gdev %.2e\n", (int)ws->rot_defer_on, (int)ws->rot_defer_ok,
@@ -1081,7 +1124,9 @@ template <class T> void rotate_tfold(ks_workspace* ws, int c0, int c, int r, con
         start_ok) {
       gate_cancel(ws);   // (a pre-enqueued rotation returns at once)
       KS_HIP(hipMemcpyAsync(ws->Qd, qs, (size_t)cin * rr * sizeof(T), hipMemcpyHostToDevice, ws->ctx->stream));
+      qstage_mark(ws);
       ws->rot_pending = true;
+      ws->rot_true_start = start_true;
       ws->rot_cin = cin; ws->rot_rr = rr; ws->rot_out0 = out0;
       ws->t_lazy = true;            // "lazy" with an empty range: every reader flushes through materialize()
       ws->ntrue = out0 + rr;
@@ -1121,6 +1166,7 @@ template <class T> void rotate_tfold(ks_workspace* ws, int c0, int c, int r, con
     KS_HIP(hipStreamSynchronize(ws->ctx->stream));
   }
   KS_HIP(hipMemcpyAsync(ws->Qd, qs, (size_t)cin * rr * sizeof(T), hipMemcpyHostToDevice, ws->ctx->stream));
+  qstage_mark(ws);
   rotate_device<D>(ws, 0, cin, rr, out0, extra_elsewhere ? dst : -1);
   ws->t_lazy = false;
   ws->t_hi = -1;
@@ -1137,6 +1183,8 @@ inline void rot_flush(ks_workspace* ws) {
   if (!ws->rot_pending) return;
   spec_drop(ws);   // (the chain's start column is about to be overwritten)
   ws->rot_pending = false;
+  ws->rot_true_start = false;
+  ws->ztrue_valid = false;
   ws->t_lazy = false;
   ws->t_hi = -1;
   if (ws->dtype == KS_F64) rotate_device<double>(ws, 0, ws->rot_cin, ws->rot_rr, ws->rot_out0, -1);
@@ -1171,6 +1219,7 @@ template <class T> void rotate_lazy(ks_workspace* ws, int c0, int c, int r, cons
   for (int jj = 0; jj < r; ++jj)
     for (int ii = 0; ii < c; ++ii) qs[ii + (size_t)jj * c] = Qh[ii + (size_t)jj * ldq] * ws->hostscale[c0 + ii];
   KS_HIP(hipMemcpyAsync(ws->Qd, qs, (size_t)c * r * sizeof(T), hipMemcpyHostToDevice, ws->ctx->stream));
+  qstage_mark(ws);
   rotate_device<D>(ws, c0, c, r);
   // the rotated columns are ordinary again; the factors of columns c0+r .. c0+c-1 (inputs only) stay as they are
   bool any = false;

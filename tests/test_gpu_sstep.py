@@ -660,7 +660,7 @@ def test_fused_rotation_and_speculative_chain_match_the_plain_sequence(monkeypat
         assert r["rel"] <= max(1e-12, 3 * plain["rel"]) and r["orth"] <= 1e-12, (r["rel"], plain["rel"], r["orth"])
 
 
-@pytest.mark.parametrize("case", ["complex-fused", "complex-20-40", "complex-30-columns", "real-30-columns", "nonsymmetric-9-or-10"])
+@pytest.mark.parametrize("case", ["complex-fused", "complex-20-40", "complex-30-columns", "real-30-columns", "nonsymmetric-9-or-10", "nonsymmetric-true-start"])
 def test_pending_rotation_and_speculative_chain_beyond_the_headline_shapes(monkeypatch, case):
     """(a) ComplexF64 at config 4's shape: k_brotdots_mfma on the real view of the basis (complex coefficients, imaginary parts of
     the inner products) + the speculative chain with complex shifts.  (b) Shapes outside the instantiated fused rotations (31
@@ -674,7 +674,12 @@ def test_pending_rotation_and_speculative_chain_beyond_the_headline_shapes(monke
                                 dtype=np.complex128, nev=12, mindim=20, maxdim=40, which="LM"),
           "complex-30-columns": dict(A=_complex_op(), dtype=np.complex128, nev=8, mindim=15, maxdim=30, which="LM"),
           "real-30-columns": dict(grid=(20, 21, 22), nev=12, mindim=15, maxdim=30, which="SR"),
-          "nonsymmetric-9-or-10": dict(A=_nonsym(), dtype=np.float64, nev=8, mindim=10, maxdim=20, which="LM")}[case]
+          "nonsymmetric-9-or-10": dict(A=_nonsym(), dtype=np.float64, nev=8, mindim=10, maxdim=20, which="LM"),
+          "nonsymmetric-true-start": dict(A=_nonsym(), dtype=np.float64, nev=8, mindim=10, maxdim=20, which="LM")}[case]
+    # (d) round 6, KS_TRUE_START=1 (off by default: slower on config 3): the same operator with the chain started
+    # from the TRUE last column (ks_workspace::ztrue, formed on the device from the basis and T) wherever the block in front
+    # carries a Gram deviation above rounding level: every restart defers, the chains are adopted.
+    monkeypatch.setenv("KS_TRUE_START", "1" if case == "nonsymmetric-true-start" else "0")
     plain = _cycles(monkeypatch, False, False, ncycles=7, **kw)
     spec = _cycles(monkeypatch, True, True, ncycles=7, **kw)
     pi, si = plain["info"], spec["info"]
@@ -684,6 +689,12 @@ def test_pending_rotation_and_speculative_chain_beyond_the_headline_shapes(monke
         # (the deferral is taken only behind a block whose Gram deviation is <= 1e-12 -- the chain starts from the STORED last
         # column --; with real shifts on this spectrum most blocks are at 1e-11..1e-10: few rotations stay pending, by design)
         assert si["split_rotations"] == 0 and si["blocks"] >= 6, si
+    elif case == "nonsymmetric-true-start":
+        # cycles 1..6 of 0..6 follow a block cycle: all six rotations stay pending (fused: both shapes have a kernel), and the
+        # chains behind cycles 1..5 are adopted (the first block cycle's chain starts from the stored column -- nothing measured
+        # yet -- and may be replaced by a true start)
+        # (... which costs that chain and one cycle of back-off)
+        assert si["fused_rotations"] + si["split_rotations"] >= 5 and si["chains_adopted"] >= 2 and si["blocks"] >= 6, si
     elif case in ("complex-fused", "complex-20-40"):
         assert si["fused_rotations"] >= (4 if case == "complex-fused" else 3) and si["split_rotations"] == 0 and si["chains_adopted"] >= (3 if case == "complex-fused" else 2), si
     else:
