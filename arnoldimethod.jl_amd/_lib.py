@@ -104,6 +104,7 @@ PROTOTYPES = {
     "ks_workspace_relation_probes": [vp, P(C.c_int)],
     "ks_workspace_fused_rotations": [vp, P(C.c_int), P(C.c_int), P(C.c_int)],
     "ks_workspace_split_rotations": [vp, P(C.c_int)],
+    "ks_workspace_deflated_blocks": [vp, P(C.c_int), P(C.c_int)],
     "ks_sstep_partition": [C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_int), C.c_int, P(C.c_int)],
     "ks_workspace_assert_arnoldi": [vp, i32],
     "ks_workspace_provenance": [vp, P(C.c_int)],

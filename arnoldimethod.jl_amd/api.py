@@ -637,8 +637,10 @@ class ArnoldiWorkspace:
         check(_lib.load().ks_workspace_fused_rotations(self._h, C.byref(fr), C.byref(sa), C.byref(sd)))
         sr = C.c_int()
         check(_lib.load().ks_workspace_split_rotations(self._h, C.byref(sr)))
+        db, dc = C.c_int(), C.c_int()
+        check(_lib.load().ks_workspace_deflated_blocks(self._h, C.byref(db), C.byref(dc)))
         return dict(s=s.value, blocks=b.value, abandoned=a.value, pivot_stage1=d[0], pivot_stage2=d[1], gram_dev=d[2], fused_rotations=fr.value,
-                    split_rotations=sr.value, chains_adopted=sa.value, chains_dropped=sd.value)
+                    split_rotations=sr.value, chains_adopted=sa.value, chains_dropped=sd.value, deflated_blocks=db.value, deflated_columns=dc.value)
 
     @property
     def relation_info(self) -> dict:

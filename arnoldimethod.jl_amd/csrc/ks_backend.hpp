@@ -87,8 +87,17 @@ template <class T> struct HipBackend : ks::Backend<T> {
       // a range of one step gains nothing.  Several ranks: two all-reduces per block (ks_block.hpp).
       std::vector<int> blk_sizes;
       ksd::BlkShifts<D> blk_sh{};
+      // in-chain deflation against locked columns of dominant eigenvalues (defl_plan): a problem that abandoned its blocks before
+      // those columns were locked gets its block size back when they are
+      std::vector<std::complex<double>> defl_ex;
+      int ndefl = 0;
+      if (tpath && !no_block && ws->sstep >= 2 && ws->sstep_eff >= 1 && op->async_capable && jend - j0 + 1 >= 2) {
+        ndefl = defl_plan(H, j0, defl_ex);
+        if (ndefl > ws->defl_last && ws->sstep_eff < ws->sstep) { ws->sstep_eff = ws->sstep; ws->blk_clean = 0; }
+        ws->defl_last = ndefl;
+      }
       if (tpath && !no_block && ws->sstep_eff >= 2 && op->async_capable && jend - j0 + 1 >= 2 &&
-          blk_make_shifts<D>(ws, std::min(ws->sstep_eff, ksd::kBlkSMax), blk_sh))
+          blk_make_shifts<D>(ws, std::min(ws->sstep_eff, ksd::kBlkSMax), blk_sh, ndefl > 0 ? &defl_ex : nullptr))
         blk_sizes = blk_partition(ws->dtype, j0, jend - j0 + 1, std::min(ws->sstep_eff, ksd::kBlkSMax));
       const bool bpath = !blk_sizes.empty();
       if (bpath) {   // (a partition that ends early: this batch goes as far as the blocks do, the next one takes the rest step by step)
@@ -111,7 +120,8 @@ template <class T> struct HipBackend : ks::Backend<T> {
         // it started from the true column; without one that column is formed now, while the old basis and its T still stand)
         const bool need_true = ws->rot_true_start;
         const bool spec_fits = ws->spec_valid && bpath && blk_sizes[0] >= ws->spec_ne && ws->spec_sh.size() == sizeof(blk_sh) && (!need_true || ws->spec_true);
-        if (bpath && j0 == ws->rot_out0 + ws->rot_rr && (fused_ok || split_ok) && ensure_zscratch<D>(ws) &&
+        // (a deflated chain needs the ROTATED locked columns before its first product: the rotation runs now)
+        if (bpath && ndefl == 0 && j0 == ws->rot_out0 + ws->rot_rr && (fused_ok || split_ok) && ensure_zscratch<D>(ws) &&
             (!need_true || spec_fits || true_start_enqueue<D>(ws))) {
           ws->rot_pending = false;
           ws->rot_true_start = false;
@@ -152,7 +162,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
       const uint64_t seq = ++ws->mbox_seq;
       if (bpath) {
         blk_ensure_buffers(ws);
-        enqueue_steps_blk<D>(ws, op, j0, blk_sizes, blk_sh);
+        enqueue_steps_blk<D>(ws, op, j0, blk_sizes, blk_sh, ndefl);
       } else if (tpath) {
         enqueue_steps_t<D>(ws, op, j0, jend);
       } else if (lazy) {
@@ -186,7 +196,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
       }
       // (only where the next expansion can be expected to adopt them: this one already had the shape of a first block that reads
       // its chain from scratch columns, and the last speculation was not dropped -- after a drop the next 1, 2, 4, 8 cycles go without)
-      if (bpath && jend == to && to == ws->maxdim &&
+      if (bpath && ndefl == 0 && jend == to && to == ws->maxdim &&
           (ks_blk_rot_ok(ws->dtype == KS_F64 ? 0 : 1, ws->maxdim + 1, j0, blk_sizes[0]) || ks_blk_zsrc_ok(ws->dtype == KS_F64 ? 0 : 1, j0, blk_sizes[0]))) {
         static const int defer_dbg2 = env_int("KS_DEFER_DEBUG", 0);
         if (defer_dbg2) std::fprintf(stderr, "[spec] enqueue? backoff %d j0 %d blk0 %d\n", ws->spec_backoff, j0, blk_sizes[0]);
@@ -323,6 +333,56 @@ template <class T> struct HipBackend : ks::Backend<T> {
       ws->ritz_valid = false;   // (note_ritz of a driver that does know them follows and takes precedence)
     }
     return early_stands;
+  }
+
+  // IN-CHAIN DEFLATION, the plan of a batch (ks_block_kernels.hpp: kDeflMax; tools/model_deflated_chain.py).  The locked columns are
+  // the leading decoupled block of the caller's H (src/run.jl:330 zeroes the sub-diagonal entry behind them; an exact breakdown
+  // leaves the same pattern, and deflating against an invariant subspace is just as valid).  Deflated: the LEADING locked columns
+  // whose eigenvalue exceeds KS_DEFLATE_RATIO (1.5) times the largest Ritz value of the rest -- a chain scaled by 1 / max|rest|
+  // multiplies a component along such a vector by that ratio per step, from a start at the level the vector was locked at (tol).
+  // Locked columns of NON-dominant eigenvalues (every :SR / :SM problem; the headline) are left alone: their components shrink.
+  // `ex`: the eigenvalues of the deflated columns (no shift is placed there).  One rank only (the dot products are not all-reduced).
+  int defl_plan(const ks::Mat<T>& H, int j0, std::vector<std::complex<double>>& ex) {
+    ex.clear();
+    if (!ws->defl_on || ws->ctx->distributed() || !ws->ritz_valid || ws->ritz.empty()) return 0;
+    static const double ratio = [] { const char* e = std::getenv("KS_DEFLATE_RATIO"); const double v = e ? std::atof(e) : 1.5; return v > 1.0 ? v : 1.5; }();
+    int nl = 0;
+    for (int j = 1; j <= j0 - 2; ++j)
+      if (H(j, j - 1) == T(0)) nl = j;
+    if (nl == 0) return 0;
+    using C = std::complex<double>;
+    std::vector<C> lam(nl);
+    std::vector<int> width(nl, 1);
+    for (int j = 0; j < nl;) {
+      if (j + 1 < nl && H(j + 1, j) != T(0)) {   // 2 x 2 block of the real Schur form
+        const C a = C(H(j, j)), b = C(H(j, j + 1)), c = C(H(j + 1, j)), d = C(H(j + 1, j + 1));
+        const C tr2 = 0.5 * (a + d), disc = std::sqrt(tr2 * tr2 - (a * d - b * c));
+        lam[j] = tr2 + disc; lam[j + 1] = tr2 - disc;
+        width[j] = 2; width[j + 1] = 0;
+        j += 2;
+      } else {
+        lam[j] = C(H(j, j));
+        ++j;
+      }
+    }
+    double rest = 0.0;
+    for (auto z : ws->ritz) {
+      if (!std::isfinite(std::abs(z))) continue;
+      bool locked = false;
+      for (int j = 0; j < nl; ++j) locked = locked || std::abs(z - lam[j]) <= 1e-6 * std::max(1.0, std::abs(lam[j]));
+      if (!locked) rest = std::max(rest, std::abs(z));
+    }
+    if (!(rest > 0.0)) return 0;
+    int nd = 0;
+    for (int j = 0; j < nl;) {
+      const int w = width[j] == 2 ? 2 : 1;
+      const double mag = w == 2 ? std::max(std::abs(lam[j]), std::abs(lam[j + 1])) : std::abs(lam[j]);
+      if (!(mag > ratio * rest) || nd + w > ksd::kDeflMax) break;
+      for (int q = 0; q < w; ++q) ex.push_back(lam[j + q]);
+      nd += w;
+      j += w;
+    }
+    return nd;
   }
 
   // The first products of the NEXT expansion's Newton chain, behind the batch that just went into the stream (see

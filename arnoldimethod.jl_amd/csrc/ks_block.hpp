@@ -147,7 +147,7 @@ template <class D> bool true_start_enqueue(ks_workspace* ws) {
 }
 
 template <class D>
-void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::vector<int>& sizes, const ksd::BlkShifts<D>& sh) {
+void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::vector<int>& sizes, const ksd::BlkShifts<D>& sh, int ndefl = 0) {
   ks_ctx* cx = ws->ctx;
   hipStream_t s_ = cx->stream;
   const int ldh = ws->maxdim + 1;
@@ -190,7 +190,18 @@ void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::v
       op->in_scale = 1.0;
       const void* src = i == 0 ? (fuse ? (chain_true ? static_cast<const void*>(ws->ztrue) : ws->col(ws->maxdim)) : ws->col(k - 1)) : zcol(i - 1);
       op->apply_shifted(src, zcol(i), tre, tim, sh.sigma[i], ws->ld, ws->st);
+      if (ndefl > 0) {
+        // in-chain deflation against the locked columns of dominant eigenvalues (ks_block_kernels.hpp: kDeflMax)
+        ProfScope ps(cx, KSP_AXPY, nb8 * 2.0 * (ndefl + 1) + nb8);
+        if (!ws->defl_part) KS_HIP(hipMalloc(&ws->defl_part, (size_t)ksd::kDeflMax * 1024 * sizeof(D)));
+        const int nbd = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(1024, cx->num_cu * 4), (ws->n + kBlock - 1) / kBlock));
+        D* zc = static_cast<D*>(zcol(i));
+        const D* U = static_cast<const D*>(ws->col(0));
+        ksd::k_defl_dots<D><<<nbd, kBlock, 0, s_>>>(U, ws->ld, ndefl, zc, ws->n, static_cast<D*>(ws->defl_part));
+        ksd::k_defl_apply<D><<<nbd, kBlock, 0, s_>>>(U, ws->ld, ndefl, zc, ws->n, static_cast<const D*>(ws->defl_part), nbd, bs->cdefl + (size_t)i * ksd::kDeflMax);
+      }
     }
+    if (ndefl > 0) ws->defl_blocks++;
     const int ne = k * s + s * (s + 1) / 2;
     int nb1, nb2;
     // reduction + small algebra of one stage.  Several ranks: reduce -> ONE all-reduce of k s + s (s + 1) / 2 elements over
@@ -202,13 +213,13 @@ void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::v
       D* red = static_cast<D*>(ws->bred);
       if (!cx->distributed()) {
         ksd::k_fin_blk<D><<<(ne + 3) / 4, kBlock, 0, s_>>>(stage, 0, part, nbp, ws->pnb, k, s, red, Hd, ldh, Tm, ws->ldt, ws->ntrue, bs, sh, first, ws->blk_pivmin,
-                                                 ws->blk_gdevmax, ws->st, ws->ctr);
+                                                 ws->blk_gdevmax, ws->st, ws->ctr, ndefl);
       } else {
         ksd::k_fin_blk<D><<<(ne + 3) / 4, kBlock, 0, s_>>>(stage, 1, part, nbp, ws->pnb, k, s, red, Hd, ldh, Tm, ws->ldt, ws->ntrue, bs, sh, first, ws->blk_pivmin,
-                                                 ws->blk_gdevmax, ws->st, ws->ctr);
+                                                 ws->blk_gdevmax, ws->st, ws->ctr, ndefl);
         cx->allreduce(reinterpret_cast<double*>(red), ne * (int)(sizeof(D) / 8));
         ksd::k_fin_blk<D><<<1, kBlock, 0, s_>>>(stage, 2, part, nbp, ws->pnb, k, s, red, Hd, ldh, Tm, ws->ldt, ws->ntrue, bs, sh, first, ws->blk_pivmin,
-                                                ws->blk_gdevmax, ws->st, ws->ctr);
+                                                ws->blk_gdevmax, ws->st, ws->ctr, ndefl);
       }
     };
     if (fuse && !split) {
@@ -233,12 +244,23 @@ void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::v
 }
 
 // shifts of a batch from the workspace's Ritz values; false: nothing to take them from (first expansion of a run)
-template <class D> bool blk_make_shifts(ks_workspace* ws, int smax, ksd::BlkShifts<D>& sh) {
+// `excluded`: eigenvalues of the locked columns the chain is deflated against (in-chain deflation): no shift there, and the scale
+// follows the rest of the spectrum
+template <class D> bool blk_make_shifts(ks_workspace* ws, int smax, ksd::BlkShifts<D>& sh, const std::vector<std::complex<double>>* excluded = nullptr) {
   if (!ws->ritz_valid || ws->ritz.empty()) return false;
   const bool real = sizeof(D) == 8;
-  const auto th = leja_shifts(ws->ritz, smax, real);
+  std::vector<std::complex<double>> pool;
+  if (excluded && !excluded->empty()) {
+    for (auto z : ws->ritz) {
+      bool ex = false;
+      for (auto q : *excluded) ex = ex || std::abs(z - q) <= 1e-6 * std::max(1.0, std::abs(q));
+      if (!ex) pool.push_back(z);
+    }
+  }
+  const std::vector<std::complex<double>>& src = pool.empty() ? ws->ritz : pool;
+  const auto th = leja_shifts(src, smax, real);
   double rho = 0.0;
-  for (auto z : ws->ritz)
+  for (auto z : src)
     if (std::isfinite(std::abs(z))) rho = std::max(rho, std::abs(z));
   if (!(rho > 0.0) || !std::isfinite(rho)) return false;
   const double sigma = std::ldexp(1.0, -(int)std::lround(std::log2(rho)));   // power of two ~ 1 / ||A||: range only, exact

@@ -1150,12 +1150,28 @@ template <class T> struct BlkShifts {
 };
 
 // device-resident scratch of a batch of blocks (one per workspace)
+// IN-CHAIN DEFLATION (round 6; tools/model_deflated_chain.py).  The Newton chain of a block is orthogonalised against the basis only
+// at the END of the block.  With locked Schur vectors U = V[:, 0:nd) of DOMINANT eigenvalues (:LM problems with outliers) that is
+// too late: A z has components along U through the non-normal coupling even though z is orthogonal to U, every further step
+// multiplies them by |lambda_locked| / |lambda_rest|, and a shift AT the locked value puts -theta z_{i-1} (a vector of the basis)
+// on top of every later column -- either way the projected columns come out parallel (pivot <= 0 at the 5th-7th column on the
+// operator of test/partial_schur.jl:122-138; cond(R_1) 3e14 in the model).  Cure: no shift at locked values, and every chain
+// vector is projected against the (few) locked columns as soon as it exists:
+//     z_i <- z_i - U c_i,  c_i = U^H z_i        (z_i = sigma_i (A - theta_i) z_{i-1} as the operator kernel wrote it)
+// so that  A z_{i-1} = z_i / sigma_i + theta_i z_{i-1} + U c_i / sigma_i  -- the H recovery of k_fin_blk adds c_i / sigma_i to the
+// locked rows.  Two launches per step, nd + 1 columns read twice: k_defl_dots (partial sums per workgroup) and k_defl_apply
+// (every workgroup sums the partials itself, updates its rows; workgroup 0 stores c_i for k_fin_blk).
+constexpr int kDeflMax = 16;
+__device__ __forceinline__ double shfl_xor_(double v, int off) { return __shfl_xor(v, off, 64); }
+__device__ __forceinline__ cd shfl_xor_(cd v, int off) { return cd{__shfl_xor(v.x, off, 64), __shfl_xor(v.y, off, 64)}; }
+
 template <class T> struct BlkScratch {
   T P[kBlkKMax * kBlkSMax];        // true coordinates of Z in V_k (k x s, column stride k)
   T R1[kBlkSMax * kBlkSMax];       // stage-1 triangular factor (s x s, column stride s)
   T coefp[kBlkKMax * kBlkSMax];    // (T P) R1^-1: what k_bupdate subtracts (k x s, column stride k)
   T r1inv[kBlkSMax * kBlkSMax];
   T u[kBlkKMax + kBlkSMax];        // coordinates of the last stored column in the true basis (valid after a block)
+  T cdefl[kBlkSMax * kDeflMax];    // in-chain deflation (k_defl_apply): U^H z_i of chain step i, column stride kDeflMax
 };
 
 __device__ __forceinline__ double inv_(double a) { return 1.0 / a; }
@@ -1303,9 +1319,63 @@ __device__ void t_times(const T* __restrict__ tb, int64_t tld, int ntrue, int k,
 // takes the same decisions (row-partitioned basis, replicated H / T: SURVEY 8e).
 template <class T>
 __global__ void __launch_bounds__(kBlock)
+    k_defl_dots(const T* __restrict__ U, int64_t ld, int nd, const T* __restrict__ z, int64_t n, T* __restrict__ partial /* [nd][gridDim.x] */) {
+  __shared__ T red[kBlock / 64][kDeflMax];
+  T acc[kDeflMax];
+#pragma unroll
+  for (int l = 0; l < kDeflMax; ++l) acc[l] = zero_of(T{});
+  for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < n; row += (int64_t)gridDim.x * kBlock) {
+    const T zv = z[row];
+#pragma unroll
+    for (int l = 0; l < kDeflMax; ++l)
+      if (l < nd) acc[l] = fma_(conj_(U[row + (int64_t)l * ld]), zv, acc[l]);
+  }
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int l = 0; l < kDeflMax; ++l) {
+    if (l < nd) {
+      T v = acc[l];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v = add_(v, shfl_xor_(v, off));
+      if (lane == 0) red[wv][l] = v;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nd) {
+    T v = zero_of(T{});
+    for (int w = 0; w < kBlock / 64; ++w) v = add_(v, red[w][threadIdx.x]);
+    partial[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = v;
+  }
+}
+
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+    k_defl_apply(const T* __restrict__ U, int64_t ld, int nd, T* __restrict__ z, int64_t n, const T* __restrict__ partial, int nbp, T* __restrict__ cout) {
+  __shared__ T c[kDeflMax];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int l = wv; l < nd; l += kBlock / 64) {   // (fixed order: every workgroup computes the same c)
+    T v = zero_of(T{});
+    for (int b = lane; b < nbp; b += 64) v = add_(v, partial[(int64_t)l * nbp + b]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = add_(v, shfl_xor_(v, off));
+    if (lane == 0) c[l] = v;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x < kDeflMax) cout[threadIdx.x] = threadIdx.x < nd ? c[threadIdx.x] : zero_of(T{});
+  for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < n; row += (int64_t)gridDim.x * kBlock) {
+    T zv = z[row];
+#pragma unroll
+    for (int l = 0; l < kDeflMax; ++l)
+      if (l < nd) zv = sub_(zv, mul_(U[row + (int64_t)l * ld], c[l]));
+    z[row] = zv;
+  }
+}
+
+template <class T>
+__global__ void __launch_bounds__(kBlock)
     k_fin_blk(int stage, int mode, const T* __restrict__ partial, int nb, int pnb, int k, int s, T* __restrict__ red, T* __restrict__ Hd,
               int ldh, T* __restrict__ Tm, int ldt, int ntrue, BlkScratch<T>* __restrict__ bs, BlkShifts<T> sh, int first,
-              double pivmin, double gdevmax, DevState* __restrict__ st, unsigned* __restrict__ counter) {
+              double pivmin, double gdevmax, DevState* __restrict__ st, unsigned* __restrict__ counter, int ndefl = 0) {
   const int bd_flag = st->breakdown;   // (tested behind the loads of the reduction: one round trip to memory instead of two in a row)
   __shared__ int last_wg;
   __shared__ double redv[kBlock / 64][3];
@@ -1560,6 +1630,7 @@ __global__ void __launch_bounds__(kBlock)
   // H column k-1:  (zeta_1 / sigma_1 + theta_1 zeta_0 - H[:, 0:k-1) u[0:k-1)) / u[k-1]
   for (int r = tid; r < m; r += kBlock) {
     T a = scl(zeta(1, r), 1.0 / sh.sigma[0]);
+    if (r < ndefl) a = add_(a, scl(bs->cdefl[r], 1.0 / sh.sigma[0]));   // (in-chain deflation: + U c_1 / sigma_1)
     if (r < k) {
       a = fma_(sh.theta[0], zu[r], a);
       T h0 = zero_of(T{}), h1 = zero_of(T{});
@@ -1582,6 +1653,7 @@ __global__ void __launch_bounds__(kBlock)
     for (int e = tid; e < m * (s - 1); e += kBlock) {
       const int r = e % m, i = 1 + e / m;
       T a = fma_(sh.theta[i], zeta(i, r), scl(zeta(i + 1, r), 1.0 / sh.sigma[i]));
+      if (r < ndefl) a = add_(a, scl(bs->cdefl[i * kDeflMax + r], 1.0 / sh.sigma[i]));
       T h0 = zero_of(T{}), h1 = zero_of(T{});
       const T* pc = A2 + (i - 1) * k;
       if (r < k) {

@@ -641,6 +641,7 @@ int ks_workspace_create(ks_ctx* ctx, int64_t n_local, int64_t n_global, int64_t 
     w->sstep_eff = w->sstep;
     w->rot_defer_on = env_int("KS_ROT_DEFER", 1) != 0;   // restart rotation left pending for the next expansion's fused first pass
     w->spec_on = env_int("KS_SPEC_CHAIN", 1) != 0;        // first products of the next expansion behind the previous one
+    w->defl_on = env_int("KS_CHAIN_DEFLATE", 1) != 0;    // Newton chains deflated against locked columns of dominant eigenvalues
     w->true_start_on = env_int("KS_TRUE_START", 0) != 0;  // chains behind a block with a Gram deviation above rounding level start from S T[:, maxdim]
     if (const char* e = std::getenv("KS_SSTEP_GDEV_MAX")) w->blk_gdevmax = std::atof(e);
     if (const char* e = std::getenv("KS_SSTEP_PIVOT_MIN")) w->blk_pivmin = std::atof(e);
@@ -745,6 +746,14 @@ int ks_workspace_split_rotations(const ks_workspace* ws, int* count) {
   return guarded([&] {
     KS_REQUIRE(ws && count, KS_ERR_ARGUMENT, "null argument");
     *count = ws->rot_split_count;
+  });
+}
+
+int ks_workspace_deflated_blocks(const ks_workspace* ws, int* blocks, int* columns) {
+  return guarded([&] {
+    KS_REQUIRE(ws != nullptr, KS_ERR_ARGUMENT, "null argument");
+    if (blocks) *blocks = ws->defl_blocks;
+    if (columns) *columns = ws->defl_last;
   });
 }
 

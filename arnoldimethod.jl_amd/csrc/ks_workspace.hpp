@@ -91,6 +91,11 @@ struct ks_workspace {
   // rounding level (real shifts on a complex spectrum: 1e-11 .. 1e-10 every time) the true column S T[:, maxdim] is formed once
   // (one product of maxdim + 1 columns with a column of the device-resident T, into the scratch column `ztrue`) and the chain
   // starts from it: the rotation may stay pending behind ANY accepted block.
+  // IN-CHAIN DEFLATION (ks_block_kernels.hpp: kDeflMax; HipBackend::defl_plan)
+  bool defl_on = true;          // KS_CHAIN_DEFLATE at creation
+  void* defl_part = nullptr;    // device: kDeflMax x 1024 partial sums
+  int defl_blocks = 0;          // blocks whose chain was deflated (ks_workspace_sstep_info: diag3[...] no -- see ks_workspace_deflated_blocks)
+  int defl_last = 0;            // columns the last block batch deflated against
   void* ztrue = nullptr;        // device: ld elements, allocated on first use
   bool true_start_on = false;   // KS_TRUE_START at creation (default 0: measured slower on config 3)
   bool ztrue_valid = false;     // ztrue holds S T[:, maxdim] of the basis as it stands (no batch, rotation or reader since)
@@ -230,6 +235,7 @@ struct ks_workspace {
     (void)hipFree(scal); (void)hipHostFree(scal_h); (void)hipHostFree(coef_h);
     if (zscratch) (void)hipFree(zscratch);
     if (ztrue) (void)hipFree(ztrue);
+    if (defl_part) (void)hipFree(defl_part);
     if (rp_event) (void)hipEventDestroy(rp_event);
     if (qstage_evt) (void)hipEventDestroy(qstage_evt);
     if (probe_col) (void)hipFree(probe_col);
@@ -1121,7 +1127,7 @@ template <class T> void rotate_tfold(ks_workspace* ws, int c0, int c, int r, con
       std::fprintf(stderr, "[defer] on %d ok %d src %d extra %d cin %d sstep_eff %d blk_tail %d tl %d thi %d gdev %.2e\n", (int)ws->rot_defer_on, (int)ws->rot_defer_ok,
                    src, (int)extra_elsewhere, cin, ws->sstep_eff, (int)ws->blk_tail, (int)tl, thi, ws->blk_diag[2]);
     if (ws->rot_defer_on && ws->rot_defer_ok && src == ws->maxdim && !extra_elsewhere && cin == ws->maxdim + 1 && ws->sstep_eff >= 8 && ws->blk_tail && tl && thi == ws->maxdim &&
-        start_ok) {
+        start_ok && ws->defl_last == 0) {   // (a deflated chain needs the rotated locked columns first: no deferral in front of one)
       gate_cancel(ws);   // (a pre-enqueued rotation returns at once)
       KS_HIP(hipMemcpyAsync(ws->Qd, qs, (size_t)cin * rr * sizeof(T), hipMemcpyHostToDevice, ws->ctx->stream));
       qstage_mark(ws);

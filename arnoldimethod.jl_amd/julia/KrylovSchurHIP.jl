@@ -334,6 +334,19 @@ function fused_rotations(w::HipWorkspace)
 end
 
 """
+    deflated_blocks(w) -> (blocks, columns)
+
+Blocks whose Newton chain was projected against locked Schur vectors of dominant eigenvalues step by step, and the number of
+columns the last block batch deflated against (include/kschur.h, ks_workspace_deflated_blocks).
+"""
+function deflated_blocks(w::HipWorkspace)
+    b = Ref{Cint}(0)
+    c = Ref{Cint}(0)
+    check(ccall((:ks_workspace_deflated_blocks, LIB), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}), w.h, b, c))
+    return Int(b[]), Int(c[])
+end
+
+"""
     split_rotations(w) -> Int
 
 Pending restart rotations that ran through the ordinary kernel in front of a first block reading its Newton chain from scratch

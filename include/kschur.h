@@ -297,6 +297,15 @@ int ks_workspace_fused_rotations(const ks_workspace* ws, int* count, int* spec_a
  * its first block read the Newton chain from scratch columns -- what this buys is that the speculative chain (above) can run
  * behind the previous expansion for these shapes too.  *count = such rotations since creation. */
 int ks_workspace_split_rotations(const ks_workspace* ws, int* count);
+/* In-chain deflation of the block expansion (round 6).  The reference orthogonalises every new Krylov vector at once
+ * (src/expansion.jl:69-109); a block of s steps does so only at its end.  Where LOCKED Schur vectors (src/run.jl:330) belong to
+ * eigenvalues that dominate the rest of the spectrum (:LM problems with outliers: test/partial_schur.jl:122-138) the Newton chain in
+ * between is projected against those columns step by step -- two small launches per product -- and no shift is placed at their
+ * eigenvalues; without it such problems abandon their blocks and run step by step.  Taken: the leading locked columns whose
+ * eigenvalue exceeds KS_DEFLATE_RATIO (1.5) x the largest other Ritz value, at most 16; one rank only; KS_CHAIN_DEFLATE=0 at
+ * workspace creation switches it off.  *blocks = blocks whose chain was deflated since creation, *columns = columns the last block
+ * batch deflated against.  Any pointer may be null. */
+int ks_workspace_deflated_blocks(const ks_workspace* ws, int* blocks, int* columns);
 /* Diagnostics (tools/blk_bench.py): average duration of `reps` back-to-back launches of one streaming kernel of the s-step
  * expansion at basis size k and block size s (which = 0: first pass, 1: second pass), timed with HIP events on the
  * library's stream; *grid = workgroups launched.  dbg: probe flags of the kernels (1: second pass without its stores).

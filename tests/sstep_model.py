@@ -218,7 +218,7 @@ def expand_block(A, st, frm, to, shifts, s_max, stats, pivot_min=1e-6, gram="dou
         blk += 1
 
 
-def expand_block2(A, st, frm, to, shifts, s_max, stats, pivot_min=1e-6, scale=None, gdev_max=1e-8, inner=None, apply=None, **_):
+def expand_block2(A, st, frm, to, shifts, s_max, stats, pivot_min=1e-6, scale=None, gdev_max=1e-8, inner=None, apply=None, ndefl=0, **_):
     """TWO-STAGE block step (what the device runs): the first pass also delivers G_Z = Z^H Z, so the block's triangular
     factor is known BEFORE the second pass, which then writes the block already (nearly) orthonormal:
 
@@ -230,7 +230,12 @@ def expand_block2(A, st, frm, to, shifts, s_max, stats, pivot_min=1e-6, scale=No
     z_i = V_k (P + C R_1)[:, i] + Q (R_2 R_1)[:, i]: the H recovery is that of the one-stage form with R = R_2 R_1 and
     C_eff = C R_1.  The cancellation in G_1 only affects how close Qt is to orthonormal (G_t = I + delta); the second stage
     (a block classical Gram-Schmidt with Pythagorean inner products, applied twice) brings the orthogonality to rounding
-    level as long as delta << 1.  The last stored column is q_s up to R_2 ~ I: no combine pass."""
+    level as long as delta << 1.  The last stored column is q_s up to R_2 ~ I: no combine pass.
+
+    IN-CHAIN DEFLATION (`ndefl` > 0; csrc/ks_block_kernels.hpp: k_defl_dots / k_defl_apply, HipBackend::defl_plan): every chain
+    vector is projected against the locked columns U = V[:, 0:ndefl) as soon as it exists,
+        z_i <- z_i - U c_i,  c_i = U^H z_i      so that      A z_{i-1} = z_i / sigma_i + theta_i z_{i-1} + U c_i / sigma_i
+    and the H recovery adds c_i / sigma_i to the locked rows."""
     S, T, H = st.S, st.T, st.H
     dtype = H.dtype
     # `inner(X, Y)` = X^H Y and `apply(x)` = A x: the only places where the n-sized data is touched -- a row-partitioned run
@@ -248,8 +253,13 @@ def expand_block2(A, st, frm, to, shifts, s_max, stats, pivot_min=1e-6, scale=No
         u = st.u if st.u is not None else np.eye(k, dtype=dtype)[:, k - 1]
         Z = np.zeros((S.shape[0], s), dtype=dtype, order="F")
         prev = S[:, k - 1]
+        U = S[:, :ndefl] if ndefl > 0 else None     # (locked columns are ordinary ones: T = I there)
+        cdefl = np.zeros((max(ndefl, 0), s), dtype=dtype)
         for i in range(s):
             Z[:, i] = (apply(prev) - th[i] * prev) * sig[i]
+            if U is not None:
+                cdefl[:, i] = inner(U, Z[:, i:i + 1])[:, 0]
+                Z[:, i] -= U @ cdefl[:, i]
             prev = Z[:, i]
         # ---- pass 1 ----
         both = inner(np.hstack([S[:, :k], Z]), Z)      # ONE reduction: S^H Z and Z^H Z
@@ -293,12 +303,14 @@ def expand_block2(A, st, frm, to, shifts, s_max, stats, pivot_min=1e-6, scale=No
         Hext = np.zeros((m, k), dtype=dtype)
         Hext[:k, :k - 1] = H[:k, :k - 1]
         a0 = zeta[:, 1] / sig[0] + th[0] * zeta[:, 0]
+        a0[:ndefl] += cdefl[:, 0] / sig[0]
         a0[:k] -= H[:k, :k - 1] @ u[:k - 1]
         Hext[:, k - 1] = a0 / u[k - 1]
         H[:m, k - 1] = Hext[:, k - 1]
         H[m:, k - 1] = 0
         if s > 1:
             rhs = zeta[:, 2:] / sig[1:][None, :] + zeta[:, 1:s] * th[1:][None, :]
+            rhs[:ndefl, :] += cdefl[:, 1:] / sig[1:][None, :]
             rhs -= Hext @ PC[:, :s - 1]
             M = np.linalg.solve(R[:s - 1, :s - 1].T, rhs.T).T
             for i in range(1, s):
@@ -347,20 +359,77 @@ def expand_steps(A, st, frm, to, stats):
         S[:, j] = w / wnorm
 
 
+def defl_plan(H, j0, ritz, ratio=1.5, nmax=16):
+    """HipBackend::defl_plan (csrc/ks_backend.hpp): the leading locked columns (decoupled leading block of H: src/run.jl:330 zeroes
+    the sub-diagonal entry behind it) whose eigenvalue exceeds `ratio` x the largest Ritz value of the rest.  Returns (number of
+    columns, their eigenvalues)."""
+    nl = 0
+    for j in range(1, j0 - 1):
+        if H[j, j - 1] == 0:
+            nl = j
+    if nl == 0 or ritz is None:
+        return 0, []
+    lam, width, j = [None] * nl, [1] * nl, 0
+    while j < nl:
+        if j + 1 < nl and H[j + 1, j] != 0:
+            a, b, c, d = (complex(H[j, j]), complex(H[j, j + 1]), complex(H[j + 1, j]), complex(H[j + 1, j + 1]))
+            tr2 = 0.5 * (a + d)
+            disc = np.sqrt(tr2 * tr2 - (a * d - b * c) + 0j)
+            lam[j], lam[j + 1] = tr2 + disc, tr2 - disc
+            width[j], width[j + 1] = 2, 0
+            j += 2
+        else:
+            lam[j] = complex(H[j, j])
+            j += 1
+    rest = 0.0
+    for z in np.asarray(ritz, dtype=np.complex128):
+        if not np.isfinite(abs(z)):
+            continue
+        if not any(abs(z - l) <= 1e-6 * max(1.0, abs(l)) for l in lam):
+            rest = max(rest, abs(z))
+    if not rest > 0:
+        return 0, []
+    nd, ex, j = 0, [], 0
+    while j < nl:
+        w = 2 if width[j] == 2 else 1
+        mag = max(abs(lam[j]), abs(lam[j + 1])) if w == 2 else abs(lam[j])
+        if not mag > ratio * rest or nd + w > nmax:
+            break
+        ex += lam[j:j + w]
+        nd += w
+        j += w
+    return nd, ex
+
+
 def expand(A, st, frm, to, stats, ritz, s, real, **kw):
     """What the backend does: blocks when shifts exist, single steps otherwise or after a bail."""
+    nd, ex = 0, []
+    if kw.pop("deflate", True) and ritz is not None:
+        nd, ex = defl_plan(st.H, frm, ritz)
+        if nd > stats.get("defl_last", 0):
+            stats.pop("s_eff", None)           # (a problem that abandoned its blocks before those columns were locked gets its block size back)
+        stats["defl_last"] = nd
     s = min(s, stats.get("s_eff", s))          # lowered after abandoned blocks (what the backend does: s -> s/2 -> 2 -> off)
     if s <= 1 or ritz is None:
         st.materialize(frm)
         expand_steps(A, st, frm, to, stats)
         return
-    shifts = newton_shifts(ritz, s, real)
+    pool = np.asarray(ritz, dtype=np.complex128)
+    if nd > 0:
+        keep = np.asarray([not any(abs(z - q) <= 1e-6 * max(1.0, abs(q)) for q in ex) for z in pool])
+        if keep.any():
+            pool = pool[keep]
+        kw["ndefl"] = nd
+        stats["defl_blocks"] = stats.get("defl_blocks", 0) + 1
+    shifts = newton_shifts(pool, s, real)
     scale = kw.pop("scale", None)
     if scale is None:
-        rho = np.abs(np.asarray(ritz)).max()
+        rho = np.abs(pool).max()
         scale = 1.0 / _pow2(max(rho, 1e-300))
     variant = kw.pop("variant", "twostage")
     kw.pop("check", None)
+    if variant != "twostage":
+        kw.pop("ndefl", None)                  # (the one-stage form has no deflation)
     try:
         (expand_block2 if variant == "twostage" else expand_block)(A, st, frm, to, shifts, s, stats, scale=scale, **kw)
     except BlockBail as b:

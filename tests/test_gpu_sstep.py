@@ -307,6 +307,60 @@ def test_whole_solves_match_the_oracle(case, s):
     assert np.abs(np.sort_complex(F.eigenvalues) - np.sort_complex(ref.eigenvalues)).max() <= 1e-10 * scale
 
 
+@pytest.mark.parametrize("case", ["disc-and-outlier", "planted-pairs", "complex-outlier"])
+def test_in_chain_deflation_keeps_the_blocks_on_dominant_outliers(monkeypatch, case):
+    """Round 6 (tests/test_sstep_model.py has the model's statement): :LM problems whose wanted eigenvalues dominate the rest of the
+    spectrum -- the operator of test/partial_schur.jl:122-138 (a disc of radius ~1 and one eigenvalue at 50), a sparse
+    nonsymmetric matrix with planted outliers incl. a conjugate pair (a locked 2 x 2 block), and a ComplexF64 one.  With
+    KS_CHAIN_DEFLATE=0 (rounds 3-5) the blocks of 10 are abandoned as soon as the outlier is locked and the run goes on step by
+    step; with the chain projected against the locked columns of dominant eigenvalues step by step (k_defl_dots / k_defl_apply,
+    the c_i / sigma_i term of k_fin_blk's H recovery, no shift at those eigenvalues: HipBackend::defl_plan) no block is abandoned.
+    Either way: the oracle's number of products, Ritz values to 1e-10, ||AQ - QR|| at the oracle's level."""
+    from oracle.matrices import hashed_nonsymmetric
+
+    dtype = np.float64
+    if case == "disc-and-outlier":
+        rng = np.random.default_rng(5)
+        A = rng.standard_normal((400, 400)) / 20.0
+        A[0, 0] = 50.0
+        kw = dict(nev=5, which="LM", mindim=10, maxdim=30, tol=1e-10)
+        mk = lambda: pkg.dense_operator(A)                                            # noqa: E731
+    elif case == "planted-pairs":
+        A = hashed_nonsymmetric(3000, seed=11, planted=[(30.0, 0.0), (25.0, 10.0), (-28.0, 0.0)])
+        kw = dict(nev=6, which="LM", mindim=10, maxdim=30, tol=1e-10)
+        mk = lambda: pkg.csr_operator(A)                                              # noqa: E731
+    else:
+        dtype = np.complex128
+        rng = np.random.default_rng(9)
+        A = ((rng.standard_normal((300, 300)) + 1j * rng.standard_normal((300, 300))) / np.sqrt(600.0)).astype(np.complex128)
+        A[0, 0], A[1, 1] = 40.0 + 5.0j, -35.0j
+        kw = dict(nev=5, which="LM", mindim=10, maxdim=30, tol=1e-10)
+        mk = lambda: pkg.dense_operator(A)                                            # noqa: E731
+    n = A.shape[0]
+    v1 = _start(dtype, n)
+    ref, rhist = oa.partialschur(A, v1=v1, restarts=200, **kw)
+    out = {}
+    for on in ("0", "1"):
+        monkeypatch.setenv("KS_CHAIN_DEFLATE", on)
+        ws = pkg.ArnoldiWorkspace(n, kw["maxdim"], dtype)
+        ws.set_sstep(10)
+        ws._v1 = v1
+        F, hist = pkg.partialschur_(mk(), ws, restarts=200, **kw)
+        info = ws.sstep_info
+        assert hist.converged and rhist.converged and hist.nconverged == rhist.nconverged
+        assert hist.mvproducts == rhist.mvproducts, (on, hist, rhist, info)
+        Q, R = F.Q, np.array(F.R)
+        res0 = np.linalg.norm(A @ ref.Q - ref.Q @ ref.R)
+        assert np.linalg.norm(A @ Q - Q @ R) <= 10 * res0 + 1e-10 and np.linalg.norm(Q.conj().T @ Q - np.eye(Q.shape[1])) <= 100 * EPS * Q.shape[1]
+        scale = np.abs(ref.eigenvalues).max()
+        assert np.abs(np.sort_complex(F.eigenvalues) - np.sort_complex(ref.eigenvalues)).max() <= 1e-10 * scale
+        out[on] = info
+        ws.close()
+    assert out["0"]["deflated_blocks"] == 0 and out["0"]["abandoned"] >= 2, out["0"]      # what it cures
+    assert out["0"]["s"] < 10                                                              # (... and the block size it was left with)
+    assert out["1"]["deflated_blocks"] > 0 and out["1"]["abandoned"] == 0 and out["1"]["s"] == 10 and out["1"]["deflated_columns"] >= 1, out
+
+
 def test_breakdown_inside_a_block_goes_back_to_single_steps():
     """test/partial_schur.jl:6-27 (KAT-2): rank-3 operator, 7 products, H[5,4] exactly as the reference leaves it; and a
     block-diagonal operator whose invariant subspace is reached in the middle of a block."""

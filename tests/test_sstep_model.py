@@ -149,3 +149,42 @@ def test_blocks_stay_off_after_a_restart_that_split_a_conjugate_pair(seed):
         assert r["stats"].get("relation_breaks", 0) > 0
         assert r["worst"]["rel"] <= 3.0 * base["worst"]["rel"], (s, r["worst"], base["worst"])
         assert r["worst"]["orth"] < 1e-12
+
+
+def _disc_and_outlier(n=400, seed=5):
+    """the operator of test/partial_schur.jl:122-138: a random matrix whose spectrum fills a disc of radius ~1, plus one eigenvalue
+    at 50"""
+    rng = np.random.default_rng(seed)
+    D = rng.standard_normal((n, n)) / np.sqrt(n)
+    D[0, 0] = 50.0
+    return D
+
+
+@pytest.mark.parametrize("case", ["disc-and-outlier", "planted-pairs"])
+def test_in_chain_deflation_keeps_the_blocks_on_dominant_outliers(case):
+    """Locked Schur vectors of DOMINANT eigenvalues (:LM with outliers) inside a block: the chain is orthogonalised against the
+    basis only at the end of the block, by which time the components along those vectors (non-normal coupling, x |lambda_locked| /
+    |lambda_rest| per step) -- or, with a shift at the locked value, the previous chain vector itself -- have made the projected
+    columns parallel: the blocks of 10 are abandoned (3 times, down to single steps) on test/partial_schur.jl:122-138's operator.
+    With the chain projected against those columns step by step and no shift at their eigenvalues (HipBackend::defl_plan,
+    k_defl_dots / k_defl_apply, the extra term of k_fin_blk's H recovery): no block is abandoned, cond(R_1) <= 100 on that operator instead of
+    3e3 (the abandoned ones: 1e14), the same products as the reference, and the relation of every cycle at rounding level."""
+    if case == "disc-and-outlier":
+        A, kw = _disc_and_outlier(), dict(nev=5, which="LM", mindim=10, maxdim=30, tol=1e-10)
+    else:
+        from oracle.matrices import hashed_nonsymmetric
+        A = hashed_nonsymmetric(3000, seed=11, planted=[(30.0, 0.0), (25.0, 10.0), (-28.0, 0.0)])
+        kw = dict(nev=6, which="LM", mindim=10, maxdim=30, tol=1e-10)
+    v1 = oa.uniform_hash(20240917, np.arange(A.shape[0]))
+    P, hist = oa.partialschur(A, v1=v1, restarts=100, **kw)
+    off = sm.solve(A, v1, restarts=100, dtype=np.float64, s=10, deflate=False, **kw)
+    on = sm.solve(A, v1, restarts=100, dtype=np.float64, s=10, **kw)
+    assert off["stats"].get("bails", 0) >= 2                                          # what it cures
+    assert on["stats"].get("bails", 0) == 0 and on["stats"].get("defl_blocks", 0) > 0, on["stats"]
+    assert on["prods"] == hist.mvproducts and len(on["eig"]) == hist.nconverged
+    assert max(d[2] for d in on["diag"]) <= (1e2 if case == "disc-and-outlier" else 1e4)   # cond(R_1) of every block
+    assert on["worst"]["orth"] <= 1e-12 and on["worst"]["rel"] <= 1e-11, on["worst"]
+    scale = np.abs(P.eigenvalues).max()
+    assert np.abs(np.sort_complex(on["eig"]) - np.sort_complex(P.eigenvalues)).max() <= 1e-10 * scale
+    Q, R = on["Q"], on["R"]
+    assert np.linalg.norm(A @ Q - Q @ R) <= 10 * np.linalg.norm(A @ P.Q - P.Q @ P.R) + 1e-10
