@@ -92,7 +92,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
       std::vector<std::complex<double>> defl_ex;
       int ndefl = 0;
       if (tpath && !no_block && ws->sstep >= 2 && ws->sstep_eff >= 1 && op->async_capable && jend - j0 + 1 >= 2) {
-        ndefl = defl_plan(H, j0, defl_ex);
+        ndefl = defl_plan(H, j0, defl_ex, std::min(std::min(ws->sstep, ksd::kBlkSMax), jend - j0 + 1));
         if (ndefl > ws->defl_last && ws->sstep_eff < ws->sstep) { ws->sstep_eff = ws->sstep; ws->blk_clean = 0; }
         ws->defl_last = ndefl;
       }
@@ -342,8 +342,15 @@ template <class T> struct HipBackend : ks::Backend<T> {
   // multiplies a component along such a vector by that ratio per step, from a start at the level the vector was locked at (tol).
   // Locked columns of NON-dominant eigenvalues (every :SR / :SM problem; the headline) are left alone: their components shrink.
   // `ex`: the eigenvalues of the deflated columns (no shift is placed there).  One rank only (the dot products are not all-reduced).
-  int defl_plan(const ks::Mat<T>& H, int j0, std::vector<std::complex<double>>& ex) {
+  // ... AND for which that growth matters over the block at hand: ratio^(steps - 1) above 1e3.  (The component does not start at
+  // the locking tolerance: for a non-normal A the product A z has an O(1) component along a locked Schur vector although z is
+  // orthogonal to it -- the coupling R12 of the Schur form.)  Calibration: a Perron eigenvalue 2.1 x the bulk (config 3, blocks of 9:
+  // 2.1^8 = 350) does no harm, and deflating against it costs two launches per product, the fused rotation and the speculative
+  // chain (measured: +22 % on config 3's whole solve); eigenvalues 25 x the bulk abandon blocks of 4 (25^3 = 1.6e4).
+  int defl_plan(const ks::Mat<T>& H, int j0, std::vector<std::complex<double>>& ex, int steps) {
     ex.clear();
+    static const int dbg = env_int("KS_DEFLATE_DEBUG", 0);
+    if (dbg) std::fprintf(stderr, "[deflate] j0 %d on %d dist %d ritz_valid %d nritz %d sstep_eff %d steps %d\n", j0, (int)ws->defl_on, (int)ws->ctx->distributed(), (int)ws->ritz_valid, (int)ws->ritz.size(), ws->sstep_eff, steps);
     if (!ws->defl_on || ws->ctx->distributed() || !ws->ritz_valid || ws->ritz.empty()) return 0;
     static const double ratio = [] { const char* e = std::getenv("KS_DEFLATE_RATIO"); const double v = e ? std::atof(e) : 1.5; return v > 1.0 ? v : 1.5; }();
     int nl = 0;
@@ -372,12 +379,14 @@ template <class T> struct HipBackend : ks::Backend<T> {
       for (int j = 0; j < nl; ++j) locked = locked || std::abs(z - lam[j]) <= 1e-6 * std::max(1.0, std::abs(lam[j]));
       if (!locked) rest = std::max(rest, std::abs(z));
     }
+    if (dbg) std::fprintf(stderr, "[deflate] locked columns %d, largest other Ritz value %.3g, |lambda_0| %.3g\n", nl, rest, std::abs(lam[0]));
     if (!(rest > 0.0)) return 0;
     int nd = 0;
     for (int j = 0; j < nl;) {
       const int w = width[j] == 2 ? 2 : 1;
       const double mag = w == 2 ? std::max(std::abs(lam[j]), std::abs(lam[j + 1])) : std::abs(lam[j]);
-      if (!(mag > ratio * rest) || nd + w > ksd::kDeflMax) break;
+      const double growth = std::pow(mag / rest, std::max(1, steps - 1));
+      if (!(mag > ratio * rest) || !(growth > 1e3) || nd + w > ksd::kDeflMax) break;
       for (int q = 0; q < w; ++q) ex.push_back(lam[j + q]);
       nd += w;
       j += w;

@@ -359,7 +359,7 @@ def expand_steps(A, st, frm, to, stats):
         S[:, j] = w / wnorm
 
 
-def defl_plan(H, j0, ritz, ratio=1.5, nmax=16):
+def defl_plan(H, j0, ritz, ratio=1.5, nmax=16, steps=10, tol=1.5e-8):
     """HipBackend::defl_plan (csrc/ks_backend.hpp): the leading locked columns (decoupled leading block of H: src/run.jl:330 zeroes
     the sub-diagonal entry behind it) whose eigenvalue exceeds `ratio` x the largest Ritz value of the rest.  Returns (number of
     columns, their eigenvalues)."""
@@ -393,7 +393,8 @@ def defl_plan(H, j0, ritz, ratio=1.5, nmax=16):
     while j < nl:
         w = 2 if width[j] == 2 else 1
         mag = max(abs(lam[j]), abs(lam[j + 1])) if w == 2 else abs(lam[j])
-        if not mag > ratio * rest or nd + w > nmax:
+        # (... and for which the growth matters over the block at hand: ratio^(steps - 1) above 1e3)
+        if not mag > ratio * rest or not (mag / rest) ** max(1, steps - 1) > 1e3 or nd + w > nmax:
             break
         ex += lam[j:j + w]
         nd += w
@@ -404,8 +405,9 @@ def defl_plan(H, j0, ritz, ratio=1.5, nmax=16):
 def expand(A, st, frm, to, stats, ritz, s, real, **kw):
     """What the backend does: blocks when shifts exist, single steps otherwise or after a bail."""
     nd, ex = 0, []
+    lock_tol = kw.pop("lock_tol", 1.5e-8)
     if kw.pop("deflate", True) and ritz is not None:
-        nd, ex = defl_plan(st.H, frm, ritz)
+        nd, ex = defl_plan(st.H, frm, ritz, steps=min(s, to - frm + 1), tol=lock_tol)
         if nd > stats.get("defl_last", 0):
             stats.pop("s_eff", None)           # (a problem that abandoned its blocks before those columns were locked gets its block size back)
         stats["defl_last"] = nd
@@ -455,6 +457,7 @@ def solve(A, v1, nev, which, tol, mindim, maxdim, restarts, dtype, s=4, **kw):
     active, k, prods = 0, mindim, mindim
     ritz = None
     check = kw.pop("check", True)
+    kw.setdefault("lock_tol", tol)             # (what the restart locks at: HipBackend::note_ritz hands it to defl_plan)
     expand(A, st, 1, mindim, stats, None, s, real)
     worst = dict(orth=0.0, rel=0.0)
     for _ in range(restarts):
