@@ -10,6 +10,7 @@
 #   pmc_sstep20_{fetch,write}.csv, pmc_summary_sstep20.txt, pmc_traffic.json   --pmc FETCH_SIZE / WRITE_SIZE, SEPARATE passes
 #   cfg{2,3,4}_sstep20.json, cfg3_true_start.json     BASELINE configs 2-4 (tools/config_bench.py); config 3 with KS_TRUE_START=1
 #   full_solves.txt            whole solves to convergence (tools/full_solve_check.py)
+#   outlier_solves.txt         :LM problems with dominant outliers: in-chain deflation on / off / step by step (tools/outlier_solves.py)
 #   dist_overhead.txt          tools/dist_overhead.py 108 (8-way share of 216^3 on one GPU), three transports, and the whole problem
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -45,6 +46,7 @@ done
 KS_TRUE_START=1 python $REPO/tools/config_bench.py cfg3 --sstep 20 --steps 20 > $OUT/cfg3_true_start.json 2>> $OUT/cfg3.err
 cd $REPO
 { python tools/full_solve_check.py 216 20 1e-6; python tools/full_solve_check.py 100 20 1e-8; } > $OUT/full_solves.txt 2>&1
+python tools/outlier_solves.py > $OUT/outlier_solves.txt 2>&1
 { echo "# tools/dist_overhead.py 108: the 8-way share of 216^3 on ONE GPU, cycles back to back (ms per Arnoldi iteration), separate processes";
   for leg in plain rccl p2p plain rccl p2p; do python tools/dist_overhead.py 108 $leg 2>&1 | grep ms/iter; done;
   echo "# the whole 216^3 on the plain context, same protocol"; python tools/dist_overhead.py 216 plain 2>&1 | grep ms/iter; } > $OUT/dist_overhead.txt 2>&1
