@@ -341,7 +341,8 @@ template <class T> struct HipBackend : ks::Backend<T> {
   // whose eigenvalue exceeds KS_DEFLATE_RATIO (1.5) times the largest Ritz value of the rest -- a chain scaled by 1 / max|rest|
   // multiplies a component along such a vector by that ratio per step, from a start at the level the vector was locked at (tol).
   // Locked columns of NON-dominant eigenvalues (every :SR / :SM problem; the headline) are left alone: their components shrink.
-  // `ex`: the eigenvalues of the deflated columns (no shift is placed there).  One rank only (the dot products are not all-reduced).
+  // `ex`: the eigenvalues of the deflated columns (no shift is placed there).  Several ranks: H and the Ritz values are replicated,
+  // every rank takes the same plan; the dot products are all-reduced (one more collective per product: ks_block.hpp).
   // ... AND for which that growth matters over the block at hand: ratio^(steps - 1) above 1e3.  (The component does not start at
   // the locking tolerance: for a non-normal A the product A z has an O(1) component along a locked Schur vector although z is
   // orthogonal to it -- the coupling R12 of the Schur form.)  Calibration: a Perron eigenvalue 2.1 x the bulk (config 3, blocks of 9:
@@ -351,7 +352,7 @@ template <class T> struct HipBackend : ks::Backend<T> {
     ex.clear();
     static const int dbg = env_int("KS_DEFLATE_DEBUG", 0);
     if (dbg) std::fprintf(stderr, "[deflate] j0 %d on %d dist %d ritz_valid %d nritz %d sstep_eff %d steps %d\n", j0, (int)ws->defl_on, (int)ws->ctx->distributed(), (int)ws->ritz_valid, (int)ws->ritz.size(), ws->sstep_eff, steps);
-    if (!ws->defl_on || ws->ctx->distributed() || !ws->ritz_valid || ws->ritz.empty()) return 0;
+    if (!ws->defl_on || !ws->ritz_valid || ws->ritz.empty()) return 0;
     static const double ratio = [] { const char* e = std::getenv("KS_DEFLATE_RATIO"); const double v = e ? std::atof(e) : 1.5; return v > 1.0 ? v : 1.5; }();
     int nl = 0;
     for (int j = 1; j <= j0 - 2; ++j)
@@ -869,7 +870,10 @@ template <class D> void tune_placement(ks_workspace* w, size_t vbytes) {
     const double spent = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if ((int)pc.cand.size() >= trials || spent > budget_ms) break;
     if ((int)pc.cand.size() + 1 > max_x) break;                      // footprint cap: held candidates <= max_x * V
-    if (pc.cand.size() >= 4 && best_ms <= 0.955 * worst_ms) break;   // a candidate from the fast cluster was found
+    // (the step-kernel probe's rule; NOT with the block probe, whose slow cluster alone spreads over 5 %: four slow candidates at
+    // 0.951 .. 0.999 ms ended the search of a bench run in the slow cluster -- 6 304 it/s against 6 570 .. 6 720 for the processes
+    // behind it on the same box, profiles/r06c_bench*.json)
+    if (!blk_probe && pc.cand.size() >= 4 && best_ms <= 0.955 * worst_ms) break;   // a candidate from the fast cluster was found
     if (blk_probe && (best_ms <= blk_fast_ms || (pc.cand.size() >= 2 && best_ms <= 0.93 * worst_ms))) break;   // (block probe: the two clusters are 10-15 % apart)
     size_t free_b = 0, total_b = 0;
     KS_HIP(hipMemGetInfo(&free_b, &total_b));

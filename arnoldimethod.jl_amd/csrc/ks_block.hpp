@@ -193,12 +193,21 @@ void enqueue_steps_blk(ks_workspace* ws, ks_operator* op, int from, const std::v
       if (ndefl > 0) {
         // in-chain deflation against the locked columns of dominant eigenvalues (ks_block_kernels.hpp: kDeflMax)
         ProfScope ps(cx, KSP_AXPY, nb8 * 2.0 * (ndefl + 1) + nb8);
-        if (!ws->defl_part) KS_HIP(hipMalloc(&ws->defl_part, (size_t)ksd::kDeflMax * 1024 * sizeof(D)));
+        if (!ws->defl_part) KS_HIP(hipMalloc(&ws->defl_part, (size_t)ksd::kDeflMax * (1024 + 1) * sizeof(D)));
         const int nbd = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(1024, cx->num_cu * 4), (ws->n + kBlock - 1) / kBlock));
         D* zc = static_cast<D*>(zcol(i));
         const D* U = static_cast<const D*>(ws->col(0));
-        ksd::k_defl_dots<D><<<nbd, kBlock, 0, s_>>>(U, ws->ld, ndefl, zc, ws->n, static_cast<D*>(ws->defl_part));
-        ksd::k_defl_apply<D><<<nbd, kBlock, 0, s_>>>(U, ws->ld, ndefl, zc, ws->n, static_cast<const D*>(ws->defl_part), nbd, bs->cdefl + (size_t)i * ksd::kDeflMax);
+        D* part = static_cast<D*>(ws->defl_part);
+        ksd::k_defl_dots<D><<<nbd, kBlock, 0, s_>>>(U, ws->ld, ndefl, zc, ws->n, part);
+        if (!cx->distributed()) {
+          ksd::k_defl_apply<D><<<nbd, kBlock, 0, s_>>>(U, ws->ld, ndefl, zc, ws->n, part, nbd, bs->cdefl + (size_t)i * ksd::kDeflMax);
+        } else {
+          // several ranks (row-partitioned basis): one more collective per product, of ndefl elements -- every rank the same c_i
+          D* red = part + (size_t)ksd::kDeflMax * 1024;
+          ksd::k_defl_reduce<D><<<1, kBlock, 0, s_>>>(part, nbd, ndefl, red);
+          cx->allreduce(reinterpret_cast<double*>(red), ndefl * (int)(sizeof(D) / 8));
+          ksd::k_defl_apply<D><<<nbd, kBlock, 0, s_>>>(U, ws->ld, ndefl, zc, ws->n, red, 1, bs->cdefl + (size_t)i * ksd::kDeflMax);
+        }
       }
     }
     if (ndefl > 0) ws->defl_blocks++;

@@ -1348,6 +1348,20 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// several ranks: the partial sums of this rank -> red[0:nd) (ONE workgroup; then the context's all-reduce, then k_defl_apply
+// with red as its only "partial")
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_defl_reduce(const T* __restrict__ partial, int nbp, int nd, T* __restrict__ red) {
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int l = wv; l < nd; l += kBlock / 64) {
+    T v = zero_of(T{});
+    for (int b = lane; b < nbp; b += 64) v = add_(v, partial[(int64_t)l * nbp + b]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = add_(v, shfl_xor_(v, off));
+    if (lane == 0) red[l] = v;
+  }
+}
+
 template <class T>
 __global__ void __launch_bounds__(kBlock)
     k_defl_apply(const T* __restrict__ U, int64_t ld, int nd, T* __restrict__ z, int64_t n, const T* __restrict__ partial, int nbp, T* __restrict__ cout) {

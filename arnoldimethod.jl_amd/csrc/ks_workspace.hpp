@@ -870,6 +870,8 @@ template <class D> bool reinit_column(ks_workspace* ws, int j, const void* v1_ho
     ws->sstep_eff = ws->sstep;
     ws->blk_clean = 0;
     ws->rp_inflight = false; ws->rp_every = 1; ws->rp_count = 0; ws->rp_done = 0; ws->rp_last = 0.0; ws->watch_tol = 0.0;   // (the drift watch starts afresh too)
+    ws->defl_last = 0;                                    // (nothing is locked in a new factorisation)
+    ws->ztrue_valid = false; ws->rot_true_start = false; ws->chain_true = false; ws->spec_true = false;
     col_scale<D>(ws, j, 1.0 / rnorm);
     return true;
   }

@@ -303,7 +303,7 @@ int ks_workspace_split_rotations(const ks_workspace* ws, int* count);
  * between is projected against those columns step by step -- two small launches per product -- and no shift is placed at their
  * eigenvalues; without it such problems abandon their blocks and run step by step.  Taken: the leading locked columns whose
  * eigenvalue exceeds the largest other Ritz value by a factor r > KS_DEFLATE_RATIO (1.5) with r^(steps of the block - 1) > 1e3, at
- * most 16; one rank only; KS_CHAIN_DEFLATE=0 at
+ * most 16; several ranks all-reduce the dot products (one more small collective per product); KS_CHAIN_DEFLATE=0 at
  * workspace creation switches it off.  *blocks = blocks whose chain was deflated since creation, *columns = columns the last block
  * batch deflated against.  Any pointer may be null. */
 int ks_workspace_deflated_blocks(const ks_workspace* ws, int* blocks, int* columns);

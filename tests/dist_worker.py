@@ -118,6 +118,17 @@ def check_matrix(A, offs, rank, world, tag):
     allH = [None] * world
     dist.all_gather_object(allH, stf.H.tobytes())
     assert all(h == allH[0] for h in allH), (tag, "ranks disagree on H: the replicated algebra must see identical sums")
+    # 4. the same blocks with IN-CHAIN DEFLATION against the first two columns (csrc/ks_block.hpp: k_defl_dots -> k_defl_reduce ->
+    # all-reduce -> k_defl_apply): the identity  A z_{i-1} = z_i / sigma_i + theta_i z_{i-1} + U c_i / sigma_i  holds for ANY columns
+    # U of the basis, so the same H and the same basis must come out; per product one more all-reduce (of ndefl doubles)
+    std = sm.Factored(r1 - r0, m, np.float64)
+    std.S[:, :5] = V[:, :5]
+    std.H[:, :4] = H[:, :4]
+    sm.expand_block2(A, std, 5, m, shifts, 4, {}, scale=1.0 / 8.0, inner=inner, apply=lambda x: dist_spmv(plan, ip, dv, x, rank), ndefl=2)
+    np.testing.assert_allclose(std.H, ows.H, atol=1e-11)
+    np.testing.assert_allclose(std.true_basis(m + 1), ows.V[r0:r1], atol=1e-9)
+    dist.all_gather_object(allH, std.H.tobytes())
+    assert all(h == allH[0] for h in allH), (tag, "ranks disagree on H with the deflated chain")
     return True
 
 

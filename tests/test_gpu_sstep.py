@@ -432,10 +432,14 @@ def test_drift_watch_switches_the_blocks_off_on_a_nonnormal_cluster():
     assert hist.converged and ws.relation_info["breaks"] == 0 and ws.relation_info["probes"] >= 4, ws.relation_info
 
 
-def test_ill_conditioned_newton_basis_is_abandoned_and_the_block_size_lowered():
+@pytest.mark.parametrize("deflate", ["0", "1"])
+def test_ill_conditioned_newton_basis_is_abandoned_and_the_block_size_lowered(monkeypatch, deflate):
     """test/partial_schur.jl:122-138's operator (dense random 100 x 100: one eigenvalue at 50, the rest in a complex disc of
     radius ~3).  With REAL shifts a block of 5 has cond ~1e7 (tests/test_sstep_model.py measures it): the written block's Gram
-    matrix is 1e-2 from I, the block is abandoned, the library drops to s = 2 and the answer keeps the oracle's accuracy."""
+    matrix is 1e-2 from I, the block is abandoned, the library drops to s = 2 and the answer keeps the oracle's accuracy
+    (KS_CHAIN_DEFLATE=0: the guard and the back-off as rounds 3-5 had them).  With the round-6 default the chain is deflated
+    against the locked outlier and no block is abandoned; same products and accuracy either way."""
+    monkeypatch.setenv("KS_CHAIN_DEFLATE", deflate)
     rng = np.random.default_rng(12)
     A = rng.random((100, 100))
     v1 = oa.uniform_hash(3, np.arange(100))
@@ -446,7 +450,10 @@ def test_ill_conditioned_newton_basis_is_abandoned_and_the_block_size_lowered():
     F, hist = pkg.partialschur_(pkg.dense_operator(A), ws, restarts=200, **kw)
     ref, rhist = oa.partialschur(A, v1=v1, restarts=200, **kw)
     info = ws.sstep_info
-    assert info["abandoned"] >= 1 and info["s"] < 5 and info["blocks"] > 0, info
+    if deflate == "0":
+        assert info["abandoned"] >= 1 and info["s"] < 5 and info["blocks"] > 0 and info["deflated_blocks"] == 0, info
+    else:
+        assert info["abandoned"] == 0 and info["s"] == 5 and info["deflated_blocks"] > 0, info
     assert hist.converged and hist.mvproducts == rhist.mvproducts
     Q, R = F.Q, np.array(F.R)
     res, res0 = np.linalg.norm(A @ Q - Q @ R), np.linalg.norm(A @ ref.Q - ref.Q @ ref.R)
@@ -647,7 +654,9 @@ def _run_ranks(nproc, mode, m=16, extra_env=None, timeout=420):
                                                     (2, "laplace", "p2p", 10), (3, "wide", "host", 10),
                                                     # (block sizes at run time: one block of 17-18 per cycle; ComplexF64 blocks of 10 on the
                                                     # matrix instruction; pending rotations in the split form + speculative chains on every rank)
-                                                    (2, "laplace", "p2p", 20), (2, "complex", "p2p", 10)])
+                                                    (2, "laplace", "p2p", 20), (2, "complex", "p2p", 10),
+                                                    # (round 6c: in-chain deflation with its dot products all-reduced over the ranks)
+                                                    (2, "outlier", "p2p", 10), (3, "outlier", "host", 10)])
 def test_blocks_with_real_ranks_on_one_gpu(nproc, mode, transport, s):
     """Rows of A and V split over `nproc` processes sharing device 0 (peer-to-peer regions, or the host-staged transport =
     the RCCL launch structure reduce -> all-reduce -> algebra): per block two all-reduces of k s + s (s + 1) / 2 elements, every

@@ -18,6 +18,9 @@ MODE
   eager    maxdim = 70 > 64: the eager (un-fused) DGKS sequence with stand-alone reductions, chunked inner
            products, out-of-place rotation.
   complex  ComplexF64 variant (complex diagonal shift): 16-byte elements through halo and reductions.
+  outlier  the hashed matrix with three planted eigenvalues 10x the bulk (one of them a conjugate pair), :LM: the in-chain
+           deflation of the block expansion with its dot products all-reduced over the ranks (KS_CHECK_BLOCKS=1 also asks for
+           deflated blocks and for no abandoned one).
   shard5   BASELINE config 5: m^3 Laplacian (m = 464 with 8 ranks = the true per-rank size 464 x 464 x 58), nev = 20,
            mindim/maxdim = 20/40, two restart cycles: same restart trail and Ritz values as rank 0's single-process
            run of the whole problem, Arnoldi relation and orthogonality evaluated on the device for both.
@@ -259,7 +262,10 @@ def main():
     else:
         n = m * m * m
         diag = np.linspace(1.0, 40.0, n) + (0.5j * np.cos(np.arange(n)) if mode == "complex" else 0.0)
-        A = (ks.matrices.hashed_nonsymmetric_csr(n, seed=11) + sp.diags(diag)).tocsr()
+        if mode == "outlier":
+            A = ks.matrices.hashed_nonsymmetric_csr(n, seed=11, planted=[(30.0, 0.0), (25.0, 10.0), (-28.0, 0.0)])
+        else:
+            A = (ks.matrices.hashed_nonsymmetric_csr(n, seed=11) + sp.diags(diag)).tocsr()
         A.sort_indices()
         offs = ksd.partition_rows(n, world)
         r0, r1 = int(offs[rank]), int(offs[rank + 1])
@@ -270,6 +276,8 @@ def main():
             kw = dict(nev=12, which="LR", tol=1e-10, mindim=30, maxdim=60, restarts=300)
         if mode == "eager":
             kw = dict(nev=12, which="LR", tol=1e-10, mindim=35, maxdim=70, restarts=300)
+        if mode == "outlier":
+            kw = dict(nev=5, which="LM", tol=1e-10, mindim=10, maxdim=30, restarts=300)
         full = lambda: A  # noqa: E731
     dtype = np.complex128 if mode == "complex" else np.float64
 
@@ -287,6 +295,9 @@ def main():
     if os.environ.get("KS_CHECK_BLOCKS") == "1":  # the s-step expansion must really have run in blocks on every rank
         info = ws.sstep_info
         msg += f" sstep={info['s']} blocks{'>0' if info['blocks'] > 0 else '=0'} ({info['blocks']}, abandoned {info['abandoned']})"
+        if mode == "outlier":
+            msg += f" deflated{'>0' if info['deflated_blocks'] > 0 else '=0'} ({info['deflated_blocks']}, columns {info['deflated_columns']})"
+            ok = ok and info["deflated_blocks"] > 0 and info["abandoned"] == 0
     if mode == "laplace":
         exact = ks.matrices.laplace3d_eigs(mx, my, mz, 6)
         err = np.abs(np.sort(F.eigenvalues.real)[:6] - exact).max() if F.nconverged >= 6 else float("nan")
