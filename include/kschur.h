@@ -289,7 +289,8 @@ int ks_workspace_relation_probes(const ks_workspace* ws, int* probes);
 int ks_workspace_fused_rotations(const ks_workspace* ws, int* count, int* spec_adopted, int* spec_dropped);
 /* Memory: the fused rotation and the speculative chain keep the Newton chain of a block in scratch columns of their own -- 20
  * (Float64) / 10 (ComplexF64) columns of the workspace's leading dimension, allocated at the first restart that leaves its rotation
- * pending (1.6 GB at n = 1e7 next to a 3.3-GB basis of 41 columns); the drift watch keeps one more column.  When the device has no
+ * pending (1.6 GB at n = 1e7 next to a 3.3-GB basis of 41 columns); the drift watch keeps one more column, KS_TRUE_START=1 (off by
+ * default) another one, the in-chain deflation 131 KB of partial sums.  When the device has no
  * room for them the library falls back to the paths that need none (rotation at once, no speculation, no watch) instead of failing:
  * a workspace that fits the device without these features runs with them switched off. */
 /* Pending restart rotations (src/run.jl:363-365) for whose shape or element type there is no fused kernel (ComplexF64; Float64
