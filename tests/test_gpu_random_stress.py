@@ -96,6 +96,78 @@ def test_random_case_against_the_oracle(seed):
         assert np.linalg.norm(Q.conj().T @ Q - np.eye(Q.shape[1])) < 1e-11 * max(1, h.nconverged), tag
 
 
+def _outlier_case(seed):
+    """Block upper triangular [[D, C], [0, B]]: B a sparse random bulk of spectral radius ~1, D planted eigenvalues 6-60 x the bulk
+    (1 x 1 and 2 x 2 blocks: exact eigenvalues of the whole), C an O(1) coupling -- the planted Schur vectors are NOT orthogonal to
+    the rest of the spectrum's invariant subspace, which is what makes a Newton chain grow along them (in-chain deflation)."""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(300, 2500))
+    cplx = bool(rng.integers(0, 4) == 0)
+    B = sp.random(n, n, density=6.0 / n, random_state=rng, format="csr", data_rvs=lambda k: rng.standard_normal(k) / np.sqrt(6.0))
+    npl = int(rng.integers(1, 5))
+    blocks, exact = [], []
+    sign = -1.0 if rng.integers(0, 3) == 0 else 1.0          # (negative outliers: dominant in magnitude, the smallest real parts)
+    for _ in range(npl):
+        mag = float(rng.uniform(6.0, 60.0))
+        if not cplx and rng.integers(0, 2) == 0:
+            a, b = sign * mag * np.cos(0.4), mag * np.sin(0.4)
+            blocks.append(np.array([[a, b], [-b, a]]))
+            exact += [complex(a, b), complex(a, -b)]
+        else:
+            z = sign * mag * (np.exp(1j * rng.uniform(-0.5, 0.5)) if cplx else 1.0)
+            blocks.append(np.array([[z]]))
+            exact.append(complex(z))
+    D = sp.block_diag(blocks, format="csr")
+    k = D.shape[0]
+    C = sp.csr_matrix(rng.standard_normal((k, n)) * (rng.random((k, n)) < 20.0 / n))
+    A = sp.bmat([[D, C], [None, B]], format="csr")
+    dtype = np.complex128 if cplx else np.float64
+    if cplx:
+        A = (A + 1j * sp.diags(np.concatenate([np.zeros(k), 0.1 * rng.standard_normal(n)]))).tocsr()
+    A = A.astype(dtype)
+    N = A.shape[0]
+    maxdim = int(rng.integers(20, 41))
+    nev = int(rng.integers(len(exact) + 1, len(exact) + 5))
+    mindim = max(nev, maxdim // 2 - int(rng.integers(0, 4)))
+    which = "LM" if sign > 0 and rng.integers(0, 2) == 0 else ("LR" if sign > 0 else "SR")
+    v1 = rng.standard_normal(N) + (1j * rng.standard_normal(N) if cplx else 0)
+    s_blk = [5, 10, 20][int(rng.integers(0, 3))]
+    return A, v1.astype(dtype), dict(nev=nev, which=which, tol=1e-9, mindim=mindim, maxdim=maxdim, restarts=80), np.array(exact), s_blk
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_random_dominant_outliers_keep_their_blocks(seed):
+    """Round 6c: random :LM / :LR / :SR problems whose wanted eigenvalues include planted outliers 6-60 x the bulk, coupled to it
+    (non-normal), Float64 (incl. locked 2 x 2 blocks) and ComplexF64, blocks of 5 / 10 / 20: the planted values are found to 1e-8,
+    the residual is no worse than the oracle's, the trail is the oracle's where it settles -- and the blocks stay ON: the chain is
+    deflated against the locked outliers (ks_workspace_deflated_blocks) and at most one block (the first after a restart that locks
+    a new outlier may still be probed too large) is abandoned, where rounds 3-5 ended such runs step by step."""
+    A, v1, kw, exact, s_blk = _outlier_case(seed)
+    ref, rh = oa.partialschur(A, v1=v1, **kw)
+    ws = pkg.ArnoldiWorkspace(A.shape[0], kw["maxdim"], A.dtype)
+    ws.set_sstep(s_blk)
+    ws._v1 = v1
+    dec, h = pkg.partialschur_(pkg.csr_operator(A), ws, **kw)
+    info = ws.sstep_info
+    tag = f"seed {seed} n={A.shape[0]} {A.dtype} s={s_blk} {kw} planted {np.round(exact, 2)}: oracle {rh} device {h} {info}"
+    assert h.nconverged >= min(len(exact), rh.nconverged), tag
+    lam = np.asarray(dec.eigenvalues)
+    if h.nconverged >= len(exact):
+        assert max(np.min(np.abs(lam - z)) for z in exact) <= 1e-8 * np.abs(exact).max(), tag
+    if rh.converged and rh.restarts <= 50:
+        assert h.converged and h.nconverged == rh.nconverged and h.mvproducts == rh.mvproducts, tag
+    if h.nconverged:
+        Q, R = np.array(dec.Q), np.array(dec.R)
+        nb = max(1.0, sp.linalg.norm(A))
+        res = np.linalg.norm(A @ Q - Q @ R)
+        res_ref = np.linalg.norm(A @ ref.Q - ref.Q @ ref.R) if rh.nconverged else 0.0
+        assert res <= 10 * res_ref + 1e-8 * nb * max(1, h.nconverged), tag + f" residual {res:.2e} (oracle {res_ref:.2e})"
+        assert np.linalg.norm(Q.conj().T @ Q - np.eye(Q.shape[1])) < 1e-11 * max(1, h.nconverged), tag
+    if info["blocks"] + info["abandoned"] > 0 and h.restarts >= 3:
+        assert info["deflated_blocks"] > 0 and info["abandoned"] <= 1, tag
+    ws.close()
+
+
 def test_enough_cases_are_compared_trail_for_trail():
     """The sweep above compares mvproducts / nconverged / Ritz values with the oracle only where the trail is a well-posed
     quantity (see the comments there; the filter was widened in round 4 to admit the s-step default).  So that the filter
