@@ -7,6 +7,7 @@ tests/sstep_model.py (the numpy statement of the block algorithm, pinned to the 
                                                         amplification of the H recovery a usable discriminator?  (no)
     python tools/model_drift_experiments.py watch       a watch that extrapolates the measured growth and HALVES the block size
     python tools/model_drift_experiments.py truncate    a block truncated at the first bad pivot / cancelling column instead of abandoned
+    python tools/model_drift_experiments.py repair      the drift split into its part inside / outside span(V); H recomputed (= V^H A V) before the restart
 Outcome (profiles/r06_model_drift_experiments.txt):
   * the drift is built INSIDE a cycle, block after block: the later blocks of a cycle (k = 34, 44 of 58) multiply the residual of the
     columns they lean on by 20-75, the restart hands the maximum to the next cycle; blocks of 8 on the same operator stay at 1e-14;
@@ -17,7 +18,10 @@ Outcome (profiles/r06_model_drift_experiments.txt):
     and the error stays (nothing in a Krylov-Schur cycle shrinks the residual of the kept columns);
   * truncation: on the dominant-outlier operators the FIRST or second chain vector already cancels (written block 0.96 away from
     orthonormal at k = 12): nothing to truncate to; on the planted config-3 miniature one block of 10 becomes 8-9 + a wasted product.
-None of the three went to the device.  What stands: detection (drift watch) + step-by-step fallback; open item in DESIGN section 9."""
+  * repair (round 6c): E = A V - V H has a component OUTSIDE span(V) as large as the one inside (3e-9 | 3e-9 at the onset): the drift is
+    not an error of the recovered H alone; recomputing H = V^H A V before the restart stops the growth (5e-9, flat for 30 cycles) but
+    does not bring the relation back.
+None of these went to the device.  What stands: detection (drift watch) + step-by-step fallback; open item in DESIGN section 9."""
 import os
 import sys
 
@@ -55,6 +59,22 @@ def segments():
                 segs.append((j, min(j + s, kw["maxdim"])))
                 j += s
             print("  cycle %2d  k=%d   " % (c, k) + "  ".join("%.0e" % cr[a:b].max() for a, b in segs))
+
+
+def repair():
+    """Where does the drift live?  E = A V_m - V_{m+1} H split into its part INSIDE span(V_{m+1}) (V^H E: an error of H alone, which a
+    recomputed H = V^H A V removes) and OUTSIDE it ((I - V V^H) E: the space is not a Krylov space any more).  Then the same run
+    with H REPAIRED (H += V^H E) before the restart whenever the relation exceeds 1e-12 ||H||."""
+    A, v1, kw, _ = case(17)
+    probe = ('_E = A @ V[:, :maxdim] - V @ H; _in = V.conj().T @ _E; _out = _E - V @ _in; _hn = np.linalg.norm(H); '
+             'stats.setdefault("rels", []).append((np.linalg.norm(_E) / _hn, np.linalg.norm(_in) / _hn, np.linalg.norm(_out) / _hn)); worst["rel"] = 0.0')
+    fix = probe + '\n            if REPAIR and np.linalg.norm(_E) > REPAIR * _hn:\n                H[:, :] += _in; stats["repairs"] = stats.get("repairs", 0) + 1'
+    for s_, thr in ((10, 0.0), (10, 1e-12), (10, 1e-13), (20, 1e-12)):
+        src = SRC.replace(REL, fix)
+        r = run(src, A.toarray(), v1, kw, s_, restarts=40, REPAIR=thr)
+        st = r["stats"]
+        print(f"seed 17, blocks of {s_}, repair above {thr:g}: repairs {st.get('repairs', 0)}, cycles {len(st['rels'])}, converged {len(r['eig'])} of {kw['nev']}, products {r['prods']}")
+        print("   relation | inside span | outside span, per cycle: " + "  ".join("%.0e|%.0e|%.0e" % t for t in st["rels"][:24]))
 
 
 def amp():
@@ -139,4 +159,4 @@ def truncate():
 
 
 if __name__ == "__main__":
-    {"segments": segments, "amp": amp, "watch": watch, "truncate": truncate}[sys.argv[1] if len(sys.argv) > 1 else "segments"]()
+    {"segments": segments, "amp": amp, "watch": watch, "truncate": truncate, "repair": repair}[sys.argv[1] if len(sys.argv) > 1 else "segments"]()
