@@ -339,11 +339,11 @@ template <class T> struct HipBackend : ks::Backend<T> {
   // the leading decoupled block of the caller's H (src/run.jl:330 zeroes the sub-diagonal entry behind them; an exact breakdown
   // leaves the same pattern, and deflating against an invariant subspace is just as valid).  Deflated: the LEADING locked columns
   // whose eigenvalue exceeds KS_DEFLATE_RATIO (1.5) times the largest Ritz value of the rest -- a chain scaled by 1 / max|rest|
-  // multiplies a component along such a vector by that ratio per step, from a start at the level the vector was locked at (tol).
+  // multiplies a component along such a vector by that ratio per step ...
   // Locked columns of NON-dominant eigenvalues (every :SR / :SM problem; the headline) are left alone: their components shrink.
   // `ex`: the eigenvalues of the deflated columns (no shift is placed there).  Several ranks: H and the Ritz values are replicated,
   // every rank takes the same plan; the dot products are all-reduced (one more collective per product: ks_block.hpp).
-  // ... AND for which that growth matters over the block at hand: ratio^(steps - 1) above 1e3.  (The component does not start at
+  // ... and for which that growth matters over the block at hand: ratio^(steps - 1) above 1e3.  (The component does not start at
   // the locking tolerance: for a non-normal A the product A z has an O(1) component along a locked Schur vector although z is
   // orthogonal to it -- the coupling R12 of the Schur form.)  Calibration: a Perron eigenvalue 2.1 x the bulk (config 3, blocks of 9:
   // 2.1^8 = 350) does no harm, and deflating against it costs two launches per product, the fused rotation and the speculative
