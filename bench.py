@@ -218,9 +218,10 @@ def main():
     ap.add_argument("--no-shift-invert", action="store_true", help="skip the side record of the sparse shift-invert operator (N = 1 only)")
     ap.add_argument("--no-profile", action="store_true", help="skip the second (HIP-event instrumented) pass")
     ap.add_argument("--sync-cycles", action="store_true",
-                    help="synchronise the device after every timed restart cycle (rounds 1-6a).  Default off on one GPU: the library's own "
+                    help="synchronise the device after every timed restart cycle (rounds 1-6a).  Default off: the library's own "
                          "driver (ks_partialschur) runs its cycles back to back -- the speculative chain of the next expansion is still on "
-                         "the device when the restart returns -- and the timed region is bracketed by a barrier + synchronize on both sides")
+                         "the device when the restart returns -- and the timed region is bracketed by a barrier + synchronize on both sides "
+                         "(any number of ranks)")
     ap.add_argument("--sstep", type=int, default=int(os.environ.get("KS_BENCH_SSTEP", "20")),
                     help="s-step (block) expansion: steps per block (ks_workspace_set_sstep; 0 = the per-step expansion of rounds 2-3)")
     ap.add_argument("--config5", action="store_true", help="also measure BASELINE config 5 (464^3 over the ranks) as a second record; "
@@ -328,9 +329,9 @@ def main():
 
         split_cycle = os.environ.get("KS_BENCH_SPLIT_CYCLE", "0") == "1"
 
-        # (several ranks: every cycle synchronised as before -- no chain is speculated on the collective transports, the stream is
-        # drained when the restart returns anyway)
-        sync_cycles = args.sync_cycles or dist is not None
+        # (several ranks too: RCCL and the peer-to-peer transport speculate chains like one rank does, every rank enqueues the same
+        # sequence; the host-staged transport drains its stream in every exchange anyway)
+        sync_cycles = args.sync_cycles
 
         def cycle(timed, sync=True):
             k = state["k"]
