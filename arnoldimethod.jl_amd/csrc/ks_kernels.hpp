@@ -718,10 +718,14 @@ __global__ void __launch_bounds__(kBlock)
     k_spmv_stencil(const MT* __restrict__ mask, const StencilDict<T> d, int nslots, const T* __restrict__ x,
                    const T* __restrict__ xg, T* __restrict__ y, int64_t n, int64_t nghost, int ntiles,
                    const DevState* __restrict__ st, HaloFused hf, HaloArgs ha, P2pDev pd, int shifted = 0, T theta = T{},
-                   double sigma = 1.0) {
+                   double sigma = 1.0, int bt_nlow = -1, int bt_skip = 0) {
   // (xg: the ghost vector of THIS exchange -- the host picks the slot of the double buffer, ks_p2p.hpp)
   if (st && st->breakdown >= 0) return;
   int tile = xcd_remap(blockIdx.x, ntiles);
+  // BOUNDARY launch (round 6c, collective transports): the grid covers only the tiles whose rows reference ghost columns -- the
+  // first bt_nlow tiles and the last ones, bt_skip tiles further up; the interior rows were written by the paired kernel
+  // (k_spmv_stencil2) on the same stream just before (ks_operators.hpp: the split product)
+  if (bt_nlow >= 0 && tile >= bt_nlow) tile += bt_skip;
   // peer-to-peer mode: the ghost exchange is part of this launch (ks_p2p.hpp).  The leading boundary rows (a slab's first
   // plane) go to the END of the dispatch order, next to the trailing ones: by the time those workgroups start, the
   // neighbours' entries have long arrived -- nobody sits on a CU spinning while the interior tiles want its slots.

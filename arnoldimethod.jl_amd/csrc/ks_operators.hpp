@@ -93,6 +93,7 @@ template <class D> struct CsrOp : ks_operator {
   D* hrecv = nullptr;
   bool p2p_halo = false;
   int64_t ghost_stride = 0;         // elements between the two ghost slots
+  mutable bool split_said = false;   // (KS_DIST_SPLIT_DEBUG: one line per operator)
   int64_t ghost_lo_end = 0, ghost_hi_begin = 0;  // only rows < ghost_lo_end or >= ghost_hi_begin reference ghost columns (fused exchange)
   size_t arena_lo = 0, arena_hi = 0;
   int32_t* send_idx_all = nullptr;  // every send entry (contiguous runs included), neighbour by neighbour
@@ -394,6 +395,48 @@ template <class D> struct CsrOp : ks_operator {
           ksd::k_spmv_stencil2<D, uint64_t><<<nt, kBlock, 0, s>>>(static_cast<const uint64_t*>(smask2), sdict, nstencil, x, y, n_local, nt, st, shift_on ? (1 | (shift_plain() ? 2 : 0)) : 0, shift_theta, shift_sigma);
         KS_HIP(hipGetLastError());
         return;
+      }
+      if (nstencil > 0 && nghost > 0 && !p2p_halo && smask2 && (stencil_mask_bytes == 1 || stencil_mask_bytes == 4) && n_local >= 2 * kBlock) {
+        // SPLIT PRODUCT of a rank on the collective transports (round 6c).  The ghost-aware kernel below is the one-row-per-lane
+        // form (8-byte gathers: 16.2 us at the 8-way share of 216^3, 1.26e6 rows) where the paired kernel of the single-GPU path
+        // takes 7.7 us.  Only the rows outside [ghost_lo_end, ghost_hi_begin) -- a slab's first and last plane -- reference ghost
+        // columns: the paired kernel runs over ALL local rows (a ghost column is clamped to a local row there: the boundary rows
+        // come out wrong), then the ghost-aware kernel rewrites the boundary tiles.  Same products in the same order as either
+        // kernel alone (both add the slots in dictionary order).  MEASURED AND LEFT OFF (KS_DIST_SPLIT=1 switches it on): a slab with
+        // two neighbours has nine slots, the paired kernel then issues two groups of eight pair loads per lane and is no faster
+        // than the one-row form, and the second launch costs its own 4 us -- 0.0491 against 0.0471 ms per iteration at the 8-way
+        // share of 216^3 (profiles/r06c_ab.txt).  Correct either way (tests/test_gpu_parity.py::test_split_product_...).
+        if constexpr (std::is_same<D, double>::value) {
+          static const int split_env = env_int("KS_DIST_SPLIT", 0);
+          const int nt1 = (int)((n_local + kBlock - 1) / kBlock);
+          const int nlow = (int)((ghost_lo_end + kBlock - 1) / kBlock), first_high = (int)(ghost_hi_begin / kBlock);
+          const int nhigh = nt1 - first_high;
+          if (split_env && env_int("KS_STENCIL_PAIRS", 1) && nlow <= first_high && 4 * (nlow + nhigh) <= nt1 && nlow + nhigh > 0) {
+            const int nt2 = (int)(((n_local + 1) / 2 + kBlock - 1) / kBlock);
+            static const int split_dbg = env_int("KS_DIST_SPLIT_DEBUG", 0);
+            if (split_dbg && !split_said) {
+              split_said = true;
+              std::fprintf(stderr, "[split] rows %lld: paired kernel on all of them, ghost-aware kernel on %d + %d boundary tiles of %d\n", (long long)n_local, nlow, nhigh, nt1);
+            }
+            // (a slab in the middle of the partition has NINE slots -- the seven of the stencil and one ghost stride per neighbour --,
+            // hence 4-byte masks: the paired kernel takes them as 64-bit words of two rows)
+            const int shf = shift_on ? (1 | (shift_plain() ? 2 : 0)) : 0;
+            ksd::HaloFused h0{};
+            if (stencil_mask_bytes == 1) {
+              ksd::k_spmv_stencil2<D, uint16_t><<<nt2, kBlock, 0, s>>>(static_cast<const uint16_t*>(smask2), sdict, nstencil, x, y, n_local, nt2, st, shf, shift_theta, shift_sigma);
+              ksd::k_spmv_stencil<D, uint8_t, 1><<<nlow + nhigh, kBlock, 0, s>>>(static_cast<const uint8_t*>(smask), sdict, nstencil, x, xg, y, n_local,
+                                                                                std::max<int64_t>(nghost, 0), nlow + nhigh, st, h0, hargs, ctx->p2p.dev, shift_on ? 1 : 0,
+                                                                                shift_theta, shift_sigma, nlow, first_high - nlow);
+            } else {
+              ksd::k_spmv_stencil2<D, uint64_t><<<nt2, kBlock, 0, s>>>(static_cast<const uint64_t*>(smask2), sdict, nstencil, x, y, n_local, nt2, st, shf, shift_theta, shift_sigma);
+              ksd::k_spmv_stencil<D, uint32_t, 1><<<nlow + nhigh, kBlock, 0, s>>>(static_cast<const uint32_t*>(smask), sdict, nstencil, x, xg, y, n_local,
+                                                                                 std::max<int64_t>(nghost, 0), nlow + nhigh, st, h0, hargs, ctx->p2p.dev, shift_on ? 1 : 0,
+                                                                                 shift_theta, shift_sigma, nlow, first_high - nlow);
+            }
+            KS_HIP(hipGetLastError());
+            return;
+          }
+        }
       }
       if (nstencil > 0) {
         static const int rpt_env = env_int("KS_STENCIL_RPT", 1);

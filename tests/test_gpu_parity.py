@@ -721,6 +721,25 @@ def test_ghost_exchange_stress_with_real_ranks(nproc, mode, transport, fused):
     assert r.stdout.count("-> OK") == nproc and "bad rounds 0" in r.stdout, r.stdout[-3000:]
 
 
+@pytest.mark.parametrize("nproc,split", [(2, "1"), (3, "1"), (2, "0")])
+def test_split_product_on_the_collective_transports(nproc, split):
+    """Round 6c, KS_DIST_SPLIT=1 (measured no faster and left off by default): on the collective transports (RCCL /
+    host-staged) a rank's stencil product runs the PAIRED kernel of the single-GPU path over all its rows and the ghost-aware
+    one-row-per-lane kernel over the boundary tiles only (a slab's first and last plane; csrc/ks_operators.hpp).  200 rounds of chains of 1-4 products on a 40 x 41 x (40 + 2 ranks) slab Laplacian,
+    every result against the whole matrix on the host -- a boundary row left with the paired kernel's clamped ghost column, or an
+    interior row missed, is an O(1) error; KS_DIST_SPLIT=0 keeps the one-kernel path covered."""
+    r = _run_ranks(nproc, "halo", m=40, extra_env={"KS_TRANSPORT": "host", "KS_DIST_SPLIT": split, "KS_DIST_SPLIT_DEBUG": "1"})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("-> OK") == nproc and "bad rounds 0" in r.stdout, r.stdout[-3000:]
+    assert ("[split]" in r.stderr) == (split == "1"), r.stderr[-2000:]
+    if nproc == 2 and split == "1":
+        # ... and the SHIFTED products of the block expansion through the same split: a whole solve in blocks of 10, every rank
+        # against rank 0's single-process run of the whole problem (same products, same Ritz values)
+        r = _run_ranks(2, "laplace", m=40, extra_env={"KS_TRANSPORT": "host", "KS_SSTEP": "10", "KS_CHECK_BLOCKS": "1", "KS_DIST_SPLIT": "1", "KS_DIST_SPLIT_DEBUG": "1"})
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        assert r.stdout.count("-> OK") == 2 and "same: True" in r.stdout and r.stdout.count("blocks>0") == 2 and "[split]" in r.stderr, r.stdout[-3000:]
+
+
 @pytest.mark.parametrize("nproc,mode,transport", [(2, "laplace", "p2p"), (3, "complex", "p2p"), (2, "laplace", "host"), (3, "hashed", "host")])
 def test_explicit_second_pass_path_with_real_ranks(nproc, mode, transport):
     """KS_PASSES=3 (second projection applied to the vector; two exchanges per step, pending norm folded into the next
