@@ -721,7 +721,7 @@ def test_ghost_exchange_stress_with_real_ranks(nproc, mode, transport, fused):
     assert r.stdout.count("-> OK") == nproc and "bad rounds 0" in r.stdout, r.stdout[-3000:]
 
 
-@pytest.mark.parametrize("nproc,split", [(2, "1"), (3, "1"), (2, "0")])
+@pytest.mark.parametrize("nproc,split", [(2, "1"), (2, "0")])   # (three ranks went with the switch's default: the suite has a time limit)
 def test_split_product_on_the_collective_transports(nproc, split):
     """Round 6c, KS_DIST_SPLIT=1 (measured no faster and left off by default): on the collective transports (RCCL /
     host-staged) a rank's stencil product runs the PAIRED kernel of the single-GPU path over all its rows and the ghost-aware
