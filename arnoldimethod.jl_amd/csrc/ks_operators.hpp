@@ -93,6 +93,7 @@ template <class D> struct CsrOp : ks_operator {
   D* hrecv = nullptr;
   bool p2p_halo = false;
   int64_t ghost_stride = 0;         // elements between the two ghost slots
+  int nstencil_local = 0;            // leading slots of the stencil dictionary; the rest name ghost columns only
   mutable bool split_said = false;   // (KS_DIST_SPLIT_DEBUG: one line per operator)
   int64_t ghost_lo_end = 0, ghost_hi_begin = 0;  // only rows < ghost_lo_end or >= ghost_hi_begin reference ghost columns (fused exchange)
   size_t arena_lo = 0, arena_hi = 0;
@@ -402,12 +403,13 @@ template <class D> struct CsrOp : ks_operator {
         // takes 7.7 us.  Only the rows outside [ghost_lo_end, ghost_hi_begin) -- a slab's first and last plane -- reference ghost
         // columns: the paired kernel runs over ALL local rows (a ghost column is clamped to a local row there: the boundary rows
         // come out wrong), then the ghost-aware kernel rewrites the boundary tiles.  Same products in the same order as either
-        // kernel alone (both add the slots in dictionary order).  MEASURED AND LEFT OFF (KS_DIST_SPLIT=1 switches it on): a slab with
-        // two neighbours has nine slots, the paired kernel then issues two groups of eight pair loads per lane and is no faster
-        // than the one-row form, and the second launch costs its own 4 us -- 0.0491 against 0.0471 ms per iteration at the 8-way
-        // share of 216^3 (profiles/r06c_ab.txt).  Correct either way (tests/test_gpu_parity.py::test_split_product_...).
+        // kernel alone (both add the slots in dictionary order).  A slab with two neighbours has NINE dictionary slots (seven of the
+        // stencil, one ghost stride per neighbour): with all nine the paired kernel issues two groups of eight pair loads per lane and
+        // the split is SLOWER (0.0491 against 0.0471 ms per iteration at the 8-way share of 216^3); with the slots that local
+        // columns use only (nstencil_local: the ghost strides come last, only boundary rows carry their bits) it is one group:
+        // 0.0444 against 0.0475 (profiles/r06c_ab.txt).  KS_DIST_SPLIT=0: the ghost-aware kernel for every row.
         if constexpr (std::is_same<D, double>::value) {
-          static const int split_env = env_int("KS_DIST_SPLIT", 0);
+          static const int split_env = env_int("KS_DIST_SPLIT", 1);
           const int nt1 = (int)((n_local + kBlock - 1) / kBlock);
           const int nlow = (int)((ghost_lo_end + kBlock - 1) / kBlock), first_high = (int)(ghost_hi_begin / kBlock);
           const int nhigh = nt1 - first_high;
@@ -416,19 +418,22 @@ template <class D> struct CsrOp : ks_operator {
             static const int split_dbg = env_int("KS_DIST_SPLIT_DEBUG", 0);
             if (split_dbg && !split_said) {
               split_said = true;
-              std::fprintf(stderr, "[split] rows %lld: paired kernel on all of them, ghost-aware kernel on %d + %d boundary tiles of %d\n", (long long)n_local, nlow, nhigh, nt1);
+              std::fprintf(stderr, "[split] rows %lld: paired kernel on all of them (%d of %d slots), ghost-aware kernel on %d + %d boundary tiles of %d\n", (long long)n_local, nstencil_local, nstencil, nlow, nhigh, nt1);
             }
             // (a slab in the middle of the partition has NINE slots -- the seven of the stencil and one ghost stride per neighbour --,
             // hence 4-byte masks: the paired kernel takes them as 64-bit words of two rows)
             const int shf = shift_on ? (1 | (shift_plain() ? 2 : 0)) : 0;
             ksd::HaloFused h0{};
+            // (the paired kernel only takes the slots that local columns use: the ghost strides come last in the dictionary, only
+            // boundary rows have their bits, and those rows are rewritten below -- one group of eight pair loads instead of two)
+            const int nsl = nstencil_local >= 1 ? nstencil_local : nstencil;
             if (stencil_mask_bytes == 1) {
-              ksd::k_spmv_stencil2<D, uint16_t><<<nt2, kBlock, 0, s>>>(static_cast<const uint16_t*>(smask2), sdict, nstencil, x, y, n_local, nt2, st, shf, shift_theta, shift_sigma);
+              ksd::k_spmv_stencil2<D, uint16_t><<<nt2, kBlock, 0, s>>>(static_cast<const uint16_t*>(smask2), sdict, nsl, x, y, n_local, nt2, st, shf, shift_theta, shift_sigma);
               ksd::k_spmv_stencil<D, uint8_t, 1><<<nlow + nhigh, kBlock, 0, s>>>(static_cast<const uint8_t*>(smask), sdict, nstencil, x, xg, y, n_local,
                                                                                 std::max<int64_t>(nghost, 0), nlow + nhigh, st, h0, hargs, ctx->p2p.dev, shift_on ? 1 : 0,
                                                                                 shift_theta, shift_sigma, nlow, first_high - nlow);
             } else {
-              ksd::k_spmv_stencil2<D, uint64_t><<<nt2, kBlock, 0, s>>>(static_cast<const uint64_t*>(smask2), sdict, nstencil, x, y, n_local, nt2, st, shf, shift_theta, shift_sigma);
+              ksd::k_spmv_stencil2<D, uint64_t><<<nt2, kBlock, 0, s>>>(static_cast<const uint64_t*>(smask2), sdict, nsl, x, y, n_local, nt2, st, shf, shift_theta, shift_sigma);
               ksd::k_spmv_stencil<D, uint32_t, 1><<<nlow + nhigh, kBlock, 0, s>>>(static_cast<const uint32_t*>(smask), sdict, nstencil, x, xg, y, n_local,
                                                                                  std::max<int64_t>(nghost, 0), nlow + nhigh, st, h0, hargs, ctx->p2p.dev, shift_on ? 1 : 0,
                                                                                  shift_theta, shift_sigma, nlow, first_high - nlow);
@@ -700,6 +705,7 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
       int64_t max_row = 0;
       Key ckey[8];
       int cid[8], ncache = 0, cnext = 0;
+      std::vector<uint8_t> local_used(256, 0);   // dictionary entry used by at least one LOCAL column (ghost-only entries: the split product)
       for (int64_t r = 0; r < nrows && ok; ++r) {
         max_row = std::max(max_row, rp[r + 1] - rp[r]);
         for (int64_t p = rp[r]; p < rp[r + 1]; ++p) {
@@ -710,7 +716,7 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
           bool hit = false;
           for (int q = 0; q < ncache; ++q)
             if (ckey[q] == k) { codes[p] = (uint8_t)cid[q]; hit = true; break; }
-          if (hit) continue;
+          if (hit) { if (ci[p] < nrows) local_used[codes[p]] = 1; continue; }
           auto it = index.find(k);
           int id;
           if (it == index.end()) {
@@ -723,6 +729,7 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
             id = it->second;
           }
           codes[p] = (uint8_t)id;
+          if (ci[p] < nrows) local_used[id] = 1;
           ckey[cnext] = k;
           cid[cnext] = id;
           cnext = (cnext + 1) & 7;
@@ -775,6 +782,9 @@ CsrOp<D>* make_csr(ks_ctx* ctx, int64_t nrows, int64_t nnz, const std::vector<in
         }
         if (sten) {
           op->nstencil = ns;
+          // (trailing slots that only ever name ghost columns -- one stride per neighbour of a slab: rows using them are boundary rows)
+          op->nstencil_local = ns;
+          for (int k = ns - 1; k >= 0 && !local_used[order[k]]; --k) op->nstencil_local = k;
           op->stencil_mask_bytes = mbytes;
           for (int k = 0; k < ns; ++k) {
             op->sdict.delta[k] = dd[order[k]];

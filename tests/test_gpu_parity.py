@@ -723,9 +723,9 @@ def test_ghost_exchange_stress_with_real_ranks(nproc, mode, transport, fused):
 
 @pytest.mark.parametrize("nproc,split", [(2, "1"), (2, "0")])   # (three ranks went with the switch's default: the suite has a time limit)
 def test_split_product_on_the_collective_transports(nproc, split):
-    """Round 6c, KS_DIST_SPLIT=1 (measured no faster and left off by default): on the collective transports (RCCL /
-    host-staged) a rank's stencil product runs the PAIRED kernel of the single-GPU path over all its rows and the ghost-aware
-    one-row-per-lane kernel over the boundary tiles only (a slab's first and last plane; csrc/ks_operators.hpp).  200 rounds of chains of 1-4 products on a 40 x 41 x (40 + 2 ranks) slab Laplacian,
+    """Round 6c (KS_DIST_SPLIT, on by default): on the collective transports (RCCL / host-staged) a rank's stencil product runs the
+    PAIRED kernel of the single-GPU path over all its rows -- with the dictionary slots that local columns use -- and the
+    ghost-aware one-row-per-lane kernel over the boundary tiles only (a slab's first and last plane; csrc/ks_operators.hpp).  200 rounds of chains of 1-4 products on a 40 x 41 x (40 + 2 ranks) slab Laplacian,
     every result against the whole matrix on the host -- a boundary row left with the paired kernel's clamped ghost column, or an
     interior row missed, is an O(1) error; KS_DIST_SPLIT=0 keeps the one-kernel path covered."""
     r = _run_ranks(nproc, "halo", m=40, extra_env={"KS_TRANSPORT": "host", "KS_DIST_SPLIT": split, "KS_DIST_SPLIT_DEBUG": "1"})
