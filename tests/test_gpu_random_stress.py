@@ -61,9 +61,14 @@ _STRICT = {}   # seed -> did the case take the strict (trail-for-trail) branch; 
 # 13-59, four different targets) -- each under the same acceptance: trail for trail where that is well posed, residual and
 # orthogonality against the oracle's own always
 CLUSTER_SEEDS = [33, 46, 53, 55, 58, 59, 64, 69, 85, 90]
+# (in the suite: seven of them -- five Float64, two ComplexF64 --; the other three ran green all round and went when the suite's
+# wall time on a slow box reached 928 s of the driver's 1 200: KS_FULL_SWEEP=1 brings them back)
+import os as _os
+_SUITE_CLUSTER_SEEDS = CLUSTER_SEEDS if _os.environ.get("KS_FULL_SWEEP") == "1" else CLUSTER_SEEDS[:7]
+_OUTLIER_SEEDS = range(14) if _os.environ.get("KS_FULL_SWEEP") == "1" else range(10)
 
 
-@pytest.mark.parametrize("seed", list(range(32)) + CLUSTER_SEEDS)
+@pytest.mark.parametrize("seed", list(range(32)) + _SUITE_CLUSTER_SEEDS)
 def test_random_case_against_the_oracle(seed):
     A, v1, kw, kind = _case(seed)
     ref, rh = oa.partialschur(A, v1=v1, **kw)
@@ -135,7 +140,7 @@ def _outlier_case(seed):
     return A, v1.astype(dtype), dict(nev=nev, which=which, tol=1e-9, mindim=mindim, maxdim=maxdim, restarts=80), np.array(exact), s_blk
 
 
-@pytest.mark.parametrize("seed", range(14))
+@pytest.mark.parametrize("seed", _OUTLIER_SEEDS)
 def test_random_dominant_outliers_keep_their_blocks(seed):
     """Round 6c: random :LM / :LR / :SR problems whose wanted eigenvalues include planted outliers 6-60 x the bulk, coupled to it
     (non-normal), Float64 (incl. locked 2 x 2 blocks) and ComplexF64, blocks of 5 / 10 / 20: the planted values are found to 1e-8,
