@@ -188,3 +188,39 @@ def test_in_chain_deflation_keeps_the_blocks_on_dominant_outliers(case):
     assert np.abs(np.sort_complex(on["eig"]) - np.sort_complex(P.eigenvalues)).max() <= 1e-10 * scale
     Q, R = on["Q"], on["R"]
     assert np.linalg.norm(A @ Q - Q @ R) <= 10 * np.linalg.norm(A @ P.Q - P.Q @ P.R) + 1e-10
+
+
+def test_deflation_plan_takes_the_leading_dominant_locked_columns():
+    """sm.defl_plan = HipBackend::defl_plan (csrc/ks_backend.hpp): locked columns are the leading decoupled block of H; taken are
+    the LEADING ones whose eigenvalue exceeds the largest other Ritz value by r > 1.5 with r^(steps - 1) > 1e3; a locked 2 x 2 block
+    (conjugate pair of the real Schur form) is taken whole or not at all; locked values that do not dominate are left alone."""
+    rng = np.random.default_rng(0)
+    m = 12
+    H = np.triu(rng.standard_normal((m + 1, m)), -1)
+    H[:4, :4] = np.triu(H[:4, :4])
+    H[0, 0] = 50.0
+    H[1:3, 1:3] = [[30.0, 10.0], [-10.0, 30.0]]        # eigenvalues 30 +- 10 i
+    H[3, 3] = 2.5
+    H[4:, :4] = 0.0                                     # columns 0..3 are locked (decoupled): H[4, 3] == 0
+    H[1, 0] = 0.0
+    H[3, 2] = 0.0
+    active = np.linalg.eigvals(H[4:m, 4:m])
+    active = 1.2 * active / np.abs(active).max()        # the rest of the spectrum: radius 1.2
+    ritz = np.concatenate([[50.0, 30 + 10j, 30 - 10j, 2.5], active])
+    nd, ex = sm.defl_plan(H, m, ritz, steps=8)
+    assert nd == 3 and len(ex) == 3                     # 50 and the pair; 2.5 is 2.1 x the rest: 2.1^7 = 170 < 1e3
+    assert abs(ex[0] - 50.0) < 1e-12 and abs(abs(ex[1]) - np.hypot(30, 10)) < 1e-9 and abs(ex[1] - np.conj(ex[2])) < 1e-9
+    nd20, _ = sm.defl_plan(H, m, ritz, steps=20)        # in a block of 20 the factor 2.1 matters too (2.1^19 = 1.3e6)
+    assert nd20 == 4
+    nd2, _ = sm.defl_plan(H, m, ritz, steps=2)          # a block of two steps: only the outlier at 50 (41.7 x the rest: 41.7 < 1e3)
+    assert nd2 == 0
+    # locked values that do NOT dominate (every :SR problem): nothing is deflated
+    Hs = H.copy()
+    Hs[0, 0], Hs[1:3, 1:3], Hs[3, 3] = 0.01, [[0.02, 0.0], [0.0, 0.03]], 0.04
+    Hs[2, 1] = 0.0
+    nd_sr, _ = sm.defl_plan(Hs, m, np.concatenate([[0.01, 0.02, 0.03, 0.04], active]), steps=20)
+    assert nd_sr == 0
+    # nothing locked: no plan
+    Hn = H.copy()
+    Hn[1, 0], Hn[3, 2], Hn[4, 3] = 0.3, 0.2, 0.1
+    assert sm.defl_plan(Hn, m, ritz, steps=20)[0] == 0
